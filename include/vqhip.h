@@ -1,0 +1,208 @@
+/*
+ * vqhip.h -- C ABI of libvqhip: the MI355X (gfx950) back end for the k-means codebook
+ * training and nearest-centroid encode path of CogitatorTech/vq (crate `vq` 0.2.1).
+ *
+ * This header IS the drop-in boundary.  The reference's only native seam is the per-pair
+ * hsdlib FFI (src/core/hsdlib_ffi.rs:37-62: caller-owned pointers + length, one out
+ * pointer, int status).  One launch per 16-float pair is useless on a GPU, so the seam
+ * moves one level up: each entry point below replaces the BODY of one reference function
+ * while the public Rust / Python signatures above it stay as they are (INTEGRATION.md
+ * shows the binding a maintainer adds).  Conventions follow hsdlib_ffi.rs:8-35:
+ *   - plain C types only; the caller owns every host buffer, the library owns device
+ *     memory behind opaque handles released by *_destroy;
+ *   - every function returns an int status: 0 ok, negative = error, text of the last
+ *     error of the calling thread via vqhip_last_error();
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute entry point
+ *     returns VQHIP_ERR_NO_DEVICE.
+ *
+ * Shape/parameter validation that the reference reports as VqError::EmptyInput /
+ * DimensionMismatch / InvalidParameter (src/pq.rs:91-117, src/core/vector.rs:396-410,
+ * src/tsvq.rs:196-210) is done by the host-language layer BEFORE the call so that the
+ * reference's own messages are preserved; the library re-checks and returns
+ * VQHIP_ERR_INVALID_INPUT.  Device failures map to VqError::FfiError (src/core/error.rs:26).
+ *
+ * RNG: the reference draws initial centroids and empty-cluster reseeds from rand 0.9's
+ * StdRng (src/core/vector.rs:412-413, 448-452).  Those draws stay on the host side of this
+ * ABI: the caller passes row ids in (vqhip_kmeans_init_from_rows, *_patch_from_row).
+ *
+ * Threading: handles are single-owner (one thread at a time per handle); distinct handles
+ * may be used from distinct threads.  Work is enqueued on the calling thread's current
+ * stream (vqhip_set_stream) of the current HIP device.
+ */
+#ifndef VQHIP_H
+#define VQHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQHIP_VERSION_MAJOR 0
+#define VQHIP_VERSION_MINOR 1
+
+/* status codes: 0/-1/-3/-4/-99 keep hsdlib's meaning (src/core/hsdlib_ffi.rs:8-16) */
+#define VQHIP_OK 0
+#define VQHIP_ERR_NULL_PTR (-1)
+#define VQHIP_ERR_INVALID_INPUT (-3)
+#define VQHIP_ERR_NO_DEVICE (-4)   /* hsdlib: "CPU not supported"; here: no gfx950 GPU */
+#define VQHIP_ERR_RUNTIME (-5)     /* HIP runtime / launch failure */
+#define VQHIP_ERR_UNSUPPORTED (-6) /* valid input outside what this build handles */
+#define VQHIP_ERR_FAILURE (-99)
+
+/* distance metrics, same order as `enum Distance` (src/core/distance.rs:8-17) */
+#define VQHIP_SQUARED_EUCLIDEAN 0
+#define VQHIP_EUCLIDEAN 1
+#define VQHIP_MANHATTAN 2
+#define VQHIP_COSINE 3
+
+/* assignment engines (results are bit-identical; this is a speed/diagnostic knob) */
+#define VQHIP_ENGINE_AUTO 0  /* MFMA screen + exact re-check where supported, else exact */
+#define VQHIP_ENGINE_EXACT 1 /* exact VALU scan of every centroid */
+#define VQHIP_ENGINE_MFMA 2  /* force the MFMA screen (error if the shape is unsupported) */
+
+typedef struct vqhip_dataset vqhip_dataset;
+typedef struct vqhip_kmeans vqhip_kmeans;
+typedef struct vqhip_pq_encoder vqhip_pq_encoder;
+typedef struct vqhip_tsvq vqhip_tsvq;
+
+/* ---- library / device -------------------------------------------------------------- */
+
+/* analogue of hsd_get_backend() (src/core/hsdlib_ffi.rs:61, 144-155): static string */
+const char *vqhip_backend(void);
+/* text of the calling thread's last error ("" if none); valid until the next failing call */
+const char *vqhip_last_error(void);
+/* number of visible gfx950 devices (0 if none / no HIP runtime) */
+int vqhip_device_count(void);
+/* select the HIP device for the calling thread (like hipSetDevice) */
+int vqhip_set_device(int device);
+/* hipStream_t (as void*) the calling thread's subsequent calls enqueue on; NULL = the
+ * library's own per-thread non-blocking stream */
+int vqhip_set_stream(void *hip_stream);
+/* block until the calling thread's stream is idle */
+int vqhip_synchronize(void);
+/* statistics of the most recent assign/encode launch of this thread: rows sent to the
+ * exact re-check, and the engine used (VQHIP_ENGINE_EXACT / _MFMA) */
+int vqhip_last_assign_stats(uint64_t *rechecked, int *engine);
+
+/* per-call HIP-event timing of the assignment stages on the launch stream.  While on, every
+ * assign/encode call records events; collect() synchronises, returns the number of calls and
+ * the summed device time of the primary stage (MFMA screen, or the exact scan when that is
+ * the engine) and of the exact re-check stage, and clears the record. */
+int vqhip_set_profiling(int on);
+int vqhip_profile_collect(uint32_t *n_calls, double *primary_ms, double *recheck_ms);
+/* device-to-device copy on the current stream (plumbing for callers that all-reduce the
+ * k-means slab in their own buffers) */
+int vqhip_memcpy_device(void *dst, const void *src, uint64_t bytes);
+
+/* ---- datasets: a row-major [n][d] f32 matrix resident in HBM -------------------------
+ * replaces the `&[&[f32]]` argument of ProductQuantizer::new / TSVQ::new (src/pq.rs:84,
+ * src/tsvq.rs:195) and the per-subspace copies of src/pq.rs:122-129 (never materialised:
+ * kernels index X[row][s*sub_dim ..] in place). */
+int vqhip_dataset_from_host(const float *rows, uint64_t n, uint32_t d, vqhip_dataset **out);
+/* borrow an existing device buffer (not freed by _destroy) */
+int vqhip_dataset_from_device(const void *dev_rows, uint64_t n, uint32_t d, vqhip_dataset **out);
+/* i.i.d. Uniform[0,1) rows generated on the device by the counter-based generator of
+ * vqhip_synth_uniform_host: element (row, col) depends only on (seed, row_offset+row, col).
+ * Mirrors the reference harness data, src/bin/common.rs:43-53. */
+int vqhip_dataset_synthetic(uint64_t n, uint32_t d, uint64_t seed, uint64_t row_offset,
+                            vqhip_dataset **out);
+int vqhip_dataset_info(const vqhip_dataset *ds, uint64_t *n, uint32_t *d, const void **dev_rows);
+int vqhip_dataset_read(const vqhip_dataset *ds, uint64_t row0, uint64_t nrows, float *out);
+int vqhip_dataset_destroy(vqhip_dataset *ds);
+/* host twin of the device generator (pure data generation; no compute fallback) */
+int vqhip_synth_uniform_host(float *out, uint64_t n, uint32_t d, uint64_t seed,
+                             uint64_t row_offset);
+
+/* ---- k-means (Lloyd / LBG) over all m subspaces at once -------------------------------
+ * replaces the body of lbg_quantize (src/core/vector.rs:415-458) as called once per
+ * subspace by ProductQuantizer::new (src/pq.rs:120-132).  m == 1 with sub_dim == d is
+ * plain lbg_quantize (src/core/vector.rs:390-395).  Assignment is always squared L2,
+ * first minimum wins (vector.rs:352-363), whatever metric the quantizer later uses. */
+int vqhip_kmeans_create(const vqhip_dataset *ds, uint32_t m, uint32_t k, vqhip_kmeans **out);
+int vqhip_kmeans_destroy(vqhip_kmeans *km);
+/* centroids [m][k][d/m] from the host */
+int vqhip_kmeans_set_centroids(vqhip_kmeans *km, const float *centroids);
+/* centroids[s][j] = row init_rows[s*k+j] restricted to subspace s (vector.rs:412-413 with
+ * the choose_multiple draw made by the caller) */
+int vqhip_kmeans_init_from_rows(vqhip_kmeans *km, const uint64_t *init_rows);
+int vqhip_kmeans_get_centroids(vqhip_kmeans *km, float *centroids);
+/* which subspaces still iterate (each converges on its own, src/pq.rs:121 + vector.rs:455);
+ * active [m] of 0/1.  Default: all active. */
+int vqhip_kmeans_set_active(vqhip_kmeans *km, const uint8_t *active);
+int vqhip_kmeans_set_engine(vqhip_kmeans *km, int engine);
+/* exact_update != 0: cluster means are the reference's sequential f32 sums in row order
+ * (bit-identical to mean_vector_by_indices, vector.rs:368-384) instead of the default
+ * blocked f32 + f64 combination (faster; within the tolerance stated in DESIGN.md). */
+int vqhip_kmeans_set_exact_update(vqhip_kmeans *km, int exact_update);
+
+/* One Lloyd iteration = assign + accumulate + reduce + finalize for every active subspace:
+ *   counts  [m][k] out (optional): members per cluster (0 => caller reseeds, vector.rs:448)
+ *   changed [m]    out (optional): 1 iff some non-empty cluster moved >= 1e-6 (vector.rs:444)
+ * Empty clusters keep their previous centroid until the caller patches them. */
+int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed);
+
+/* Split form for row-sharded multi-GPU training (one process per GPU):
+ *   accumulate: assign + per-cluster partial sums/counts of THIS shard into a device slab
+ *               of f64 [m][k][d/m + 1] (last column = count)
+ *   partials:   device pointer + length of that slab, for the caller's all-reduce(sum)
+ *   finalize:   means, 1e-6 convergence test, new centroids (identical on every rank after
+ *               an all-reduce) */
+int vqhip_kmeans_accumulate(vqhip_kmeans *km);
+int vqhip_kmeans_partials(vqhip_kmeans *km, void **dev_slab, uint64_t *n_doubles);
+int vqhip_kmeans_finalize(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed);
+
+/* empty-cluster reseed (vector.rs:448-452): the caller draws the row */
+int vqhip_kmeans_patch_centroid(vqhip_kmeans *km, uint32_t s, uint32_t j, const float *sub_row);
+int vqhip_kmeans_patch_from_row(vqhip_kmeans *km, uint32_t s, uint32_t j, uint64_t row);
+/* assignment codes [n][m] of the most recent step/accumulate (the reference's
+ * `assignments`, vector.rs:417-429), copied to the host */
+int vqhip_kmeans_get_assignments(vqhip_kmeans *km, uint8_t *codes);
+
+/* ---- PQ encode -----------------------------------------------------------------------
+ * replaces the loop of ProductQuantizer::quantize (src/pq.rs:177-196) for a whole batch.
+ * codebooks [m][k][sub_dim] f32 on the host; k <= 256 (codes are one byte per subspace). */
+int vqhip_pq_encoder_create(const float *codebooks, uint32_t m, uint32_t k, uint32_t sub_dim,
+                            int metric, vqhip_pq_encoder **out);
+int vqhip_pq_encoder_destroy(vqhip_pq_encoder *enc);
+int vqhip_pq_encoder_set_engine(vqhip_pq_encoder *enc, int engine);
+/* host batch: rows [n][m*sub_dim];  codes [n][m] (optional) = best_idx per subspace
+ * (pq.rs:183-191);  f16_out [n][m*sub_dim] (optional) = selected centroids as IEEE
+ * binary16 bits, round-to-nearest-even (pq.rs:193-195) */
+int vqhip_pq_encode(vqhip_pq_encoder *enc, const float *rows, uint64_t n, uint8_t *codes,
+                    uint16_t *f16_out);
+/* device batch: all pointers are device pointers; asynchronous on the current stream */
+int vqhip_pq_encode_device(vqhip_pq_encoder *enc, const void *dev_rows, uint64_t n,
+                           void *dev_codes, void *dev_f16_out);
+/* Quantizer::dequantize for a batch (src/pq.rs:201-209): f16 bits -> f32, host buffers */
+int vqhip_dequantize_f16(const uint16_t *f16_in, uint64_t count, float *out);
+/* reconstruction from codes: out[n][m*sub_dim] f32 = codebook[s][codes[n][s]] (new API) */
+int vqhip_pq_decode(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n, float *out);
+
+/* ---- pairwise distances --------------------------------------------------------------
+ * Distance::compute (src/core/distance.rs:48-64, scalar paths 76-82, 94, 107-119) for n
+ * independent pairs: out[i] = metric(a[i][0..d), b[i][0..d)).  Host buffers. */
+int vqhip_distance_batch(int metric, const float *a, const float *b, uint64_t n, uint32_t d,
+                         float *out);
+
+/* ---- TSVQ ----------------------------------------------------------------------------
+ * build replaces TSVQNode::build (src/tsvq.rs:31-115); the tree comes back flattened in
+ * pre-order (node 0 = root, left subtree, right subtree): centroids [cap][d], left/right
+ * child index or -1.  cap must be >= min(2^(max_depth+1)-1, 2n-1). */
+int vqhip_tsvq_build(const vqhip_dataset *ds, uint32_t max_depth, uint32_t cap, float *centroids,
+                     int32_t *left, int32_t *right, int32_t *n_nodes);
+/* encoder over a flattened tree; encode replaces find_leaf + quantize (tsvq.rs:117-132,
+ * 239-255) for a batch: leaf [n] (optional) node index, f16_out [n][d] (optional) */
+int vqhip_tsvq_create(const float *centroids, const int32_t *left, const int32_t *right,
+                      uint32_t n_nodes, uint32_t d, int metric, vqhip_tsvq **out);
+int vqhip_tsvq_destroy(vqhip_tsvq *t);
+int vqhip_tsvq_encode(vqhip_tsvq *t, const float *rows, uint64_t n, int32_t *leaf,
+                      uint16_t *f16_out);
+int vqhip_tsvq_encode_device(vqhip_tsvq *t, const void *dev_rows, uint64_t n, void *dev_leaf,
+                             void *dev_f16_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQHIP_H */

@@ -1,0 +1,279 @@
+"""GPU parity tests (run with -m gpu on a MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs.
+
+Bar: assignment codes, counts and f16 outputs BIT-EXACT; centroids after one Lloyd step
+within |d| <= 1e-5 * max(1, |c|) (DESIGN.md "centroid tolerance": blocked f32 partial sums
+combined in f64 vs the reference's sequential f32 sum).
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from vq_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+F = np.float32
+CENTROID_RTOL = 1e-5
+
+
+def _data(seed, n, d, kind):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":  # the reference harness distribution, src/bin/common.rs:43-53
+        return rng.random((n, d), dtype=F)
+    if kind == "normal":
+        return rng.standard_normal((n, d)).astype(F)
+    if kind == "lattice":  # exact ties everywhere
+        return rng.integers(0, 3, (n, d)).astype(F)
+    if kind == "clustered":
+        centers = rng.standard_normal((32, d)).astype(F) * 4
+        return (centers[rng.integers(0, 32, n)] + 0.05 * rng.standard_normal((n, d))).astype(F)
+    if kind == "tiny":  # denormal-range magnitudes
+        return (rng.standard_normal((n, d)) * 1e-38).astype(F)
+    if kind == "huge":
+        return (rng.standard_normal((n, d)) * 1e18).astype(F)
+    raise ValueError(kind)
+
+
+def _check_encode(oracle, X, cb, metric, engine):
+    enc = _lib.PQEncoder(cb, metric)
+    enc.set_engine(engine)
+    codes, f16 = enc.encode(X)
+    want_c, want_f = oracle.pq_encode(metric, X, cb, threads=0)
+    np.testing.assert_array_equal(codes.astype(np.uint32), want_c)
+    got_bits, want_bits = f16.view(np.uint16), want_f
+    same = (got_bits == want_bits) | (np.isnan(f16) & np.isnan(want_f.view(np.float16)))
+    assert same.all()
+    enc.close()
+
+
+SHAPES = [  # (n, d, m, k)
+    (3000, 64, 4, 16),     # BASELINE config 1 shape (sub_dim 16)
+    (2500, 128, 8, 256),   # config 2 shape
+    (1000, 128, 16, 256),  # config 5 shape (sub_dim 8)
+    (1777, 32, 8, 100),    # k not a multiple of 16, sub_dim 4
+    (999, 64, 2, 33),      # sub_dim 32
+    (500, 12, 4, 7),       # sub_dim 3: no MFMA form -> exact engine
+    (257, 5, 1, 3),        # m = 1, odd dim
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("kind", ["uniform", "normal", "lattice", "clustered"])
+@pytest.mark.parametrize("metric", [O.SQUARED_EUCLIDEAN, O.EUCLIDEAN])
+def test_encode_l2_bit_exact(oracle, shape, kind, metric):
+    n, d, m, k = shape
+    X = _data(1, n, d, kind)
+    cb = _data(2, m * k, d // m, kind).reshape(m, k, d // m)
+    if kind == "lattice":
+        cb[:, k // 2] = cb[:, 0]  # duplicate centroid: lower index must win
+    _check_encode(oracle, X, cb, metric, _lib.ENGINE_AUTO)
+    _check_encode(oracle, X, cb, metric, _lib.ENGINE_EXACT)
+
+
+@pytest.mark.parametrize("shape", SHAPES[:5])
+@pytest.mark.parametrize("kind", ["uniform", "normal", "lattice"])
+@pytest.mark.parametrize("metric", [O.MANHATTAN, O.COSINE])
+def test_encode_l1_cosine_bit_exact(oracle, shape, kind, metric):
+    n, d, m, k = shape
+    X = _data(3, n, d, kind)
+    cb = _data(4, m * k, d // m, kind).reshape(m, k, d // m)
+    if kind == "lattice":
+        cb[0, 1] = 0  # zero centroid -> cosine distance exactly 1.0
+        X[5] = 0      # zero row
+    _check_encode(oracle, X, cb, metric, _lib.ENGINE_AUTO)
+
+
+def test_encode_codebook_rows_are_their_own_code(oracle):
+    # k = N distinct rows (tests/regression_tests.rs:357-363 generalised): quantize(x_i) == f16(x_i)
+    rng = np.random.default_rng(5)
+    X = rng.random((256, 32), dtype=F)
+    cb = np.ascontiguousarray(X.reshape(256, 2, 16).transpose(1, 0, 2))
+    enc = _lib.PQEncoder(cb, _lib.EUCLIDEAN)
+    codes, f16 = enc.encode(X)
+    np.testing.assert_array_equal(f16, X.astype(np.float16))
+    np.testing.assert_array_equal(codes, np.tile(np.arange(256, dtype=np.uint8)[:, None], (1, 2)))
+
+
+@pytest.mark.parametrize("kind", ["tiny", "huge"])
+@pytest.mark.parametrize("metric", [O.SQUARED_EUCLIDEAN, O.EUCLIDEAN, O.MANHATTAN, O.COSINE])
+def test_encode_extreme_magnitudes(oracle, kind, metric):
+    X = _data(6, 700, 64, kind)
+    cb = _data(7, 4 * 64, 16, kind).reshape(4, 64, 16)
+    _check_encode(oracle, X, cb, metric, _lib.ENGINE_AUTO)
+
+
+def test_encode_nan_inf_inputs(oracle):
+    # NaN never wins a strict '<' (src/pq.rs:187); a NaN distance at centroid 0 blocks all
+    rng = np.random.default_rng(8)
+    X = rng.random((400, 64), dtype=F)
+    X[3, 5] = np.nan
+    X[10, 20] = np.inf
+    X[11, 21] = -np.inf
+    X[12, :] = np.nan
+    cb = rng.random((4, 32, 16), dtype=F)
+    for metric in (O.SQUARED_EUCLIDEAN, O.EUCLIDEAN, O.MANHATTAN, O.COSINE):
+        _check_encode(oracle, X, cb, metric, _lib.ENGINE_AUTO)
+    cb2 = cb.copy()
+    cb2[0, 0, 3] = np.nan   # NaN in centroid 0 of subspace 0: every row maps to 0 there
+    cb2[1, 7, 0] = np.nan   # NaN elsewhere: that centroid can never win
+    cb2[2, 5, 1] = np.inf
+    for metric in (O.SQUARED_EUCLIDEAN, O.EUCLIDEAN, O.MANHATTAN, O.COSINE):
+        _check_encode(oracle, X, cb2, metric, _lib.ENGINE_AUTO)
+
+
+def test_encode_adversarial_near_ties(oracle):
+    """Centroid pairs 1 ulp apart and rows on the bisector: the MFMA screen must hand these
+    to the exact re-check, and the first minimum must win."""
+    rng = np.random.default_rng(9)
+    m, k, sd = 4, 64, 16
+    cb = rng.random((m, k, sd), dtype=F)
+    for s in range(m):
+        for j in range(0, k, 2):  # odd centroids = even ones nudged by 1 ulp in one coordinate
+            cb[s, j + 1] = cb[s, j]
+            t = (j // 2) % sd
+            cb[s, j + 1, t] = np.nextafter(cb[s, j, t], F(2.0))
+    X = np.empty((2048, m * sd), F)
+    for i in range(X.shape[0]):
+        for s in range(m):
+            j = rng.integers(0, k)
+            X[i, s * sd:(s + 1) * sd] = cb[s, j] + (1e-3 * rng.standard_normal(sd)).astype(F)
+    for metric in (O.SQUARED_EUCLIDEAN, O.EUCLIDEAN):
+        _check_encode(oracle, X, cb, metric, _lib.ENGINE_AUTO)
+    rechecked, engine = _lib.last_assign_stats()
+    assert engine == _lib.ENGINE_MFMA and rechecked > 0
+
+
+def test_encode_ragged_sizes(oracle):
+    rng = np.random.default_rng(10)
+    cb = rng.random((8, 256, 16), dtype=F)
+    for n in (1, 2, 15, 16, 17, 63, 64, 65, 1023):
+        X = rng.random((n, 128), dtype=F)
+        _check_encode(oracle, X, cb, O.EUCLIDEAN, _lib.ENGINE_AUTO)
+    enc = _lib.PQEncoder(cb, _lib.EUCLIDEAN)
+    codes, f16 = enc.encode(np.empty((0, 128), F))
+    assert codes.shape == (0, 8) and f16.shape == (0, 128)
+
+
+@pytest.mark.parametrize("shape", [(4000, 64, 4, 16), (6000, 128, 8, 256), (3000, 128, 16, 64)])
+@pytest.mark.parametrize("kind", ["uniform", "clustered"])
+@pytest.mark.parametrize("engine", [_lib.ENGINE_AUTO, _lib.ENGINE_EXACT])
+def test_lloyd_step_parity(oracle, shape, kind, engine):
+    n, d, m, k = shape
+    sd = d // m
+    X = _data(11, n, d, kind)
+    init = np.array([[(j * (n // k) + 7 * s) % n for j in range(k)] for s in range(m)], np.uint64)
+    ds = _lib.Dataset.from_host(X)
+    km = _lib.KMeans(ds, m, k)
+    km.set_engine(engine)
+    km.init_from_rows(init)
+    np.testing.assert_array_equal(km.get_centroids(),
+                                  np.stack([X[init[s].astype(np.int64), s * sd:(s + 1) * sd] for s in range(m)]))
+    counts, changed = km.step()
+    assign = km.get_assignments()
+    cent = km.get_centroids()
+    for s in range(m):
+        c0 = X[init[s].astype(np.int64), s * sd:(s + 1) * sd]
+        c1, a_ref, n_ref, ch_ref = oracle.lloyd_step(X[:, s * sd:(s + 1) * sd], c0, threads=0)
+        np.testing.assert_array_equal(assign[:, s].astype(np.uint32), a_ref)   # exact
+        np.testing.assert_array_equal(counts[s], n_ref)                        # exact
+        nonempty = n_ref > 0
+        err = np.abs(cent[s][nonempty] - c1[nonempty]) / np.maximum(1.0, np.abs(c1[nonempty]))
+        assert err.max() <= CENTROID_RTOL
+        # empty clusters keep their centroid until the caller reseeds (vector.rs:448-452)
+        np.testing.assert_array_equal(cent[s][~nonempty], c0[~nonempty])
+        assert bool(changed[s]) == ch_ref
+    km.close()
+    ds.close()
+
+
+def test_lloyd_full_fit_matches_oracle_quality(oracle):
+    """Multi-iteration trajectories may differ at boundary points once centroids differ in
+    the last bits, so the full fit is compared on quantisation error (inertia), +-0.1 %."""
+    from vq_amd.pq import fit_codebooks
+
+    n, d, m, k = 20000, 64, 4, 32
+    sd = d // m
+    X = _data(12, n, d, "uniform")
+    init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64)
+    ds = _lib.Dataset.from_host(X)
+    stats = {}
+    cb = fit_codebooks(ds, m, k, 8, init_rows=init, reseed_rows=[[1] * 64] * m, stats=stats)
+    cb_ref, it_ref = oracle.pq_fit(X, m, k, 8, init, reseed_rows=np.ones((m, 64), np.uint64), threads=0)
+
+    def inertia(c):
+        codes, _ = oracle.pq_encode(O.SQUARED_EUCLIDEAN, X, c, want_f16=False, threads=0)
+        rec = np.concatenate([c[s][codes[:, s]] for s in range(m)], axis=1)
+        return float(((X - rec) ** 2).sum())
+
+    a, b = inertia(cb), inertia(cb_ref)
+    assert abs(a - b) / b < 1e-3
+    assert stats["iters"].tolist() == it_ref.tolist()
+    ds.close()
+
+
+def test_lloyd_inactive_subspaces_are_frozen(oracle):
+    n, d, m, k = 3000, 64, 4, 16
+    X = _data(13, n, d, "uniform")
+    ds = _lib.Dataset.from_host(X)
+    km = _lib.KMeans(ds, m, k)
+    init = np.array([[j * 100 + s for j in range(k)] for s in range(m)], np.uint64)
+    km.init_from_rows(init)
+    before = km.get_centroids()
+    km.set_active([1, 0, 1, 0])
+    counts, changed = km.step()
+    after = km.get_centroids()
+    np.testing.assert_array_equal(after[1], before[1])
+    np.testing.assert_array_equal(after[3], before[3])
+    assert not changed[1] and not changed[3]
+    assert (after[0] != before[0]).any() and (after[2] != before[2]).any()
+    assert counts[1].sum() == 0 and counts[0].sum() == n
+    km.close()
+    ds.close()
+
+
+def test_patch_and_reseed(oracle):
+    n, d, m, k = 2000, 32, 2, 8
+    X = _data(14, n, d, "uniform")
+    ds = _lib.Dataset.from_host(X)
+    km = _lib.KMeans(ds, m, k)
+    km.init_from_rows(np.arange(m * k, dtype=np.uint64).reshape(m, k))
+    km.patch_from_row(1, 3, 1234)
+    km.patch_centroid(0, 2, np.arange(16, dtype=F))
+    c = km.get_centroids()
+    np.testing.assert_array_equal(c[1, 3], X[1234, 16:32])
+    np.testing.assert_array_equal(c[0, 2], np.arange(16, dtype=F))
+    km.close()
+    ds.close()
+
+
+def test_synthetic_generator_device_equals_host():
+    ds = _lib.Dataset.synthetic(5000, 96, seed=66, row_offset=12345)
+    np.testing.assert_array_equal(ds.read(), _lib.synth_uniform_host(5000, 96, 66, 12345))
+    x = ds.read()
+    assert x.min() >= 0.0 and x.max() < 1.0 and abs(x.mean() - 0.5) < 0.01
+    ds.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2, 3])
+def test_distance_batch_bit_exact(oracle, metric):
+    from vq_amd._pairwise import pairwise_distance
+
+    rng = np.random.default_rng(15)
+    a = rng.standard_normal((500, 37)).astype(F)
+    b = rng.standard_normal((500, 37)).astype(F)
+    a[0] = 0
+    got = pairwise_distance(metric, a, b)
+    want = np.array([oracle.distance(metric, a[i], b[i]) for i in range(500)], F)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_dequantize_and_decode(oracle):
+    rng = np.random.default_rng(16)
+    h = rng.standard_normal(4096).astype(np.float16)
+    np.testing.assert_array_equal(_lib.dequantize_f16(h), h.astype(F))
+    cb = rng.random((4, 16, 8), dtype=F)
+    enc = _lib.PQEncoder(cb, _lib.EUCLIDEAN)
+    codes = rng.integers(0, 16, (100, 4)).astype(np.uint8)
+    want = np.concatenate([cb[s][codes[:, s]] for s in range(4)], axis=1)
+    np.testing.assert_array_equal(enc.decode(codes), want)

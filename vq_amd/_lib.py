@@ -1,0 +1,345 @@
+"""ctypes binding of libvqhip.so (include/vqhip.h).
+
+The shared library is built in-tree (``vq_amd/libvqhip.so``, see ``__graft_entry__.build``)
+and is the ONLY compute back end: if it is missing or fails to load this module raises --
+there is no eager/numpy fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .errors import FfiError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvqhip.so")
+
+OK = 0
+ERR_NULL_PTR, ERR_INVALID_INPUT, ERR_NO_DEVICE, ERR_RUNTIME, ERR_UNSUPPORTED, ERR_FAILURE = (
+    -1, -3, -4, -5, -6, -99)
+
+SQUARED_EUCLIDEAN, EUCLIDEAN, MANHATTAN, COSINE = 0, 1, 2, 3
+ENGINE_AUTO, ENGINE_EXACT, ENGINE_MFMA = 0, 1, 2
+
+_u8p = C.POINTER(C.c_uint8)
+_u16p = C.POINTER(C.c_uint16)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+_vp = C.c_void_p
+_vpp = C.POINTER(C.c_void_p)
+
+# every symbol include/vqhip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "vqhip_backend": (C.c_char_p, []),
+    "vqhip_last_error": (C.c_char_p, []),
+    "vqhip_device_count": (C.c_int, []),
+    "vqhip_set_device": (C.c_int, [C.c_int]),
+    "vqhip_set_stream": (C.c_int, [_vp]),
+    "vqhip_synchronize": (C.c_int, []),
+    "vqhip_last_assign_stats": (C.c_int, [_u64p, C.POINTER(C.c_int)]),
+    "vqhip_set_profiling": (C.c_int, [C.c_int]),
+    "vqhip_profile_collect": (C.c_int, [_u32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vqhip_memcpy_device": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "vqhip_dataset_from_host": (C.c_int, [_f32p, C.c_uint64, C.c_uint32, _vpp]),
+    "vqhip_dataset_from_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vpp]),
+    "vqhip_dataset_synthetic": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, _vpp]),
+    "vqhip_dataset_info": (C.c_int, [_vp, _u64p, _u32p, _vpp]),
+    "vqhip_dataset_read": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _f32p]),
+    "vqhip_dataset_destroy": (C.c_int, [_vp]),
+    "vqhip_synth_uniform_host": (C.c_int, [_f32p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "vqhip_kmeans_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vpp]),
+    "vqhip_kmeans_destroy": (C.c_int, [_vp]),
+    "vqhip_kmeans_set_centroids": (C.c_int, [_vp, _f32p]),
+    "vqhip_kmeans_init_from_rows": (C.c_int, [_vp, _u64p]),
+    "vqhip_kmeans_get_centroids": (C.c_int, [_vp, _f32p]),
+    "vqhip_kmeans_set_active": (C.c_int, [_vp, _u8p]),
+    "vqhip_kmeans_set_engine": (C.c_int, [_vp, C.c_int]),
+    "vqhip_kmeans_set_exact_update": (C.c_int, [_vp, C.c_int]),
+    "vqhip_kmeans_step": (C.c_int, [_vp, _u32p, _u8p]),
+    "vqhip_kmeans_accumulate": (C.c_int, [_vp]),
+    "vqhip_kmeans_partials": (C.c_int, [_vp, _vpp, _u64p]),
+    "vqhip_kmeans_finalize": (C.c_int, [_vp, _u32p, _u8p]),
+    "vqhip_kmeans_patch_centroid": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _f32p]),
+    "vqhip_kmeans_patch_from_row": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "vqhip_kmeans_get_assignments": (C.c_int, [_vp, _u8p]),
+    "vqhip_pq_encoder_create": (C.c_int, [_f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _vpp]),
+    "vqhip_pq_encoder_destroy": (C.c_int, [_vp]),
+    "vqhip_pq_encoder_set_engine": (C.c_int, [_vp, C.c_int]),
+    "vqhip_pq_encode": (C.c_int, [_vp, _f32p, C.c_uint64, _u8p, _u16p]),
+    "vqhip_pq_encode_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "vqhip_dequantize_f16": (C.c_int, [_u16p, C.c_uint64, _f32p]),
+    "vqhip_pq_decode": (C.c_int, [_vp, _u8p, C.c_uint64, _f32p]),
+    "vqhip_distance_batch": (C.c_int, [C.c_int, _f32p, _f32p, C.c_uint64, C.c_uint32, _f32p]),
+    "vqhip_tsvq_build": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _f32p, _i32p, _i32p, _i32p]),
+    "vqhip_tsvq_create": (C.c_int, [_f32p, _i32p, _i32p, C.c_uint32, C.c_uint32, C.c_int, _vpp]),
+    "vqhip_tsvq_destroy": (C.c_int, [_vp]),
+    "vqhip_tsvq_encode": (C.c_int, [_vp, _f32p, C.c_uint64, _i32p, _u16p]),
+    "vqhip_tsvq_encode_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libvqhip.so and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FfiError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C vq_amd/csrc`).  vq_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise FfiError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise FfiError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().vqhip_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc != OK:
+        raise FfiError(last_error() or f"libvqhip status {rc}", rc)
+
+
+def ptr(a: np.ndarray | None, ty):
+    return None if a is None else a.ctypes.data_as(ty)
+
+
+def f32c(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Handle:
+    """Owns one opaque library handle and destroys it with the matching *_destroy."""
+
+    _destroy = ""
+
+    def __init__(self, raw: C.c_void_p):
+        self.raw = raw
+
+    def close(self):
+        if getattr(self, "raw", None):
+            getattr(load(), self._destroy)(self.raw)
+            self.raw = None
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Dataset(Handle):
+    """Row-major [n][d] f32 matrix resident in HBM (vqhip_dataset)."""
+
+    _destroy = "vqhip_dataset_destroy"
+
+    def __init__(self, raw, n: int, d: int, keepalive=None):
+        super().__init__(raw)
+        self.n, self.d = int(n), int(d)
+        self._keepalive = keepalive
+
+    @classmethod
+    def from_host(cls, rows: np.ndarray) -> "Dataset":
+        rows = f32c(rows)
+        n, d = rows.shape
+        h = C.c_void_p()
+        check(load().vqhip_dataset_from_host(ptr(rows, _f32p), n, d, C.byref(h)))
+        return cls(h, n, d)
+
+    @classmethod
+    def from_device(cls, dev_ptr: int, n: int, d: int, keepalive=None) -> "Dataset":
+        h = C.c_void_p()
+        check(load().vqhip_dataset_from_device(C.c_void_p(dev_ptr), n, d, C.byref(h)))
+        return cls(h, n, d, keepalive)
+
+    @classmethod
+    def synthetic(cls, n: int, d: int, seed: int, row_offset: int = 0) -> "Dataset":
+        h = C.c_void_p()
+        check(load().vqhip_dataset_synthetic(n, d, seed, row_offset, C.byref(h)))
+        return cls(h, n, d)
+
+    @property
+    def device_ptr(self) -> int:
+        p = C.c_void_p()
+        check(load().vqhip_dataset_info(self.raw, None, None, C.byref(p)))
+        return int(p.value)
+
+    def read(self, row0: int = 0, nrows: int | None = None) -> np.ndarray:
+        nrows = self.n - row0 if nrows is None else nrows
+        out = np.empty((nrows, self.d), np.float32)
+        check(load().vqhip_dataset_read(self.raw, row0, nrows, ptr(out, _f32p)))
+        return out
+
+
+def synth_uniform_host(n: int, d: int, seed: int, row_offset: int = 0) -> np.ndarray:
+    out = np.empty((n, d), np.float32)
+    check(load().vqhip_synth_uniform_host(ptr(out, _f32p), n, d, seed, row_offset))
+    return out
+
+
+class KMeans(Handle):
+    """vqhip_kmeans: Lloyd iterations over all m subspaces of a resident dataset."""
+
+    _destroy = "vqhip_kmeans_destroy"
+
+    def __init__(self, ds: Dataset, m: int, k: int):
+        h = C.c_void_p()
+        check(load().vqhip_kmeans_create(ds.raw, m, k, C.byref(h)))
+        super().__init__(h)
+        self.ds, self.m, self.k, self.sd = ds, int(m), int(k), ds.d // int(m)
+
+    def set_centroids(self, c):
+        c = f32c(c).reshape(self.m, self.k, self.sd)
+        check(load().vqhip_kmeans_set_centroids(self.raw, ptr(c, _f32p)))
+
+    def init_from_rows(self, rows):
+        r = np.ascontiguousarray(rows, dtype=np.uint64).reshape(self.m, self.k)
+        check(load().vqhip_kmeans_init_from_rows(self.raw, ptr(r, _u64p)))
+
+    def get_centroids(self) -> np.ndarray:
+        out = np.empty((self.m, self.k, self.sd), np.float32)
+        check(load().vqhip_kmeans_get_centroids(self.raw, ptr(out, _f32p)))
+        return out
+
+    def set_active(self, active):
+        a = np.ascontiguousarray(active, dtype=np.uint8).reshape(self.m)
+        check(load().vqhip_kmeans_set_active(self.raw, ptr(a, _u8p)))
+
+    def set_engine(self, engine: int):
+        check(load().vqhip_kmeans_set_engine(self.raw, engine))
+
+    def set_exact_update(self, on: bool):
+        check(load().vqhip_kmeans_set_exact_update(self.raw, 1 if on else 0))
+
+    def step(self):
+        counts = np.empty((self.m, self.k), np.uint32)
+        changed = np.empty(self.m, np.uint8)
+        check(load().vqhip_kmeans_step(self.raw, ptr(counts, _u32p), ptr(changed, _u8p)))
+        return counts, changed.astype(bool)
+
+    def accumulate(self):
+        check(load().vqhip_kmeans_accumulate(self.raw))
+
+    def partials(self):
+        """(device pointer, number of f64 elements) of the per-cluster sums/counts slab"""
+        p, n = C.c_void_p(), C.c_uint64()
+        check(load().vqhip_kmeans_partials(self.raw, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
+    def finalize(self):
+        counts = np.empty((self.m, self.k), np.uint32)
+        changed = np.empty(self.m, np.uint8)
+        check(load().vqhip_kmeans_finalize(self.raw, ptr(counts, _u32p), ptr(changed, _u8p)))
+        return counts, changed.astype(bool)
+
+    def patch_centroid(self, s: int, j: int, sub_row):
+        r = f32c(sub_row).reshape(self.sd)
+        check(load().vqhip_kmeans_patch_centroid(self.raw, s, j, ptr(r, _f32p)))
+
+    def patch_from_row(self, s: int, j: int, row: int):
+        check(load().vqhip_kmeans_patch_from_row(self.raw, s, j, row))
+
+    def get_assignments(self) -> np.ndarray:
+        out = np.empty((self.ds.n, self.m), np.uint8)
+        check(load().vqhip_kmeans_get_assignments(self.raw, ptr(out, _u8p)))
+        return out
+
+
+class PQEncoder(Handle):
+    """vqhip_pq_encoder: batch nearest-centroid encode against fixed codebooks."""
+
+    _destroy = "vqhip_pq_encoder_destroy"
+
+    def __init__(self, codebooks, metric: int):
+        cb = f32c(codebooks)
+        m, k, sd = cb.shape
+        h = C.c_void_p()
+        check(load().vqhip_pq_encoder_create(ptr(cb, _f32p), m, k, sd, metric, C.byref(h)))
+        super().__init__(h)
+        self.m, self.k, self.sd, self.metric = m, k, sd, metric
+
+    def set_engine(self, engine: int):
+        check(load().vqhip_pq_encoder_set_engine(self.raw, engine))
+
+    def encode(self, rows, want_codes=True, want_f16=True):
+        rows = f32c(rows).reshape(-1, self.m * self.sd)
+        n = rows.shape[0]
+        codes = np.empty((n, self.m), np.uint8) if want_codes else None
+        f16 = np.empty((n, self.m * self.sd), np.uint16) if want_f16 else None
+        check(load().vqhip_pq_encode(self.raw, ptr(rows, _f32p), n, ptr(codes, _u8p), ptr(f16, _u16p)))
+        return codes, (None if f16 is None else f16.view(np.float16))
+
+    def encode_device(self, dev_rows: int, n: int, dev_codes: int | None, dev_f16: int | None):
+        check(load().vqhip_pq_encode_device(self.raw, C.c_void_p(dev_rows), n,
+                                            C.c_void_p(dev_codes or 0), C.c_void_p(dev_f16 or 0)))
+
+    def decode(self, codes) -> np.ndarray:
+        codes = np.ascontiguousarray(codes, dtype=np.uint8).reshape(-1, self.m)
+        out = np.empty((codes.shape[0], self.m * self.sd), np.float32)
+        check(load().vqhip_pq_decode(self.raw, ptr(codes, _u8p), codes.shape[0], ptr(out, _f32p)))
+        return out
+
+
+def dequantize_f16(f16) -> np.ndarray:
+    h = np.ascontiguousarray(f16, dtype=np.float16)
+    out = np.empty(h.shape, np.float32)
+    check(load().vqhip_dequantize_f16(ptr(h.view(np.uint16), _u16p), h.size, ptr(out, _f32p)))
+    return out
+
+
+def set_device(device: int):
+    check(load().vqhip_set_device(device))
+
+
+def set_stream(stream_ptr: int | None):
+    check(load().vqhip_set_stream(C.c_void_p(stream_ptr or 0)))
+
+
+def synchronize():
+    check(load().vqhip_synchronize())
+
+
+def device_count() -> int:
+    return int(load().vqhip_device_count())
+
+
+def backend() -> str:
+    return load().vqhip_backend().decode()
+
+
+def set_profiling(on: bool):
+    check(load().vqhip_set_profiling(1 if on else 0))
+
+
+def profile_collect():
+    """(calls, primary-stage ms total, re-check ms total) since the last collect"""
+    n, a, b = C.c_uint32(), C.c_double(), C.c_double()
+    check(load().vqhip_profile_collect(C.byref(n), C.byref(a), C.byref(b)))
+    return int(n.value), float(a.value), float(b.value)
+
+
+def memcpy_device(dst: int, src: int, nbytes: int):
+    check(load().vqhip_memcpy_device(C.c_void_p(dst), C.c_void_p(src), nbytes))
+
+
+def last_assign_stats():
+    r, e = C.c_uint64(), C.c_int()
+    check(load().vqhip_last_assign_stats(C.byref(r), C.byref(e)))
+    return int(r.value), int(e.value)

@@ -1,0 +1,872 @@
+// api.hip -- extern "C" entry points of libvqhip (see include/vqhip.h for the contract and
+// the reference file:line each entry replaces).  Host-side orchestration only; the kernels
+// are in k_*.hip.  No CPU compute fallback exists anywhere in this file.
+#include <algorithm>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace vqhip {
+
+// ---------------------------------------------------------------- thread-local state ----
+ThreadState &tls() {
+    static thread_local ThreadState st;
+    return st;
+}
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    tls().last_error = buf;
+    return code;
+}
+
+static int g_num_cus[64];
+static int g_dev_ok[64];  // 0 unknown, 1 gfx950, -1 other
+
+int require_gfx950() {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(VQHIP_ERR_NO_DEVICE, "no HIP device available (%s); libvqhip has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    int dev = 0;
+    VQ_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(VQHIP_ERR_NO_DEVICE, "device index %d out of range", dev);
+    if (g_dev_ok[dev] == 0) {
+        hipDeviceProp_t prop;
+        VQ_HIP(hipGetDeviceProperties(&prop, dev));
+        g_num_cus[dev] = prop.multiProcessorCount;
+        g_dev_ok[dev] = (strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : -1;
+        if (g_dev_ok[dev] < 0)
+            tls().last_error = std::string("device is ") + prop.gcnArchName + ", libvqhip is built for gfx950 only";
+    }
+    if (g_dev_ok[dev] < 0)
+        return fail(VQHIP_ERR_NO_DEVICE, "current HIP device is not gfx950; libvqhip targets MI355X only");
+    return VQHIP_OK;
+}
+
+int num_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    return g_num_cus[dev] > 0 ? g_num_cus[dev] : 256;
+}
+
+int current_stream(hipStream_t *out) {
+    ThreadState &st = tls();
+    if (st.user_stream_set) {
+        *out = st.user_stream;
+        return VQHIP_OK;
+    }
+    int dev = 0;
+    VQ_HIP(hipGetDevice(&dev));
+    if (!st.own_stream || st.own_stream_device != dev) {
+        // one lazily created non-blocking stream per thread and device
+        hipStream_t s;
+        VQ_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        st.own_stream = s;
+        st.own_stream_device = dev;
+    }
+    *out = st.own_stream;
+    return VQHIP_OK;
+}
+
+// ------------------------------------------------------------------ codebook state ----
+struct CodebookState {
+    uint32_t m = 0, k = 0, sd = 0, nt = 0, ks = 0;
+    bool mfma_ok = false;
+    bool prepared = false;
+    DevBuf cb, prepA, prepCn, meta, cnsqrt;
+
+    int init(uint32_t m_, uint32_t k_, uint32_t sd_) {
+        m = m_;
+        k = k_;
+        sd = sd_;
+        mfma_ok = screen_supported(sd, k);
+        VQ_TRY(cb.alloc((size_t)m * k * sd * 4));
+        VQ_TRY(cnsqrt.alloc((size_t)m * k * 4));
+        VQ_TRY(meta.alloc((size_t)m * 4 * 4));
+        if (mfma_ok) {
+            screen_tiling(sd, k, &nt, &ks);
+            VQ_TRY(prepA.alloc((size_t)m * nt * ks * 64 * 4));
+            VQ_TRY(prepCn.alloc((size_t)m * nt * 16 * 4));
+        }
+        prepared = false;
+        return VQHIP_OK;
+    }
+    CodebookView view() const {
+        CodebookView v;
+        v.m = m;
+        v.k = k;
+        v.sd = sd;
+        v.cb = cb.as<float>();
+        v.nt = nt;
+        v.ks = ks;
+        v.prepA = mfma_ok ? prepA.as<float>() : nullptr;
+        v.prepCn = mfma_ok ? prepCn.as<float>() : nullptr;
+        v.meta = meta.as<float>();
+        v.cnsqrt = cnsqrt.as<float>();
+        return v;
+    }
+    int prepare(hipStream_t stream) {
+        if (prepared) return VQHIP_OK;
+        CodebookView v = view();
+        VQ_TRY(launch_prepare_codebook(v, mfma_ok ? prepA.as<float>() : nullptr,
+                                       mfma_ok ? prepCn.as<float>() : nullptr, meta.as<float>(),
+                                       cnsqrt.as<float>(), stream));
+        prepared = true;
+        return VQHIP_OK;
+    }
+};
+
+// --------------------------------------------------------------- assign workspace ----
+struct AssignWorkspace {
+    DevBuf wl_rows, wl_count, sub_list;
+    uint64_t wl_stride = 0;
+    uint32_t wl_m = 0;
+    std::vector<uint32_t> sub_host;
+    uint32_t *stats_host = nullptr;  // pinned [m]
+    uint32_t stats_m = 0;
+    bool stats_pending = false;
+    int last_engine = 0;
+    ~AssignWorkspace() {
+        if (stats_host) (void)hipHostFree(stats_host);
+    }
+    int ensure(uint32_t m, uint64_t n, bool need_wl) {
+        if (!sub_list.p || sub_list.bytes < (size_t)m * 4) VQ_TRY(sub_list.alloc((size_t)m * 4));
+        if (!wl_count.p || wl_m < m) {
+            VQ_TRY(wl_count.alloc((size_t)m * 4));
+            if (stats_host) (void)hipHostFree(stats_host);
+            stats_host = nullptr;
+            VQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&stats_host), (size_t)m * 4));
+            memset(stats_host, 0, (size_t)m * 4);
+            stats_m = m;
+        }
+        if (need_wl && (wl_stride < n || wl_m < m)) {
+            VQ_TRY(wl_rows.alloc((size_t)m * (size_t)n * 4));
+            wl_stride = n;
+        }
+        if (wl_m < m) wl_m = m;
+        return VQHIP_OK;
+    }
+    int set_sub_list(const std::vector<uint32_t> &subs, hipStream_t stream) {
+        if (subs != sub_host) {
+            // the previous list may still be read by queued kernels: order on the stream
+            VQ_HIP(hipMemcpyAsync(sub_list.p, subs.data(), subs.size() * 4, hipMemcpyHostToDevice, stream));
+            VQ_HIP(hipStreamSynchronize(stream));
+            sub_host = subs;
+        }
+        return VQHIP_OK;
+    }
+};
+
+// Optional per-call HIP-event timing of the two assignment stages, recorded on the stream
+// the kernels are launched on (bench.py derives the roofline figure from it).
+struct ProfileState {
+    bool on = false;
+    std::vector<hipEvent_t> ev;  // triples: start, after screen (or exact), after re-check
+    std::vector<int> engines;
+};
+static thread_local ProfileState g_prof;
+
+static int pick_engine(int requested, const CodebookState &cs, int metric, int *engine) {
+    const bool mfma_metric = (metric == VQHIP_SQUARED_EUCLIDEAN || metric == VQHIP_EUCLIDEAN);
+    if (requested == VQHIP_ENGINE_EXACT) {
+        *engine = VQHIP_ENGINE_EXACT;
+    } else if (requested == VQHIP_ENGINE_MFMA) {
+        if (!cs.mfma_ok || !mfma_metric)
+            return fail(VQHIP_ERR_UNSUPPORTED, "MFMA engine unavailable for sub_dim=%u k=%u metric=%d",
+                        cs.sd, cs.k, metric);
+        *engine = VQHIP_ENGINE_MFMA;
+    } else {
+        *engine = (cs.mfma_ok && mfma_metric) ? VQHIP_ENGINE_MFMA : VQHIP_ENGINE_EXACT;
+    }
+    return VQHIP_OK;
+}
+
+// assignment of every row of X [n][d] for the listed subspaces -> codes [n][m]
+static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, uint64_t n, uint32_t d,
+                      int metric, const std::vector<uint32_t> &subs, uint8_t *codes, int engine_req,
+                      hipStream_t stream) {
+    if (n == 0 || subs.empty()) return VQHIP_OK;
+    if (n >= (1ull << 32)) return fail(VQHIP_ERR_UNSUPPORTED, "more than 2^32-1 rows per device");
+    if ((reinterpret_cast<uintptr_t>(X) & 15) != 0)
+        return fail(VQHIP_ERR_INVALID_INPUT, "device row buffer must be 16-byte aligned");
+    int engine = 0;
+    VQ_TRY(pick_engine(engine_req, cs, metric, &engine));
+    VQ_TRY(cs.prepare(stream));
+    VQ_TRY(ws.ensure(cs.m, n, engine == VQHIP_ENGINE_MFMA));
+    VQ_TRY(ws.set_sub_list(subs, stream));
+    AssignArgs a;
+    a.X = X;
+    a.n = n;
+    a.d = d;
+    a.metric = metric;
+    a.sub_list = ws.sub_list.as<uint32_t>();
+    a.n_sub = (uint32_t)subs.size();
+    a.codes = codes;
+    a.wl_rows = ws.wl_rows.as<uint32_t>();
+    a.wl_count = ws.wl_count.as<uint32_t>();
+    a.wl_stride = ws.wl_stride;
+    CodebookView v = cs.view();
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (g_prof.on) {
+        VQ_HIP(hipEventCreate(&e0));
+        VQ_HIP(hipEventCreate(&e1));
+        VQ_HIP(hipEventCreate(&e2));
+        g_prof.ev.push_back(e0);
+        g_prof.ev.push_back(e1);
+        g_prof.ev.push_back(e2);
+        g_prof.engines.push_back(engine);
+    }
+    if (engine == VQHIP_ENGINE_MFMA) {
+        VQ_HIP(hipMemsetAsync(ws.wl_count.p, 0, (size_t)cs.m * 4, stream));
+        if (e0) VQ_HIP(hipEventRecord(e0, stream));
+        VQ_TRY(launch_assign_screen(v, a, stream));
+        if (e1) VQ_HIP(hipEventRecord(e1, stream));
+        VQ_TRY(launch_assign_exact(v, a, true, stream));
+        if (e2) VQ_HIP(hipEventRecord(e2, stream));
+        VQ_HIP(hipMemcpyAsync(ws.stats_host, ws.wl_count.p, (size_t)cs.m * 4, hipMemcpyDeviceToHost, stream));
+        ws.stats_pending = true;
+    } else {
+        if (e0) VQ_HIP(hipEventRecord(e0, stream));
+        VQ_TRY(launch_assign_exact(v, a, false, stream));
+        if (e1) VQ_HIP(hipEventRecord(e1, stream));
+        if (e2) VQ_HIP(hipEventRecord(e2, stream));
+        ws.stats_pending = false;
+    }
+    ws.last_engine = engine;
+    ThreadState &st = tls();
+    st.last_engine = engine;
+    st.last_rechecked = 0;
+    return VQHIP_OK;
+}
+
+static thread_local AssignWorkspace *g_last_ws = nullptr;
+
+
+}  // namespace vqhip
+
+using namespace vqhip;
+
+// ------------------------------------------------------------------------ handles ----
+struct vqhip_dataset {
+    DevBuf own;
+    const float *X = nullptr;
+    uint64_t n = 0;
+    uint32_t d = 0;
+};
+
+struct vqhip_kmeans {
+    const vqhip_dataset *ds = nullptr;
+    CodebookState cs;
+    AssignWorkspace ws;
+    UpdatePlan plan;
+    DevBuf codes, partial_sums, partial_counts, slab, counts, changed, active_dev, rows_tmp, xs_ws;
+    std::vector<uint8_t> active;
+    bool all_active = true;
+    int engine = VQHIP_ENGINE_AUTO;
+    int exact_update = 0;
+    bool accumulated = false;
+    uint32_t *counts_host = nullptr;   // pinned [m*k]
+    uint32_t *changed_host = nullptr;  // pinned [m]
+    ~vqhip_kmeans() {
+        if (counts_host) (void)hipHostFree(counts_host);
+        if (changed_host) (void)hipHostFree(changed_host);
+    }
+};
+
+struct vqhip_pq_encoder {
+    CodebookState cs;
+    AssignWorkspace ws;
+    int metric = VQHIP_EUCLIDEAN;
+    int engine = VQHIP_ENGINE_AUTO;
+    DevBuf xbuf, codes, f16buf, f32buf;
+    std::vector<uint32_t> all_subs;
+};
+
+struct vqhip_tsvq {
+    uint32_t n_nodes = 0, d = 0;
+    int metric = VQHIP_EUCLIDEAN;
+    DevBuf centroids, left, right, xbuf, leafbuf, f16buf;
+};
+
+#define VQ_API_BEGIN try {
+#define VQ_API_END                                                                  \
+    }                                                                               \
+    catch (const std::bad_alloc &) { return fail(VQHIP_ERR_FAILURE, "host allocation failed"); } \
+    catch (...) { return fail(VQHIP_ERR_FAILURE, "unexpected C++ exception"); }
+
+extern "C" {
+
+// ------------------------------------------------------------------ library/device ----
+const char *vqhip_backend(void) { return "libvqhip 0.1 (HIP, gfx950 / MI355X: fp32 MFMA screen + exact VALU re-check)"; }
+
+const char *vqhip_last_error(void) { return tls().last_error.c_str(); }
+
+int vqhip_device_count(void) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return 0;
+    int good = 0;
+    for (int i = 0; i < ndev; ++i) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+            ++good;
+    }
+    return good;
+}
+
+int vqhip_set_device(int device) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(VQHIP_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(VQHIP_ERR_INVALID_INPUT, "device %d out of range [0,%d)", device, ndev);
+    VQ_HIP(hipSetDevice(device));
+    return require_gfx950();
+}
+
+int vqhip_set_stream(void *hip_stream) {
+    ThreadState &st = tls();
+    st.user_stream = reinterpret_cast<hipStream_t>(hip_stream);
+    st.user_stream_set = (hip_stream != nullptr);
+    return VQHIP_OK;
+}
+
+int vqhip_synchronize(void) {
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_HIP(hipStreamSynchronize(s));
+    return VQHIP_OK;
+}
+
+int vqhip_last_assign_stats(uint64_t *rechecked, int *engine) {
+    ThreadState &st = tls();
+    if (engine) *engine = st.last_engine;
+    if (rechecked) {
+        *rechecked = 0;
+        AssignWorkspace *ws = g_last_ws;
+        if (ws && ws->stats_pending) {
+            hipStream_t s;
+            VQ_TRY(current_stream(&s));
+            VQ_HIP(hipStreamSynchronize(s));
+            uint64_t tot = 0;
+            for (uint32_t i = 0; i < ws->stats_m; ++i) tot += ws->stats_host[i];
+            *rechecked = tot;
+        }
+    }
+    return VQHIP_OK;
+}
+
+int vqhip_set_profiling(int on) {
+    g_prof.on = on != 0;
+    return VQHIP_OK;
+}
+
+int vqhip_profile_collect(uint32_t *n_calls, double *primary_ms, double *recheck_ms) {
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_HIP(hipStreamSynchronize(s));
+    double a = 0.0, b = 0.0;
+    const size_t calls = g_prof.ev.size() / 3;
+    for (size_t i = 0; i < calls; ++i) {
+        float t01 = 0.f, t12 = 0.f;
+        VQ_HIP(hipEventElapsedTime(&t01, g_prof.ev[3 * i], g_prof.ev[3 * i + 1]));
+        VQ_HIP(hipEventElapsedTime(&t12, g_prof.ev[3 * i + 1], g_prof.ev[3 * i + 2]));
+        a += t01;
+        b += t12;
+    }
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear();
+    g_prof.engines.clear();
+    if (n_calls) *n_calls = (uint32_t)calls;
+    if (primary_ms) *primary_ms = a;
+    if (recheck_ms) *recheck_ms = b;
+    return VQHIP_OK;
+}
+
+int vqhip_memcpy_device(void *dst, const void *src, uint64_t bytes) {
+    if (bytes == 0) return VQHIP_OK;
+    if (!dst || !src) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    return VQHIP_OK;
+}
+
+// ------------------------------------------------------------------------ datasets ----
+int vqhip_dataset_from_host(const float *rows, uint64_t n, uint32_t d, vqhip_dataset **out) {
+    VQ_API_BEGIN
+    if (!out) return fail(VQHIP_ERR_NULL_PTR, "out is NULL");
+    *out = nullptr;
+    if (n == 0 || d == 0) return fail(VQHIP_ERR_INVALID_INPUT, "empty dataset (n=%llu, d=%u)", (unsigned long long)n, d);
+    if (!rows) return fail(VQHIP_ERR_NULL_PTR, "rows is NULL");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    vqhip_dataset *ds = new vqhip_dataset();
+    int rc = ds->own.alloc((size_t)n * d * 4);
+    if (rc != VQHIP_OK) {
+        delete ds;
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(ds->own.p, rows, (size_t)n * d * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        delete ds;
+        return fail(VQHIP_ERR_RUNTIME, "H2D copy of the dataset failed: %s", hipGetErrorString(e));
+    }
+    ds->X = ds->own.as<float>();
+    ds->n = n;
+    ds->d = d;
+    *out = ds;
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_dataset_from_device(const void *dev_rows, uint64_t n, uint32_t d, vqhip_dataset **out) {
+    VQ_API_BEGIN
+    if (!out) return fail(VQHIP_ERR_NULL_PTR, "out is NULL");
+    *out = nullptr;
+    if (n == 0 || d == 0) return fail(VQHIP_ERR_INVALID_INPUT, "empty dataset");
+    if (!dev_rows) return fail(VQHIP_ERR_NULL_PTR, "dev_rows is NULL");
+    if ((reinterpret_cast<uintptr_t>(dev_rows) & 15) != 0)
+        return fail(VQHIP_ERR_INVALID_INPUT, "device row buffer must be 16-byte aligned");
+    VQ_TRY(require_gfx950());
+    vqhip_dataset *ds = new vqhip_dataset();
+    ds->X = reinterpret_cast<const float *>(dev_rows);
+    ds->n = n;
+    ds->d = d;
+    *out = ds;
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_dataset_synthetic(uint64_t n, uint32_t d, uint64_t seed, uint64_t row_offset, vqhip_dataset **out) {
+    VQ_API_BEGIN
+    if (!out) return fail(VQHIP_ERR_NULL_PTR, "out is NULL");
+    *out = nullptr;
+    if (n == 0 || d == 0) return fail(VQHIP_ERR_INVALID_INPUT, "empty dataset");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    vqhip_dataset *ds = new vqhip_dataset();
+    int rc = ds->own.alloc((size_t)n * d * 4);
+    if (rc == VQHIP_OK) rc = launch_synth_uniform(ds->own.as<float>(), n, d, seed, row_offset, s);
+    if (rc != VQHIP_OK) {
+        delete ds;
+        return rc;
+    }
+    ds->X = ds->own.as<float>();
+    ds->n = n;
+    ds->d = d;
+    *out = ds;
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_dataset_info(const vqhip_dataset *ds, uint64_t *n, uint32_t *d, const void **dev_rows) {
+    if (!ds) return fail(VQHIP_ERR_NULL_PTR, "dataset is NULL");
+    if (n) *n = ds->n;
+    if (d) *d = ds->d;
+    if (dev_rows) *dev_rows = ds->X;
+    return VQHIP_OK;
+}
+
+int vqhip_dataset_read(const vqhip_dataset *ds, uint64_t row0, uint64_t nrows, float *out) {
+    if (!ds || !out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (row0 > ds->n || nrows > ds->n - row0) return fail(VQHIP_ERR_INVALID_INPUT, "row range out of bounds");
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_HIP(hipMemcpyAsync(out, ds->X + row0 * ds->d, (size_t)nrows * ds->d * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    return VQHIP_OK;
+}
+
+int vqhip_dataset_destroy(vqhip_dataset *ds) {
+    delete ds;
+    return VQHIP_OK;
+}
+
+int vqhip_synth_uniform_host(float *out, uint64_t n, uint32_t d, uint64_t seed, uint64_t row_offset) {
+    if (!out) return fail(VQHIP_ERR_NULL_PTR, "out is NULL");
+    synth_uniform_host(out, n, d, seed, row_offset);
+    return VQHIP_OK;
+}
+
+// ------------------------------------------------------------------------- k-means ----
+int vqhip_kmeans_create(const vqhip_dataset *ds, uint32_t m, uint32_t k, vqhip_kmeans **out) {
+    VQ_API_BEGIN
+    if (!out) return fail(VQHIP_ERR_NULL_PTR, "out is NULL");
+    *out = nullptr;
+    if (!ds) return fail(VQHIP_ERR_NULL_PTR, "dataset is NULL");
+    if (m == 0 || ds->d < m || ds->d % m != 0)
+        return fail(VQHIP_ERR_INVALID_INPUT, "dimension (%u) must be divisible by m (%u)", ds->d, m);
+    if (k == 0) return fail(VQHIP_ERR_INVALID_INPUT, "k must be greater than 0");
+    if (k > 256) return fail(VQHIP_ERR_UNSUPPORTED, "k=%u > 256: codes are one byte per subspace", k);
+    VQ_TRY(require_gfx950());
+    const uint32_t sd = ds->d / m;
+    std::unique_ptr<vqhip_kmeans> km(new vqhip_kmeans());
+    km->ds = ds;
+    VQ_TRY(km->cs.init(m, k, sd));
+    VQ_TRY(plan_update(m, k, sd, ds->n, &km->plan));
+    VQ_TRY(km->codes.alloc((size_t)ds->n * m));
+    VQ_TRY(km->partial_sums.alloc(km->plan.partial_floats * km->plan.n_row_chunks * 4));
+    VQ_TRY(km->partial_counts.alloc(km->plan.partial_counts * km->plan.n_row_chunks * 4));
+    VQ_TRY(km->slab.alloc((size_t)m * k * (sd + 1) * 8));
+    VQ_TRY(km->counts.alloc((size_t)m * k * 4));
+    VQ_TRY(km->changed.alloc((size_t)m * 4));
+    VQ_TRY(km->active_dev.alloc(m));
+    VQ_TRY(km->rows_tmp.alloc((size_t)m * k * 8));
+    VQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&km->counts_host), (size_t)m * k * 4));
+    VQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&km->changed_host), (size_t)m * 4));
+    km->active.assign(m, 1);
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_HIP(hipMemsetAsync(km->active_dev.p, 1, m, s));
+    VQ_HIP(hipMemsetAsync(km->cs.cb.p, 0, km->cs.cb.bytes, s));
+    VQ_HIP(hipMemsetAsync(km->slab.p, 0, km->slab.bytes, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    *out = km.release();
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_kmeans_destroy(vqhip_kmeans *km) {
+    if (km && g_last_ws == &km->ws) g_last_ws = nullptr;
+    delete km;
+    return VQHIP_OK;
+}
+
+int vqhip_kmeans_set_centroids(vqhip_kmeans *km, const float *centroids) {
+    if (!km || !centroids) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_HIP(hipMemcpyAsync(km->cs.cb.p, centroids, (size_t)km->cs.m * km->cs.k * km->cs.sd * 4, hipMemcpyHostToDevice, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    km->cs.prepared = false;
+    return VQHIP_OK;
+}
+
+int vqhip_kmeans_init_from_rows(vqhip_kmeans *km, const uint64_t *init_rows) {
+    if (!km || !init_rows) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    const size_t cnt = (size_t)km->cs.m * km->cs.k;
+    for (size_t i = 0; i < cnt; ++i)
+        if (init_rows[i] >= km->ds->n)
+            return fail(VQHIP_ERR_INVALID_INPUT, "init row %llu out of range", (unsigned long long)init_rows[i]);
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_HIP(hipMemcpyAsync(km->rows_tmp.p, init_rows, cnt * 8, hipMemcpyHostToDevice, s));
+    VQ_TRY(launch_gather_rows(km->ds->X, km->ds->d, km->cs.m, km->cs.k, km->cs.sd, km->rows_tmp.as<uint64_t>(),
+                              km->cs.cb.as<float>(), s));
+    VQ_HIP(hipStreamSynchronize(s));
+    km->cs.prepared = false;
+    return VQHIP_OK;
+}
+
+int vqhip_kmeans_get_centroids(vqhip_kmeans *km, float *centroids) {
+    if (!km || !centroids) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_HIP(hipMemcpyAsync(centroids, km->cs.cb.p, (size_t)km->cs.m * km->cs.k * km->cs.sd * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    return VQHIP_OK;
+}
+
+int vqhip_kmeans_set_active(vqhip_kmeans *km, const uint8_t *active) {
+    if (!km || !active) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    bool all = true;
+    for (uint32_t s = 0; s < km->cs.m; ++s) {
+        km->active[s] = active[s] ? 1 : 0;
+        all = all && km->active[s];
+    }
+    km->all_active = all;
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_HIP(hipMemcpyAsync(km->active_dev.p, km->active.data(), km->cs.m, hipMemcpyHostToDevice, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    return VQHIP_OK;
+}
+
+int vqhip_kmeans_set_engine(vqhip_kmeans *km, int engine) {
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (engine < VQHIP_ENGINE_AUTO || engine > VQHIP_ENGINE_MFMA) return fail(VQHIP_ERR_INVALID_INPUT, "unknown engine %d", engine);
+    km->engine = engine;
+    return VQHIP_OK;
+}
+
+int vqhip_kmeans_set_exact_update(vqhip_kmeans *km, int exact_update) {
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    km->exact_update = exact_update ? 1 : 0;
+    return VQHIP_OK;
+}
+
+int vqhip_kmeans_accumulate(vqhip_kmeans *km) {
+    VQ_API_BEGIN
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    std::vector<uint32_t> subs;
+    for (uint32_t i = 0; i < km->cs.m; ++i)
+        if (km->active[i]) subs.push_back(i);
+    const vqhip_dataset *ds = km->ds;
+    g_last_ws = &km->ws;
+    // assignment: always squared L2 (src/core/vector.rs:352-363)
+    VQ_TRY(run_assign(km->cs, km->ws, ds->X, ds->n, ds->d, VQHIP_SQUARED_EUCLIDEAN, subs,
+                      km->codes.as<uint8_t>(), km->engine, s));
+    const uint8_t *act = km->all_active ? nullptr : km->active_dev.as<uint8_t>();
+    if (km->exact_update) {
+        size_t need = exact_sums_workspace_bytes(km->cs.m, km->cs.k, ds->n);
+        VQ_TRY(km->xs_ws.ensure(need));
+        VQ_TRY(launch_exact_sums(km->cs.m, km->cs.k, km->cs.sd, ds->X, ds->n, ds->d, km->codes.as<uint8_t>(), act,
+                                 km->xs_ws.p, km->xs_ws.bytes, km->slab.as<double>(), s));
+    } else {
+        VQ_TRY(launch_accumulate(km->plan, ds->X, ds->n, ds->d, km->codes.as<uint8_t>(), act,
+                                 km->partial_sums.as<float>(), km->partial_counts.as<uint32_t>(), s));
+        VQ_TRY(launch_reduce_partials(km->plan, km->partial_sums.as<float>(), km->partial_counts.as<uint32_t>(), act,
+                                      km->slab.as<double>(), s));
+    }
+    km->accumulated = true;
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_kmeans_partials(vqhip_kmeans *km, void **dev_slab, uint64_t *n_doubles) {
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (dev_slab) *dev_slab = km->slab.p;
+    if (n_doubles) *n_doubles = (uint64_t)km->cs.m * km->cs.k * (km->cs.sd + 1);
+    return VQHIP_OK;
+}
+
+int vqhip_kmeans_finalize(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
+    VQ_API_BEGIN
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (!km->accumulated) return fail(VQHIP_ERR_INVALID_INPUT, "finalize without a preceding accumulate");
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    const uint8_t *act = km->all_active ? nullptr : km->active_dev.as<uint8_t>();
+    const uint32_t m = km->cs.m, k = km->cs.k;
+    VQ_TRY(launch_finalize(m, k, km->cs.sd, km->slab.as<double>(), act, km->cs.cb.as<float>(),
+                           km->counts.as<uint32_t>(), km->changed.as<uint32_t>(), km->exact_update, s));
+    km->cs.prepared = false;
+    km->accumulated = false;
+    VQ_HIP(hipMemcpyAsync(km->counts_host, km->counts.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipMemcpyAsync(km->changed_host, km->changed.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    if (counts) memcpy(counts, km->counts_host, (size_t)m * k * 4);
+    if (changed)
+        for (uint32_t i = 0; i < m; ++i) changed[i] = (km->active[i] && km->changed_host[i]) ? 1 : 0;
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
+    VQ_TRY(vqhip_kmeans_accumulate(km));
+    return vqhip_kmeans_finalize(km, counts, changed);
+}
+
+int vqhip_kmeans_patch_centroid(vqhip_kmeans *km, uint32_t s, uint32_t j, const float *sub_row) {
+    if (!km || !sub_row) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (s >= km->cs.m || j >= km->cs.k) return fail(VQHIP_ERR_INVALID_INPUT, "centroid (%u,%u) out of range", s, j);
+    hipStream_t st;
+    VQ_TRY(current_stream(&st));
+    float *dst = km->cs.cb.as<float>() + ((size_t)s * km->cs.k + j) * km->cs.sd;
+    VQ_HIP(hipMemcpyAsync(dst, sub_row, (size_t)km->cs.sd * 4, hipMemcpyHostToDevice, st));
+    VQ_HIP(hipStreamSynchronize(st));
+    km->cs.prepared = false;
+    return VQHIP_OK;
+}
+
+int vqhip_kmeans_patch_from_row(vqhip_kmeans *km, uint32_t s, uint32_t j, uint64_t row) {
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (s >= km->cs.m || j >= km->cs.k) return fail(VQHIP_ERR_INVALID_INPUT, "centroid (%u,%u) out of range", s, j);
+    if (row >= km->ds->n) return fail(VQHIP_ERR_INVALID_INPUT, "row %llu out of range", (unsigned long long)row);
+    hipStream_t st;
+    VQ_TRY(current_stream(&st));
+    float *dst = km->cs.cb.as<float>() + ((size_t)s * km->cs.k + j) * km->cs.sd;
+    const float *src = km->ds->X + row * km->ds->d + (size_t)s * km->cs.sd;
+    VQ_HIP(hipMemcpyAsync(dst, src, (size_t)km->cs.sd * 4, hipMemcpyDeviceToDevice, st));
+    km->cs.prepared = false;
+    return VQHIP_OK;
+}
+
+int vqhip_kmeans_get_assignments(vqhip_kmeans *km, uint8_t *codes) {
+    if (!km || !codes) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_HIP(hipMemcpyAsync(codes, km->codes.p, (size_t)km->ds->n * km->cs.m, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    return VQHIP_OK;
+}
+
+// ----------------------------------------------------------------------- PQ encode ----
+int vqhip_pq_encoder_create(const float *codebooks, uint32_t m, uint32_t k, uint32_t sub_dim, int metric,
+                            vqhip_pq_encoder **out) {
+    VQ_API_BEGIN
+    if (!out) return fail(VQHIP_ERR_NULL_PTR, "out is NULL");
+    *out = nullptr;
+    if (!codebooks) return fail(VQHIP_ERR_NULL_PTR, "codebooks is NULL");
+    if (m == 0 || k == 0 || sub_dim == 0) return fail(VQHIP_ERR_INVALID_INPUT, "m, k and sub_dim must be positive");
+    if (k > 256) return fail(VQHIP_ERR_UNSUPPORTED, "k=%u > 256: codes are one byte per subspace", k);
+    if (metric < VQHIP_SQUARED_EUCLIDEAN || metric > VQHIP_COSINE) return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", metric);
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    std::unique_ptr<vqhip_pq_encoder> enc(new vqhip_pq_encoder());
+    enc->metric = metric;
+    VQ_TRY(enc->cs.init(m, k, sub_dim));
+    VQ_HIP(hipMemcpyAsync(enc->cs.cb.p, codebooks, (size_t)m * k * sub_dim * 4, hipMemcpyHostToDevice, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    for (uint32_t i = 0; i < m; ++i) enc->all_subs.push_back(i);
+    *out = enc.release();
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_pq_encoder_destroy(vqhip_pq_encoder *enc) {
+    if (enc && g_last_ws == &enc->ws) g_last_ws = nullptr;
+    delete enc;
+    return VQHIP_OK;
+}
+
+int vqhip_pq_encoder_set_engine(vqhip_pq_encoder *enc, int engine) {
+    if (!enc) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (engine < VQHIP_ENGINE_AUTO || engine > VQHIP_ENGINE_MFMA) return fail(VQHIP_ERR_INVALID_INPUT, "unknown engine %d", engine);
+    enc->engine = engine;
+    return VQHIP_OK;
+}
+
+int vqhip_pq_encode_device(vqhip_pq_encoder *enc, const void *dev_rows, uint64_t n, void *dev_codes, void *dev_f16_out) {
+    VQ_API_BEGIN
+    if (!enc) return fail(VQHIP_ERR_NULL_PTR, "encoder is NULL");
+    if (n == 0) return VQHIP_OK;
+    if (!dev_rows) return fail(VQHIP_ERR_NULL_PTR, "dev_rows is NULL");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    uint8_t *codes = reinterpret_cast<uint8_t *>(dev_codes);
+    if (!codes) {  // f16-only output still needs the codes internally
+        VQ_TRY(enc->codes.ensure((size_t)n * enc->cs.m));
+        codes = enc->codes.as<uint8_t>();
+    }
+    g_last_ws = &enc->ws;
+    VQ_TRY(run_assign(enc->cs, enc->ws, reinterpret_cast<const float *>(dev_rows), n, enc->cs.m * enc->cs.sd,
+                      enc->metric, enc->all_subs, codes, enc->engine, s));
+    if (dev_f16_out) VQ_TRY(launch_gather_f16(enc->cs.view(), codes, n, reinterpret_cast<uint16_t *>(dev_f16_out), s));
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_pq_encode(vqhip_pq_encoder *enc, const float *rows, uint64_t n, uint8_t *codes, uint16_t *f16_out) {
+    VQ_API_BEGIN
+    if (!enc) return fail(VQHIP_ERR_NULL_PTR, "encoder is NULL");
+    if (n == 0) return VQHIP_OK;
+    if (!rows) return fail(VQHIP_ERR_NULL_PTR, "rows is NULL");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    const uint32_t m = enc->cs.m, d = enc->cs.m * enc->cs.sd;
+    // bounded staging: at most ~1 GiB of rows per pass
+    uint64_t chunk = std::max<uint64_t>(1, (1ull << 30) / ((uint64_t)d * 4));
+    if (chunk > n) chunk = n;
+    VQ_TRY(enc->xbuf.ensure((size_t)chunk * d * 4));
+    VQ_TRY(enc->codes.ensure((size_t)chunk * m));
+    if (f16_out) VQ_TRY(enc->f16buf.ensure((size_t)chunk * d * 2));
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk) {
+        const uint64_t nr = std::min(chunk, n - r0);
+        VQ_HIP(hipMemcpyAsync(enc->xbuf.p, rows + r0 * d, (size_t)nr * d * 4, hipMemcpyHostToDevice, s));
+        VQ_TRY(vqhip_pq_encode_device(enc, enc->xbuf.p, nr, enc->codes.p, f16_out ? enc->f16buf.p : nullptr));
+        if (codes) VQ_HIP(hipMemcpyAsync(codes + r0 * m, enc->codes.p, (size_t)nr * m, hipMemcpyDeviceToHost, s));
+        if (f16_out) VQ_HIP(hipMemcpyAsync(f16_out + r0 * d, enc->f16buf.p, (size_t)nr * d * 2, hipMemcpyDeviceToHost, s));
+        VQ_HIP(hipStreamSynchronize(s));
+    }
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_dequantize_f16(const uint16_t *f16_in, uint64_t count, float *out) {
+    VQ_API_BEGIN
+    if (count == 0) return VQHIP_OK;
+    if (!f16_in || !out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    DevBuf in, o;
+    VQ_TRY(in.alloc((size_t)count * 2));
+    VQ_TRY(o.alloc((size_t)count * 4));
+    VQ_HIP(hipMemcpyAsync(in.p, f16_in, (size_t)count * 2, hipMemcpyHostToDevice, s));
+    VQ_TRY(launch_dequant_f16(in.as<uint16_t>(), count, o.as<float>(), s));
+    VQ_HIP(hipMemcpyAsync(out, o.p, (size_t)count * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_pq_decode(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n, float *out) {
+    VQ_API_BEGIN
+    if (!enc) return fail(VQHIP_ERR_NULL_PTR, "encoder is NULL");
+    if (n == 0) return VQHIP_OK;
+    if (!codes || !out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    const uint32_t m = enc->cs.m, d = enc->cs.m * enc->cs.sd;
+    for (uint64_t i = 0; i < n * m; ++i)
+        if (codes[i] >= enc->cs.k) return fail(VQHIP_ERR_INVALID_INPUT, "code %u >= k=%u", codes[i], enc->cs.k);
+    VQ_TRY(enc->codes.ensure((size_t)n * m));
+    VQ_TRY(enc->f32buf.ensure((size_t)n * d * 4));
+    VQ_HIP(hipMemcpyAsync(enc->codes.p, codes, (size_t)n * m, hipMemcpyHostToDevice, s));
+    VQ_TRY(launch_decode_f32(enc->cs.view(), enc->codes.as<uint8_t>(), n, enc->f32buf.as<float>(), s));
+    VQ_HIP(hipMemcpyAsync(out, enc->f32buf.p, (size_t)n * d * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_distance_batch(int metric, const float *a, const float *b, uint64_t n, uint32_t d, float *out) {
+    VQ_API_BEGIN
+    if (n == 0) return VQHIP_OK;
+    if (!a || !b || !out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (metric < VQHIP_SQUARED_EUCLIDEAN || metric > VQHIP_COSINE) return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", metric);
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    DevBuf da, db, dout;
+    VQ_TRY(da.alloc((size_t)n * d * 4));
+    VQ_TRY(db.alloc((size_t)n * d * 4));
+    VQ_TRY(dout.alloc((size_t)n * 4));
+    VQ_HIP(hipMemcpyAsync(da.p, a, (size_t)n * d * 4, hipMemcpyHostToDevice, s));
+    VQ_HIP(hipMemcpyAsync(db.p, b, (size_t)n * d * 4, hipMemcpyHostToDevice, s));
+    VQ_TRY(launch_distance_batch(metric, da.as<float>(), db.as<float>(), n, d, dout.as<float>(), s));
+    VQ_HIP(hipMemcpyAsync(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+// ---------------------------------------------------------------------------- TSVQ ----
+int vqhip_tsvq_build(const vqhip_dataset *, uint32_t, uint32_t, float *, int32_t *, int32_t *, int32_t *) {
+    return fail(VQHIP_ERR_UNSUPPORTED, "TSVQ build kernels are not part of this build yet");
+}
+int vqhip_tsvq_create(const float *, const int32_t *, const int32_t *, uint32_t, uint32_t, int, vqhip_tsvq **) {
+    return fail(VQHIP_ERR_UNSUPPORTED, "TSVQ encode kernels are not part of this build yet");
+}
+int vqhip_tsvq_destroy(vqhip_tsvq *t) {
+    delete t;
+    return VQHIP_OK;
+}
+int vqhip_tsvq_encode(vqhip_tsvq *, const float *, uint64_t, int32_t *, uint16_t *) {
+    return fail(VQHIP_ERR_UNSUPPORTED, "TSVQ encode kernels are not part of this build yet");
+}
+int vqhip_tsvq_encode_device(vqhip_tsvq *, const void *, uint64_t, void *, void *) {
+    return fail(VQHIP_ERR_UNSUPPORTED, "TSVQ encode kernels are not part of this build yet");
+}
+
+}  // extern "C"

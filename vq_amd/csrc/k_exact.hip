@@ -1,0 +1,334 @@
+// k_exact.hip -- exact nearest-centroid scan in the reference's arithmetic (gfx950).
+//
+// Every distance is evaluated with the reference's operation order: sequential f32,
+// one rounding per operation, no fused multiply-add (src/core/vector.rs:135-143,
+// src/core/distance.rs:76-82, 94, 107-119), and the argmin keeps the FIRST minimum
+// (strict '<', src/core/vector.rs:355-361, src/pq.rs:185-191).  This kernel is
+//   (1) the re-check stage behind the MFMA screen (k_screen.hip) -- it alone decides the
+//       rows the screen could not prove, and
+//   (2) the assignment engine for shapes/metrics without an MFMA form (Manhattan, cosine,
+//       sub_dim not a multiple of 4, k > 256-tile budget).
+// It also prepares the per-codebook constants both engines need.
+//
+// Roofline: VALU.  3 ops per (row, centroid, dim) for L2 (sub, mul, add; they cannot fuse),
+// algorithmic bytes 4*d in + m out per row.  Centroids are wave-uniform (one subspace per
+// workgroup) so they arrive through the scalar cache and feed VALU ops as SGPR operands.
+#include "kernels.hpp"
+
+// The reference never contracts a*b+c (Rust has no implicit FMA).  Belt and braces with
+// -ffp-contract=off on the command line.
+#pragma clang fp contract(off)
+
+namespace vqhip {
+namespace {
+
+constexpr int kExactBlock = 256;
+
+template <int METRIC, int SD, bool GENERIC>
+__device__ __forceinline__ uint32_t scan_one(const float *__restrict__ xrow, uint32_t sd_rt,
+                                             const float *__restrict__ cbs,
+                                             const float *__restrict__ cnsq, uint32_t k) {
+    const uint32_t sd = GENERIC ? sd_rt : (uint32_t)SD;
+    float x[GENERIC ? 1 : SD];
+    if constexpr (!GENERIC) {
+#pragma unroll
+        for (int t = 0; t < SD; ++t) x[t] = xrow[t];
+    }
+    float na = 0.0f;
+    if constexpr (METRIC == VQHIP_COSINE) {
+        float sa = -0.0f;  // `.sum()` folds from -0.0 (Rust 1.85); invisible after sqrt/compare
+        if constexpr (GENERIC) {
+            for (uint32_t t = 0; t < sd; ++t) {
+                float p = xrow[t] * xrow[t];
+                sa = sa + p;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < SD; ++t) {
+                float p = x[t] * x[t];
+                sa = sa + p;
+            }
+        }
+        na = sqrtf(sa);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+    }
+    uint32_t best = 0;
+    float best_dist = 0.0f;
+    for (uint32_t j = 0; j < k; ++j) {
+        const float *c = cbs + (size_t)j * sd;
+        float dist;
+        if constexpr (METRIC == VQHIP_SQUARED_EUCLIDEAN || METRIC == VQHIP_EUCLIDEAN) {
+            float acc = 0.0f;
+            if constexpr (GENERIC) {
+                for (uint32_t t = 0; t < sd; ++t) {
+                    float diff = xrow[t] - c[t];
+                    float sq = diff * diff;
+                    acc = acc + sq;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < SD; ++t) {
+                    float diff = x[t] - c[t];
+                    float sq = diff * diff;
+                    acc = acc + sq;
+                }
+            }
+            dist = (METRIC == VQHIP_EUCLIDEAN) ? sqrtf(acc) : acc;
+        } else if constexpr (METRIC == VQHIP_MANHATTAN) {
+            float acc = 0.0f;
+            if constexpr (GENERIC) {
+                for (uint32_t t = 0; t < sd; ++t) {
+                    float diff = xrow[t] - c[t];
+                    acc = acc + fabsf(diff);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < SD; ++t) {
+                    float diff = x[t] - c[t];
+                    acc = acc + fabsf(diff);
+                }
+            }
+            dist = acc;
+        } else {  // cosine, src/core/distance.rs:107-119
+            float dot = -0.0f;
+            if constexpr (GENERIC) {
+                for (uint32_t t = 0; t < sd; ++t) {
+                    float p = xrow[t] * c[t];
+                    dot = dot + p;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < SD; ++t) {
+                    float p = x[t] * c[t];
+                    dot = dot + p;
+                }
+            }
+            const float nb = cnsq[j];  // sqrt(sum c^2): depends on c only, hoisted
+            const float EPS = 1e-10f;
+            if (na < EPS || nb < EPS) {
+                dist = 1.0f;
+            } else {
+                float denom = na * nb;
+                float q = dot / denom;  // correctly rounded
+                float v = 1.0f - q;
+                dist = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);  // f32::clamp keeps NaN
+            }
+        }
+        if (j == 0) {
+            best_dist = dist;
+        } else if (dist < best_dist) {  // strict: first minimum wins; NaN never wins
+            best_dist = dist;
+            best = j;
+        }
+    }
+    return best;
+}
+
+template <int METRIC, int SD, bool GENERIC>
+__global__ __launch_bounds__(kExactBlock) void k_assign_exact(
+    const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m, uint32_t k, uint32_t sd_rt,
+    const float *__restrict__ cb, const float *__restrict__ cnsqrt,
+    const uint32_t *__restrict__ sub_list, const uint32_t *__restrict__ wl_rows,
+    const uint32_t *__restrict__ wl_count, uint64_t wl_stride, uint8_t *__restrict__ codes) {
+    const uint32_t sd = GENERIC ? sd_rt : (uint32_t)SD;
+    const uint32_t s = sub_list ? sub_list[blockIdx.y] : blockIdx.y;
+    const uint64_t count = wl_rows ? (uint64_t)wl_count[s] : n;
+    const float *cbs = cb + (size_t)s * k * sd;
+    const float *cnsq = cnsqrt ? cnsqrt + (size_t)s * k : nullptr;
+    for (uint64_t i = (uint64_t)blockIdx.x * kExactBlock + threadIdx.x; i < count;
+         i += (uint64_t)gridDim.x * kExactBlock) {
+        const uint64_t row = wl_rows ? (uint64_t)wl_rows[(size_t)s * wl_stride + i] : i;
+        const float *xrow = X + row * d + (size_t)s * sd;
+        uint32_t best = scan_one<METRIC, SD, GENERIC>(xrow, sd, cbs, cnsq, k);
+        codes[row * m + s] = (uint8_t)best;
+    }
+}
+
+// One workgroup per subspace: squared norms, the screen's A-operand image, flags.
+__global__ __launch_bounds__(256) void k_prepare_codebook(const float *__restrict__ cb, uint32_t m,
+                                                          uint32_t k, uint32_t sd, uint32_t nt,
+                                                          uint32_t ks, float *__restrict__ prepA,
+                                                          float *__restrict__ prepCn,
+                                                          float *__restrict__ meta,
+                                                          float *__restrict__ cnsqrt) {
+    __shared__ float s_max[256];
+    __shared__ int s_bad[256];
+    const uint32_t s = blockIdx.x;
+    const float *cbs = cb + (size_t)s * k * sd;
+    float lmax = 0.0f;
+    int bad = 0;
+    const uint32_t kpad = nt * 16;
+    for (uint32_t j = threadIdx.x; j < (kpad > k ? kpad : k); j += blockDim.x) {
+        if (j < k) {
+            float acc = -0.0f;
+            for (uint32_t t = 0; t < sd; ++t) {
+                float v = cbs[(size_t)j * sd + t];
+                float p = v * v;
+                acc = acc + p;
+                if (!(fabsf(v) <= 3.0e38f)) bad = 1;  // NaN or Inf
+            }
+            if (!(acc <= 3.0e38f)) bad = 1;
+            if (cnsqrt) cnsqrt[(size_t)s * k + j] = sqrtf(acc);
+            if (prepCn) prepCn[(size_t)s * kpad + j] = acc + 0.0f;
+            lmax = fmaxf(lmax, acc);
+        } else if (prepCn) {
+            prepCn[(size_t)s * kpad + j] = __builtin_inff();  // padding never wins
+        }
+    }
+    s_max[threadIdx.x] = lmax;
+    s_bad[threadIdx.x] = bad;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + off]);
+            s_bad[threadIdx.x] |= s_bad[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && meta) {
+        // margin coefficient: see DESIGN.md "screen soundness".  (8*sd+16)*2^-24 covers
+        // (6*sd+8)(1+eps) from the error analysis with ~1.4x slack; a non-finite codebook
+        // gets +inf so that every row of the subspace goes to the exact re-check.
+        const float u = 5.9604644775390625e-08f;  // 2^-24
+        float coef = (8.0f * (float)sd + 16.0f) * u;
+        meta[s * 4 + 0] = sqrtf(s_max[0]) * 1.0000005f + 1e-30f;
+        meta[s * 4 + 1] = s_bad[0] ? __builtin_inff() : coef;
+        meta[s * 4 + 2] = 0.0f;
+        meta[s * 4 + 3] = 0.0f;
+    }
+    if (prepA) {
+        // A operand of v_mfma_f32_16x16x4_f32: lane l holds A[row = l&15][k = l>>4].  Tile i,
+        // k-step q, lane l  <-  -2 * C[16i + (l&15)][ks*(l>>4) + q]  (k order permuted the same
+        // way as the B operand the screen kernel loads; any order is a valid dot product).
+        const uint32_t total = nt * ks * 64;
+        for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+            uint32_t lane = e & 63, q = (e >> 6) % ks, i = (e >> 6) / ks;
+            uint32_t j = 16 * i + (lane & 15);
+            uint32_t t = ks * (lane >> 4) + q;
+            float v = (j < k) ? -2.0f * cbs[(size_t)j * sd + t] : 0.0f;
+            prepA[(size_t)s * total + e] = v;
+        }
+    }
+}
+
+// Distance::compute for one pair, runtime length (src/core/distance.rs:48-64)
+__device__ float exact_distance_rt(int metric, const float *__restrict__ a,
+                                   const float *__restrict__ b, uint32_t n) {
+    if (metric == VQHIP_SQUARED_EUCLIDEAN || metric == VQHIP_EUCLIDEAN) {
+        float acc = -0.0f;
+        for (uint32_t t = 0; t < n; ++t) {
+            float diff = a[t] - b[t];
+            float sq = diff * diff;
+            acc = acc + sq;
+        }
+        return metric == VQHIP_EUCLIDEAN ? sqrtf(acc) : acc;
+    }
+    if (metric == VQHIP_MANHATTAN) {
+        float acc = -0.0f;
+        for (uint32_t t = 0; t < n; ++t) {
+            float diff = a[t] - b[t];
+            acc = acc + fabsf(diff);
+        }
+        return acc;
+    }
+    float dot = -0.0f, sa = -0.0f, sb = -0.0f;
+    for (uint32_t t = 0; t < n; ++t) {
+        float p = a[t] * b[t];
+        dot = dot + p;
+    }
+    for (uint32_t t = 0; t < n; ++t) {
+        float p = a[t] * a[t];
+        sa = sa + p;
+    }
+    for (uint32_t t = 0; t < n; ++t) {
+        float p = b[t] * b[t];
+        sb = sb + p;
+    }
+    const float na = sqrtf(sa), nb = sqrtf(sb);
+    const float EPS = 1e-10f;
+    if (na < EPS || nb < EPS) return 1.0f;
+    float denom = na * nb;
+    float q = dot / denom;
+    float v = 1.0f - q;
+    return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+}
+
+__global__ __launch_bounds__(256) void k_distance_batch(int metric, const float *__restrict__ a,
+                                                        const float *__restrict__ b, uint64_t n,
+                                                        uint32_t d, float *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        out[i] = exact_distance_rt(metric, a + i * d, b + i * d, d);
+}
+
+template <int METRIC>
+int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 grid,
+                   hipStream_t stream) {
+    const uint32_t *wlr = wl ? a.wl_rows : nullptr;
+    const uint32_t *wlc = wl ? a.wl_count : nullptr;
+#define VQ_EXACT_CASE(SDV)                                                                    \
+    case SDV:                                                                                  \
+        hipLaunchKernelGGL((k_assign_exact<METRIC, SDV, false>), grid, dim3(kExactBlock), 0,   \
+                           stream, a.X, a.n, a.d, cb.m, cb.k, cb.sd, cb.cb, cb.cnsqrt,         \
+                           a.sub_list, wlr, wlc, a.wl_stride, a.codes);                        \
+        break;
+    switch (cb.sd) {
+        VQ_EXACT_CASE(1)
+        VQ_EXACT_CASE(2)
+        VQ_EXACT_CASE(4)
+        VQ_EXACT_CASE(8)
+        VQ_EXACT_CASE(16)
+        VQ_EXACT_CASE(32)
+    default:
+        hipLaunchKernelGGL((k_assign_exact<METRIC, 1, true>), grid, dim3(kExactBlock), 0, stream,
+                           a.X, a.n, a.d, cb.m, cb.k, cb.sd, cb.cb, cb.cnsqrt, a.sub_list, wlr, wlc,
+                           a.wl_stride, a.codes);
+    }
+#undef VQ_EXACT_CASE
+    VQ_LAUNCH_CHECK("k_assign_exact");
+    return VQHIP_OK;
+}
+
+}  // namespace
+
+int launch_prepare_codebook(const CodebookView &v, float *prepA, float *prepCn, float *meta,
+                            float *cnsqrt, hipStream_t stream) {
+    if (v.m == 0) return VQHIP_OK;
+    hipLaunchKernelGGL(k_prepare_codebook, dim3(v.m), dim3(256), 0, stream, v.cb, v.m, v.k, v.sd,
+                       v.nt, v.ks, prepA, prepCn, meta, cnsqrt);
+    VQ_LAUNCH_CHECK("k_prepare_codebook");
+    return VQHIP_OK;
+}
+
+int launch_distance_batch(int metric, const float *a, const float *b, uint64_t n, uint32_t d,
+                          float *out, hipStream_t stream) {
+    if (n == 0) return VQHIP_OK;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > (uint64_t)num_cus() * 8) blocks = (uint64_t)num_cus() * 8;
+    hipLaunchKernelGGL(k_distance_batch, dim3((uint32_t)blocks), dim3(256), 0, stream, metric, a, b,
+                       n, d, out);
+    VQ_LAUNCH_CHECK("k_distance_batch");
+    return VQHIP_OK;
+}
+
+int launch_assign_exact(const CodebookView &cb, const AssignArgs &a, bool use_worklist,
+                        hipStream_t stream) {
+    if (a.n == 0 || a.n_sub == 0) return VQHIP_OK;
+    if (a.metric == VQHIP_COSINE && !cb.cnsqrt)
+        return fail(VQHIP_ERR_FAILURE, "cosine assignment needs prepared centroid norms");
+    // work-list launches do not know their size on the host: a fixed grid strides over it
+    uint64_t items = use_worklist ? (uint64_t)num_cus() * 4 * kExactBlock : a.n;
+    uint32_t gx = (uint32_t)((items + kExactBlock - 1) / kExactBlock);
+    uint32_t cap = (uint32_t)num_cus() * 16;
+    if (gx > cap) gx = cap;
+    if (gx == 0) gx = 1;
+    dim3 grid(gx, a.n_sub);
+    switch (a.metric) {
+    case VQHIP_SQUARED_EUCLIDEAN:
+        return dispatch_exact<VQHIP_SQUARED_EUCLIDEAN>(cb, a, use_worklist, grid, stream);
+    case VQHIP_EUCLIDEAN: return dispatch_exact<VQHIP_EUCLIDEAN>(cb, a, use_worklist, grid, stream);
+    case VQHIP_MANHATTAN: return dispatch_exact<VQHIP_MANHATTAN>(cb, a, use_worklist, grid, stream);
+    case VQHIP_COSINE: return dispatch_exact<VQHIP_COSINE>(cb, a, use_worklist, grid, stream);
+    default: return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", a.metric);
+    }
+}
+
+}  // namespace vqhip

@@ -1,0 +1,121 @@
+// k_misc.hip -- output gathers and the synthetic data generator (gfx950).  All HBM-bound.
+#include <hip/hip_fp16.h>
+
+#include "kernels.hpp"
+
+namespace vqhip {
+namespace {
+
+// splitmix64 finaliser on a per-element counter: element (row, col) of the synthetic matrix
+// depends only on (seed, global row, col), so any shard of any size reproduces the same data
+// on the device and on the host.  24 random bits -> exact multiples of 2^-24 in [0, 1).
+__host__ __device__ inline float synth_value(uint64_t seed, uint64_t row, uint32_t col, uint32_t d) {
+    uint64_t z = seed + (row * (uint64_t)d + col + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f;
+}
+
+__global__ __launch_bounds__(256) void k_synth_uniform(float *__restrict__ X, uint64_t n, uint32_t d,
+                                                       uint64_t seed, uint64_t row_offset) {
+    const uint64_t total = n * d;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (uint64_t)gridDim.x * 256) {
+        const uint64_t row = e / d;
+        const uint32_t col = (uint32_t)(e - row * d);
+        X[e] = synth_value(seed, row_offset + row, col, d);
+    }
+}
+
+// out[row][s*sd + t] = f16(codebook[s][codes[row][s]][t]), src/pq.rs:193-195.
+// One lane per pair of output elements (4 B stores, fully coalesced along the row).
+__global__ __launch_bounds__(256) void k_gather_f16(const float *__restrict__ cb, uint32_t m,
+                                                    uint32_t k, uint32_t sd,
+                                                    const uint8_t *__restrict__ codes, uint64_t n,
+                                                    uint16_t *__restrict__ out) {
+    const uint32_t d = m * sd;
+    const uint64_t total = n * d;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (uint64_t)gridDim.x * 256) {
+        const uint64_t row = e / d;
+        const uint32_t col = (uint32_t)(e - row * d);
+        const uint32_t s = col / sd, t = col - s * sd;
+        const uint32_t code = codes[row * m + s];
+        const float v = cb[((size_t)s * k + code) * sd + t];
+        out[e] = __half_as_ushort(__float2half_rn(v));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_decode_f32(const float *__restrict__ cb, uint32_t m,
+                                                    uint32_t k, uint32_t sd,
+                                                    const uint8_t *__restrict__ codes, uint64_t n,
+                                                    float *__restrict__ out) {
+    const uint32_t d = m * sd;
+    const uint64_t total = n * d;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (uint64_t)gridDim.x * 256) {
+        const uint64_t row = e / d;
+        const uint32_t col = (uint32_t)(e - row * d);
+        const uint32_t s = col / sd, t = col - s * sd;
+        out[e] = cb[((size_t)s * k + codes[row * m + s]) * sd + t];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dequant_f16(const uint16_t *__restrict__ in, uint64_t count,
+                                                     float *__restrict__ out) {
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < count;
+         e += (uint64_t)gridDim.x * 256)
+        out[e] = __half2float(__ushort_as_half(in[e]));  // exact, src/pq.rs:208
+}
+
+uint32_t stream_grid(uint64_t total) {
+    uint64_t b = (total + 255) / 256;
+    uint64_t cap = (uint64_t)num_cus() * 8;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (uint32_t)b;
+}
+
+}  // namespace
+
+int launch_gather_f16(const CodebookView &cb, const uint8_t *codes, uint64_t n, uint16_t *f16_out,
+                      hipStream_t stream) {
+    if (n == 0) return VQHIP_OK;
+    hipLaunchKernelGGL(k_gather_f16, dim3(stream_grid(n * cb.m * cb.sd)), dim3(256), 0, stream,
+                       cb.cb, cb.m, cb.k, cb.sd, codes, n, f16_out);
+    VQ_LAUNCH_CHECK("k_gather_f16");
+    return VQHIP_OK;
+}
+
+int launch_decode_f32(const CodebookView &cb, const uint8_t *codes, uint64_t n, float *out,
+                      hipStream_t stream) {
+    if (n == 0) return VQHIP_OK;
+    hipLaunchKernelGGL(k_decode_f32, dim3(stream_grid(n * cb.m * cb.sd)), dim3(256), 0, stream,
+                       cb.cb, cb.m, cb.k, cb.sd, codes, n, out);
+    VQ_LAUNCH_CHECK("k_decode_f32");
+    return VQHIP_OK;
+}
+
+int launch_dequant_f16(const uint16_t *in, uint64_t count, float *out, hipStream_t stream) {
+    if (count == 0) return VQHIP_OK;
+    hipLaunchKernelGGL(k_dequant_f16, dim3(stream_grid(count)), dim3(256), 0, stream, in, count, out);
+    VQ_LAUNCH_CHECK("k_dequant_f16");
+    return VQHIP_OK;
+}
+
+int launch_synth_uniform(float *X, uint64_t n, uint32_t d, uint64_t seed, uint64_t row_offset,
+                         hipStream_t stream) {
+    if (n == 0) return VQHIP_OK;
+    hipLaunchKernelGGL(k_synth_uniform, dim3(stream_grid(n * d)), dim3(256), 0, stream, X, n, d,
+                       seed, row_offset);
+    VQ_LAUNCH_CHECK("k_synth_uniform");
+    return VQHIP_OK;
+}
+
+void synth_uniform_host(float *out, uint64_t n, uint32_t d, uint64_t seed, uint64_t row_offset) {
+    for (uint64_t r = 0; r < n; ++r)
+        for (uint32_t c = 0; c < d; ++c) out[r * d + c] = synth_value(seed, row_offset + r, c, d);
+}
+
+}  // namespace vqhip

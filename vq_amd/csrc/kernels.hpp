@@ -1,0 +1,99 @@
+// kernels.hpp -- launch wrappers of the gfx950 kernels (implemented in k_*.hip).
+// Every wrapper enqueues on `stream` and returns a vqhip status.
+#pragma once
+
+#include "common.hpp"
+
+namespace vqhip {
+
+// ---- prepared codebook ------------------------------------------------------------
+// Device-side view of m codebooks of k centroids of sub_dim floats, plus what the
+// assignment kernels derive from it once per codebook change.
+struct CodebookView {
+    uint32_t m = 0, k = 0, sd = 0;
+    const float *cb = nullptr;       // [m][k][sd]
+    // MFMA screen operands (null when the shape has no MFMA instantiation)
+    uint32_t nt = 0, ks = 0;         // 16-centroid tiles (padded, power of two), k-steps = sd/4
+    const float *prepA = nullptr;    // [m][nt][ks][64]   -2*c in MFMA A-operand lane order
+    const float *prepCn = nullptr;   // [m][nt*16]        |c|^2 (padding = +inf)
+    const float *meta = nullptr;     // [m][4]            {max|c|, margin coefficient, -, -}
+    const float *cnsqrt = nullptr;   // [m][k]            sqrt(sum c^2) (cosine's norm_b)
+};
+
+// MFMA screen availability for a shape
+bool screen_supported(uint32_t sd, uint32_t k);
+void screen_tiling(uint32_t sd, uint32_t k, uint32_t *nt, uint32_t *ks);
+
+int launch_prepare_codebook(const CodebookView &v, float *prepA, float *prepCn, float *meta,
+                            float *cnsqrt, hipStream_t stream);
+
+// ---- assignment -------------------------------------------------------------------
+struct AssignArgs {
+    const float *X = nullptr;  // [n][d]
+    uint64_t n = 0;
+    uint32_t d = 0;
+    int metric = VQHIP_SQUARED_EUCLIDEAN;
+    const uint32_t *sub_list = nullptr;  // device [n_sub] subspace ids to process
+    uint32_t n_sub = 0;
+    uint8_t *codes = nullptr;  // [n][m]
+    // per-subspace work lists of rows needing the exact re-check (screen -> exact)
+    uint32_t *wl_rows = nullptr;   // [m][wl_stride]
+    uint32_t *wl_count = nullptr;  // [m]
+    uint64_t wl_stride = 0;
+};
+
+// exact VALU scan of every centroid (reference op order); if use_worklist, only the rows
+// listed per subspace in wl_rows/wl_count are processed
+int launch_assign_exact(const CodebookView &cb, const AssignArgs &a, bool use_worklist,
+                        hipStream_t stream);
+// MFMA screen: writes a provisional code for every row and appends the rows whose winner is
+// not provably the reference's to the work lists (wl_count must be zeroed before)
+int launch_assign_screen(const CodebookView &cb, const AssignArgs &a, hipStream_t stream);
+
+// out[i] = metric(a[i], b[i]) in the reference's arithmetic (Distance::compute)
+int launch_distance_batch(int metric, const float *a, const float *b, uint64_t n, uint32_t d,
+                          float *out, hipStream_t stream);
+
+// ---- centroid update --------------------------------------------------------------
+struct UpdatePlan {
+    uint32_t m = 0, k = 0, sd = 0;
+    uint32_t subs_per_chunk = 0;  // subspaces whose accumulators share one workgroup's LDS
+    uint32_t n_sub_chunks = 0;
+    uint32_t n_row_chunks = 0;
+    size_t partial_floats = 0;    // per row chunk: m*k*sd sums
+    size_t partial_counts = 0;    // per row chunk: m*k counts
+};
+int plan_update(uint32_t m, uint32_t k, uint32_t sd, uint64_t n, UpdatePlan *plan);
+
+// per-workgroup LDS accumulation of sums/counts by code -> partial slabs
+int launch_accumulate(const UpdatePlan &p, const float *X, uint64_t n, uint32_t d,
+                      const uint8_t *codes, const uint8_t *active, float *partial_sums,
+                      uint32_t *partial_counts, hipStream_t stream);
+// fixed-order f64 combination of the partial slabs -> slab [m][k][sd+1] (last = count)
+int launch_reduce_partials(const UpdatePlan &p, const float *partial_sums,
+                           const uint32_t *partial_counts, const uint8_t *active, double *slab,
+                           hipStream_t stream);
+// exact (reference-order) cluster sums: stable bucket by code + sequential f32 chains
+int launch_exact_sums(uint32_t m, uint32_t k, uint32_t sd, const float *X, uint64_t n, uint32_t d,
+                      const uint8_t *codes, const uint8_t *active, void *workspace,
+                      size_t workspace_bytes, double *slab, hipStream_t stream);
+size_t exact_sums_workspace_bytes(uint32_t m, uint32_t k, uint64_t n);
+// means + 1e-6 convergence test; exact_div: slab sums are f32-exact values -> f32 divide
+int launch_finalize(uint32_t m, uint32_t k, uint32_t sd, const double *slab, const uint8_t *active,
+                    float *centroids, uint32_t *counts, uint32_t *changed, int exact_div,
+                    hipStream_t stream);
+// centroids[s][j] = X[rows[s*k+j]][s*sd ..]
+int launch_gather_rows(const float *X, uint32_t d, uint32_t m, uint32_t k, uint32_t sd,
+                       const uint64_t *rows, float *centroids, hipStream_t stream);
+
+// ---- outputs / misc ---------------------------------------------------------------
+int launch_gather_f16(const CodebookView &cb, const uint8_t *codes, uint64_t n, uint16_t *f16_out,
+                      hipStream_t stream);
+int launch_decode_f32(const CodebookView &cb, const uint8_t *codes, uint64_t n, float *out,
+                      hipStream_t stream);
+int launch_dequant_f16(const uint16_t *in, uint64_t count, float *out, hipStream_t stream);
+int launch_synth_uniform(float *X, uint64_t n, uint32_t d, uint64_t seed, uint64_t row_offset,
+                         hipStream_t stream);
+void synth_uniform_host(float *out, uint64_t n, uint32_t d, uint64_t seed, uint64_t row_offset);
+
+}  // namespace vqhip

@@ -1,0 +1,229 @@
+"""``ProductQuantizer`` -- host mirror of the reference's public PQ interface.
+
+Same constructor keywords, defaults, properties, ``repr`` and error text as
+pyvq.ProductQuantizer (reference pyvq/src/pq.rs:48-155) / ``ProductQuantizer::new``
+(src/pq.rs:83-141); the bodies run on the MI355X through libvqhip:
+
+* ``__init__``      -> vqhip_kmeans_* : Lloyd iterations for all m subspaces at once (the
+                       reference runs them one after the other, src/pq.rs:121); each subspace
+                       still converges on its own and draws its own init/reseed rows from an
+                       RNG seeded with ``seed + s`` (src/pq.rs:130).
+* ``quantize``      -> vqhip_pq_encode : first-minimum argmin per subspace, selected centroid
+                       as float16 (src/pq.rs:167-199).
+* new, batch-shaped: ``quantize_batch``, ``encode`` (the internal ``best_idx`` codes),
+                       ``decode``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .distance import Distance
+from .errors import DimensionMismatch, EmptyInput, InvalidParameter
+from .rng import HostRng
+
+
+def _as_training_matrix(training_data) -> np.ndarray:
+    """``&[&[f32]]`` -> one contiguous [n][d] f32 matrix with the reference's checks
+    (src/pq.rs:91-104, pyvq/src/pq.rs:59-62)."""
+    if isinstance(training_data, np.ndarray):
+        if training_data.ndim != 2:
+            raise ValueError("training_data must be a 2D array")
+        if training_data.shape[0] == 0:
+            raise ValueError("Training data cannot be empty")  # pyvq/src/pq.rs:61
+        return np.ascontiguousarray(training_data, dtype=np.float32)
+    rows = list(training_data)
+    if len(rows) == 0:
+        raise EmptyInput()
+    dim = len(rows[0])
+    for r in rows:
+        if len(r) != dim:
+            raise DimensionMismatch(dim, len(r))
+    return np.ascontiguousarray(np.asarray(rows, dtype=np.float32).reshape(len(rows), dim))
+
+
+def fit_codebooks(ds: "_lib.Dataset", m: int, k: int, max_iters: int, seed: int = 42, *,
+                  init_rows=None, reseed_rows=None, engine: int = _lib.ENGINE_AUTO,
+                  exact_update: bool = False, stats: dict | None = None) -> np.ndarray:
+    """Lloyd / LBG for all m subspaces of a resident dataset: the control flow of
+    ``lbg_quantize`` (src/core/vector.rs:396-460) with the device doing each iteration.
+
+    ``init_rows`` [m][k] and ``reseed_rows`` (m sequences consumed in order) replace the
+    package's own RNG draws -- this is how identical draws give reference-identical results.
+    """
+    n, d = ds.n, ds.d
+    # validation order and messages: src/pq.rs:106-117 then src/core/vector.rs:396-410
+    if m == 0:
+        raise InvalidParameter("m", "must be greater than 0")
+    if d < m:
+        raise InvalidParameter("m", f"must be at most the data dimension ({d})")
+    if d % m != 0:
+        raise InvalidParameter("m", f"dimension ({d}) must be divisible by m")
+    if k == 0:
+        raise InvalidParameter("k", "must be greater than 0")
+    if n < k:
+        raise InvalidParameter("k", f"not enough data points ({n}) for {k} clusters")
+    rngs = [HostRng(seed + s) for s in range(m)]  # seed + i, src/pq.rs:130
+    if init_rows is None:
+        init = np.array([rngs[s].choose_multiple(n, k) for s in range(m)], dtype=np.uint64)
+    else:
+        init = np.ascontiguousarray(init_rows, dtype=np.uint64).reshape(m, k)
+    reseed_iters = None if reseed_rows is None else [iter(list(r)) for r in reseed_rows]
+
+    km = _lib.KMeans(ds, m, k)
+    try:
+        km.set_engine(engine)
+        km.set_exact_update(exact_update)
+        km.init_from_rows(init)
+        active = np.ones(m, dtype=bool)
+        iters = np.zeros(m, dtype=np.int64)
+        n_reseeds = 0
+        for _ in range(max_iters):  # vector.rs:415
+            if not active.any():
+                break
+            counts, changed = km.step()
+            for s in np.nonzero(active)[0]:
+                iters[s] += 1
+                for j in np.nonzero(counts[s] == 0)[0]:  # vector.rs:448-452, ascending j
+                    if reseed_iters is not None:
+                        try:
+                            row = int(next(reseed_iters[s]))
+                        except StopIteration:
+                            raise InvalidParameter("reseed_rows", f"exhausted for subspace {s}")
+                    else:
+                        row = rngs[s].choose(n)
+                    km.patch_from_row(int(s), int(j), row)
+                    n_reseeds += 1
+                if not changed[s]:  # vector.rs:455-457
+                    active[s] = False
+            km.set_active(active)
+        if stats is not None:
+            stats["iters"] = iters
+            stats["reseeds"] = n_reseeds
+        return km.get_centroids()
+    finally:
+        km.close()
+
+
+class ProductQuantizer:
+    """Product quantizer: m subspaces, k centroids each.
+
+    Args (pyvq/src/pq.rs:36-49): training_data (n, dim) float32; num_subspaces (m);
+    num_centroids (k); max_iters=10; distance=None (-> Euclidean); seed=42.
+    """
+
+    def __init__(self, training_data, num_subspaces: int, num_centroids: int, max_iters: int = 10,
+                 distance: Distance | None = None, seed: int = 42, *, init_rows=None,
+                 reseed_rows=None, engine: int = _lib.ENGINE_AUTO, exact_update: bool = False):
+        X = _as_training_matrix(training_data)
+        n, dim = X.shape
+        m, k = int(num_subspaces), int(num_centroids)
+        if m == 0:
+            raise InvalidParameter("m", "must be greater than 0")
+        if dim < m:
+            raise InvalidParameter("m", f"must be at most the data dimension ({dim})")
+        if dim % m != 0:
+            raise InvalidParameter("m", f"dimension ({dim}) must be divisible by m")
+        if k == 0:
+            raise InvalidParameter("k", "must be greater than 0")
+        if n < k:
+            raise InvalidParameter("k", f"not enough data points ({n}) for {k} clusters")
+        self._distance = distance if distance is not None else Distance.euclidean()
+        self._m, self._k, self._dim, self._sub_dim = m, k, dim, dim // m
+        self.fit_stats: dict = {}
+        ds = _lib.Dataset.from_host(X)
+        try:
+            self._codebooks = fit_codebooks(ds, m, k, int(max_iters), int(seed), init_rows=init_rows,
+                                            reseed_rows=reseed_rows, engine=engine,
+                                            exact_update=exact_update, stats=self.fit_stats)
+        finally:
+            ds.close()
+        self._enc = _lib.PQEncoder(self._codebooks, self._distance.metric)
+        self._enc.set_engine(engine)
+
+    @classmethod
+    def from_codebooks(cls, codebooks, distance: Distance | None = None,
+                       engine: int = _lib.ENGINE_AUTO) -> "ProductQuantizer":
+        """Wrap existing codebooks [m][k][sub_dim] (no training)."""
+        self = cls.__new__(cls)
+        cb = np.ascontiguousarray(codebooks, dtype=np.float32)
+        if cb.ndim != 3:
+            raise ValueError("codebooks must have shape (m, k, sub_dim)")
+        self._m, self._k, self._sub_dim = (int(x) for x in cb.shape)
+        self._dim = self._m * self._sub_dim
+        self._distance = distance if distance is not None else Distance.euclidean()
+        self._codebooks = cb
+        self.fit_stats = {}
+        self._enc = _lib.PQEncoder(cb, self._distance.metric)
+        self._enc.set_engine(engine)
+        return self
+
+    # -- reference surface ----------------------------------------------------------------
+    def quantize(self, vector) -> np.ndarray:
+        """float32 (dim,) -> float16 (dim,): the selected centroids (src/pq.rs:167-199)"""
+        v = np.ascontiguousarray(vector, dtype=np.float32).ravel()
+        if v.size != self._dim:
+            raise DimensionMismatch(self._dim, v.size)
+        _, f16 = self._enc.encode(v[None, :], want_codes=False, want_f16=True)
+        return f16[0]
+
+    def dequantize(self, codes) -> np.ndarray:
+        """float16 (dim,) -> float32 (dim,) (src/pq.rs:201-209)"""
+        q = np.ascontiguousarray(codes, dtype=np.float16).ravel()
+        if q.size != self._dim:
+            raise DimensionMismatch(self._dim, q.size)
+        return _lib.dequantize_f16(q)
+
+    @property
+    def num_subspaces(self) -> int:
+        return self._m
+
+    @property
+    def sub_dim(self) -> int:
+        return self._sub_dim
+
+    @property
+    def dim(self) -> int:
+        return self._dim
+
+    def distance_metric(self) -> str:
+        return self._distance.name()
+
+    def __repr__(self) -> str:  # pyvq/src/pq.rs:147-154
+        return (f"ProductQuantizer(dim={self._dim}, num_subspaces={self._m}, "
+                f"sub_dim={self._sub_dim})")
+
+    # -- batch additions (ROADMAP.md:30 "batch quantization" is open upstream) --------------
+    @property
+    def num_centroids(self) -> int:
+        return self._k
+
+    @property
+    def codebooks(self) -> np.ndarray:
+        return self._codebooks
+
+    def _check_batch(self, X) -> np.ndarray:
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        if X.ndim != 2:
+            raise ValueError("expected a 2D array (n, dim)")
+        if X.shape[1] != self._dim:
+            raise DimensionMismatch(self._dim, X.shape[1])
+        return X
+
+    def quantize_batch(self, X) -> np.ndarray:
+        """(n, dim) float32 -> (n, dim) float16, row i == quantize(X[i])"""
+        X = self._check_batch(X)
+        if X.shape[0] == 0:
+            return np.empty((0, self._dim), np.float16)
+        return self._enc.encode(X, want_codes=False, want_f16=True)[1]
+
+    def encode(self, X) -> np.ndarray:
+        """(n, dim) float32 -> (n, m) uint8 codes: ``best_idx`` per subspace (src/pq.rs:183-191)"""
+        X = self._check_batch(X)
+        if X.shape[0] == 0:
+            return np.empty((0, self._m), np.uint8)
+        return self._enc.encode(X, want_codes=True, want_f16=False)[0]
+
+    def decode(self, codes) -> np.ndarray:
+        """(n, m) uint8 -> (n, dim) float32 centroids (un-rounded)"""
+        return self._enc.decode(codes)
