@@ -39,6 +39,7 @@ def _check_encode(oracle, X, cb, metric, engine):
     enc = _lib.PQEncoder(cb, metric)
     enc.set_engine(engine)
     codes, f16 = enc.encode(X)
+    _check_encode.last_stats = _lib.last_assign_stats()
     want_c, want_f = oracle.pq_encode(metric, X, cb, threads=0)
     np.testing.assert_array_equal(codes.astype(np.uint32), want_c)
     got_bits, want_bits = f16.view(np.uint16), want_f
@@ -140,7 +141,7 @@ def test_encode_adversarial_near_ties(oracle):
             X[i, s * sd:(s + 1) * sd] = cb[s, j] + (1e-3 * rng.standard_normal(sd)).astype(F)
     for metric in (O.SQUARED_EUCLIDEAN, O.EUCLIDEAN):
         _check_encode(oracle, X, cb, metric, _lib.ENGINE_AUTO)
-    rechecked, engine = _lib.last_assign_stats()
+    rechecked, engine = _check_encode.last_stats
     assert engine == _lib.ENGINE_MFMA and rechecked > 0
 
 
