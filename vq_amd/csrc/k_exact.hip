@@ -143,6 +143,104 @@ __global__ __launch_bounds__(kExactBlock) void k_assign_exact(
     }
 }
 
+// Exact distance of one row to one centroid, compile-time length (same op order as scan_one).
+template <int METRIC, int SD>
+__device__ __forceinline__ float exact_dist_fixed(const float (&x)[SD], const float *__restrict__ c,
+                                                  float na, float nb) {
+    if constexpr (METRIC == VQHIP_SQUARED_EUCLIDEAN || METRIC == VQHIP_EUCLIDEAN) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int t = 0; t < SD; ++t) {
+            float diff = x[t] - c[t];
+            float sq = diff * diff;
+            acc = acc + sq;
+        }
+        return (METRIC == VQHIP_EUCLIDEAN) ? sqrtf(acc) : acc;
+    } else if constexpr (METRIC == VQHIP_MANHATTAN) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int t = 0; t < SD; ++t) {
+            float diff = x[t] - c[t];
+            acc = acc + fabsf(diff);
+        }
+        return acc;
+    } else {
+        float dot = -0.0f;
+#pragma unroll
+        for (int t = 0; t < SD; ++t) {
+            float p = x[t] * c[t];
+            dot = dot + p;
+        }
+        const float EPS = 1e-10f;
+        if (na < EPS || nb < EPS) return 1.0f;
+        float denom = na * nb;
+        float q = dot / denom;
+        float v = 1.0f - q;
+        return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    }
+}
+
+// Re-check stage behind the MFMA screen: ONE WAVE per work-list entry.  Lane l evaluates
+// centroids l, l+64, l+128, ... exactly (ascending, strict '<'), then the 64 partial winners
+// are merged with "smaller distance, then smaller index" -- which equals the reference's
+// sequential first-minimum scan as long as centroid 0's distance is not NaN; if it is, no
+// later `dist < best` can ever be true and the answer is 0 (src/pq.rs:184-190).
+template <int METRIC, int SD>
+__global__ __launch_bounds__(256) void k_recheck_wave(
+    const float *__restrict__ X, uint32_t d, uint32_t m, uint32_t k,
+    const float *__restrict__ cb, const float *__restrict__ cnsqrt,
+    const uint32_t *__restrict__ sub_list, const uint32_t *__restrict__ wl_rows,
+    const uint32_t *__restrict__ wl_count, uint64_t wl_stride, uint8_t *__restrict__ codes) {
+    const uint32_t s = sub_list ? sub_list[blockIdx.y] : blockIdx.y;
+    const uint32_t count = wl_count[s];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * 4;
+    const float *cbs = cb + (size_t)s * k * SD;
+    const float *cnsq = cnsqrt ? cnsqrt + (size_t)s * k : nullptr;
+    const uint32_t NONE = 0xFFFFFFFFu;
+    for (uint32_t i = wave; i < count; i += n_waves) {
+        const uint64_t row = wl_rows[(size_t)s * wl_stride + i];
+        const float *xrow = X + row * d + (size_t)s * SD;
+        float x[SD];
+#pragma unroll
+        for (int t = 0; t < SD; ++t) x[t] = xrow[t];
+        float na = 0.0f;
+        if constexpr (METRIC == VQHIP_COSINE) {
+            float sa = -0.0f;
+#pragma unroll
+            for (int t = 0; t < SD; ++t) {
+                float p = x[t] * x[t];
+                sa = sa + p;
+            }
+            na = sqrtf(sa);
+        }
+        float bd = __builtin_inff();
+        uint32_t bj = NONE;
+        bool d0_nan = false;
+        for (uint32_t j = lane; j < k; j += 64) {
+            const float dist = exact_dist_fixed<METRIC, SD>(x, cbs + (size_t)j * SD, na,
+                                                            METRIC == VQHIP_COSINE ? cnsq[j] : 0.0f);
+            const bool isnan_d = dist != dist;
+            if (j == 0) d0_nan = isnan_d;
+            if (!isnan_d && (bj == NONE || dist < bd)) {
+                bd = dist;
+                bj = j;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_xor(bd, off);
+            const uint32_t oj = (uint32_t)__shfl_xor((int)bj, off);
+            const bool take = (oj != NONE) && (bj == NONE || od < bd || (od == bd && oj < bj));
+            bd = take ? od : bd;
+            bj = take ? oj : bj;
+        }
+        const bool blocked = __shfl((int)d0_nan, 0) != 0;
+        if (lane == 0) codes[row * m + s] = (uint8_t)((blocked || bj == NONE) ? 0u : bj);
+    }
+}
+
 // One workgroup per subspace: squared norms, the screen's A-operand image, flags.
 __global__ __launch_bounds__(256) void k_prepare_codebook(const float *__restrict__ cb, uint32_t m,
                                                           uint32_t k, uint32_t sd, uint32_t nt,
@@ -264,6 +362,24 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
                    hipStream_t stream) {
     const uint32_t *wlr = wl ? a.wl_rows : nullptr;
     const uint32_t *wlc = wl ? a.wl_count : nullptr;
+    if (wl) {
+        const dim3 wgrid((uint32_t)num_cus() * 4, a.n_sub);
+#define VQ_RECHECK_CASE(SDV)                                                                   \
+    case SDV:                                                                                  \
+        hipLaunchKernelGGL((k_recheck_wave<METRIC, SDV>), wgrid, dim3(256), 0, stream, a.X, a.d, \
+                           cb.m, cb.k, cb.cb, cb.cnsqrt, a.sub_list, wlr, wlc, a.wl_stride,     \
+                           a.codes);                                                           \
+        VQ_LAUNCH_CHECK("k_recheck_wave");                                                     \
+        return VQHIP_OK;
+        switch (cb.sd) {
+            VQ_RECHECK_CASE(4)
+            VQ_RECHECK_CASE(8)
+            VQ_RECHECK_CASE(16)
+            VQ_RECHECK_CASE(32)
+        default: break;
+        }
+#undef VQ_RECHECK_CASE
+    }
 #define VQ_EXACT_CASE(SDV)                                                                    \
     case SDV:                                                                                  \
         hipLaunchKernelGGL((k_assign_exact<METRIC, SDV, false>), grid, dim3(kExactBlock), 0,   \
