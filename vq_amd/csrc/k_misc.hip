@@ -29,21 +29,35 @@ __global__ __launch_bounds__(256) void k_synth_uniform(float *__restrict__ X, ui
 }
 
 // out[row][s*sd + t] = f16(codebook[s][codes[row][s]][t]), src/pq.rs:193-195.
-// One lane per pair of output elements (4 B stores, fully coalesced along the row).
+// VEC output elements per lane (8 -> one 16-byte store; the codebook rows come from L1/L2).
+template <int VEC>
 __global__ __launch_bounds__(256) void k_gather_f16(const float *__restrict__ cb, uint32_t m,
                                                     uint32_t k, uint32_t sd,
                                                     const uint8_t *__restrict__ codes, uint64_t n,
                                                     uint16_t *__restrict__ out) {
     const uint32_t d = m * sd;
-    const uint64_t total = n * d;
+    const uint32_t gpr = d / VEC;  // groups per row
+    const uint64_t total = n * gpr;
     for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < total;
          e += (uint64_t)gridDim.x * 256) {
-        const uint64_t row = e / d;
-        const uint32_t col = (uint32_t)(e - row * d);
+        const uint64_t row = e / gpr;
+        const uint32_t col = (uint32_t)(e - row * gpr) * VEC;
         const uint32_t s = col / sd, t = col - s * sd;
         const uint32_t code = codes[row * m + s];
-        const float v = cb[((size_t)s * k + code) * sd + t];
-        out[e] = __half_as_ushort(__float2half_rn(v));
+        const float *src = cb + ((size_t)s * k + code) * sd + t;
+        if constexpr (VEC == 8) {
+            const float4 a = *reinterpret_cast<const float4 *>(src);
+            const float4 b = *reinterpret_cast<const float4 *>(src + 4);
+            uint4 o;
+            o.x = (uint32_t)__half_as_ushort(__float2half_rn(a.x)) | ((uint32_t)__half_as_ushort(__float2half_rn(a.y)) << 16);
+            o.y = (uint32_t)__half_as_ushort(__float2half_rn(a.z)) | ((uint32_t)__half_as_ushort(__float2half_rn(a.w)) << 16);
+            o.z = (uint32_t)__half_as_ushort(__float2half_rn(b.x)) | ((uint32_t)__half_as_ushort(__float2half_rn(b.y)) << 16);
+            o.w = (uint32_t)__half_as_ushort(__float2half_rn(b.z)) | ((uint32_t)__half_as_ushort(__float2half_rn(b.w)) << 16);
+            *reinterpret_cast<uint4 *>(out + row * d + col) = o;
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) out[row * d + col + i] = __half_as_ushort(__float2half_rn(src[i]));
+        }
     }
 }
 
@@ -82,8 +96,14 @@ uint32_t stream_grid(uint64_t total) {
 int launch_gather_f16(const CodebookView &cb, const uint8_t *codes, uint64_t n, uint16_t *f16_out,
                       hipStream_t stream) {
     if (n == 0) return VQHIP_OK;
-    hipLaunchKernelGGL(k_gather_f16, dim3(stream_grid(n * cb.m * cb.sd)), dim3(256), 0, stream,
-                       cb.cb, cb.m, cb.k, cb.sd, codes, n, f16_out);
+    const bool vec8 = (cb.sd % 8 == 0) && ((reinterpret_cast<uintptr_t>(f16_out) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(cb.cb) & 15) == 0);
+    if (vec8)
+        hipLaunchKernelGGL(k_gather_f16<8>, dim3(stream_grid(n * cb.m * cb.sd / 8)), dim3(256), 0,
+                           stream, cb.cb, cb.m, cb.k, cb.sd, codes, n, f16_out);
+    else
+        hipLaunchKernelGGL(k_gather_f16<1>, dim3(stream_grid(n * cb.m * cb.sd)), dim3(256), 0, stream,
+                           cb.cb, cb.m, cb.k, cb.sd, codes, n, f16_out);
     VQ_LAUNCH_CHECK("k_gather_f16");
     return VQHIP_OK;
 }

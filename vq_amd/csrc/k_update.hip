@@ -28,6 +28,9 @@ namespace {
 constexpr uint32_t kAccBlock = 1024;
 constexpr uint32_t kLdsBudgetWords = 38912;  // 152 KiB of the CU's 160 KiB
 
+// LDS image of one workgroup: for each of its `spc` subspaces k rows of (sd + 1) floats (the
+// pad word spreads the k rows over all 32 LDS banks: with stride sd = 16 every row would start
+// on bank 0 or 16 and a wave's 64 atomics would pile onto 8 banks), then spc*k counts.
 template <int VEC>
 __global__ __launch_bounds__(kAccBlock) void k_accumulate(
     const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m, uint32_t k, uint32_t sd,
@@ -37,102 +40,226 @@ __global__ __launch_bounds__(kAccBlock) void k_accumulate(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t s0 = blockIdx.y * spc;
     const uint32_t ns = (m - s0 < spc) ? (m - s0) : spc;
-    const uint32_t W = ns * sd;            // floats of a row handled by this workgroup
-    float *sums = lds;                     // [ns][k][sd]
-    uint32_t *cnts = reinterpret_cast<uint32_t *>(lds + (size_t)spc * k * sd);  // [ns][k]
-    const uint32_t words = ns * k * sd;
-    for (uint32_t e = threadIdx.x; e < words; e += kAccBlock) sums[e] = 0.0f;
+    const uint32_t W = ns * sd;  // floats of a row handled by this workgroup
+    const uint32_t rstride = sd + 1;
+    float *sums = lds;                                                             // [ns][k][sd+1]
+    uint32_t *cnts = reinterpret_cast<uint32_t *>(lds + (size_t)spc * k * rstride);  // [ns][k]
+    for (uint32_t e = threadIdx.x; e < ns * k * rstride; e += kAccBlock) sums[e] = 0.0f;
     for (uint32_t e = threadIdx.x; e < ns * k; e += kAccBlock) cnts[e] = 0u;
     __syncthreads();
 
     const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_chunk;
     uint64_t r1 = r0 + rows_per_chunk;
     if (r1 > n) r1 = n;
-    if (r0 < r1) {
-        const uint32_t ipr = W / VEC;  // items per row
-        const uint32_t items = (uint32_t)(r1 - r0) * ipr;
-        for (uint32_t it = threadIdx.x; it < items; it += kAccBlock) {
-            const uint32_t rr = it / ipr, q = it - rr * ipr;
-            const uint32_t col = q * VEC;
-            const uint32_t ls = col / sd, t = col - ls * sd;
-            const uint32_t s = s0 + ls;
-            if (active && !active[s]) continue;
-            const uint64_t row = r0 + rr;
-            const uint32_t code = codes[row * m + s];
-            const float *px = X + row * d + (size_t)s0 * sd + col;
-            float *dst = sums + ((size_t)ls * k + code) * sd + t;
+    // a thread keeps ONE column group of the row slice for the whole chunk and walks down the
+    // rows: no per-item index arithmetic in the loop
+    const uint32_t ipr = W / VEC;                  // items per row
+    const uint32_t rpp = kAccBlock / ipr;          // rows per pass (>= 1: W <= 4096 words)
+    const uint32_t q = threadIdx.x % ipr, rr = threadIdx.x / ipr;
+    const uint32_t col = q * VEC, ls = col / sd, t = col - ls * sd;
+    const uint32_t s = s0 + ls;
+    const bool live = (rr < rpp) && (!active || active[s]);
+    if (live) {
+        float *base = sums + (size_t)ls * k * rstride + t;
+        uint32_t *cbase = cnts + ls * k;
+        const float *px = X + (size_t)s0 * sd + col;
+        const uint8_t *pc = codes + s;
+        uint64_t row = r0 + rr;
+        // two rows in flight per thread
+        for (; row + rpp < r1; row += 2 * (uint64_t)rpp) {
+            const uint64_t rowb = row + rpp;
+            const uint32_t ca = pc[row * m], cb2 = pc[rowb * m];
             if constexpr (VEC == 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(px);
-                atomicAdd(dst + 0, v.x);
-                atomicAdd(dst + 1, v.y);
-                atomicAdd(dst + 2, v.z);
-                atomicAdd(dst + 3, v.w);
+                const float4 va = *reinterpret_cast<const float4 *>(px + row * d);
+                const float4 vb = *reinterpret_cast<const float4 *>(px + rowb * d);
+                float *da = base + ca * rstride, *db = base + cb2 * rstride;
+                atomicAdd(da + 0, va.x);
+                atomicAdd(da + 1, va.y);
+                atomicAdd(da + 2, va.z);
+                atomicAdd(da + 3, va.w);
+                atomicAdd(db + 0, vb.x);
+                atomicAdd(db + 1, vb.y);
+                atomicAdd(db + 2, vb.z);
+                atomicAdd(db + 3, vb.w);
             } else {
-                atomicAdd(dst, px[0]);
+                atomicAdd(base + ca * rstride, px[row * d]);
+                atomicAdd(base + cb2 * rstride, px[rowb * d]);
             }
-            if (t == 0) atomicAdd(&cnts[ls * k + code], 1u);
+            if (t == 0) {
+                atomicAdd(cbase + ca, 1u);
+                atomicAdd(cbase + cb2, 1u);
+            }
+        }
+        for (; row < r1; row += rpp) {
+            const uint32_t ca = pc[row * m];
+            if constexpr (VEC == 4) {
+                const float4 va = *reinterpret_cast<const float4 *>(px + row * d);
+                float *da = base + ca * rstride;
+                atomicAdd(da + 0, va.x);
+                atomicAdd(da + 1, va.y);
+                atomicAdd(da + 2, va.z);
+                atomicAdd(da + 3, va.w);
+            } else {
+                atomicAdd(base + ca * rstride, px[row * d]);
+            }
+            if (t == 0) atomicAdd(cbase + ca, 1u);
         }
     }
     __syncthreads();
-    // partial slab of this row chunk: sums [m][k][sd], counts [m][k]
+    // partial slab of this row chunk: sums [m][k][sd] (un-padded), counts [m][k]
     float *ps = partial_sums + ((size_t)blockIdx.x * m + s0) * k * sd;
-    for (uint32_t e = threadIdx.x; e < words; e += kAccBlock) ps[e] = sums[e];
-    uint32_t *pc = partial_counts + ((size_t)blockIdx.x * m + s0) * k;
-    for (uint32_t e = threadIdx.x; e < ns * k; e += kAccBlock) pc[e] = cnts[e];
+    for (uint32_t e = threadIdx.x; e < ns * k * sd; e += kAccBlock) {
+        const uint32_t rowi = e / sd, tt = e - rowi * sd;
+        ps[e] = sums[(size_t)rowi * rstride + tt];
+    }
+    uint32_t *pcnt = partial_counts + ((size_t)blockIdx.x * m + s0) * k;
+    for (uint32_t e = threadIdx.x; e < ns * k; e += kAccBlock) pcnt[e] = cnts[e];
 }
 
+// Wave-owned accumulation (the fast path).  LDS float atomics run at ~1 lane per 3 cycles on
+// gfx950 (k_accumulate above is LDS-bound at 0.8 TB/s), so this kernel uses none: wave w of a
+// workgroup OWNS the accumulators of subspace s0+w ([k][sd] f32 + [k] counts in LDS) and is the
+// only writer.  One wave step covers RPS = 64/KS consecutive rows (KS = sd/4 lanes of 16 B per
+// row).  Rows of the same step that share a cluster would collide in a plain read-modify-write,
+// so each row gets rank = number of EARLIER rows of the step with the same code, and the step
+// runs rounds r = 0, 1, ...: rows of rank r add themselves with ds_read_b128 / add / ds_write_b128.
+// Every cluster therefore receives its rows in ascending row order: the chunk's partial sum is
+// the reference's sequential f32 sum over the chunk (src/core/vector.rs:376-380), bit for bit
+// and run to run.
+template <int KS>
+__global__ __launch_bounds__(512) void k_accumulate_owned(
+    const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m, uint32_t k,
+    uint32_t waves_per_block, uint64_t rows_per_chunk, const uint8_t *__restrict__ codes,
+    const uint8_t *__restrict__ active, float *__restrict__ partial_sums,
+    uint32_t *__restrict__ partial_counts) {
+    constexpr uint32_t SD = KS * 4;
+    constexpr uint32_t RPS = 64 / KS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t s = blockIdx.y * waves_per_block + wave;
+    if (s >= m) return;                       // no barrier below: waves are independent
+    if (active && !active[s]) return;
+    const uint32_t per_wave = (k * (SD + 1) + 3u) & ~3u;  // keeps every wave's base 16-byte aligned
+    float *sums = lds + (size_t)wave * per_wave;           // [k][SD] then [k] counts
+    uint32_t *cnts = reinterpret_cast<uint32_t *>(sums + (size_t)k * SD);
+    for (uint32_t e = lane; e < k * SD; e += 64) sums[e] = 0.0f;
+    for (uint32_t e = lane; e < k; e += 64) cnts[e] = 0u;
+
+    const uint32_t p = lane / KS, g = lane % KS;
+    const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_chunk;
+    uint64_t r1 = r0 + rows_per_chunk;
+    if (r1 > n) r1 = n;
+    const float *px = X + (size_t)s * SD + 4 * g;
+    auto load_x = [&](uint64_t row) {
+        return (row < r1) ? *reinterpret_cast<const float4 *>(px + row * d) : make_float4(0, 0, 0, 0);
+    };
+    auto load_c = [&](uint64_t row) { return (row < r1) ? (uint32_t)codes[row * m + s] : 0xFFFFFFFFu; };
+
+    float4 xn = load_x(r0 + p);
+    uint32_t cn_ = load_c(r0 + p);
+    for (uint64_t base = r0; base < r1; base += RPS) {
+        const float4 x = xn;
+        const uint32_t code = cn_;
+        xn = load_x(base + RPS + p);
+        cn_ = load_c(base + RPS + p);
+        const bool valid = code != 0xFFFFFFFFu;
+        // rank among the step's rows (row q's code sits in lane q*KS)
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t q = 0; q + 1 < RPS; ++q) {
+            const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)code, (int)(q * KS));
+            rank += (q < p && cq == code) ? 1u : 0u;
+        }
+        // xor-swizzled 16-byte slot so that the KS parts of different clusters spread over banks
+        float4 *slot = reinterpret_cast<float4 *>(sums + (size_t)code * SD) + (g ^ (code & (KS - 1)));
+        uint32_t pending = valid ? 1u : 0u;
+        for (uint32_t r = 0; __any(pending != 0); ++r) {
+            if (pending && rank == r) {
+                float4 a = *slot;
+                a.x = a.x + x.x;
+                a.y = a.y + x.y;
+                a.z = a.z + x.z;
+                a.w = a.w + x.w;
+                *slot = a;
+                if (g == 0) cnts[code] += 1u;
+                pending = 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // partial slab of this (row chunk, subspace): un-swizzle on the way out
+    float *ps = partial_sums + ((size_t)blockIdx.x * m + s) * k * SD;
+    for (uint32_t e = lane; e < k * KS; e += 64) {
+        const uint32_t j = e / KS, gg = e % KS;
+        const float4 v = reinterpret_cast<const float4 *>(sums + (size_t)j * SD)[gg ^ (j & (KS - 1))];
+        reinterpret_cast<float4 *>(ps + (size_t)j * SD)[gg] = v;
+    }
+    uint32_t *pcnt = partial_counts + ((size_t)blockIdx.x * m + s) * k;
+    for (uint32_t e = lane; e < k; e += 64) pcnt[e] = cnts[e];
+}
+
+// 32 slab elements x 8 chunk groups per workgroup; every element's chunks are summed in a
+// fixed order (group-strided, then groups ascending), so the result is reproducible.
+constexpr uint32_t kRedGroups = 8;
 __global__ __launch_bounds__(256) void k_reduce_partials(
     const float *__restrict__ partial_sums, const uint32_t *__restrict__ partial_counts,
     uint32_t n_row_chunks, uint32_t m, uint32_t k, uint32_t sd, const uint8_t *__restrict__ active,
     double *__restrict__ slab) {
+    __shared__ double part[kRedGroups][32];
     const uint32_t total = m * k * (sd + 1);
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    const uint32_t t = e % (sd + 1), sj = e / (sd + 1), s = sj / k;
+    const uint32_t el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const uint32_t e = blockIdx.x * 32 + el;
     double acc = 0.0;
-    if (!active || active[s]) {
-        if (t < sd) {
-            const size_t stride = (size_t)m * k * sd;
-            const float *p = partial_sums + (size_t)sj * sd + t;
-            for (uint32_t c = 0; c < n_row_chunks; ++c) acc += (double)p[c * stride];
-        } else {
-            const size_t stride = (size_t)m * k;
-            const uint32_t *p = partial_counts + sj;
-            unsigned long long cnt = 0;
-            for (uint32_t c = 0; c < n_row_chunks; ++c) cnt += p[c * stride];
-            acc = (double)cnt;
+    if (e < total) {
+        const uint32_t t = e % (sd + 1), sj = e / (sd + 1), s = sj / k;
+        if (!active || active[s]) {
+            if (t < sd) {
+                const size_t stride = (size_t)m * k * sd;
+                const float *p = partial_sums + (size_t)sj * sd + t;
+                for (uint32_t c = grp; c < n_row_chunks; c += kRedGroups) acc += (double)p[c * stride];
+            } else {
+                const size_t stride = (size_t)m * k;
+                const uint32_t *p = partial_counts + sj;
+                unsigned long long cnt = 0;
+                for (uint32_t c = grp; c < n_row_chunks; c += kRedGroups) cnt += p[c * stride];
+                acc = (double)cnt;
+            }
         }
     }
-    slab[e] = acc;
+    part[grp][el] = acc;
+    __syncthreads();
+    if (grp == 0 && e < total) {
+        double r = part[0][el];
+        for (uint32_t g = 1; g < kRedGroups; ++g) r += part[g][el];
+        slab[e] = r;
+    }
 }
 
+// one lane per centroid component
 __global__ __launch_bounds__(256) void k_finalize(uint32_t m, uint32_t k, uint32_t sd,
                                                   const double *__restrict__ slab,
                                                   const uint8_t *__restrict__ active,
                                                   float *__restrict__ centroids,
                                                   uint32_t *__restrict__ counts,
                                                   uint32_t *__restrict__ changed, int exact_div) {
-    const uint32_t sj = blockIdx.x * 256 + threadIdx.x;
-    if (sj >= m * k) return;
-    const uint32_t s = sj / k;
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * k * sd) return;
+    const uint32_t sj = e / sd, t = e - sj * sd, s = sj / k;
     const bool act = !active || active[s];
     const double *row = slab + (size_t)sj * (sd + 1);
     const double cnt = row[sd];
-    if (counts) counts[sj] = act ? (uint32_t)cnt : 0u;
+    if (t == 0 && counts) counts[sj] = act ? (uint32_t)cnt : 0u;
     if (!act || !(cnt > 0.0)) return;
-    float *c = centroids + (size_t)sj * sd;
-    bool moved = false;
     const float EPSILON = 1e-6f;  // vector.rs:439
-    const float nf = (float)cnt;   // indices.len() as f32, vector.rs:373
-    for (uint32_t t = 0; t < sd; ++t) {
-        float nv;
-        if (exact_div) nv = (float)row[t] / nf;  // row[t] holds an exact f32 value
-        else nv = (float)(row[t] / cnt);
-        const float diff = nv - c[t];
-        if (!(fabsf(diff) < EPSILON)) moved = true;
-        c[t] = nv;
-    }
-    if (moved) atomicOr(&changed[s], 1u);
+    float nv;
+    if (exact_div) nv = (float)row[t] / (float)cnt;  // row[t] holds an exact f32 value; vector.rs:373,382
+    else nv = (float)(row[t] / cnt);
+    const float diff = nv - centroids[e];
+    // every writer stores the same value: no atomic needed (34816 contended atomicOr on m words
+    // cost 370 us)
+    if (!(fabsf(diff) < EPSILON)) changed[s] = 1u;  // vector.rs:232-240, 444-446
+    centroids[e] = nv;
 }
 
 __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ X, uint32_t d,
@@ -151,13 +278,15 @@ int plan_update(uint32_t m, uint32_t k, uint32_t sd, uint64_t n, UpdatePlan *p) 
     p->m = m;
     p->k = k;
     p->sd = sd;
-    const uint64_t per_sub = (uint64_t)k * (sd + 1);
+    const uint64_t per_sub = (uint64_t)k * (sd + 2);  // padded sums + counts
     if (per_sub > kLdsBudgetWords)
         return fail(VQHIP_ERR_UNSUPPORTED,
-                    "k*(sub_dim+1)=%llu accumulators exceed one CU's LDS (%u words)",
+                    "k*(sub_dim+2)=%llu accumulator words exceed one CU's LDS (%u words)",
                     (unsigned long long)per_sub, kLdsBudgetWords);
     uint32_t spc = (uint32_t)(kLdsBudgetWords / per_sub);
     if (spc > m) spc = m;
+    if (sd > 1024) return fail(VQHIP_ERR_UNSUPPORTED, "sub_dim=%u > 1024 in the LDS update kernel", sd);
+    while (spc > 1 && (uint64_t)spc * sd > 1024) --spc;  // one workgroup pass covers >= 1 row
     p->subs_per_chunk = spc;
     p->n_sub_chunks = (m + spc - 1) / spc;
     uint32_t target = (uint32_t)num_cus();
@@ -168,20 +297,71 @@ int plan_update(uint32_t m, uint32_t k, uint32_t sd, uint64_t n, UpdatePlan *p) 
     if (max_rc < 1) max_rc = 1;
     if (rc > max_rc) rc = (uint32_t)max_rc;
     p->n_row_chunks = rc;
+    // wave-owned path: sub_dim a power of two in [4,256]; as many waves (= subspaces) per
+    // workgroup as fit the LDS budget, at most 8
+    p->owned_waves = 0;
+    if (sd >= 4 && sd <= 256 && (sd & (sd - 1)) == 0) {
+        uint64_t per_wave = ((uint64_t)k * (sd + 1) + 3) & ~3ull;
+        uint32_t w = (uint32_t)(kLdsBudgetWords / per_wave);
+        if (w > 8) w = 8;
+        if (w > m) w = m;
+        p->owned_waves = w;
+        if (w > 0) {
+            uint32_t sub_groups = (m + w - 1) / w;
+            uint32_t rc2 = (uint32_t)num_cus() / sub_groups;
+            if (rc2 < 1) rc2 = 1;
+            if (rc2 > max_rc) rc2 = (uint32_t)max_rc;
+            p->n_row_chunks = rc2;
+        }
+    }
     p->partial_floats = (size_t)m * k * sd;
     p->partial_counts = (size_t)m * k;
+    return VQHIP_OK;
+}
+
+template <int KS>
+static int launch_owned(const UpdatePlan &p, const float *X, uint64_t n, uint32_t d,
+                        const uint8_t *codes, const uint8_t *active, float *partial_sums,
+                        uint32_t *partial_counts, uint32_t wpb, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_accumulate_owned<KS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const uint64_t rows_per_chunk = (n + p.n_row_chunks - 1) / p.n_row_chunks;
+    const size_t lds_bytes = (size_t)wpb * ((p.k * (p.sd + 1) + 3u) & ~3u) * 4;
+    dim3 grid(p.n_row_chunks, (p.m + wpb - 1) / wpb);
+    hipLaunchKernelGGL(k_accumulate_owned<KS>, grid, dim3(wpb * 64), lds_bytes, stream, X, n, d, p.m,
+                       p.k, wpb, rows_per_chunk, codes, active, partial_sums, partial_counts);
+    VQ_LAUNCH_CHECK("k_accumulate_owned");
     return VQHIP_OK;
 }
 
 int launch_accumulate(const UpdatePlan &p, const float *X, uint64_t n, uint32_t d,
                       const uint8_t *codes, const uint8_t *active, float *partial_sums,
                       uint32_t *partial_counts, hipStream_t stream) {
+    const bool aligned = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    // wave-owned accumulators: sub_dim a power of two in [4, 256], one subspace's [k][sd+1]
+    // words per wave
+    if (aligned && p.owned_waves > 0) {
+        switch (p.sd) {
+        case 4: return launch_owned<1>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 8: return launch_owned<2>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 16: return launch_owned<4>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 32: return launch_owned<8>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 64: return launch_owned<16>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 128: return launch_owned<32>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 256: return launch_owned<64>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        default: break;
+        }
+    }
     const uint64_t rows_per_chunk = (n + p.n_row_chunks - 1) / p.n_row_chunks;
     if (rows_per_chunk * (uint64_t)p.subs_per_chunk * p.sd >= (1ull << 32))
         return fail(VQHIP_ERR_UNSUPPORTED, "row chunk too large for 32-bit item index");
-    const size_t lds_bytes = ((size_t)p.subs_per_chunk * p.k * (p.sd + 1)) * 4;
+    const size_t lds_bytes = ((size_t)p.subs_per_chunk * p.k * (p.sd + 2)) * 4;
     dim3 grid(p.n_row_chunks, p.n_sub_chunks);
-    const bool vec4 = (p.sd % 4 == 0) && (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const bool vec4 = (p.sd % 4 == 0) && aligned;
     if (vec4) {
         static bool attr_set4 = false;
         if (!attr_set4) {
@@ -211,7 +391,7 @@ int launch_reduce_partials(const UpdatePlan &p, const float *partial_sums,
                            const uint32_t *partial_counts, const uint8_t *active, double *slab,
                            hipStream_t stream) {
     const uint32_t total = p.m * p.k * (p.sd + 1);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((total + 255) / 256), dim3(256), 0, stream,
+    hipLaunchKernelGGL(k_reduce_partials, dim3((total + 31) / 32), dim3(256), 0, stream,
                        partial_sums, partial_counts, p.n_row_chunks, p.m, p.k, p.sd, active, slab);
     VQ_LAUNCH_CHECK("k_reduce_partials");
     return VQHIP_OK;
@@ -221,7 +401,7 @@ int launch_finalize(uint32_t m, uint32_t k, uint32_t sd, const double *slab, con
                     float *centroids, uint32_t *counts, uint32_t *changed, int exact_div,
                     hipStream_t stream) {
     VQ_HIP(hipMemsetAsync(changed, 0, (size_t)m * sizeof(uint32_t), stream));
-    hipLaunchKernelGGL(k_finalize, dim3((m * k + 255) / 256), dim3(256), 0, stream, m, k, sd, slab,
+    hipLaunchKernelGGL(k_finalize, dim3((m * k * sd + 255) / 256), dim3(256), 0, stream, m, k, sd, slab,
                        active, centroids, counts, changed, exact_div);
     VQ_LAUNCH_CHECK("k_finalize");
     return VQHIP_OK;

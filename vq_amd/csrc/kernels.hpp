@@ -60,6 +60,7 @@ struct UpdatePlan {
     uint32_t subs_per_chunk = 0;  // subspaces whose accumulators share one workgroup's LDS
     uint32_t n_sub_chunks = 0;
     uint32_t n_row_chunks = 0;
+    uint32_t owned_waves = 0;     // > 0: wave-owned (atomic-free) accumulate, subspaces per workgroup
     size_t partial_floats = 0;    // per row chunk: m*k*sd sums
     size_t partial_counts = 0;    // per row chunk: m*k counts
 };
