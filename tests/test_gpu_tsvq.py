@@ -1,0 +1,118 @@
+"""GPU parity of the TSVQ build and descent against the oracle: the tree (structure AND
+centroid bits) and the leaves must be identical -- the build keeps the reference's sequential
+f32 column sums, so even near-tied split dimensions resolve the same way."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from vq_amd import TSVQ, Distance, _lib
+from vq_amd.tsvq import build_tree
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _data(seed, n, d, kind):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return rng.random((n, d), dtype=F)
+    if kind == "normal":
+        return rng.standard_normal((n, d)).astype(F)
+    if kind == "lattice":
+        return rng.integers(0, 4, (n, d)).astype(F)
+    if kind == "structured":  # the reference's own test data, src/tsvq.rs:287-289
+        return np.array([[(i + j) % 50 for j in range(d)] for i in range(n)], F)
+    raise ValueError(kind)
+
+
+def _assert_same_tree(got, want):
+    cent, left, right = got
+    np.testing.assert_array_equal(left, want["left"])
+    np.testing.assert_array_equal(right, want["right"])
+    a, b = cent, want["centroids"]
+    assert a.shape == b.shape
+    same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), f"{(~same).sum()} centroid components differ"
+
+
+@pytest.mark.parametrize("kind", ["uniform", "normal", "lattice", "structured"])
+@pytest.mark.parametrize("shape", [(1000, 32, 5), (3001, 12, 8), (700, 128, 3), (50, 6, 4), (5000, 20, 0), (2, 4, 2), (1, 4, 3)])
+def test_build_bit_identical(oracle, kind, shape):
+    n, d, depth = shape
+    X = _data(21, n, d, kind)
+    ds = _lib.Dataset.from_host(X)
+    got = build_tree(ds, depth)
+    ds.close()
+    _assert_same_tree(got, oracle.tsvq_build(X, depth))
+
+
+def test_build_partial_nan_and_identical_rows(oracle):
+    X = _data(22, 500, 8, "normal")
+    X[17, 3] = np.nan
+    X[200:260] = X[200]
+    ds = _lib.Dataset.from_host(X)
+    got = build_tree(ds, 6)
+    ds.close()
+    _assert_same_tree(got, oracle.tsvq_build(X, 6))
+    # identical vectors: root is a leaf (src/tsvq.rs:273-284)
+    Y = np.tile(np.array([1, 2, 3, 4, 5], F), (10, 1))
+    t = TSVQ(Y, 3, Distance.squared_euclidean())
+    assert t.tree[0].shape[0] == 1
+    assert np.all(np.abs(t.quantize(Y[0]).astype(F) - Y[0]) < 1e-2)
+
+
+def test_build_all_nan_split_column_reports_reference_panic():
+    X = np.full((3, 1), np.nan, F)
+    with pytest.raises(_lib.FfiError) as e:
+        ds = _lib.Dataset.from_host(X)
+        build_tree(ds, 2)
+    assert "panics" in str(e.value)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2, 3])
+@pytest.mark.parametrize("kind", ["uniform", "normal", "lattice"])
+def test_descent_bit_identical(oracle, metric, kind):
+    X = _data(23, 4000, 24, kind)
+    Q = _data(24, 3000, 24, kind)
+    tree = oracle.tsvq_build(X, 7)
+    names = {0: "squared_euclidean", 1: "euclidean", 2: "manhattan", 3: "cosine"}
+    t = TSVQ.from_tree(tree["centroids"], tree["left"], tree["right"], Distance(names[metric]))
+    want_leaf, want_f16 = oracle.tsvq_encode(metric, Q, tree, threads=0)
+    np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)
+    np.testing.assert_array_equal(t.quantize_batch(Q).view(np.uint16), want_f16)
+    np.testing.assert_array_equal(t.quantize(Q[5]).view(np.uint16), want_f16[5])
+
+
+def test_golden_tsvq_fixture():
+    g = np.load(os.path.join(GOLD, "tsvq_depth5.npz"))
+    ds = _lib.Dataset.from_host(g["X"])
+    cent, left, right = build_tree(ds, 5)
+    ds.close()
+    assert cent.tobytes() == g["centroids"].tobytes()
+    np.testing.assert_array_equal(left, g["left"])
+    np.testing.assert_array_equal(right, g["right"])
+    for metric, mname, dn in ((0, "sqeuclid", "squared_euclidean"), (1, "euclid", "euclidean"),
+                              (2, "manhattan", "manhattan"), (3, "cosine", "cosine")):
+        t = TSVQ.from_tree(cent, left, right, Distance(dn))
+        np.testing.assert_array_equal(t.leaf_ids(g["Q"]), g[f"leaf_{mname}"])
+        np.testing.assert_array_equal(t.quantize_batch(g["Q"]).view(np.uint16), g[f"f16_{mname}"])
+
+
+def test_config4_fullsize_depth8(oracle):
+    """BASELINE config 4: TSVQ depth 8 on 1M x 128.  The oracle needs ~10 s for the build;
+    compare the whole tree, then the descent of a sample."""
+    n, d, depth = 1_000_000, 128, 8
+    ds = _lib.Dataset.synthetic(n, d, seed=66)
+    cent, left, right = build_tree(ds, depth)
+    X = ds.read()
+    ds.close()
+    want = oracle.tsvq_build(X, depth)
+    _assert_same_tree((cent, left, right), want)
+    assert cent.shape[0] == 511
+    t = TSVQ.from_tree(cent, left, right, Distance.euclidean())
+    Q = X[::997]
+    want_leaf, _ = oracle.tsvq_encode(O.EUCLIDEAN, Q, want, want_f16=False, threads=0)
+    np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)

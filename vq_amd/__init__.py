@@ -9,9 +9,10 @@ from .distance import Distance
 from .errors import (DimensionMismatch, EmptyInput, FfiError, InvalidData, InvalidParameter,
                      VqError)
 from .pq import ProductQuantizer, fit_codebooks
+from .tsvq import TSVQ
 
 __all__ = [
-    "Distance", "ProductQuantizer", "fit_codebooks", "VqError", "DimensionMismatch", "EmptyInput",
+    "Distance", "ProductQuantizer", "TSVQ", "fit_codebooks", "VqError", "DimensionMismatch", "EmptyInput",
     "InvalidParameter", "InvalidData", "FfiError", "get_simd_backend",
 ]
 

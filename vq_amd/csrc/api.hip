@@ -852,21 +852,99 @@ int vqhip_distance_batch(int metric, const float *a, const float *b, uint64_t n,
 }
 
 // ---------------------------------------------------------------------------- TSVQ ----
-int vqhip_tsvq_build(const vqhip_dataset *, uint32_t, uint32_t, float *, int32_t *, int32_t *, int32_t *) {
-    return fail(VQHIP_ERR_UNSUPPORTED, "TSVQ build kernels are not part of this build yet");
+int vqhip_tsvq_build(const vqhip_dataset *ds, uint32_t max_depth, uint32_t cap, float *centroids, int32_t *left,
+                     int32_t *right, int32_t *n_nodes) {
+    VQ_API_BEGIN
+    if (!ds || !centroids || !left || !right || !n_nodes) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    return tsvq_build_device(ds->X, ds->n, ds->d, max_depth, cap, centroids, left, right, n_nodes, s);
+    VQ_API_END
 }
-int vqhip_tsvq_create(const float *, const int32_t *, const int32_t *, uint32_t, uint32_t, int, vqhip_tsvq **) {
-    return fail(VQHIP_ERR_UNSUPPORTED, "TSVQ encode kernels are not part of this build yet");
+
+int vqhip_tsvq_create(const float *centroids, const int32_t *left, const int32_t *right, uint32_t n_nodes, uint32_t d,
+                      int metric, vqhip_tsvq **out) {
+    VQ_API_BEGIN
+    if (!out) return fail(VQHIP_ERR_NULL_PTR, "out is NULL");
+    *out = nullptr;
+    if (!centroids || !left || !right) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (n_nodes == 0 || d == 0) return fail(VQHIP_ERR_INVALID_INPUT, "empty tree");
+    if (metric < VQHIP_SQUARED_EUCLIDEAN || metric > VQHIP_COSINE) return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", metric);
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        // children must point forward (pre-order) so that the descent terminates
+        if ((left[i] >= 0 && (left[i] <= (int32_t)i || left[i] >= (int32_t)n_nodes)) ||
+            (right[i] >= 0 && (right[i] <= (int32_t)i || right[i] >= (int32_t)n_nodes)))
+            return fail(VQHIP_ERR_INVALID_INPUT, "node %u has an out-of-order child index", i);
+    }
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    std::unique_ptr<vqhip_tsvq> t(new vqhip_tsvq());
+    t->n_nodes = n_nodes;
+    t->d = d;
+    t->metric = metric;
+    VQ_TRY(t->centroids.alloc((size_t)n_nodes * d * 4));
+    VQ_TRY(t->left.alloc((size_t)n_nodes * 4));
+    VQ_TRY(t->right.alloc((size_t)n_nodes * 4));
+    VQ_HIP(hipMemcpyAsync(t->centroids.p, centroids, (size_t)n_nodes * d * 4, hipMemcpyHostToDevice, s));
+    VQ_HIP(hipMemcpyAsync(t->left.p, left, (size_t)n_nodes * 4, hipMemcpyHostToDevice, s));
+    VQ_HIP(hipMemcpyAsync(t->right.p, right, (size_t)n_nodes * 4, hipMemcpyHostToDevice, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    *out = t.release();
+    return VQHIP_OK;
+    VQ_API_END
 }
+
 int vqhip_tsvq_destroy(vqhip_tsvq *t) {
     delete t;
     return VQHIP_OK;
 }
-int vqhip_tsvq_encode(vqhip_tsvq *, const float *, uint64_t, int32_t *, uint16_t *) {
-    return fail(VQHIP_ERR_UNSUPPORTED, "TSVQ encode kernels are not part of this build yet");
+
+int vqhip_tsvq_encode_device(vqhip_tsvq *t, const void *dev_rows, uint64_t n, void *dev_leaf, void *dev_f16_out) {
+    VQ_API_BEGIN
+    if (!t) return fail(VQHIP_ERR_NULL_PTR, "tree is NULL");
+    if (n == 0) return VQHIP_OK;
+    if (!dev_rows) return fail(VQHIP_ERR_NULL_PTR, "dev_rows is NULL");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    int32_t *leaf = reinterpret_cast<int32_t *>(dev_leaf);
+    if (!leaf) {
+        VQ_TRY(t->leafbuf.ensure((size_t)n * 4));
+        leaf = t->leafbuf.as<int32_t>();
+    }
+    return launch_tsvq_encode(reinterpret_cast<const float *>(dev_rows), n, t->d, t->centroids.as<float>(),
+                              t->left.as<int32_t>(), t->right.as<int32_t>(), t->metric, leaf,
+                              reinterpret_cast<uint16_t *>(dev_f16_out), s);
+    VQ_API_END
 }
-int vqhip_tsvq_encode_device(vqhip_tsvq *, const void *, uint64_t, void *, void *) {
-    return fail(VQHIP_ERR_UNSUPPORTED, "TSVQ encode kernels are not part of this build yet");
+
+int vqhip_tsvq_encode(vqhip_tsvq *t, const float *rows, uint64_t n, int32_t *leaf, uint16_t *f16_out) {
+    VQ_API_BEGIN
+    if (!t) return fail(VQHIP_ERR_NULL_PTR, "tree is NULL");
+    if (n == 0) return VQHIP_OK;
+    if (!rows) return fail(VQHIP_ERR_NULL_PTR, "rows is NULL");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    const uint32_t d = t->d;
+    uint64_t chunk = std::max<uint64_t>(1, (1ull << 30) / ((uint64_t)d * 4));
+    if (chunk > n) chunk = n;
+    VQ_TRY(t->xbuf.ensure((size_t)chunk * d * 4));
+    DevBuf leafdev;
+    VQ_TRY(leafdev.alloc((size_t)chunk * 4));
+    if (f16_out) VQ_TRY(t->f16buf.ensure((size_t)chunk * d * 2));
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk) {
+        const uint64_t nr = std::min(chunk, n - r0);
+        VQ_HIP(hipMemcpyAsync(t->xbuf.p, rows + r0 * d, (size_t)nr * d * 4, hipMemcpyHostToDevice, s));
+        VQ_TRY(vqhip_tsvq_encode_device(t, t->xbuf.p, nr, leafdev.p, f16_out ? t->f16buf.p : nullptr));
+        if (leaf) VQ_HIP(hipMemcpyAsync(leaf + r0, leafdev.p, (size_t)nr * 4, hipMemcpyDeviceToHost, s));
+        if (f16_out) VQ_HIP(hipMemcpyAsync(f16_out + r0 * d, t->f16buf.p, (size_t)nr * d * 2, hipMemcpyDeviceToHost, s));
+        VQ_HIP(hipStreamSynchronize(s));
+    }
+    return VQHIP_OK;
+    VQ_API_END
 }
 
 }  // extern "C"

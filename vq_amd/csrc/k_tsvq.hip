@@ -1,3 +1,666 @@
-// k_tsvq.hip -- TSVQ kernels (placeholder translation unit; filled in by a later milestone).
+// k_tsvq.hip -- TSVQ tree build and tree descent on gfx950.
+//
+// Build replaces TSVQNode::build (src/tsvq.rs:31-115): per node the MEAN of its rows, the
+// per-dimension un-normalised variance, the split on the dimension of maximum variance at the
+// exact median, and a stable partition (`x <= median` left, NaN right).  The reference's
+// arithmetic is sequential f32 in row order (src/core/vector.rs:332-348, src/tsvq.rs:46-57),
+// and the split dimension is an argmax over sums that differ by O(1/sqrt(n)) on isotropic
+// data, so a different summation order would pick other dimensions and change the whole
+// tree.  The column sums here therefore keep the reference order exactly: one lane owns one
+// dimension of one node and adds its rows in ascending order (the stable partition keeps a
+// node's rows in their original relative order).  Throughput comes from the level: all nodes
+// of a level and all dimension groups run concurrently, rows are staged through LDS by 15
+// loader waves per workgroup so that the single consumer wave's dependent add chain (the
+// true critical path, ~5 cycles per row) never waits for HBM.
+//
+// Median: exact order statistics by 4-round radix select on order-preserving keys
+// (f32::total_cmp order, src/tsvq.rs:75), two ranks at once for even counts (tsvq.rs:77-81).
+// Partition: flags + exclusive scan + scatter (stable), src/tsvq.rs:84-85.
+//
+// Encode replaces find_leaf (src/tsvq.rs:117-132): one lane per row walks the tree, the two
+// child distances in the reference's sequential arithmetic, left on `<=`.
+//
+// Rooflines: build = dependent-add latency at the top levels (N adds per dimension), HBM at
+// the deep ones (2 passes x 4*N*D bytes per level); encode = HBM, 4*D in + 2*D out per row.
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
+#include <vector>
+
 #include "kernels.hpp"
-namespace vqhip {}
+
+#pragma clang fp contract(off)
+
+namespace vqhip {
+namespace {
+
+constexpr uint32_t kInactive = 0xFFFFFFFFu;
+constexpr uint32_t DG = 16;          // dimensions per workgroup in the column-sum kernel
+constexpr uint32_t kTileRows = 480;  // rows per LDS tile: 15 loader waves x 32 rows
+
+struct NodeArrays {
+    uint32_t *seg_start, *seg_len, *split_dim, *nv, *nleft;
+    float *median;
+    uint32_t *sel_prefix, *sel_rank;  // [cap][2]
+    uint32_t *child_local;            // [cap][2] level-local index of children in the NEXT level
+    float *centroid;                  // [cap][d]
+    float *var;                       // [cap][d]
+};
+
+// order-preserving map f32 -> u32 (total order: -NaN < -inf < ... < -0 < +0 < ... < +inf < +NaN)
+__device__ __forceinline__ uint32_t order_key(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(b);
+}
+
+// MODE 0: out = (sequential sum of x) / n  -> centroid;  MODE 1: out = sequential sum (x-mu)^2
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_seg_colsum(const float *__restrict__ X, uint32_t d,
+                                                     const uint32_t *__restrict__ perm,
+                                                     const uint32_t *__restrict__ lvl_node,
+                                                     NodeArrays na) {
+    __shared__ float tile[2][kTileRows][DG];
+    const uint32_t node = lvl_node[blockIdx.x];
+    const uint32_t a = na.seg_start[node], n = na.seg_len[node];
+    const uint32_t t0 = blockIdx.y * DG;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n_tiles = (n + kTileRows - 1) / kTileRows;
+    float acc = (MODE == 0) ? 0.0f : -0.0f;
+    float mu = 0.0f;
+    if (MODE == 1 && wave == 0 && lane < DG && t0 + lane < d) mu = na.centroid[(size_t)node * d + t0 + lane];
+
+    auto stage = [&](uint32_t tile_idx, uint32_t buf) {
+        // loader waves 1..15: lane -> (row within the wave's 32-row slab, 8-byte half-quarter)
+        if (wave == 0) return;
+        const uint32_t base = tile_idx * kTileRows + (wave - 1) * 32;
+#pragma unroll
+        for (uint32_t rep = 0; rep < 2; ++rep) {
+            const uint32_t r = (lane >> 2) + rep * 16, q = lane & 3;  // 16 rows x 4 float4 per rep
+            const uint32_t idx = base + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < n) {
+                const float *src = X + (size_t)perm[a + idx] * d + t0 + 4 * q;
+                if (t0 + 4 * q + 3 < d && (d % 4 == 0)) {
+                    v = *reinterpret_cast<const float4 *>(src);
+                } else {
+                    if (t0 + 4 * q + 0 < d) v.x = src[0];
+                    if (t0 + 4 * q + 1 < d) v.y = src[1];
+                    if (t0 + 4 * q + 2 < d) v.z = src[2];
+                    if (t0 + 4 * q + 3 < d) v.w = src[3];
+                }
+            }
+            *reinterpret_cast<float4 *>(&tile[buf][(wave - 1) * 32 + r][4 * q]) = v;
+        }
+    };
+
+    if (n_tiles > 0) stage(0, 0);
+    __syncthreads();
+    for (uint32_t ti = 0; ti < n_tiles; ++ti) {
+        const uint32_t buf = ti & 1;
+        if (ti + 1 < n_tiles) stage(ti + 1, buf ^ 1);
+        if (wave == 0 && lane < DG) {
+            const uint32_t rows = min(kTileRows, n - ti * kTileRows);
+            for (uint32_t r = 0; r < rows; ++r) {
+                const float x = tile[buf][r][lane];
+                if (MODE == 0) {
+                    acc = acc + x;
+                } else {
+                    const float diff = x - mu;
+                    const float sq = diff * diff;
+                    acc = acc + sq;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0 && lane < DG && t0 + lane < d) {
+        if (MODE == 0) na.centroid[(size_t)node * d + t0 + lane] = acc / (float)n;  // T::from_usize(n)
+        else na.var[(size_t)node * d + t0 + lane] = acc;
+    }
+}
+
+// split dimension: NaN filtered, LAST maximum wins (Iterator::max_by), none -> 0 (tsvq.rs:59-66)
+__global__ void k_pick_split(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, uint32_t d, NodeArrays na) {
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_lvl) return;
+    const uint32_t node = lvl_node[li];
+    const float *v = na.var + (size_t)node * d;
+    uint32_t best_t = 0;
+    bool have = false;
+    float best = 0.0f;
+    for (uint32_t t = 0; t < d; ++t) {
+        const float x = v[t];
+        if (x != x) continue;
+        if (!have || !(x < best)) {
+            best = x;
+            best_t = t;
+            have = true;
+        }
+    }
+    na.split_dim[node] = best_t;
+    na.nv[node] = 0;
+    na.sel_prefix[2 * node] = na.sel_prefix[2 * node + 1] = 0;
+}
+
+// vals[i] = X[perm[i]][split_dim(node of i)]; counts the non-NaN values per node
+__global__ __launch_bounds__(256) void k_gather_vals(const float *__restrict__ X, uint32_t d, uint32_t n,
+                                                     const uint32_t *__restrict__ perm,
+                                                     const uint32_t *__restrict__ node_of,
+                                                     const uint32_t *__restrict__ lvl_node, NodeArrays na,
+                                                     float *__restrict__ vals) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t li = node_of[i];
+    if (li == kInactive) return;
+    const uint32_t node = lvl_node[li];
+    const float x = X[(size_t)perm[i] * d + na.split_dim[node]];
+    vals[i] = x;
+    if (x == x) atomicAdd(&na.nv[node], 1u);
+}
+
+// ranks of the two order statistics the median needs (tsvq.rs:77-81)
+__global__ void k_select_init(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, NodeArrays na) {
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_lvl) return;
+    const uint32_t node = lvl_node[li];
+    const uint32_t nv = na.nv[node];
+    if (nv == 0) {
+        na.sel_rank[2 * node] = na.sel_rank[2 * node + 1] = 0;
+        return;
+    }
+    const uint32_t h = nv / 2;
+    na.sel_rank[2 * node + 0] = (nv % 2 == 0) ? h - 1 : h;
+    na.sel_rank[2 * node + 1] = h;
+}
+
+// one radix-select round: histogram of the byte at `shift` among keys matching the prefix
+__global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ vals, uint32_t n,
+                                                     const uint32_t *__restrict__ node_of,
+                                                     const uint32_t *__restrict__ lvl_node, NodeArrays na,
+                                                     uint32_t shift, uint32_t *__restrict__ hist) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t li = node_of[i];
+    if (li == kInactive) return;
+    const float x = vals[i];
+    if (x != x) return;
+    const uint32_t node = lvl_node[li];
+    const uint32_t key = order_key(x);
+    const uint32_t hi_mask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+#pragma unroll
+    for (uint32_t sel = 0; sel < 2; ++sel)
+        if ((key & hi_mask) == na.sel_prefix[2 * node + sel])
+            atomicAdd(&hist[((size_t)li * 2 + sel) * 256 + ((key >> shift) & 255u)], 1u);
+}
+
+__global__ void k_select_pick(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, NodeArrays na,
+                              uint32_t shift, uint32_t *__restrict__ hist) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_lvl * 2) return;
+    const uint32_t li = idx >> 1, sel = idx & 1;
+    const uint32_t node = lvl_node[li];
+    uint32_t *h = hist + ((size_t)li * 2 + sel) * 256;
+    uint32_t rank = na.sel_rank[2 * node + sel];
+    uint32_t b = 0;
+    if (na.nv[node] != 0) {
+        for (; b < 255; ++b) {
+            const uint32_t c = h[b];
+            if (rank < c) break;
+            rank -= c;
+        }
+    }
+    na.sel_rank[2 * node + sel] = rank;
+    na.sel_prefix[2 * node + sel] |= b << shift;
+    for (uint32_t q = 0; q < 256; ++q) h[q] = 0;  // ready for the next round
+}
+
+__global__ void k_median(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, NodeArrays na) {
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_lvl) return;
+    const uint32_t node = lvl_node[li];
+    const uint32_t nv = na.nv[node];
+    if (nv == 0) {
+        na.median[node] = 0.0f;
+        return;
+    }
+    const float lo = key_to_float(na.sel_prefix[2 * node + 0]);
+    const float hi = key_to_float(na.sel_prefix[2 * node + 1]);
+    if (nv % 2 == 0) {
+        const float s2 = lo + hi;
+        na.median[node] = s2 / 2.0f;
+    } else {
+        na.median[node] = hi;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_flags(const float *__restrict__ vals, uint32_t n,
+                                               const uint32_t *__restrict__ node_of,
+                                               const uint32_t *__restrict__ lvl_node, NodeArrays na,
+                                               uint32_t *__restrict__ flags) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t li = node_of[i];
+    uint32_t f = 0;
+    if (li != kInactive) f = (vals[i] <= na.median[lvl_node[li]]) ? 1u : 0u;  // NaN -> right
+    flags[i] = f;
+}
+
+// exclusive scan of u32 flags: 1024 elements per block
+__global__ __launch_bounds__(256) void k_scan_blocks(const uint32_t *__restrict__ in, uint32_t n,
+                                                     uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t sh[256];
+    const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v[q] = (base + q < n) ? in[base + q] : 0u;
+        s += v[q];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        uint32_t t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t excl = sh[threadIdx.x] - s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (base + q < n) out[base + q] = excl;
+        excl += v[q];
+    }
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = sh[255];
+}
+__global__ __launch_bounds__(1024) void k_scan_sums(uint32_t *__restrict__ block_sums, uint32_t nb) {
+    // single workgroup; nb <= a few thousand: serial chunks of 1024
+    __shared__ uint32_t sh[1024];
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < nb; c0 += 1024) {
+        const uint32_t i = c0 + threadIdx.x;
+        const uint32_t v = (i < nb) ? block_sums[i] : 0u;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            uint32_t t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nb) block_sums[i] = carry + sh[threadIdx.x] - v;
+        const uint32_t tot = sh[1023];
+        __syncthreads();
+        carry += tot;
+    }
+}
+__global__ __launch_bounds__(256) void k_scan_apply(uint32_t *__restrict__ out, uint32_t n,
+                                                    const uint32_t *__restrict__ block_sums) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] += block_sums[i >> 10];
+}
+
+// lefts per node = P[a+len] - P[a] (P exclusive; the last element adds its own flag)
+__global__ void k_nleft(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, NodeArrays na,
+                        const uint32_t *__restrict__ P, const uint32_t *__restrict__ flags) {
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_lvl) return;
+    const uint32_t node = lvl_node[li];
+    const uint32_t a = na.seg_start[node], len = na.seg_len[node];
+    na.nleft[node] = (P[a + len - 1] + flags[a + len - 1]) - P[a];
+}
+
+// stable partition of every split node's segment (tsvq.rs:84-85)
+__global__ __launch_bounds__(256) void k_scatter(uint32_t n, const uint32_t *__restrict__ perm,
+                                                 const uint32_t *__restrict__ node_of,
+                                                 const uint32_t *__restrict__ lvl_node, NodeArrays na,
+                                                 const uint32_t *__restrict__ P,
+                                                 const uint32_t *__restrict__ flags,
+                                                 uint32_t *__restrict__ perm2, uint32_t *__restrict__ node_of2) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t li = node_of[i];
+    if (li == kInactive) {
+        perm2[i] = perm[i];
+        node_of2[i] = kInactive;
+        return;
+    }
+    const uint32_t node = lvl_node[li];
+    const uint32_t a = na.seg_start[node];
+    const uint32_t lr = P[i] - P[a];
+    const uint32_t f = flags[i];
+    const uint32_t pos = f ? (a + lr) : (a + na.nleft[node] + (i - a - lr));
+    perm2[pos] = perm[i];
+    node_of2[pos] = na.child_local[2 * node + (f ? 0 : 1)];
+}
+
+__global__ __launch_bounds__(256) void k_iota(uint32_t *__restrict__ perm, uint32_t *__restrict__ node_of, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        perm[i] = i;
+        node_of[i] = 0;
+    }
+}
+
+// ---- encode ------------------------------------------------------------------------------
+__device__ float dist_rt(int metric, const float *__restrict__ a, const float *__restrict__ b, uint32_t n) {
+    if (metric == VQHIP_SQUARED_EUCLIDEAN || metric == VQHIP_EUCLIDEAN) {
+        float acc = -0.0f;
+        for (uint32_t t = 0; t < n; ++t) {
+            const float diff = a[t] - b[t];
+            const float sq = diff * diff;
+            acc = acc + sq;
+        }
+        return metric == VQHIP_EUCLIDEAN ? sqrtf(acc) : acc;
+    }
+    if (metric == VQHIP_MANHATTAN) {
+        float acc = -0.0f;
+        for (uint32_t t = 0; t < n; ++t) {
+            const float diff = a[t] - b[t];
+            acc = acc + fabsf(diff);
+        }
+        return acc;
+    }
+    float dot = -0.0f, sa = -0.0f, sb = -0.0f;
+    for (uint32_t t = 0; t < n; ++t) {
+        const float p = a[t] * b[t];
+        dot = dot + p;
+    }
+    for (uint32_t t = 0; t < n; ++t) {
+        const float p = a[t] * a[t];
+        sa = sa + p;
+    }
+    for (uint32_t t = 0; t < n; ++t) {
+        const float p = b[t] * b[t];
+        sb = sb + p;
+    }
+    const float na = sqrtf(sa), nb = sqrtf(sb);
+    if (na < 1e-10f || nb < 1e-10f) return 1.0f;
+    const float denom = na * nb;
+    const float q = dot / denom;
+    const float v = 1.0f - q;
+    return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+}
+
+__global__ __launch_bounds__(256) void k_tsvq_descend(const float *__restrict__ X, uint64_t n, uint32_t d,
+                                                      const float *__restrict__ centroids,
+                                                      const int32_t *__restrict__ left,
+                                                      const int32_t *__restrict__ right, int metric,
+                                                      int32_t *__restrict__ leaf_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *x = X + i * d;
+    int32_t node = 0;
+    for (;;) {
+        const int32_t l = left[node], r = right[node];
+        if (l >= 0 && r >= 0) {
+            const float dl = dist_rt(metric, x, centroids + (size_t)l * d, d);
+            const float dr = dist_rt(metric, x, centroids + (size_t)r * d, d);
+            node = (dl <= dr) ? l : r;  // left on ties, tsvq.rs:122
+        } else if (l >= 0) {
+            node = l;
+        } else if (r >= 0) {
+            node = r;
+        } else {
+            break;
+        }
+    }
+    leaf_out[i] = node;
+}
+
+__global__ __launch_bounds__(256) void k_tsvq_gather_f16(const float *__restrict__ centroids, uint32_t d,
+                                                         const int32_t *__restrict__ leaf, uint64_t n,
+                                                         uint16_t *__restrict__ out) {
+    const uint64_t total = n * d;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (uint64_t)gridDim.x * 256) {
+        const uint64_t row = e / d;
+        const uint32_t t = (uint32_t)(e - row * d);
+        out[e] = __half_as_ushort(__float2half_rn(centroids[(size_t)leaf[row] * d + t]));
+    }
+}
+
+}  // namespace
+
+// ---- host driver of the build ------------------------------------------------------------
+int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_depth, uint32_t cap,
+                      float *centroids_out, int32_t *left_out, int32_t *right_out, int32_t *n_nodes_out,
+                      hipStream_t stream) {
+    if (n64 >= (1ull << 31)) return fail(VQHIP_ERR_UNSUPPORTED, "TSVQ build supports < 2^31 rows per device");
+    const uint32_t n = (uint32_t)n64;
+    // BFS node storage
+    struct HostNode {
+        uint32_t start, len, depth_left;
+        int32_t left = -1, right = -1;
+    };
+    std::vector<HostNode> nodes;
+    nodes.push_back({0, n, max_depth, -1, -1});
+    const uint64_t need_cap = (max_depth < 31) ? std::min<uint64_t>((1ull << (max_depth + 1)) - 1, 2ull * n - 1) : 2ull * n - 1;
+    if (cap < need_cap)
+        return fail(VQHIP_ERR_INVALID_INPUT, "node capacity %u < required %llu", cap, (unsigned long long)need_cap);
+    const uint32_t dcap = (uint32_t)need_cap;
+
+    DevBuf b_perm[2], b_nodeof[2], b_vals, b_flags, b_scan, b_bsums, b_hist, b_lvl;
+    DevBuf b_seg_start, b_seg_len, b_split, b_nv, b_nleft, b_median, b_selp, b_selr, b_child, b_cent, b_var;
+    for (int q = 0; q < 2; ++q) {
+        VQ_TRY(b_perm[q].alloc((size_t)n * 4));
+        VQ_TRY(b_nodeof[q].alloc((size_t)n * 4));
+    }
+    VQ_TRY(b_vals.alloc((size_t)n * 4));
+    VQ_TRY(b_flags.alloc((size_t)n * 4));
+    VQ_TRY(b_scan.alloc((size_t)n * 4));
+    const uint32_t nblk = (n + 1023) / 1024;
+    VQ_TRY(b_bsums.alloc((size_t)nblk * 4));
+    VQ_TRY(b_seg_start.alloc((size_t)dcap * 4));
+    VQ_TRY(b_seg_len.alloc((size_t)dcap * 4));
+    VQ_TRY(b_split.alloc((size_t)dcap * 4));
+    VQ_TRY(b_nv.alloc((size_t)dcap * 4));
+    VQ_TRY(b_nleft.alloc((size_t)dcap * 4));
+    VQ_TRY(b_median.alloc((size_t)dcap * 4));
+    VQ_TRY(b_selp.alloc((size_t)dcap * 8));
+    VQ_TRY(b_selr.alloc((size_t)dcap * 8));
+    VQ_TRY(b_child.alloc((size_t)dcap * 8));
+    VQ_TRY(b_cent.alloc((size_t)dcap * d * 4));
+    VQ_TRY(b_var.alloc((size_t)dcap * d * 4));
+    NodeArrays na;
+    na.seg_start = b_seg_start.as<uint32_t>();
+    na.seg_len = b_seg_len.as<uint32_t>();
+    na.split_dim = b_split.as<uint32_t>();
+    na.nv = b_nv.as<uint32_t>();
+    na.nleft = b_nleft.as<uint32_t>();
+    na.median = b_median.as<float>();
+    na.sel_prefix = b_selp.as<uint32_t>();
+    na.sel_rank = b_selr.as<uint32_t>();
+    na.child_local = b_child.as<uint32_t>();
+    na.centroid = b_cent.as<float>();
+    na.var = b_var.as<float>();
+
+    hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, stream, b_perm[0].as<uint32_t>(),
+                       b_nodeof[0].as<uint32_t>(), n);
+    VQ_LAUNCH_CHECK("k_iota");
+    int cur = 0;
+    std::vector<uint32_t> level = {0};  // global node ids of the current level
+    const uint32_t dgroups = (d + DG - 1) / DG;
+
+    while (!level.empty()) {
+        const uint32_t n_lvl = (uint32_t)level.size();
+        VQ_TRY(b_lvl.ensure((size_t)n_lvl * 4));
+        // node segment info for this level
+        {
+            std::vector<uint32_t> st(n_lvl), ln(n_lvl);
+            for (uint32_t li = 0; li < n_lvl; ++li) {
+                st[li] = nodes[level[li]].start;
+                ln[li] = nodes[level[li]].len;
+            }
+            // nodes of a level are created consecutively -> contiguous id range
+            const uint32_t first = level[0];
+            VQ_HIP(hipMemcpyAsync(na.seg_start + first, st.data(), (size_t)n_lvl * 4, hipMemcpyHostToDevice, stream));
+            VQ_HIP(hipMemcpyAsync(na.seg_len + first, ln.data(), (size_t)n_lvl * 4, hipMemcpyHostToDevice, stream));
+            VQ_HIP(hipMemcpyAsync(b_lvl.p, level.data(), (size_t)n_lvl * 4, hipMemcpyHostToDevice, stream));
+            VQ_HIP(hipStreamSynchronize(stream));  // host vectors go out of scope
+        }
+        const uint32_t *lvl = b_lvl.as<uint32_t>();
+        uint32_t *perm = b_perm[cur].as<uint32_t>(), *node_of = b_nodeof[cur].as<uint32_t>();
+        // means of every node of the level (tsvq.rs:36)
+        hipLaunchKernelGGL(k_seg_colsum<0>, dim3(n_lvl, dgroups), dim3(1024), 0, stream, X, d, perm, lvl, na);
+        VQ_LAUNCH_CHECK("k_seg_colsum<mean>");
+
+        // which nodes split? (tsvq.rs:38-44)
+        std::vector<uint32_t> split_nodes;
+        for (uint32_t id : level)
+            if (nodes[id].depth_left > 0 && nodes[id].len > 1) split_nodes.push_back(id);
+        if (split_nodes.empty()) break;
+        // the split nodes form the working level from here on: rebuild node_of for them only if
+        // some nodes of the level are leaves (their rows become inactive)
+        const uint32_t n_split = (uint32_t)split_nodes.size();
+        if (n_split != n_lvl) {
+            // remap level-local indices: leaves -> inactive.  Done on the host-known segment ranges.
+            std::vector<uint32_t> newidx(n_lvl, kInactive);
+            {
+                uint32_t q = 0;
+                for (uint32_t li = 0; li < n_lvl; ++li)
+                    if (nodes[level[li]].depth_left > 0 && nodes[level[li]].len > 1) newidx[li] = q++;
+            }
+            // tiny remap kernel via memset-style loops per leaf segment
+            for (uint32_t li = 0; li < n_lvl; ++li) {
+                const HostNode &hn = nodes[level[li]];
+                if (newidx[li] == kInactive) {
+                    VQ_HIP(hipMemsetAsync(node_of + hn.start, 0xFF, (size_t)hn.len * 4, stream));
+                } else if (newidx[li] != li) {
+                    // fill with the new index: use hipMemsetD32Async
+                    VQ_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(node_of + hn.start), (int)newidx[li], hn.len, stream));
+                }
+            }
+            VQ_HIP(hipMemcpyAsync(b_lvl.p, split_nodes.data(), (size_t)n_split * 4, hipMemcpyHostToDevice, stream));
+            VQ_HIP(hipStreamSynchronize(stream));
+        }
+        // variances + split dimension (tsvq.rs:46-66)
+        hipLaunchKernelGGL(k_seg_colsum<1>, dim3(n_split, dgroups), dim3(1024), 0, stream, X, d, perm, lvl, na);
+        VQ_LAUNCH_CHECK("k_seg_colsum<var>");
+        hipLaunchKernelGGL(k_pick_split, dim3((n_split + 63) / 64), dim3(64), 0, stream, lvl, n_split, d, na);
+        VQ_LAUNCH_CHECK("k_pick_split");
+        // median (tsvq.rs:68-81)
+        hipLaunchKernelGGL(k_gather_vals, dim3((n + 255) / 256), dim3(256), 0, stream, X, d, n, perm, node_of, lvl, na,
+                           b_vals.as<float>());
+        VQ_LAUNCH_CHECK("k_gather_vals");
+        hipLaunchKernelGGL(k_select_init, dim3((n_split + 63) / 64), dim3(64), 0, stream, lvl, n_split, na);
+        VQ_LAUNCH_CHECK("k_select_init");
+        VQ_TRY(b_hist.ensure((size_t)n_split * 2 * 256 * 4));
+        VQ_HIP(hipMemsetAsync(b_hist.p, 0, (size_t)n_split * 2 * 256 * 4, stream));
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hipLaunchKernelGGL(k_select_hist, dim3((n + 255) / 256), dim3(256), 0, stream, b_vals.as<float>(), n,
+                               node_of, lvl, na, (uint32_t)shift, b_hist.as<uint32_t>());
+            VQ_LAUNCH_CHECK("k_select_hist");
+            hipLaunchKernelGGL(k_select_pick, dim3((n_split * 2 + 63) / 64), dim3(64), 0, stream, lvl, n_split, na,
+                               (uint32_t)shift, b_hist.as<uint32_t>());
+            VQ_LAUNCH_CHECK("k_select_pick");
+        }
+        hipLaunchKernelGGL(k_median, dim3((n_split + 63) / 64), dim3(64), 0, stream, lvl, n_split, na);
+        VQ_LAUNCH_CHECK("k_median");
+        // partition (tsvq.rs:84-85)
+        hipLaunchKernelGGL(k_flags, dim3((n + 255) / 256), dim3(256), 0, stream, b_vals.as<float>(), n, node_of, lvl,
+                           na, b_flags.as<uint32_t>());
+        VQ_LAUNCH_CHECK("k_flags");
+        hipLaunchKernelGGL(k_scan_blocks, dim3(nblk), dim3(256), 0, stream, b_flags.as<uint32_t>(), n,
+                           b_scan.as<uint32_t>(), b_bsums.as<uint32_t>());
+        VQ_LAUNCH_CHECK("k_scan_blocks");
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, b_bsums.as<uint32_t>(), nblk);
+        VQ_LAUNCH_CHECK("k_scan_sums");
+        hipLaunchKernelGGL(k_scan_apply, dim3((n + 255) / 256), dim3(256), 0, stream, b_scan.as<uint32_t>(), n,
+                           b_bsums.as<uint32_t>());
+        VQ_LAUNCH_CHECK("k_scan_apply");
+        hipLaunchKernelGGL(k_nleft, dim3((n_split + 63) / 64), dim3(64), 0, stream, lvl, n_split, na,
+                           b_scan.as<uint32_t>(), b_flags.as<uint32_t>());
+        VQ_LAUNCH_CHECK("k_nleft");
+        // children (tsvq.rs:88-108) -- decided on the host from nleft / nv
+        std::vector<uint32_t> nleft_all(nodes.size()), nv_all(nodes.size());
+        {
+            const uint32_t first = split_nodes.front(), last = split_nodes.back();
+            VQ_HIP(hipMemcpyAsync(nleft_all.data() + first, na.nleft + first, (size_t)(last - first + 1) * 4,
+                                  hipMemcpyDeviceToHost, stream));
+            VQ_HIP(hipMemcpyAsync(nv_all.data() + first, na.nv + first, (size_t)(last - first + 1) * 4,
+                                  hipMemcpyDeviceToHost, stream));
+            VQ_HIP(hipStreamSynchronize(stream));
+        }
+        std::vector<uint32_t> next;
+        std::vector<uint32_t> child_local((size_t)nodes.size() * 2, kInactive);
+        for (uint32_t id : split_nodes) {
+            if (nv_all[id] == 0)
+                return fail(VQHIP_ERR_INVALID_INPUT,
+                            "TSVQ: every value on a split dimension is NaN (the reference panics here, src/tsvq.rs:77-78)");
+            const uint32_t len = nodes[id].len, nl = nleft_all[id], nr = len - nl;
+            if (nl != 0 && nl < len) {
+                nodes[id].left = (int32_t)nodes.size();
+                child_local[2 * id] = (uint32_t)next.size();
+                next.push_back((uint32_t)nodes.size());
+                nodes.push_back({nodes[id].start, nl, nodes[id].depth_left - 1, -1, -1});
+            }
+            if (nr != 0 && nr < len) {
+                nodes[id].right = (int32_t)nodes.size();
+                child_local[2 * id + 1] = (uint32_t)next.size();
+                next.push_back((uint32_t)nodes.size());
+                nodes.push_back({nodes[id].start + nl, nr, nodes[id].depth_left - 1, -1, -1});
+            }
+        }
+        if (next.empty()) break;
+        if (nodes.size() > dcap) return fail(VQHIP_ERR_FAILURE, "TSVQ node count exceeded its bound");
+        {
+            const uint32_t first = split_nodes.front(), last = split_nodes.back();
+            VQ_HIP(hipMemcpyAsync(na.child_local + 2 * first, child_local.data() + 2 * first,
+                                  (size_t)(last - first + 1) * 8, hipMemcpyHostToDevice, stream));
+        }
+        hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, n, perm, node_of, lvl, na,
+                           b_scan.as<uint32_t>(), b_flags.as<uint32_t>(), b_perm[cur ^ 1].as<uint32_t>(),
+                           b_nodeof[cur ^ 1].as<uint32_t>());
+        VQ_LAUNCH_CHECK("k_scatter");
+        VQ_HIP(hipStreamSynchronize(stream));  // child_local host vector
+        cur ^= 1;
+        level.swap(next);
+    }
+
+    // centroids of all nodes -> host, then BFS -> pre-order (the oracle's numbering)
+    const uint32_t total = (uint32_t)nodes.size();
+    std::vector<float> cent((size_t)total * d);
+    VQ_HIP(hipMemcpyAsync(cent.data(), na.centroid, (size_t)total * d * 4, hipMemcpyDeviceToHost, stream));
+    VQ_HIP(hipStreamSynchronize(stream));
+    std::vector<int32_t> order;  // pre-order list of BFS ids
+    order.reserve(total);
+    std::vector<int32_t> stack = {0};
+    while (!stack.empty()) {
+        const int32_t id = stack.back();
+        stack.pop_back();
+        order.push_back(id);
+        if (nodes[id].right >= 0) stack.push_back(nodes[id].right);
+        if (nodes[id].left >= 0) stack.push_back(nodes[id].left);
+    }
+    std::vector<int32_t> newid(total, -1);
+    for (uint32_t q = 0; q < order.size(); ++q) newid[order[q]] = (int32_t)q;
+    for (uint32_t q = 0; q < order.size(); ++q) {
+        const int32_t id = order[q];
+        memcpy(centroids_out + (size_t)q * d, cent.data() + (size_t)id * d, (size_t)d * 4);
+        left_out[q] = nodes[id].left >= 0 ? newid[nodes[id].left] : -1;
+        right_out[q] = nodes[id].right >= 0 ? newid[nodes[id].right] : -1;
+    }
+    *n_nodes_out = (int32_t)order.size();
+    return VQHIP_OK;
+}
+
+int launch_tsvq_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const int32_t *left,
+                       const int32_t *right, int metric, int32_t *leaf, uint16_t *f16_out, hipStream_t stream) {
+    if (n == 0) return VQHIP_OK;
+    hipLaunchKernelGGL(k_tsvq_descend, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, X, n, d, centroids,
+                       left, right, metric, leaf);
+    VQ_LAUNCH_CHECK("k_tsvq_descend");
+    if (f16_out) {
+        uint64_t blocks = (n * d + 255) / 256;
+        if (blocks > (uint64_t)num_cus() * 8) blocks = (uint64_t)num_cus() * 8;
+        hipLaunchKernelGGL(k_tsvq_gather_f16, dim3((uint32_t)blocks), dim3(256), 0, stream, centroids, d, leaf, n,
+                           f16_out);
+        VQ_LAUNCH_CHECK("k_tsvq_gather_f16");
+    }
+    return VQHIP_OK;
+}
+
+}  // namespace vqhip
