@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the other BASELINE.json configurations (bench.py stays the
+headline contract).  One JSON line per configuration on one MI355X:
+
+  C1  PQ m=4  k=16  Euclidean, 10k x 64     (the reference's own CPU-sized case)
+  C2  PQ m=8  k=256 L2,        1M x 128     fit (10 Lloyd iterations) + encode
+  C3  PQ m=96 k=256 cosine,    1M x 768     fit + cosine encode (exact VALU engine)
+  C4  TSVQ depth 8 L2,         1M x 128     build + encode
+  C5  PQ m=16 k=256 L2,        per-GPU shard of 100M x 128 (12.5M rows) fit iteration + encode
+
+    python bench_configs.py [C1 C2 ...]
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def _sync():
+    from vq_amd import _lib
+
+    _lib.synchronize()
+
+
+def pq_config(name, n, d, m, k, metric_name, iters=10, encode_reps=5):
+    import torch
+
+    from vq_amd import _lib
+
+    metric = {"l2": _lib.SQUARED_EUCLIDEAN, "euclidean": _lib.EUCLIDEAN, "cosine": _lib.COSINE}[metric_name]
+    ds = _lib.Dataset.synthetic(n, d, 66, 0)
+    km = _lib.KMeans(ds, m, k)
+    init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64)
+    km.init_from_rows(init)
+    km.step()  # warm-up (allocations, code objects)
+    km.init_from_rows(init)
+    _sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        km.step()
+    _sync()
+    fit_s = time.perf_counter() - t0
+    cb = km.get_centroids()
+    km.close()
+    enc = _lib.PQEncoder(cb, metric)
+    codes = torch.empty((n, m), dtype=torch.uint8, device="cuda")
+    f16 = torch.empty((n, d), dtype=torch.float16, device="cuda")
+    enc.encode_device(ds.device_ptr, n, codes.data_ptr(), None)
+    _sync()
+    _lib.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(encode_reps):
+        enc.encode_device(ds.device_ptr, n, codes.data_ptr(), None)
+    _sync()
+    enc_s = (time.perf_counter() - t0) / encode_reps
+    calls, prim_ms, re_ms = _lib.profile_collect()
+    _lib.set_profiling(False)
+    rechecked, engine = _lib.last_assign_stats()
+    t0 = time.perf_counter()
+    for _ in range(encode_reps):
+        enc.encode_device(ds.device_ptr, n, codes.data_ptr(), f16.data_ptr())
+    _sync()
+    enc16_s = (time.perf_counter() - t0) / encode_reps
+    flop = 2.0 * k * d * n
+    out = {
+        "config": name, "n": n, "d": d, "m": m, "k": k, "metric": metric_name,
+        "kmeans_ms_per_iter": fit_s / iters * 1e3, "kmeans_iter_per_s": iters / fit_s,
+        "encode_vectors_per_s": n / enc_s, "encode_ms": enc_s * 1e3,
+        "encode_f16_out_vectors_per_s": n / enc16_s,
+        "engine": {1: "exact", 2: "mfma_screen+exact_recheck"}[engine],
+        "recheck_fraction": rechecked / float(n * m),
+        "primary_kernel_ms": prim_ms / max(calls, 1), "recheck_kernel_ms": re_ms / max(calls, 1),
+        "algorithmic_tflops": flop / enc_s / 1e12,
+    }
+    enc.close()
+    ds.close()
+    return out
+
+
+def tsvq_config(name, n, d, depth, reps=3):
+    import torch
+
+    from vq_amd import TSVQ, Distance, _lib
+    from vq_amd.tsvq import build_tree
+
+    ds = _lib.Dataset.synthetic(n, d, 66, 0)
+    build_tree(ds, depth)  # warm-up
+    _sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cent, left, right = build_tree(ds, depth)
+    _sync()
+    build_s = (time.perf_counter() - t0) / reps
+    t = TSVQ.from_tree(cent, left, right, Distance.euclidean())
+    leaf = torch.empty(n, dtype=torch.int32, device="cuda")
+    f16 = torch.empty((n, d), dtype=torch.float16, device="cuda")
+    lib = _lib.load()
+    import ctypes as C
+
+    def run():
+        _lib.check(lib.vqhip_tsvq_encode_device(t._enc.raw, C.c_void_p(ds.device_ptr), n,
+                                                C.c_void_p(leaf.data_ptr()), C.c_void_p(f16.data_ptr())))
+    run()
+    _sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    _sync()
+    enc_s = (time.perf_counter() - t0) / reps
+    levels = depth
+    build_bytes = 4.0 * n * d * (2 * levels + 1)
+    out = {
+        "config": name, "n": n, "d": d, "depth": depth, "nodes": int(cent.shape[0]),
+        "build_ms": build_s * 1e3, "build_algorithmic_GBps": build_bytes / build_s / 1e9,
+        "encode_vectors_per_s": n / enc_s, "encode_ms": enc_s * 1e3,
+        "encode_algorithmic_GBps": (4.0 * d + 2.0 * d) * n / enc_s / 1e9,
+    }
+    ds.close()
+    return out
+
+
+CONFIGS = {
+    "C1": lambda: pq_config("C1", 10_000, 64, 4, 16, "euclidean"),
+    "C2": lambda: pq_config("C2", 1_000_000, 128, 8, 256, "l2"),
+    "C3": lambda: pq_config("C3", 1_000_000, 768, 96, 256, "cosine", iters=5, encode_reps=2),
+    "C4": lambda: tsvq_config("C4", 1_000_000, 128, 8),
+    "C5": lambda: pq_config("C5_per_gpu_shard", 12_500_000, 128, 16, 256, "l2", iters=3, encode_reps=2),
+}
+
+if __name__ == "__main__":
+    from vq_amd import _lib
+
+    _lib.load()
+    _lib.set_device(0)
+    which = sys.argv[1:] or list(CONFIGS)
+    for c in which:
+        print(json.dumps(CONFIGS[c]()), flush=True)

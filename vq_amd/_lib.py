@@ -93,6 +93,14 @@ def load() -> C.CDLL:
         raise FfiError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (or `make -C vq_amd/csrc`).  vq_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64.
+    # If libvqhip pulled in /opt/rocm's copy first, torch's later initialisation finds no GPU.
+    # Importing torch first makes both resolve the same SONAMEs to the same loaded objects
+    # (plumbing only: nothing here calls into torch).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch-free hosts use the system runtime
+        pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the host

@@ -294,7 +294,7 @@ struct vqhip_pq_encoder {
 struct vqhip_tsvq {
     uint32_t n_nodes = 0, d = 0;
     int metric = VQHIP_EUCLIDEAN;
-    DevBuf centroids, left, right, xbuf, leafbuf, f16buf;
+    DevBuf centroids, cnorm, left, right, xbuf, leafbuf, f16buf;
 };
 
 #define VQ_API_BEGIN try {
@@ -890,6 +890,8 @@ int vqhip_tsvq_create(const float *centroids, const int32_t *left, const int32_t
     VQ_HIP(hipMemcpyAsync(t->centroids.p, centroids, (size_t)n_nodes * d * 4, hipMemcpyHostToDevice, s));
     VQ_HIP(hipMemcpyAsync(t->left.p, left, (size_t)n_nodes * 4, hipMemcpyHostToDevice, s));
     VQ_HIP(hipMemcpyAsync(t->right.p, right, (size_t)n_nodes * 4, hipMemcpyHostToDevice, s));
+    VQ_TRY(t->cnorm.alloc((size_t)n_nodes * 4));
+    VQ_TRY(launch_tsvq_node_norms(t->centroids.as<float>(), n_nodes, d, t->cnorm.as<float>(), s));
     VQ_HIP(hipStreamSynchronize(s));
     *out = t.release();
     return VQHIP_OK;
@@ -915,7 +917,7 @@ int vqhip_tsvq_encode_device(vqhip_tsvq *t, const void *dev_rows, uint64_t n, vo
         leaf = t->leafbuf.as<int32_t>();
     }
     return launch_tsvq_encode(reinterpret_cast<const float *>(dev_rows), n, t->d, t->centroids.as<float>(),
-                              t->left.as<int32_t>(), t->right.as<int32_t>(), t->metric, leaf,
+                              t->cnorm.as<float>(), t->left.as<int32_t>(), t->right.as<int32_t>(), t->metric, leaf,
                               reinterpret_cast<uint16_t *>(dev_f16_out), s);
     VQ_API_END
 }

@@ -58,6 +58,14 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
 }
 
 // MODE 0: out = (sequential sum of x) / n  -> centroid;  MODE 1: out = sequential sum (x-mu)^2
+//
+// Workgroup = 16 waves for one (node, 16-dimension group): waves 1..15 stream the node's rows
+// (gathered through `perm`, 64 B per row) into a 2-buffer LDS ring, wave 0 is the consumer
+// whose lanes 0..15 each own one dimension and add the staged rows in order.  Loads run two
+// tiles ahead of the consumer in registers (issue early, write to LDS one iteration later), so
+// an HBM miss (~2 us) is covered by two consumer tiles (~1 us each at 5 cycles per dependent
+// add).  The consumer reads 32 staged values at a time before adding them, so the LDS latency
+// is paid once per 32 rows, not per row.
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_seg_colsum(const float *__restrict__ X, uint32_t d,
                                                      const uint32_t *__restrict__ perm,
@@ -72,39 +80,70 @@ __global__ __launch_bounds__(1024) void k_seg_colsum(const float *__restrict__ X
     float acc = (MODE == 0) ? 0.0f : -0.0f;
     float mu = 0.0f;
     if (MODE == 1 && wave == 0 && lane < DG && t0 + lane < d) mu = na.centroid[(size_t)node * d + t0 + lane];
+    const bool vec_ok = (d % 4 == 0);
+    const uint32_t q = lane & 3;
 
-    auto stage = [&](uint32_t tile_idx, uint32_t buf) {
-        // loader waves 1..15: lane -> (row within the wave's 32-row slab, 8-byte half-quarter)
-        if (wave == 0) return;
+    // loader lanes: 2 x (16 rows x 4 float4) per tile
+    auto fetch = [&](uint32_t tile_idx, float4 (&v)[2]) {
         const uint32_t base = tile_idx * kTileRows + (wave - 1) * 32;
 #pragma unroll
         for (uint32_t rep = 0; rep < 2; ++rep) {
-            const uint32_t r = (lane >> 2) + rep * 16, q = lane & 3;  // 16 rows x 4 float4 per rep
-            const uint32_t idx = base + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < n) {
+            const uint32_t idx = base + (lane >> 2) + rep * 16;
+            v[rep] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tile_idx < n_tiles && idx < n) {
                 const float *src = X + (size_t)perm[a + idx] * d + t0 + 4 * q;
-                if (t0 + 4 * q + 3 < d && (d % 4 == 0)) {
-                    v = *reinterpret_cast<const float4 *>(src);
+                if (vec_ok && t0 + 4 * q + 3 < d) {
+                    v[rep] = *reinterpret_cast<const float4 *>(src);
                 } else {
-                    if (t0 + 4 * q + 0 < d) v.x = src[0];
-                    if (t0 + 4 * q + 1 < d) v.y = src[1];
-                    if (t0 + 4 * q + 2 < d) v.z = src[2];
-                    if (t0 + 4 * q + 3 < d) v.w = src[3];
+                    if (t0 + 4 * q + 0 < d) v[rep].x = src[0];
+                    if (t0 + 4 * q + 1 < d) v[rep].y = src[1];
+                    if (t0 + 4 * q + 2 < d) v[rep].z = src[2];
+                    if (t0 + 4 * q + 3 < d) v[rep].w = src[3];
                 }
             }
-            *reinterpret_cast<float4 *>(&tile[buf][(wave - 1) * 32 + r][4 * q]) = v;
         }
     };
+    auto put = [&](uint32_t buf, const float4 (&v)[2]) {
+#pragma unroll
+        for (uint32_t rep = 0; rep < 2; ++rep)
+            *reinterpret_cast<float4 *>(&tile[buf][(wave - 1) * 32 + (lane >> 2) + rep * 16][4 * q]) = v[rep];
+    };
 
-    if (n_tiles > 0) stage(0, 0);
+    float4 r1[2], r2[2];  // tiles ti+1 and ti+2 in flight (loader waves only)
+    if (wave != 0) {
+        float4 r0[2];
+        fetch(0, r0);
+        fetch(1, r1);
+        fetch(2, r2);
+        put(0, r0);
+    }
     __syncthreads();
     for (uint32_t ti = 0; ti < n_tiles; ++ti) {
         const uint32_t buf = ti & 1;
-        if (ti + 1 < n_tiles) stage(ti + 1, buf ^ 1);
-        if (wave == 0 && lane < DG) {
+        if (wave != 0) {
+            put(buf ^ 1, r1);  // tile ti+1 (loaded two iterations ago)
+            r1[0] = r2[0];
+            r1[1] = r2[1];
+            fetch(ti + 3, r2);
+        } else if (lane < DG) {
             const uint32_t rows = min(kTileRows, n - ti * kTileRows);
-            for (uint32_t r = 0; r < rows; ++r) {
+            uint32_t r = 0;
+            for (; r + 32 <= rows; r += 32) {
+                float v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) v[u] = tile[buf][r + u][lane];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    if (MODE == 0) {
+                        acc = acc + v[u];
+                    } else {
+                        const float diff = v[u] - mu;
+                        const float sq = diff * diff;
+                        acc = acc + sq;
+                    }
+                }
+            }
+            for (; r < rows; ++r) {
                 const float x = tile[buf][r][lane];
                 if (MODE == 0) {
                     acc = acc + x;
@@ -142,11 +181,11 @@ __global__ void k_pick_split(const uint32_t *__restrict__ lvl_node, uint32_t n_l
         }
     }
     na.split_dim[node] = best_t;
-    na.nv[node] = 0;
+    na.nv[node] = na.seg_len[node];  // non-NaN count: k_gather_vals subtracts the NaNs
     na.sel_prefix[2 * node] = na.sel_prefix[2 * node + 1] = 0;
 }
 
-// vals[i] = X[perm[i]][split_dim(node of i)]; counts the non-NaN values per node
+// vals[i] = X[perm[i]][split_dim(node of i)]; nv[node] ends as the non-NaN count
 __global__ __launch_bounds__(256) void k_gather_vals(const float *__restrict__ X, uint32_t d, uint32_t n,
                                                      const uint32_t *__restrict__ perm,
                                                      const uint32_t *__restrict__ node_of,
@@ -159,7 +198,7 @@ __global__ __launch_bounds__(256) void k_gather_vals(const float *__restrict__ X
     const uint32_t node = lvl_node[li];
     const float x = X[(size_t)perm[i] * d + na.split_dim[node]];
     vals[i] = x;
-    if (x == x) atomicAdd(&na.nv[node], 1u);
+    if (x != x) atomicSub(&na.nv[node], 1u);  // nv starts at seg_len (k_pick_split); NaNs are rare
 }
 
 // ranks of the two order statistics the median needs (tsvq.rs:77-81)
@@ -177,24 +216,53 @@ __global__ void k_select_init(const uint32_t *__restrict__ lvl_node, uint32_t n_
     na.sel_rank[2 * node + 1] = h;
 }
 
-// one radix-select round: histogram of the byte at `shift` among keys matching the prefix
+// one radix-select round: histogram of the byte at `shift` among keys matching the prefix.
+// Positions are grouped by node, so a workgroup's contiguous chunk touches very few nodes:
+// histograms are privatised in LDS (8 slots keyed by the level-local node index, claimed with
+// a CAS) and flushed once; the rare slot collision falls back to a global atomic.  Unprivatised,
+// the root level is 1M atomics on 512 words (0.64 ms per round).
+constexpr uint32_t kHistSlots = 8;
 __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ vals, uint32_t n,
+                                                     uint32_t chunk,
                                                      const uint32_t *__restrict__ node_of,
                                                      const uint32_t *__restrict__ lvl_node, NodeArrays na,
                                                      uint32_t shift, uint32_t *__restrict__ hist) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t li = node_of[i];
-    if (li == kInactive) return;
-    const float x = vals[i];
-    if (x != x) return;
-    const uint32_t node = lvl_node[li];
-    const uint32_t key = order_key(x);
+    __shared__ uint32_t tags[kHistSlots];
+    __shared__ uint32_t lh[kHistSlots][2][256];
+    for (uint32_t e = threadIdx.x; e < kHistSlots * 512; e += 256) (&lh[0][0][0])[e] = 0u;
+    if (threadIdx.x < kHistSlots) tags[threadIdx.x] = kInactive;
+    __syncthreads();
     const uint32_t hi_mask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+    const uint32_t i0 = blockIdx.x * chunk;
+    const uint32_t i1 = min(n, i0 + chunk);
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const uint32_t li = node_of[i];
+        if (li == kInactive) continue;
+        const float x = vals[i];
+        if (x != x) continue;
+        const uint32_t node = lvl_node[li];
+        const uint32_t key = order_key(x);
+        const uint32_t slot = li & (kHistSlots - 1);
+        uint32_t owner = tags[slot];
+        if (owner == kInactive) {
+            const uint32_t old = atomicCAS(&tags[slot], kInactive, li);
+            owner = (old == kInactive) ? li : old;
+        }
 #pragma unroll
-    for (uint32_t sel = 0; sel < 2; ++sel)
-        if ((key & hi_mask) == na.sel_prefix[2 * node + sel])
-            atomicAdd(&hist[((size_t)li * 2 + sel) * 256 + ((key >> shift) & 255u)], 1u);
+        for (uint32_t sel = 0; sel < 2; ++sel)
+            if ((key & hi_mask) == na.sel_prefix[2 * node + sel]) {
+                const uint32_t bin = (key >> shift) & 255u;
+                if (owner == li) atomicAdd(&lh[slot][sel][bin], 1u);
+                else atomicAdd(&hist[((size_t)li * 2 + sel) * 256 + bin], 1u);
+            }
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < kHistSlots * 512; e += 256) {
+        const uint32_t slot = e >> 9, rest = e & 511;
+        const uint32_t c = (&lh[0][0][0])[e];
+        const uint32_t li = tags[slot];
+        if (c != 0 && li != kInactive) atomicAdd(&hist[(size_t)li * 512 + rest], c);
+    }
 }
 
 __global__ void k_select_pick(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, NodeArrays na,
@@ -411,6 +479,120 @@ __global__ __launch_bounds__(256) void k_tsvq_descend(const float *__restrict__ 
     leaf_out[i] = node;
 }
 
+// Fast descent: a workgroup stages RB rows transposed in LDS (xs[t][i], conflict-free for the
+// per-lane sequential walks over t), then every lane walks the tree for its row.  Both child
+// distances are evaluated in one pass over t (two independent dependent-add chains), the
+// child centroids come from L1/L2 as float4 (the whole tree is <= 261 KB at depth 8).
+template <int METRIC, int RB>
+__global__ __launch_bounds__(RB) void k_tsvq_descend_lds(const float *__restrict__ X, uint64_t n, uint32_t d,
+                                                         const float *__restrict__ centroids,
+                                                         const float *__restrict__ cnorm,
+                                                         const int32_t *__restrict__ left,
+                                                         const int32_t *__restrict__ right,
+                                                         int32_t *__restrict__ leaf_out) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [d][RB]
+    const uint64_t row0 = (uint64_t)blockIdx.x * RB;
+    const uint32_t rows = (uint32_t)min((uint64_t)RB, n - row0);
+    // coalesced stage: consecutive threads read consecutive floats of the row block
+    for (uint32_t e = threadIdx.x; e < rows * d; e += RB) {
+        const uint32_t i = e / d, t = e - i * d;
+        xs[t * RB + i] = X[row0 * d + e];
+    }
+    __syncthreads();
+    const uint32_t i = threadIdx.x;
+    if (i >= rows) return;
+    const float *x = xs + i;
+    float na = 0.0f;
+    if (METRIC == VQHIP_COSINE) {
+        float sa = -0.0f;
+        for (uint32_t t = 0; t < d; ++t) {
+            const float v = x[t * RB];
+            const float p = v * v;
+            sa = sa + p;
+        }
+        na = sqrtf(sa);
+    }
+    int32_t node = 0;
+    for (;;) {
+        const int32_t l = left[node], r = right[node];
+        if (l >= 0 && r >= 0) {
+            const float4 *cl = reinterpret_cast<const float4 *>(centroids + (size_t)l * d);
+            const float4 *cr = reinterpret_cast<const float4 *>(centroids + (size_t)r * d);
+            float al = -0.0f, ar = -0.0f;
+            for (uint32_t t4 = 0; t4 < d / 4; ++t4) {
+                const float4 a4 = cl[t4], b4 = cr[t4];
+                const float ca[4] = {a4.x, a4.y, a4.z, a4.w}, cb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float v = x[(t4 * 4 + u) * RB];
+                    if (METRIC == VQHIP_SQUARED_EUCLIDEAN || METRIC == VQHIP_EUCLIDEAN) {
+                        const float d1 = v - ca[u], d2 = v - cb[u];
+                        const float s1 = d1 * d1, s2 = d2 * d2;
+                        al = al + s1;
+                        ar = ar + s2;
+                    } else if (METRIC == VQHIP_MANHATTAN) {
+                        const float d1 = v - ca[u], d2 = v - cb[u];
+                        al = al + fabsf(d1);
+                        ar = ar + fabsf(d2);
+                    } else {
+                        const float p1 = v * ca[u], p2 = v * cb[u];
+                        al = al + p1;
+                        ar = ar + p2;
+                    }
+                }
+            }
+            float dl, dr;
+            if (METRIC == VQHIP_EUCLIDEAN) {
+                dl = sqrtf(al);
+                dr = sqrtf(ar);
+            } else if (METRIC == VQHIP_COSINE) {
+                const float nl = cnorm[l], nr = cnorm[r];
+                if (na < 1e-10f || nl < 1e-10f) {
+                    dl = 1.0f;
+                } else {
+                    const float den = na * nl;
+                    const float qq = al / den;
+                    const float v = 1.0f - qq;
+                    dl = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                }
+                if (na < 1e-10f || nr < 1e-10f) {
+                    dr = 1.0f;
+                } else {
+                    const float den = na * nr;
+                    const float qq = ar / den;
+                    const float v = 1.0f - qq;
+                    dr = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                }
+            } else {
+                dl = al;
+                dr = ar;
+            }
+            node = (dl <= dr) ? l : r;
+        } else if (l >= 0) {
+            node = l;
+        } else if (r >= 0) {
+            node = r;
+        } else {
+            break;
+        }
+    }
+    leaf_out[row0 + i] = node;
+}
+
+// sqrt(sum c^2) per node: cosine's norm_b depends on the node only (src/core/distance.rs:109)
+__global__ void k_tsvq_node_norms(const float *__restrict__ centroids, uint32_t n_nodes, uint32_t d,
+                                  float *__restrict__ cnorm) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_nodes) return;
+    float sb = -0.0f;
+    for (uint32_t t = 0; t < d; ++t) {
+        const float v = centroids[(size_t)j * d + t];
+        const float p = v * v;
+        sb = sb + p;
+    }
+    cnorm[j] = sqrtf(sb);
+}
+
 __global__ __launch_bounds__(256) void k_tsvq_gather_f16(const float *__restrict__ centroids, uint32_t d,
                                                          const int32_t *__restrict__ leaf, uint64_t n,
                                                          uint16_t *__restrict__ out) {
@@ -550,7 +732,9 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         VQ_TRY(b_hist.ensure((size_t)n_split * 2 * 256 * 4));
         VQ_HIP(hipMemsetAsync(b_hist.p, 0, (size_t)n_split * 2 * 256 * 4, stream));
         for (int shift = 24; shift >= 0; shift -= 8) {
-            hipLaunchKernelGGL(k_select_hist, dim3((n + 255) / 256), dim3(256), 0, stream, b_vals.as<float>(), n,
+            const uint32_t hblocks = std::min<uint32_t>((n + 2047) / 2048, (uint32_t)num_cus() * 4);
+            const uint32_t hchunk = (n + hblocks - 1) / hblocks;
+            hipLaunchKernelGGL(k_select_hist, dim3(hblocks), dim3(256), 0, stream, b_vals.as<float>(), n, hchunk,
                                node_of, lvl, na, (uint32_t)shift, b_hist.as<uint32_t>());
             VQ_LAUNCH_CHECK("k_select_hist");
             hipLaunchKernelGGL(k_select_pick, dim3((n_split * 2 + 63) / 64), dim3(64), 0, stream, lvl, n_split, na,
@@ -647,12 +831,59 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     return VQHIP_OK;
 }
 
-int launch_tsvq_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const int32_t *left,
-                       const int32_t *right, int metric, int32_t *leaf, uint16_t *f16_out, hipStream_t stream) {
+int launch_tsvq_node_norms(const float *centroids, uint32_t n_nodes, uint32_t d, float *cnorm, hipStream_t stream) {
+    hipLaunchKernelGGL(k_tsvq_node_norms, dim3((n_nodes + 63) / 64), dim3(64), 0, stream, centroids, n_nodes, d, cnorm);
+    VQ_LAUNCH_CHECK("k_tsvq_node_norms");
+    return VQHIP_OK;
+}
+
+template <int METRIC, int RB>
+static int launch_descend_lds(const float *X, uint64_t n, uint32_t d, const float *centroids, const float *cnorm,
+                              const int32_t *left, const int32_t *right, int32_t *leaf, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_descend_lds<METRIC, RB>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_tsvq_descend_lds<METRIC, RB>), dim3((uint32_t)((n + RB - 1) / RB)), dim3(RB),
+                       (size_t)d * RB * 4, stream, X, n, d, centroids, cnorm, left, right, leaf);
+    VQ_LAUNCH_CHECK("k_tsvq_descend_lds");
+    return VQHIP_OK;
+}
+
+template <int METRIC>
+static int dispatch_descend(const float *X, uint64_t n, uint32_t d, const float *centroids, const float *cnorm,
+                            const int32_t *left, const int32_t *right, int32_t *leaf, hipStream_t stream, bool *done) {
+    const size_t budget = 150 * 1024;
+    *done = true;
+    if ((size_t)d * 256 * 4 <= budget) return launch_descend_lds<METRIC, 256>(X, n, d, centroids, cnorm, left, right, leaf, stream);
+    if ((size_t)d * 128 * 4 <= budget) return launch_descend_lds<METRIC, 128>(X, n, d, centroids, cnorm, left, right, leaf, stream);
+    if ((size_t)d * 64 * 4 <= budget) return launch_descend_lds<METRIC, 64>(X, n, d, centroids, cnorm, left, right, leaf, stream);
+    *done = false;
+    return VQHIP_OK;
+}
+
+int launch_tsvq_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const float *cnorm,
+                       const int32_t *left, const int32_t *right, int metric, int32_t *leaf, uint16_t *f16_out,
+                       hipStream_t stream) {
     if (n == 0) return VQHIP_OK;
-    hipLaunchKernelGGL(k_tsvq_descend, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, X, n, d, centroids,
-                       left, right, metric, leaf);
-    VQ_LAUNCH_CHECK("k_tsvq_descend");
+    bool done = false;
+    const bool vec = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(centroids) & 15) == 0);
+    if (vec) {
+        switch (metric) {
+        case VQHIP_SQUARED_EUCLIDEAN: VQ_TRY(dispatch_descend<VQHIP_SQUARED_EUCLIDEAN>(X, n, d, centroids, cnorm, left, right, leaf, stream, &done)); break;
+        case VQHIP_EUCLIDEAN: VQ_TRY(dispatch_descend<VQHIP_EUCLIDEAN>(X, n, d, centroids, cnorm, left, right, leaf, stream, &done)); break;
+        case VQHIP_MANHATTAN: VQ_TRY(dispatch_descend<VQHIP_MANHATTAN>(X, n, d, centroids, cnorm, left, right, leaf, stream, &done)); break;
+        case VQHIP_COSINE: VQ_TRY(dispatch_descend<VQHIP_COSINE>(X, n, d, centroids, cnorm, left, right, leaf, stream, &done)); break;
+        default: return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", metric);
+        }
+    }
+    if (!done) {
+        hipLaunchKernelGGL(k_tsvq_descend, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, X, n, d, centroids,
+                           left, right, metric, leaf);
+        VQ_LAUNCH_CHECK("k_tsvq_descend");
+    }
     if (f16_out) {
         uint64_t blocks = (n * d + 255) / 256;
         if (blocks > (uint64_t)num_cus() * 8) blocks = (uint64_t)num_cus() * 8;

@@ -92,8 +92,10 @@ int launch_gather_rows(const float *X, uint32_t d, uint32_t m, uint32_t k, uint3
 int tsvq_build_device(const float *X, uint64_t n, uint32_t d, uint32_t max_depth, uint32_t cap,
                       float *centroids_out, int32_t *left_out, int32_t *right_out, int32_t *n_nodes_out,
                       hipStream_t stream);
-int launch_tsvq_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const int32_t *left,
-                       const int32_t *right, int metric, int32_t *leaf, uint16_t *f16_out, hipStream_t stream);
+int launch_tsvq_node_norms(const float *centroids, uint32_t n_nodes, uint32_t d, float *cnorm, hipStream_t stream);
+int launch_tsvq_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const float *cnorm,
+                       const int32_t *left, const int32_t *right, int metric, int32_t *leaf, uint16_t *f16_out,
+                       hipStream_t stream);
 
 // ---- outputs / misc ---------------------------------------------------------------
 int launch_gather_f16(const CodebookView &cb, const uint8_t *codes, uint64_t n, uint16_t *f16_out,
