@@ -278,3 +278,49 @@ def test_dequantize_and_decode(oracle):
     codes = rng.integers(0, 16, (100, 4)).astype(np.uint8)
     want = np.concatenate([cb[s][codes[:, s]] for s in range(4)], axis=1)
     np.testing.assert_array_equal(enc.decode(codes), want)
+
+
+# ---- exact_update: reference-order cluster sums -> bit-identical centroids ----------------
+@pytest.mark.parametrize("shape", [(4000, 64, 4, 16), (6000, 128, 8, 256), (3000, 128, 16, 64), (999, 12, 4, 7)])
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "lattice"])
+def test_exact_update_step_is_bit_identical(oracle, shape, kind):
+    n, d, m, k = shape
+    sd = d // m
+    X = _data(31, n, d, kind)
+    init = np.array([[(j * (n // k) + 3 * s) % n for j in range(k)] for s in range(m)], np.uint64)
+    ds = _lib.Dataset.from_host(X)
+    km = _lib.KMeans(ds, m, k)
+    km.set_exact_update(True)
+    km.init_from_rows(init)
+    counts, changed = km.step()
+    cent = km.get_centroids()
+    for s in range(m):
+        c0 = X[init[s].astype(np.int64), s * sd:(s + 1) * sd]
+        c1, a_ref, n_ref, ch_ref = oracle.lloyd_step(X[:, s * sd:(s + 1) * sd], c0, threads=0)
+        np.testing.assert_array_equal(counts[s], n_ref)
+        nonempty = n_ref > 0
+        assert cent[s][nonempty].tobytes() == c1[nonempty].tobytes()
+        assert bool(changed[s]) == ch_ref
+    km.close()
+    ds.close()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered"])
+def test_exact_update_full_fit_is_bit_identical(oracle, kind):
+    """With the reference-order update the whole Lloyd trajectory -- every iteration's codes and
+    centroids, the iteration counts and the reseeds -- reproduces the oracle bit for bit."""
+    from vq_amd.pq import fit_codebooks
+
+    n, d, m, k = 20000, 64, 4, 32
+    X = _data(32, n, d, kind)
+    init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64)
+    if kind == "clustered":
+        init[:, 1] = init[:, 0]  # duplicate initial centroid -> empty cluster -> reseed path
+    reseed = np.array([[11, 222, 3333, 4444, 5555, 6666, 7777, 8888]] * m, np.uint64)
+    ds = _lib.Dataset.from_host(X)
+    stats = {}
+    cb = fit_codebooks(ds, m, k, 12, init_rows=init, reseed_rows=reseed, exact_update=True, stats=stats)
+    ds.close()
+    cb_ref, it_ref = oracle.pq_fit(X, m, k, 12, init, reseed_rows=reseed, threads=0)
+    assert stats["iters"].tolist() == it_ref.tolist()
+    assert cb.tobytes() == cb_ref.tobytes()

@@ -18,6 +18,8 @@
 //                centroid (the caller reseeds, vector.rs:448-452).
 //
 // Algorithmic bytes per row: 4*d + m.  Roofline: HBM.
+#include <algorithm>
+
 #include "kernels.hpp"
 
 #pragma clang fp contract(off)
@@ -416,11 +418,164 @@ int launch_gather_rows(const float *X, uint32_t d, uint32_t m, uint32_t k, uint3
     return VQHIP_OK;
 }
 
-size_t exact_sums_workspace_bytes(uint32_t, uint32_t, uint64_t) { return 0; }
+// ---- exact (reference-order) cluster sums -------------------------------------------------
+// mean_vector_by_indices (src/core/vector.rs:368-384) adds a cluster's member rows in ascending
+// row order, one rounding per add.  To reproduce those bits the rows are first bucketed by
+// code with a STABLE counting sort (per-chunk histograms -> offsets -> in-order scatter, the
+// GPU form of `cluster_indices[c].push(i)`, vector.rs:432-435), then one lane per
+// (subspace, cluster, dimension) walks its member list and adds sequentially.  The chain is
+// latency-bound (N/k dependent adds per lane, 32 row gathers in flight), ~0.5 ms at C2.
+namespace {
 
-int launch_exact_sums(uint32_t, uint32_t, uint32_t, const float *, uint64_t, uint32_t,
-                      const uint8_t *, const uint8_t *, void *, size_t, double *, hipStream_t) {
-    return fail(VQHIP_ERR_UNSUPPORTED, "exact (reference-order) centroid sums are not built yet");
+constexpr uint32_t kXsChunks = 1024;  // row chunks of the bucket passes
+
+__global__ __launch_bounds__(256) void k_chunk_counts(const uint8_t *__restrict__ codes, uint64_t n,
+                                                      uint32_t m, uint32_t k, uint64_t rows_per_chunk,
+                                                      const uint8_t *__restrict__ active,
+                                                      uint32_t *__restrict__ chunk_counts) {
+    __shared__ uint32_t hist[256];
+    const uint32_t s = blockIdx.y;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    if (!active || active[s]) {
+        const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_chunk;
+        uint64_t r1 = r0 + rows_per_chunk;
+        if (r1 > n) r1 = n;
+        for (uint64_t r = r0 + threadIdx.x; r < r1; r += 256) atomicAdd(&hist[codes[r * m + s]], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < k) chunk_counts[((size_t)blockIdx.x * m + s) * k + threadIdx.x] = hist[threadIdx.x];
+}
+
+// chunk_counts [chunks][m][k] -> in place: write offset of (chunk, s, j) inside members[s][..];
+// start [m][k+1]: first member of cluster j (start[s][k] = rows of the subspace)
+__global__ __launch_bounds__(256) void k_bucket_offsets(uint32_t *__restrict__ chunk_counts, uint32_t n_chunks,
+                                                        uint32_t m, uint32_t k, uint32_t *__restrict__ start) {
+    __shared__ uint32_t tot[256];
+    const uint32_t s = blockIdx.x, j = threadIdx.x;
+    uint32_t total = 0;
+    if (j < k)
+        for (uint32_t c = 0; c < n_chunks; ++c) total += chunk_counts[((size_t)c * m + s) * k + j];
+    tot[j] = (j < k) ? total : 0;
+    __syncthreads();
+    // exclusive scan over clusters (k <= 256)
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        const uint32_t t = (j >= off) ? tot[j - off] : 0u;
+        __syncthreads();
+        tot[j] += t;
+        __syncthreads();
+    }
+    const uint32_t first = tot[j] - total;
+    if (j < k) {
+        start[s * (k + 1) + j] = first;
+        if (j == k - 1) start[s * (k + 1) + k] = tot[j];
+        uint32_t run = first;
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            uint32_t *p = &chunk_counts[((size_t)c * m + s) * k + j];
+            const uint32_t cnt = *p;
+            *p = run;
+            run += cnt;
+        }
+    }
+}
+
+// in-order scatter of row ids: one wave per (chunk, subspace); 64 consecutive rows per step
+__global__ __launch_bounds__(64) void k_bucket_scatter(const uint8_t *__restrict__ codes, uint64_t n, uint32_t m,
+                                                       uint32_t k, uint64_t rows_per_chunk,
+                                                       const uint8_t *__restrict__ active,
+                                                       const uint32_t *__restrict__ offsets,
+                                                       uint32_t *__restrict__ members, uint64_t members_stride) {
+    __shared__ uint32_t cur[256];
+    const uint32_t s = blockIdx.y, lane = threadIdx.x;
+    if (active && !active[s]) return;
+    for (uint32_t j = lane; j < k; j += 64) cur[j] = offsets[((size_t)blockIdx.x * m + s) * k + j];
+    const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_chunk;
+    uint64_t r1 = r0 + rows_per_chunk;
+    if (r1 > n) r1 = n;
+    uint32_t *dst = members + (size_t)s * members_stride;
+    for (uint64_t base = r0; base < r1; base += 64) {
+        const uint64_t row = base + lane;
+        const uint32_t code = (row < r1) ? (uint32_t)codes[row * m + s] : 0xFFFFFFFFu;
+        uint32_t rank = 0, later = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 64; ++q) {
+            const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)code, (int)q);
+            rank += (q < lane && cq == code) ? 1u : 0u;
+            later |= (q > lane && cq == code) ? 1u : 0u;
+        }
+        if (code != 0xFFFFFFFFu) {
+            const uint32_t pos = cur[code] + rank;
+            dst[pos] = (uint32_t)row;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (code != 0xFFFFFFFFu && !later) cur[code] += rank + 1;  // last row of its code in this step
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// one lane per (s, j, t): sequential f32 sum of the members in ascending row order
+__global__ __launch_bounds__(256) void k_chain_sums(const float *__restrict__ X, uint32_t d, uint32_t m, uint32_t k,
+                                                    uint32_t sd, const uint8_t *__restrict__ active,
+                                                    const uint32_t *__restrict__ start,
+                                                    const uint32_t *__restrict__ members, uint64_t members_stride,
+                                                    double *__restrict__ slab) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * k * sd) return;
+    const uint32_t sj = e / sd, t = e - sj * sd, s = sj / k, j = sj - s * k;
+    double *row = slab + (size_t)sj * (sd + 1);
+    if (active && !active[s]) {
+        row[t] = 0.0;
+        if (t == 0) row[sd] = 0.0;
+        return;
+    }
+    const uint32_t a = start[s * (k + 1) + j], b = start[s * (k + 1) + j + 1];
+    const uint32_t *mem = members + (size_t)s * members_stride;
+    const float *px = X + (size_t)s * sd + t;
+    float acc = 0.0f;  // vector.rs:374
+    uint32_t i = a;
+    constexpr int U = 16;
+    for (; i + U <= b; i += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = px[(size_t)mem[i + u] * d];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = acc + v[u];
+    }
+    for (; i < b; ++i) acc = acc + px[(size_t)mem[i] * d];
+    row[t] = (double)acc;
+    if (t == 0) row[sd] = (double)(b - a);
+}
+
+}  // namespace
+
+size_t exact_sums_workspace_bytes(uint32_t m, uint32_t k, uint64_t n) {
+    return ((size_t)m * n + (size_t)kXsChunks * m * k + (size_t)m * (k + 1)) * 4 + 256;
+}
+
+int launch_exact_sums(uint32_t m, uint32_t k, uint32_t sd, const float *X, uint64_t n, uint32_t d,
+                      const uint8_t *codes, const uint8_t *active, void *workspace, size_t workspace_bytes,
+                      double *slab, hipStream_t stream) {
+    if (k > 256) return fail(VQHIP_ERR_UNSUPPORTED, "exact update needs k <= 256");
+    if (workspace_bytes < exact_sums_workspace_bytes(m, k, n)) return fail(VQHIP_ERR_FAILURE, "exact-update workspace too small");
+    uint32_t *members = reinterpret_cast<uint32_t *>(workspace);
+    uint32_t *chunk_counts = members + (size_t)m * n;
+    uint32_t *start = chunk_counts + (size_t)kXsChunks * m * k;
+    uint32_t n_chunks = (uint32_t)std::min<uint64_t>(kXsChunks, (n + 255) / 256);
+    if (n_chunks < 1) n_chunks = 1;
+    const uint64_t rows_per_chunk = (n + n_chunks - 1) / n_chunks;
+    hipLaunchKernelGGL(k_chunk_counts, dim3(n_chunks, m), dim3(256), 0, stream, codes, n, m, k, rows_per_chunk, active,
+                       chunk_counts);
+    VQ_LAUNCH_CHECK("k_chunk_counts");
+    hipLaunchKernelGGL(k_bucket_offsets, dim3(m), dim3(256), 0, stream, chunk_counts, n_chunks, m, k, start);
+    VQ_LAUNCH_CHECK("k_bucket_offsets");
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(n_chunks, m), dim3(64), 0, stream, codes, n, m, k, rows_per_chunk, active,
+                       chunk_counts, members, n);
+    VQ_LAUNCH_CHECK("k_bucket_scatter");
+    const uint32_t total = m * k * sd;
+    hipLaunchKernelGGL(k_chain_sums, dim3((total + 255) / 256), dim3(256), 0, stream, X, d, m, k, sd, active, start,
+                       members, n, slab);
+    VQ_LAUNCH_CHECK("k_chain_sums");
+    return VQHIP_OK;
 }
 
 }  // namespace vqhip
