@@ -58,9 +58,10 @@ extern "C" {
 #define VQHIP_COSINE 3
 
 /* assignment engines (results are bit-identical; this is a speed/diagnostic knob) */
-#define VQHIP_ENGINE_AUTO 0  /* MFMA screen + exact re-check where supported, else exact */
+#define VQHIP_ENGINE_AUTO 0  /* fastest available: bf16-split MFMA screen, fp32 MFMA screen, exact */
 #define VQHIP_ENGINE_EXACT 1 /* exact VALU scan of every centroid */
-#define VQHIP_ENGINE_MFMA 2  /* force the MFMA screen (error if the shape is unsupported) */
+#define VQHIP_ENGINE_MFMA 2  /* fp32 MFMA screen + exact re-check (error if the shape is unsupported) */
+#define VQHIP_ENGINE_MFMA_BF16 3 /* 3-way bf16-split MFMA screen + exact re-check */
 
 typedef struct vqhip_dataset vqhip_dataset;
 typedef struct vqhip_kmeans vqhip_kmeans;

@@ -67,7 +67,10 @@ def test_gpu_reproduces_encode_fixture(name):
 
     g = _load(name)
     for metric, mname in METRICS:
-        for engine in (_lib.ENGINE_AUTO, _lib.ENGINE_EXACT):
+        engines = [_lib.ENGINE_AUTO, _lib.ENGINE_EXACT]
+        if metric in (0, 1):
+            engines += [_lib.ENGINE_MFMA, _lib.ENGINE_MFMA_BF16]
+        for engine in engines:
             enc = _lib.PQEncoder(g["codebooks"], metric)
             enc.set_engine(engine)
             codes, f16 = enc.encode(g["X"])

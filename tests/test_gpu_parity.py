@@ -70,6 +70,9 @@ def test_encode_l2_bit_exact(oracle, shape, kind, metric):
         cb[:, k // 2] = cb[:, 0]  # duplicate centroid: lower index must win
     _check_encode(oracle, X, cb, metric, _lib.ENGINE_AUTO)
     _check_encode(oracle, X, cb, metric, _lib.ENGINE_EXACT)
+    if d // m in (4, 8, 16, 32):
+        _check_encode(oracle, X, cb, metric, _lib.ENGINE_MFMA)       # fp32 MFMA screen
+        _check_encode(oracle, X, cb, metric, _lib.ENGINE_MFMA_BF16)  # bf16-split screen
 
 
 @pytest.mark.parametrize("shape", SHAPES[:5])
@@ -142,7 +145,7 @@ def test_encode_adversarial_near_ties(oracle):
     for metric in (O.SQUARED_EUCLIDEAN, O.EUCLIDEAN):
         _check_encode(oracle, X, cb, metric, _lib.ENGINE_AUTO)
     rechecked, engine = _check_encode.last_stats
-    assert engine == _lib.ENGINE_MFMA and rechecked > 0
+    assert engine in (_lib.ENGINE_MFMA, _lib.ENGINE_MFMA_BF16) and rechecked > 0
 
 
 def test_encode_ragged_sizes(oracle):
@@ -158,7 +161,7 @@ def test_encode_ragged_sizes(oracle):
 
 @pytest.mark.parametrize("shape", [(4000, 64, 4, 16), (6000, 128, 8, 256), (3000, 128, 16, 64)])
 @pytest.mark.parametrize("kind", ["uniform", "clustered"])
-@pytest.mark.parametrize("engine", [_lib.ENGINE_AUTO, _lib.ENGINE_EXACT])
+@pytest.mark.parametrize("engine", [_lib.ENGINE_AUTO, _lib.ENGINE_EXACT, _lib.ENGINE_MFMA])
 def test_lloyd_step_parity(oracle, shape, kind, engine):
     n, d, m, k = shape
     sd = d // m

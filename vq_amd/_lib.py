@@ -21,7 +21,7 @@ ERR_NULL_PTR, ERR_INVALID_INPUT, ERR_NO_DEVICE, ERR_RUNTIME, ERR_UNSUPPORTED, ER
     -1, -3, -4, -5, -6, -99)
 
 SQUARED_EUCLIDEAN, EUCLIDEAN, MANHATTAN, COSINE = 0, 1, 2, 3
-ENGINE_AUTO, ENGINE_EXACT, ENGINE_MFMA = 0, 1, 2
+ENGINE_AUTO, ENGINE_EXACT, ENGINE_MFMA, ENGINE_MFMA_BF16 = 0, 1, 2, 3
 
 _u8p = C.POINTER(C.c_uint8)
 _u16p = C.POINTER(C.c_uint16)

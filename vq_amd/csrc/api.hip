@@ -80,9 +80,10 @@ int current_stream(hipStream_t *out) {
 // ------------------------------------------------------------------ codebook state ----
 struct CodebookState {
     uint32_t m = 0, k = 0, sd = 0, nt = 0, ks = 0;
-    bool mfma_ok = false;
+    bool mfma_ok = false, bf16_ok = false;
     bool prepared = false;
-    DevBuf cb, prepA, prepCn, meta, cnsqrt;
+    DevBuf cb, prepA, prepCn, meta, cnsqrt, prepA16, prepA32;
+    bool x32_ok = false;
 
     int init(uint32_t m_, uint32_t k_, uint32_t sd_) {
         m = m_;
@@ -96,6 +97,10 @@ struct CodebookState {
             screen_tiling(sd, k, &nt, &ks);
             VQ_TRY(prepA.alloc((size_t)m * nt * ks * 64 * 4));
             VQ_TRY(prepCn.alloc((size_t)m * nt * 16 * 4));
+            bf16_ok = screen_bf16_supported(sd, k);
+            if (bf16_ok) VQ_TRY(prepA16.alloc((size_t)m * nt * screen_bf16_mfmas(sd) * 4 * 64 * 4));
+            x32_ok = bf16_ok && screen_bf16_x32_supported(sd, k);
+            if (x32_ok) VQ_TRY(prepA32.alloc((size_t)m * ((k + 31) / 32) * screen_bf16_x32_mfmas(sd) * 4 * 64 * 4));
         }
         prepared = false;
         return VQHIP_OK;
@@ -112,6 +117,8 @@ struct CodebookState {
         v.prepCn = mfma_ok ? prepCn.as<float>() : nullptr;
         v.meta = meta.as<float>();
         v.cnsqrt = cnsqrt.as<float>();
+        v.prepA16 = bf16_ok ? prepA16.as<uint32_t>() : nullptr;
+        v.prepA32 = x32_ok ? prepA32.as<uint32_t>() : nullptr;
         return v;
     }
     int prepare(hipStream_t stream) {
@@ -120,6 +127,8 @@ struct CodebookState {
         VQ_TRY(launch_prepare_codebook(v, mfma_ok ? prepA.as<float>() : nullptr,
                                        mfma_ok ? prepCn.as<float>() : nullptr, meta.as<float>(),
                                        cnsqrt.as<float>(), stream));
+        if (bf16_ok) VQ_TRY(launch_prepare_bf16(v, prepA16.as<uint32_t>(), stream));
+        if (x32_ok) VQ_TRY(launch_prepare_bf16_x32(v, prepA32.as<uint32_t>(), stream));
         prepared = true;
         return VQHIP_OK;
     }
@@ -127,7 +136,10 @@ struct CodebookState {
 
 // --------------------------------------------------------------- assign workspace ----
 struct AssignWorkspace {
-    DevBuf wl_rows, wl_count, sub_list;
+    DevBuf wl_rows, wl_count, sub_list, wl_seg;
+    static constexpr uint32_t kSegCap = 4096;  // wave-private work-list segments per subspace
+    uint32_t *seg_host = nullptr;               // pinned [m][kSegCap][2]
+    uint32_t last_n_seg = 0;
     uint64_t wl_stride = 0;
     uint32_t wl_m = 0;
     std::vector<uint32_t> sub_host;
@@ -137,6 +149,7 @@ struct AssignWorkspace {
     int last_engine = 0;
     ~AssignWorkspace() {
         if (stats_host) (void)hipHostFree(stats_host);
+        if (seg_host) (void)hipHostFree(seg_host);
     }
     int ensure(uint32_t m, uint64_t n, bool need_wl) {
         if (!sub_list.p || sub_list.bytes < (size_t)m * 4) VQ_TRY(sub_list.alloc((size_t)m * 4));
@@ -147,6 +160,10 @@ struct AssignWorkspace {
             VQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&stats_host), (size_t)m * 4));
             memset(stats_host, 0, (size_t)m * 4);
             stats_m = m;
+            VQ_TRY(wl_seg.alloc((size_t)m * kSegCap * 8));
+            if (seg_host) (void)hipHostFree(seg_host);
+            seg_host = nullptr;
+            VQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&seg_host), (size_t)m * kSegCap * 8));
         }
         if (need_wl && (wl_stride < n || wl_m < m)) {
             VQ_TRY(wl_rows.alloc((size_t)m * (size_t)n * 4));
@@ -181,11 +198,19 @@ static int pick_engine(int requested, const CodebookState &cs, int metric, int *
         *engine = VQHIP_ENGINE_EXACT;
     } else if (requested == VQHIP_ENGINE_MFMA) {
         if (!cs.mfma_ok || !mfma_metric)
-            return fail(VQHIP_ERR_UNSUPPORTED, "MFMA engine unavailable for sub_dim=%u k=%u metric=%d",
+            return fail(VQHIP_ERR_UNSUPPORTED, "fp32 MFMA engine unavailable for sub_dim=%u k=%u metric=%d",
                         cs.sd, cs.k, metric);
         *engine = VQHIP_ENGINE_MFMA;
+    } else if (requested == VQHIP_ENGINE_MFMA_BF16) {
+        if (!cs.bf16_ok || !mfma_metric)
+            return fail(VQHIP_ERR_UNSUPPORTED, "bf16 MFMA engine unavailable for sub_dim=%u k=%u metric=%d",
+                        cs.sd, cs.k, metric);
+        *engine = VQHIP_ENGINE_MFMA_BF16;
     } else {
-        *engine = (cs.mfma_ok && mfma_metric) ? VQHIP_ENGINE_MFMA : VQHIP_ENGINE_EXACT;
+        *engine = !mfma_metric ? VQHIP_ENGINE_EXACT
+                  : cs.bf16_ok ? VQHIP_ENGINE_MFMA_BF16
+                  : cs.mfma_ok ? VQHIP_ENGINE_MFMA
+                               : VQHIP_ENGINE_EXACT;
     }
     return VQHIP_OK;
 }
@@ -201,7 +226,8 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
     int engine = 0;
     VQ_TRY(pick_engine(engine_req, cs, metric, &engine));
     VQ_TRY(cs.prepare(stream));
-    VQ_TRY(ws.ensure(cs.m, n, engine == VQHIP_ENGINE_MFMA));
+    const bool screened = (engine == VQHIP_ENGINE_MFMA || engine == VQHIP_ENGINE_MFMA_BF16);
+    VQ_TRY(ws.ensure(cs.m, n, screened));
     VQ_TRY(ws.set_sub_list(subs, stream));
     AssignArgs a;
     a.X = X;
@@ -214,6 +240,9 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
     a.wl_rows = ws.wl_rows.as<uint32_t>();
     a.wl_count = ws.wl_count.as<uint32_t>();
     a.wl_stride = ws.wl_stride;
+    a.wl_seg = ws.wl_seg.as<uint32_t>();
+    a.wl_seg_cap = AssignWorkspace::kSegCap;
+    a.n_seg = 0;
     CodebookView v = cs.view();
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (g_prof.on) {
@@ -225,14 +254,19 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
         g_prof.ev.push_back(e2);
         g_prof.engines.push_back(engine);
     }
-    if (engine == VQHIP_ENGINE_MFMA) {
+    if (screened) {
         VQ_HIP(hipMemsetAsync(ws.wl_count.p, 0, (size_t)cs.m * 4, stream));
         if (e0) VQ_HIP(hipEventRecord(e0, stream));
-        VQ_TRY(launch_assign_screen(v, a, stream));
+        if (engine == VQHIP_ENGINE_MFMA_BF16) VQ_TRY(launch_assign_screen_bf16(v, a, stream));
+        else VQ_TRY(launch_assign_screen(v, a, stream));
         if (e1) VQ_HIP(hipEventRecord(e1, stream));
         VQ_TRY(launch_assign_exact(v, a, true, stream));
         if (e2) VQ_HIP(hipEventRecord(e2, stream));
-        VQ_HIP(hipMemcpyAsync(ws.stats_host, ws.wl_count.p, (size_t)cs.m * 4, hipMemcpyDeviceToHost, stream));
+        ws.last_n_seg = a.n_seg;
+        if (a.n_seg > 0)
+            VQ_HIP(hipMemcpyAsync(ws.seg_host, ws.wl_seg.p, (size_t)cs.m * a.n_seg * 8, hipMemcpyDeviceToHost, stream));
+        else
+            VQ_HIP(hipMemcpyAsync(ws.stats_host, ws.wl_count.p, (size_t)cs.m * 4, hipMemcpyDeviceToHost, stream));
         ws.stats_pending = true;
     } else {
         if (e0) VQ_HIP(hipEventRecord(e0, stream));
@@ -357,7 +391,11 @@ int vqhip_last_assign_stats(uint64_t *rechecked, int *engine) {
             VQ_TRY(current_stream(&s));
             VQ_HIP(hipStreamSynchronize(s));
             uint64_t tot = 0;
-            for (uint32_t i = 0; i < ws->stats_m; ++i) tot += ws->stats_host[i];
+            if (ws->last_n_seg > 0) {
+                for (size_t i = 0; i < (size_t)ws->stats_m * ws->last_n_seg; ++i) tot += ws->seg_host[2 * i + 1];
+            } else {
+                for (uint32_t i = 0; i < ws->stats_m; ++i) tot += ws->stats_host[i];
+            }
             *rechecked = tot;
         }
     }
@@ -596,7 +634,7 @@ int vqhip_kmeans_set_active(vqhip_kmeans *km, const uint8_t *active) {
 
 int vqhip_kmeans_set_engine(vqhip_kmeans *km, int engine) {
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
-    if (engine < VQHIP_ENGINE_AUTO || engine > VQHIP_ENGINE_MFMA) return fail(VQHIP_ERR_INVALID_INPUT, "unknown engine %d", engine);
+    if (engine < VQHIP_ENGINE_AUTO || engine > VQHIP_ENGINE_MFMA_BF16) return fail(VQHIP_ERR_INVALID_INPUT, "unknown engine %d", engine);
     km->engine = engine;
     return VQHIP_OK;
 }
@@ -738,7 +776,7 @@ int vqhip_pq_encoder_destroy(vqhip_pq_encoder *enc) {
 
 int vqhip_pq_encoder_set_engine(vqhip_pq_encoder *enc, int engine) {
     if (!enc) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
-    if (engine < VQHIP_ENGINE_AUTO || engine > VQHIP_ENGINE_MFMA) return fail(VQHIP_ERR_INVALID_INPUT, "unknown engine %d", engine);
+    if (engine < VQHIP_ENGINE_AUTO || engine > VQHIP_ENGINE_MFMA_BF16) return fail(VQHIP_ERR_INVALID_INPUT, "unknown engine %d", engine);
     enc->engine = engine;
     return VQHIP_OK;
 }

@@ -190,17 +190,31 @@ __global__ __launch_bounds__(256) void k_recheck_wave(
     const float *__restrict__ X, uint32_t d, uint32_t m, uint32_t k,
     const float *__restrict__ cb, const float *__restrict__ cnsqrt,
     const uint32_t *__restrict__ sub_list, const uint32_t *__restrict__ wl_rows,
-    const uint32_t *__restrict__ wl_count, uint64_t wl_stride, uint8_t *__restrict__ codes) {
+    const uint32_t *__restrict__ wl_count, uint64_t wl_stride, const uint32_t *__restrict__ wl_seg,
+    uint32_t n_seg, uint8_t *__restrict__ codes) {
     const uint32_t s = sub_list ? sub_list[blockIdx.y] : blockIdx.y;
-    const uint32_t count = wl_count[s];
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * 4;
+    // two work-list forms: one global list per subspace (count in wl_count[s]), or wave-private
+    // segments written without atomics by the X32 screen (wl_seg[s][seg] = {first slot, count});
+    // in the segmented form workgroup blockIdx.x owns segment blockIdx.x
+    uint32_t count, first, wave, n_waves;
+    if (wl_seg) {
+        const uint32_t *sg = wl_seg + ((size_t)s * n_seg + blockIdx.x) * 2;
+        first = sg[0];
+        count = sg[1];
+        wave = threadIdx.x >> 6;
+        n_waves = 4;
+    } else {
+        first = 0;
+        count = wl_count[s];
+        wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+        n_waves = gridDim.x * 4;
+    }
     const float *cbs = cb + (size_t)s * k * SD;
     const float *cnsq = cnsqrt ? cnsqrt + (size_t)s * k : nullptr;
     const uint32_t NONE = 0xFFFFFFFFu;
     for (uint32_t i = wave; i < count; i += n_waves) {
-        const uint64_t row = wl_rows[(size_t)s * wl_stride + i];
+        const uint64_t row = wl_rows[(size_t)s * wl_stride + first + i];
         const float *xrow = X + row * d + (size_t)s * SD;
         float x[SD];
 #pragma unroll
@@ -290,8 +304,16 @@ __global__ __launch_bounds__(256) void k_prepare_codebook(const float *__restric
         float coef = (8.0f * (float)sd + 16.0f) * u;
         meta[s * 4 + 0] = sqrtf(s_max[0]) * 1.0000005f + 1e-30f;
         meta[s * 4 + 1] = s_bad[0] ? __builtin_inff() : coef;
-        meta[s * 4 + 2] = 0.0f;
-        meta[s * 4 + 3] = 0.0f;
+        // bf16-split screen (k_screen_bf16.hip): + 32 per MFMA (eps_M = 16 * 2^-24, both ends of
+        // the gap) + 16 for the dropped cross terms
+        float coef16 = __builtin_inff();
+        if (sd % 4 == 0 && sd >= 4 && sd <= 32) {
+            const uint32_t dpg = sd / 4, pp = 8 / dpg, nm = (6 + pp - 1) / pp;
+            coef16 = (8.0f * (float)sd + 16.0f + 32.0f * (float)nm + 16.0f) * u;
+        }
+        meta[s * 4 + 2] = s_bad[0] ? __builtin_inff() : coef16;
+        // X32 variant packs a 6-bit index into the low mantissa bits: |perturbation| < 2^-18 |s|
+        meta[s * 4 + 3] = s_bad[0] ? __builtin_inff() : coef16 + 128.0f * u;
     }
     if (prepA) {
         // A operand of v_mfma_f32_16x16x4_f32: lane l holds A[row = l&15][k = l>>4].  Tile i,
@@ -363,12 +385,14 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
     const uint32_t *wlr = wl ? a.wl_rows : nullptr;
     const uint32_t *wlc = wl ? a.wl_count : nullptr;
     if (wl) {
-        const dim3 wgrid((uint32_t)num_cus() * 4, a.n_sub);
+        const bool seg = (a.wl_seg != nullptr && a.n_seg > 0);
+        const dim3 wgrid(seg ? a.n_seg : (uint32_t)num_cus() * 4, a.n_sub);
+        const uint32_t *wls = seg ? a.wl_seg : nullptr;
 #define VQ_RECHECK_CASE(SDV)                                                                   \
     case SDV:                                                                                  \
         hipLaunchKernelGGL((k_recheck_wave<METRIC, SDV>), wgrid, dim3(256), 0, stream, a.X, a.d, \
                            cb.m, cb.k, cb.cb, cb.cnsqrt, a.sub_list, wlr, wlc, a.wl_stride,     \
-                           a.codes);                                                           \
+                           wls, a.n_seg, a.codes);                                                           \
         VQ_LAUNCH_CHECK("k_recheck_wave");                                                     \
         return VQHIP_OK;
         switch (cb.sd) {

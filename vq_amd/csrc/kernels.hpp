@@ -18,11 +18,21 @@ struct CodebookView {
     const float *prepCn = nullptr;   // [m][nt*16]        |c|^2 (padding = +inf)
     const float *meta = nullptr;     // [m][4]            {max|c|, margin coefficient, -, -}
     const float *cnsqrt = nullptr;   // [m][k]            sqrt(sum c^2) (cosine's norm_b)
+    const uint32_t *prepA16 = nullptr;  // [m][nt][NM][4][64] packed bf16 slices of -2*c (bf16 screen)
+    const uint32_t *prepA32 = nullptr;  // [m][ceil(k/32)][NMF][4][64] same, 32x32x16 MFMA lane order
 };
 
 // MFMA screen availability for a shape
 bool screen_supported(uint32_t sd, uint32_t k);
 void screen_tiling(uint32_t sd, uint32_t k, uint32_t *nt, uint32_t *ks);
+
+// bf16-split screen (k_screen_bf16.hip)
+bool screen_bf16_supported(uint32_t sd, uint32_t k);
+uint32_t screen_bf16_mfmas(uint32_t sd);
+int launch_prepare_bf16(const CodebookView &v, uint32_t *prepA16, hipStream_t stream);
+bool screen_bf16_x32_supported(uint32_t sd, uint32_t k);
+uint32_t screen_bf16_x32_mfmas(uint32_t sd);
+int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, hipStream_t stream);
 
 int launch_prepare_codebook(const CodebookView &v, float *prepA, float *prepCn, float *meta,
                             float *cnsqrt, hipStream_t stream);
@@ -40,6 +50,11 @@ struct AssignArgs {
     uint32_t *wl_rows = nullptr;   // [m][wl_stride]
     uint32_t *wl_count = nullptr;  // [m]
     uint64_t wl_stride = 0;
+    // segmented form (wave-private segments, no atomics): wl_seg [m][n_seg][2] = {first slot, count};
+    // a screen launch that uses it sets n_seg (> 0) for the re-check launch that follows
+    uint32_t *wl_seg = nullptr;
+    uint32_t wl_seg_cap = 0;
+    mutable uint32_t n_seg = 0;
 };
 
 // exact VALU scan of every centroid (reference op order); if use_worklist, only the rows
@@ -49,6 +64,7 @@ int launch_assign_exact(const CodebookView &cb, const AssignArgs &a, bool use_wo
 // MFMA screen: writes a provisional code for every row and appends the rows whose winner is
 // not provably the reference's to the work lists (wl_count must be zeroed before)
 int launch_assign_screen(const CodebookView &cb, const AssignArgs &a, hipStream_t stream);
+int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipStream_t stream);
 
 // out[i] = metric(a[i], b[i]) in the reference's arithmetic (Distance::compute)
 int launch_distance_batch(int metric, const float *a, const float *b, uint64_t n, uint32_t d,
