@@ -63,6 +63,25 @@ def cpu_baseline(m, k, dim, codebooks, target_seconds=12.0):
     return out
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary (separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/run_profile.sh).  Units are KiB; FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md prescribes for gfx950 (it reports half of a coalesced stream).
+    Returns (bytes or None, source)."""
+    import glob
+
+    base = kernel_name.split("<")[0]
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(path)).get(base)
+            if d and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                kib = 2.0 * d["FETCH_SIZE"]["avg_per_launch"] + d["WRITE_SIZE"]["avg_per_launch"]
+                return kib * 1024.0, os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,7 +90,7 @@ def main():
     ap.add_argument("--rows", type=int, default=N_PER_GPU, help="rows per GPU (default: the workload's)")
     ap.add_argument("--kmeans-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--engine", choices=["auto", "exact", "mfma"], default="auto")
+    ap.add_argument("--engine", choices=["auto", "exact", "mfma", "bf16"], default="auto")
     args = ap.parse_args()
 
     import numpy as np
@@ -99,7 +118,8 @@ def main():
     _lib.load()
     _lib.set_device(local_rank)
     stream = torch.cuda.Stream()
-    engine = {"auto": _lib.ENGINE_AUTO, "exact": _lib.ENGINE_EXACT, "mfma": _lib.ENGINE_MFMA}[args.engine]
+    engine = {"auto": _lib.ENGINE_AUTO, "exact": _lib.ENGINE_EXACT, "mfma": _lib.ENGINE_MFMA,
+              "bf16": _lib.ENGINE_MFMA_BF16}[args.engine]
 
     def barrier():
         if world > 1:
@@ -180,6 +200,8 @@ def main():
         flop_per_row = 2.0 * K * DIM  # the -2.x.c contraction only
         kern_s = primary_ms / 1e3 / max(calls, 1)
         achieved = flop_per_row * n / kern_s / 1e12 if kern_s > 0 else 0.0
+        kernel_name = {2: "k_assign_screen<16,16>", 3: "k_assign_screen_bf16_x32<16,8>"}.get(used_engine, "k_assign_exact")
+        traffic, traffic_src = pmc_traffic(kernel_name) if n == N_PER_GPU else (None, None)
         line = {
             "metric": "pq_encode_vectors_per_s",
             "value": value,
@@ -197,13 +219,17 @@ def main():
                 "workload": f"PQ m={M} k={K} L2 encode on {n}x{DIM} f32 rows per GPU, device-resident "
                             "(BASELINE.json configs[1]); codes out (1 byte per subspace)",
                 "rows_per_gpu": n, "dim": DIM, "m": M, "k": K, "sub_dim": DIM // M,
-                "engine": {1: "exact", 2: "mfma_screen+exact_recheck"}.get(used_engine, str(used_engine)),
+                "engine": {1: "exact", 2: "fp32_mfma_screen+exact_recheck",
+                           3: "bf16x3_mfma_screen+exact_recheck"}.get(used_engine, str(used_engine)),
                 "recheck_fraction": rechecked / float(n * M),
                 "codebooks": f"{TRAIN_ITERS} Lloyd iterations from strided init rows",
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "k_assign_screen<16,16>" if used_engine == 2 else "k_assign_exact",
+                "kernel": kernel_name,
+                "note": "achieved = algorithmic 2*k*D flop per row / device time of the screen kernel; with the "
+                        "bf16-split engine the contraction runs as 6 bf16 products per fp32 product on the bf16 "
+                        "matrix pipe and the kernel is VALU-bound (epilogue), see DESIGN.md 4.1",
                 "achieved": achieved,
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
@@ -211,7 +237,9 @@ def main():
                 "flop_per_launch": flop_per_row * n,
                 "avg_launch_ms": kern_s * 1e3,
                 "recheck_avg_launch_ms": recheck_ms / max(calls, 1),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": (4.0 * DIM + M) * n,
             },
             "kmeans_iter_per_s": args.kmeans_iters / km_dt,
             "kmeans_ms_per_iter": km_dt / args.kmeans_iters * 1e3,

@@ -74,7 +74,7 @@ def pq_config(name, n, d, m, k, metric_name, iters=10, encode_reps=5):
         "kmeans_ms_per_iter": fit_s / iters * 1e3, "kmeans_iter_per_s": iters / fit_s,
         "encode_vectors_per_s": n / enc_s, "encode_ms": enc_s * 1e3,
         "encode_f16_out_vectors_per_s": n / enc16_s,
-        "engine": {1: "exact", 2: "mfma_screen+exact_recheck"}[engine],
+        "engine": {1: "exact", 2: "fp32_mfma_screen+exact_recheck", 3: "bf16x3_mfma_screen+exact_recheck"}[engine],
         "recheck_fraction": rechecked / float(n * m),
         "primary_kernel_ms": prim_ms / max(calls, 1), "recheck_kernel_ms": re_ms / max(calls, 1),
         "algorithmic_tflops": flop / enc_s / 1e12,

@@ -127,8 +127,9 @@ struct CodebookState {
         VQ_TRY(launch_prepare_codebook(v, mfma_ok ? prepA.as<float>() : nullptr,
                                        mfma_ok ? prepCn.as<float>() : nullptr, meta.as<float>(),
                                        cnsqrt.as<float>(), stream));
-        if (bf16_ok) VQ_TRY(launch_prepare_bf16(v, prepA16.as<uint32_t>(), stream));
-        if (x32_ok) VQ_TRY(launch_prepare_bf16_x32(v, prepA32.as<uint32_t>(), stream));
+        const bool use32 = x32_ok && screen_bf16_uses_x32(sd, k);
+        if (bf16_ok && !use32) VQ_TRY(launch_prepare_bf16(v, prepA16.as<uint32_t>(), stream));
+        if (use32) VQ_TRY(launch_prepare_bf16_x32(v, prepA32.as<uint32_t>(), stream));
         prepared = true;
         return VQHIP_OK;
     }

@@ -186,7 +186,7 @@ __device__ __forceinline__ float exact_dist_fixed(const float (&x)[SD], const fl
 // sequential first-minimum scan as long as centroid 0's distance is not NaN; if it is, no
 // later `dist < best` can ever be true and the answer is 0 (src/pq.rs:184-190).
 template <int METRIC, int SD>
-__global__ __launch_bounds__(256) void k_recheck_wave(
+__global__ __launch_bounds__(1024) void k_recheck_wave(
     const float *__restrict__ X, uint32_t d, uint32_t m, uint32_t k,
     const float *__restrict__ cb, const float *__restrict__ cnsqrt,
     const uint32_t *__restrict__ sub_list, const uint32_t *__restrict__ wl_rows,
@@ -203,12 +203,12 @@ __global__ __launch_bounds__(256) void k_recheck_wave(
         first = sg[0];
         count = sg[1];
         wave = threadIdx.x >> 6;
-        n_waves = 4;
+        n_waves = blockDim.x >> 6;
     } else {
         first = 0;
         count = wl_count[s];
-        wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-        n_waves = gridDim.x * 4;
+        wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        n_waves = gridDim.x * (blockDim.x >> 6);
     }
     const float *cbs = cb + (size_t)s * k * SD;
     const float *cnsq = cnsqrt ? cnsqrt + (size_t)s * k : nullptr;
@@ -390,7 +390,7 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
         const uint32_t *wls = seg ? a.wl_seg : nullptr;
 #define VQ_RECHECK_CASE(SDV)                                                                   \
     case SDV:                                                                                  \
-        hipLaunchKernelGGL((k_recheck_wave<METRIC, SDV>), wgrid, dim3(256), 0, stream, a.X, a.d, \
+        hipLaunchKernelGGL((k_recheck_wave<METRIC, SDV>), wgrid, dim3(seg ? 1024 : 256), 0, stream, a.X, a.d, \
                            cb.m, cb.k, cb.cb, cb.cnsqrt, a.sub_list, wlr, wlc, a.wl_stride,     \
                            wls, a.n_seg, a.codes);                                                           \
         VQ_LAUNCH_CHECK("k_recheck_wave");                                                     \

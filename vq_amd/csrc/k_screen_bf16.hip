@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_prepare_bf16(const float *__restrict__ 
     const uint32_t dpg = sd / 4, pp = 8 / dpg;
     const float *cbs = cb + (size_t)s * k * sd;
     const uint32_t total = nt * nm * 4 * 64;
-    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+    for (uint32_t e = blockIdx.y * blockDim.x + threadIdx.x; e < total; e += gridDim.y * blockDim.x) {
         const uint32_t lane = e & 63, w = (e >> 6) & 3, r = (e >> 8) % nm, i = (e >> 8) / nm;
         const uint32_t g = lane >> 4, c = lane & 15, j = 16 * i + c;
         uint32_t half[2] = {0u, 0u};
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
     const uint32_t dph = sd / 2, ppm = 8 / dph;
     const float *cbs = cb + (size_t)s * k * sd;
     const uint32_t total = nt32 * nmf * 4 * 64;
-    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+    for (uint32_t e = blockIdx.y * blockDim.x + threadIdx.x; e < total; e += gridDim.y * blockDim.x) {
         const uint32_t lane = e & 63, w = (e >> 6) & 3, f = (e >> 8) % nmf, i = (e >> 8) / nmf;
         const uint32_t h = lane >> 5, c = lane & 31, j = 32 * i + c;
         uint32_t half[2] = {0u, 0u};
@@ -1379,6 +1379,12 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
 
 }  // namespace
 
+// true when launch_assign_screen_bf16 will take the X32 path (so only that image is needed)
+bool screen_bf16_uses_x32(uint32_t sd, uint32_t k) {
+    const char *variant = getenv("VQHIP_BF16_VARIANT");
+    return (!variant || variant[0] == 'x') && screen_bf16_x32_supported(sd, k);
+}
+
 bool screen_bf16_x32_supported(uint32_t sd, uint32_t k) {
     if (!(sd == 8 || sd == 16)) return false;
     if (k == 0 || k > 256) return false;
@@ -1390,7 +1396,7 @@ uint32_t screen_bf16_x32_mfmas(uint32_t sd) {
 }
 int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, hipStream_t stream) {
     if (v.m == 0) return VQHIP_OK;
-    hipLaunchKernelGGL(k_prepare_bf16_x32, dim3(v.m), dim3(256), 0, stream, v.cb, v.m, v.k, v.sd, (v.k + 31) / 32,
+    hipLaunchKernelGGL(k_prepare_bf16_x32, dim3(v.m, 16), dim3(256), 0, stream, v.cb, v.m, v.k, v.sd, (v.k + 31) / 32,
                        screen_bf16_x32_mfmas(v.sd), prepA32);
     VQ_LAUNCH_CHECK("k_prepare_bf16_x32");
     return VQHIP_OK;
@@ -1415,7 +1421,7 @@ bool screen_bf16_supported(uint32_t sd, uint32_t k) {
 
 int launch_prepare_bf16(const CodebookView &v, uint32_t *prepA16, hipStream_t stream) {
     if (v.m == 0) return VQHIP_OK;
-    hipLaunchKernelGGL(k_prepare_bf16, dim3(v.m), dim3(256), 0, stream, v.cb, v.m, v.k, v.sd, v.nt,
+    hipLaunchKernelGGL(k_prepare_bf16, dim3(v.m, 16), dim3(256), 0, stream, v.cb, v.m, v.k, v.sd, v.nt,
                        screen_bf16_mfmas(v.sd), prepA16);
     VQ_LAUNCH_CHECK("k_prepare_bf16");
     return VQHIP_OK;

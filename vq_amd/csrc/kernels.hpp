@@ -31,6 +31,7 @@ bool screen_bf16_supported(uint32_t sd, uint32_t k);
 uint32_t screen_bf16_mfmas(uint32_t sd);
 int launch_prepare_bf16(const CodebookView &v, uint32_t *prepA16, hipStream_t stream);
 bool screen_bf16_x32_supported(uint32_t sd, uint32_t k);
+bool screen_bf16_uses_x32(uint32_t sd, uint32_t k);
 uint32_t screen_bf16_x32_mfmas(uint32_t sd);
 int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, hipStream_t stream);
 
