@@ -1,0 +1,48 @@
+"""GPU side of the row-sharded driver with a single rank: the libvqhip back end (HipShard), the
+zero-copy view of the f64 slab that the all-reduce operates on, and equality of the sharded
+control flow with the plain fit.  (world_size 2 is covered on CPU ranks, test_sharded_gloo.py;
+the 8-GPU run is the driver's.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def test_hipshard_slab_aliases_library_buffer_and_fit_matches():
+    import torch
+
+    from vq_amd import _lib
+    from vq_amd.pq import fit_codebooks
+    from vq_amd.sharded import Comm, HipShard, ShardedKMeans
+
+    n, d, m, k = 6000, 64, 4, 32
+    X = np.random.default_rng(5).random((n, d), dtype=F)
+    init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.int64)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        _lib.set_stream(stream.cuda_stream)
+        try:
+            ds = _lib.Dataset.from_host(X)
+            shard = HipShard(ds, m, k, 0)
+            skm = ShardedKMeans(shard, n, Comm())
+            skm.init_from_global_rows(init)
+            shard.accumulate()
+            t = shard.slab()
+            ptr, cnt = shard.km.partials()
+            assert t.dtype == torch.float64 and t.numel() == cnt == m * k * (d // m + 1)
+            assert shard._slab_alias and t.data_ptr() == ptr  # zero copy
+            slab = t.cpu().numpy().reshape(m, k, d // m + 1)
+            assert slab[:, :, -1].sum() == n * m  # counts column
+            np.testing.assert_allclose(slab[:, :, :-1].sum(axis=1).reshape(-1),
+                                       X.astype(np.float64).sum(axis=0), rtol=1e-6)
+            shard.commit_slab()
+            counts, changed = shard.finalize()
+            assert counts.sum() == n * m
+            cb = skm.fit(6, seed=3, init_rows=init, reseed_rows=[[1] * 32] * m)
+            cb_ref = fit_codebooks(ds, m, k, 6, init_rows=init.astype(np.uint64), reseed_rows=[[1] * 32] * m)
+            np.testing.assert_array_equal(cb, cb_ref)
+            shard.close()
+            ds.close()
+        finally:
+            _lib.set_stream(None)
