@@ -4,7 +4,7 @@ headline contract).  One JSON line per configuration on one MI355X:
 
   C1  PQ m=4  k=16  Euclidean, 10k x 64     (the reference's own CPU-sized case)
   C2  PQ m=8  k=256 L2,        1M x 128     fit (10 Lloyd iterations) + encode
-  C3  PQ m=96 k=256 cosine,    1M x 768     fit + cosine encode (exact VALU engine)
+  C3  PQ m=96 k=256 cosine,    1M x 768     fit + cosine encode (bf16 MFMA cosine screen + exact re-check)
   C4  TSVQ depth 8 L2,         1M x 128     build + encode
   C5  PQ m=16 k=256 L2,        per-GPU shard of 100M x 128 (12.5M rows) fit iteration + encode
 

@@ -88,6 +88,61 @@ def test_encode_l1_cosine_bit_exact(oracle, shape, kind, metric):
     _check_encode(oracle, X, cb, metric, _lib.ENGINE_AUTO)
 
 
+COSINE_SHAPES = [(3000, 64, 4, 16), (2500, 128, 8, 256), (1000, 128, 16, 256), (1200, 768, 96, 256),
+                 (1500, 64, 8, 37)]
+
+
+@pytest.mark.parametrize("shape", COSINE_SHAPES)
+@pytest.mark.parametrize("kind", ["uniform", "normal", "lattice", "clustered"])
+def test_encode_cosine_screen_bit_exact(oracle, shape, kind):
+    """Cosine on the bf16 MFMA screen (s_j = -x.c_j/|c_j|, sub_dim 8 / 16) + exact re-check."""
+    n, d, m, k = shape
+    X = _data(41, n, d, kind)
+    cb = _data(42, m * k, d // m, kind).reshape(m, k, d // m)
+    if kind == "lattice":
+        cb[:, k // 2] = cb[:, 0]           # duplicate centroid
+        cb[:, 3] = 2.0 * cb[:, 1]          # parallel centroid: cosine tie up to rounding
+        cb[:, 2] = 0.0                     # zero centroid: distance 1.0 (src/core/distance.rs:113-115)
+        X[::7] = 0.0                       # zero rows: every distance 1.0 -> code 0
+    _check_encode(oracle, X, cb, O.COSINE, _lib.ENGINE_MFMA_BF16)
+    rechecked, engine = _check_encode.last_stats
+    assert engine == _lib.ENGINE_MFMA_BF16
+    if kind in ("uniform", "normal"):
+        assert rechecked < 0.2 * n * m     # the screen decides most rows
+    _check_encode(oracle, X, cb, O.COSINE, _lib.ENGINE_AUTO)
+    assert _check_encode.last_stats[1] == _lib.ENGINE_MFMA_BF16
+
+
+def test_encode_cosine_screen_adversarial(oracle):
+    """Rows whose best cosine is <= 0 (every distance may clamp to 1.0), rows near the 1e-10 norm
+    cut-off, centroids below it, scaled copies of one direction and non-finite values."""
+    rng = np.random.default_rng(43)
+    n, d, m, k = 4096, 32, 2, 64
+    sd = d // m
+    cb = rng.standard_normal((m, k, sd)).astype(F)
+    cb[:, 5] = cb[:, 4] * F(3.0)           # same direction
+    cb[:, 6] = cb[:, 4] * F(1.0000001)
+    cb[:, 7] = 1e-12                       # below the norm cut-off
+    cb[:, 8] = 3e-10
+    X = rng.standard_normal((n, d)).astype(F)
+    X[:256] = -np.abs(X[:256])
+    cb_pos = np.abs(cb)
+    X[256:512] *= 1e-10
+    X[512:768] *= 3e-11
+    X[768:1024] *= 1e-9
+    X[1024:1100] = np.tile(cb[0, 4], m)[None, :] * rng.random((76, 1), dtype=F)  # exactly parallel to 4,5,6
+    X[1100:1200] *= 1e18
+    for codebook in (cb, cb_pos):
+        _check_encode(oracle, X, codebook, O.COSINE, _lib.ENGINE_MFMA_BF16)
+    Xn = X.copy()
+    Xn[5, 3] = np.nan
+    Xn[6, 17] = np.inf
+    _check_encode(oracle, Xn, cb, O.COSINE, _lib.ENGINE_MFMA_BF16)
+    cbn = cb.copy()
+    cbn[1, 9, 2] = np.nan
+    _check_encode(oracle, X, cbn, O.COSINE, _lib.ENGINE_MFMA_BF16)
+
+
 def test_encode_codebook_rows_are_their_own_code(oracle):
     # k = N distinct rows (tests/regression_tests.rs:357-363 generalised): quantize(x_i) == f16(x_i)
     rng = np.random.default_rng(5)

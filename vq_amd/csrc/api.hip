@@ -82,6 +82,7 @@ struct CodebookState {
     uint32_t m = 0, k = 0, sd = 0, nt = 0, ks = 0;
     bool mfma_ok = false, bf16_ok = false;
     bool prepared = false;
+    int metric = VQHIP_SQUARED_EUCLIDEAN;  // what the prepared images are for (cosine differs)
     DevBuf cb, prepA, prepCn, meta, cnsqrt, prepA16, prepA32;
     bool x32_ok = false;
 
@@ -129,7 +130,7 @@ struct CodebookState {
                                        cnsqrt.as<float>(), stream));
         const bool use32 = x32_ok && screen_bf16_uses_x32(sd, k);
         if (bf16_ok && !use32) VQ_TRY(launch_prepare_bf16(v, prepA16.as<uint32_t>(), stream));
-        if (use32) VQ_TRY(launch_prepare_bf16_x32(v, prepA32.as<uint32_t>(), stream));
+        if (use32) VQ_TRY(launch_prepare_bf16_x32(v, prepA32.as<uint32_t>(), metric == VQHIP_COSINE ? 1 : 0, stream));
         prepared = true;
         return VQHIP_OK;
     }
@@ -194,24 +195,28 @@ struct ProfileState {
 static thread_local ProfileState g_prof;
 
 static int pick_engine(int requested, const CodebookState &cs, int metric, int *engine) {
-    const bool mfma_metric = (metric == VQHIP_SQUARED_EUCLIDEAN || metric == VQHIP_EUCLIDEAN);
+    const bool l2_metric = (metric == VQHIP_SQUARED_EUCLIDEAN || metric == VQHIP_EUCLIDEAN);
+    // cosine has a screen too (s = -x.c/|c| on the X32 bf16 engine); Manhattan has no contraction form
+    const bool cos_ok = (metric == VQHIP_COSINE) && cs.x32_ok && screen_bf16_uses_x32(cs.sd, cs.k) &&
+                        cs.metric == VQHIP_COSINE;
     if (requested == VQHIP_ENGINE_EXACT) {
         *engine = VQHIP_ENGINE_EXACT;
     } else if (requested == VQHIP_ENGINE_MFMA) {
-        if (!cs.mfma_ok || !mfma_metric)
+        if (!cs.mfma_ok || !l2_metric)
             return fail(VQHIP_ERR_UNSUPPORTED, "fp32 MFMA engine unavailable for sub_dim=%u k=%u metric=%d",
                         cs.sd, cs.k, metric);
         *engine = VQHIP_ENGINE_MFMA;
     } else if (requested == VQHIP_ENGINE_MFMA_BF16) {
-        if (!cs.bf16_ok || !mfma_metric)
+        if (!((cs.bf16_ok && l2_metric) || cos_ok))
             return fail(VQHIP_ERR_UNSUPPORTED, "bf16 MFMA engine unavailable for sub_dim=%u k=%u metric=%d",
                         cs.sd, cs.k, metric);
         *engine = VQHIP_ENGINE_MFMA_BF16;
     } else {
-        *engine = !mfma_metric ? VQHIP_ENGINE_EXACT
-                  : cs.bf16_ok ? VQHIP_ENGINE_MFMA_BF16
-                  : cs.mfma_ok ? VQHIP_ENGINE_MFMA
-                               : VQHIP_ENGINE_EXACT;
+        *engine = cos_ok                     ? VQHIP_ENGINE_MFMA_BF16
+                  : !l2_metric               ? VQHIP_ENGINE_EXACT
+                  : cs.bf16_ok               ? VQHIP_ENGINE_MFMA_BF16
+                  : cs.mfma_ok               ? VQHIP_ENGINE_MFMA
+                                             : VQHIP_ENGINE_EXACT;
     }
     return VQHIP_OK;
 }
@@ -761,6 +766,7 @@ int vqhip_pq_encoder_create(const float *codebooks, uint32_t m, uint32_t k, uint
     std::unique_ptr<vqhip_pq_encoder> enc(new vqhip_pq_encoder());
     enc->metric = metric;
     VQ_TRY(enc->cs.init(m, k, sub_dim));
+    enc->cs.metric = (metric == VQHIP_COSINE) ? VQHIP_COSINE : VQHIP_SQUARED_EUCLIDEAN;
     VQ_HIP(hipMemcpyAsync(enc->cs.cb.p, codebooks, (size_t)m * k * sub_dim * 4, hipMemcpyHostToDevice, s));
     VQ_HIP(hipStreamSynchronize(s));
     for (uint32_t i = 0; i < m; ++i) enc->all_subs.push_back(i);

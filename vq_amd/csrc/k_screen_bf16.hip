@@ -594,8 +594,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // A image for the 32x32x16 form: [m][NT32][NMF][4 dwords][64 lanes]; lane (h = l>>5, c = l&31),
 // k-slot j (0..7) of MFMA f: pair = f*PPM + j/DPH, dim = h*DPH + j%DPH, with DPH = sd/2, PPM = 8/DPH
+// cosine != 0: the image holds -c/|c| (zero for |c| < 1e-10, whose distance is the constant 1.0,
+// src/core/distance.rs:113-115) so that the screen forms s_j = -|x| cos(x, c_j)
 __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restrict__ cb, uint32_t m, uint32_t k,
-                                                          uint32_t sd, uint32_t nt32, uint32_t nmf,
+                                                          uint32_t sd, uint32_t nt32, uint32_t nmf, int cosine,
+                                                          const float *__restrict__ cnsqrt,
                                                           uint32_t *__restrict__ prepA32) {
     const uint32_t s = blockIdx.x;
     const uint32_t dph = sd / 2, ppm = 8 / dph;
@@ -611,7 +614,13 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
             const uint32_t pair = f * ppm + pq;
             if (pair < 6 && j < k) {
                 uint32_t parts[3];
-                split3(-2.0f * cbs[(size_t)j * sd + h * dph + dd], parts);
+                const float c = cbs[(size_t)j * sd + h * dph + dd];
+                float av = -2.0f * c;
+                if (cosine) {
+                    const float nb = cnsqrt[(size_t)s * k + j];
+                    av = (nb < 1e-10f) ? 0.0f : -(c / nb);
+                }
+                split3(av, parts);
                 half[hh] = parts[pair_a((int)pair)] >> 16;
             }
         }
@@ -625,7 +634,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
     const uint32_t *__restrict__ prepA32, const float *__restrict__ prepCn, uint32_t cn_stride,
     const float *__restrict__ meta, const uint32_t *__restrict__ sub_list, uint32_t n_sub,
     uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_seg,
-    uint32_t n_seg, uint64_t wl_stride) {
+    uint32_t n_seg, uint64_t wl_stride, int cosine, uint32_t k_real) {
     constexpr int DPH = SD / 2;            // dims owned by a lane half
     constexpr int PPM = 8 / DPH;           // term pairs per MFMA
     constexpr int NMF = (6 + PPM - 1) / PPM;
@@ -667,6 +676,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
         // padding (and +inf norms) as a large FINITE value: a packed +inf would turn into a NaN
         for (uint32_t e = lane; e < NT32 * 32; e += 64) {
             float v = (e < cn_stride) ? pc[e] : 3.0e38f;
+            if (cosine) v = (e < k_real) ? 0.0f : 3.0e38f;  // s_j = -x.c_j/|c_j| has no norm term
             lds_cn[wave][e] = (v < 3.0e38f) ? v : 3.0e38f;
         }
     }
@@ -677,7 +687,9 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
     asm volatile("" : "+s"(idx_mask));
     asm volatile("" : "+s"(pinf), "+s"(ninf));
     const float cmax = meta[s * 4 + 0];
-    const float tcoef = meta[s * 4 + 3];  // bf16 coefficient + 128 * 2^-24 for the index packing
+    float tcoef = meta[s * 4 + 3];  // bf16 coefficient + 128 * 2^-24 for the index packing
+    if (cosine && tcoef <= 3.0e38f)    // DESIGN.md "screen soundness", cosine: (6*sd + 40*NMF + 200) * 2^-24 * |x|
+        tcoef = (6.0f * SD + 40.0f * NMF + 200.0f) * 5.9604644775390625e-08f;
 
     const size_t col0 = (size_t)s * SD + (size_t)DPH * h;
     auto load_x = [&](uint64_t row, float (&x)[DPH]) {
@@ -838,11 +850,16 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
             j = take ? rj[1] : rj[0];
             m1 = take ? b1 : a1;
         }
-        const float xn = __builtin_sqrtf(xs) * 1.000001f + cmax;
-        const float bnd = xn * xn;
+        // squared-L2 / Euclid: T = coef * (|x| + max|c|)^2.  Cosine: s = -|x| cos, T = coef * |x|, and the
+        // row is also re-checked when the best cosine is not clearly positive (all distances may
+        // clamp to 1.0, src/core/distance.rs:118) or |x| is near the 1e-10 cut-off (distance.rs:113)
+        const float xnorm = __builtin_sqrtf(xs) * 1.000001f;
+        const float xn = xnorm + cmax;
+        const float bnd = cosine ? xnorm : xn * xn;
         const float T = tcoef * bnd + 1e-35f * xn + 1e-37f;
         const float gap = m2 - m1;
-        const bool proven = (gap > T) && (fabsf(m1) <= 3.0e38f) && (T <= 3.0e38f);
+        bool proven = (gap > T) && (fabsf(m1) <= 3.0e38f) && (T <= 3.0e38f);
+        if (cosine) proven = proven && (m1 < -T) && (xnorm > 4e-10f);
         const uint64_t row = st * 32 + p;
         const bool writer = (h == 0) && (row < n);
         if (writer) codes[row * m + s] = (uint8_t)j;
@@ -1372,7 +1389,7 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
     a.n_seg = n_chunks;
     hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d,
                        cb.m, cb.prepA32, cb.prepCn, cb.nt * 16, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
-                       a.wl_seg, n_chunks, a.wl_stride);
+                       a.wl_seg, n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k);
     VQ_LAUNCH_CHECK("k_assign_screen_bf16_x32");
     return VQHIP_OK;
 }
@@ -1394,10 +1411,10 @@ uint32_t screen_bf16_x32_mfmas(uint32_t sd) {
     const uint32_t dph = sd / 2, ppm = 8 / dph;
     return (6 + ppm - 1) / ppm;
 }
-int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, hipStream_t stream) {
+int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine, hipStream_t stream) {
     if (v.m == 0) return VQHIP_OK;
     hipLaunchKernelGGL(k_prepare_bf16_x32, dim3(v.m, 16), dim3(256), 0, stream, v.cb, v.m, v.k, v.sd, (v.k + 31) / 32,
-                       screen_bf16_x32_mfmas(v.sd), prepA32);
+                       screen_bf16_x32_mfmas(v.sd), cosine, v.cnsqrt, prepA32);
     VQ_LAUNCH_CHECK("k_prepare_bf16_x32");
     return VQHIP_OK;
 }
@@ -1429,8 +1446,10 @@ int launch_prepare_bf16(const CodebookView &v, uint32_t *prepA16, hipStream_t st
 
 int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) {
     if (a.n == 0 || a.n_sub == 0) return VQHIP_OK;
-    if (!screen_bf16_supported(cb.sd, cb.k) || !cb.prepA16)
+    if (!screen_bf16_supported(cb.sd, cb.k) || (!cb.prepA16 && !cb.prepA32))
         return fail(VQHIP_ERR_UNSUPPORTED, "no bf16 MFMA screen for sub_dim=%u k=%u", cb.sd, cb.k);
+    if (a.metric == VQHIP_COSINE && !(cb.prepA32 && screen_bf16_uses_x32(cb.sd, cb.k)))
+        return fail(VQHIP_ERR_UNSUPPORTED, "cosine screen needs the X32 variant (sub_dim 8 or 16)");
     // A/B knob for profiling: VQHIP_BF16_VARIANT = x32 (default) | regs | lds | lds2
     static const char *variant = getenv("VQHIP_BF16_VARIANT");
     const int which = !variant ? 3 : (variant[0] == 'x' ? 3 : variant[0] == 'r' ? 0 : (strcmp(variant, "lds") == 0 ? 1 : 2));

@@ -33,7 +33,7 @@ int launch_prepare_bf16(const CodebookView &v, uint32_t *prepA16, hipStream_t st
 bool screen_bf16_x32_supported(uint32_t sd, uint32_t k);
 bool screen_bf16_uses_x32(uint32_t sd, uint32_t k);
 uint32_t screen_bf16_x32_mfmas(uint32_t sd);
-int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, hipStream_t stream);
+int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine, hipStream_t stream);
 
 int launch_prepare_codebook(const CodebookView &v, float *prepA, float *prepCn, float *meta,
                             float *cnsqrt, hipStream_t stream);
