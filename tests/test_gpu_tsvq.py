@@ -86,6 +86,57 @@ def test_descent_bit_identical(oracle, metric, kind):
     np.testing.assert_array_equal(t.quantize(Q[5]).view(np.uint16), want_f16[5])
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("kind", ["uniform", "normal", "lattice", "structured"])
+@pytest.mark.parametrize("shape", [(6000, 32, 9), (5000, 64, 7), (6000, 128, 8), (3000, 256, 5), (400, 128, 12)])
+def test_screened_descent_bit_identical(oracle, metric, kind, shape):
+    """Squared-L2 / Euclidean descent with d in {32,64,128,256}: one dot product per level decides
+    the rows whose margin is provable, the rest resume from their node in exact arithmetic."""
+    n, d, depth = shape
+    X = _data(25, n, d, kind)
+    Q = np.concatenate([_data(26, 5000, d, kind), X[:500]])  # training rows sit on cell boundaries more often
+    tree = oracle.tsvq_build(X, depth)
+    names = {0: "squared_euclidean", 1: "euclidean"}
+    t = TSVQ.from_tree(tree["centroids"], tree["left"], tree["right"], Distance(names[metric]))
+    want_leaf, want_f16 = oracle.tsvq_encode(metric, Q, tree, threads=0)
+    np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)
+    screened, undecided = t.last_encode_stats()
+    if tree["centroids"].shape[0] > 1 and (tree["left"] >= 0).sum() * d * 4 < 140 * 1024:
+        assert screened
+        if kind in ("uniform", "normal"):
+            assert undecided < 0.25 * len(Q)
+    np.testing.assert_array_equal(t.quantize_batch(Q).view(np.uint16), want_f16)
+
+
+def test_screened_descent_adversarial(oracle):
+    """Queries on the bisecting planes (exact ties -> left), at the centroids, non-finite, huge
+    and denormal magnitudes; a tree with a non-finite centroid."""
+    rng = np.random.default_rng(27)
+    n, d, depth = 4000, 64, 6
+    X = rng.standard_normal((n, d)).astype(F)
+    tree = oracle.tsvq_build(X, depth)
+    cent, left, right = tree["centroids"], tree["left"], tree["right"]
+    inner = np.where((left >= 0) & (right >= 0))[0]
+    mid = ((cent[left[inner]].astype(np.float64) + cent[right[inner]]) / 2).astype(F)  # on the plane, up to rounding
+    Q = np.concatenate([mid, cent, mid + F(1e-7), mid - F(1e-7), rng.standard_normal((2000, d)).astype(F) * F(1e18),
+                        rng.standard_normal((500, d)).astype(F) * F(1e-30),
+                        rng.standard_normal((500, d)).astype(F) * F(1e-41), np.zeros((3, d), F)])
+    Q[7, 5] = np.nan
+    Q[8, 9] = np.inf
+    Q[9, 1] = -np.inf
+    for metric, name in ((0, "squared_euclidean"), (1, "euclidean")):
+        t = TSVQ.from_tree(cent, left, right, Distance(name))
+        want_leaf, _ = oracle.tsvq_encode(metric, Q, tree, want_f16=False, threads=0)
+        np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)
+        assert t.last_encode_stats()[0]
+    bad = {k: v.copy() for k, v in tree.items()}
+    bad["centroids"][3, 2] = np.nan
+    bad["centroids"][5, 0] = np.inf
+    t = TSVQ.from_tree(bad["centroids"], left, right, Distance("squared_euclidean"))
+    want_leaf, _ = oracle.tsvq_encode(0, Q, bad, want_f16=False, threads=0)
+    np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)
+
+
 def test_golden_tsvq_fixture():
     g = np.load(os.path.join(GOLD, "tsvq_depth5.npz"))
     ds = _lib.Dataset.from_host(g["X"])
@@ -116,3 +167,14 @@ def test_config4_fullsize_depth8(oracle):
     Q = X[::997]
     want_leaf, _ = oracle.tsvq_encode(O.EUCLIDEAN, Q, want, want_f16=False, threads=0)
     np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)
+    screened, undecided = t.last_encode_stats()
+    assert screened and undecided < 0.1 * len(Q)
+    # every row: the screened descent against the all-exact walk of the same library
+    all_leaf = t.leaf_ids(X)
+    os.environ["VQHIP_TSVQ_EXACT"] = "1"
+    try:
+        t_exact = TSVQ.from_tree(cent, left, right, Distance.euclidean())
+    finally:
+        del os.environ["VQHIP_TSVQ_EXACT"]
+    np.testing.assert_array_equal(all_leaf, t_exact.leaf_ids(X))
+    assert not t_exact.last_encode_stats()[0]

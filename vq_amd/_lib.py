@@ -79,6 +79,7 @@ SIGNATURES = {
     "vqhip_tsvq_destroy": (C.c_int, [_vp]),
     "vqhip_tsvq_encode": (C.c_int, [_vp, _f32p, C.c_uint64, _i32p, _u16p]),
     "vqhip_tsvq_encode_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "vqhip_tsvq_last_stats": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

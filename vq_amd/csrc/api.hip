@@ -2,6 +2,10 @@
 // the reference file:line each entry replaces).  Host-side orchestration only; the kernels
 // are in k_*.hip.  No CPU compute fallback exists anywhere in this file.
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -335,7 +339,80 @@ struct vqhip_tsvq {
     uint32_t n_nodes = 0, d = 0;
     int metric = VQHIP_EUCLIDEAN;
     DevBuf centroids, cnorm, left, right, xbuf, leafbuf, f16buf;
+    // screened descent (squared-L2 / Euclidean, k_tsvq_screen.hip); use_screen = false -> exact walk only
+    bool use_screen = false, last_screened = false;
+    TsvqScreen scr;
+    DevBuf scr_w, scr_info, scr_mu, scr_wl, scr_count;
 };
+
+// Per-node data of the screened descent, from the host copy of the tree (f64, rounded once).
+static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int32_t *left, const int32_t *right,
+                               hipStream_t s) {
+    const uint32_t n_nodes = t->n_nodes, d = t->d;
+    uint32_t n_int = 0;
+    for (uint32_t i = 0; i < n_nodes; ++i) n_int += (left[i] >= 0 && right[i] >= 0) ? 1u : 0u;
+    const char *off = getenv("VQHIP_TSVQ_EXACT");
+    if ((off && off[0] == '1') || !tsvq_screen_supported(n_int, n_nodes, d, t->metric)) return VQHIP_OK;
+    std::vector<float> w((size_t)n_int * d);
+    std::vector<int32_t> info((size_t)n_nodes * 4);
+    const float *mu = centroids;  // root
+    double r2max = 0.0;
+    bool finite = true;
+    std::vector<double> a2(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        double acc = 0.0;
+        for (uint32_t q = 0; q < d; ++q) {
+            const double a = (double)centroids[(size_t)i * d + q] - (double)mu[q];
+            acc += a * a;
+        }
+        a2[i] = acc;
+        if (!(acc <= 1e300)) finite = false;
+        if (acc > r2max) r2max = acc;
+    }
+    uint32_t slot = 0;
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        const int32_t l = left[i], r = right[i];
+        int32_t *rec = info.data() + (size_t)i * 4;
+        rec[0] = (int32_t)((uint32_t)(l + 1) | ((uint32_t)(r + 1) << 16));
+        rec[1] = 0;
+        float b = 0.0f, wn = 0.0f;
+        if (l >= 0 && r >= 0) {
+            double w2 = 0.0;
+            for (uint32_t q = 0; q < d; ++q) {
+                const float wv = centroids[(size_t)l * d + q] - centroids[(size_t)r * d + q];
+                w[(size_t)slot * d + q] = wv;
+                w2 += (double)wv * (double)wv;
+            }
+            b = (float)(a2[l] - a2[r]);
+            wn = (float)(std::sqrt(w2) * 1.000001);
+            if (!(w2 <= 1e300)) finite = false;
+            rec[1] = (int32_t)slot++;
+        }
+        memcpy(&rec[2], &b, 4);
+        memcpy(&rec[3], &wn, 4);
+    }
+    VQ_TRY(t->scr_w.alloc(w.size() * 4));
+    VQ_TRY(t->scr_info.alloc(info.size() * 4));
+    VQ_TRY(t->scr_mu.alloc((size_t)d * 4));
+    VQ_TRY(t->scr_count.alloc(4));
+    VQ_HIP(hipMemcpyAsync(t->scr_w.p, w.data(), w.size() * 4, hipMemcpyHostToDevice, s));
+    VQ_HIP(hipMemcpyAsync(t->scr_info.p, info.data(), info.size() * 4, hipMemcpyHostToDevice, s));
+    VQ_HIP(hipMemcpyAsync(t->scr_mu.p, mu, (size_t)d * 4, hipMemcpyHostToDevice, s));
+    VQ_HIP(hipStreamSynchronize(s));  // w / info are stack-owned
+    t->scr.w = t->scr_w.as<float>();
+    t->scr.info = t->scr_info.as<int4>();
+    t->scr.mu = t->scr_mu.as<float>();
+    t->scr.wl_count = t->scr_count.as<uint32_t>();
+    t->scr.n_int = n_int;
+    t->scr.n_nodes = n_nodes;
+    // a non-finite tree sends every row to the exact continuation (T = NaN never passes)
+    t->scr.R = finite ? (float)(std::sqrt(r2max) * 1.000001) : std::numeric_limits<float>::quiet_NaN();
+    // T = u * base * (coef_a * base + coef_b * |w|), base >= |x - mu| + R
+    t->scr.coef_a = 1.1f * (2.0f * d + 20.0f);
+    t->scr.coef_b = 1.1f * (2.0f * d + 16.0f);
+    t->use_screen = true;
+    return VQHIP_OK;
+}
 
 #define VQ_API_BEGIN try {
 #define VQ_API_END                                                                  \
@@ -937,6 +1014,7 @@ int vqhip_tsvq_create(const float *centroids, const int32_t *left, const int32_t
     VQ_HIP(hipMemcpyAsync(t->right.p, right, (size_t)n_nodes * 4, hipMemcpyHostToDevice, s));
     VQ_TRY(t->cnorm.alloc((size_t)n_nodes * 4));
     VQ_TRY(launch_tsvq_node_norms(t->centroids.as<float>(), n_nodes, d, t->cnorm.as<float>(), s));
+    VQ_TRY(tsvq_prepare_screen(t.get(), centroids, left, right, s));
     VQ_HIP(hipStreamSynchronize(s));
     *out = t.release();
     return VQHIP_OK;
@@ -961,9 +1039,38 @@ int vqhip_tsvq_encode_device(vqhip_tsvq *t, const void *dev_rows, uint64_t n, vo
         VQ_TRY(t->leafbuf.ensure((size_t)n * 4));
         leaf = t->leafbuf.as<int32_t>();
     }
+    t->last_screened = false;
+    if (t->use_screen && n <= 0xFFFFFFFFull && (reinterpret_cast<uintptr_t>(dev_rows) & 15) == 0) {
+        t->last_screened = true;
+        VQ_TRY(t->scr_wl.ensure((size_t)n * 8));
+        t->scr.wl = t->scr_wl.as<uint2>();
+        VQ_TRY(launch_tsvq_screen_encode(reinterpret_cast<const float *>(dev_rows), n, t->d, t->centroids.as<float>(),
+                                         t->left.as<int32_t>(), t->right.as<int32_t>(), t->metric, t->scr, leaf, s));
+        if (dev_f16_out)
+            VQ_TRY(launch_tsvq_gather_f16(t->centroids.as<float>(), t->d, leaf, n,
+                                          reinterpret_cast<uint16_t *>(dev_f16_out), s));
+        return VQHIP_OK;
+    }
     return launch_tsvq_encode(reinterpret_cast<const float *>(dev_rows), n, t->d, t->centroids.as<float>(),
                               t->cnorm.as<float>(), t->left.as<int32_t>(), t->right.as<int32_t>(), t->metric, leaf,
                               reinterpret_cast<uint16_t *>(dev_f16_out), s);
+    VQ_API_END
+}
+
+int vqhip_tsvq_last_stats(vqhip_tsvq *t, int *screened, uint64_t *undecided) {
+    VQ_API_BEGIN
+    if (!t || !screened || !undecided) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    *screened = t->last_screened ? 1 : 0;
+    *undecided = 0;
+    if (t->last_screened) {
+        hipStream_t s;
+        VQ_TRY(current_stream(&s));
+        uint32_t c = 0;
+        VQ_HIP(hipMemcpyAsync(&c, t->scr_count.p, 4, hipMemcpyDeviceToHost, s));
+        VQ_HIP(hipStreamSynchronize(s));
+        *undecided = c;
+    }
+    return VQHIP_OK;
     VQ_API_END
 }
 

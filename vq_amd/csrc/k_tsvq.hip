@@ -884,13 +884,17 @@ int launch_tsvq_encode(const float *X, uint64_t n, uint32_t d, const float *cent
                            left, right, metric, leaf);
         VQ_LAUNCH_CHECK("k_tsvq_descend");
     }
-    if (f16_out) {
-        uint64_t blocks = (n * d + 255) / 256;
-        if (blocks > (uint64_t)num_cus() * 8) blocks = (uint64_t)num_cus() * 8;
-        hipLaunchKernelGGL(k_tsvq_gather_f16, dim3((uint32_t)blocks), dim3(256), 0, stream, centroids, d, leaf, n,
-                           f16_out);
-        VQ_LAUNCH_CHECK("k_tsvq_gather_f16");
-    }
+    if (f16_out) VQ_TRY(launch_tsvq_gather_f16(centroids, d, leaf, n, f16_out, stream));
+    return VQHIP_OK;
+}
+
+int launch_tsvq_gather_f16(const float *centroids, uint32_t d, const int32_t *leaf, uint64_t n, uint16_t *f16_out,
+                           hipStream_t stream) {
+    if (n == 0) return VQHIP_OK;
+    uint64_t blocks = (n * d + 255) / 256;
+    if (blocks > (uint64_t)num_cus() * 8) blocks = (uint64_t)num_cus() * 8;
+    hipLaunchKernelGGL(k_tsvq_gather_f16, dim3((uint32_t)blocks), dim3(256), 0, stream, centroids, d, leaf, n, f16_out);
+    VQ_LAUNCH_CHECK("k_tsvq_gather_f16");
     return VQHIP_OK;
 }
 

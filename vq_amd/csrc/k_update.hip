@@ -158,36 +158,57 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
     };
     auto load_c = [&](uint64_t row) { return (row < r1) ? (uint32_t)codes[row * m + s] : 0xFFFFFFFFu; };
 
-    float4 xn = load_x(r0 + p);
-    uint32_t cn_ = load_c(r0 + p);
-    for (uint64_t base = r0; base < r1; base += RPS) {
-        const float4 x = xn;
-        const uint32_t code = cn_;
-        xn = load_x(base + RPS + p);
-        cn_ = load_c(base + RPS + p);
-        const bool valid = code != 0xFFFFFFFFu;
-        // rank among the step's rows (row q's code sits in lane q*KS)
-        uint32_t rank = 0;
+    // HBM latency (~2 us under load) against one 1-KB load per wave limited the first version to
+    // 2.1 TB/s; batches of PF steps are double-buffered so a wave keeps 2*PF KB in flight
+    constexpr uint32_t PF = 4;
+    float4 xb[PF];
+    uint32_t cb_[PF];
 #pragma unroll
-        for (uint32_t q = 0; q + 1 < RPS; ++q) {
-            const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)code, (int)(q * KS));
-            rank += (q < p && cq == code) ? 1u : 0u;
+    for (uint32_t i = 0; i < PF; ++i) {
+        xb[i] = load_x(r0 + i * RPS + p);
+        cb_[i] = load_c(r0 + i * RPS + p);
+    }
+    for (uint64_t base = r0; base < r1; base += (uint64_t)PF * RPS) {
+        float4 xc[PF];
+        uint32_t cc[PF];
+#pragma unroll
+        for (uint32_t i = 0; i < PF; ++i) {
+            xc[i] = xb[i];
+            cc[i] = cb_[i];
         }
-        // xor-swizzled 16-byte slot so that the KS parts of different clusters spread over banks
-        float4 *slot = reinterpret_cast<float4 *>(sums + (size_t)code * SD) + (g ^ (code & (KS - 1)));
-        uint32_t pending = valid ? 1u : 0u;
-        for (uint32_t r = 0; __any(pending != 0); ++r) {
-            if (pending && rank == r) {
-                float4 a = *slot;
-                a.x = a.x + x.x;
-                a.y = a.y + x.y;
-                a.z = a.z + x.z;
-                a.w = a.w + x.w;
-                *slot = a;
-                if (g == 0) cnts[code] += 1u;
-                pending = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < PF; ++i) {
+            xb[i] = load_x(base + (uint64_t)(PF + i) * RPS + p);
+            cb_[i] = load_c(base + (uint64_t)(PF + i) * RPS + p);
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < PF; ++i) {
+            const float4 x = xc[i];
+            const uint32_t code = cc[i];
+            const bool valid = code != 0xFFFFFFFFu;
+            // rank among the step's rows (row q's code sits in lane q*KS)
+            uint32_t rank = 0;
+#pragma unroll
+            for (uint32_t q = 0; q + 1 < RPS; ++q) {
+                const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)code, (int)(q * KS));
+                rank += (q < p && cq == code) ? 1u : 0u;
             }
-            __builtin_amdgcn_wave_barrier();
+            // xor-swizzled 16-byte slot so that the KS parts of different clusters spread over banks
+            float4 *slot = reinterpret_cast<float4 *>(sums + (size_t)code * SD) + (g ^ (code & (KS - 1)));
+            uint32_t pending = valid ? 1u : 0u;
+            for (uint32_t r = 0; __any(pending != 0); ++r) {
+                if (pending && rank == r) {
+                    float4 a = *slot;
+                    a.x = a.x + x.x;
+                    a.y = a.y + x.y;
+                    a.z = a.z + x.z;
+                    a.w = a.w + x.w;
+                    *slot = a;
+                    if (g == 0) cnts[code] += 1u;
+                    pending = 0;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     // partial slab of this (row chunk, subspace): un-swizzle on the way out

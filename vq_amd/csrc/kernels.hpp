@@ -109,6 +109,24 @@ int launch_gather_rows(const float *X, uint32_t d, uint32_t m, uint32_t k, uint3
 int tsvq_build_device(const float *X, uint64_t n, uint32_t d, uint32_t max_depth, uint32_t cap,
                       float *centroids_out, int32_t *left_out, int32_t *right_out, int32_t *n_nodes_out,
                       hipStream_t stream);
+// prepared per-node data of the screened squared-L2 / Euclidean descent (k_tsvq_screen.hip)
+struct TsvqScreen {
+    const float *w = nullptr;     // [n_int][d]  c_left - c_right of every two-child node
+    const int4 *info = nullptr;   // [n_nodes]   {(l+1)|(r+1)<<16, slot in w, bits(b), bits(|w|)}
+    const float *mu = nullptr;    // [d]         root centroid
+    uint32_t n_int = 0, n_nodes = 0;
+    float R = 0.0f;               // >= max_node |c - mu|
+    float coef_a = 0.0f, coef_b = 0.0f;
+    uint2 *wl = nullptr;          // [n] undecided (row, node)
+    uint32_t *wl_count = nullptr;
+};
+size_t tsvq_screen_lds_bytes(uint32_t n_int, uint32_t n_nodes, uint32_t d);
+bool tsvq_screen_supported(uint32_t n_int, uint32_t n_nodes, uint32_t d, int metric);
+int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const int32_t *left,
+                              const int32_t *right, int metric, const TsvqScreen &s, int32_t *leaf,
+                              hipStream_t stream);
+int launch_tsvq_gather_f16(const float *centroids, uint32_t d, const int32_t *leaf, uint64_t n, uint16_t *f16_out,
+                           hipStream_t stream);
 int launch_tsvq_node_norms(const float *centroids, uint32_t n_nodes, uint32_t d, float *cnorm, hipStream_t stream);
 int launch_tsvq_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const float *cnorm,
                        const int32_t *left, const int32_t *right, int metric, int32_t *leaf, uint16_t *f16_out,

@@ -118,6 +118,14 @@ class TSVQ:
     def quantize_batch(self, X) -> np.ndarray:
         return self._encode(X, False, True)[1]
 
+    def last_encode_stats(self):
+        """(screened descent used?, rows finished by the exact continuation) of the last batch"""
+        import ctypes as C
+
+        scr, und = C.c_int(0), C.c_uint64(0)
+        _lib.check(_lib.load().vqhip_tsvq_last_stats(self._enc.raw, C.byref(scr), C.byref(und)))
+        return bool(scr.value), int(und.value)
+
     def leaf_ids(self, X) -> np.ndarray:
         """node index (pre-order) of the leaf each row descends to"""
         return self._encode(X, True, False)[0]
