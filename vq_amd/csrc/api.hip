@@ -338,7 +338,7 @@ struct vqhip_pq_encoder {
 struct vqhip_tsvq {
     uint32_t n_nodes = 0, d = 0;
     int metric = VQHIP_EUCLIDEAN;
-    DevBuf centroids, cnorm, left, right, xbuf, leafbuf, f16buf;
+    DevBuf centroids, cnorm, left, right, xbuf, leafbuf, f16buf, table16;
     // screened descent (squared-L2 / Euclidean, k_tsvq_screen.hip); use_screen = false -> exact walk only
     bool use_screen = false, last_screened = false;
     TsvqScreen scr;
@@ -1014,6 +1014,8 @@ int vqhip_tsvq_create(const float *centroids, const int32_t *left, const int32_t
     VQ_HIP(hipMemcpyAsync(t->right.p, right, (size_t)n_nodes * 4, hipMemcpyHostToDevice, s));
     VQ_TRY(t->cnorm.alloc((size_t)n_nodes * 4));
     VQ_TRY(launch_tsvq_node_norms(t->centroids.as<float>(), n_nodes, d, t->cnorm.as<float>(), s));
+    VQ_TRY(t->table16.alloc((size_t)n_nodes * d * 2));
+    VQ_TRY(launch_tsvq_table_f16(t->centroids.as<float>(), n_nodes, d, t->table16.as<uint16_t>(), s));
     VQ_TRY(tsvq_prepare_screen(t.get(), centroids, left, right, s));
     VQ_HIP(hipStreamSynchronize(s));
     *out = t.release();
@@ -1040,20 +1042,25 @@ int vqhip_tsvq_encode_device(vqhip_tsvq *t, const void *dev_rows, uint64_t n, vo
         leaf = t->leafbuf.as<int32_t>();
     }
     t->last_screened = false;
+    const float *X = reinterpret_cast<const float *>(dev_rows);
     if (t->use_screen && n <= 0xFFFFFFFFull && (reinterpret_cast<uintptr_t>(dev_rows) & 15) == 0) {
         t->last_screened = true;
         VQ_TRY(t->scr_wl.ensure((size_t)n * 8));
         t->scr.wl = t->scr_wl.as<uint2>();
-        VQ_TRY(launch_tsvq_screen_encode(reinterpret_cast<const float *>(dev_rows), n, t->d, t->centroids.as<float>(),
-                                         t->left.as<int32_t>(), t->right.as<int32_t>(), t->metric, t->scr, leaf, s));
-        if (dev_f16_out)
-            VQ_TRY(launch_tsvq_gather_f16(t->centroids.as<float>(), t->d, leaf, n,
-                                          reinterpret_cast<uint16_t *>(dev_f16_out), s));
-        return VQHIP_OK;
+        VQ_TRY(launch_tsvq_screen_encode(X, n, t->d, t->centroids.as<float>(), t->left.as<int32_t>(),
+                                         t->right.as<int32_t>(), t->metric, t->scr, leaf, s));
+    } else {
+        VQ_TRY(launch_tsvq_encode(X, n, t->d, t->centroids.as<float>(), t->cnorm.as<float>(), t->left.as<int32_t>(),
+                                  t->right.as<int32_t>(), t->metric, leaf, s));
     }
-    return launch_tsvq_encode(reinterpret_cast<const float *>(dev_rows), n, t->d, t->centroids.as<float>(),
-                              t->cnorm.as<float>(), t->left.as<int32_t>(), t->right.as<int32_t>(), t->metric, leaf,
-                              reinterpret_cast<uint16_t *>(dev_f16_out), s);
+    if (dev_f16_out) {
+        uint16_t *out = reinterpret_cast<uint16_t *>(dev_f16_out);
+        if (t->d % 8 == 0 && (reinterpret_cast<uintptr_t>(dev_f16_out) & 15) == 0)
+            VQ_TRY(launch_tsvq_gather_table(t->table16.as<uint16_t>(), t->d, leaf, n, out, s));
+        else
+            VQ_TRY(launch_tsvq_gather_f16(t->centroids.as<float>(), t->d, leaf, n, out, s));
+    }
+    return VQHIP_OK;
     VQ_API_END
 }
 

@@ -604,7 +604,46 @@ __global__ __launch_bounds__(256) void k_tsvq_gather_f16(const float *__restrict
     }
 }
 
+// f16 image of the node centroids (RNE, half::f16::from_f32 as src/tsvq.rs:249-253 applies per call)
+__global__ __launch_bounds__(256) void k_tsvq_table_f16(const float *__restrict__ centroids, uint64_t total,
+                                                        uint16_t *__restrict__ table) {
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < total) table[e] = __half_as_ushort(__float2half_rn(centroids[e]));
+}
+
+// out[row] = table[leaf[row]], 16 bytes per lane (d % 8 == 0)
+__global__ __launch_bounds__(256) void k_tsvq_gather_f16v(const uint4 *__restrict__ table, uint32_t d8,
+                                                          const int32_t *__restrict__ leaf, uint64_t n,
+                                                          uint4 *__restrict__ out) {
+    const uint64_t total = n * d8;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (uint64_t)gridDim.x * 256) {
+        const uint64_t row = e / d8;
+        const uint32_t t = (uint32_t)(e - row * d8);
+        out[e] = table[(size_t)leaf[row] * d8 + t];
+    }
+}
+
 }  // namespace
+
+int launch_tsvq_table_f16(const float *centroids, uint32_t n_nodes, uint32_t d, uint16_t *table, hipStream_t stream) {
+    const uint64_t total = (uint64_t)n_nodes * d;
+    hipLaunchKernelGGL(k_tsvq_table_f16, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, stream, centroids, total,
+                       table);
+    VQ_LAUNCH_CHECK("k_tsvq_table_f16");
+    return VQHIP_OK;
+}
+
+int launch_tsvq_gather_table(const uint16_t *table, uint32_t d, const int32_t *leaf, uint64_t n, uint16_t *f16_out,
+                             hipStream_t stream) {
+    if (n == 0) return VQHIP_OK;
+    const uint32_t d8 = d / 8;
+    uint64_t blocks = (n * d8 + 255) / 256;
+    if (blocks > (uint64_t)num_cus() * 16) blocks = (uint64_t)num_cus() * 16;
+    hipLaunchKernelGGL(k_tsvq_gather_f16v, dim3((uint32_t)blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const uint4 *>(table), d8, leaf, n, reinterpret_cast<uint4 *>(f16_out));
+    VQ_LAUNCH_CHECK("k_tsvq_gather_f16v");
+    return VQHIP_OK;
+}
 
 // ---- host driver of the build ------------------------------------------------------------
 int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_depth, uint32_t cap,
@@ -865,8 +904,7 @@ static int dispatch_descend(const float *X, uint64_t n, uint32_t d, const float 
 }
 
 int launch_tsvq_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const float *cnorm,
-                       const int32_t *left, const int32_t *right, int metric, int32_t *leaf, uint16_t *f16_out,
-                       hipStream_t stream) {
+                       const int32_t *left, const int32_t *right, int metric, int32_t *leaf, hipStream_t stream) {
     if (n == 0) return VQHIP_OK;
     bool done = false;
     const bool vec = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(centroids) & 15) == 0);
@@ -884,7 +922,6 @@ int launch_tsvq_encode(const float *X, uint64_t n, uint32_t d, const float *cent
                            left, right, metric, leaf);
         VQ_LAUNCH_CHECK("k_tsvq_descend");
     }
-    if (f16_out) VQ_TRY(launch_tsvq_gather_f16(centroids, d, leaf, n, f16_out, stream));
     return VQHIP_OK;
 }
 

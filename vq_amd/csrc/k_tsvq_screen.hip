@@ -152,53 +152,115 @@ __global__ __launch_bounds__(kWaves * 64) void k_tsvq_screen_descend(
     if (wl_n) flush();
 }
 
-// sequential un-fused distances of the reference (the same arithmetic as k_tsvq.hip's exact walk)
-__device__ __forceinline__ void child_distances(const float *__restrict__ x, const float *__restrict__ cl,
-                                                const float *__restrict__ cr, uint32_t d, float &al, float &ar) {
-    al = -0.0f;
-    ar = -0.0f;
-    for (uint32_t t = 0; t < d; ++t) {
-        const float v = x[t];
-        const float d1 = v - cl[t], d2 = v - cr[t];
-        const float s1 = d1 * d1, s2 = d2 * d2;
-        al = al + s1;
-        ar = ar + s2;
+// Finishes the undecided rows in the reference's arithmetic: entry = (row, node to resume from).
+// 16 lanes per entry: lane j keeps the V-float pieces [q*16V + jV, +V) of the row, computes its
+// (x-c)^2 terms for both children in parallel, and the two running sums travel lane 0 -> 15 (DPP
+// row rotate) chunk after chunk, i.e. the additions happen in the reference's order t = 0..D-1
+// (src/core/distance.rs:76-82) while four entries per wave progress side by side.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+template <int V>
+__device__ __forceinline__ void load_piece(const float *__restrict__ p, float *out) {
+    if (V == 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(p);
+        out[0] = v.x, out[1] = v.y, out[2] = v.z, out[3] = v.w;
+    } else {
+        const float2 v = *reinterpret_cast<const float2 *>(p);
+        out[0] = v.x, out[1] = v.y;
     }
 }
 
-// finishes the undecided rows: entry = (row, node to resume from)
-__global__ __launch_bounds__(64) void k_tsvq_continue(const float *__restrict__ X, uint32_t d,
-                                                      const float *__restrict__ centroids,
-                                                      const int32_t *__restrict__ left,
-                                                      const int32_t *__restrict__ right, int euclid,
-                                                      const uint2 *__restrict__ wl,
-                                                      const uint32_t *__restrict__ wl_count,
-                                                      int32_t *__restrict__ leaf_out) {
+template <int D>
+__global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__ X,
+                                                       const float *__restrict__ centroids,
+                                                       const int32_t *__restrict__ left,
+                                                       const int32_t *__restrict__ right, int euclid,
+                                                       const uint2 *__restrict__ wl,
+                                                       const uint32_t *__restrict__ wl_count,
+                                                       int32_t *__restrict__ leaf_out) {
+    constexpr int NQ = (D >= 64) ? D / 64 : 1;  // chunks of 16 lanes x V floats
+    constexpr int V = D / NQ / 16;              // 2 (D = 32) or 4
     const uint32_t count = *wl_count;
-    for (uint32_t e = blockIdx.x * 64 + threadIdx.x; e < count; e += gridDim.x * 64) {
-        const uint2 ent = wl[e];
-        const float *x = X + (size_t)ent.x * d;
+    const uint32_t lane = threadIdx.x & 63, j = lane & 15;
+    const uint32_t slot = (blockIdx.x * 256 + threadIdx.x) >> 4;
+    const uint32_t n_slots = (gridDim.x * 256) >> 4;
+    for (uint32_t e0 = 0; e0 < count; e0 += n_slots) {  // wave-uniform trip count
+        const uint32_t e = e0 + slot;
+        const bool valid = e < count;
+        const uint2 ent = valid ? wl[e] : make_uint2(0u, 0u);
+        const float *px = X + (size_t)ent.x * D + j * V;
+        float x[NQ][V];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) load_piece<V>(px + q * 16 * V, x[q]);
         int32_t node = (int32_t)ent.y;
-        for (;;) {
+        bool walking = valid;
+        while (__any(walking)) {
             const int32_t l = left[node], r = right[node];
-            if (l >= 0 && r >= 0) {
-                float al, ar;
-                child_distances(x, centroids + (size_t)l * d, centroids + (size_t)r * d, d, al, ar);
-                if (euclid) {
-                    al = sqrtf(al);
-                    ar = sqrtf(ar);
+            const bool both = (l >= 0) && (r >= 0);
+            const float *pl = centroids + (size_t)(both ? l : 0) * D + j * V;
+            const float *pr = centroids + (size_t)(both ? r : 0) * D + j * V;
+            float s1[NQ][V], s2[NQ][V];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float cl[V], cr[V];
+                load_piece<V>(pl + q * 16 * V, cl);
+                load_piece<V>(pr + q * 16 * V, cr);
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const float d1 = x[q][v] - cl[v], d2 = x[q][v] - cr[v];
+                    s1[q][v] = d1 * d1;
+                    s2[q][v] = d2 * d2;
                 }
-                node = (al <= ar) ? l : r;  // left on ties, tsvq.rs:122
-            } else if (l >= 0) {
-                node = l;
-            } else if (r >= 0) {
-                node = r;
-            } else {
-                break;
+            }
+            float al = -0.0f, ar = -0.0f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll 1
+                for (int hop = 0; hop < 16; ++hop) {
+                    // lane `hop` receives the running sums from lane hop-1 (lane 15 -> 0 between chunks),
+                    // adds its V terms in order; the other lanes compute values nobody reads
+                    float tl = dpp_move<0x121>(al), tr = dpp_move<0x121>(ar);  // row_ror:1
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        tl = tl + s1[q][v];
+                        tr = tr + s2[q][v];
+                    }
+                    if (j == (uint32_t)hop) {
+                        al = tl;
+                        ar = tr;
+                    }
+                }
+            }
+            // lane 15 holds both distances
+            float dl = dpp_move<0x121>(al), dr = dpp_move<0x121>(ar);  // now in lane 0
+            if (euclid) {
+                dl = sqrtf(dl);
+                dr = sqrtf(dr);
+            }
+            int go_left = (dl <= dr) ? 1 : 0;  // left on ties, tsvq.rs:122
+            // broadcast lane 0's verdict to its 16 lanes (row_shr chain would cost more than one readlane set)
+            go_left = __builtin_amdgcn_ds_bpermute((int)((lane & 48u) << 2), go_left);
+            if (walking) {
+                if (both) node = go_left ? l : r;
+                else if (l >= 0) node = l;
+                else if (r >= 0) node = r;
+                else walking = false;
             }
         }
-        leaf_out[ent.x] = node;
+        if (valid && j == 0) leaf_out[ent.x] = node;
     }
+}
+
+template <int D>
+static int launch_continue(const float *X, const float *centroids, const int32_t *left, const int32_t *right,
+                           int euclid, const TsvqScreen &s, int32_t *leaf, hipStream_t stream) {
+    hipLaunchKernelGGL(k_tsvq_continue<D>, dim3(1024), dim3(256), 0, stream, X, centroids, left, right, euclid, s.wl,
+                       s.wl_count, leaf);
+    VQ_LAUNCH_CHECK("k_tsvq_continue");
+    return VQHIP_OK;
 }
 
 template <int DPL>
@@ -239,16 +301,26 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
     if (n == 0) return VQHIP_OK;
     if (n > 0xFFFFFFFFull) return fail(VQHIP_ERR_UNSUPPORTED, "screened TSVQ descent takes < 2^32 rows per call");
     VQ_HIP(hipMemsetAsync(s.wl_count, 0, 4, stream));
+    const int euclid = metric == VQHIP_EUCLIDEAN ? 1 : 0;
     switch (d) {
-    case 32: VQ_TRY(launch_screen<4>(X, n, s, stream, leaf)); break;
-    case 64: VQ_TRY(launch_screen<8>(X, n, s, stream, leaf)); break;
-    case 128: VQ_TRY(launch_screen<16>(X, n, s, stream, leaf)); break;
-    case 256: VQ_TRY(launch_screen<32>(X, n, s, stream, leaf)); break;
+    case 32:
+        VQ_TRY(launch_screen<4>(X, n, s, stream, leaf));
+        VQ_TRY(launch_continue<32>(X, centroids, left, right, euclid, s, leaf, stream));
+        break;
+    case 64:
+        VQ_TRY(launch_screen<8>(X, n, s, stream, leaf));
+        VQ_TRY(launch_continue<64>(X, centroids, left, right, euclid, s, leaf, stream));
+        break;
+    case 128:
+        VQ_TRY(launch_screen<16>(X, n, s, stream, leaf));
+        VQ_TRY(launch_continue<128>(X, centroids, left, right, euclid, s, leaf, stream));
+        break;
+    case 256:
+        VQ_TRY(launch_screen<32>(X, n, s, stream, leaf));
+        VQ_TRY(launch_continue<256>(X, centroids, left, right, euclid, s, leaf, stream));
+        break;
     default: return fail(VQHIP_ERR_UNSUPPORTED, "screened TSVQ descent: d=%u", d);
     }
-    hipLaunchKernelGGL(k_tsvq_continue, dim3(2048), dim3(64), 0, stream, X, d, centroids, left, right,
-                       metric == VQHIP_EUCLIDEAN ? 1 : 0, s.wl, s.wl_count, leaf);
-    VQ_LAUNCH_CHECK("k_tsvq_continue");
     return VQHIP_OK;
 }
 

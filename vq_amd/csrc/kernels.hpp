@@ -129,8 +129,10 @@ int launch_tsvq_gather_f16(const float *centroids, uint32_t d, const int32_t *le
                            hipStream_t stream);
 int launch_tsvq_node_norms(const float *centroids, uint32_t n_nodes, uint32_t d, float *cnorm, hipStream_t stream);
 int launch_tsvq_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const float *cnorm,
-                       const int32_t *left, const int32_t *right, int metric, int32_t *leaf, uint16_t *f16_out,
-                       hipStream_t stream);
+                       const int32_t *left, const int32_t *right, int metric, int32_t *leaf, hipStream_t stream);
+int launch_tsvq_table_f16(const float *centroids, uint32_t n_nodes, uint32_t d, uint16_t *table, hipStream_t stream);
+int launch_tsvq_gather_table(const uint16_t *table, uint32_t d, const int32_t *leaf, uint64_t n, uint16_t *f16_out,
+                             hipStream_t stream);
 
 // ---- outputs / misc ---------------------------------------------------------------
 int launch_gather_f16(const CodebookView &cb, const uint8_t *codes, uint64_t n, uint16_t *f16_out,
