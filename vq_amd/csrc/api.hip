@@ -342,7 +342,7 @@ struct vqhip_tsvq {
     // screened descent (squared-L2 / Euclidean, k_tsvq_screen.hip); use_screen = false -> exact walk only
     bool use_screen = false, last_screened = false;
     TsvqScreen scr;
-    DevBuf scr_w, scr_info, scr_mu, scr_wl, scr_count;
+    DevBuf scr_w, scr_info, scr_mu, scr_wl, scr_count, scr_slot_node;
 };
 
 // Per-node data of the screened descent, from the host copy of the tree (f64, rounded once).
@@ -354,7 +354,7 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     const char *off = getenv("VQHIP_TSVQ_EXACT");
     if ((off && off[0] == '1') || !tsvq_screen_supported(n_int, n_nodes, d, t->metric)) return VQHIP_OK;
     std::vector<float> w((size_t)n_int * d);
-    std::vector<int32_t> info((size_t)n_nodes * 4);
+    std::vector<int32_t> info((size_t)n_int * 4), slot_node(n_int), slot_of(n_nodes, -1);
     const float *mu = centroids;  // root
     double r2max = 0.0;
     bool finite = true;
@@ -370,27 +370,44 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
         if (acc > r2max) r2max = acc;
     }
     uint32_t slot = 0;
-    for (uint32_t i = 0; i < n_nodes; ++i) {
-        const int32_t l = left[i], r = right[i];
-        int32_t *rec = info.data() + (size_t)i * 4;
-        rec[0] = (int32_t)((uint32_t)(l + 1) | ((uint32_t)(r + 1) << 16));
-        rec[1] = 0;
-        float b = 0.0f, wn = 0.0f;
-        if (l >= 0 && r >= 0) {
-            double w2 = 0.0;
-            for (uint32_t q = 0; q < d; ++q) {
-                const float wv = centroids[(size_t)l * d + q] - centroids[(size_t)r * d + q];
-                w[(size_t)slot * d + q] = wv;
-                w2 += (double)wv * (double)wv;
-            }
-            b = (float)(a2[l] - a2[r]);
-            wn = (float)(std::sqrt(w2) * 1.000001);
-            if (!(w2 <= 1e300)) finite = false;
-            rec[1] = (int32_t)slot++;
+    for (uint32_t i = 0; i < n_nodes; ++i)
+        if (left[i] >= 0 && right[i] >= 0) {
+            slot_of[i] = (int32_t)slot;
+            slot_node[slot++] = (int32_t)i;
         }
+    // where a walk entering node i first has to decide (slot >= 0) or ends (leaf: -1-node); one-child
+    // nodes just pass the row on (tsvq.rs:124-129)
+    auto resolve = [&](int32_t i) {
+        for (;;) {
+            const int32_t l = left[i], r = right[i];
+            if (l >= 0 && r >= 0) return slot_of[i];
+            if (l < 0 && r < 0) return -1 - i;
+            i = (l >= 0) ? l : r;
+        }
+    };
+    for (uint32_t sl = 0; sl < n_int; ++sl) {
+        const int32_t i = slot_node[sl], l = left[i], r = right[i];
+        int32_t *rec = info.data() + (size_t)sl * 4;
+        double w2 = 0.0;
+        for (uint32_t q = 0; q < d; ++q) {
+            const float wv = centroids[(size_t)l * d + q] - centroids[(size_t)r * d + q];
+            w[(size_t)sl * d + q] = wv;
+            w2 += (double)wv * (double)wv;
+        }
+        const float b = (float)(a2[l] - a2[r]);
+        const float wn = (float)(std::sqrt(w2) * 1.000001);
+        if (!(w2 <= 1e300)) finite = false;
+        rec[0] = resolve(l);
+        rec[1] = resolve(r);
         memcpy(&rec[2], &b, 4);
         memcpy(&rec[3], &wn, 4);
     }
+    const int32_t start = resolve(0);
+    if (start < 0) return VQHIP_OK;  // the root leads to one leaf without any decision: exact walk
+    t->scr.start_slot = start;
+    VQ_TRY(t->scr_slot_node.alloc((size_t)n_int * 4));
+    VQ_HIP(hipMemcpyAsync(t->scr_slot_node.p, slot_node.data(), (size_t)n_int * 4, hipMemcpyHostToDevice, s));
+    t->scr.slot_node = t->scr_slot_node.as<int32_t>();
     VQ_TRY(t->scr_w.alloc(w.size() * 4));
     VQ_TRY(t->scr_info.alloc(info.size() * 4));
     VQ_TRY(t->scr_mu.alloc((size_t)d * 4));

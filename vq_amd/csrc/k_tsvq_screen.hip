@@ -12,10 +12,11 @@
 // while |delta^| > T(row, node) (DESIGN.md 4.4 "descent soundness"); otherwise (row, node) goes to
 // a work list and k_tsvq_continue finishes it from that node in the reference's arithmetic.
 //
-// Mapping: 8 lanes per row (a row's 128-B pieces are read whole), each lane keeps D/8 values
-// of y in registers for the whole descent; the tree's w vectors live in LDS (130 KB at depth
-// 8, D = 128); lane groups 2,3 of every 32 walk the 128-B chunks in swapped order so that a
-// ds_read_b128 lane group touches all 64 banks when its four rows sit in different nodes.
+// Mapping: 8 lanes per row, each lane keeps its D/8 values of y in registers for the whole
+// descent; the tree's w vectors live in LDS (130 KB at depth 8, D = 128).
+#include <cstdint>
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -30,40 +31,65 @@ __device__ __forceinline__ float dpp_add(float v) {
     const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
     return v + o;
 }
-// sum over the 8 lanes of a row group; every lane gets the same bits (each step adds a symmetric pair)
-__device__ __forceinline__ float allreduce8(float v) {
-    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);  // row_half_mirror
-    return v;
-}
 
-template <int DPL, int U>
+// State of a row = the SLOT of the two-child node it stands at (slots number those nodes; chains
+// of one-child nodes are collapsed on the host).  info[slot] = {code_l, code_r, bits(b), bits(|w|)},
+// code >= 0: the child's slot, code < 0: the child ends in leaf -1-code.  `cur` >= 0: deciding at
+// slot cur; cur in [-n_nodes, -1]: arrived at leaf -1-cur; cur < kFlagBase/2: undecided at slot
+// cur - kFlagBase.  The w vector and the info record of a slot are fetched together (one LDS round
+// trip per level) and the verdict is select-only: ~46 instructions per level for 64/LPR rows.
+//
+// LPR = 8 lanes share a row, so every global load instruction asks for whole 128-B lines (with 4
+// lanes per row the two 64-B halves of a line arrive as separate L2 misses: measured FETCH_SIZE
+// 1.7x the algorithmic bytes and 176 us instead of 137 us at C4, profiles/r1).  In step c a lane
+// reads chunk (c + rot) of its row, rot chosen so that the rows inside one ds_read_b128 lane group
+// ({0-3,12-15,20-27}, ... MI355X_MICROARCH.md LDS) hit different bank halves when they stand in
+// different nodes.
+constexpr int32_t kFlagBase = INT32_MIN;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int D, int LPR>
 __global__ __launch_bounds__(kWaves * 64) void k_tsvq_screen_descend(
     const float *__restrict__ X, uint64_t n, const float *__restrict__ w_g, const int4 *__restrict__ info_g,
-    const float *__restrict__ mu_g, uint32_t n_nodes, uint32_t n_int, float R, float coef_a, float coef_b,
+    const float *__restrict__ mu_g, uint32_t n_int, int32_t start_slot, float R, float coef_a, float coef_b,
     int32_t *__restrict__ leaf_out, uint2 *__restrict__ wl, uint32_t *__restrict__ wl_count) {
-    constexpr int D = DPL * 8;
-    constexpr int NCH = DPL / 4;  // 128-B chunks (32 floats) per row
+    constexpr int CH = LPR * 4;       // floats per chunk (LPR lanes x float4)
+    constexpr int NCH = D / CH;       // chunks per row = float4 values per lane
+    constexpr int RPW = 64 / LPR;     // rows per wave step
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *lds_w = lds;                                                       // [n_int][D]
-    int4 *lds_info = reinterpret_cast<int4 *>(lds + (size_t)n_int * D);        // [n_nodes]
-    uint2 *lds_wl = reinterpret_cast<uint2 *>(lds_info + n_nodes);             // [kWaves][kWlBuf]
-    for (uint32_t e = threadIdx.x; e < n_int * (D / 4); e += kWaves * 64)
-        reinterpret_cast<float4 *>(lds_w)[e] = reinterpret_cast<const float4 *>(w_g)[e];
-    for (uint32_t e = threadIdx.x; e < n_nodes; e += kWaves * 64) lds_info[e] = info_g[e];
+    int4 *lds_info = reinterpret_cast<int4 *>(lds + (size_t)n_int * D);        // [n_int]
+    uint2 *lds_wl = reinterpret_cast<uint2 *>(lds_info + n_int);               // [kWaves][kWlBuf]
+    {
+        constexpr uint32_t T = kWaves * 64;
+        const uint32_t total = n_int * (D / 4);
+        for (uint32_t e0 = 0; e0 < total; e0 += 4 * T) {  // 4 loads in flight per thread
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t e = e0 + i * T + threadIdx.x;
+                v[i] = reinterpret_cast<const float4 *>(w_g)[e < total ? e : 0];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t e = e0 + i * T + threadIdx.x;
+                if (e < total) reinterpret_cast<float4 *>(lds_w)[e] = v[i];
+            }
+        }
+        for (uint32_t e = threadIdx.x; e < n_int; e += T) lds_info[e] = info_g[e];
+    }
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t j = lane & 7, g = lane >> 3;
-    const uint32_t swap = (NCH >= 2) ? ((lane >> 4) & 1u) : 0u;
+    const uint32_t j = lane % LPR, g = lane / LPR;
+    const uint32_t rot = (LPR == 4) ? ((lane >> 3) & 3u) : ((lane >> 4) & 1u);
     uint32_t off[NCH];
 #pragma unroll
-    for (int q = 0; q < NCH; ++q) off[q] = ((uint32_t)q ^ swap) * 32 + 4 * j;
+    for (int c = 0; c < NCH; ++c) off[c] = (((uint32_t)c + rot) % NCH) * CH + 4 * j;
     float4 mu[NCH];
 #pragma unroll
-    for (int q = 0; q < NCH; ++q) mu[q] = *reinterpret_cast<const float4 *>(mu_g + off[q]);
+    for (int c = 0; c < NCH; ++c) mu[c] = *reinterpret_cast<const float4 *>(mu_g + off[c]);
     uint2 *my_wl = lds_wl + (size_t)wave * kWlBuf;
     uint32_t wl_n = 0;  // wave-uniform
 
@@ -74,80 +100,75 @@ __global__ __launch_bounds__(kWaves * 64) void k_tsvq_screen_descend(
         if (lane < wl_n) wl[base + lane] = my_wl[lane];
         wl_n = 0;
     };
+    auto allreduce = [&](float v) {
+        v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+        v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+        if (LPR == 8) v = dpp_add<0x141>(v);  // row_half_mirror
+        return v;
+    };
 
-    const uint64_t n_tiles = (n + 8 * U - 1) / (8 * U);
-    for (uint64_t tile = (uint64_t)blockIdx.x * kWaves + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * kWaves) {
-        float4 y[U][NCH];
-        float base[U];
-        int32_t node[U];
-        uint32_t state[U];  // 0 active, 1 leaf reached, 2 undecided at `node`, 3 no row
-        uint64_t row[U];
+    const uint64_t n_tiles = (n + RPW - 1) / RPW;
+    const uint64_t tile_stride = (uint64_t)gridDim.x * kWaves;
+    auto load_tile = [&](uint64_t tile, float4 (&xv)[NCH]) {
+        const uint64_t r = tile * RPW + g;
+        const float *px = X + ((r < n) ? r : (n - 1)) * D;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            row[u] = tile * (8 * U) + (uint64_t)u * 8 + g;
-            const bool valid = row[u] < n;
-            const float *px = X + (valid ? row[u] : 0) * D;
-            float ysq = 0.0f;
+        for (int c = 0; c < NCH; ++c) xv[c] = *reinterpret_cast<const float4 *>(px + off[c]);
+    };
+    uint64_t tile = (uint64_t)blockIdx.x * kWaves + wave;
+    float4 xn[NCH];
+    if (tile < n_tiles) load_tile(tile, xn);
+    for (; tile < n_tiles; tile += tile_stride) {
+        const uint64_t row = tile * RPW + g;
+        float4 y[NCH];
+        float ysq0 = 0.0f, ysq1 = 0.0f;
 #pragma unroll
-            for (int q = 0; q < NCH; ++q) {
-                const float4 xv = *reinterpret_cast<const float4 *>(px + off[q]);
-                y[u][q] = make_float4(xv.x - mu[q].x, xv.y - mu[q].y, xv.z - mu[q].z, xv.w - mu[q].w);
-                ysq = fmaf(y[u][q].x, y[u][q].x, ysq);
-                ysq = fmaf(y[u][q].y, y[u][q].y, ysq);
-                ysq = fmaf(y[u][q].z, y[u][q].z, ysq);
-                ysq = fmaf(y[u][q].w, y[u][q].w, ysq);
-            }
-            ysq = allreduce8(ysq);
-            base[u] = (__builtin_sqrtf(ysq) + R) * 1.0001f;
-            node[u] = 0;
-            state[u] = valid ? 0u : 3u;
+        for (int c = 0; c < NCH; ++c) {
+            y[c] = make_float4(xn[c].x - mu[c].x, xn[c].y - mu[c].y, xn[c].z - mu[c].z, xn[c].w - mu[c].w);
+            ysq0 = fmaf(y[c].x, y[c].x, ysq0);
+            ysq1 = fmaf(y[c].y, y[c].y, ysq1);
+            ysq0 = fmaf(y[c].z, y[c].z, ysq0);
+            ysq1 = fmaf(y[c].w, y[c].w, ysq1);
         }
+        const float base = (__builtin_sqrtf(allreduce(ysq0 + ysq1)) + R) * 1.0001f;
+        // T = u * base * (coef_a * base + coef_b * |w|) + 1e-36
+        const float t_a = fmaf(5.9604644775390625e-08f * coef_a * base, base, 1e-36f);
+        const float t_b = 5.9604644775390625e-08f * coef_b * base;
+        int32_t cur = (row < n) ? start_slot : -1;
+        if (tile + tile_stride < n_tiles) load_tile(tile + tile_stride, xn);  // in flight during the descent
         for (;;) {
-            bool any_active = false;
+            const int32_t a = cur > 0 ? cur : 0;
+            const int4 inf = lds_info[a];
+            const float *wp = lds_w + (size_t)a * D;
+            float4 wv[NCH];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int4 inf = lds_info[node[u]];
-                const int32_t l = (inf.x & 0xFFFF) - 1, r = (int32_t)((uint32_t)inf.x >> 16) - 1;
-                const bool both = (l >= 0) && (r >= 0);
-                const float *wp = lds_w + (size_t)(both ? inf.y : 0) * D;
-                float acc0 = 0.0f, acc1 = 0.0f;
+            for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
+            // register-adjacent pairs -> v_pk_fma_f32 without operand shuffles
+            f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
 #pragma unroll
-                for (int q = 0; q < NCH; ++q) {
-                    const float4 wv = *reinterpret_cast<const float4 *>(wp + off[q]);
-                    acc0 = fmaf(y[u][q].x, wv.x, acc0);
-                    acc1 = fmaf(y[u][q].y, wv.y, acc1);
-                    acc0 = fmaf(y[u][q].z, wv.z, acc0);
-                    acc1 = fmaf(y[u][q].w, wv.w, acc1);
-                }
-                const float acc = allreduce8(acc0 + acc1);
-                const float delta = fmaf(-2.0f, acc, __int_as_float(inf.z));
-                const float T = 5.9604644775390625e-08f * base[u] * fmaf(coef_b, __int_as_float(inf.w), coef_a * base[u]) +
-                                1e-36f;
-                const bool pass = fabsf(delta) > T;  // false for NaN / inf thresholds
-                const bool active = state[u] == 0u;
-                const bool leaf = (l < 0) && (r < 0);
-                if (active) {
-                    if (leaf) state[u] = 1u;
-                    else if (both && !pass) state[u] = 2u;
-                    else node[u] = both ? (delta < 0.0f ? l : r) : (l >= 0 ? l : r);
-                }
-                any_active = any_active || (state[u] == 0u);
+            for (int c = 0; c < NCH; ++c) {
+                acc01 = __builtin_elementwise_fma(f32x2{y[c].x, y[c].y}, f32x2{wv[c].x, wv[c].y}, acc01);
+                acc23 = __builtin_elementwise_fma(f32x2{y[c].z, y[c].w}, f32x2{wv[c].z, wv[c].w}, acc23);
             }
-            if (!__any(any_active)) break;
+            acc01 = acc01 + acc23;
+            const float acc = allreduce(acc01.x + acc01.y);
+            const float delta = fmaf(-2.0f, acc, __int_as_float(inf.z));
+            const float T = fmaf(t_b, __int_as_float(inf.w), t_a);
+            const int32_t code = (delta < 0.0f) ? inf.x : inf.y;
+            const int32_t next = (fabsf(delta) > T) ? code : (kFlagBase + a);  // NaN / inf thresholds never pass
+            cur = (cur >= 0) ? next : cur;
+            if (!__any(cur >= 0)) break;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (j == 0 && state[u] == 1u) leaf_out[row[u]] = node[u];
-            const bool push = (j == 0) && (state[u] == 2u);
-            const uint64_t mask = __ballot(push);
-            if (mask) {
-                const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                if (push) my_wl[wl_n + before] = make_uint2((uint32_t)row[u], (uint32_t)node[u]);
-                wl_n += (uint32_t)__popcll(mask);
-            }
+        if (j == 0 && cur < 0 && cur > kFlagBase / 2 && row < n) leaf_out[row] = -1 - cur;
+        const bool push = (j == 0) && (cur <= kFlagBase / 2);
+        const uint64_t mask = __ballot(push);
+        if (mask) {
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (push) my_wl[wl_n + before] = make_uint2((uint32_t)row, (uint32_t)(cur - kFlagBase));
+            wl_n += (uint32_t)__popcll(mask);
         }
-        if (wl_n > kWlBuf - 8 * U) flush();
+        if (wl_n > kWlBuf - RPW) flush();
     }
     if (wl_n) flush();
 }
@@ -178,6 +199,7 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
                                                        const float *__restrict__ centroids,
                                                        const int32_t *__restrict__ left,
                                                        const int32_t *__restrict__ right, int euclid,
+                                                       const int32_t *__restrict__ slot_node,
                                                        const uint2 *__restrict__ wl,
                                                        const uint32_t *__restrict__ wl_count,
                                                        int32_t *__restrict__ leaf_out) {
@@ -195,7 +217,7 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
         float x[NQ][V];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) load_piece<V>(px + q * 16 * V, x[q]);
-        int32_t node = (int32_t)ent.y;
+        int32_t node = valid ? slot_node[ent.y] : 0;
         bool walking = valid;
         while (__any(walking)) {
             const int32_t l = left[node], r = right[node];
@@ -257,27 +279,27 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
 template <int D>
 static int launch_continue(const float *X, const float *centroids, const int32_t *left, const int32_t *right,
                            int euclid, const TsvqScreen &s, int32_t *leaf, hipStream_t stream) {
-    hipLaunchKernelGGL(k_tsvq_continue<D>, dim3(1024), dim3(256), 0, stream, X, centroids, left, right, euclid, s.wl,
-                       s.wl_count, leaf);
+    hipLaunchKernelGGL(k_tsvq_continue<D>, dim3(1024), dim3(256), 0, stream, X, centroids, left, right, euclid,
+                       s.slot_node, s.wl, s.wl_count, leaf);
     VQ_LAUNCH_CHECK("k_tsvq_continue");
     return VQHIP_OK;
 }
 
-template <int DPL>
+template <int D, int LPR>
 int launch_screen(const float *X, uint64_t n, const TsvqScreen &s, hipStream_t stream, int32_t *leaf) {
-    constexpr int U = 2;
-    const size_t lds_bytes = tsvq_screen_lds_bytes(s.n_int, s.n_nodes, DPL * 8);
+    constexpr int RPW = 64 / LPR;
+    const size_t lds_bytes = tsvq_screen_lds_bytes(s.n_int, s.n_nodes, D);
     static bool attr_set = false;
     if (!attr_set) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<DPL, U>),
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    const uint64_t n_tiles = (n + 8 * U - 1) / (8 * U);
+    const uint64_t n_tiles = (n + RPW - 1) / RPW;
     uint64_t grid = (n_tiles + kWaves - 1) / kWaves;
     if (grid > (uint64_t)num_cus()) grid = (uint64_t)num_cus();
-    hipLaunchKernelGGL((k_tsvq_screen_descend<DPL, U>), dim3((uint32_t)grid), dim3(kWaves * 64), lds_bytes, stream, X,
-                       n, s.w, s.info, s.mu, s.n_nodes, s.n_int, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count);
+    hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR>), dim3((uint32_t)grid), dim3(kWaves * 64), lds_bytes, stream, X,
+                       n, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count);
     VQ_LAUNCH_CHECK("k_tsvq_screen_descend");
     return VQHIP_OK;
 }
@@ -285,13 +307,14 @@ int launch_screen(const float *X, uint64_t n, const TsvqScreen &s, hipStream_t s
 }  // namespace
 
 size_t tsvq_screen_lds_bytes(uint32_t n_int, uint32_t n_nodes, uint32_t d) {
-    return (size_t)n_int * d * 4 + (size_t)n_nodes * 16 + (size_t)kWaves * kWlBuf * 8;
+    (void)n_nodes;
+    return (size_t)n_int * d * 4 + (size_t)n_int * 16 + (size_t)kWaves * kWlBuf * 8;
 }
 
 bool tsvq_screen_supported(uint32_t n_int, uint32_t n_nodes, uint32_t d, int metric) {
     if (metric != VQHIP_SQUARED_EUCLIDEAN && metric != VQHIP_EUCLIDEAN) return false;
     if (!(d == 32 || d == 64 || d == 128 || d == 256)) return false;
-    if (n_nodes >= 65535 || n_int == 0) return false;
+    if (n_int == 0) return false;
     return tsvq_screen_lds_bytes(n_int, n_nodes, d) <= 160 * 1024;
 }
 
@@ -304,19 +327,19 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
     const int euclid = metric == VQHIP_EUCLIDEAN ? 1 : 0;
     switch (d) {
     case 32:
-        VQ_TRY(launch_screen<4>(X, n, s, stream, leaf));
+        VQ_TRY((launch_screen<32, 8>(X, n, s, stream, leaf)));
         VQ_TRY(launch_continue<32>(X, centroids, left, right, euclid, s, leaf, stream));
         break;
     case 64:
-        VQ_TRY(launch_screen<8>(X, n, s, stream, leaf));
+        VQ_TRY((launch_screen<64, 8>(X, n, s, stream, leaf)));
         VQ_TRY(launch_continue<64>(X, centroids, left, right, euclid, s, leaf, stream));
         break;
     case 128:
-        VQ_TRY(launch_screen<16>(X, n, s, stream, leaf));
+        VQ_TRY((launch_screen<128, 8>(X, n, s, stream, leaf)));
         VQ_TRY(launch_continue<128>(X, centroids, left, right, euclid, s, leaf, stream));
         break;
     case 256:
-        VQ_TRY(launch_screen<32>(X, n, s, stream, leaf));
+        VQ_TRY((launch_screen<256, 8>(X, n, s, stream, leaf)));
         VQ_TRY(launch_continue<256>(X, centroids, left, right, euclid, s, leaf, stream));
         break;
     default: return fail(VQHIP_ERR_UNSUPPORTED, "screened TSVQ descent: d=%u", d);

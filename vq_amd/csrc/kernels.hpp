@@ -112,7 +112,9 @@ int tsvq_build_device(const float *X, uint64_t n, uint32_t d, uint32_t max_depth
 // prepared per-node data of the screened squared-L2 / Euclidean descent (k_tsvq_screen.hip)
 struct TsvqScreen {
     const float *w = nullptr;     // [n_int][d]  c_left - c_right of every two-child node
-    const int4 *info = nullptr;   // [n_nodes]   {(l+1)|(r+1)<<16, slot in w, bits(b), bits(|w|)}
+    const int4 *info = nullptr;   // [n_int]     {code_l, code_r, bits(b), bits(|w|)}; code >= 0 slot, < 0 leaf -1-code
+    const int32_t *slot_node = nullptr;  // [n_int] node index of a slot
+    int32_t start_slot = 0;       // slot the root resolves to
     const float *mu = nullptr;    // [d]         root centroid
     uint32_t n_int = 0, n_nodes = 0;
     float R = 0.0f;               // >= max_node |c - mu|
