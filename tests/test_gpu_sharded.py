@@ -46,3 +46,53 @@ def test_hipshard_slab_aliases_library_buffer_and_fit_matches():
             ds.close()
         finally:
             _lib.set_stream(None)
+
+
+_RCCL_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["VQ_REPO"])
+import torch
+import torch.distributed as dist
+from vq_amd import _lib
+from vq_amd.pq import fit_codebooks
+from vq_amd.sharded import Comm, HipShard, ShardedKMeans
+
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+_lib.load(); _lib.set_device(0)
+n, d, m, k = 20000, 64, 4, 32
+X = np.random.default_rng(6).random((n, d), dtype=np.float32)
+init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.int64)
+stream = torch.cuda.Stream()
+with torch.cuda.stream(stream):
+    _lib.set_stream(stream.cuda_stream)
+    ds = _lib.Dataset.from_host(X)
+    shard = HipShard(ds, m, k, 0)
+    skm = ShardedKMeans(shard, n, Comm(force=True))       # 1-rank group, collectives ON
+    assert skm.comm.on and skm._collective_device() is not None
+    cb = skm.fit(5, seed=3, init_rows=init, reseed_rows=[[7] * 32] * m)
+    assert shard._slab_alias
+    cb_ref = fit_codebooks(ds, m, k, 5, init_rows=init.astype(np.uint64), reseed_rows=[[7] * 32] * m)
+    np.testing.assert_array_equal(cb, cb_ref)
+    torch.cuda.synchronize()
+    _lib.set_stream(None)
+dist.destroy_process_group()
+print("RCCL_OK")
+'''
+
+
+def test_collectives_over_rccl_single_rank(tmp_path):
+    """The all-reduce / broadcast calls of the sharded fit on a real RCCL process group (one
+    rank, collectives forced on): same stream, zero-copy slab, identical codebooks."""
+    import os
+    import subprocess
+    import sys
+
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29531", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               VQ_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

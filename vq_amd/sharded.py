@@ -61,11 +61,12 @@ def owner_of(n_global: int, world: int, row: int) -> int:
 class Comm:
     """torch.distributed wrapper that degrades to a no-op for a single process."""
 
-    def __init__(self):
+    def __init__(self, force: bool = False):
+        """force=True keeps the collectives on for a 1-rank group (used to exercise RCCL on one GPU)"""
         import torch.distributed as dist
 
         self.dist = dist
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.on = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
         self.rank = dist.get_rank() if self.on else 0
         self.world = dist.get_world_size() if self.on else 1
 
