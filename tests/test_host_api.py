@@ -189,3 +189,42 @@ def test_tsvq_surface_and_quality():
 @pytest.mark.gpu
 def test_get_simd_backend_names_the_device_backend():
     assert "gfx950" in pyvq.get_simd_backend()
+
+
+@pytest.mark.gpu
+def test_code_index_reproduces_quantize_output(tmp_path):
+    # m code bytes per vector + codebooks carry what quantize() returns (src/pq.rs:183-196)
+    from vq_amd.store import PQIndex
+
+    X = np.random.default_rng(8).random((3000, 32), dtype=F)
+    pq = pyvq.ProductQuantizer(X, 8, 64, max_iters=5, distance=pyvq.Distance.squared_euclidean())
+    idx = PQIndex.from_quantizer(pq, X)
+    np.testing.assert_array_equal(idx.reconstruct_f16().view(np.uint16), pq.quantize_batch(X).view(np.uint16))
+    np.testing.assert_array_equal(idx.reconstruct(), pq.decode(idx.codes))
+    idx.save(tmp_path / "i.vqpq")
+    back = PQIndex.load(tmp_path / "i.vqpq")
+    pq2 = pyvq.ProductQuantizer.from_codebooks(back.codebooks, back.distance)
+    np.testing.assert_array_equal(pq2.encode(X[:100]), idx.codes[:100])
+    assert 4 * 32 * len(idx) / idx.codes.nbytes == 16.0  # vs 2x for the f16 form
+
+
+@pytest.mark.gpu
+def test_eval_report_has_the_reference_lines(capsys):
+    # src/bin/eval_pq.rs:33-69, src/bin/eval_tsvq.rs:27-56
+    from vq_amd import evalcli
+
+    assert evalcli.main(["pq", "--samples", "1000", "2000", "--dim", "32", "--m", "4", "--k", "16"]) == 0
+    out = capsys.readouterr().out
+    assert out.startswith("Product Quantizer Evaluation\n============================\n")
+    assert out.count("Samples: ") == 2 and "Samples: 2000" in out
+    for key in ("Training time:", "Quantization time:", "Reconstruction error:", "Recall@10:"):
+        assert out.count(key) == 2
+    err = float(out.split("Reconstruction error: ")[1].split()[0])
+    assert 0.0 < err < 1.0 / 12  # better than quantizing Uniform[0,1) to its mean
+    assert evalcli.main(["tsvq", "--samples", "1000", "--dim", "32", "--max-depth", "4", "--json"]) == 0
+    import json
+
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    res = json.loads(lines[0])
+    assert set(res) >= {"n_samples", "n_dims", "training_time_ms", "quantization_time_ms", "reconstruction_error",
+                        "recall", "memory_reduction_ratio"}
