@@ -143,6 +143,24 @@ def test_encode_cosine_screen_adversarial(oracle):
     _check_encode(oracle, X, cbn, O.COSINE, _lib.ENGINE_MFMA_BF16)
 
 
+@pytest.mark.parametrize("offset", [0.0, 100.0, -3000.0, 1e6])
+def test_encode_offset_data_centred_screen(oracle, offset):
+    """The X32 screen works on x - mu, c - mu (mu = mean centroid): data far from the origin keeps a
+    tight margin (few re-checks) and stays bit-exact."""
+    rng = np.random.default_rng(51)
+    n, d, m, k = 8192, 128, 8, 256
+    X = (rng.random((n, d), dtype=F) + F(offset)).astype(F)
+    cb = X[rng.choice(n, m * k, replace=False)].reshape(m, k, d)[:, :, :d // m].copy()
+    for s in range(m):
+        cb[s] = X[rng.choice(n, k, replace=False), s * (d // m):(s + 1) * (d // m)]
+    for metric in (O.SQUARED_EUCLIDEAN, O.EUCLIDEAN):
+        _check_encode(oracle, X, cb, metric, _lib.ENGINE_MFMA_BF16)
+        rechecked, engine = _check_encode.last_stats
+        assert engine == _lib.ENGINE_MFMA_BF16
+        if abs(offset) <= 100.0:
+            assert rechecked < 0.05 * n * m
+
+
 def test_encode_codebook_rows_are_their_own_code(oracle):
     # k = N distinct rows (tests/regression_tests.rs:357-363 generalised): quantize(x_i) == f16(x_i)
     rng = np.random.default_rng(5)

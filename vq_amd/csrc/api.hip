@@ -87,7 +87,7 @@ struct CodebookState {
     bool mfma_ok = false, bf16_ok = false;
     bool prepared = false;
     int metric = VQHIP_SQUARED_EUCLIDEAN;  // what the prepared images are for (cosine differs)
-    DevBuf cb, prepA, prepCn, meta, cnsqrt, prepA16, prepA32;
+    DevBuf cb, prepA, prepCn, meta, cnsqrt, prepA16, prepA32, cbc, cen, cn32;
     bool x32_ok = false;
 
     int init(uint32_t m_, uint32_t k_, uint32_t sd_) {
@@ -105,7 +105,12 @@ struct CodebookState {
             bf16_ok = screen_bf16_supported(sd, k);
             if (bf16_ok) VQ_TRY(prepA16.alloc((size_t)m * nt * screen_bf16_mfmas(sd) * 4 * 64 * 4));
             x32_ok = bf16_ok && screen_bf16_x32_supported(sd, k);
-            if (x32_ok) VQ_TRY(prepA32.alloc((size_t)m * ((k + 31) / 32) * screen_bf16_x32_mfmas(sd) * 4 * 64 * 4));
+            if (x32_ok) {
+                VQ_TRY(prepA32.alloc((size_t)m * ((k + 31) / 32) * screen_bf16_x32_mfmas(sd) * 4 * 64 * 4));
+                VQ_TRY(cbc.alloc((size_t)m * k * sd * 4));
+                VQ_TRY(cen.alloc((size_t)m * (sd + 4) * 4));
+                VQ_TRY(cn32.alloc((size_t)m * ((k + 31) / 32) * 32 * 4));
+            }
         }
         prepared = false;
         return VQHIP_OK;
@@ -124,6 +129,8 @@ struct CodebookState {
         v.cnsqrt = cnsqrt.as<float>();
         v.prepA16 = bf16_ok ? prepA16.as<uint32_t>() : nullptr;
         v.prepA32 = x32_ok ? prepA32.as<uint32_t>() : nullptr;
+        v.cen = x32_ok ? cen.as<float>() : nullptr;
+        v.cn32 = x32_ok ? cn32.as<float>() : nullptr;
         return v;
     }
     int prepare(hipStream_t stream) {
@@ -134,7 +141,9 @@ struct CodebookState {
                                        cnsqrt.as<float>(), stream));
         const bool use32 = x32_ok && screen_bf16_uses_x32(sd, k);
         if (bf16_ok && !use32) VQ_TRY(launch_prepare_bf16(v, prepA16.as<uint32_t>(), stream));
-        if (use32) VQ_TRY(launch_prepare_bf16_x32(v, prepA32.as<uint32_t>(), metric == VQHIP_COSINE ? 1 : 0, stream));
+        if (use32)
+            VQ_TRY(launch_prepare_bf16_x32(v, prepA32.as<uint32_t>(), metric == VQHIP_COSINE ? 1 : 0, cbc.as<float>(),
+                                           cen.as<float>(), cn32.as<float>(), stream));
         prepared = true;
         return VQHIP_OK;
     }

@@ -594,6 +594,70 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // A image for the 32x32x16 form: [m][NT32][NMF][4 dwords][64 lanes]; lane (h = l>>5, c = l&31),
 // k-slot j (0..7) of MFMA f: pair = f*PPM + j/DPH, dim = h*DPH + j%DPH, with DPH = sd/2, PPM = 8/DPH
+// Centred copy of a codebook for the X32 squared-L2 screen.  Distances do not change under a
+// common translation, but the margin T is proportional to (|x - mu| + max|c - mu|)^2, so the
+// screen works on x - mu and c - mu with mu = the mean centroid of the subspace: Uniform[0,1)
+// sub-vectors of 16 dimensions shrink from |x| ~ 2.3 to ~ 1.15 (T / 4), data with a large common
+// offset by far more.  cen[s] = {mu[sd], max|c - mu|, margin coefficient, -, -}; cn32 = |c - mu|^2
+// (sequential f32 like k_prepare_codebook), padded with a large finite value.
+__global__ __launch_bounds__(256) void k_center_codebook_x32(const float *__restrict__ cb, uint32_t m, uint32_t k,
+                                                             uint32_t sd, uint32_t cn_stride, uint32_t nmf,
+                                                             float *__restrict__ cbc, float *__restrict__ cen,
+                                                             float *__restrict__ cn32) {
+    __shared__ float s_mu[64];
+    __shared__ float s_max[256];
+    __shared__ int s_bad[256];
+    const uint32_t s = blockIdx.x;
+    const float *cbs = cb + (size_t)s * k * sd;
+    float *cen_s = cen + (size_t)s * (sd + 4);
+    if (threadIdx.x < sd) {
+        double acc = 0.0;
+        for (uint32_t j = 0; j < k; ++j) acc += (double)cbs[(size_t)j * sd + threadIdx.x];
+        const float mu = (float)(acc / (double)k);
+        s_mu[threadIdx.x] = mu;
+        cen_s[threadIdx.x] = mu;
+    }
+    __syncthreads();
+    float lmax = 0.0f;
+    int bad = 0;
+    for (uint32_t j = threadIdx.x; j < cn_stride; j += 256) {
+        if (j < k) {
+            float acc = -0.0f;
+            for (uint32_t t = 0; t < sd; ++t) {
+                const float v = cbs[(size_t)j * sd + t] - s_mu[t];
+                cbc[((size_t)s * k + j) * sd + t] = v;
+                const float p = v * v;
+                acc = acc + p;
+                if (!(fabsf(v) <= 3.0e38f)) bad = 1;
+            }
+            if (!(acc <= 3.0e38f)) bad = 1;
+            cn32[(size_t)s * cn_stride + j] = (acc <= 3.0e38f) ? acc + 0.0f : 3.0e38f;
+            lmax = fmaxf(lmax, acc);
+        } else {
+            cn32[(size_t)s * cn_stride + j] = 3.0e38f;  // padding never wins; finite (index packing)
+        }
+    }
+    s_max[threadIdx.x] = lmax;
+    s_bad[threadIdx.x] = bad;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + off]);
+            s_bad[threadIdx.x] |= s_bad[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // DESIGN.md "screen soundness": bf16 coefficient + 128 (index packing) + 16 (rounding of x - mu, c - mu)
+        const float u = 5.9604644775390625e-08f;
+        const float coef = (8.0f * (float)sd + 16.0f + 32.0f * (float)nmf + 16.0f + 128.0f + 16.0f) * u;
+        cen_s[sd] = sqrtf(s_max[0]) * 1.0000005f + 1e-30f;
+        cen_s[sd + 1] = s_bad[0] ? __builtin_inff() : coef;
+        cen_s[sd + 2] = 0.0f;
+        cen_s[sd + 3] = 0.0f;
+    }
+}
+
 // cosine != 0: the image holds -c/|c| (zero for |c| < 1e-10, whose distance is the constant 1.0,
 // src/core/distance.rs:113-115) so that the screen forms s_j = -|x| cos(x, c_j)
 __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restrict__ cb, uint32_t m, uint32_t k,
@@ -634,7 +698,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
     const uint32_t *__restrict__ prepA32, const float *__restrict__ prepCn, uint32_t cn_stride,
     const float *__restrict__ meta, const uint32_t *__restrict__ sub_list, uint32_t n_sub,
     uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_seg,
-    uint32_t n_seg, uint64_t wl_stride, int cosine, uint32_t k_real) {
+    uint32_t n_seg, uint64_t wl_stride, int cosine, uint32_t k_real, const float *__restrict__ cen) {
     constexpr int DPH = SD / 2;            // dims owned by a lane half
     constexpr int PPM = 8 / DPH;           // term pairs per MFMA
     constexpr int NMF = (6 + PPM - 1) / PPM;
@@ -686,10 +750,23 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
     uint32_t idx_mask = 0xFFFFFFC0u;  // low 6 mantissa bits carry the value index
     asm volatile("" : "+s"(idx_mask));
     asm volatile("" : "+s"(pinf), "+s"(ninf));
-    const float cmax = meta[s * 4 + 0];
-    float tcoef = meta[s * 4 + 3];  // bf16 coefficient + 128 * 2^-24 for the index packing
-    if (cosine && tcoef <= 3.0e38f)    // DESIGN.md "screen soundness", cosine: (6*sd + 40*NMF + 200) * 2^-24 * |x|
-        tcoef = (6.0f * SD + 40.0f * NMF + 200.0f) * 5.9604644775390625e-08f;
+    // squared-L2 / Euclidean: centred operands (k_center_codebook_x32); cosine: as is
+    float cmax, tcoef;
+    float mu[DPH];
+    if (cosine) {
+        cmax = 0.0f;
+        tcoef = meta[s * 4 + 3];  // only its finiteness matters here
+        if (tcoef <= 3.0e38f)     // DESIGN.md "screen soundness", cosine: (6*sd + 40*NMF + 200) * 2^-24 * |x|
+            tcoef = (6.0f * SD + 40.0f * NMF + 200.0f) * 5.9604644775390625e-08f;
+#pragma unroll
+        for (int q = 0; q < DPH; ++q) mu[q] = 0.0f;
+    } else {
+        const float *cs = cen + (size_t)s * (SD + 4);
+        cmax = cs[SD];
+        tcoef = cs[SD + 1];
+#pragma unroll
+        for (int q = 0; q < DPH; ++q) mu[q] = cs[DPH * h + q];
+    }
 
     const size_t col0 = (size_t)s * SD + (size_t)DPH * h;
     auto load_x = [&](uint64_t row, float (&x)[DPH]) {
@@ -720,7 +797,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
     for (uint64_t st = st0; st < st1; ++st) {
         float x[DPH];
 #pragma unroll
-        for (int q = 0; q < DPH; ++q) x[q] = xn_[q];
+        for (int q = 0; q < DPH; ++q) x[q] = xn_[q] - mu[q];
         if (st + 1 < st1) load_x((st + 1) * 32 + p, xn_);
 
         // three bf16 slices of the lane's DPH components, packed two per dword
@@ -1388,8 +1465,8 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
     VQ_HIP(hipMemsetAsync(a.wl_seg, 0, (size_t)cb.m * n_chunks * 8, stream));
     a.n_seg = n_chunks;
     hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d,
-                       cb.m, cb.prepA32, cb.prepCn, cb.nt * 16, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
-                       a.wl_seg, n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k);
+                       cb.m, cb.prepA32, cb.cn32, NT32 * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
+                       a.wl_seg, n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen);
     VQ_LAUNCH_CHECK("k_assign_screen_bf16_x32");
     return VQHIP_OK;
 }
@@ -1411,9 +1488,20 @@ uint32_t screen_bf16_x32_mfmas(uint32_t sd) {
     const uint32_t dph = sd / 2, ppm = 8 / dph;
     return (6 + ppm - 1) / ppm;
 }
-int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine, hipStream_t stream) {
+// X32 images of a codebook.  Squared-L2 / Euclidean: centred copy (cbc), its norms (cn32) and {mu, max|c-mu|,
+// coefficient} (cen), then the bf16 slices of -2(c - mu); cosine: bf16 slices of -c/|c| from the codebook as is.
+int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine, float *cbc, float *cen,
+                            float *cn32, hipStream_t stream) {
     if (v.m == 0) return VQHIP_OK;
-    hipLaunchKernelGGL(k_prepare_bf16_x32, dim3(v.m, 16), dim3(256), 0, stream, v.cb, v.m, v.k, v.sd, (v.k + 31) / 32,
+    const uint32_t nt32 = (v.k + 31) / 32;
+    const float *src = v.cb;
+    if (!cosine) {
+        hipLaunchKernelGGL(k_center_codebook_x32, dim3(v.m), dim3(256), 0, stream, v.cb, v.m, v.k, v.sd, nt32 * 32,
+                           screen_bf16_x32_mfmas(v.sd), cbc, cen, cn32);
+        VQ_LAUNCH_CHECK("k_center_codebook_x32");
+        src = cbc;
+    }
+    hipLaunchKernelGGL(k_prepare_bf16_x32, dim3(v.m, 16), dim3(256), 0, stream, src, v.m, v.k, v.sd, nt32,
                        screen_bf16_x32_mfmas(v.sd), cosine, v.cnsqrt, prepA32);
     VQ_LAUNCH_CHECK("k_prepare_bf16_x32");
     return VQHIP_OK;

@@ -20,6 +20,8 @@ struct CodebookView {
     const float *cnsqrt = nullptr;   // [m][k]            sqrt(sum c^2) (cosine's norm_b)
     const uint32_t *prepA16 = nullptr;  // [m][nt][NM][4][64] packed bf16 slices of -2*c (bf16 screen)
     const uint32_t *prepA32 = nullptr;  // [m][ceil(k/32)][NMF][4][64] same, 32x32x16 MFMA lane order
+    const float *cen = nullptr;      // [m][sd+4]  X32, L2: {mu[sd], max|c-mu|, margin coefficient, -, -}
+    const float *cn32 = nullptr;     // [m][ceil(k/32)*32]  X32, L2: |c-mu|^2, finite padding
 };
 
 // MFMA screen availability for a shape
@@ -33,7 +35,8 @@ int launch_prepare_bf16(const CodebookView &v, uint32_t *prepA16, hipStream_t st
 bool screen_bf16_x32_supported(uint32_t sd, uint32_t k);
 bool screen_bf16_uses_x32(uint32_t sd, uint32_t k);
 uint32_t screen_bf16_x32_mfmas(uint32_t sd);
-int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine, hipStream_t stream);
+int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine, float *cbc, float *cen,
+                            float *cn32, hipStream_t stream);
 
 int launch_prepare_codebook(const CodebookView &v, float *prepA, float *prepCn, float *meta,
                             float *cnsqrt, hipStream_t stream);
