@@ -610,12 +610,23 @@ __global__ __launch_bounds__(256) void k_center_codebook_x32(const float *__rest
     const uint32_t s = blockIdx.x;
     const float *cbs = cb + (size_t)s * k * sd;
     float *cen_s = cen + (size_t)s * (sd + 4);
-    if (threadIdx.x < sd) {
+    // column means: 256 threads = (256/sd) row groups x sd columns, partial sums through LDS
+    // (a single thread per column walking k dependent loads cost 25 us per launch)
+    {
+        __shared__ double s_part[256];
+        const uint32_t col = threadIdx.x % sd, grp = threadIdx.x / sd, n_grp = 256 / sd;
         double acc = 0.0;
-        for (uint32_t j = 0; j < k; ++j) acc += (double)cbs[(size_t)j * sd + threadIdx.x];
-        const float mu = (float)(acc / (double)k);
-        s_mu[threadIdx.x] = mu;
-        cen_s[threadIdx.x] = mu;
+        if (grp < n_grp)
+            for (uint32_t j = grp; j < k; j += n_grp) acc += (double)cbs[(size_t)j * sd + col];
+        s_part[threadIdx.x] = (grp < n_grp) ? acc : 0.0;
+        __syncthreads();
+        if (threadIdx.x < sd) {
+            double tot = 0.0;
+            for (uint32_t g2 = 0; g2 < n_grp; ++g2) tot += s_part[g2 * sd + threadIdx.x];
+            const float mu = (float)(tot / (double)k);
+            s_mu[threadIdx.x] = mu;
+            cen_s[threadIdx.x] = mu;
+        }
     }
     __syncthreads();
     float lmax = 0.0f;
