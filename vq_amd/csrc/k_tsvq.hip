@@ -37,6 +37,7 @@ namespace {
 constexpr uint32_t kInactive = 0xFFFFFFFFu;
 constexpr uint32_t DG = 16;          // dimensions per workgroup in the column-sum kernel
 constexpr uint32_t kTileRows = 480;  // rows per LDS tile: 15 loader waves x 32 rows
+constexpr uint32_t kTilePitch = kTileRows + 4;
 
 struct NodeArrays {
     uint32_t *seg_start, *seg_len, *split_dim, *nv, *nleft;
@@ -71,17 +72,26 @@ __global__ __launch_bounds__(1024) void k_seg_colsum(const float *__restrict__ X
                                                      const uint32_t *__restrict__ perm,
                                                      const uint32_t *__restrict__ lvl_node,
                                                      NodeArrays na) {
-    __shared__ float tile[2][kTileRows][DG];
+    // column-major tiles: the consumer lane of a column reads 4 consecutive rows per ds_read_b128
+    // (pitch 484 floats: the 16 columns start 36 banks apart -> conflict-free 16-byte reads)
+    __shared__ __attribute__((aligned(16))) float tile[2][DG][kTilePitch];
     const uint32_t node = lvl_node[blockIdx.x];
     const uint32_t a = na.seg_start[node], n = na.seg_len[node];
     const uint32_t t0 = blockIdx.y * DG;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n_tiles = (n + kTileRows - 1) / kTileRows;
     float acc = (MODE == 0) ? 0.0f : -0.0f;
-    float mu = 0.0f;
-    if (MODE == 1 && wave == 0 && lane < DG && t0 + lane < d) mu = na.centroid[(size_t)node * d + t0 + lane];
-    const bool vec_ok = (d % 4 == 0);
     const uint32_t q = lane & 3;
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);  // the consumer's add chain is the critical path
+    // variance pass: the loader lanes form (x - mean)^2 (same two roundings as tsvq.rs:47-55), the
+    // consumer only carries the ordered additions
+    float mu4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (MODE == 1 && wave != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (t0 + 4 * q + i < d) mu4[i] = na.centroid[(size_t)node * d + t0 + 4 * q + i];
+    }
+    const bool vec_ok = (d % 4 == 0);
 
     // loader lanes: 2 x (16 rows x 4 float4) per tile
     auto fetch = [&](uint32_t tile_idx, float4 (&v)[2]) {
@@ -105,8 +115,18 @@ __global__ __launch_bounds__(1024) void k_seg_colsum(const float *__restrict__ X
     };
     auto put = [&](uint32_t buf, const float4 (&v)[2]) {
 #pragma unroll
-        for (uint32_t rep = 0; rep < 2; ++rep)
-            *reinterpret_cast<float4 *>(&tile[buf][(wave - 1) * 32 + (lane >> 2) + rep * 16][4 * q]) = v[rep];
+        for (uint32_t rep = 0; rep < 2; ++rep) {
+            const uint32_t row = (wave - 1) * 32 + (lane >> 2) + rep * 16;
+            float e[4] = {v[rep].x, v[rep].y, v[rep].z, v[rep].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (MODE == 1) {
+                    const float diff = e[i] - mu4[i];
+                    e[i] = diff * diff;
+                }
+                tile[buf][4 * q + i][row] = e[i];
+            }
+        }
     };
 
     float4 r1[2], r2[2];  // tiles ti+1 and ti+2 in flight (loader waves only)
@@ -127,32 +147,21 @@ __global__ __launch_bounds__(1024) void k_seg_colsum(const float *__restrict__ X
             fetch(ti + 3, r2);
         } else if (lane < DG) {
             const uint32_t rows = min(kTileRows, n - ti * kTileRows);
+            const float *col = &tile[buf][lane][0];
             uint32_t r = 0;
             for (; r + 32 <= rows; r += 32) {
-                float v[32];
+                float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 32; ++u) v[u] = tile[buf][r + u][lane];
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(col + r + 4 * u);
 #pragma unroll
-                for (int u = 0; u < 32; ++u) {
-                    if (MODE == 0) {
-                        acc = acc + v[u];
-                    } else {
-                        const float diff = v[u] - mu;
-                        const float sq = diff * diff;
-                        acc = acc + sq;
-                    }
+                for (int u = 0; u < 8; ++u) {
+                    acc = acc + v[u].x;
+                    acc = acc + v[u].y;
+                    acc = acc + v[u].z;
+                    acc = acc + v[u].w;
                 }
             }
-            for (; r < rows; ++r) {
-                const float x = tile[buf][r][lane];
-                if (MODE == 0) {
-                    acc = acc + x;
-                } else {
-                    const float diff = x - mu;
-                    const float sq = diff * diff;
-                    acc = acc + sq;
-                }
-            }
+            for (; r < rows; ++r) acc = acc + col[r];
         }
         __syncthreads();
     }
