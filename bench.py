@@ -297,6 +297,8 @@ def main():
             "codes_checksum_rank0": checksum,
         }
         line.update(extras)
+        r32, r16, trusted = _lib.selftest()
+        line["bf16_mfma_selftest"] = {"ratio_32x32x16": r32, "ratio_16x16x32": r16, "budget": 32.0, "trusted": trusted}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(M, K, DIM, codebooks)
         print(json.dumps(line))

@@ -83,6 +83,12 @@ int vqhip_set_device(int device);
 int vqhip_set_stream(void *hip_stream);
 /* block until the calling thread's stream is idle */
 int vqhip_synchronize(void);
+/* One-time device self-test behind the bf16-split engine: worst observed accumulation error of
+ * v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16 in units of 2^-24 (|C| + sum|a*b|) over
+ * adversarial operand families (exact f64 reference on the device).  The margin coefficients
+ * budget 32; *trusted = 1 iff both ratios are <= 16, otherwise ENGINE_AUTO uses the fp32 MFMA
+ * screen and ENGINE_MFMA_BF16 is refused.  Any out-pointer may be NULL. */
+int vqhip_selftest(float *bf16_32x32x16_ratio, float *bf16_16x16x32_ratio, int *bf16_engine_trusted);
 /* statistics of the most recent assign/encode launch of this thread: rows sent to the
  * exact re-check, and the engine used (VQHIP_ENGINE_EXACT / _MFMA) */
 int vqhip_last_assign_stats(uint64_t *rechecked, int *engine);

@@ -161,6 +161,13 @@ def test_encode_offset_data_centred_screen(oracle, offset):
             assert rechecked < 0.05 * n * m
 
 
+def test_bf16_mfma_accumulation_selftest():
+    """The bf16-split screen's margin budgets 32 * 2^-24 (|C| + sum|ab|) of accumulation error per MFMA
+    (DESIGN.md "screen soundness"); the library measures it on this device and must see <= 16."""
+    r32, r16, trusted = _lib.selftest()
+    assert trusted and 0.0 < r32 <= 16.0 and 0.0 < r16 <= 16.0, (r32, r16)
+
+
 def test_encode_codebook_rows_are_their_own_code(oracle):
     # k = N distinct rows (tests/regression_tests.rs:357-363 generalised): quantize(x_i) == f16(x_i)
     rng = np.random.default_rng(5)

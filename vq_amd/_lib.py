@@ -79,6 +79,7 @@ SIGNATURES = {
     "vqhip_tsvq_destroy": (C.c_int, [_vp]),
     "vqhip_tsvq_encode": (C.c_int, [_vp, _f32p, C.c_uint64, _i32p, _u16p]),
     "vqhip_tsvq_encode_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "vqhip_selftest": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "vqhip_tsvq_last_stats": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
 }
 
@@ -319,6 +320,13 @@ def set_device(device: int):
 
 def set_stream(stream_ptr: int | None):
     check(load().vqhip_set_stream(C.c_void_p(stream_ptr or 0)))
+
+
+def selftest():
+    """(ratio 32x32x16, ratio 16x16x32, trusted): bf16 MFMA accumulation error in units of 2^-24"""
+    a, b, t = C.c_float(0), C.c_float(0), C.c_int(0)
+    check(load().vqhip_selftest(C.byref(a), C.byref(b), C.byref(t)))
+    return float(a.value), float(b.value), bool(t.value)
 
 
 def synchronize():

@@ -103,6 +103,11 @@ struct CodebookState {
             VQ_TRY(prepA.alloc((size_t)m * nt * ks * 64 * 4));
             VQ_TRY(prepCn.alloc((size_t)m * nt * 16 * 4));
             bf16_ok = screen_bf16_supported(sd, k);
+            if (bf16_ok) {  // the bf16 engine is used only on a device whose MFMA passed the accumulation self-test
+                int trusted = 0;
+                VQ_TRY(bf16_mfma_selftest(nullptr, nullptr, &trusted));
+                bf16_ok = trusted != 0;
+            }
             if (bf16_ok) VQ_TRY(prepA16.alloc((size_t)m * nt * screen_bf16_mfmas(sd) * 4 * 64 * 4));
             x32_ok = bf16_ok && screen_bf16_x32_supported(sd, k);
             if (x32_ok) {
@@ -479,6 +484,13 @@ int vqhip_set_stream(void *hip_stream) {
     st.user_stream = reinterpret_cast<hipStream_t>(hip_stream);
     st.user_stream_set = (hip_stream != nullptr);
     return VQHIP_OK;
+}
+
+int vqhip_selftest(float *bf16_32x32x16_ratio, float *bf16_16x16x32_ratio, int *bf16_engine_trusted) {
+    VQ_API_BEGIN
+    VQ_TRY(require_gfx950());
+    return bf16_mfma_selftest(bf16_32x32x16_ratio, bf16_16x16x32_ratio, bf16_engine_trusted);
+    VQ_API_END
 }
 
 int vqhip_synchronize(void) {

@@ -304,12 +304,12 @@ __global__ __launch_bounds__(256) void k_prepare_codebook(const float *__restric
         float coef = (8.0f * (float)sd + 16.0f) * u;
         meta[s * 4 + 0] = sqrtf(s_max[0]) * 1.0000005f + 1e-30f;
         meta[s * 4 + 1] = s_bad[0] ? __builtin_inff() : coef;
-        // bf16-split screen (k_screen_bf16.hip): + 32 per MFMA (eps_M = 16 * 2^-24, both ends of
-        // the gap) + 16 for the dropped cross terms
+        // bf16-split screen (k_screen_bf16.hip): + 2 * kBf16AssumedUlps per MFMA (both ends of the
+        // gap; the constant is checked on the device by k_selftest.hip) + 16 for the dropped cross terms
         float coef16 = __builtin_inff();
         if (sd % 4 == 0 && sd >= 4 && sd <= 32) {
             const uint32_t dpg = sd / 4, pp = 8 / dpg, nm = (6 + pp - 1) / pp;
-            coef16 = (8.0f * (float)sd + 16.0f + 32.0f * (float)nm + 16.0f) * u;
+            coef16 = (8.0f * (float)sd + 16.0f + 2.0f * kBf16AssumedUlps * (float)nm + 16.0f) * u;
         }
         meta[s * 4 + 2] = s_bad[0] ? __builtin_inff() : coef16;
         // X32 variant packs a 6-bit index into the low mantissa bits: |perturbation| < 2^-18 |s|

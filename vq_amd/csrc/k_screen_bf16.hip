@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void k_center_codebook_x32(const float *__rest
     if (threadIdx.x == 0) {
         // DESIGN.md "screen soundness": bf16 coefficient + 128 (index packing) + 16 (rounding of x - mu, c - mu)
         const float u = 5.9604644775390625e-08f;
-        const float coef = (8.0f * (float)sd + 16.0f + 32.0f * (float)nmf + 16.0f + 128.0f + 16.0f) * u;
+        const float coef = (8.0f * (float)sd + 16.0f + 2.0f * kBf16AssumedUlps * (float)nmf + 16.0f + 128.0f + 16.0f) * u;
         cen_s[sd] = sqrtf(s_max[0]) * 1.0000005f + 1e-30f;
         cen_s[sd + 1] = s_bad[0] ? __builtin_inff() : coef;
         cen_s[sd + 2] = 0.0f;
@@ -767,8 +767,8 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
     if (cosine) {
         cmax = 0.0f;
         tcoef = meta[s * 4 + 3];  // only its finiteness matters here
-        if (tcoef <= 3.0e38f)     // DESIGN.md "screen soundness", cosine: (6*sd + 40*NMF + 200) * 2^-24 * |x|
-            tcoef = (6.0f * SD + 40.0f * NMF + 200.0f) * 5.9604644775390625e-08f;
+        if (tcoef <= 3.0e38f)     // DESIGN.md "screen soundness", cosine: (6*sd + 2.5*eps_M*NMF + 200) * 2^-24 * |x|
+            tcoef = (6.0f * SD + 2.5f * kBf16AssumedUlps * NMF + 200.0f) * 5.9604644775390625e-08f;
 #pragma unroll
         for (int q = 0; q < DPH; ++q) mu[q] = 0.0f;
     } else {

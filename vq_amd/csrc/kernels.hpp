@@ -28,6 +28,11 @@ struct CodebookView {
 bool screen_supported(uint32_t sd, uint32_t k);
 void screen_tiling(uint32_t sd, uint32_t k, uint32_t *nt, uint32_t *ks);
 
+// per-MFMA accumulation error (in units of 2^-24 (|C| + sum|ab|)) that the bf16 margin coefficients budget
+constexpr float kBf16AssumedUlps = 32.0f;
+// one-time device measurement of that quantity (k_selftest.hip); trusted = measured <= half the budget
+int bf16_mfma_selftest(float *ratio32, float *ratio16, int *trusted);
+
 // bf16-split screen (k_screen_bf16.hip)
 bool screen_bf16_supported(uint32_t sd, uint32_t k);
 uint32_t screen_bf16_mfmas(uint32_t sd);
