@@ -56,6 +56,8 @@ SHAPES = [  # (n, d, m, k)
     (999, 64, 2, 33),      # sub_dim 32
     (500, 12, 4, 7),       # sub_dim 3: no MFMA form -> exact engine
     (257, 5, 1, 3),        # m = 1, odd dim
+    (2000, 96, 4, 256),    # sub_dim 24 (the reference eval's DIM=384, M=16 shape): X32 engine only
+    (1500, 48, 2, 40),     # sub_dim 24, ragged k
 ]
 
 
@@ -72,7 +74,9 @@ def test_encode_l2_bit_exact(oracle, shape, kind, metric):
     _check_encode(oracle, X, cb, metric, _lib.ENGINE_EXACT)
     if d // m in (4, 8, 16, 32):
         _check_encode(oracle, X, cb, metric, _lib.ENGINE_MFMA)       # fp32 MFMA screen
+    if d // m in (4, 8, 16, 24, 32):
         _check_encode(oracle, X, cb, metric, _lib.ENGINE_MFMA_BF16)  # bf16-split screen
+        assert _check_encode.last_stats[1] == _lib.ENGINE_MFMA_BF16
 
 
 @pytest.mark.parametrize("shape", SHAPES[:5])
@@ -89,7 +93,7 @@ def test_encode_l1_cosine_bit_exact(oracle, shape, kind, metric):
 
 
 COSINE_SHAPES = [(3000, 64, 4, 16), (2500, 128, 8, 256), (1000, 128, 16, 256), (1200, 768, 96, 256),
-                 (1500, 64, 8, 37)]
+                 (1500, 64, 8, 37), (1800, 96, 4, 200)]
 
 
 @pytest.mark.parametrize("shape", COSINE_SHAPES)
@@ -239,12 +243,14 @@ def test_encode_ragged_sizes(oracle):
     assert codes.shape == (0, 8) and f16.shape == (0, 128)
 
 
-@pytest.mark.parametrize("shape", [(4000, 64, 4, 16), (6000, 128, 8, 256), (3000, 128, 16, 64)])
+@pytest.mark.parametrize("shape", [(4000, 64, 4, 16), (6000, 128, 8, 256), (3000, 128, 16, 64), (5000, 96, 4, 64)])
 @pytest.mark.parametrize("kind", ["uniform", "clustered"])
 @pytest.mark.parametrize("engine", [_lib.ENGINE_AUTO, _lib.ENGINE_EXACT, _lib.ENGINE_MFMA])
 def test_lloyd_step_parity(oracle, shape, kind, engine):
     n, d, m, k = shape
     sd = d // m
+    if engine == _lib.ENGINE_MFMA and sd not in (4, 8, 16, 32):
+        pytest.skip("no fp32 MFMA instantiation for this sub_dim (bf16 X32 engine only)")
     X = _data(11, n, d, kind)
     init = np.array([[(j * (n // k) + 7 * s) % n for j in range(k)] for s in range(m)], np.uint64)
     ds = _lib.Dataset.from_host(X)

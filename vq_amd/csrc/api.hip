@@ -84,7 +84,7 @@ int current_stream(hipStream_t *out) {
 // ------------------------------------------------------------------ codebook state ----
 struct CodebookState {
     uint32_t m = 0, k = 0, sd = 0, nt = 0, ks = 0;
-    bool mfma_ok = false, bf16_ok = false;
+    bool mfma_ok = false, bf16_ok = false, bf16_16 = false;
     bool prepared = false;
     int metric = VQHIP_SQUARED_EUCLIDEAN;  // what the prepared images are for (cosine differs)
     DevBuf cb, prepA, prepCn, meta, cnsqrt, prepA16, prepA32, cbc, cen, cn32;
@@ -98,24 +98,27 @@ struct CodebookState {
         VQ_TRY(cb.alloc((size_t)m * k * sd * 4));
         VQ_TRY(cnsqrt.alloc((size_t)m * k * 4));
         VQ_TRY(meta.alloc((size_t)m * 4 * 4));
+        nt = ks = 0;
         if (mfma_ok) {
             screen_tiling(sd, k, &nt, &ks);
             VQ_TRY(prepA.alloc((size_t)m * nt * ks * 64 * 4));
             VQ_TRY(prepCn.alloc((size_t)m * nt * 16 * 4));
-            bf16_ok = screen_bf16_supported(sd, k);
-            if (bf16_ok) {  // the bf16 engine is used only on a device whose MFMA passed the accumulation self-test
-                int trusted = 0;
-                VQ_TRY(bf16_mfma_selftest(nullptr, nullptr, &trusted));
-                bf16_ok = trusted != 0;
-            }
-            if (bf16_ok) VQ_TRY(prepA16.alloc((size_t)m * nt * screen_bf16_mfmas(sd) * 4 * 64 * 4));
-            x32_ok = bf16_ok && screen_bf16_x32_supported(sd, k);
-            if (x32_ok) {
-                VQ_TRY(prepA32.alloc((size_t)m * ((k + 31) / 32) * screen_bf16_x32_mfmas(sd) * 4 * 64 * 4));
-                VQ_TRY(cbc.alloc((size_t)m * k * sd * 4));
-                VQ_TRY(cen.alloc((size_t)m * (sd + 4) * 4));
-                VQ_TRY(cn32.alloc((size_t)m * ((k + 31) / 32) * 32 * 4));
-            }
+        }
+        // bf16 engines (16x16 variants share the fp32 engine's tiling; X32 has its own shapes, e.g. sub_dim 24)
+        bf16_16 = mfma_ok && screen_bf16_supported(sd, k);
+        x32_ok = screen_bf16_x32_supported(sd, k);
+        if (bf16_16 || x32_ok) {  // only on a device whose bf16 MFMA passed the accumulation self-test
+            int trusted = 0;
+            VQ_TRY(bf16_mfma_selftest(nullptr, nullptr, &trusted));
+            if (!trusted) bf16_16 = x32_ok = false;
+        }
+        bf16_ok = bf16_16 || x32_ok;
+        if (bf16_16) VQ_TRY(prepA16.alloc((size_t)m * nt * screen_bf16_mfmas(sd) * 4 * 64 * 4));
+        if (x32_ok) {
+            VQ_TRY(prepA32.alloc((size_t)m * ((k + 31) / 32) * screen_bf16_x32_mfmas(sd) * 4 * 64 * 4));
+            VQ_TRY(cbc.alloc((size_t)m * k * sd * 4));
+            VQ_TRY(cen.alloc((size_t)m * (sd + 4) * 4));
+            VQ_TRY(cn32.alloc((size_t)m * ((k + 31) / 32) * 32 * 4));
         }
         prepared = false;
         return VQHIP_OK;
@@ -132,7 +135,7 @@ struct CodebookState {
         v.prepCn = mfma_ok ? prepCn.as<float>() : nullptr;
         v.meta = meta.as<float>();
         v.cnsqrt = cnsqrt.as<float>();
-        v.prepA16 = bf16_ok ? prepA16.as<uint32_t>() : nullptr;
+        v.prepA16 = bf16_16 ? prepA16.as<uint32_t>() : nullptr;
         v.prepA32 = x32_ok ? prepA32.as<uint32_t>() : nullptr;
         v.cen = x32_ok ? cen.as<float>() : nullptr;
         v.cn32 = x32_ok ? cn32.as<float>() : nullptr;
@@ -145,7 +148,7 @@ struct CodebookState {
                                        mfma_ok ? prepCn.as<float>() : nullptr, meta.as<float>(),
                                        cnsqrt.as<float>(), stream));
         const bool use32 = x32_ok && screen_bf16_uses_x32(sd, k);
-        if (bf16_ok && !use32) VQ_TRY(launch_prepare_bf16(v, prepA16.as<uint32_t>(), stream));
+        if (bf16_16 && !use32) VQ_TRY(launch_prepare_bf16(v, prepA16.as<uint32_t>(), stream));
         if (use32)
             VQ_TRY(launch_prepare_bf16_x32(v, prepA32.as<uint32_t>(), metric == VQHIP_COSINE ? 1 : 0, cbc.as<float>(),
                                            cen.as<float>(), cn32.as<float>(), stream));

@@ -593,7 +593,8 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_pipe(
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // A image for the 32x32x16 form: [m][NT32][NMF][4 dwords][64 lanes]; lane (h = l>>5, c = l&31),
-// k-slot j (0..7) of MFMA f: pair = f*PPM + j/DPH, dim = h*DPH + j%DPH, with DPH = sd/2, PPM = 8/DPH
+// k-slot j (0..7) of MFMA f: flat = 8f + j, pair = flat / DPH, dim = h*DPH + flat % DPH, with DPH = sd/2
+// (sd = 8: two pairs per MFMA; 16: one; 24: nine MFMAs carry the 6 x 12 (pair, dim) slots of a lane half)
 // Centred copy of a codebook for the X32 squared-L2 screen.  Distances do not change under a
 // common translation, but the margin T is proportional to (|x - mu| + max|c - mu|)^2, so the
 // screen works on x - mu and c - mu with mu = the mean centroid of the subspace: Uniform[0,1)
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
                                                           const float *__restrict__ cnsqrt,
                                                           uint32_t *__restrict__ prepA32) {
     const uint32_t s = blockIdx.x;
-    const uint32_t dph = sd / 2, ppm = 8 / dph;
+    const uint32_t dph = sd / 2;
     const float *cbs = cb + (size_t)s * k * sd;
     const uint32_t total = nt32 * nmf * 4 * 64;
     for (uint32_t e = blockIdx.y * blockDim.x + threadIdx.x; e < total; e += gridDim.y * blockDim.x) {
@@ -684,9 +685,8 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
         const uint32_t h = lane >> 5, c = lane & 31, j = 32 * i + c;
         uint32_t half[2] = {0u, 0u};
         for (uint32_t hh = 0; hh < 2; ++hh) {
-            const uint32_t slot = 2 * w + hh;
-            const uint32_t pq = slot / dph, dd = slot - pq * dph;
-            const uint32_t pair = f * ppm + pq;
+            const uint32_t flat = 8 * f + 2 * w + hh;  // k-slot of this lane half over all MFMAs
+            const uint32_t pair = flat / dph, dd = flat - pair * dph;
             if (pair < 6 && j < k) {
                 uint32_t parts[3];
                 const float c = cbs[(size_t)j * sd + h * dph + dd];
@@ -711,8 +711,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
     uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_seg,
     uint32_t n_seg, uint64_t wl_stride, int cosine, uint32_t k_real, const float *__restrict__ cen) {
     constexpr int DPH = SD / 2;            // dims owned by a lane half
-    constexpr int PPM = 8 / DPH;           // term pairs per MFMA
-    constexpr int NMF = (6 + PPM - 1) / PPM;
+    constexpr int NMF = (6 * DPH + 7) / 8;  // MFMAs per 32x32 tile: 6 term pairs x DPH dims per lane half
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t h = lane >> 5, p = lane & 31;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -832,7 +831,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
                 uint32_t hw[2];
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
-                    const int sl = 2 * w + hh, pq = sl / DPH, dd = sl % DPH, pair = f * PPM + pq;
+                    const int flat = 8 * f + 2 * w + hh, pair = flat / DPH, dd = flat % DPH;
                     hw[hh] = (pair < 6) ? xp[pair_x(pair)][dd] : 0u;
                 }
                 v[w] = (hw[0] >> 16) | (hw[1] & 0xFFFF0000u);
@@ -866,6 +865,15 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
                 q1[r] = __builtin_amdgcn_fmed3f(q1[r], pk, ninf);
             }
         };
+        // A operands are named as AGPRs while they fit (256); the image of sub_dim 24 at k = 256 is 288
+        // registers, its last tile stays in VGPRs (an "a" operand beyond the file would be copied in
+        // front of every use, behind the compiler's back as far as MFMA hazards go)
+        auto mfma = [&](f32x16 &accv, int ti, int f) {
+            if ((ti * NMF + f + 1) * 4 <= 256)
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv) : "a"(a[ti][f]), "v"(b[f]));
+            else
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv) : "v"(a[ti][f]), "v"(b[f]));
+        };
         float snap[4] = {pinf, pinf, pinf, pinf};
         init_acc(acc[0], 0);
         if (NT32 > 1) init_acc(acc[1], 1);
@@ -873,11 +881,11 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
         asm volatile("s_nop 1");
 #pragma unroll
         for (int f = 0; f < NMF; ++f)
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[0]) : "a"(a[0][f]), "v"(b[f]));
+            mfma(acc[0], 0, f);
         if (NT32 > 1) {
 #pragma unroll
             for (int f = 0; f < NMF; ++f)
-                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[1]) : "a"(a[1][f]), "v"(b[f]));
+                mfma(acc[1], 1, f);
         } else {
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
         }
@@ -889,14 +897,22 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
                 for (int r = 0; r < 4; ++r) snap[r] = q1[r];
             }
             constexpr int kGroups = 4;
+            if constexpr (NMF <= 6) {
 #pragma unroll
-            for (int f = 0; f < (NMF > kGroups ? NMF : kGroups); ++f) {
-                if (i + 2 < NT32 && f < NMF)
-                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
-                                 : "+v"(acc[(i + 2) & 3])
-                                 : "a"(a[(i + 2 < NT32) ? i + 2 : 0][f]), "v"(b[f]));
-                if (f < kGroups) reduce4(acc[i & 3], i, f);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int f = 0; f < (NMF > kGroups ? NMF : kGroups); ++f) {
+                    if (i + 2 < NT32 && f < NMF) mfma(acc[(i + 2) & 3], (i + 2 < NT32) ? i + 2 : 0, f);
+                    if (f < kGroups) reduce4(acc[i & 3], i, f);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {  // longer chains (sub_dim 24): reduce group g follows MFMA ceil((g+1) NMF / 4) - 1
+#pragma unroll
+                for (int f = 0; f < NMF; ++f) {
+                    if (i + 2 < NT32) mfma(acc[(i + 2) & 3], (i + 2 < NT32) ? i + 2 : 0, f);
+#pragma unroll
+                    for (int g4 = 0; g4 < kGroups; ++g4)
+                        if (f == ((g4 + 1) * NMF + kGroups - 1) / kGroups - 1) reduce4(acc[i & 3], i, g4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             if (i + 2 >= NT32 && i + 1 < NT32) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
         }
@@ -1491,13 +1507,12 @@ bool screen_bf16_uses_x32(uint32_t sd, uint32_t k) {
 }
 
 bool screen_bf16_x32_supported(uint32_t sd, uint32_t k) {
-    if (!(sd == 8 || sd == 16)) return false;
+    if (!(sd == 8 || sd == 16 || sd == 24)) return false;
     if (k == 0 || k > 256) return false;
     return true;
 }
 uint32_t screen_bf16_x32_mfmas(uint32_t sd) {
-    const uint32_t dph = sd / 2, ppm = 8 / dph;
-    return (6 + ppm - 1) / ppm;
+    return (6 * (sd / 2) + 7) / 8;
 }
 // X32 images of a codebook.  Squared-L2 / Euclidean: centred copy (cbc), its norms (cn32) and {mu, max|c-mu|,
 // coefficient} (cen), then the bf16 slices of -2(c - mu); cosine: bf16 slices of -c/|c| from the codebook as is.
@@ -1545,7 +1560,8 @@ int launch_prepare_bf16(const CodebookView &v, uint32_t *prepA16, hipStream_t st
 
 int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) {
     if (a.n == 0 || a.n_sub == 0) return VQHIP_OK;
-    if (!screen_bf16_supported(cb.sd, cb.k) || (!cb.prepA16 && !cb.prepA32))
+    const bool x32_ready = cb.prepA32 && screen_bf16_x32_supported(cb.sd, cb.k);
+    if (!x32_ready && !(screen_bf16_supported(cb.sd, cb.k) && cb.prepA16))
         return fail(VQHIP_ERR_UNSUPPORTED, "no bf16 MFMA screen for sub_dim=%u k=%u", cb.sd, cb.k);
     if (a.metric == VQHIP_COSINE && !(cb.prepA32 && screen_bf16_uses_x32(cb.sd, cb.k)))
         return fail(VQHIP_ERR_UNSUPPORTED, "cosine screen needs the X32 variant (sub_dim 8 or 16)");
@@ -1558,6 +1574,7 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
     if (cb.sd == SDV && nt32 == NTV) return launch_one_x32<SDV, NTV>(cb, a, stream);
         VQ_X32(16, 1) VQ_X32(16, 2) VQ_X32(16, 3) VQ_X32(16, 4) VQ_X32(16, 5) VQ_X32(16, 6) VQ_X32(16, 7) VQ_X32(16, 8)
         VQ_X32(8, 1) VQ_X32(8, 2) VQ_X32(8, 3) VQ_X32(8, 4) VQ_X32(8, 5) VQ_X32(8, 6) VQ_X32(8, 7) VQ_X32(8, 8)
+        VQ_X32(24, 1) VQ_X32(24, 2) VQ_X32(24, 3) VQ_X32(24, 4) VQ_X32(24, 5) VQ_X32(24, 6) VQ_X32(24, 7) VQ_X32(24, 8)
 #undef VQ_X32
     }
 #define VQ_CASE(SDV, NTV)                                                              \
