@@ -243,7 +243,7 @@ def test_encode_ragged_sizes(oracle):
     assert codes.shape == (0, 8) and f16.shape == (0, 128)
 
 
-@pytest.mark.parametrize("shape", [(4000, 64, 4, 16), (6000, 128, 8, 256), (3000, 128, 16, 64), (5000, 96, 4, 64)])
+@pytest.mark.parametrize("shape", [(4000, 64, 4, 16), (6000, 128, 8, 256), (3000, 128, 16, 64), (5000, 96, 4, 64), (3000, 48, 4, 32), (2000, 96, 2, 16)])
 @pytest.mark.parametrize("kind", ["uniform", "clustered"])
 @pytest.mark.parametrize("engine", [_lib.ENGINE_AUTO, _lib.ENGINE_EXACT, _lib.ENGINE_MFMA])
 def test_lloyd_step_parity(oracle, shape, kind, engine):

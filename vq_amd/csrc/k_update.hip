@@ -135,7 +135,8 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
     const uint8_t *__restrict__ active, float *__restrict__ partial_sums,
     uint32_t *__restrict__ partial_counts) {
     constexpr uint32_t SD = KS * 4;
-    constexpr uint32_t RPS = 64 / KS;
+    constexpr uint32_t RPS = 64 / KS;  // rows per step; lanes >= RPS*KS idle when KS is not a power of two
+    constexpr bool POW2 = (KS & (KS - 1)) == 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -149,14 +150,18 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
     for (uint32_t e = lane; e < k; e += 64) cnts[e] = 0u;
 
     const uint32_t p = lane / KS, g = lane % KS;
+    const bool lane_on = lane < RPS * KS;
+    // 16-byte slot of part gg of cluster c: xor swizzle (power-of-two KS) or rotation, so that the
+    // KS parts of different clusters spread over the banks
+    auto swz = [](uint32_t gg, uint32_t c) { return POW2 ? (gg ^ (c & (KS - 1))) : ((gg + c) % KS); };
     const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_chunk;
     uint64_t r1 = r0 + rows_per_chunk;
     if (r1 > n) r1 = n;
     const float *px = X + (size_t)s * SD + 4 * g;
     auto load_x = [&](uint64_t row) {
-        return (row < r1) ? *reinterpret_cast<const float4 *>(px + row * d) : make_float4(0, 0, 0, 0);
+        return (lane_on && row < r1) ? *reinterpret_cast<const float4 *>(px + row * d) : make_float4(0, 0, 0, 0);
     };
-    auto load_c = [&](uint64_t row) { return (row < r1) ? (uint32_t)codes[row * m + s] : 0xFFFFFFFFu; };
+    auto load_c = [&](uint64_t row) { return (lane_on && row < r1) ? (uint32_t)codes[row * m + s] : 0xFFFFFFFFu; };
 
     // HBM latency (~2 us under load) against one 1-KB load per wave limited the first version to
     // 2.1 TB/s; batches of PF steps are double-buffered so a wave keeps 2*PF KB in flight
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
                 rank += (q < p && cq == code) ? 1u : 0u;
             }
             // xor-swizzled 16-byte slot so that the KS parts of different clusters spread over banks
-            float4 *slot = reinterpret_cast<float4 *>(sums + (size_t)code * SD) + (g ^ (code & (KS - 1)));
+            float4 *slot = reinterpret_cast<float4 *>(sums + (size_t)(valid ? code : 0u) * SD) + swz(g, code);
             uint32_t pending = valid ? 1u : 0u;
             for (uint32_t r = 0; __any(pending != 0); ++r) {
                 if (pending && rank == r) {
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
     float *ps = partial_sums + ((size_t)blockIdx.x * m + s) * k * SD;
     for (uint32_t e = lane; e < k * KS; e += 64) {
         const uint32_t j = e / KS, gg = e % KS;
-        const float4 v = reinterpret_cast<const float4 *>(sums + (size_t)j * SD)[gg ^ (j & (KS - 1))];
+        const float4 v = reinterpret_cast<const float4 *>(sums + (size_t)j * SD)[swz(gg, j)];
         reinterpret_cast<float4 *>(ps + (size_t)j * SD)[gg] = v;
     }
     uint32_t *pcnt = partial_counts + ((size_t)blockIdx.x * m + s) * k;
@@ -297,6 +302,14 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ X
 
 }  // namespace
 
+// sub_dims with a wave-owned instantiation (KS = sd/4 lanes per row)
+static bool owned_sub_dim(uint32_t sd) {
+    switch (sd) {
+    case 4: case 8: case 12: case 16: case 24: case 32: case 48: case 64: case 96: case 128: case 256: return true;
+    default: return false;
+    }
+}
+
 int plan_update(uint32_t m, uint32_t k, uint32_t sd, uint64_t n, UpdatePlan *p) {
     p->m = m;
     p->k = k;
@@ -320,10 +333,10 @@ int plan_update(uint32_t m, uint32_t k, uint32_t sd, uint64_t n, UpdatePlan *p) 
     if (max_rc < 1) max_rc = 1;
     if (rc > max_rc) rc = (uint32_t)max_rc;
     p->n_row_chunks = rc;
-    // wave-owned path: sub_dim a power of two in [4,256]; as many waves (= subspaces) per
+    // wave-owned path: sub_dim with an instantiation (owned_sub_dim); as many waves (= subspaces) per
     // workgroup as fit the LDS budget, at most 8
     p->owned_waves = 0;
-    if (sd >= 4 && sd <= 256 && (sd & (sd - 1)) == 0) {
+    if (owned_sub_dim(sd)) {
         uint64_t per_wave = ((uint64_t)k * (sd + 1) + 3) & ~3ull;
         uint32_t w = (uint32_t)(kLdsBudgetWords / per_wave);
         if (w > 8) w = 8;
@@ -371,7 +384,11 @@ int launch_accumulate(const UpdatePlan &p, const float *X, uint64_t n, uint32_t 
         switch (p.sd) {
         case 4: return launch_owned<1>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 8: return launch_owned<2>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 12: return launch_owned<3>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 16: return launch_owned<4>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 24: return launch_owned<6>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 48: return launch_owned<12>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 96: return launch_owned<24>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 32: return launch_owned<8>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 64: return launch_owned<16>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 128: return launch_owned<32>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
