@@ -58,6 +58,7 @@ SHAPES = [  # (n, d, m, k)
     (257, 5, 1, 3),        # m = 1, odd dim
     (2000, 96, 4, 256),    # sub_dim 24 (the reference eval's DIM=384, M=16 shape): X32 engine only
     (1500, 48, 2, 40),     # sub_dim 24, ragged k
+    (1800, 48, 4, 256),    # sub_dim 12 (DIM=384, m=32): X32 engine, 8-byte aligned lane halves
 ]
 
 
@@ -74,7 +75,7 @@ def test_encode_l2_bit_exact(oracle, shape, kind, metric):
     _check_encode(oracle, X, cb, metric, _lib.ENGINE_EXACT)
     if d // m in (4, 8, 16, 32):
         _check_encode(oracle, X, cb, metric, _lib.ENGINE_MFMA)       # fp32 MFMA screen
-    if d // m in (4, 8, 16, 24, 32):
+    if d // m in (4, 8, 12, 16, 24, 32):
         _check_encode(oracle, X, cb, metric, _lib.ENGINE_MFMA_BF16)  # bf16-split screen
         assert _check_encode.last_stats[1] == _lib.ENGINE_MFMA_BF16
 
@@ -93,7 +94,7 @@ def test_encode_l1_cosine_bit_exact(oracle, shape, kind, metric):
 
 
 COSINE_SHAPES = [(3000, 64, 4, 16), (2500, 128, 8, 256), (1000, 128, 16, 256), (1200, 768, 96, 256),
-                 (1500, 64, 8, 37), (1800, 96, 4, 200)]
+                 (1500, 64, 8, 37), (1800, 96, 4, 200), (1300, 48, 4, 77)]
 
 
 @pytest.mark.parametrize("shape", COSINE_SHAPES)

@@ -398,6 +398,7 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
         switch (cb.sd) {
             VQ_RECHECK_CASE(4)
             VQ_RECHECK_CASE(8)
+            VQ_RECHECK_CASE(12)
             VQ_RECHECK_CASE(16)
             VQ_RECHECK_CASE(24)
             VQ_RECHECK_CASE(32)
@@ -416,6 +417,7 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
         VQ_EXACT_CASE(2)
         VQ_EXACT_CASE(4)
         VQ_EXACT_CASE(8)
+        VQ_EXACT_CASE(12)
         VQ_EXACT_CASE(16)
         VQ_EXACT_CASE(24)
         VQ_EXACT_CASE(32)

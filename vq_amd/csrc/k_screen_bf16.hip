@@ -782,13 +782,22 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
     auto load_x = [&](uint64_t row, float (&x)[DPH]) {
         if (row >= n) row = n - 1;
         const float *ptr = X + row * d + col0;
+        if constexpr (DPH % 4 == 0) {
 #pragma unroll
-        for (int q = 0; q < DPH; q += 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(ptr + q);
-            x[q + 0] = t.x;
-            x[q + 1] = t.y;
-            x[q + 2] = t.z;
-            x[q + 3] = t.w;
+            for (int q = 0; q < DPH; q += 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(ptr + q);
+                x[q + 0] = t.x;
+                x[q + 1] = t.y;
+                x[q + 2] = t.z;
+                x[q + 3] = t.w;
+            }
+        } else {  // sub_dim 12: the lane half's 6 floats start on an 8-byte boundary only
+#pragma unroll
+            for (int q = 0; q < DPH; q += 2) {
+                const float2 t = *reinterpret_cast<const float2 *>(ptr + q);
+                x[q + 0] = t.x;
+                x[q + 1] = t.y;
+            }
         }
     };
     auto init_acc = [&](f32x16 &acc, int i) {
@@ -1507,7 +1516,7 @@ bool screen_bf16_uses_x32(uint32_t sd, uint32_t k) {
 }
 
 bool screen_bf16_x32_supported(uint32_t sd, uint32_t k) {
-    if (!(sd == 8 || sd == 16 || sd == 24)) return false;
+    if (!(sd == 8 || sd == 12 || sd == 16 || sd == 24)) return false;
     if (k == 0 || k > 256) return false;
     return true;
 }
@@ -1574,6 +1583,7 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
     if (cb.sd == SDV && nt32 == NTV) return launch_one_x32<SDV, NTV>(cb, a, stream);
         VQ_X32(16, 1) VQ_X32(16, 2) VQ_X32(16, 3) VQ_X32(16, 4) VQ_X32(16, 5) VQ_X32(16, 6) VQ_X32(16, 7) VQ_X32(16, 8)
         VQ_X32(8, 1) VQ_X32(8, 2) VQ_X32(8, 3) VQ_X32(8, 4) VQ_X32(8, 5) VQ_X32(8, 6) VQ_X32(8, 7) VQ_X32(8, 8)
+        VQ_X32(12, 1) VQ_X32(12, 2) VQ_X32(12, 3) VQ_X32(12, 4) VQ_X32(12, 5) VQ_X32(12, 6) VQ_X32(12, 7) VQ_X32(12, 8)
         VQ_X32(24, 1) VQ_X32(24, 2) VQ_X32(24, 3) VQ_X32(24, 4) VQ_X32(24, 5) VQ_X32(24, 6) VQ_X32(24, 7) VQ_X32(24, 8)
 #undef VQ_X32
     }
