@@ -104,3 +104,48 @@ def test_fullsize_mean_property():
         np.testing.assert_allclose(rec, col[s * sd:(s + 1) * sd], rtol=2e-6)
     km.close()
     ds.close()
+
+
+@pytest.mark.parametrize("kind", ["clustered", "heavy_tail", "offset", "tiny_scale"])
+@pytest.mark.parametrize("shape", [(400_000, 128, 8, 256), (300_000, 384, 16, 256), (300_000, 96, 8, 100)])
+def test_fullsize_engine_agreement_distributions(kind, shape):
+    """Screen + re-check == exact scan on every row for data that stresses the margin: tight
+    clusters (genuine near-ties), heavy tails (a few huge norms), a common offset far from the
+    origin, and values near the f32 underflow range.  Squared-L2 and cosine; sub_dim 16 / 24 / 12."""
+    import torch
+
+    n, d, m, k = shape
+    g = torch.Generator(device="cuda").manual_seed(97)
+    if kind == "clustered":
+        centers = torch.randn((k, d), device="cuda", generator=g)
+        X = centers[torch.randint(0, k, (n,), device="cuda", generator=g)] + \
+            0.01 * torch.randn((n, d), device="cuda", generator=g)
+    elif kind == "heavy_tail":
+        X = torch.randn((n, d), device="cuda", generator=g) * torch.exp(2.5 * torch.randn((n, 1), device="cuda", generator=g))
+    elif kind == "offset":
+        X = torch.rand((n, d), device="cuda", generator=g) + 517.25
+    else:
+        X = torch.rand((n, d), device="cuda", generator=g) * 1e-19
+    X = X.to(torch.float32).contiguous()
+    torch.cuda.synchronize()
+    ds = _lib.Dataset.from_device(X.data_ptr(), n, d, keepalive=X)
+    km, _ = _trained(ds, m, k, iters=2)
+    cb = km.get_centroids()
+    km.close()
+    for metric in (_lib.SQUARED_EUCLIDEAN, _lib.COSINE):
+        enc = _lib.PQEncoder(cb, metric)
+        a = torch.empty((n, m), dtype=torch.uint8, device="cuda")
+        b = torch.empty((n, m), dtype=torch.uint8, device="cuda")
+        enc.set_engine(_lib.ENGINE_AUTO)
+        enc.encode_device(ds.device_ptr, n, a.data_ptr(), None)
+        _lib.synchronize()
+        _, engine = _lib.last_assign_stats()
+        assert engine == _lib.ENGINE_MFMA_BF16
+        enc.set_engine(_lib.ENGINE_EXACT)
+        enc.encode_device(ds.device_ptr, n, b.data_ptr(), None)
+        _lib.synchronize()
+        torch.cuda.synchronize()
+        diff = int((a != b).sum().item())
+        assert diff == 0, f"{diff} codes differ ({kind}, metric {metric})"
+        enc.close()
+    ds.close()

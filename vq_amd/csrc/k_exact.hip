@@ -421,6 +421,10 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
         VQ_EXACT_CASE(16)
         VQ_EXACT_CASE(24)
         VQ_EXACT_CASE(32)
+        VQ_EXACT_CASE(48)
+        VQ_EXACT_CASE(64)
+        VQ_EXACT_CASE(96)
+        VQ_EXACT_CASE(128)
     default:
         hipLaunchKernelGGL((k_assign_exact<METRIC, 1, true>), grid, dim3(kExactBlock), 0, stream,
                            a.X, a.n, a.d, cb.m, cb.k, cb.sd, cb.cb, cb.cnsqrt, a.sub_list, wlr, wlc,
