@@ -7,6 +7,7 @@ headline contract).  One JSON line per configuration on one MI355X:
   C3  PQ m=96 k=256 cosine,    1M x 768     fit + cosine encode (bf16 MFMA cosine screen + exact re-check)
   C4  TSVQ depth 8 L2,         1M x 128     build + encode
   C5  PQ m=16 k=256 L2,        per-GPU shard of 100M x 128 (12.5M rows) fit iteration + encode
+  C2_manhattan  C2 with Distance::Manhattan for the encode (no contraction form: exact VALU engine)
   E   PQ m=16 k=256 Euclidean, 1M x 384     (the reference's `make eval` shape, src/bin/common.rs:10-15: sub_dim 24)
 
     python bench_configs.py [C1 C2 ...]
@@ -35,7 +36,8 @@ def pq_config(name, n, d, m, k, metric_name, iters=10, encode_reps=5):
 
     from vq_amd import _lib
 
-    metric = {"l2": _lib.SQUARED_EUCLIDEAN, "euclidean": _lib.EUCLIDEAN, "cosine": _lib.COSINE}[metric_name]
+    metric = {"l2": _lib.SQUARED_EUCLIDEAN, "euclidean": _lib.EUCLIDEAN, "cosine": _lib.COSINE,
+              "manhattan": _lib.MANHATTAN}[metric_name]
     ds = _lib.Dataset.synthetic(n, d, 66, 0)
     km = _lib.KMeans(ds, m, k)
     init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64)
@@ -133,6 +135,7 @@ CONFIGS = {
     "C3": lambda: pq_config("C3", 1_000_000, 768, 96, 256, "cosine", iters=5, encode_reps=2),
     "C4": lambda: tsvq_config("C4", 1_000_000, 128, 8),
     "C5": lambda: pq_config("C5_per_gpu_shard", 12_500_000, 128, 16, 256, "l2", iters=3, encode_reps=2),
+    "C2_manhattan": lambda: pq_config("C2_manhattan", 1_000_000, 128, 8, 256, "manhattan", iters=3, encode_reps=3),
     "E": lambda: pq_config("E_eval_shape", 1_000_000, 384, 16, 256, "euclidean", iters=5, encode_reps=3),
 }
 
