@@ -1,0 +1,123 @@
+"""Randomised parity sweep (GPU vs oracle): shapes, metrics, engines and data kinds drawn from a
+fixed seed -- the cases nobody thought of.  Every draw must be bit-exact (codes, f16, leaves, tree)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from vq_amd import TSVQ, Distance, _lib
+from vq_amd.tsvq import build_tree
+
+import os
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+SCALE = int(os.environ.get("VQ_FUZZ_SCALE", "1"))  # VQ_FUZZ_SCALE=20 for a long hunt
+KINDS = ["uniform", "normal", "lattice", "clustered", "offset", "mixed_scale", "sparse", "dupes"]
+
+
+def _draw_data(rng, n, d, kind):
+    if kind == "uniform":
+        return rng.random((n, d), dtype=F)
+    if kind == "normal":
+        return rng.standard_normal((n, d)).astype(F)
+    if kind == "lattice":
+        return rng.integers(-2, 3, (n, d)).astype(F)
+    if kind == "clustered":
+        c = rng.standard_normal((17, d)).astype(F) * 3
+        return (c[rng.integers(0, 17, n)] + 0.01 * rng.standard_normal((n, d))).astype(F)
+    if kind == "offset":
+        return (rng.random((n, d), dtype=F) * F(0.5) + F(rng.choice([-200.0, 33.0, 4096.0]))).astype(F)
+    if kind == "mixed_scale":  # columns spanning 12 orders of magnitude
+        return (rng.standard_normal((n, d)) * np.exp(rng.uniform(-14, 14, d))).astype(F)
+    if kind == "sparse":
+        x = rng.standard_normal((n, d)).astype(F)
+        x[rng.random((n, d)) < 0.8] = 0
+        return x
+    if kind == "dupes":  # many identical rows
+        base = rng.standard_normal((max(3, n // 50), d)).astype(F)
+        return base[rng.integers(0, len(base), n)]
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("seed", range(40 * SCALE))
+def test_fuzz_pq_encode(oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    sd = int(rng.choice([1, 2, 3, 4, 5, 8, 8, 12, 16, 16, 24, 32, 40]))
+    m = int(rng.choice([1, 2, 3, 4, 8, 16]))
+    d = sd * m
+    k = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 64, 100, 128, 200, 255, 256]))
+    n = int(rng.integers(1, 3000))
+    kind = KINDS[int(rng.integers(0, len(KINDS)))]
+    metric = int(rng.integers(0, 4))
+    X = _draw_data(rng, n, d, kind)
+    if rng.random() < 0.5 and n >= k:  # centroids drawn from the data (exact zeros, ties)
+        cb = np.stack([X[rng.choice(n, k, replace=False), s * sd:(s + 1) * sd] for s in range(m)])
+    else:
+        cb = _draw_data(rng, m * k, sd, kind).reshape(m, k, sd)
+    if rng.random() < 0.3 and k > 3:
+        cb[:, k - 1] = cb[:, 0]  # duplicate centroid: the lower index must win
+    cb = np.ascontiguousarray(cb, F)
+    enc = _lib.PQEncoder(cb, metric)
+    engines = [_lib.ENGINE_AUTO, _lib.ENGINE_EXACT]
+    want_c, want_f = oracle.pq_encode(metric, X, cb, threads=0)
+    for engine in engines:
+        enc.set_engine(engine)
+        codes, f16 = enc.encode(X)
+        np.testing.assert_array_equal(codes.astype(np.uint32), want_c, err_msg=f"sd={sd} m={m} k={k} n={n} {kind} metric={metric} engine={engine}")
+        same = (f16.view(np.uint16) == want_f) | (np.isnan(f16) & np.isnan(want_f.view(np.float16)))
+        assert same.all()
+    enc.close()
+
+
+@pytest.mark.parametrize("seed", range(16 * SCALE))
+def test_fuzz_lloyd_step(oracle, seed):
+    rng = np.random.default_rng(2000 + seed)
+    sd = int(rng.choice([2, 4, 8, 12, 16, 24, 32]))
+    m = int(rng.choice([1, 2, 4, 8]))
+    d = sd * m
+    k = int(rng.choice([2, 16, 50, 128, 256]))
+    n = int(rng.integers(k, 6000))
+    kind = KINDS[int(rng.integers(0, len(KINDS)))]
+    X = _draw_data(rng, n, d, kind)
+    init = np.stack([rng.choice(n, k, replace=False) for _ in range(m)]).astype(np.uint64)
+    ds = _lib.Dataset.from_host(X)
+    km = _lib.KMeans(ds, m, k)
+    km.set_exact_update(True)  # reference-order sums: centroids bit-identical too
+    km.init_from_rows(init)
+    counts, changed = km.step()
+    cent = km.get_centroids()
+    assign = km.get_assignments()
+    for s in range(m):
+        c0 = X[init[s].astype(np.int64), s * sd:(s + 1) * sd]
+        c1, a_ref, n_ref, ch_ref = oracle.lloyd_step(X[:, s * sd:(s + 1) * sd], c0, threads=0)
+        np.testing.assert_array_equal(assign[:, s].astype(np.uint32), a_ref, err_msg=f"sd={sd} m={m} k={k} n={n} {kind}")
+        np.testing.assert_array_equal(counts[s], n_ref)
+        ne = n_ref > 0
+        assert cent[s][ne].tobytes() == c1[ne].tobytes()
+        assert bool(changed[s]) == ch_ref
+    km.close()
+    ds.close()
+
+
+@pytest.mark.parametrize("seed", range(16 * SCALE))
+def test_fuzz_tsvq(oracle, seed):
+    rng = np.random.default_rng(3000 + seed)
+    d = int(rng.choice([1, 3, 8, 24, 32, 64, 128]))
+    n = int(rng.integers(1, 5000))
+    depth = int(rng.integers(0, 10))
+    kind = KINDS[int(rng.integers(0, len(KINDS)))]
+    metric = int(rng.integers(0, 4))
+    X = _draw_data(rng, n, d, kind)
+    Q = np.concatenate([_draw_data(rng, 700, d, kind), X[:200]])
+    ds = _lib.Dataset.from_host(X)
+    cent, left, right = build_tree(ds, depth)
+    ds.close()
+    want = oracle.tsvq_build(X, depth)
+    np.testing.assert_array_equal(left, want["left"], err_msg=f"d={d} n={n} depth={depth} {kind}")
+    np.testing.assert_array_equal(right, want["right"])
+    assert cent.tobytes() == want["centroids"].tobytes()
+    names = ["squared_euclidean", "euclidean", "manhattan", "cosine"]
+    t = TSVQ.from_tree(cent, left, right, Distance(names[metric]))
+    want_leaf, want_f16 = oracle.tsvq_encode(metric, Q, want, threads=0)
+    np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf, err_msg=f"d={d} n={n} depth={depth} {kind} metric={metric}")
+    np.testing.assert_array_equal(t.quantize_batch(Q).view(np.uint16), want_f16)
