@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -36,6 +38,22 @@ int current_stream(hipStream_t *out);
 int require_gfx950();
 
 int num_cus();
+
+// Per-device "has this call site configured its kernel yet" flag (hipFuncSetAttribute is per device;
+// a process may drive several GPUs through vqhip_set_device).  Idempotent under races.
+struct PerDeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    bool needed() const {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        return !(mask.load(std::memory_order_acquire) & (1ull << (dev & 63)));
+    }
+    void done() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        mask.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+};
 
 #define VQ_HIP(expr)                                                                     \
     do {                                                                                 \

@@ -1417,11 +1417,11 @@ int launch_one_lds2(const CodebookView &cb, const AssignArgs &a, hipStream_t str
     const size_t img_bytes = (size_t)NT * NM * 4 * 64 * 4;
     const uint32_t groups = (a.n_sub + 1) / 2;
     const size_t lds = 2 * img_bytes + 2 * (size_t)NT * 16 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.needed()) {
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign_screen_bf16_lds2<SD, NT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.done();
     }
     const uint64_t n_steps = (a.n + 31) / 32;
     uint32_t chunks = (uint32_t)num_cus() / groups;   // one 16-wave workgroup per CU
@@ -1441,11 +1441,11 @@ int launch_one_lds(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
     const size_t img_bytes = (size_t)NT * NM * 4 * 64 * 4;
     const uint32_t groups = (a.n_sub + 1) / 2;
     const size_t lds = 2 * img_bytes;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.needed()) {
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign_screen_bf16_lds<SD, NT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.done();
     }
     // workgroups per CU by LDS (at most 2: the launch bound is 2 waves/SIMD of 8-wave groups)
     uint32_t per_cu = (uint32_t)((150 * 1024) / (lds ? lds : 1));

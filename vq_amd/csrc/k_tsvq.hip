@@ -888,11 +888,11 @@ int launch_tsvq_node_norms(const float *centroids, uint32_t n_nodes, uint32_t d,
 template <int METRIC, int RB>
 static int launch_descend_lds(const float *X, uint64_t n, uint32_t d, const float *centroids, const float *cnorm,
                               const int32_t *left, const int32_t *right, int32_t *leaf, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.needed()) {
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_descend_lds<METRIC, RB>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.done();
     }
     hipLaunchKernelGGL((k_tsvq_descend_lds<METRIC, RB>), dim3((uint32_t)((n + RB - 1) / RB)), dim3(RB),
                        (size_t)d * RB * 4, stream, X, n, d, centroids, cnorm, left, right, leaf);

@@ -289,11 +289,11 @@ template <int D, int LPR>
 int launch_screen(const float *X, uint64_t n, const TsvqScreen &s, hipStream_t stream, int32_t *leaf) {
     constexpr int RPW = 64 / LPR;
     const size_t lds_bytes = tsvq_screen_lds_bytes(s.n_int, s.n_nodes, D);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.needed()) {
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.done();
     }
     const uint64_t n_tiles = (n + RPW - 1) / RPW;
     uint64_t grid = (n_tiles + kWaves - 1) / kWaves;

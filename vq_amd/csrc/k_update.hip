@@ -359,11 +359,11 @@ template <int KS>
 static int launch_owned(const UpdatePlan &p, const float *X, uint64_t n, uint32_t d,
                         const uint8_t *codes, const uint8_t *active, float *partial_sums,
                         uint32_t *partial_counts, uint32_t wpb, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.needed()) {
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_accumulate_owned<KS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.done();
     }
     const uint64_t rows_per_chunk = (n + p.n_row_chunks - 1) / p.n_row_chunks;
     const size_t lds_bytes = (size_t)wpb * ((p.k * (p.sd + 1) + 3u) & ~3u) * 4;
@@ -403,21 +403,21 @@ int launch_accumulate(const UpdatePlan &p, const float *X, uint64_t n, uint32_t 
     dim3 grid(p.n_row_chunks, p.n_sub_chunks);
     const bool vec4 = (p.sd % 4 == 0) && aligned;
     if (vec4) {
-        static bool attr_set4 = false;
-        if (!attr_set4) {
+        static PerDeviceOnce attr_set4;
+        if (attr_set4.needed()) {
             VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_accumulate<4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set4 = true;
+            attr_set4.done();
         }
         hipLaunchKernelGGL(k_accumulate<4>, grid, dim3(kAccBlock), lds_bytes, stream, X, n, d, p.m,
                            p.k, p.sd, p.subs_per_chunk, rows_per_chunk, codes, active, partial_sums,
                            partial_counts);
     } else {
-        static bool attr_set1 = false;
-        if (!attr_set1) {
+        static PerDeviceOnce attr_set1;
+        if (attr_set1.needed()) {
             VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_accumulate<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set1 = true;
+            attr_set1.done();
         }
         hipLaunchKernelGGL(k_accumulate<1>, grid, dim3(kAccBlock), lds_bytes, stream, X, n, d, p.m,
                            p.k, p.sd, p.subs_per_chunk, rows_per_chunk, codes, active, partial_sums,
