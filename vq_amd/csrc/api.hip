@@ -337,7 +337,17 @@ struct vqhip_kmeans {
     bool accumulated = false;
     uint32_t *counts_host = nullptr;   // pinned [m*k]
     uint32_t *changed_host = nullptr;  // pinned [m]
+    // launch-bound regime (small n): one Lloyd step = ~14 stream operations, replayed as a hipGraph
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t graph_stream = nullptr;
+    uint64_t graph_key = 0, warm_key = 0;
+    bool graph_failed = false;
+    void drop_graph() {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        graph_exec = nullptr;
+    }
     ~vqhip_kmeans() {
+        drop_graph();
         if (counts_host) (void)hipHostFree(counts_host);
         if (changed_host) (void)hipHostFree(changed_host);
     }
@@ -769,12 +779,8 @@ int vqhip_kmeans_set_exact_update(vqhip_kmeans *km, int exact_update) {
     return VQHIP_OK;
 }
 
-int vqhip_kmeans_accumulate(vqhip_kmeans *km) {
-    VQ_API_BEGIN
-    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
-    VQ_TRY(require_gfx950());
-    hipStream_t s;
-    VQ_TRY(current_stream(&s));
+// queue assign + update of one Lloyd iteration on `s` (no host synchronisation: capturable)
+static int kmeans_accumulate_enqueue(vqhip_kmeans *km, hipStream_t s) {
     std::vector<uint32_t> subs;
     for (uint32_t i = 0; i < km->cs.m; ++i)
         if (km->active[i]) subs.push_back(i);
@@ -797,6 +803,15 @@ int vqhip_kmeans_accumulate(vqhip_kmeans *km) {
     }
     km->accumulated = true;
     return VQHIP_OK;
+}
+
+int vqhip_kmeans_accumulate(vqhip_kmeans *km) {
+    VQ_API_BEGIN
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    return kmeans_accumulate_enqueue(km, s);
     VQ_API_END
 }
 
@@ -807,12 +822,8 @@ int vqhip_kmeans_partials(vqhip_kmeans *km, void **dev_slab, uint64_t *n_doubles
     return VQHIP_OK;
 }
 
-int vqhip_kmeans_finalize(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
-    VQ_API_BEGIN
-    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
-    if (!km->accumulated) return fail(VQHIP_ERR_INVALID_INPUT, "finalize without a preceding accumulate");
-    hipStream_t s;
-    VQ_TRY(current_stream(&s));
+// queue mean / convergence test + the read-back of counts and flags (capturable)
+static int kmeans_finalize_enqueue(vqhip_kmeans *km, hipStream_t s) {
     const uint8_t *act = km->all_active ? nullptr : km->active_dev.as<uint8_t>();
     const uint32_t m = km->cs.m, k = km->cs.k;
     VQ_TRY(launch_finalize(m, k, km->cs.sd, km->slab.as<double>(), act, km->cs.cb.as<float>(),
@@ -821,17 +832,100 @@ int vqhip_kmeans_finalize(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) 
     km->accumulated = false;
     VQ_HIP(hipMemcpyAsync(km->counts_host, km->counts.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipMemcpyAsync(km->changed_host, km->changed.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-    VQ_HIP(hipStreamSynchronize(s));
+    return VQHIP_OK;
+}
+static void kmeans_finalize_collect(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
+    const uint32_t m = km->cs.m, k = km->cs.k;
     if (counts) memcpy(counts, km->counts_host, (size_t)m * k * 4);
     if (changed)
         for (uint32_t i = 0; i < m; ++i) changed[i] = (km->active[i] && km->changed_host[i]) ? 1 : 0;
+}
+
+int vqhip_kmeans_finalize(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
+    VQ_API_BEGIN
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (!km->accumulated) return fail(VQHIP_ERR_INVALID_INPUT, "finalize without a preceding accumulate");
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_TRY(kmeans_finalize_enqueue(km, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    kmeans_finalize_collect(km, counts, changed);
     return VQHIP_OK;
     VQ_API_END
 }
 
+// Small data sets are launch-bound (C1, 10k x 64: ~60 us of kernels behind ~14 stream operations),
+// so the whole step is captured once per (active set, engine) and replayed as a hipGraph; the first
+// step with a given key runs eagerly (allocations, code objects, sub-list upload), the second is
+// captured, later ones are replays.  VQHIP_GRAPH=0 disables, =1 forces it for any size.
+static bool kmeans_graph_eligible(const vqhip_kmeans *km) {
+    static const char *env = getenv("VQHIP_GRAPH");
+    if (env && env[0] == '0') return false;
+    if (km->graph_failed || km->exact_update || g_prof.on) return false;
+    if (env && env[0] == '1') return true;
+    return (uint64_t)km->ds->n * km->cs.m <= (4ull << 20);
+}
+
 int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
-    VQ_TRY(vqhip_kmeans_accumulate(km));
-    return vqhip_kmeans_finalize(km, counts, changed);
+    VQ_API_BEGIN
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    if (!kmeans_graph_eligible(km)) {
+        VQ_TRY(kmeans_accumulate_enqueue(km, s));
+        VQ_TRY(kmeans_finalize_enqueue(km, s));
+        VQ_HIP(hipStreamSynchronize(s));
+        kmeans_finalize_collect(km, counts, changed);
+        return VQHIP_OK;
+    }
+    uint64_t key = 1469598103934665603ull;  // FNV-1a over what shapes the launch sequence
+    auto mix = [&](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+    for (uint32_t i = 0; i < km->cs.m; ++i) mix(km->active[i]);
+    mix((uint64_t)km->engine + 17);
+    mix(reinterpret_cast<uintptr_t>(s));
+    if (km->graph_exec && km->graph_key == key) {
+        VQ_HIP(hipGraphLaunch(km->graph_exec, s));
+        VQ_HIP(hipStreamSynchronize(s));
+    } else if (km->warm_key == key) {
+        km->drop_graph();
+        km->cs.prepared = false;  // the codebook images must be part of the captured sequence
+        hipGraph_t graph = nullptr;
+        VQ_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc = kmeans_accumulate_enqueue(km, s);
+        if (rc == VQHIP_OK) rc = kmeans_finalize_enqueue(km, s);
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        if (rc == VQHIP_OK && e == hipSuccess && graph &&
+            hipGraphInstantiate(&km->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            (void)hipGraphDestroy(graph);
+            km->graph_key = key;
+            VQ_HIP(hipGraphLaunch(km->graph_exec, s));
+            VQ_HIP(hipStreamSynchronize(s));
+        } else {  // capture is an optimisation only: fall back to the plain sequence for this handle
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            km->graph_exec = nullptr;
+            km->graph_failed = true;
+            km->cs.prepared = false;
+            VQ_TRY(kmeans_accumulate_enqueue(km, s));
+            VQ_TRY(kmeans_finalize_enqueue(km, s));
+            VQ_HIP(hipStreamSynchronize(s));
+        }
+    } else {
+        VQ_TRY(kmeans_accumulate_enqueue(km, s));
+        VQ_TRY(kmeans_finalize_enqueue(km, s));
+        VQ_HIP(hipStreamSynchronize(s));
+        km->warm_key = key;
+    }
+    // host-side state the enqueue functions leave behind (a replay does not run them)
+    km->cs.prepared = false;
+    km->accumulated = false;
+    km->ws.stats_pending = (km->ws.last_engine == VQHIP_ENGINE_MFMA || km->ws.last_engine == VQHIP_ENGINE_MFMA_BF16);
+    g_last_ws = &km->ws;
+    tls().last_engine = km->ws.last_engine;
+    kmeans_finalize_collect(km, counts, changed);
+    return VQHIP_OK;
+    VQ_API_END
 }
 
 int vqhip_kmeans_patch_centroid(vqhip_kmeans *km, uint32_t s, uint32_t j, const float *sub_row) {
