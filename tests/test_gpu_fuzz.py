@@ -121,3 +121,89 @@ def test_fuzz_tsvq(oracle, seed):
     want_leaf, want_f16 = oracle.tsvq_encode(metric, Q, want, threads=0)
     np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf, err_msg=f"d={d} n={n} depth={depth} {kind} metric={metric}")
     np.testing.assert_array_equal(t.quantize_batch(Q).view(np.uint16), want_f16)
+
+
+@pytest.mark.parametrize("rep", range(SCALE))
+@pytest.mark.parametrize("kind", KINDS + ["nan_rows", "huge_then_small", "half_ulps"])
+@pytest.mark.parametrize("shape", [(40_000, 32, 4), (70_001, 64, 3), (120_000, 128, 2)])
+def test_tsvq_build_long_nodes_bit_identical(oracle, kind, shape, rep):
+    """Nodes of >= 16384 rows take the tile-parallel exact emulation of the sequential column sums
+    (k_fs_*): the tree must still be the oracle's bit for bit on data that stresses the binade /
+    parity logic -- mixed signs, cancellation, exact half-ulp addends, NaN, scale jumps."""
+    n, d, depth = shape
+    import zlib
+
+    rng = np.random.default_rng(zlib.crc32(f"{kind}-{n}-{rep}".encode()))
+    if kind == "nan_rows":
+        X = rng.standard_normal((n, d)).astype(F)
+        X[rng.integers(0, n, 7), rng.integers(0, d, 7)] = np.nan
+    elif kind == "huge_then_small":
+        X = rng.random((n, d), dtype=F)
+        X[: n // 3] *= F(1e12)
+        X[n // 3: 2 * n // 3] *= F(1e-9)
+    elif kind == "half_ulps":  # sums of dyadic values: exact ties in every addition once s is large
+        X = (rng.integers(0, 8, (n, d)) * 0.5).astype(F) + F(0.25) * (rng.integers(0, 2, (n, d))).astype(F)
+    else:
+        X = _draw_data(rng, n, d, kind)
+    ds = _lib.Dataset.from_host(X)
+    try:
+        cent, left, right = build_tree(ds, depth)
+    except _lib.FfiError as e:  # the reference panics when a split column is all NaN
+        assert "panics" in str(e)
+        return
+    finally:
+        ds.close()
+    want = oracle.tsvq_build(X, depth)
+    np.testing.assert_array_equal(left, want["left"], err_msg=f"{kind} {shape} rep={rep}")
+    np.testing.assert_array_equal(right, want["right"])
+    a, b = cent, want["centroids"]
+    same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), f"{(~same).sum()} centroid components differ ({kind} {shape})"
+
+
+_SEQ_WORKER = r'''
+import os, sys, zlib
+import numpy as np
+sys.path.insert(0, os.environ["VQ_REPO"]); sys.path.insert(0, os.path.join(os.environ["VQ_REPO"], "tests"))
+from vq_amd import _lib
+from vq_amd.tsvq import build_tree
+from test_gpu_fuzz import _draw_data, KINDS
+_lib.load(); _lib.set_device(0)
+out = {}
+for kind in KINDS:
+    for n, d, depth in ((300_000, 64, 3), (1_000_000, 32, 2)):
+        rng = np.random.default_rng(zlib.crc32(f"seq-{kind}-{n}".encode()))
+        X = _draw_data(rng, n, d, kind)
+        ds = _lib.Dataset.from_host(X)
+        cent, left, right = build_tree(ds, depth)
+        ds.close()
+        out[f"{kind}-{n}-c"] = cent; out[f"{kind}-{n}-l"] = left; out[f"{kind}-{n}-r"] = right
+np.savez(sys.argv[1], **out)
+print("WORKER_OK")
+'''
+
+
+def test_tsvq_build_fast_sums_equal_sequential_kernel(tmp_path):
+    """At sizes the CPU oracle is too slow for: the tile-parallel exact column sums (default) against
+    the plain sequential kernel (VQHIP_TSVQ_SEQSUM=1), same library, 8 data kinds, up to 1M rows."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(_SEQ_WORKER)
+    res = {}
+    for tag, env_extra in (("fast", {}), ("seq", {"VQHIP_TSVQ_SEQSUM": "1"})):
+        out = tmp_path / f"{tag}.npz"
+        env = dict(os.environ, VQ_REPO=root, **env_extra)
+        r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0 and "WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+        res[tag] = np.load(out)
+    for key in res["fast"].files:
+        a, b = res["fast"][key], res["seq"][key]
+        assert a.shape == b.shape, key
+        if a.dtype == np.float32:
+            same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), f"{key}: {(~same).sum()} components differ"
+        else:
+            np.testing.assert_array_equal(a, b, err_msg=key)

@@ -613,6 +613,360 @@ __global__ __launch_bounds__(256) void k_tsvq_gather_f16(const float *__restrict
     }
 }
 
+// ---- tile-parallel EXACT emulation of the reference's sequential f32 column sums -------------
+// acc = acc + v over the rows of a node, in row order, is one chain of len dependent rounded
+// additions (mean: src/core/vector.rs:332-348, variance: src/tsvq.rs:47-55); at the top levels
+// of a 1M-row build that chain (10 cycles per row) is the whole cost.  While the running sum s
+// stays inside one binade [2^e, 2^(e+1)), ulp(s) = 2^(e-23) is constant and, with S = s/ulp an
+// integer and x/ulp = a + f (a = floor, 0 <= f < 1),
+//     fl(s + x) / ulp = S + a + (f > 1/2 ? 1 : f == 1/2 ? (S + a) odd : 0)       (round to nearest even)
+// -- a transducer whose only state is the parity of S.  Such maps compose associatively
+// ((delta for even S, delta for odd S), plus the min/max prefix needed to know whether the sum
+// really stayed in the binade), so the chain is cut into tiles of 512 rows that are summarised
+// IN PARALLEL under a guessed binade (from an f64 prefix of plain tile sums), and a short
+// sequential pass per column then walks the tile summaries with the exact S, checks the guess
+// (exponent of s, S + min >= 2^23, S + max < 2^24) and re-adds a tile row by row whenever the
+// check fails (binade crossings, the first tiles, cancellation, NaN/inf).  Every result is the
+// reference's bit pattern; only the schedule differs.
+constexpr uint32_t kFsTile = 512;        // rows per tile
+constexpr uint32_t kFsCols = 32;         // columns per workgroup (one 128-byte line per row)
+constexpr uint32_t kFsMinRows = 16384;   // shorter nodes keep the plain sequential kernel
+
+struct FsTile {
+    uint32_t node, t;  // node id, tile index inside the node
+};
+struct FsSumm {
+    int32_t d0, d1, lo0, hi0, lo1, hi1, e, flag;  // flag != 0: no usable summary
+};
+
+template <int MODE>
+__device__ __forceinline__ float fs_value(float x, float mu) {
+    if (MODE == 0) return x;
+    const float diff = x - mu;
+    return diff * diff;
+}
+
+// plain f64 sums per (tile, column): only used to guess the binade of the running sum at a tile
+template <int MODE>
+__global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ X, uint32_t d,
+                                                      const uint32_t *__restrict__ perm,
+                                                      const FsTile *__restrict__ tiles, NodeArrays na,
+                                                      double *__restrict__ tile_sum) {
+    __shared__ double part[32][kFsCols + 1];
+    const FsTile tl = tiles[blockIdx.x];
+    const uint32_t a = na.seg_start[tl.node], len = na.seg_len[tl.node];
+    const uint32_t c0 = blockIdx.y * kFsCols, q = threadIdx.x & 7, rr = threadIdx.x >> 3;
+    float mu[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mu[i] = na.centroid[(size_t)tl.node * d + c0 + 4 * q + i];
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (uint32_t i = 0; i < kFsTile / 32; ++i) {
+        const uint32_t r = tl.t * kFsTile + rr + 32 * i;
+        if (r < len) {
+            const float4 v = *reinterpret_cast<const float4 *>(X + (size_t)perm[a + r] * d + c0 + 4 * q);
+            acc[0] += (double)fs_value<MODE>(v.x, mu[0]);
+            acc[1] += (double)fs_value<MODE>(v.y, mu[1]);
+            acc[2] += (double)fs_value<MODE>(v.z, mu[2]);
+            acc[3] += (double)fs_value<MODE>(v.w, mu[3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[rr][4 * q + i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < kFsCols) {
+        double s = 0.0;
+        for (int r = 0; r < 32; ++r) s += part[r][threadIdx.x];
+        tile_sum[(size_t)blockIdx.x * d + c0 + threadIdx.x] = s;
+    }
+}
+
+// exclusive prefix over the tiles of a node, per column, in place: 32 chunk lanes x 32 columns per
+// workgroup (chunk sums -> LDS -> offsets -> rewrite); only a guess is needed, so f64 order is free
+__global__ __launch_bounds__(1024) void k_fs_prefix(uint32_t d, const uint32_t *__restrict__ tile_base,
+                                                    const uint32_t *__restrict__ n_tiles_of, double *__restrict__ tile_sum) {
+    __shared__ double part[32][kFsCols + 1];
+    const uint32_t c = blockIdx.y * kFsCols + (threadIdx.x & 31), lt = threadIdx.x >> 5;
+    const uint32_t base = tile_base[blockIdx.x], nt = n_tiles_of[blockIdx.x];
+    const uint32_t chunk = (nt + 31) / 32, t0 = lt * chunk, t1 = min(nt, t0 + chunk);
+    double local = 0.0;
+    for (uint32_t t = t0; t < t1; ++t) local += tile_sum[(size_t)(base + t) * d + c];
+    part[lt][threadIdx.x & 31] = local;
+    __syncthreads();
+    double run = 0.0;
+    for (uint32_t q = 0; q < lt; ++q) run += part[q][threadIdx.x & 31];
+    for (uint32_t t = t0; t < t1; ++t) {
+        double *p = tile_sum + (size_t)(base + t) * d + c;
+        const double v = *p;
+        *p = run;
+        run += v;
+    }
+}
+
+struct FsAcc {  // transducer summary of a run of rows: for even / odd incoming S
+    long long d[2], lo[2], hi[2];
+};
+
+// summaries of all tiles in parallel, under the binade guessed from the f64 prefix.  Phase 1: the
+// workgroup fetches its 512 x 32 tile with 16 independent 16-byte loads per thread (whole 128-byte
+// lines) and parks the addends column-major in LDS; phase 2: thread (column, segment) folds its 64
+// addends from LDS into the parity transducer.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ X, uint32_t d,
+                                                      const uint32_t *__restrict__ perm,
+                                                      const FsTile *__restrict__ tiles, NodeArrays na,
+                                                      const double *__restrict__ tile_pref,
+                                                      FsSumm *__restrict__ summ, float *__restrict__ side,
+                                                      uint32_t side_cap, uint32_t *__restrict__ side_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fs_lds[];
+    float(*lds_v)[kFsTile + 1] = reinterpret_cast<float(*)[kFsTile + 1]>(fs_lds);             // [32][513]
+    FsAcc(*seg_acc)[kFsCols] = reinterpret_cast<FsAcc(*)[kFsCols]>(fs_lds + kFsCols * (kFsTile + 1) * 4);  // [8][32]
+    __shared__ int seg_bad[8][kFsCols];
+    __shared__ int col_slot[kFsCols];
+    const FsTile tl = tiles[blockIdx.x];
+    const uint32_t a = na.seg_start[tl.node], len = na.seg_len[tl.node];
+    const uint32_t row0 = tl.t * kFsTile, rows = min(kFsTile, len - row0);
+    const uint32_t c0 = blockIdx.y * kFsCols;
+    {   // phase 1
+        const uint32_t q = threadIdx.x & 7, rr = threadIdx.x >> 3;
+        float mu4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mu4[i] = na.centroid[(size_t)tl.node * d + c0 + 4 * q + i];
+        }
+        uint32_t prow[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t r = rr + 32 * i;
+            prow[i] = (r < rows) ? perm[a + row0 + r] : 0u;
+        }
+        float4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (size_t)prow[i] * d + c0 + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t r = rr + 32 * i;
+            lds_v[4 * q + 0][r] = fs_value<MODE>(v[i].x, mu4[0]);
+            lds_v[4 * q + 1][r] = fs_value<MODE>(v[i].y, mu4[1]);
+            lds_v[4 * q + 2][r] = fs_value<MODE>(v[i].z, mu4[2]);
+            lds_v[4 * q + 3][r] = fs_value<MODE>(v[i].w, mu4[3]);
+        }
+    }
+    __syncthreads();
+    const uint32_t cl = threadIdx.x & 31, c = c0 + cl, seg = threadIdx.x >> 5;
+    const float s_guess = (float)tile_pref[(size_t)blockIdx.x * d + c];
+    const uint32_t gb = __float_as_uint(s_guess), ge = (gb >> 23) & 0xFFu;
+    const int e = (int)ge - 127;
+    // scale = 2^(23-e): needs a normal guess and a representable power of two
+    bool bad = (ge == 0u) || (ge == 255u) || (23 - e > 126) || (23 - e < -126);
+    const float scale = bad ? 1.0f : __uint_as_float((uint32_t)(23 - e + 127) << 23);
+    // per 64-row segment everything fits 32 bits: |q| < 2^24 is enforced (an addend of 2 s or more
+    // cannot leave s in its binade), so |prefix| < 2^30
+    int32_t dd[2] = {0, 0}, lo[2] = {0, 0}, hi[2] = {0, 0};
+    const uint32_t i0 = seg * 64, i1 = min(rows, i0 + 64);
+    for (uint32_t i = i0; i < i1; ++i) {
+        const float q = lds_v[cl][i] * scale;
+        const bool in_range = fabsf(q) < 16777216.0f;  // else |q| >= 2^24, inf or NaN: cannot stay in the binade
+        bad = bad || !in_range;
+        const float qq = in_range ? q : 0.0f;
+        const float fl = floorf(qq), fr = qq - fl;
+        const int32_t ai = (int32_t)fl;
+        const int32_t up = fr > 0.5f ? 1 : 0, tie = fr == 0.5f ? 1 : 0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int32_t base = dd[p] + ai;
+            const int32_t inc = base + (up | (tie & (p + base)));  // tie: round to the even S
+            dd[p] = inc;
+            lo[p] = min(lo[p], inc);
+            hi[p] = max(hi[p], inc);
+        }
+    }
+    FsAcc acc;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        acc.d[p] = dd[p];
+        acc.lo[p] = lo[p];
+        acc.hi[p] = hi[p];
+    }
+    seg_acc[seg][cl] = acc;
+    seg_bad[seg][cl] = bad ? 1 : 0;
+    __syncthreads();
+    if (seg == 0) {
+        FsAcc f = seg_acc[0][threadIdx.x];
+        int anybad = seg_bad[0][threadIdx.x];
+        for (int g = 1; g < 8; ++g) {  // f then g, in row order
+            const FsAcc gg = seg_acc[g][threadIdx.x];
+            anybad |= seg_bad[g][threadIdx.x];
+            FsAcc h;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int p2 = (int)((p + f.d[p]) & 1);
+                h.d[p] = f.d[p] + gg.d[p2];
+                const long long l2 = f.d[p] + gg.lo[p2], h2 = f.d[p] + gg.hi[p2];
+                h.lo[p] = f.lo[p] < l2 ? f.lo[p] : l2;
+                h.hi[p] = f.hi[p] > h2 ? f.hi[p] : h2;
+            }
+            f = h;
+        }
+        const long long lim = 1ll << 28;
+        if (f.hi[0] > lim || f.hi[1] > lim || f.lo[0] < -lim || f.lo[1] < -lim) anybad = 1;
+        // Will the chain have to re-add this tile?  Predict it from the guessed S (margin 2^14 of the
+        // 2^23-wide binade) and, if so, park the tile's addends column-contiguous in the side buffer:
+        // the re-addition then reads 2 KB instead of gathering 4 bytes from each of 512 rows.
+        int slot = -1;
+        {
+            const int32_t mag = (int32_t)((gb & 0x7FFFFFu) | 0x800000u);
+            const long long Sg = (gb >> 31) ? -(long long)mag : (long long)mag;
+            const long long lo2 = f.lo[0] < f.lo[1] ? f.lo[0] : f.lo[1], hi2 = f.hi[0] > f.hi[1] ? f.hi[0] : f.hi[1];
+            const long long margin = 1ll << 14;  // 0.2 % of the binade; the f64 guess is good to ~1e-5
+            const bool leaves = (Sg > 0) ? (Sg + lo2 < (1ll << 23) + margin || Sg + hi2 > (1ll << 24) - margin)
+                                         : (Sg + hi2 > -(1ll << 23) - margin || Sg + lo2 < -(1ll << 24) + margin);
+            if ((anybad || leaves) && side_cap) {
+                const uint32_t got = atomicAdd(side_count, 1u);
+                if (got < side_cap) slot = (int)got;
+            }
+        }
+        col_slot[threadIdx.x] = slot;
+        FsSumm o;
+        o.d0 = (int32_t)f.d[0];
+        o.d1 = (int32_t)f.d[1];
+        o.lo0 = (int32_t)f.lo[0];
+        o.hi0 = (int32_t)f.hi[0];
+        o.lo1 = (int32_t)f.lo[1];
+        o.hi1 = (int32_t)f.hi[1];
+        o.e = e;
+        o.flag = (anybad ? 1 : 0) | ((slot + 1) << 1);  // bit 0: unusable; bits 1..: side slot + 1
+        summ[(size_t)blockIdx.x * d + c] = o;
+    }
+    __syncthreads();
+    for (uint32_t cc = 0; cc < kFsCols; ++cc) {  // rare: park the flagged columns (already in LDS)
+        const int slot = col_slot[cc];
+        if (slot < 0) continue;
+        float *dst = side + (size_t)slot * kFsTile;
+        for (uint32_t i = threadIdx.x; i < rows; i += 256) dst[i] = lds_v[cc][i];
+    }
+}
+
+// the exact chain: one wave per (node, column).  The tile summaries are themselves parity
+// transducers, so 64 tiles at a time are composed with a wave scan: lane l learns the exact S
+// entering tile t0+l (as if every earlier tile of the batch held), checks its own tile (same
+// binade as the guess, prefixes inside it), and the first lane that fails marks where the batch
+// stops: the tiles before it are applied in one step, that tile is re-added row by row in the
+// reference's order (the additions run through v_readlane), and the scan resumes behind it.
+struct FsPair {
+    int32_t d[2], lo[2], hi[2];
+};
+__device__ __forceinline__ FsPair fs_compose(const FsPair &f, const FsPair &g) {  // f first, then g
+    FsPair h;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int p2 = (p + f.d[p]) & 1;
+        // saturating enough: summaries are clamped to |.| <= 2^28 and a batch is stopped at the first
+        // tile that leaves the binade, so valid prefixes stay below 2^25
+        h.d[p] = f.d[p] + g.d[p2];
+        h.lo[p] = min(f.lo[p], f.d[p] + g.lo[p2]);
+        h.hi[p] = max(f.hi[p], f.d[p] + g.hi[p2]);
+    }
+    return h;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, uint32_t d,
+                                                 const uint32_t *__restrict__ perm,
+                                                 const uint32_t *__restrict__ fast_nodes,
+                                                 const uint32_t *__restrict__ tile_base, NodeArrays na,
+                                                 const FsSumm *__restrict__ summ, const float *__restrict__ side,
+                                                 uint32_t *__restrict__ n_fallback) {
+    const uint32_t node = fast_nodes[blockIdx.x], c = blockIdx.y, lane = threadIdx.x;
+    const uint32_t a = na.seg_start[node], len = na.seg_len[node];
+    const uint32_t nt = (len + kFsTile - 1) / kFsTile, base = tile_base[blockIdx.x];
+    const float mu = (MODE == 1) ? na.centroid[(size_t)node * d + c] : 0.0f;
+    float s = (MODE == 0) ? 0.0f : -0.0f;
+    uint32_t fallbacks = 0;
+    uint32_t t0 = 0;  // first tile not yet applied
+    while (t0 < nt) {
+        const uint32_t cnt = min(64u, nt - t0);
+        FsSumm mine;
+        mine.flag = 1;
+        mine.e = 0;
+        mine.d0 = mine.d1 = mine.lo0 = mine.lo1 = mine.hi0 = mine.hi1 = 0;
+        if (lane < cnt) mine = summ[(size_t)(base + t0 + lane) * d + c];
+        const uint32_t sb = __float_as_uint(s), se = (sb >> 23) & 0xFFu;
+        const bool s_normal = (se != 0u) && (se != 255u);
+        const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
+        const int32_t S = (sb >> 31) ? -mag : mag;
+        // exclusive scan of the tile transducers over the lanes (Hillis-Steele on inclusive, then shift)
+        FsPair incl;
+        incl.d[0] = mine.d0, incl.d[1] = mine.d1;
+        incl.lo[0] = mine.lo0, incl.lo[1] = mine.lo1;
+        incl.hi[0] = mine.hi0, incl.hi[1] = mine.hi1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            FsPair prev;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                prev.d[p] = __shfl_up(incl.d[p], off);
+                prev.lo[p] = __shfl_up(incl.lo[p], off);
+                prev.hi[p] = __shfl_up(incl.hi[p], off);
+            }
+            if ((int)lane >= off) incl = fs_compose(prev, incl);
+        }
+        // delta from the batch start to the start of my tile, for the actual parity of S
+        const int odd = S & 1;
+        int32_t before = __shfl_up(incl.d[odd], 1);
+        if (lane == 0) before = 0;
+        const int32_t Sin = S + before;
+        const int podd = Sin & 1;
+        const int32_t lo = podd ? mine.lo1 : mine.lo0, hi = podd ? mine.hi1 : mine.hi0;
+        bool ok = s_normal && (lane < cnt) && ((mine.flag & 1) == 0) && ((int)se - 127 == mine.e);
+        ok = ok && ((S > 0) ? (Sin + lo >= (1 << 23) && Sin + hi <= (1 << 24) - 1)
+                            : (Sin + hi <= -(1 << 23) && Sin + lo >= -((1 << 24) - 1)));
+        const uint64_t bad_mask = __ballot(!ok) | (cnt < 64 ? (~0ull << cnt) : 0ull);
+        const uint32_t good = bad_mask ? (uint32_t)__builtin_ctzll(bad_mask) : 64u;  // tiles t0 .. t0+good-1 hold
+        if (good > 0) {
+            const int32_t total = __shfl(incl.d[odd], (int)good - 1);
+            const int32_t S2 = S + total;
+            const uint32_t m2 = (uint32_t)(S2 < 0 ? -S2 : S2);
+            s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2 & 0x7FFFFFu));
+            t0 += good;
+        }
+        if (good < cnt) {  // re-add tile t0 (the first that failed) in the reference's order
+            ++fallbacks;
+            const int32_t flag = __shfl(mine.flag, (int)good);
+            const uint32_t r0 = t0 * kFsTile;
+            float v[8];
+            const int slot = (flag >> 1) - 1;
+            if (slot >= 0) {  // parked by k_fs_transduce: contiguous
+                const float *src = side + (size_t)slot * kFsTile;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = src[i * 64 + lane];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t r = r0 + (uint32_t)i * 64 + lane;
+                    v[i] = (r < len) ? fs_value<MODE>(X[(size_t)perm[a + r] * d + c], mu) : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t first = r0 + (uint32_t)i * 64;
+                if (first >= len) break;
+                const uint32_t m = min(64u, len - first);
+                for (uint32_t l = 0; l < m; ++l)
+                    s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i]), (int)l));
+            }
+            t0 += 1;
+        }
+    }
+    if (lane == 0) {
+        if (MODE == 0) na.centroid[(size_t)node * d + c] = s / (float)len;  // T::from_usize(n)
+        else na.var[(size_t)node * d + c] = s;
+        if (n_fallback && fallbacks) atomicAdd(n_fallback, fallbacks);
+    }
+}
+
 // f16 image of the node centroids (RNE, half::f16::from_f32 as src/tsvq.rs:249-253 applies per call)
 __global__ __launch_bounds__(256) void k_tsvq_table_f16(const float *__restrict__ centroids, uint64_t total,
                                                         uint16_t *__restrict__ table) {
@@ -714,6 +1068,88 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     std::vector<uint32_t> level = {0};  // global node ids of the current level
     const uint32_t dgroups = (d + DG - 1) / DG;
 
+    // sequential-order column sums of a set of nodes: long nodes through the tile-parallel exact
+    // emulation (k_fs_*), the rest through the plain chain kernel
+    DevBuf b_fs_tiles, b_fs_nodes, b_fs_base, b_fs_nt, b_fs_sum, b_fs_summ, b_lvl_slow, b_fs_fb, b_fs_side;
+    VQ_TRY(b_fs_fb.alloc(8));  // [0] tile re-additions (diagnostic), [1] side-buffer slots handed out
+    VQ_HIP(hipMemsetAsync(b_fs_fb.p, 0, 8, stream));
+    static const char *nopark = getenv("VQHIP_TSVQ_NOPARK");
+    const uint32_t side_cap = (nopark && nopark[0] == '1') ? 0u : 32768u;  // parked tiles per call (64 MB); beyond it the re-addition gathers
+    static const char *seq_env = getenv("VQHIP_TSVQ_SEQSUM");  // =1: plain chain everywhere (A/B)
+    const bool can_fast = (d % kFsCols == 0) && !(seq_env && seq_env[0] == '1');
+    const size_t fs_lds_bytes = (size_t)kFsCols * (kFsTile + 1) * 4 + 8 * kFsCols * sizeof(FsAcc);
+    {
+        static PerDeviceOnce fs_attr;
+        if (fs_attr.needed()) {
+            VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fs_transduce<0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fs_lds_bytes));
+            VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fs_transduce<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fs_lds_bytes));
+            fs_attr.done();
+        }
+    }
+    auto colsum = [&](int mode, const std::vector<uint32_t> &ids, const uint32_t *perm) -> int {
+        std::vector<uint32_t> slow, fast;
+        for (uint32_t id : ids) ((can_fast && nodes[id].len >= kFsMinRows) ? fast : slow).push_back(id);
+        std::vector<FsTile> tiles;
+        std::vector<uint32_t> tbase, tcount;
+        for (uint32_t id : fast) {
+            const uint32_t nt = (nodes[id].len + kFsTile - 1) / kFsTile;
+            tbase.push_back((uint32_t)tiles.size());
+            tcount.push_back(nt);
+            for (uint32_t t = 0; t < nt; ++t) tiles.push_back({id, t});
+        }
+        if (!slow.empty()) {
+            VQ_TRY(b_lvl_slow.ensure(slow.size() * 4));
+            VQ_HIP(hipMemcpyAsync(b_lvl_slow.p, slow.data(), slow.size() * 4, hipMemcpyHostToDevice, stream));
+        }
+        if (!fast.empty()) {
+            VQ_TRY(b_fs_tiles.ensure(tiles.size() * sizeof(FsTile)));
+            VQ_TRY(b_fs_nodes.ensure(fast.size() * 4));
+            VQ_TRY(b_fs_base.ensure(fast.size() * 4));
+            VQ_TRY(b_fs_nt.ensure(fast.size() * 4));
+            VQ_TRY(b_fs_sum.ensure(tiles.size() * (size_t)d * 8));
+            VQ_TRY(b_fs_summ.ensure(tiles.size() * (size_t)d * sizeof(FsSumm)));
+            VQ_TRY(b_fs_side.ensure((size_t)side_cap * kFsTile * 4));
+            VQ_HIP(hipMemsetAsync(b_fs_fb.as<uint32_t>() + 1, 0, 4, stream));
+            VQ_HIP(hipMemcpyAsync(b_fs_tiles.p, tiles.data(), tiles.size() * sizeof(FsTile), hipMemcpyHostToDevice, stream));
+            VQ_HIP(hipMemcpyAsync(b_fs_nodes.p, fast.data(), fast.size() * 4, hipMemcpyHostToDevice, stream));
+            VQ_HIP(hipMemcpyAsync(b_fs_base.p, tbase.data(), fast.size() * 4, hipMemcpyHostToDevice, stream));
+            VQ_HIP(hipMemcpyAsync(b_fs_nt.p, tcount.data(), fast.size() * 4, hipMemcpyHostToDevice, stream));
+        }
+        VQ_HIP(hipStreamSynchronize(stream));  // the host vectors above go out of scope
+        if (!slow.empty()) {
+            if (mode == 0)
+                hipLaunchKernelGGL(k_seg_colsum<0>, dim3((uint32_t)slow.size(), dgroups), dim3(1024), 0, stream, X, d, perm,
+                                   b_lvl_slow.as<uint32_t>(), na);
+            else
+                hipLaunchKernelGGL(k_seg_colsum<1>, dim3((uint32_t)slow.size(), dgroups), dim3(1024), 0, stream, X, d, perm,
+                                   b_lvl_slow.as<uint32_t>(), na);
+            VQ_LAUNCH_CHECK("k_seg_colsum");
+        }
+        if (!fast.empty()) {
+            const dim3 tgrid((uint32_t)tiles.size(), d / kFsCols);
+            const FsTile *tl = b_fs_tiles.as<FsTile>();
+            double *ts = b_fs_sum.as<double>();
+            FsSumm *sm = b_fs_summ.as<FsSumm>();
+            const uint32_t *fn = b_fs_nodes.as<uint32_t>(), *fb = b_fs_base.as<uint32_t>(), *fc = b_fs_nt.as<uint32_t>();
+            const dim3 cgrid((uint32_t)fast.size(), d);
+            if (mode == 0) {
+                hipLaunchKernelGGL(k_fs_tile_sums<0>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts);
+                hipLaunchKernelGGL(k_fs_prefix, dim3((uint32_t)fast.size(), d / kFsCols), dim3(1024), 0, stream, d, fb, fc, ts);
+                hipLaunchKernelGGL(k_fs_transduce<0>, tgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1);
+                hipLaunchKernelGGL(k_fs_chain<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, b_fs_side.as<float>(), b_fs_fb.as<uint32_t>());
+            } else {
+                hipLaunchKernelGGL(k_fs_tile_sums<1>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts);
+                hipLaunchKernelGGL(k_fs_prefix, dim3((uint32_t)fast.size(), d / kFsCols), dim3(1024), 0, stream, d, fb, fc, ts);
+                hipLaunchKernelGGL(k_fs_transduce<1>, tgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1);
+                hipLaunchKernelGGL(k_fs_chain<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, b_fs_side.as<float>(), b_fs_fb.as<uint32_t>());
+            }
+            VQ_LAUNCH_CHECK("k_fs_*");
+        }
+        return VQHIP_OK;
+    };
+
     while (!level.empty()) {
         const uint32_t n_lvl = (uint32_t)level.size();
         VQ_TRY(b_lvl.ensure((size_t)n_lvl * 4));
@@ -734,8 +1170,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         const uint32_t *lvl = b_lvl.as<uint32_t>();
         uint32_t *perm = b_perm[cur].as<uint32_t>(), *node_of = b_nodeof[cur].as<uint32_t>();
         // means of every node of the level (tsvq.rs:36)
-        hipLaunchKernelGGL(k_seg_colsum<0>, dim3(n_lvl, dgroups), dim3(1024), 0, stream, X, d, perm, lvl, na);
-        VQ_LAUNCH_CHECK("k_seg_colsum<mean>");
+        VQ_TRY(colsum(0, level, perm));
 
         // which nodes split? (tsvq.rs:38-44)
         std::vector<uint32_t> split_nodes;
@@ -767,8 +1202,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             VQ_HIP(hipStreamSynchronize(stream));
         }
         // variances + split dimension (tsvq.rs:46-66)
-        hipLaunchKernelGGL(k_seg_colsum<1>, dim3(n_split, dgroups), dim3(1024), 0, stream, X, d, perm, lvl, na);
-        VQ_LAUNCH_CHECK("k_seg_colsum<var>");
+        VQ_TRY(colsum(1, split_nodes, perm));
         hipLaunchKernelGGL(k_pick_split, dim3((n_split + 63) / 64), dim3(64), 0, stream, lvl, n_split, d, na);
         VQ_LAUNCH_CHECK("k_pick_split");
         // median (tsvq.rs:68-81)
@@ -852,6 +1286,12 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         level.swap(next);
     }
 
+    if (getenv("VQHIP_TSVQ_DEBUG")) {
+        uint32_t fb = 0;
+        VQ_HIP(hipMemcpyAsync(&fb, b_fs_fb.p, 4, hipMemcpyDeviceToHost, stream));
+        VQ_HIP(hipStreamSynchronize(stream));
+        fprintf(stderr, "[vqhip] tsvq build: %u tile re-additions in the exact column sums\n", fb);
+    }
     // centroids of all nodes -> host, then BFS -> pre-order (the oracle's numbering)
     const uint32_t total = (uint32_t)nodes.size();
     std::vector<float> cent((size_t)total * d);
