@@ -274,25 +274,58 @@ __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ v
     }
 }
 
-__global__ void k_select_pick(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, NodeArrays na,
-                              uint32_t shift, uint32_t *__restrict__ hist) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per (node, which of the two ranks): lane l owns bins 4l..4l+3, a wave prefix scan finds
+// the bin holding the rank (the serial walk over 256 dependent loads cost 25 us per launch)
+__global__ __launch_bounds__(64) void k_select_pick(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl,
+                                                    NodeArrays na, uint32_t shift, uint32_t *__restrict__ hist) {
+    const uint32_t idx = blockIdx.x, lane = threadIdx.x;
     if (idx >= n_lvl * 2) return;
     const uint32_t li = idx >> 1, sel = idx & 1;
     const uint32_t node = lvl_node[li];
-    uint32_t *h = hist + ((size_t)li * 2 + sel) * 256;
-    uint32_t rank = na.sel_rank[2 * node + sel];
-    uint32_t b = 0;
-    if (na.nv[node] != 0) {
-        for (; b < 255; ++b) {
-            const uint32_t c = h[b];
-            if (rank < c) break;
-            rank -= c;
-        }
+    uint4 *h4 = reinterpret_cast<uint4 *>(hist + ((size_t)li * 2 + sel) * 256);
+    const uint4 c = h4[lane];
+    h4[lane] = make_uint4(0u, 0u, 0u, 0u);  // ready for the next round
+    const uint32_t rank = na.sel_rank[2 * node + sel];
+    const uint32_t mine = c.x + c.y + c.z + c.w;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+        if ((int)lane >= off) incl += up;
     }
-    na.sel_rank[2 * node + sel] = rank;
-    na.sel_prefix[2 * node + sel] |= b << shift;
-    for (uint32_t q = 0; q < 256; ++q) h[q] = 0;  // ready for the next round
+    const uint32_t excl = incl - mine;
+    // first bin b with rank < cumulative(b); the serial rule stops at bin 255 if none does
+    const bool here = (rank >= excl) && (rank < incl);
+    const uint64_t m = __ballot(here);
+    uint32_t b = 255, new_rank;
+    if (na.nv[node] == 0) {
+        b = 0;
+        new_rank = rank;
+    } else if (m) {
+        const int src = __builtin_ctzll(m);
+        uint32_t r = rank - excl, bb = 4 * lane;
+        if (r >= c.x) {
+            r -= c.x;
+            ++bb;
+            if (r >= c.y) {
+                r -= c.y;
+                ++bb;
+                if (r >= c.z) {
+                    r -= c.z;
+                    ++bb;
+                }
+            }
+        }
+        b = (uint32_t)__shfl((int)bb, src);
+        new_rank = (uint32_t)__shfl((int)r, src);
+    } else {  // rank beyond every bin: walk ends at bin 255 with the counts of bins 0..254 removed
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63), last = (uint32_t)__shfl((int)c.w, 63);
+        new_rank = rank - (total - last);
+    }
+    if (lane == 0) {
+        na.sel_rank[2 * node + sel] = new_rank;
+        na.sel_prefix[2 * node + sel] |= b << shift;
+    }
 }
 
 __global__ void k_median(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, NodeArrays na) {
@@ -1219,7 +1252,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             hipLaunchKernelGGL(k_select_hist, dim3(hblocks), dim3(256), 0, stream, b_vals.as<float>(), n, hchunk,
                                node_of, lvl, na, (uint32_t)shift, b_hist.as<uint32_t>());
             VQ_LAUNCH_CHECK("k_select_hist");
-            hipLaunchKernelGGL(k_select_pick, dim3((n_split * 2 + 63) / 64), dim3(64), 0, stream, lvl, n_split, na,
+            hipLaunchKernelGGL(k_select_pick, dim3(n_split * 2), dim3(64), 0, stream, lvl, n_split, na,
                                (uint32_t)shift, b_hist.as<uint32_t>());
             VQ_LAUNCH_CHECK("k_select_pick");
         }
