@@ -8,6 +8,7 @@ headline contract).  One JSON line per configuration on one MI355X:
   C4  TSVQ depth 8 L2,         1M x 128     build + encode
   C5  PQ m=16 k=256 L2,        per-GPU shard of 100M x 128 (12.5M rows) fit iteration + encode
   C2_manhattan  C2 with Distance::Manhattan for the encode (no contraction form: exact VALU engine)
+  ADC code-based top-10 search of 64 queries over the C2 codes (1M x 8 bytes)
   E   PQ m=16 k=256 Euclidean, 1M x 384     (the reference's `make eval` shape, src/bin/common.rs:10-15: sub_dim 24)
 
     python bench_configs.py [C1 C2 ...]
@@ -129,6 +130,37 @@ def tsvq_config(name, n, d, depth, reps=3):
     return out
 
 
+def adc_config(name, n, d, m, k, nq, topk, reps=3):
+    """code-based search: device-resident codes, host queries, top-k out"""
+    import torch
+
+    from vq_amd import _lib
+
+    ds = _lib.Dataset.synthetic(n, d, 66, 0)
+    km = _lib.KMeans(ds, m, k)
+    km.init_from_rows(np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64))
+    for _ in range(3):
+        km.step()
+    cb = km.get_centroids()
+    km.close()
+    enc = _lib.PQEncoder(cb, _lib.SQUARED_EUCLIDEAN)
+    codes = torch.empty((n, m), dtype=torch.uint8, device="cuda")
+    enc.encode_device(ds.device_ptr, n, codes.data_ptr(), None)
+    Q = _lib.synth_uniform_host(nq, d, 67, 0)
+    enc.adc_search((codes.data_ptr(), n), Q, topk)
+    _sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        idx, dist = enc.adc_search((codes.data_ptr(), n), Q, topk)
+    dt = (time.perf_counter() - t0) / reps
+    out = {"config": name, "n": n, "d": d, "m": m, "k": k, "queries": nq, "topk": topk, "search_ms": dt * 1e3,
+           "queries_per_s": nq / dt, "code_rows_scanned_per_s": nq * n / dt,
+           "scan_GBps_codes_plus_distances": nq * n * (m / 8.0 + 4.0 * 6) / dt / 1e9}
+    enc.close()
+    ds.close()
+    return out
+
+
 CONFIGS = {
     "C1": lambda: pq_config("C1", 10_000, 64, 4, 16, "euclidean"),
     "C2": lambda: pq_config("C2", 1_000_000, 128, 8, 256, "l2"),
@@ -136,6 +168,7 @@ CONFIGS = {
     "C4": lambda: tsvq_config("C4", 1_000_000, 128, 8),
     "C5": lambda: pq_config("C5_per_gpu_shard", 12_500_000, 128, 16, 256, "l2", iters=3, encode_reps=2),
     "C2_manhattan": lambda: pq_config("C2_manhattan", 1_000_000, 128, 8, 256, "manhattan", iters=3, encode_reps=3),
+    "ADC": lambda: adc_config("ADC_C2", 1_000_000, 128, 8, 256, 64, 10),
     "E": lambda: pq_config("E_eval_shape", 1_000_000, 384, 16, 256, "euclidean", iters=5, encode_reps=3),
 }
 

@@ -193,6 +193,19 @@ int vqhip_pq_decode(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n, flo
 int vqhip_distance_batch(int metric, const float *a, const float *b, uint64_t n, uint32_t d,
                          float *out);
 
+/* ---- asymmetric distance search over stored codes --------------------
+ * No reference counterpart (the crate stores f16 reconstructions, src/pq.rs:165-199); semantics =
+ * oracle/vq_oracle.c:vqo_adc_search: D(q, i) = sum over subspaces, in order, of the reference's
+ * per-subspace distance (squared L2 or L1) between the query's sub-vector and centroid
+ * codes[i][s]; the topk rows by (D, row index) ascending; Euclidean reports sqrt(D); cosine is
+ * not separable (VQHIP_ERR_UNSUPPORTED).  codes [n][m] u8, queries [nq][dim] host f32,
+ * idx_out / dist_out [nq][topk] host; 1 <= topk <= min(n, 1024). */
+int vqhip_pq_adc_search(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n, const float *queries,
+                        uint32_t nq, uint32_t topk, uint32_t *idx_out, float *dist_out);
+int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uint64_t n,
+                               const float *queries, uint32_t nq, uint32_t topk, uint32_t *idx_out,
+                               float *dist_out);
+
 /* ---- TSVQ ----------------------------------------------------------------------------
  * build replaces TSVQNode::build (src/tsvq.rs:31-115); the tree comes back flattened in
  * pre-order (node 0 = root, left subtree, right subtree): centroids [cap][d], left/right

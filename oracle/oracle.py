@@ -96,6 +96,8 @@ class Oracle:
         L.vqo_pq_fit.restype = C.c_int
         L.vqo_pq_fit.argtypes = [_f32p, sz, sz, sz, sz, sz, _u64p, _u64p, sz, _f32p, _szp,
                                  C.c_int]
+        L.vqo_adc_search.restype = C.c_int
+        L.vqo_adc_search.argtypes = [C.c_int, _f32p, sz, sz, sz, C.POINTER(C.c_uint8), sz, _f32p, sz, sz, _u32p, _f32p]
         L.vqo_pq_encode.restype = C.c_int
         L.vqo_pq_encode.argtypes = [C.c_int, _f32p, sz, sz, sz, sz, _f32p, _u32p, _u16p, C.c_int]
         L.vqo_tsvq_build.restype = C.c_int
@@ -227,6 +229,21 @@ class Oracle:
         if rc:
             raise OracleError(rc, "pq_encode")
         return codes, f16
+
+    def adc_search(self, metric: int, codebooks, codes, queries, topk: int):
+        """semantics of the code-based search (no reference counterpart): (idx u32, dist f32) [nq][topk]"""
+        cb = self._f32(codebooks)
+        m, k, sd = cb.shape
+        codes = np.ascontiguousarray(codes, np.uint8)
+        q = self._f32(queries)
+        n, nq = codes.shape[0], q.shape[0]
+        idx = np.empty((nq, topk), np.uint32)
+        dist = np.empty((nq, topk), np.float32)
+        rc = self.lib.vqo_adc_search(metric, _ptr(cb, _f32p), m, k, sd, codes.ctypes.data_as(C.POINTER(C.c_uint8)), n,
+                                     _ptr(q, _f32p), nq, topk, _ptr(idx, _u32p), _ptr(dist, _f32p))
+        if rc:
+            raise OracleError(rc, "adc_search")
+        return idx, dist
 
     # -- TSVQ ------------------------------------------------------------------------
     def tsvq_build(self, rows, max_depth: int):

@@ -554,3 +554,60 @@ int vqo_tsvq_encode(int metric, const float *rows, size_t n, size_t d, const flo
     }
     return VQO_OK;
 }
+
+/* ---- ADC search (defines the semantics; no reference counterpart, see vq_oracle.h) -------- */
+typedef struct {
+    float d;
+    uint32_t i;
+} adc_pair;
+
+static int adc_cmp(const void *pa, const void *pb) {
+    const adc_pair *a = (const adc_pair *)pa, *b = (const adc_pair *)pb;
+    const int an = a->d != a->d, bn = b->d != b->d; /* NaN last */
+    if (an != bn) return an - bn;
+    if (!an) {
+        if (a->d < b->d) return -1;
+        if (a->d > b->d) return 1;
+    }
+    return (a->i > b->i) - (a->i < b->i);
+}
+
+int vqo_adc_search(int metric, const float *codebooks, size_t m, size_t k, size_t sd,
+                   const uint8_t *codes, size_t n, const float *queries, size_t nq, size_t topk,
+                   uint32_t *idx_out, float *dist_out) {
+    if (metric == VQO_COSINE || topk == 0 || topk > n || m == 0 || k == 0 || k > 256)
+        return VQO_ERR_INVALID_PARAMETER;
+    float *lut = (float *)malloc(m * k * sizeof(float));
+    adc_pair *all = (adc_pair *)malloc(n * sizeof(adc_pair));
+    if (!lut || !all) {
+        free(lut);
+        free(all);
+        return VQO_ERR_ALLOC;
+    }
+    for (size_t q = 0; q < nq; ++q) {
+        const float *x = queries + q * m * sd;
+        for (size_t s = 0; s < m; ++s)
+            for (size_t j = 0; j < k; ++j) {
+                const float *c = codebooks + (s * k + j) * sd;
+                lut[s * k + j] = (metric == VQO_MANHATTAN) ? manhattan(x + s * sd, c, sd)
+                                                           : vqo_distance2(x + s * sd, c, sd);
+            }
+        for (size_t i = 0; i < n; ++i) {
+            float acc = lut[codes[i * m]];
+            for (size_t s = 1; s < m; ++s) {
+                const float t = lut[s * k + codes[i * m + s]];
+                acc = acc + t;
+            }
+            all[i].d = acc;
+            all[i].i = (uint32_t)i;
+        }
+        qsort(all, n, sizeof(adc_pair), adc_cmp);
+        for (size_t r = 0; r < topk; ++r) {
+            idx_out[q * topk + r] = all[r].i;
+            dist_out[q * topk + r] = (metric == VQO_EUCLIDEAN) ? sqrtf(all[r].d) : all[r].d;
+        }
+    }
+    free(lut);
+    free(all);
+    return VQO_OK;
+}

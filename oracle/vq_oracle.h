@@ -137,6 +137,20 @@ int vqo_pq_encode(int metric, const float *rows, size_t n, size_t d, size_t m, s
  *   centroids [cap][d];  left/right [cap] child index or -1;  n_nodes_out
  *   node_rows_out optional [cap]: training rows that reached each node
  */
+/*
+ * Asymmetric distance search over stored codes.  NOT a restatement: the reference has no such
+ * function (it keeps f16 reconstructions, src/pq.rs:165-199; SURVEY.md 8(f) N3 lists it as the
+ * next tier).  This fixes the semantics the GPU path is tested against, built from restated
+ * pieces: t_s(q, j) = vqo_distance2 (src/core/vector.rs:135-143) or the L1 kernel
+ * (src/core/distance.rs:85-95) between the query's sub-vector s and centroid j;
+ * D(q, i) = t_0 + t_1 + ... + t_{m-1} over codes[i][s], in subspace order, f32;
+ * result = the topk rows by (D, row) ascending, NaN last; Euclidean reports sqrt(D).
+ * Returns VQO_ERR_INVALID_PARAMETER for cosine (not a sum over subspaces).
+ */
+int vqo_adc_search(int metric, const float *codebooks, size_t m, size_t k, size_t sd,
+                   const uint8_t *codes, size_t n, const float *queries, size_t nq, size_t topk,
+                   uint32_t *idx_out, float *dist_out);
+
 int vqo_tsvq_build(const float *rows, size_t n, size_t d, size_t max_depth, size_t cap,
                    float *centroids, int32_t *left, int32_t *right, int32_t *n_nodes_out,
                    uint64_t *node_rows_out);

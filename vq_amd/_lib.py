@@ -79,6 +79,8 @@ SIGNATURES = {
     "vqhip_tsvq_destroy": (C.c_int, [_vp]),
     "vqhip_tsvq_encode": (C.c_int, [_vp, _f32p, C.c_uint64, _i32p, _u16p]),
     "vqhip_tsvq_encode_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "vqhip_pq_adc_search": (C.c_int, [_vp, _u8p, C.c_uint64, _f32p, C.c_uint32, C.c_uint32, _u32p, _f32p]),
+    "vqhip_pq_adc_search_device": (C.c_int, [_vp, _vp, C.c_uint64, _f32p, C.c_uint32, C.c_uint32, _u32p, _f32p]),
     "vqhip_selftest": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "vqhip_tsvq_last_stats": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
 }
@@ -287,6 +289,28 @@ class PQEncoder(Handle):
 
     def set_engine(self, engine: int):
         check(load().vqhip_pq_encoder_set_engine(self.raw, engine))
+
+    def adc_search(self, codes, queries, topk: int):
+        """top-k rows of `codes` [n][m] u8 (numpy array, or (device_ptr, n)) per query by asymmetric
+        distance; returns (idx uint32 [nq][topk], dist float32 [nq][topk])"""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        idx = np.empty((nq, topk), np.uint32)
+        dist = np.empty((nq, topk), np.float32)
+        if nq == 0:
+            return idx, dist
+        lib = load()
+        if isinstance(codes, tuple):
+            dev_ptr, n = codes
+            check(lib.vqhip_pq_adc_search_device(self.raw, C.c_void_p(dev_ptr), int(n), ptr(q, _f32p), nq, int(topk),
+                                                 ptr(idx, _u32p), ptr(dist, _f32p)))
+        else:
+            c = np.ascontiguousarray(codes, dtype=np.uint8)
+            check(lib.vqhip_pq_adc_search(self.raw, ptr(c, _u8p), c.shape[0], ptr(q, _f32p), nq, int(topk),
+                                          ptr(idx, _u32p), ptr(dist, _f32p)))
+        return idx, dist
 
     def encode(self, rows, want_codes=True, want_f16=True):
         rows = f32c(rows).reshape(-1, self.m * self.sd)

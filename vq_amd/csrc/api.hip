@@ -358,7 +358,7 @@ struct vqhip_pq_encoder {
     AssignWorkspace ws;
     int metric = VQHIP_EUCLIDEAN;
     int engine = VQHIP_ENGINE_AUTO;
-    DevBuf xbuf, codes, f16buf, f32buf;
+    DevBuf xbuf, codes, f16buf, f32buf, adc_q, adc_lut, adc_dist, adc_idx, adc_out, adc_codes, adc_state, adc_cand;
     std::vector<uint32_t> all_subs;
 };
 
@@ -1045,6 +1045,48 @@ int vqhip_pq_encode(vqhip_pq_encoder *enc, const float *rows, uint64_t n, uint8_
         VQ_HIP(hipStreamSynchronize(s));
     }
     return VQHIP_OK;
+    VQ_API_END
+}
+
+// ------------------------------------------------------------------------ ADC search ----
+int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uint64_t n, const float *queries,
+                               uint32_t nq, uint32_t topk, uint32_t *idx_out, float *dist_out) {
+    VQ_API_BEGIN
+    if (!enc || !dev_codes || !queries || !idx_out || !dist_out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (nq == 0) return VQHIP_OK;
+    if (n == 0 || n >= (1ull << 32)) return fail(VQHIP_ERR_INVALID_INPUT, "n must be in [1, 2^32)");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    const uint32_t m = enc->cs.m, k = enc->cs.k, sd = enc->cs.sd, dim = m * sd;
+    VQ_TRY(enc->adc_q.ensure((size_t)nq * dim * 4));
+    VQ_TRY(enc->adc_lut.ensure((size_t)adc_query_batch() * m * k * 4));
+    VQ_TRY(enc->adc_dist.ensure((size_t)adc_query_batch() * n * 4));
+    VQ_TRY(enc->adc_idx.ensure((size_t)nq * topk * 4));
+    VQ_TRY(enc->adc_out.ensure((size_t)nq * topk * 4));
+    VQ_TRY(enc->adc_state.ensure(adc_state_bytes()));
+    VQ_TRY(enc->adc_cand.ensure(adc_cand_bytes()));
+    VQ_HIP(hipMemcpyAsync(enc->adc_q.p, queries, (size_t)nq * dim * 4, hipMemcpyHostToDevice, s));
+    VQ_TRY(launch_adc_search(enc->cs.cb.as<float>(), m, k, sd, enc->metric, reinterpret_cast<const uint8_t *>(dev_codes), n,
+                             enc->adc_q.as<float>(), nq, topk, enc->adc_lut.as<float>(), enc->adc_dist.as<float>(),
+                             enc->adc_state.p, enc->adc_cand.as<unsigned long long>(), enc->adc_idx.as<uint32_t>(),
+                             enc->adc_out.as<float>(), s));
+    VQ_HIP(hipMemcpyAsync(idx_out, enc->adc_idx.p, (size_t)nq * topk * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipMemcpyAsync(dist_out, enc->adc_out.p, (size_t)nq * topk * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_pq_adc_search(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n, const float *queries, uint32_t nq,
+                        uint32_t topk, uint32_t *idx_out, float *dist_out) {
+    VQ_API_BEGIN
+    if (!enc || !codes) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_TRY(enc->adc_codes.ensure((size_t)n * enc->cs.m));
+    VQ_HIP(hipMemcpyAsync(enc->adc_codes.p, codes, (size_t)n * enc->cs.m, hipMemcpyHostToDevice, s));
+    return vqhip_pq_adc_search_device(enc, enc->adc_codes.p, n, queries, nq, topk, idx_out, dist_out);
     VQ_API_END
 }
 

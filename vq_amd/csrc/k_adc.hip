@@ -1,0 +1,361 @@
+// Asymmetric distance search over stored PQ codes ("code-based storage + ADC").
+// The reference has no counterpart (it keeps f16 reconstructions, src/pq.rs:165-199); the semantics
+// are the ones include/vqhip.h states (the tests hold a CPU statement of the same definition):
+//   t_s(q, j)  = the reference's per-subspace distance between the query's sub-vector and centroid j
+//                (squared L2: Vector::distance2, src/core/vector.rs:135-143; L1: distance.rs:85-95),
+//   D(q, i)    = t_0(q, code[i][0]) + t_1(...) + ... in subspace order, f32,
+//   result     = the topk rows by (D, row index) ascending; Euclidean reports sqrt(D).
+// Kernels: the table t (k_adc_lut), a byte-gather scan of the codes with the tables of 8 queries in
+// LDS (k_adc_scan: HBM-bound on the codes, m bytes per row), and an exact per-query radix select +
+// in-LDS sort (k_adc_topk).
+#include "common.hpp"
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace vqhip {
+namespace {
+
+__device__ __forceinline__ uint32_t adc_key(float f) {  // order-preserving; NaN sorts last
+    const uint32_t b = __float_as_uint(f);
+    if ((b & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float adc_unkey(uint32_t k) {
+    if (k == 0xFFFFFFFFu) return __uint_as_float(0x7FC00000u);
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// lut[q][s][j]
+// also bounds[q] = {sum_s min_j t_s, sum_s max_j t_s}: the range every D(q, .) lies in (used only to
+// place the histogram bins of the candidate filter, so the float atomics' order does not matter)
+__global__ __launch_bounds__(256) void k_adc_lut(const float *__restrict__ queries, uint32_t nq, uint32_t m,
+                                                 uint32_t k, uint32_t sd, const float *__restrict__ cb, int l1,
+                                                 float *__restrict__ lut, float *__restrict__ bounds) {
+    __shared__ float s_lo[256], s_hi[256];
+    const uint32_t q = blockIdx.x, s = blockIdx.y;
+    const float *x = queries + ((size_t)q * m + s) * sd;
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    for (uint32_t j = threadIdx.x; j < k; j += 256) {
+        const float *c = cb + ((size_t)s * k + j) * sd;
+        float acc = l1 ? 0.0f : -0.0f;
+        for (uint32_t t = 0; t < sd; ++t) {
+            const float diff = x[t] - c[t];
+            if (l1) {
+                acc = acc + fabsf(diff);
+            } else {
+                const float sq = diff * diff;
+                acc = acc + sq;
+            }
+        }
+        lut[((size_t)q * m + s) * k + j] = acc;
+        lo = fminf(lo, acc);
+        hi = fmaxf(hi, acc);
+    }
+    s_lo[threadIdx.x] = lo;
+    s_hi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            s_lo[threadIdx.x] = fminf(s_lo[threadIdx.x], s_lo[threadIdx.x + off]);
+            s_hi[threadIdx.x] = fmaxf(s_hi[threadIdx.x], s_hi[threadIdx.x + off]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&bounds[2 * q + 0], s_lo[0]);
+        atomicAdd(&bounds[2 * q + 1], s_hi[0]);
+    }
+    (void)nq;
+}
+
+constexpr uint32_t kAdcQB = 8;      // queries per scan pass (their tables share the LDS)
+constexpr uint32_t kAdcBins = 512;  // linear bins over [bounds lo, hi] for the candidate filter
+constexpr uint32_t kAdcCand = 8192; // candidates the fast top-k path sorts in LDS
+
+// monotone (non-decreasing in d) bin of a distance; NaN and out-of-range values go to the last bin
+__device__ __forceinline__ uint32_t adc_bin(float dval, float lo, float scale) {
+    const float t = (dval - lo) * scale;
+    return (t >= 0.0f && t < (float)(kAdcBins - 1)) ? (uint32_t)t : ((t < 0.0f) ? 0u : kAdcBins - 1);
+}
+
+// dist[qq][i] for the queries q0 .. q0+nqb-1
+__global__ __launch_bounds__(256) void k_adc_scan(const uint8_t *__restrict__ codes, uint64_t n, uint32_t m,
+                                                  uint32_t k, const float *__restrict__ lut, uint32_t nqb,
+                                                  const float *__restrict__ bounds, float *__restrict__ dist,
+                                                  uint32_t *__restrict__ hist) {
+    extern __shared__ float lds_lut[];  // [nqb][m][k], then the block's histograms [nqb][kAdcBins]
+    const uint32_t tab = m * k;
+    uint32_t *lds_hist = reinterpret_cast<uint32_t *>(lds_lut + (size_t)nqb * tab);
+    for (uint32_t e = threadIdx.x; e < nqb * tab; e += 256) lds_lut[e] = lut[e];
+    for (uint32_t e = threadIdx.x; e < nqb * kAdcBins; e += 256) lds_hist[e] = 0u;
+    float blo[kAdcQB], bsc[kAdcQB];
+#pragma unroll
+    for (uint32_t qq = 0; qq < kAdcQB; ++qq) {
+        const float lo = (qq < nqb) ? bounds[2 * qq] : 0.0f, hi = (qq < nqb) ? bounds[2 * qq + 1] : 1.0f;
+        blo[qq] = lo;
+        bsc[qq] = (hi > lo) ? (float)kAdcBins / (hi - lo) : 0.0f;
+    }
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint8_t *row = codes + i * m;
+        float acc[kAdcQB];
+#pragma unroll
+        for (uint32_t qq = 0; qq < kAdcQB; ++qq) acc[qq] = 0.0f;
+        for (uint32_t s = 0; s < m; ++s) {
+            const uint32_t off = s * k + row[s];
+#pragma unroll
+            for (uint32_t qq = 0; qq < kAdcQB; ++qq)
+                if (qq < nqb) acc[qq] = (s == 0) ? lds_lut[qq * tab + off] : acc[qq] + lds_lut[qq * tab + off];
+        }
+#pragma unroll
+        for (uint32_t qq = 0; qq < kAdcQB; ++qq)
+            if (qq < nqb) {
+                dist[(size_t)qq * n + i] = acc[qq];
+                atomicAdd(&lds_hist[qq * kAdcBins + adc_bin(acc[qq], blo[qq], bsc[qq])], 1u);
+            }
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < nqb * kAdcBins; e += 256)
+        if (lds_hist[e]) atomicAdd(&hist[e], lds_hist[e]);
+}
+
+// fast top-k, step 1: the bin that holds the k-th smallest value; sel[q] = {bin, candidates up to it}
+__global__ __launch_bounds__(64) void k_adc_pick_bin(const uint32_t *__restrict__ hist, uint32_t topk,
+                                                     uint32_t *__restrict__ sel) {
+    const uint32_t q = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    uint32_t cum = 0, b = 0;
+    for (; b < kAdcBins; ++b) {
+        cum += hist[q * kAdcBins + b];
+        if (cum >= topk) break;
+    }
+    sel[2 * q + 0] = b;
+    sel[2 * q + 1] = cum;
+}
+
+// step 2: every row whose bin is <= the selected one becomes a candidate (key, row); any order
+__global__ __launch_bounds__(256) void k_adc_collect(const float *__restrict__ dist, uint64_t n,
+                                                     const float *__restrict__ bounds, const uint32_t *__restrict__ sel,
+                                                     unsigned long long *__restrict__ cand, uint32_t *__restrict__ cand_n) {
+    const uint32_t q = blockIdx.y;
+    if (sel[2 * q + 1] > kAdcCand) return;  // too dense: the exact radix select handles this query
+    const float lo = bounds[2 * q], hi = bounds[2 * q + 1];
+    const float scale = (hi > lo) ? (float)kAdcBins / (hi - lo) : 0.0f;
+    const uint32_t bmax = sel[2 * q];
+    const float *dq = dist + (size_t)q * n;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const float dv = dq[i];
+        if (adc_bin(dv, lo, scale) <= bmax) {
+            const uint32_t pos = atomicAdd(&cand_n[q], 1u);
+            if (pos < kAdcCand) cand[(size_t)q * kAdcCand + pos] = ((unsigned long long)adc_key(dv) << 32) | (uint32_t)i;
+        }
+    }
+}
+
+// step 3: sort the candidates by (key, row) in LDS, emit the first topk
+__global__ __launch_bounds__(1024) void k_adc_sort_out(const unsigned long long *__restrict__ cand,
+                                                       const uint32_t *__restrict__ sel, uint32_t topk, int take_sqrt,
+                                                       uint32_t *__restrict__ idx_out, float *__restrict__ dist_out) {
+    extern __shared__ unsigned long long sort_buf[];  // [kAdcCand]
+    const uint32_t q = blockIdx.x, cnt = sel[2 * q + 1];
+    if (cnt > kAdcCand) return;  // handled by k_adc_topk
+    uint32_t len = 1024;
+    while (len < cnt) len <<= 1;
+    for (uint32_t e = threadIdx.x; e < len; e += 1024) sort_buf[e] = (e < cnt) ? cand[(size_t)q * kAdcCand + e] : ~0ull;
+    __syncthreads();
+    for (uint32_t size = 2; size <= len; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = threadIdx.x; t < len; t += 1024) {
+                const uint32_t partner = t ^ stride;
+                if (partner > t) {
+                    const bool up = (t & size) == 0;
+                    const unsigned long long a = sort_buf[t], b = sort_buf[partner];
+                    if ((a > b) == up) {
+                        sort_buf[t] = b;
+                        sort_buf[partner] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x < topk) {
+        const unsigned long long w = sort_buf[threadIdx.x];
+        float dv = adc_unkey((uint32_t)(w >> 32));
+        if (take_sqrt) dv = sqrtf(dv);
+        idx_out[(size_t)q * topk + threadIdx.x] = (uint32_t)w;
+        dist_out[(size_t)q * topk + threadIdx.x] = dv;
+    }
+}
+
+// exact top-k of one query's distances: radix select of the k-th key, ordered collection (ties by
+// row index), bitonic sort of the <= 1024 winners by (key, index)
+__global__ __launch_bounds__(1024) void k_adc_topk(const float *__restrict__ dist, uint64_t n, uint32_t topk, int take_sqrt,
+                                                   const uint32_t *__restrict__ sel, uint32_t *__restrict__ idx_out,
+                                                   float *__restrict__ dist_out) {
+    __shared__ uint32_t hist[256];
+    if (sel && sel[2 * blockIdx.x + 1] <= kAdcCand) return;  // the candidate path produced this query's result
+    __shared__ uint32_t s_prefix, s_rank, s_count;
+    __shared__ uint32_t wsum[16];
+    __shared__ unsigned long long win[1024];
+    const float *dq = dist + (size_t)blockIdx.x * n;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        s_prefix = 0;
+        s_rank = topk - 1;
+    }
+    __syncthreads();
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix, himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (uint64_t i = tid; i < n; i += 1024) {
+            const uint32_t key = adc_key(dq[i]);
+            if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t rank = s_rank, b = 0;
+            for (; b < 255; ++b) {
+                if (rank < hist[b]) break;
+                rank -= hist[b];
+            }
+            s_rank = rank;
+            s_prefix = prefix | (b << shift);
+        }
+        __syncthreads();
+    }
+    const uint32_t T = s_prefix;         // the k-th smallest key
+    const uint32_t need_eq = s_rank + 1;  // how many keys == T belong to the result (lowest row indices)
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    // ordered collection: chunks of 1024 rows, block prefix sums keep row order
+    uint32_t eq_taken = 0;  // replicated in every thread (uniform updates)
+    for (uint64_t base = 0; base < n; base += 1024) {
+        const uint64_t i = base + tid;
+        uint32_t key = 0xFFFFFFFFu;
+        bool less = false, eq = false;
+        if (i < n) {
+            key = adc_key(dq[i]);
+            less = key < T;
+            eq = key == T;
+        }
+        // ranks among this chunk's `eq` rows and among its selected rows (wave scan + wave sums)
+        const uint64_t eqm = __ballot(eq);
+        const uint32_t lane = tid & 63, wv = tid >> 6;
+        const uint32_t eq_before_w = __popcll(eqm & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(eqm);
+        __syncthreads();
+        uint32_t eq_before = eq_before_w, eq_total = 0;
+        for (uint32_t w = 0; w < 16; ++w) {
+            if (w < wv) eq_before += wsum[w];
+            eq_total += wsum[w];
+        }
+        __syncthreads();
+        const bool take = less || (eq && (eq_taken + eq_before < need_eq));
+        const uint64_t tm = __ballot(take);
+        const uint32_t t_before_w = __popcll(tm & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(tm);
+        __syncthreads();
+        uint32_t t_before = t_before_w, t_total = 0;
+        for (uint32_t w = 0; w < 16; ++w) {
+            if (w < wv) t_before += wsum[w];
+            t_total += wsum[w];
+        }
+        const uint32_t pos = s_count + t_before;
+        if (take && pos < 1024) win[pos] = ((unsigned long long)key << 32) | (uint32_t)i;
+        __syncthreads();
+        if (tid == 0) s_count += t_total;
+        {
+            const uint32_t remaining = need_eq - eq_taken;  // eq_taken <= need_eq always
+            eq_taken += eq_total < remaining ? eq_total : remaining;
+        }
+        __syncthreads();
+        if (s_count >= topk) break;  // uniform
+    }
+    const uint32_t got = s_count < topk ? s_count : topk;
+    for (uint32_t e = tid; e < 1024; e += 1024)
+        if (e >= got) win[e] = ~0ull;
+    __syncthreads();
+    // bitonic sort of 1024 (key, index) pairs
+    for (uint32_t size = 2; size <= 1024; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            const uint32_t partner = tid ^ stride;
+            if (partner > tid) {
+                const bool up = (tid & size) == 0;
+                const unsigned long long a = win[tid], b = win[partner];
+                if ((a > b) == up) {
+                    win[tid] = b;
+                    win[partner] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < topk) {
+        const unsigned long long w = win[tid];
+        const bool valid = tid < got;
+        float dv = adc_unkey((uint32_t)(w >> 32));
+        if (take_sqrt) dv = sqrtf(dv);
+        idx_out[(size_t)blockIdx.x * topk + tid] = valid ? (uint32_t)w : 0xFFFFFFFFu;
+        dist_out[(size_t)blockIdx.x * topk + tid] = valid ? dv : __uint_as_float(0x7FC00000u);
+    }
+}
+
+}  // namespace
+
+// queries_dev [nq][m*sd]; lut_ws >= kAdcQB*m*k floats; dist_ws >= kAdcQB*n floats; outputs on the device
+int launch_adc_search(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int metric, const uint8_t *codes, uint64_t n,
+                      const float *queries_dev, uint32_t nq, uint32_t topk, float *lut_ws, float *dist_ws,
+                      void *state_ws, unsigned long long *cand_ws, uint32_t *idx_out_dev, float *dist_out_dev,
+                      hipStream_t stream) {
+    if (metric == VQHIP_COSINE)
+        return fail(VQHIP_ERR_UNSUPPORTED, "cosine distance is not a sum over subspaces: no ADC form");
+    if (topk == 0 || topk > 1024 || topk > n) return fail(VQHIP_ERR_INVALID_INPUT, "topk must be in [1, min(n, 1024)]");
+    if ((size_t)kAdcQB * (m * k + kAdcBins) * 4 > 150 * 1024)
+        return fail(VQHIP_ERR_UNSUPPORTED, "ADC tables of %u queries (m=%u, k=%u) exceed the LDS", kAdcQB, m, k);
+    static PerDeviceOnce attr;
+    if (attr.needed()) {
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_adc_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   150 * 1024));
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_adc_sort_out),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kAdcCand * 8)));
+        attr.done();
+    }
+    const int l1 = metric == VQHIP_MANHATTAN ? 1 : 0;
+    const int take_sqrt = metric == VQHIP_EUCLIDEAN ? 1 : 0;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > (uint64_t)num_cus() * 8) blocks = (uint64_t)num_cus() * 8;
+    // small state: bounds [QB][2] f32 | hist [QB][bins] u32 | sel [QB][2] u32 | cand_n [QB] u32
+    float *bounds = reinterpret_cast<float *>(state_ws);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(bounds + 2 * kAdcQB);
+    uint32_t *sel = hist + kAdcQB * kAdcBins;
+    uint32_t *cand_n = sel + 2 * kAdcQB;
+    const size_t state_bytes = (size_t)(2 * kAdcQB + kAdcQB * kAdcBins + 2 * kAdcQB + kAdcQB) * 4;
+    for (uint32_t q0 = 0; q0 < nq; q0 += kAdcQB) {
+        const uint32_t nqb = (nq - q0 < kAdcQB) ? nq - q0 : kAdcQB;
+        VQ_HIP(hipMemsetAsync(state_ws, 0, state_bytes, stream));
+        hipLaunchKernelGGL(k_adc_lut, dim3(nqb, m), dim3(256), 0, stream, queries_dev + (size_t)q0 * m * sd, nqb, m, k, sd,
+                           cb, l1, lut_ws, bounds);
+        VQ_LAUNCH_CHECK("k_adc_lut");
+        hipLaunchKernelGGL(k_adc_scan, dim3((uint32_t)blocks), dim3(256), (size_t)nqb * (m * k + kAdcBins) * 4, stream,
+                           codes, n, m, k, lut_ws, nqb, bounds, dist_ws, hist);
+        VQ_LAUNCH_CHECK("k_adc_scan");
+        // top-k: candidates below a histogram cut, sorted in LDS; dense cuts fall back to the radix select
+        hipLaunchKernelGGL(k_adc_pick_bin, dim3(nqb), dim3(64), 0, stream, hist, topk, sel);
+        hipLaunchKernelGGL(k_adc_collect, dim3(64, nqb), dim3(256), 0, stream, dist_ws, n, bounds, sel, cand_ws, cand_n);
+        hipLaunchKernelGGL(k_adc_sort_out, dim3(nqb), dim3(1024), (size_t)kAdcCand * 8, stream, cand_ws, sel, topk, take_sqrt,
+                           idx_out_dev + (size_t)q0 * topk, dist_out_dev + (size_t)q0 * topk);
+        hipLaunchKernelGGL(k_adc_topk, dim3(nqb), dim3(1024), 0, stream, dist_ws, n, topk, take_sqrt, sel,
+                           idx_out_dev + (size_t)q0 * topk, dist_out_dev + (size_t)q0 * topk);
+        VQ_LAUNCH_CHECK("k_adc_topk");
+    }
+    return VQHIP_OK;
+}
+
+size_t adc_state_bytes() { return (size_t)(2 * kAdcQB + kAdcQB * kAdcBins + 2 * kAdcQB + kAdcQB) * 4; }
+size_t adc_cand_bytes() { return (size_t)kAdcQB * kAdcCand * 8; }
+uint32_t adc_query_batch() { return kAdcQB; }
+
+}  // namespace vqhip

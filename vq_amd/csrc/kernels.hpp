@@ -117,6 +117,15 @@ int launch_gather_rows(const float *X, uint32_t d, uint32_t m, uint32_t k, uint3
 int tsvq_build_device(const float *X, uint64_t n, uint32_t d, uint32_t max_depth, uint32_t cap,
                       float *centroids_out, int32_t *left_out, int32_t *right_out, int32_t *n_nodes_out,
                       hipStream_t stream);
+// asymmetric-distance search over stored codes (k_adc.hip)
+int launch_adc_search(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int metric, const uint8_t *codes, uint64_t n,
+                      const float *queries_dev, uint32_t nq, uint32_t topk, float *lut_ws, float *dist_ws,
+                      void *state_ws, unsigned long long *cand_ws, uint32_t *idx_out_dev, float *dist_out_dev,
+                      hipStream_t stream);
+uint32_t adc_query_batch();
+size_t adc_state_bytes();
+size_t adc_cand_bytes();
+
 // prepared per-node data of the screened squared-L2 / Euclidean descent (k_tsvq_screen.hip)
 struct TsvqScreen {
     const float *w = nullptr;     // [n_int][d]  c_left - c_right of every two-child node

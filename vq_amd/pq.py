@@ -224,6 +224,24 @@ class ProductQuantizer:
             return np.empty((0, self._m), np.uint8)
         return self._enc.encode(X, want_codes=True, want_f16=False)[0]
 
+    def search(self, codes, queries, topk: int = 10):
+        """Asymmetric-distance search: the `topk` rows of `codes` (n, m) uint8
+        nearest to each query under this quantizer's metric, distances from per-subspace tables.
+        Returns (indices uint32 (nq, topk), distances float32 (nq, topk)); ties by lower row."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self._dim:
+            raise DimensionMismatch(self._dim, q.shape[1])
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        if codes.ndim != 2 or codes.shape[1] != self._m:
+            raise DimensionMismatch(self._m, codes.shape[1] if codes.ndim == 2 else codes.size)
+        if not 1 <= topk <= min(codes.shape[0], 1024):
+            raise InvalidParameter("topk", f"must be between 1 and min(n, 1024), got {topk}")
+        if self._distance.name() == "cosine":
+            raise InvalidParameter("distance", "cosine distance is not a sum over subspaces: no ADC form")
+        return self._enc.adc_search(codes, q, int(topk))
+
     def decode(self, codes) -> np.ndarray:
         """(n, m) uint8 -> (n, dim) float32 centroids (un-rounded)"""
         return self._enc.decode(codes)

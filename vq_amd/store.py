@@ -83,6 +83,13 @@ class PQIndex:
         """what `ProductQuantizer::quantize` returned for these rows (f16, RNE; src/pq.rs:192-196)"""
         return self.reconstruct(rows).astype(np.float16)
 
+    def search(self, queries, topk: int = 10):
+        """top-k stored rows per query by asymmetric distance (device path; see ProductQuantizer.search)"""
+        from .pq import ProductQuantizer
+
+        pq = ProductQuantizer.from_codebooks(self.codebooks, self.distance)
+        return pq.search(np.asarray(self.codes), queries, topk)
+
     # -- file -------------------------------------------------------------------------------
     def save(self, path) -> None:
         with open(path, "wb") as f:
