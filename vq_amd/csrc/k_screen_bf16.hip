@@ -704,7 +704,8 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
 }
 
 template <int SD, int NT32>
-__global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_x32(
+// k <= 128 at sub_dim <= 16: the A image is <= 96 registers, two waves fit a SIMD (0.30 vs 0.37 ms at C2 / k=128)
+__global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_assign_screen_bf16_x32(
     const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m,
     const uint32_t *__restrict__ prepA32, const float *__restrict__ prepCn, uint32_t cn_stride,
     const float *__restrict__ meta, const uint32_t *__restrict__ sub_list, uint32_t n_sub,
@@ -1489,7 +1490,8 @@ int launch_one(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) 
 template <int SD, int NT32>
 int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) {
     const uint64_t n_steps = (a.n + 31) / 32;
-    uint64_t want_waves = (uint64_t)num_cus() * kWavesPerBlock;  // one wave per SIMD
+    const uint32_t waves_per_simd = (NT32 <= 4 && SD <= 16) ? 2 : 1;  // small A images leave room for two
+    uint64_t want_waves = (uint64_t)num_cus() * kWavesPerBlock * waves_per_simd;
     const uint64_t max_useful = n_steps * a.n_sub;
     if (want_waves > max_useful) want_waves = max_useful;
     if (want_waves < a.n_sub) want_waves = a.n_sub;
