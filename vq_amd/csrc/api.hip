@@ -467,7 +467,7 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
 extern "C" {
 
 // ------------------------------------------------------------------ library/device ----
-const char *vqhip_backend(void) { return "libvqhip 0.1 (HIP, gfx950 / MI355X: fp32 MFMA screen + exact VALU re-check)"; }
+const char *vqhip_backend(void) { return "libvqhip 0.1 (HIP, gfx950 / MI355X: bf16-split MFMA screen + exact VALU re-check)"; }
 
 const char *vqhip_last_error(void) { return tls().last_error.c_str(); }
 
