@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void k_tsvq_gather_f16(const float *__restrict
 // really stayed in the binade), so the chain is cut into tiles of 512 rows that are summarised
 // IN PARALLEL under a guessed binade (from an f64 prefix of plain tile sums), and a short
 // sequential pass per column then walks the tile summaries with the exact S, checks the guess
-// (exponent of s, S + min >= 2^23, S + max < 2^24) and re-adds a tile row by row whenever the
+// (exponent of s, S + min > 2^23 strictly, S + max < 2^24) and re-adds a tile row by row whenever the
 // check fails (binade crossings, the first tiles, cancellation, NaN/inf).  Every result is the
 // reference's bit pattern; only the schedule differs.
 constexpr uint32_t kFsTile = 512;        // rows per tile
@@ -804,9 +804,15 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
         const bool in_range = fabsf(q) < 16777216.0f;  // else |q| >= 2^24, inf or NaN: cannot stay in the binade
         bad = bad || !in_range;
         const float qq = in_range ? q : 0.0f;
-        const float fl = floorf(qq), fr = qq - fl;
-        const int32_t ai = (int32_t)fl;
-        const int32_t up = fr > 0.5f ? 1 : 0, tie = fr == 0.5f ? 1 : 0;
+        // q = a + f with a = floor(q), 0 <= f < 1, classified EXACTLY: the fraction of |q| is exact in
+        // f32 (it is made of |q|'s own low bits), whereas q - floor(q) is not for -1 < q < 0 (1 + q
+        // needs bits below 2^-24: -0.49999997 would read as a tie).  For q < 0 with fraction ft of |q|:
+        // a = -floor|q| - (ft != 0), f = 1 - ft.
+        const float t = fabsf(qq), at = floorf(t), ft = t - at;
+        const bool neg = qq < 0.0f, frac = ft != 0.0f;
+        const int32_t ai = neg ? -(int32_t)at - (frac ? 1 : 0) : (int32_t)at;
+        const int32_t tie = ft == 0.5f ? 1 : 0;
+        const int32_t up = (neg ? (frac && ft < 0.5f) : (ft > 0.5f)) ? 1 : 0;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int32_t base = dd[p] + ai;
@@ -953,9 +959,12 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
         const int32_t Sin = S + before;
         const int podd = Sin & 1;
         const int32_t lo = podd ? mine.lo1 : mine.lo0, hi = podd ? mine.hi1 : mine.hi0;
+        // every prefix must stay STRICTLY inside the binade on the zero side: a sum that rounds to exactly
+        // +-2^23 on this grid may have had a smaller magnitude, which the finer grid below represents
+        // differently (it may also be exact -- then the tile is merely re-added)
         bool ok = s_normal && (lane < cnt) && ((mine.flag & 1) == 0) && ((int)se - 127 == mine.e);
-        ok = ok && ((S > 0) ? (Sin + lo >= (1 << 23) && Sin + hi <= (1 << 24) - 1)
-                            : (Sin + hi <= -(1 << 23) && Sin + lo >= -((1 << 24) - 1)));
+        ok = ok && ((S > 0) ? (Sin + lo > (1 << 23) && Sin + hi <= (1 << 24) - 1)
+                            : (Sin + hi < -(1 << 23) && Sin + lo >= -((1 << 24) - 1)));
         const uint64_t bad_mask = __ballot(!ok) | (cnt < 64 ? (~0ull << cnt) : 0ull);
         const uint32_t good = bad_mask ? (uint32_t)__builtin_ctzll(bad_mask) : 64u;  // tiles t0 .. t0+good-1 hold
         if (good > 0) {
@@ -997,6 +1006,71 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
         if (MODE == 0) na.centroid[(size_t)node * d + c] = s / (float)len;  // T::from_usize(n)
         else na.var[(size_t)node * d + c] = s;
         if (n_fallback && fallbacks) atomicAdd(n_fallback, fallbacks);
+    }
+}
+
+// debug aid (VQHIP_TSVQ_CHECK=1): per (node, column) walk the tiles one by one, compare the summary-applied
+// sum with the row-by-row sum and report the first disagreement
+template <int MODE>
+__global__ __launch_bounds__(64) void k_fs_check(const float *__restrict__ X, uint32_t d, const uint32_t *__restrict__ perm,
+                                                 const uint32_t *__restrict__ fast_nodes,
+                                                 const uint32_t *__restrict__ tile_base, NodeArrays na,
+                                                 const FsSumm *__restrict__ summ) {
+    const uint32_t node = fast_nodes[blockIdx.x], c = blockIdx.y;
+    if (threadIdx.x != 0) return;
+    const uint32_t a = na.seg_start[node], len = na.seg_len[node];
+    const uint32_t nt = (len + kFsTile - 1) / kFsTile, base = tile_base[blockIdx.x];
+    const float mu = (MODE == 1) ? na.centroid[(size_t)node * d + c] : 0.0f;
+    float s = (MODE == 0) ? 0.0f : -0.0f;
+    for (uint32_t t = 0; t < nt; ++t) {
+        const FsSumm sm = summ[(size_t)(base + t) * d + c];
+        float seq = s;
+        const uint32_t r0 = t * kFsTile, r1 = min(len, r0 + kFsTile);
+        for (uint32_t r = r0; r < r1; ++r) seq = seq + fs_value<MODE>(X[(size_t)perm[a + r] * d + c], mu);
+        const uint32_t sb = __float_as_uint(s), se = (sb >> 23) & 0xFFu;
+        bool ok = ((sm.flag & 1) == 0) && se != 0u && se != 255u && ((int)se - 127 == sm.e);
+        float fast = seq;
+        if (ok) {
+            const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
+            const int32_t S = (sb >> 31) ? -mag : mag;
+            const int odd = S & 1;
+            const int32_t D = odd ? sm.d1 : sm.d0, lo = odd ? sm.lo1 : sm.lo0, hi = odd ? sm.hi1 : sm.hi0;
+            ok = (S > 0) ? (S + lo > (1 << 23) && S + hi <= (1 << 24) - 1) : (S + hi < -(1 << 23) && S + lo >= -((1 << 24) - 1));
+            if (ok) {
+                const int32_t S2 = S + D;
+                const uint32_t m2 = (uint32_t)(S2 < 0 ? -S2 : S2);
+                fast = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2 & 0x7FFFFFu));
+                if (__float_as_uint(fast) != __float_as_uint(seq)) {
+                    printf("[fs_check] mode %d node %u col %u tile %u: s=%.9g (S=%d odd=%d e=%d) summary D=%d lo=%d hi=%d -> %.9g, row by row %.9g\n",
+                           MODE, node, c, t, s, S, odd, sm.e, D, lo, hi, fast, seq);
+                    // find the first element where the transducer deviates
+                    float run = s;
+                    int32_t Sr = S;
+                    const float scale = __uint_as_float((uint32_t)(23 - sm.e + 127) << 23);
+                    for (uint32_t r = r0; r < r1; ++r) {
+                        const float v = fs_value<MODE>(X[(size_t)perm[a + r] * d + c], mu);
+                        run = run + v;
+                        const float q = v * scale;
+                        const float tt = fabsf(q), at = floorf(tt), ft = tt - at;
+                        const bool neg = q < 0.0f, frac = ft != 0.0f;
+                        const int32_t ai = neg ? -(int32_t)at - (frac ? 1 : 0) : (int32_t)at;
+                        const int32_t tie = ft == 0.5f, up = (neg ? (frac && ft < 0.5f) : (ft > 0.5f));
+                        const int32_t bse = Sr + ai;
+                        Sr = bse + (up | (tie & bse));
+                        const uint32_t rb = __float_as_uint(run);
+                        const int32_t rm = (int32_t)((rb & 0x7FFFFFu) | 0x800000u);
+                        const int32_t Rr = (rb >> 31) ? -rm : rm;
+                        if (Rr != Sr || ((rb >> 23) & 0xFFu) != se) {
+                            printf("[fs_check]   first deviation at row %u: v=%.9g q=%.9g ai=%d up=%d tie=%d  transducer S=%d, float S=%d (exp %u vs %u)\n",
+                                   r - r0, v, q, ai, up, tie, Sr, Rr, (rb >> 23) & 0xFFu, se);
+                            break;
+                        }
+                    }
+                    return;
+                }
+            }
+        }
+        s = seq;
     }
 }
 
@@ -1179,6 +1253,11 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
                 hipLaunchKernelGGL(k_fs_chain<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, b_fs_side.as<float>(), b_fs_fb.as<uint32_t>());
             }
             VQ_LAUNCH_CHECK("k_fs_*");
+            if (getenv("VQHIP_TSVQ_CHECK")) {
+                if (mode == 0) hipLaunchKernelGGL(k_fs_check<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm);
+                else hipLaunchKernelGGL(k_fs_check<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm);
+                VQ_HIP(hipStreamSynchronize(stream));
+            }
         }
         return VQHIP_OK;
     };
