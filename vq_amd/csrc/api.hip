@@ -353,12 +353,46 @@ struct vqhip_kmeans {
     }
 };
 
+// Pinned, device-mapped staging for the per-vector latency path (k_small.hip)
+struct PinnedStage {
+    void *host = nullptr, *dev = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return VQHIP_OK;
+        if (host) (void)hipHostFree(host);
+        host = dev = nullptr;
+        bytes = 0;
+        const size_t cap = need < 65536 ? 65536 : need;
+        VQ_HIP(hipHostMalloc(&host, cap, hipHostMallocMapped));
+        VQ_HIP(hipHostGetDevicePointer(&dev, host, 0));
+        bytes = cap;
+        return VQHIP_OK;
+    }
+    ~PinnedStage() {
+        if (host) (void)hipHostFree(host);
+    }
+};
+constexpr uint64_t kSmallRows = 8;  // calls with at most this many host rows take the one-kernel path
+
+// wait for a ~10-40 us kernel by polling: hipStreamSynchronize parks the thread after a short spin and
+// then costs ~100 us to wake up (measured 134 us per TSVQ quantize call against a 14 us kernel)
+static int spin_wait(hipStream_t s) {
+    for (int i = 0; i < 200000; ++i) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return VQHIP_OK;
+        if (e != hipErrorNotReady) return fail(VQHIP_ERR_RUNTIME, "stream query failed: %s", hipGetErrorString(e));
+    }
+    VQ_HIP(hipStreamSynchronize(s));
+    return VQHIP_OK;
+}
+
 struct vqhip_pq_encoder {
     CodebookState cs;
     AssignWorkspace ws;
     int metric = VQHIP_EUCLIDEAN;
     int engine = VQHIP_ENGINE_AUTO;
     DevBuf xbuf, codes, f16buf, f32buf, adc_q, adc_lut, adc_dist, adc_idx, adc_out, adc_codes, adc_state, adc_cand;
+    PinnedStage stage;
     std::vector<uint32_t> all_subs;
 };
 
@@ -366,6 +400,7 @@ struct vqhip_tsvq {
     uint32_t n_nodes = 0, d = 0;
     int metric = VQHIP_EUCLIDEAN;
     DevBuf centroids, cnorm, left, right, xbuf, leafbuf, f16buf, table16;
+    PinnedStage stage;
     // screened descent (squared-L2 / Euclidean, k_tsvq_screen.hip); use_screen = false -> exact walk only
     bool use_screen = false, last_screened = false;
     TsvqScreen scr;
@@ -1030,6 +1065,28 @@ int vqhip_pq_encode(vqhip_pq_encoder *enc, const float *rows, uint64_t n, uint8_
     hipStream_t s;
     VQ_TRY(current_stream(&s));
     const uint32_t m = enc->cs.m, d = enc->cs.m * enc->cs.sd;
+    static const char *no_small = getenv("VQHIP_NO_SMALL_PATH");
+    if (n <= kSmallRows && !(no_small && no_small[0] == '1')) {
+        // per-vector calls (Quantizer::quantize): one kernel over mapped pinned memory, exact arithmetic
+        const size_t in_b = (size_t)n * d * 4, code_b = ((size_t)n * m + 15) & ~(size_t)15, f16_b = (size_t)n * d * 2;
+        VQ_TRY(enc->stage.ensure(in_b + code_b + f16_b));
+        VQ_TRY(enc->cs.prepare(s));  // centroid norms (cosine)
+        char *hb = static_cast<char *>(enc->stage.host), *db = static_cast<char *>(enc->stage.dev);
+        memcpy(hb, rows, in_b);
+        VQ_TRY(launch_pq_encode_small(reinterpret_cast<const float *>(db), (uint32_t)n, d, m, enc->cs.k, enc->cs.sd,
+                                      enc->metric, enc->cs.cb.as<float>(), enc->cs.cnsqrt.as<float>(),
+                                      reinterpret_cast<uint8_t *>(db + in_b),
+                                      f16_out ? reinterpret_cast<uint16_t *>(db + in_b + code_b) : nullptr, s));
+        VQ_TRY(spin_wait(s));
+        if (codes) memcpy(codes, hb + in_b, (size_t)n * m);
+        if (f16_out) memcpy(f16_out, hb + in_b + code_b, f16_b);
+        ThreadState &st = tls();
+        st.last_engine = VQHIP_ENGINE_EXACT;
+        st.last_rechecked = 0;
+        enc->ws.stats_pending = false;
+        enc->ws.last_engine = VQHIP_ENGINE_EXACT;
+        return VQHIP_OK;
+    }
     // bounded staging: at most ~1 GiB of rows per pass
     uint64_t chunk = std::max<uint64_t>(1, (1ull << 30) / ((uint64_t)d * 4));
     if (chunk > n) chunk = n;
@@ -1267,6 +1324,22 @@ int vqhip_tsvq_encode(vqhip_tsvq *t, const float *rows, uint64_t n, int32_t *lea
     hipStream_t s;
     VQ_TRY(current_stream(&s));
     const uint32_t d = t->d;
+    static const char *no_small = getenv("VQHIP_NO_SMALL_PATH");
+    if (n <= kSmallRows && tsvq_small_supported(d) && !(no_small && no_small[0] == '1')) {
+        const size_t in_b = (size_t)n * d * 4, leaf_b = ((size_t)n * 4 + 15) & ~(size_t)15, f16_b = (size_t)n * d * 2;
+        VQ_TRY(t->stage.ensure(in_b + leaf_b + f16_b));
+        char *hb = static_cast<char *>(t->stage.host), *db = static_cast<char *>(t->stage.dev);
+        memcpy(hb, rows, in_b);
+        VQ_TRY(launch_tsvq_encode_small(reinterpret_cast<const float *>(db), (uint32_t)n, d, t->metric,
+                                        t->centroids.as<float>(), t->cnorm.as<float>(), t->left.as<int32_t>(),
+                                        t->right.as<int32_t>(), reinterpret_cast<int32_t *>(db + in_b),
+                                        f16_out ? reinterpret_cast<uint16_t *>(db + in_b + leaf_b) : nullptr, s));
+        VQ_TRY(spin_wait(s));
+        if (leaf) memcpy(leaf, hb + in_b, (size_t)n * 4);
+        if (f16_out) memcpy(f16_out, hb + in_b + leaf_b, f16_b);
+        t->last_screened = false;
+        return VQHIP_OK;
+    }
     uint64_t chunk = std::max<uint64_t>(1, (1ull << 30) / ((uint64_t)d * 4));
     if (chunk > n) chunk = n;
     VQ_TRY(t->xbuf.ensure((size_t)chunk * d * 4));

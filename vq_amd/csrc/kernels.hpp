@@ -117,6 +117,15 @@ int launch_gather_rows(const float *X, uint32_t d, uint32_t m, uint32_t k, uint3
 int tsvq_build_device(const float *X, uint64_t n, uint32_t d, uint32_t max_depth, uint32_t cap,
                       float *centroids_out, int32_t *left_out, int32_t *right_out, int32_t *n_nodes_out,
                       hipStream_t stream);
+// latency path for a handful of rows (k_small.hip): rows / outputs are device-visible pinned host pointers
+int launch_pq_encode_small(const float *rows_dev, uint32_t n, uint32_t d, uint32_t m, uint32_t k, uint32_t sd, int metric,
+                           const float *cb, const float *cnsqrt, uint8_t *codes_dev, uint16_t *f16_dev,
+                           hipStream_t stream);
+bool tsvq_small_supported(uint32_t d);
+int launch_tsvq_encode_small(const float *rows_dev, uint32_t n, uint32_t d, int metric, const float *centroids,
+                             const float *cnorm, const int32_t *left, const int32_t *right, int32_t *leaf_dev,
+                             uint16_t *f16_dev, hipStream_t stream);
+
 // asymmetric-distance search over stored codes (k_adc.hip)
 int launch_adc_search(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int metric, const uint8_t *codes, uint64_t n,
                       const float *queries_dev, uint32_t nq, uint32_t topk, float *lut_ws, float *dist_ws,
