@@ -921,7 +921,7 @@ int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
     mix(reinterpret_cast<uintptr_t>(s));
     if (km->graph_exec && km->graph_key == key) {
         VQ_HIP(hipGraphLaunch(km->graph_exec, s));
-        VQ_HIP(hipStreamSynchronize(s));
+        VQ_TRY(spin_wait(s));
     } else if (km->warm_key == key) {
         km->drop_graph();
         km->cs.prepared = false;  // the codebook images must be part of the captured sequence
@@ -935,7 +935,7 @@ int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
             (void)hipGraphDestroy(graph);
             km->graph_key = key;
             VQ_HIP(hipGraphLaunch(km->graph_exec, s));
-            VQ_HIP(hipStreamSynchronize(s));
+            VQ_TRY(spin_wait(s));
         } else {  // capture is an optimisation only: fall back to the plain sequence for this handle
             if (graph) (void)hipGraphDestroy(graph);
             (void)hipGetLastError();
@@ -944,12 +944,12 @@ int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
             km->cs.prepared = false;
             VQ_TRY(kmeans_accumulate_enqueue(km, s));
             VQ_TRY(kmeans_finalize_enqueue(km, s));
-            VQ_HIP(hipStreamSynchronize(s));
+            VQ_TRY(spin_wait(s));
         }
     } else {
         VQ_TRY(kmeans_accumulate_enqueue(km, s));
         VQ_TRY(kmeans_finalize_enqueue(km, s));
-        VQ_HIP(hipStreamSynchronize(s));
+        VQ_TRY(spin_wait(s));
         km->warm_key = key;
     }
     // host-side state the enqueue functions leave behind (a replay does not run them)
