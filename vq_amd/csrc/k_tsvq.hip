@@ -1175,6 +1175,44 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     std::vector<uint32_t> level = {0};  // global node ids of the current level
     const uint32_t dgroups = (d + DG - 1) / DG;
 
+    // small host -> device uploads (node lists, tile tables) go through one pinned arena so that they are
+    // truly asynchronous: no stream synchronisation just to keep a std::vector alive (9 levels x ~10 of
+    // them were ~1.5 ms of a 13 ms build); an upload that does not fit falls back to copy + synchronise
+    struct PinnedArena {
+        char *base = nullptr;
+        size_t cap = 0, off = 0;
+        ~PinnedArena() {
+            if (base) (void)hipHostFree(base);
+        }
+    } arena;
+    {
+        void *pz = nullptr;
+        if (hipHostMalloc(&pz, 8u << 20, hipHostMallocDefault) == hipSuccess) {
+            arena.base = static_cast<char *>(pz);
+            arena.cap = 8u << 20;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    bool upload_needs_sync = false;
+    auto upload = [&](void *dst, const void *src, size_t bytes) -> int {
+        const size_t at = (arena.off + 15) & ~(size_t)15;
+        if (arena.base && at + bytes <= arena.cap) {
+            memcpy(arena.base + at, src, bytes);
+            arena.off = at + bytes;
+            VQ_HIP(hipMemcpyAsync(dst, arena.base + at, bytes, hipMemcpyHostToDevice, stream));
+        } else {
+            VQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+            upload_needs_sync = true;
+        }
+        return VQHIP_OK;
+    };
+    auto upload_fence = [&]() -> int {  // call before the source vectors of a fallback upload die
+        if (upload_needs_sync) VQ_HIP(hipStreamSynchronize(stream));
+        upload_needs_sync = false;
+        return VQHIP_OK;
+    };
+
     // sequential-order column sums of a set of nodes: long nodes through the tile-parallel exact
     // emulation (k_fs_*), the rest through the plain chain kernel
     DevBuf b_fs_tiles, b_fs_nodes, b_fs_base, b_fs_nt, b_fs_sum, b_fs_summ, b_lvl_slow, b_fs_fb, b_fs_side;
@@ -1208,7 +1246,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         }
         if (!slow.empty()) {
             VQ_TRY(b_lvl_slow.ensure(slow.size() * 4));
-            VQ_HIP(hipMemcpyAsync(b_lvl_slow.p, slow.data(), slow.size() * 4, hipMemcpyHostToDevice, stream));
+            VQ_TRY(upload(b_lvl_slow.p, slow.data(), slow.size() * 4));
         }
         if (!fast.empty()) {
             VQ_TRY(b_fs_tiles.ensure(tiles.size() * sizeof(FsTile)));
@@ -1219,12 +1257,12 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             VQ_TRY(b_fs_summ.ensure(tiles.size() * (size_t)d * sizeof(FsSumm)));
             VQ_TRY(b_fs_side.ensure((size_t)side_cap * kFsTile * 4));
             VQ_HIP(hipMemsetAsync(b_fs_fb.as<uint32_t>() + 1, 0, 4, stream));
-            VQ_HIP(hipMemcpyAsync(b_fs_tiles.p, tiles.data(), tiles.size() * sizeof(FsTile), hipMemcpyHostToDevice, stream));
-            VQ_HIP(hipMemcpyAsync(b_fs_nodes.p, fast.data(), fast.size() * 4, hipMemcpyHostToDevice, stream));
-            VQ_HIP(hipMemcpyAsync(b_fs_base.p, tbase.data(), fast.size() * 4, hipMemcpyHostToDevice, stream));
-            VQ_HIP(hipMemcpyAsync(b_fs_nt.p, tcount.data(), fast.size() * 4, hipMemcpyHostToDevice, stream));
+            VQ_TRY(upload(b_fs_tiles.p, tiles.data(), tiles.size() * sizeof(FsTile)));
+            VQ_TRY(upload(b_fs_nodes.p, fast.data(), fast.size() * 4));
+            VQ_TRY(upload(b_fs_base.p, tbase.data(), fast.size() * 4));
+            VQ_TRY(upload(b_fs_nt.p, tcount.data(), fast.size() * 4));
         }
-        VQ_HIP(hipStreamSynchronize(stream));  // the host vectors above go out of scope
+        VQ_TRY(upload_fence());  // the host vectors above go out of scope
         if (!slow.empty()) {
             if (mode == 0)
                 hipLaunchKernelGGL(k_seg_colsum<0>, dim3((uint32_t)slow.size(), dgroups), dim3(1024), 0, stream, X, d, perm,
@@ -1274,10 +1312,10 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             }
             // nodes of a level are created consecutively -> contiguous id range
             const uint32_t first = level[0];
-            VQ_HIP(hipMemcpyAsync(na.seg_start + first, st.data(), (size_t)n_lvl * 4, hipMemcpyHostToDevice, stream));
-            VQ_HIP(hipMemcpyAsync(na.seg_len + first, ln.data(), (size_t)n_lvl * 4, hipMemcpyHostToDevice, stream));
-            VQ_HIP(hipMemcpyAsync(b_lvl.p, level.data(), (size_t)n_lvl * 4, hipMemcpyHostToDevice, stream));
-            VQ_HIP(hipStreamSynchronize(stream));  // host vectors go out of scope
+            VQ_TRY(upload(na.seg_start + first, st.data(), (size_t)n_lvl * 4));
+            VQ_TRY(upload(na.seg_len + first, ln.data(), (size_t)n_lvl * 4));
+            VQ_TRY(upload(b_lvl.p, level.data(), (size_t)n_lvl * 4));
+            VQ_TRY(upload_fence());  // host vectors go out of scope
         }
         const uint32_t *lvl = b_lvl.as<uint32_t>();
         uint32_t *perm = b_perm[cur].as<uint32_t>(), *node_of = b_nodeof[cur].as<uint32_t>();
@@ -1310,8 +1348,8 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
                     VQ_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(node_of + hn.start), (int)newidx[li], hn.len, stream));
                 }
             }
-            VQ_HIP(hipMemcpyAsync(b_lvl.p, split_nodes.data(), (size_t)n_split * 4, hipMemcpyHostToDevice, stream));
-            VQ_HIP(hipStreamSynchronize(stream));
+            VQ_TRY(upload(b_lvl.p, split_nodes.data(), (size_t)n_split * 4));
+            VQ_TRY(upload_fence());
         }
         // variances + split dimension (tsvq.rs:46-66)
         VQ_TRY(colsum(1, split_nodes, perm));
@@ -1386,14 +1424,13 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         if (nodes.size() > dcap) return fail(VQHIP_ERR_FAILURE, "TSVQ node count exceeded its bound");
         {
             const uint32_t first = split_nodes.front(), last = split_nodes.back();
-            VQ_HIP(hipMemcpyAsync(na.child_local + 2 * first, child_local.data() + 2 * first,
-                                  (size_t)(last - first + 1) * 8, hipMemcpyHostToDevice, stream));
+            VQ_TRY(upload(na.child_local + 2 * first, child_local.data() + 2 * first, (size_t)(last - first + 1) * 8));
         }
         hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, n, perm, node_of, lvl, na,
                            b_scan.as<uint32_t>(), b_flags.as<uint32_t>(), b_perm[cur ^ 1].as<uint32_t>(),
                            b_nodeof[cur ^ 1].as<uint32_t>());
         VQ_LAUNCH_CHECK("k_scatter");
-        VQ_HIP(hipStreamSynchronize(stream));  // child_local host vector
+        VQ_TRY(upload_fence());  // child_local host vector
         cur ^= 1;
         level.swap(next);
     }
