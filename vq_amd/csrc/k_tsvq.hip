@@ -1116,6 +1116,33 @@ int launch_tsvq_gather_table(const uint16_t *table, uint32_t d, const int32_t *l
 }
 
 // ---- host driver of the build ------------------------------------------------------------
+// Device / pinned scratch of a build, kept per host thread between builds (28 buffers: their hipMalloc /
+// hipHostMalloc calls were 2-3 ms of a 13 ms build); dropped when it exceeds 1 GiB or the device changes.
+struct TsvqBuildWs {
+    int device = -1;
+    DevBuf b_perm[2], b_nodeof[2], b_vals, b_flags, b_scan, b_bsums, b_hist, b_lvl;
+    DevBuf b_seg_start, b_seg_len, b_split, b_nv, b_nleft, b_median, b_selp, b_selr, b_child, b_cent, b_var;
+    DevBuf b_fs_tiles, b_fs_nodes, b_fs_base, b_fs_nt, b_fs_sum, b_fs_summ, b_lvl_slow, b_fs_fb, b_fs_side;
+    char *arena_base = nullptr;
+    size_t arena_cap = 0;
+    DevBuf *all[30] = {&b_perm[0], &b_perm[1], &b_nodeof[0], &b_nodeof[1], &b_vals, &b_flags, &b_scan, &b_bsums, &b_hist,
+                       &b_lvl, &b_seg_start, &b_seg_len, &b_split, &b_nv, &b_nleft, &b_median, &b_selp, &b_selr, &b_child,
+                       &b_cent, &b_var, &b_fs_tiles, &b_fs_nodes, &b_fs_base, &b_fs_nt, &b_fs_sum, &b_fs_summ, &b_lvl_slow,
+                       &b_fs_fb, &b_fs_side};
+    size_t total() const {
+        size_t t = 0;
+        for (const DevBuf *b : all) t += b->bytes;
+        return t;
+    }
+    void release() {
+        for (DevBuf *b : all) b->release();
+        if (arena_base) (void)hipHostFree(arena_base);
+        arena_base = nullptr;
+        arena_cap = 0;
+    }
+    ~TsvqBuildWs() { release(); }
+};
+
 int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_depth, uint32_t cap,
                       float *centroids_out, int32_t *left_out, int32_t *right_out, int32_t *n_nodes_out,
                       hipStream_t stream) {
@@ -1133,28 +1160,46 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         return fail(VQHIP_ERR_INVALID_INPUT, "node capacity %u < required %llu", cap, (unsigned long long)need_cap);
     const uint32_t dcap = (uint32_t)need_cap;
 
-    DevBuf b_perm[2], b_nodeof[2], b_vals, b_flags, b_scan, b_bsums, b_hist, b_lvl;
-    DevBuf b_seg_start, b_seg_len, b_split, b_nv, b_nleft, b_median, b_selp, b_selr, b_child, b_cent, b_var;
-    for (int q = 0; q < 2; ++q) {
-        VQ_TRY(b_perm[q].alloc((size_t)n * 4));
-        VQ_TRY(b_nodeof[q].alloc((size_t)n * 4));
+    static thread_local TsvqBuildWs ws;
+    {
+        int dev = 0;
+        VQ_HIP(hipGetDevice(&dev));
+        if (ws.device != dev) ws.release();
+        ws.device = dev;
     }
-    VQ_TRY(b_vals.alloc((size_t)n * 4));
-    VQ_TRY(b_flags.alloc((size_t)n * 4));
-    VQ_TRY(b_scan.alloc((size_t)n * 4));
+    struct WsTrim {  // keep the scratch for the next build unless it is large
+        TsvqBuildWs &w;
+        ~WsTrim() {
+            if (w.total() > (1ull << 30)) w.release();
+        }
+    } ws_trim{ws};
+    DevBuf(&b_perm)[2] = ws.b_perm;
+    DevBuf(&b_nodeof)[2] = ws.b_nodeof;
+    DevBuf &b_vals = ws.b_vals, &b_flags = ws.b_flags, &b_scan = ws.b_scan, &b_bsums = ws.b_bsums, &b_hist = ws.b_hist,
+           &b_lvl = ws.b_lvl;
+    DevBuf &b_seg_start = ws.b_seg_start, &b_seg_len = ws.b_seg_len, &b_split = ws.b_split, &b_nv = ws.b_nv,
+           &b_nleft = ws.b_nleft, &b_median = ws.b_median, &b_selp = ws.b_selp, &b_selr = ws.b_selr, &b_child = ws.b_child,
+           &b_cent = ws.b_cent, &b_var = ws.b_var;
+    for (int q = 0; q < 2; ++q) {
+        VQ_TRY(b_perm[q].ensure((size_t)n * 4));
+        VQ_TRY(b_nodeof[q].ensure((size_t)n * 4));
+    }
+    VQ_TRY(b_vals.ensure((size_t)n * 4));
+    VQ_TRY(b_flags.ensure((size_t)n * 4));
+    VQ_TRY(b_scan.ensure((size_t)n * 4));
     const uint32_t nblk = (n + 1023) / 1024;
-    VQ_TRY(b_bsums.alloc((size_t)nblk * 4));
-    VQ_TRY(b_seg_start.alloc((size_t)dcap * 4));
-    VQ_TRY(b_seg_len.alloc((size_t)dcap * 4));
-    VQ_TRY(b_split.alloc((size_t)dcap * 4));
-    VQ_TRY(b_nv.alloc((size_t)dcap * 4));
-    VQ_TRY(b_nleft.alloc((size_t)dcap * 4));
-    VQ_TRY(b_median.alloc((size_t)dcap * 4));
-    VQ_TRY(b_selp.alloc((size_t)dcap * 8));
-    VQ_TRY(b_selr.alloc((size_t)dcap * 8));
-    VQ_TRY(b_child.alloc((size_t)dcap * 8));
-    VQ_TRY(b_cent.alloc((size_t)dcap * d * 4));
-    VQ_TRY(b_var.alloc((size_t)dcap * d * 4));
+    VQ_TRY(b_bsums.ensure((size_t)nblk * 4));
+    VQ_TRY(b_seg_start.ensure((size_t)dcap * 4));
+    VQ_TRY(b_seg_len.ensure((size_t)dcap * 4));
+    VQ_TRY(b_split.ensure((size_t)dcap * 4));
+    VQ_TRY(b_nv.ensure((size_t)dcap * 4));
+    VQ_TRY(b_nleft.ensure((size_t)dcap * 4));
+    VQ_TRY(b_median.ensure((size_t)dcap * 4));
+    VQ_TRY(b_selp.ensure((size_t)dcap * 8));
+    VQ_TRY(b_selr.ensure((size_t)dcap * 8));
+    VQ_TRY(b_child.ensure((size_t)dcap * 8));
+    VQ_TRY(b_cent.ensure((size_t)dcap * d * 4));
+    VQ_TRY(b_var.ensure((size_t)dcap * d * 4));
     NodeArrays na;
     na.seg_start = b_seg_start.as<uint32_t>();
     na.seg_len = b_seg_len.as<uint32_t>();
@@ -1181,19 +1226,18 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     struct PinnedArena {
         char *base = nullptr;
         size_t cap = 0, off = 0;
-        ~PinnedArena() {
-            if (base) (void)hipHostFree(base);
-        }
     } arena;
-    {
+    if (!ws.arena_base) {
         void *pz = nullptr;
         if (hipHostMalloc(&pz, 8u << 20, hipHostMallocDefault) == hipSuccess) {
-            arena.base = static_cast<char *>(pz);
-            arena.cap = 8u << 20;
+            ws.arena_base = static_cast<char *>(pz);
+            ws.arena_cap = 8u << 20;
         } else {
             (void)hipGetLastError();
         }
     }
+    arena.base = ws.arena_base;
+    arena.cap = ws.arena_cap;
     bool upload_needs_sync = false;
     auto upload = [&](void *dst, const void *src, size_t bytes) -> int {
         const size_t at = (arena.off + 15) & ~(size_t)15;
@@ -1215,8 +1259,10 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
 
     // sequential-order column sums of a set of nodes: long nodes through the tile-parallel exact
     // emulation (k_fs_*), the rest through the plain chain kernel
-    DevBuf b_fs_tiles, b_fs_nodes, b_fs_base, b_fs_nt, b_fs_sum, b_fs_summ, b_lvl_slow, b_fs_fb, b_fs_side;
-    VQ_TRY(b_fs_fb.alloc(8));  // [0] tile re-additions (diagnostic), [1] side-buffer slots handed out
+    DevBuf &b_fs_tiles = ws.b_fs_tiles, &b_fs_nodes = ws.b_fs_nodes, &b_fs_base = ws.b_fs_base, &b_fs_nt = ws.b_fs_nt,
+           &b_fs_sum = ws.b_fs_sum, &b_fs_summ = ws.b_fs_summ, &b_lvl_slow = ws.b_lvl_slow, &b_fs_fb = ws.b_fs_fb,
+           &b_fs_side = ws.b_fs_side;
+    VQ_TRY(b_fs_fb.ensure(8));  // [0] tile re-additions (diagnostic), [1] side-buffer slots handed out
     VQ_HIP(hipMemsetAsync(b_fs_fb.p, 0, 8, stream));
     static const char *nopark = getenv("VQHIP_TSVQ_NOPARK");
     const uint32_t side_cap = (nopark && nopark[0] == '1') ? 0u : 32768u;  // parked tiles per call (64 MB); beyond it the re-addition gathers
@@ -1361,7 +1407,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         VQ_LAUNCH_CHECK("k_gather_vals");
         hipLaunchKernelGGL(k_select_init, dim3((n_split + 63) / 64), dim3(64), 0, stream, lvl, n_split, na);
         VQ_LAUNCH_CHECK("k_select_init");
-        VQ_TRY(b_hist.ensure((size_t)n_split * 2 * 256 * 4));
+        VQ_TRY(b_hist.ensure((size_t)std::min<uint64_t>(dcap, n) * 2 * 256 * 4));  // once, for the widest level
         VQ_HIP(hipMemsetAsync(b_hist.p, 0, (size_t)n_split * 2 * 256 * 4, stream));
         for (int shift = 24; shift >= 0; shift -= 8) {
             const uint32_t hblocks = std::min<uint32_t>((n + 2047) / 2048, (uint32_t)num_cus() * 4);
