@@ -71,6 +71,19 @@ def cpu_baseline(m, k, dim, codebooks, target_seconds=12.0):
         out["generous_note"] = f"-O3 -march=native build, {nt} threads over rows"
     except Exception as e:  # the native build is best effort (needs gcc on the bench host)
         out["generous_note"] = f"native build unavailable: {e}"
+    # k-means iteration, faithful threading (SURVEY.md 8(d) variant A): assignment over all host cores
+    # like rayon's par_iter (src/core/vector.rs:417-423), update serial, subspaces one after the other
+    # (src/pq.rs:121), on a bounded sample of the same matrix; a Lloyd iteration is linear in the rows
+    nk = min(100_000, n)
+    Xk = X[:nk]
+    sd = dim // m
+    t0 = time.perf_counter()
+    for s_ in range(m):
+        orc.lloyd_step(Xk[:, s_ * sd:(s_ + 1) * sd], codebooks[s_], threads=nt)
+    dtk = time.perf_counter() - t0
+    out["kmeans"] = {"rows": nk, "ms_per_iter": dtk * 1e3, "threads": nt,
+                     "iter_per_s_extrapolated_to_workload_rows": 1.0 / (dtk * N_PER_GPU / nk),
+                     "note": "one Lloyd iteration over all m subspaces on the sample, assign parallel / update serial"}
     return out
 
 
