@@ -7,12 +7,15 @@ import pytest
 import oracle as O
 from vq_amd import TSVQ, Distance, _lib
 
+import os
+
 pytestmark = pytest.mark.gpu
 F = np.float32
+SCALE = int(os.environ.get("VQ_FUZZ_SCALE", "1"))
 NAMES = ["squared_euclidean", "euclidean", "manhattan", "cosine"]
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_small_pq_encode_matches_oracle_and_batch_path(oracle, seed):
     rng = np.random.default_rng(4000 + seed)
     sd = int(rng.choice([1, 3, 8, 16, 24, 40, 100]))
@@ -43,7 +46,7 @@ def test_small_pq_encode_matches_oracle_and_batch_path(oracle, seed):
     enc.close()
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_small_tsvq_encode_matches_oracle(oracle, seed):
     rng = np.random.default_rng(5000 + seed)
     d = int(rng.choice([1, 5, 24, 64, 128, 130, 300]))
