@@ -89,6 +89,7 @@ struct CodebookState {
     int metric = VQHIP_SQUARED_EUCLIDEAN;  // what the prepared images are for (cosine differs)
     DevBuf cb, prepA, prepCn, meta, cnsqrt, prepA16, prepA32, cbc, cen, cn32;
     bool x32_ok = false;
+    uint32_t x32_groups = 0;  // > 1: centroid groups (sub_dim 32 / 48), partial verdicts merged per row
 
     int init(uint32_t m_, uint32_t k_, uint32_t sd_) {
         m = m_;
@@ -114,11 +115,15 @@ struct CodebookState {
         }
         bf16_ok = bf16_16 || x32_ok;
         if (bf16_16) VQ_TRY(prepA16.alloc((size_t)m * nt * screen_bf16_mfmas(sd) * 4 * 64 * 4));
+        x32_groups = 0;
         if (x32_ok) {
-            VQ_TRY(prepA32.alloc((size_t)m * ((k + 31) / 32) * screen_bf16_x32_mfmas(sd) * 4 * 64 * 4));
+            uint32_t per = 0;
+            screen_bf16_x32_tiling(sd, k, &per, &x32_groups);
+            const size_t tiles = (size_t)per * x32_groups;  // image padded to whole centroid groups
+            VQ_TRY(prepA32.alloc((size_t)m * tiles * screen_bf16_x32_mfmas(sd) * 4 * 64 * 4));
             VQ_TRY(cbc.alloc((size_t)m * k * sd * 4));
             VQ_TRY(cen.alloc((size_t)m * (sd + 4) * 4));
-            VQ_TRY(cn32.alloc((size_t)m * ((k + 31) / 32) * 32 * 4));
+            VQ_TRY(cn32.alloc((size_t)m * tiles * 32 * 4));
         }
         prepared = false;
         return VQHIP_OK;
@@ -159,7 +164,7 @@ struct CodebookState {
 
 // --------------------------------------------------------------- assign workspace ----
 struct AssignWorkspace {
-    DevBuf wl_rows, wl_count, sub_list, wl_seg;
+    DevBuf wl_rows, wl_count, sub_list, wl_seg, part;
     static constexpr uint32_t kSegCap = 4096;  // wave-private work-list segments per subspace
     uint32_t *seg_host = nullptr;               // pinned [m][kSegCap][2]
     uint32_t last_n_seg = 0;
@@ -218,8 +223,8 @@ static thread_local ProfileState g_prof;
 static int pick_engine(int requested, const CodebookState &cs, int metric, int *engine) {
     const bool l2_metric = (metric == VQHIP_SQUARED_EUCLIDEAN || metric == VQHIP_EUCLIDEAN);
     // cosine has a screen too (s = -x.c/|c| on the X32 bf16 engine); Manhattan has no contraction form
-    const bool cos_ok = (metric == VQHIP_COSINE) && cs.x32_ok && screen_bf16_uses_x32(cs.sd, cs.k) &&
-                        cs.metric == VQHIP_COSINE;
+    const bool cos_ok = (metric == VQHIP_COSINE) && cs.x32_ok && cs.x32_groups == 1 &&
+                        screen_bf16_uses_x32(cs.sd, cs.k) && cs.metric == VQHIP_COSINE;
     if (requested == VQHIP_ENGINE_EXACT) {
         *engine = VQHIP_ENGINE_EXACT;
     } else if (requested == VQHIP_ENGINE_MFMA) {
@@ -270,6 +275,10 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
     a.wl_seg = ws.wl_seg.as<uint32_t>();
     a.wl_seg_cap = AssignWorkspace::kSegCap;
     a.n_seg = 0;
+    if (engine == VQHIP_ENGINE_MFMA_BF16 && cs.x32_groups > 1 && screen_bf16_uses_x32(cs.sd, cs.k)) {
+        VQ_TRY(ws.part.ensure((size_t)cs.m * cs.x32_groups * n * 16));
+        a.part = ws.part.p;
+    }
     CodebookView v = cs.view();
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (g_prof.on) {

@@ -703,14 +703,20 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
     }
 }
 
-template <int SD, int NT32>
+// G > 1 ("centroid groups", sub_dim 32 / 48 at k up to 256): the A image of all k centroids does not
+// fit the register file, so G waves share a (row chunk, subspace), each holding NT32 tiles = one group
+// of centroids; a wave then stops after merging its two lane halves and writes {min, second min,
+// argmin, |x - mu|^2} per row to `part`; k_merge_partials_x32 merges the groups, applies the margin
+// test and feeds the (unsegmented) re-check list.  G = 1 is the single-pass kernel.
+template <int SD, int NT32, int G = 1>
 // k <= 128 at sub_dim <= 16: the A image is <= 96 registers, two waves fit a SIMD (0.30 vs 0.37 ms at C2 / k=128)
 __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_assign_screen_bf16_x32(
     const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m,
     const uint32_t *__restrict__ prepA32, const float *__restrict__ prepCn, uint32_t cn_stride,
     const float *__restrict__ meta, const uint32_t *__restrict__ sub_list, uint32_t n_sub,
     uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_seg,
-    uint32_t n_seg, uint64_t wl_stride, int cosine, uint32_t k_real, const float *__restrict__ cen) {
+    uint32_t n_seg, uint64_t wl_stride, int cosine, uint32_t k_real, const float *__restrict__ cen,
+    uint4 *__restrict__ part) {
     constexpr int DPH = SD / 2;            // dims owned by a lane half
     constexpr int NMF = (6 * DPH + 7) / 8;  // MFMAs per 32x32 tile: 6 term pairs x DPH dims per lane half
     const uint32_t lane = threadIdx.x & 63;
@@ -718,10 +724,13 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;
     const uint32_t total_waves = gridDim.x * kWavesPerBlock;
-    const uint32_t n_chunks = total_waves / n_sub;
-    if (gw >= n_chunks * n_sub) return;
-    const uint32_t s = sub_list[gw % n_sub];
-    const uint32_t chunk = gw / n_sub;
+    const uint32_t n_virt = n_sub * G;  // (subspace, centroid group) pairs
+    const uint32_t n_chunks = total_waves / n_virt;
+    if (gw >= n_chunks * n_virt) return;
+    const uint32_t vv = gw % n_virt;
+    const uint32_t s = sub_list[vv / G];
+    const uint32_t grp = vv % G;
+    const uint32_t chunk = gw / n_virt;
     const uint64_t n_steps = (n + 31) / 32;
     const uint64_t steps_per_chunk = (n_steps + n_chunks - 1) / n_chunks;
     const uint64_t st0 = (uint64_t)chunk * steps_per_chunk;
@@ -737,7 +746,7 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
     __shared__ __attribute__((aligned(16))) float lds_cn[kWavesPerBlock][NT32 * 32];
     bf16x8 a[NT32][NMF];
     {
-        const uint32_t *base = prepA32 + (size_t)s * NT32 * NMF * 4 * 64 + lane;
+        const uint32_t *base = prepA32 + ((size_t)s * (NT32 * G) + (size_t)grp * NT32) * NMF * 4 * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NT32; ++i)
 #pragma unroll
@@ -747,11 +756,12 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
                 for (int w = 0; w < 4; ++w) v[w] = base[((i * NMF + f) * 4 + w) * 64];
                 a[i][f] = __builtin_bit_cast(bf16x8, v);
             }
-        const float *pc = prepCn + (size_t)s * cn_stride;  // padded with +inf up to cn_stride >= NT32*32
+        const uint32_t c_first = grp * NT32 * 32;           // first centroid of this wave's group
+        const float *pc = prepCn + (size_t)s * cn_stride + c_first;  // padded up to cn_stride >= G*NT32*32
         // padding (and +inf norms) as a large FINITE value: a packed +inf would turn into a NaN
         for (uint32_t e = lane; e < NT32 * 32; e += 64) {
-            float v = (e < cn_stride) ? pc[e] : 3.0e38f;
-            if (cosine) v = (e < k_real) ? 0.0f : 3.0e38f;  // s_j = -x.c_j/|c_j| has no norm term
+            float v = (c_first + e < cn_stride) ? pc[e] : 3.0e38f;
+            if (cosine) v = (c_first + e < k_real) ? 0.0f : 3.0e38f;  // s_j = -x.c_j/|c_j| has no norm term
             lds_cn[wave][e] = (v < 3.0e38f) ? v : 3.0e38f;
         }
     }
@@ -948,7 +958,7 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
         merge2(q1[2], q2[2], vi[2], q1[3], q2[3], vi[3], w1, w2, wi);
         merge2(u1, u2, ui, w1, w2, wi, m1, m2, vidx);
         // value index -> centroid: tile = vidx>>4, r = vidx&15: 32*tile + (r&3) + 8*(r>>2) + 4*h
-        uint32_t j = ((vidx >> 4) << 5) + (vidx & 3u) + (((vidx >> 2) & 3u) << 3) + 4 * h;
+        uint32_t j = ((vidx >> 4) << 5) + (vidx & 3u) + (((vidx >> 2) & 3u) << 3) + 4 * h + grp * NT32 * 32;
         {
             const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m1), __float_as_uint(m1), false, false);
             const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m2), __float_as_uint(m2), false, false);
@@ -963,6 +973,13 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
             const bool take = (b1 < a1) || (b1 == a1 && rj[1] < rj[0]);
             j = take ? rj[1] : rj[0];
             m1 = take ? b1 : a1;
+        }
+        if constexpr (G > 1) {  // this group's verdict per row; the margin test happens after the groups are merged
+            const uint64_t prow = st * 32 + p;
+            if (h == 0 && prow < n)
+                part[((size_t)s * G + grp) * n + prow] =
+                    make_uint4(__float_as_uint(m1), __float_as_uint(m2), j, __float_as_uint(xs));
+            continue;
         }
         // squared-L2 / Euclid: T = coef * (|x| + max|c|)^2.  Cosine: s = -|x| cos, T = coef * |x|, and the
         // row is also re-checked when the best cosine is not clearly positive (all distances may
@@ -987,10 +1004,57 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
             seg_count += (uint32_t)__popcll(mask);
         }
     }
-    if (lane == 0) {
+    if (G == 1 && lane == 0) {
         uint32_t *sg = wl_seg + ((size_t)s * n_seg + chunk) * 2;
         sg[0] = seg_first;
         sg[1] = seg_count;
+    }
+}
+
+// merges the G group verdicts of every (row, subspace), applies the margin test of the single-pass
+// kernel and either writes the code or appends the row to the subspace's re-check list
+template <int G>
+__global__ __launch_bounds__(256) void k_merge_partials_x32(const uint4 *__restrict__ part, uint64_t n, uint32_t m,
+                                                            uint32_t sd, const uint32_t *__restrict__ sub_list,
+                                                            const float *__restrict__ cen, uint8_t *__restrict__ codes,
+                                                            uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_count,
+                                                            uint64_t wl_stride) {
+    const uint32_t s = sub_list[blockIdx.y];
+    const float *cs = cen + (size_t)s * (sd + 4);
+    const float cmax = cs[sd], tcoef = cs[sd + 1];
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint64_t row0 = (uint64_t)blockIdx.x * 256; row0 < n; row0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t row = row0 + threadIdx.x;
+        bool recheck = false;
+        if (row < n) {
+            const uint4 p0 = part[((size_t)s * G) * n + row];
+            float m1 = __uint_as_float(p0.x), m2 = __uint_as_float(p0.y);
+            uint32_t j = p0.z;
+            const float xs = __uint_as_float(p0.w);
+#pragma unroll
+            for (int g = 1; g < G; ++g) {
+                const uint4 pg = part[((size_t)s * G + g) * n + row];
+                const float b1 = __uint_as_float(pg.x), b2 = __uint_as_float(pg.y);
+                const float hi = fmaxf(m1, b1), lo2 = fminf(m2, b2);
+                const bool take = (b1 < m1) || (b1 == m1 && pg.z < j);
+                m2 = fminf(hi, lo2);
+                j = take ? pg.z : j;
+                m1 = take ? b1 : m1;
+            }
+            const float xnorm = __builtin_sqrtf(xs) * 1.000001f;
+            const float xn = xnorm + cmax;
+            const float T = tcoef * (xn * xn) + 1e-35f * xn + 1e-37f;
+            const bool proven = (m2 - m1 > T) && (fabsf(m1) <= 3.0e38f) && (T <= 3.0e38f);
+            codes[row * m + s] = (uint8_t)j;
+            recheck = !proven;
+        }
+        const unsigned long long mask = __ballot(recheck);
+        if (mask != 0ull) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&wl_count[s], (uint32_t)__popcll(mask));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (recheck) wl_rows[(size_t)s * wl_stride + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)row;
+        }
     }
 }
 
@@ -1487,25 +1551,40 @@ int launch_one(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) 
     return VQHIP_OK;
 }
 
-template <int SD, int NT32>
+template <int SD, int NT32, int G = 1>
 int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) {
     const uint64_t n_steps = (a.n + 31) / 32;
     const uint32_t waves_per_simd = (NT32 <= 4 && SD <= 16) ? 2 : 1;  // small A images leave room for two
+    const uint32_t n_virt = a.n_sub * G;
     uint64_t want_waves = (uint64_t)num_cus() * kWavesPerBlock * waves_per_simd;
-    const uint64_t max_useful = n_steps * a.n_sub;
+    const uint64_t max_useful = n_steps * n_virt;
     if (want_waves > max_useful) want_waves = max_useful;
-    if (want_waves < a.n_sub) want_waves = a.n_sub;
+    if (want_waves < n_virt) want_waves = n_virt;
     uint32_t blocks = (uint32_t)((want_waves + kWavesPerBlock - 1) / kWavesPerBlock);
-    while ((uint64_t)blocks * kWavesPerBlock < a.n_sub) ++blocks;
-    const uint32_t n_chunks = (blocks * kWavesPerBlock) / a.n_sub;
-    if (!a.wl_seg || n_chunks > a.wl_seg_cap)
-        return fail(VQHIP_ERR_FAILURE, "segmented work list missing or too small (%u > %u)", n_chunks, a.wl_seg_cap);
-    VQ_HIP(hipMemsetAsync(a.wl_seg, 0, (size_t)cb.m * n_chunks * 8, stream));
-    a.n_seg = n_chunks;
-    hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d,
-                       cb.m, cb.prepA32, cb.cn32, NT32 * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
-                       a.wl_seg, n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen);
+    while ((uint64_t)blocks * kWavesPerBlock < n_virt) ++blocks;
+    const uint32_t n_chunks = (blocks * kWavesPerBlock) / n_virt;
+    if (G == 1) {
+        if (!a.wl_seg || n_chunks > a.wl_seg_cap)
+            return fail(VQHIP_ERR_FAILURE, "segmented work list missing or too small (%u > %u)", n_chunks, a.wl_seg_cap);
+        VQ_HIP(hipMemsetAsync(a.wl_seg, 0, (size_t)cb.m * n_chunks * 8, stream));
+        a.n_seg = n_chunks;
+    } else {
+        if (!a.part) return fail(VQHIP_ERR_FAILURE, "grouped screen without a partial-result buffer");
+        a.n_seg = 0;  // the merge kernel appends to the unsegmented list
+    }
+    hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32, G>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d,
+                       cb.m, cb.prepA32, cb.cn32, NT32 * G * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
+                       a.wl_seg, n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen,
+                       reinterpret_cast<uint4 *>(a.part));
     VQ_LAUNCH_CHECK("k_assign_screen_bf16_x32");
+    if (G > 1) {
+        uint64_t mblocks = (a.n + 255) / 256;
+        if (mblocks > (uint64_t)num_cus() * 8) mblocks = (uint64_t)num_cus() * 8;
+        hipLaunchKernelGGL((k_merge_partials_x32<G>), dim3((uint32_t)mblocks, a.n_sub), dim3(256), 0, stream,
+                           reinterpret_cast<const uint4 *>(a.part), a.n, cb.m, cb.sd, a.sub_list, cb.cen, a.codes,
+                           a.wl_rows, a.wl_count, a.wl_stride);
+        VQ_LAUNCH_CHECK("k_merge_partials_x32");
+    }
     return VQHIP_OK;
 }
 
@@ -1517,10 +1596,27 @@ bool screen_bf16_uses_x32(uint32_t sd, uint32_t k) {
     return (!variant || variant[0] == 'x') && screen_bf16_x32_supported(sd, k);
 }
 
+// tiles of 32 centroids per wave and centroid groups for a shape (0 = no X32 form)
+void screen_bf16_x32_tiling(uint32_t sd, uint32_t k, uint32_t *nt32_per_group, uint32_t *groups) {
+    *nt32_per_group = *groups = 0;
+    if (k == 0 || k > 256) return;
+    const uint32_t nt = (k + 31) / 32;
+    uint32_t cap;  // tiles whose A image fits next to the working set: NMF * cap * 4 registers
+    switch (sd) {
+    case 8: case 12: case 16: case 24: cap = 8; break;
+    case 32: cap = 4; break;   // 12 MFMAs per tile: 192 registers
+    case 48: cap = 2; break;   // 18 MFMAs per tile: 144 registers
+    default: return;
+    }
+    const uint32_t per = nt < cap ? nt : cap;
+    *nt32_per_group = per;
+    *groups = (nt + per - 1) / per;
+}
+
 bool screen_bf16_x32_supported(uint32_t sd, uint32_t k) {
-    if (!(sd == 8 || sd == 12 || sd == 16 || sd == 24)) return false;
-    if (k == 0 || k > 256) return false;
-    return true;
+    uint32_t per, groups;
+    screen_bf16_x32_tiling(sd, k, &per, &groups);
+    return per != 0;
 }
 uint32_t screen_bf16_x32_mfmas(uint32_t sd) {
     return (6 * (sd / 2) + 7) / 8;
@@ -1530,7 +1626,9 @@ uint32_t screen_bf16_x32_mfmas(uint32_t sd) {
 int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine, float *cbc, float *cen,
                             float *cn32, hipStream_t stream) {
     if (v.m == 0) return VQHIP_OK;
-    const uint32_t nt32 = (v.k + 31) / 32;
+    uint32_t per = 0, groups = 0;
+    screen_bf16_x32_tiling(v.sd, v.k, &per, &groups);
+    const uint32_t nt32 = per * groups;  // image padded to whole groups (zero operands, never-winning norms)
     const float *src = v.cb;
     if (!cosine) {
         hipLaunchKernelGGL(k_center_codebook_x32, dim3(v.m), dim3(256), 0, stream, v.cb, v.m, v.k, v.sd, nt32 * 32,
@@ -1580,14 +1678,22 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
     static const char *variant = getenv("VQHIP_BF16_VARIANT");
     const int which = !variant ? 3 : (variant[0] == 'x' ? 3 : variant[0] == 'r' ? 0 : (strcmp(variant, "lds") == 0 ? 1 : 2));
     if (which == 3 && cb.prepA32 && screen_bf16_x32_supported(cb.sd, cb.k)) {
-        const uint32_t nt32 = (cb.k + 31) / 32;
+        uint32_t nt32 = 0, groups = 0;
+        screen_bf16_x32_tiling(cb.sd, cb.k, &nt32, &groups);
+        if (groups > 1 && a.metric == VQHIP_COSINE)
+            return fail(VQHIP_ERR_UNSUPPORTED, "cosine screen for sub_dim=%u needs k <= %u", cb.sd, nt32 * 32);
 #define VQ_X32(SDV, NTV) \
-    if (cb.sd == SDV && nt32 == NTV) return launch_one_x32<SDV, NTV>(cb, a, stream);
+    if (cb.sd == SDV && nt32 == NTV && groups == 1) return launch_one_x32<SDV, NTV>(cb, a, stream);
+#define VQ_X32G(SDV, NTV, GV) \
+    if (cb.sd == SDV && nt32 == NTV && groups == GV) return launch_one_x32<SDV, NTV, GV>(cb, a, stream);
         VQ_X32(16, 1) VQ_X32(16, 2) VQ_X32(16, 3) VQ_X32(16, 4) VQ_X32(16, 5) VQ_X32(16, 6) VQ_X32(16, 7) VQ_X32(16, 8)
         VQ_X32(8, 1) VQ_X32(8, 2) VQ_X32(8, 3) VQ_X32(8, 4) VQ_X32(8, 5) VQ_X32(8, 6) VQ_X32(8, 7) VQ_X32(8, 8)
         VQ_X32(12, 1) VQ_X32(12, 2) VQ_X32(12, 3) VQ_X32(12, 4) VQ_X32(12, 5) VQ_X32(12, 6) VQ_X32(12, 7) VQ_X32(12, 8)
         VQ_X32(24, 1) VQ_X32(24, 2) VQ_X32(24, 3) VQ_X32(24, 4) VQ_X32(24, 5) VQ_X32(24, 6) VQ_X32(24, 7) VQ_X32(24, 8)
+        VQ_X32(32, 1) VQ_X32(32, 2) VQ_X32(32, 3) VQ_X32(32, 4) VQ_X32G(32, 4, 2)
+        VQ_X32(48, 1) VQ_X32(48, 2) VQ_X32G(48, 2, 2) VQ_X32G(48, 2, 3) VQ_X32G(48, 2, 4)
 #undef VQ_X32
+#undef VQ_X32G
     }
 #define VQ_CASE(SDV, NTV)                                                              \
     if (cb.sd == SDV && cb.nt == NTV)                                                  \

@@ -38,6 +38,7 @@ bool screen_bf16_supported(uint32_t sd, uint32_t k);
 uint32_t screen_bf16_mfmas(uint32_t sd);
 int launch_prepare_bf16(const CodebookView &v, uint32_t *prepA16, hipStream_t stream);
 bool screen_bf16_x32_supported(uint32_t sd, uint32_t k);
+void screen_bf16_x32_tiling(uint32_t sd, uint32_t k, uint32_t *nt32_per_group, uint32_t *groups);
 bool screen_bf16_uses_x32(uint32_t sd, uint32_t k);
 uint32_t screen_bf16_x32_mfmas(uint32_t sd);
 int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine, float *cbc, float *cen,
@@ -63,6 +64,7 @@ struct AssignArgs {
     // a screen launch that uses it sets n_seg (> 0) for the re-check launch that follows
     uint32_t *wl_seg = nullptr;
     uint32_t wl_seg_cap = 0;
+    void *part = nullptr;            // grouped X32 screen: [m][G][n] uint4 partial verdicts
     mutable uint32_t n_seg = 0;
 };
 
