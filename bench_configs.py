@@ -170,6 +170,7 @@ CONFIGS = {
     "C2_manhattan": lambda: pq_config("C2_manhattan", 1_000_000, 128, 8, 256, "manhattan", iters=3, encode_reps=3),
     "SD32": lambda: pq_config("SD32_1Mx128_m4", 1_000_000, 128, 4, 256, "l2", iters=3, encode_reps=5),
     "SD48": lambda: pq_config("SD48_1Mx384_m8", 1_000_000, 384, 8, 256, "l2", iters=3, encode_reps=3),
+    "SD64": lambda: pq_config("SD64_1Mx128_m2", 1_000_000, 128, 2, 256, "l2", iters=3, encode_reps=5),
     "C2_k128": lambda: pq_config("C2_k128", 1_000_000, 128, 8, 128, "l2", iters=3, encode_reps=5),
     "ADC": lambda: adc_config("ADC_C2", 1_000_000, 128, 8, 256, 64, 10),
     "E": lambda: pq_config("E_eval_shape", 1_000_000, 384, 16, 256, "euclidean", iters=5, encode_reps=3),

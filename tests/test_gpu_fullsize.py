@@ -108,7 +108,7 @@ def test_fullsize_mean_property():
 
 @pytest.mark.parametrize("kind", ["clustered", "heavy_tail", "offset", "tiny_scale"])
 @pytest.mark.parametrize("shape", [(400_000, 128, 8, 256), (300_000, 384, 16, 256), (300_000, 96, 8, 100),
-                                   (300_000, 128, 4, 256), (200_000, 192, 4, 256)])
+                                   (300_000, 128, 4, 256), (200_000, 192, 4, 256), (200_000, 128, 2, 256)])
 def test_fullsize_engine_agreement_distributions(kind, shape):
     """Screen + re-check == exact scan on every row for data that stresses the margin: tight
     clusters (genuine near-ties), heavy tails (a few huge norms), a common offset far from the

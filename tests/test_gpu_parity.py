@@ -63,6 +63,8 @@ SHAPES = [  # (n, d, m, k)
     (1500, 64, 2, 100),    # sub_dim 32, one group of 4 tiles
     (1900, 96, 2, 256),    # sub_dim 48: four groups of 64 centroids
     (1300, 144, 3, 150),   # sub_dim 48: three groups, ragged k
+    (1700, 128, 2, 256),   # sub_dim 64: four groups of 64 centroids
+    (900, 64, 1, 50),      # sub_dim 64, one group
 ]
 
 
@@ -82,7 +84,7 @@ def test_encode_l2_bit_exact(oracle, shape, kind, metric):
             _check_encode(oracle, X, cb, metric, _lib.ENGINE_MFMA)   # fp32 MFMA screen
         except _lib.FfiError as e:  # e.g. sub_dim 32 at k = 256: its A image exceeds the register budget
             assert "unavailable" in str(e)
-    if d // m in (4, 8, 12, 16, 24, 32, 48):
+    if d // m in (4, 8, 12, 16, 24, 32, 48, 64):
         _check_encode(oracle, X, cb, metric, _lib.ENGINE_MFMA_BF16)  # bf16-split screen
         assert _check_encode.last_stats[1] == _lib.ENGINE_MFMA_BF16
 
@@ -252,7 +254,7 @@ def test_encode_ragged_sizes(oracle):
 
 
 @pytest.mark.parametrize("shape", [(4000, 64, 4, 16), (6000, 128, 8, 256), (3000, 128, 16, 64), (5000, 96, 4, 64), (3000, 48, 4, 32), (2000, 96, 2, 16),
-                                   (6000, 128, 4, 256), (4000, 96, 2, 200)])
+                                   (6000, 128, 4, 256), (4000, 96, 2, 200), (3000, 128, 2, 256)])
 @pytest.mark.parametrize("kind", ["uniform", "clustered"])
 @pytest.mark.parametrize("engine", [_lib.ENGINE_AUTO, _lib.ENGINE_EXACT, _lib.ENGINE_MFMA])
 def test_lloyd_step_parity(oracle, shape, kind, engine):

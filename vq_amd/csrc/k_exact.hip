@@ -403,6 +403,7 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
             VQ_RECHECK_CASE(24)
             VQ_RECHECK_CASE(32)
             VQ_RECHECK_CASE(48)
+            VQ_RECHECK_CASE(64)
         default: break;
         }
 #undef VQ_RECHECK_CASE

@@ -1606,6 +1606,7 @@ void screen_bf16_x32_tiling(uint32_t sd, uint32_t k, uint32_t *nt32_per_group, u
     case 8: case 12: case 16: case 24: cap = 8; break;
     case 32: cap = 4; break;   // 12 MFMAs per tile: 192 registers
     case 48: cap = 2; break;   // 18 MFMAs per tile: 144 registers
+    case 64: cap = 2; break;   // 24 MFMAs per tile: 192 registers
     default: return;
     }
     const uint32_t per = nt < cap ? nt : cap;
@@ -1692,6 +1693,7 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
         VQ_X32(24, 1) VQ_X32(24, 2) VQ_X32(24, 3) VQ_X32(24, 4) VQ_X32(24, 5) VQ_X32(24, 6) VQ_X32(24, 7) VQ_X32(24, 8)
         VQ_X32(32, 1) VQ_X32(32, 2) VQ_X32(32, 3) VQ_X32(32, 4) VQ_X32G(32, 4, 2)
         VQ_X32(48, 1) VQ_X32(48, 2) VQ_X32G(48, 2, 2) VQ_X32G(48, 2, 3) VQ_X32G(48, 2, 4)
+        VQ_X32(64, 1) VQ_X32(64, 2) VQ_X32G(64, 2, 2) VQ_X32G(64, 2, 3) VQ_X32G(64, 2, 4)
 #undef VQ_X32
 #undef VQ_X32G
     }
