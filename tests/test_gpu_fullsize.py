@@ -134,8 +134,6 @@ def test_fullsize_engine_agreement_distributions(kind, shape):
     cb = km.get_centroids()
     km.close()
     for metric in (_lib.SQUARED_EUCLIDEAN, _lib.COSINE):
-        if metric == _lib.COSINE and d // m > 24:
-            continue  # grouped shapes (sub_dim 32 / 48 at k = 256) have no cosine screen
         enc = _lib.PQEncoder(cb, metric)
         a = torch.empty((n, m), dtype=torch.uint8, device="cuda")
         b = torch.empty((n, m), dtype=torch.uint8, device="cuda")

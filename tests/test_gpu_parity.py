@@ -103,7 +103,8 @@ def test_encode_l1_cosine_bit_exact(oracle, shape, kind, metric):
 
 
 COSINE_SHAPES = [(3000, 64, 4, 16), (2500, 128, 8, 256), (1000, 128, 16, 256), (1200, 768, 96, 256),
-                 (1500, 64, 8, 37), (1800, 96, 4, 200), (1300, 48, 4, 77)]
+                 (1500, 64, 8, 37), (1800, 96, 4, 200), (1300, 48, 4, 77),
+                 (2000, 128, 4, 256), (1500, 192, 4, 200), (1200, 128, 2, 256)]
 
 
 @pytest.mark.parametrize("shape", COSINE_SHAPES)

@@ -223,8 +223,8 @@ static thread_local ProfileState g_prof;
 static int pick_engine(int requested, const CodebookState &cs, int metric, int *engine) {
     const bool l2_metric = (metric == VQHIP_SQUARED_EUCLIDEAN || metric == VQHIP_EUCLIDEAN);
     // cosine has a screen too (s = -x.c/|c| on the X32 bf16 engine); Manhattan has no contraction form
-    const bool cos_ok = (metric == VQHIP_COSINE) && cs.x32_ok && cs.x32_groups == 1 &&
-                        screen_bf16_uses_x32(cs.sd, cs.k) && cs.metric == VQHIP_COSINE;
+    const bool cos_ok = (metric == VQHIP_COSINE) && cs.x32_ok && screen_bf16_uses_x32(cs.sd, cs.k) &&
+                        cs.metric == VQHIP_COSINE;
     if (requested == VQHIP_ENGINE_EXACT) {
         *engine = VQHIP_ENGINE_EXACT;
     } else if (requested == VQHIP_ENGINE_MFMA) {

@@ -310,6 +310,10 @@ __global__ __launch_bounds__(256) void k_prepare_codebook(const float *__restric
         if (sd % 4 == 0 && sd >= 4 && sd <= 32) {
             const uint32_t dpg = sd / 4, pp = 8 / dpg, nm = (6 + pp - 1) / pp;
             coef16 = (8.0f * (float)sd + 16.0f + 2.0f * kBf16AssumedUlps * (float)nm + 16.0f) * u;
+        } else if (sd % 4 == 0) {
+            // no 16x16 variant for this sub_dim; the X32 kernels read [3] only as "codebook finite?" (cosine)
+            const uint32_t nm32 = (6 * (sd / 2) + 7) / 8;
+            coef16 = (8.0f * (float)sd + 16.0f + 2.0f * kBf16AssumedUlps * (float)nm32 + 16.0f) * u;
         }
         meta[s * 4 + 2] = s_bad[0] ? __builtin_inff() : coef16;
         // X32 variant packs a 6-bit index into the low mantissa bits: |perturbation| < 2^-18 |s|

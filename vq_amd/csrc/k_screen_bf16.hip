@@ -1016,12 +1016,19 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
 template <int G>
 __global__ __launch_bounds__(256) void k_merge_partials_x32(const uint4 *__restrict__ part, uint64_t n, uint32_t m,
                                                             uint32_t sd, const uint32_t *__restrict__ sub_list,
-                                                            const float *__restrict__ cen, uint8_t *__restrict__ codes,
+                                                            const float *__restrict__ cen, const float *__restrict__ meta,
+                                                            int cosine, uint8_t *__restrict__ codes,
                                                             uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_count,
                                                             uint64_t wl_stride) {
     const uint32_t s = sub_list[blockIdx.y];
     const float *cs = cen + (size_t)s * (sd + 4);
-    const float cmax = cs[sd], tcoef = cs[sd + 1];
+    float cmax = cs[sd], tcoef = cs[sd + 1];
+    if (cosine) {  // same margin as the single-pass kernel: (6 sd + 2.5 eps_M NMF + 200) 2^-24 |x|, inf for a non-finite codebook
+        const float nmf = (float)((6 * (sd / 2) + 7) / 8);
+        cmax = 0.0f;
+        tcoef = (meta[s * 4 + 3] <= 3.0e38f) ? (6.0f * (float)sd + 2.5f * kBf16AssumedUlps * nmf + 200.0f) * 5.9604644775390625e-08f
+                                             : __builtin_inff();
+    }
     const uint32_t lane = threadIdx.x & 63;
     for (uint64_t row0 = (uint64_t)blockIdx.x * 256; row0 < n; row0 += (uint64_t)gridDim.x * 256) {
         const uint64_t row = row0 + threadIdx.x;
@@ -1043,8 +1050,9 @@ __global__ __launch_bounds__(256) void k_merge_partials_x32(const uint4 *__restr
             }
             const float xnorm = __builtin_sqrtf(xs) * 1.000001f;
             const float xn = xnorm + cmax;
-            const float T = tcoef * (xn * xn) + 1e-35f * xn + 1e-37f;
-            const bool proven = (m2 - m1 > T) && (fabsf(m1) <= 3.0e38f) && (T <= 3.0e38f);
+            const float T = tcoef * (cosine ? xnorm : xn * xn) + 1e-35f * xn + 1e-37f;
+            bool proven = (m2 - m1 > T) && (fabsf(m1) <= 3.0e38f) && (T <= 3.0e38f);
+            if (cosine) proven = proven && (m1 < -T) && (xnorm > 4e-10f);
             codes[row * m + s] = (uint8_t)j;
             recheck = !proven;
         }
@@ -1581,8 +1589,8 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
         uint64_t mblocks = (a.n + 255) / 256;
         if (mblocks > (uint64_t)num_cus() * 8) mblocks = (uint64_t)num_cus() * 8;
         hipLaunchKernelGGL((k_merge_partials_x32<G>), dim3((uint32_t)mblocks, a.n_sub), dim3(256), 0, stream,
-                           reinterpret_cast<const uint4 *>(a.part), a.n, cb.m, cb.sd, a.sub_list, cb.cen, a.codes,
-                           a.wl_rows, a.wl_count, a.wl_stride);
+                           reinterpret_cast<const uint4 *>(a.part), a.n, cb.m, cb.sd, a.sub_list, cb.cen, cb.meta,
+                           a.metric == VQHIP_COSINE ? 1 : 0, a.codes, a.wl_rows, a.wl_count, a.wl_stride);
         VQ_LAUNCH_CHECK("k_merge_partials_x32");
     }
     return VQHIP_OK;
@@ -1681,8 +1689,6 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
     if (which == 3 && cb.prepA32 && screen_bf16_x32_supported(cb.sd, cb.k)) {
         uint32_t nt32 = 0, groups = 0;
         screen_bf16_x32_tiling(cb.sd, cb.k, &nt32, &groups);
-        if (groups > 1 && a.metric == VQHIP_COSINE)
-            return fail(VQHIP_ERR_UNSUPPORTED, "cosine screen for sub_dim=%u needs k <= %u", cb.sd, nt32 * 32);
 #define VQ_X32(SDV, NTV) \
     if (cb.sd == SDV && nt32 == NTV && groups == 1) return launch_one_x32<SDV, NTV>(cb, a, stream);
 #define VQ_X32G(SDV, NTV, GV) \
