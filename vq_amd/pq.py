@@ -82,21 +82,24 @@ def fit_codebooks(ds: "_lib.Dataset", m: int, k: int, max_iters: int, seed: int 
             if not active.any():
                 break
             counts, changed = km.step()
-            for s in np.nonzero(active)[0]:
-                iters[s] += 1
-                for j in np.nonzero(counts[s] == 0)[0]:  # vector.rs:448-452, ascending j
-                    if reseed_iters is not None:
-                        try:
-                            row = int(next(reseed_iters[s]))
-                        except StopIteration:
-                            raise InvalidParameter("reseed_rows", f"exhausted for subspace {s}")
-                    else:
-                        row = rngs[s].choose(n)
-                    km.patch_from_row(int(s), int(j), row)
-                    n_reseeds += 1
-                if not changed[s]:  # vector.rs:455-457
-                    active[s] = False
-            km.set_active(active)
+            iters[active] += 1
+            # empty clusters of active subspaces in (subspace, ascending j) order, vector.rs:448-452
+            # (one vectorised scan: the per-subspace Python loop cost ~1 ms per iteration at m = 96)
+            empties = np.argwhere((counts == 0) & active[:, None])
+            for s, j in empties:
+                if reseed_iters is not None:
+                    try:
+                        row = int(next(reseed_iters[s]))
+                    except StopIteration:
+                        raise InvalidParameter("reseed_rows", f"exhausted for subspace {s}")
+                else:
+                    row = rngs[s].choose(n)
+                km.patch_from_row(int(s), int(j), row)
+                n_reseeds += 1
+            converged = active & ~np.asarray(changed, dtype=bool)  # vector.rs:455-457
+            if converged.any():
+                active[converged] = False
+                km.set_active(active)
         if stats is not None:
             stats["iters"] = iters
             stats["reseeds"] = n_reseeds
