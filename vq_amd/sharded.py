@@ -168,14 +168,14 @@ class ShardedKMeans:
             if not self.active.any():
                 break
             counts, changed = self.step()
-            for s in np.nonzero(self.active)[0]:
-                self.iters[s] += 1
-                for j in np.nonzero(counts[s] == 0)[0]:
-                    row = int(next(reseed_it[s])) if reseed_it is not None else rngs[s].choose(n)
-                    b.patch_centroid(int(s), int(j), self._bcast_sub_row(int(s), row))
-                if not changed[s]:
-                    self.active[s] = False
-            b.set_active(self.active)
+            self.iters[self.active] += 1
+            for s, j in np.argwhere((counts == 0) & self.active[:, None]):  # (subspace, ascending j)
+                row = int(next(reseed_it[s])) if reseed_it is not None else rngs[s].choose(n)
+                b.patch_centroid(int(s), int(j), self._bcast_sub_row(int(s), row))
+            converged = self.active & ~np.asarray(changed, dtype=bool)
+            if converged.any():
+                self.active[converged] = False
+                b.set_active(self.active)
         return b.get_centroids()
 
 
