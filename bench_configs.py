@@ -32,7 +32,7 @@ def _sync():
     _lib.synchronize()
 
 
-def pq_config(name, n, d, m, k, metric_name, iters=10, encode_reps=5):
+def pq_config(name, n, d, m, k, metric_name, iters=10, encode_reps=5, engine=None):
     import torch
 
     from vq_amd import _lib
@@ -41,6 +41,8 @@ def pq_config(name, n, d, m, k, metric_name, iters=10, encode_reps=5):
               "manhattan": _lib.MANHATTAN}[metric_name]
     ds = _lib.Dataset.synthetic(n, d, 66, 0)
     km = _lib.KMeans(ds, m, k)
+    if engine is not None:
+        km.set_engine(engine)
     init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64)
     km.init_from_rows(init)
     km.step()  # warm-up (allocations, code objects)
@@ -54,7 +56,9 @@ def pq_config(name, n, d, m, k, metric_name, iters=10, encode_reps=5):
     cb = km.get_centroids()
     km.close()
     enc = _lib.PQEncoder(cb, metric)
-    codes = torch.empty((n, m), dtype=torch.uint8, device="cuda")
+    if engine is not None:
+        enc.set_engine(engine)
+    codes = torch.empty((n, m * (1 if k <= 256 else 2)), dtype=torch.uint8, device="cuda")  # u16 codes above 256
     f16 = torch.empty((n, d), dtype=torch.float16, device="cuda")
     enc.encode_device(ds.device_ptr, n, codes.data_ptr(), None)
     _sync()
@@ -172,6 +176,9 @@ CONFIGS = {
     "SD48": lambda: pq_config("SD48_1Mx384_m8", 1_000_000, 384, 8, 256, "l2", iters=3, encode_reps=3),
     "SD64": lambda: pq_config("SD64_1Mx128_m2", 1_000_000, 128, 2, 256, "l2", iters=3, encode_reps=5),
     "C2_k128": lambda: pq_config("C2_k128", 1_000_000, 128, 8, 128, "l2", iters=3, encode_reps=5),
+    "C2_k1024": lambda: pq_config("C2_k1024", 1_000_000, 128, 8, 1024, "l2", iters=3, encode_reps=3),
+    "C2_k1024_exact": lambda: pq_config("C2_k1024_exact", 1_000_000, 128, 8, 1024, "l2", iters=3, encode_reps=3, engine=1),
+    "C2_k4096": lambda: pq_config("C2_k4096", 1_000_000, 128, 8, 4096, "l2", iters=2, encode_reps=2),
     "ADC": lambda: adc_config("ADC_C2", 1_000_000, 128, 8, 256, 64, 10),
     "E": lambda: pq_config("E_eval_shape", 1_000_000, 384, 16, 256, "euclidean", iters=5, encode_reps=3),
 }

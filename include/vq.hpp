@@ -295,10 +295,26 @@ class ProductQuantizer {
         if (n) detail::check(vqhip_pq_encode(enc_.get(), rows, n, nullptr, reinterpret_cast<std::uint16_t *>(out.data())));
         return out;
     }
-    std::vector<std::uint8_t> encode(const float *rows, std::size_t n) const {  // best_idx per subspace
+    std::vector<std::uint8_t> encode(const float *rows, std::size_t n) const {  // best_idx per subspace, k <= 256
+        if (k_ > 256) throw VqError::InvalidParameter("k", "one-byte codes need k <= 256: use encode_wide");
         std::vector<std::uint8_t> codes(n * m_);
         if (n) detail::check(vqhip_pq_encode(enc_.get(), rows, n, codes.data(), nullptr));
         return codes;
+    }
+    // any k: the library's one- or two-byte codes (vqhip.h "code width") widened to 32 bits
+    std::vector<std::uint32_t> encode_wide(const float *rows, std::size_t n) const {
+        std::vector<std::uint32_t> out(n * m_);
+        if (!n) return out;
+        if (vqhip_code_bytes((std::uint32_t)k_) == 1) {
+            std::vector<std::uint8_t> c(n * m_);
+            detail::check(vqhip_pq_encode(enc_.get(), rows, n, c.data(), nullptr));
+            for (std::size_t i = 0; i < c.size(); ++i) out[i] = c[i];
+        } else {
+            std::vector<std::uint16_t> c(n * m_);
+            detail::check(vqhip_pq_encode(enc_.get(), rows, n, reinterpret_cast<std::uint8_t *>(c.data()), nullptr));
+            for (std::size_t i = 0; i < c.size(); ++i) out[i] = c[i];
+        }
+        return out;
     }
 
    private:
@@ -309,7 +325,7 @@ class ProductQuantizer {
         if (dim % m != 0)
             throw VqError::InvalidParameter("m", "dimension (" + std::to_string(dim) + ") must be divisible by m");
         detail::check_lbg_params(n, k);
-        if (k > 256) throw VqError::InvalidParameter("k", "this build stores one-byte codes (k <= 256)");
+        if (k > 65536) throw VqError::InvalidParameter("k", "codes are at most two bytes (k <= 65536)");
         m_ = m;
         k_ = k;
         dim_ = dim;
@@ -412,7 +428,7 @@ inline std::vector<std::vector<float>> lbg_quantize(const std::vector<std::vecto
     if (data.size() < k)
         throw VqError::InvalidParameter("k", "not enough data points (" + std::to_string(data.size()) + ") for " +
                                                  std::to_string(k) + " clusters");
-    if (k > 256) throw VqError::InvalidParameter("k", "this build stores one-byte codes (k <= 256)");
+    if (k > 65536) throw VqError::InvalidParameter("k", "codes are at most two bytes (k <= 65536)");
     std::size_t dim = 0;
     const std::vector<float> flat = detail::flatten(data, &dim);
     vqhip_dataset *raw = nullptr;

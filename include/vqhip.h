@@ -122,6 +122,17 @@ int vqhip_dataset_destroy(vqhip_dataset *ds);
 int vqhip_synth_uniform_host(float *out, uint64_t n, uint32_t d, uint64_t seed,
                              uint64_t row_offset);
 
+/* ---- code width ----------------------------------------------------------------------
+ * The reference keeps a `usize` best_idx per subspace (src/pq.rs:183-191, vector.rs:417); this
+ * library stores it in the narrowest of two widths, chosen by k alone:
+ *     k <= 256          one byte per (row, subspace)
+ *     256 < k <= 65536  one little-endian uint16_t per (row, subspace)
+ * Every `codes` buffer below (host or device) is [n][m] of that width, i.e.
+ * n * m * vqhip_code_bytes(k) bytes; the parameter stays `uint8_t *` for both.  k > 256 runs the
+ * exact VALU engine (the MFMA screens are instantiated for k <= 256); the ADC search takes one-byte
+ * codes only. */
+uint32_t vqhip_code_bytes(uint32_t k);
+
 /* ---- k-means (Lloyd / LBG) over all m subspaces at once -------------------------------
  * replaces the body of lbg_quantize (src/core/vector.rs:415-458) as called once per
  * subspace by ProductQuantizer::new (src/pq.rs:120-132).  m == 1 with sub_dim == d is
@@ -141,7 +152,8 @@ int vqhip_kmeans_set_active(vqhip_kmeans *km, const uint8_t *active);
 int vqhip_kmeans_set_engine(vqhip_kmeans *km, int engine);
 /* exact_update != 0: cluster means are the reference's sequential f32 sums in row order
  * (bit-identical to mean_vector_by_indices, vector.rs:368-384) instead of the default
- * blocked f32 + f64 combination (faster; within the tolerance stated in DESIGN.md). */
+ * blocked f32 + f64 combination (faster; within the tolerance stated in DESIGN.md).
+ * Needs k <= 16384. */
 int vqhip_kmeans_set_exact_update(vqhip_kmeans *km, int exact_update);
 
 /* One Lloyd iteration = assign + accumulate + reduce + finalize for every active subspace:
@@ -165,18 +177,18 @@ int vqhip_kmeans_finalize(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed);
 /* empty-cluster reseed (vector.rs:448-452): the caller draws the row */
 int vqhip_kmeans_patch_centroid(vqhip_kmeans *km, uint32_t s, uint32_t j, const float *sub_row);
 int vqhip_kmeans_patch_from_row(vqhip_kmeans *km, uint32_t s, uint32_t j, uint64_t row);
-/* assignment codes [n][m] of the most recent step/accumulate (the reference's
- * `assignments`, vector.rs:417-429), copied to the host */
+/* assignment codes [n][m] (see "code width") of the most recent step/accumulate (the
+ * reference's `assignments`, vector.rs:417-429), copied to the host */
 int vqhip_kmeans_get_assignments(vqhip_kmeans *km, uint8_t *codes);
 
 /* ---- PQ encode -----------------------------------------------------------------------
  * replaces the loop of ProductQuantizer::quantize (src/pq.rs:177-196) for a whole batch.
- * codebooks [m][k][sub_dim] f32 on the host; k <= 256 (codes are one byte per subspace). */
+ * codebooks [m][k][sub_dim] f32 on the host; k <= 65536 (see "code width"). */
 int vqhip_pq_encoder_create(const float *codebooks, uint32_t m, uint32_t k, uint32_t sub_dim,
                             int metric, vqhip_pq_encoder **out);
 int vqhip_pq_encoder_destroy(vqhip_pq_encoder *enc);
 int vqhip_pq_encoder_set_engine(vqhip_pq_encoder *enc, int engine);
-/* host batch: rows [n][m*sub_dim];  codes [n][m] (optional) = best_idx per subspace
+/* host batch: rows [n][m*sub_dim];  codes [n][m] (optional, "code width") = best_idx per subspace
  * (pq.rs:183-191);  f16_out [n][m*sub_dim] (optional) = selected centroids as IEEE
  * binary16 bits, round-to-nearest-even (pq.rs:193-195).  Calls with n <= 8 (the reference's
  * one-vector-per-call `quantize`) take a single-kernel latency path over pinned memory with the

@@ -44,6 +44,7 @@ SIGNATURES = {
     "vqhip_set_profiling": (C.c_int, [C.c_int]),
     "vqhip_profile_collect": (C.c_int, [_u32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vqhip_memcpy_device": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "vqhip_code_bytes": (C.c_uint32, [C.c_uint32]),
     "vqhip_dataset_from_host": (C.c_int, [_f32p, C.c_uint64, C.c_uint32, _vpp]),
     "vqhip_dataset_from_device": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vpp]),
     "vqhip_dataset_synthetic": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, _vpp]),
@@ -135,6 +136,11 @@ def ptr(a: np.ndarray | None, ty):
 
 def f32c(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def code_dtype(k: int):
+    """codes are one byte while k <= 256 and a u16 above (include/vqhip.h, "code width")"""
+    return np.uint8 if int(k) <= 256 else np.uint16
 
 
 class Handle:
@@ -269,7 +275,7 @@ class KMeans(Handle):
         check(load().vqhip_kmeans_patch_from_row(self.raw, s, j, row))
 
     def get_assignments(self) -> np.ndarray:
-        out = np.empty((self.ds.n, self.m), np.uint8)
+        out = np.empty((self.ds.n, self.m), code_dtype(self.k))
         check(load().vqhip_kmeans_get_assignments(self.raw, ptr(out, _u8p)))
         return out
 
@@ -315,7 +321,7 @@ class PQEncoder(Handle):
     def encode(self, rows, want_codes=True, want_f16=True):
         rows = f32c(rows).reshape(-1, self.m * self.sd)
         n = rows.shape[0]
-        codes = np.empty((n, self.m), np.uint8) if want_codes else None
+        codes = np.empty((n, self.m), code_dtype(self.k)) if want_codes else None
         f16 = np.empty((n, self.m * self.sd), np.uint16) if want_f16 else None
         check(load().vqhip_pq_encode(self.raw, ptr(rows, _f32p), n, ptr(codes, _u8p), ptr(f16, _u16p)))
         return codes, (None if f16 is None else f16.view(np.float16))
@@ -325,7 +331,10 @@ class PQEncoder(Handle):
                                             C.c_void_p(dev_codes or 0), C.c_void_p(dev_f16 or 0)))
 
     def decode(self, codes) -> np.ndarray:
-        codes = np.ascontiguousarray(codes, dtype=np.uint8).reshape(-1, self.m)
+        codes = np.asarray(codes)
+        if codes.size and (codes.min() < 0 or codes.max() >= self.k):
+            raise FfiError(f"code outside [0, {self.k})", ERR_INVALID_INPUT)
+        codes = np.ascontiguousarray(codes, dtype=code_dtype(self.k)).reshape(-1, self.m)
         out = np.empty((codes.shape[0], self.m * self.sd), np.float32)
         check(load().vqhip_pq_decode(self.raw, ptr(codes, _u8p), codes.shape[0], ptr(out, _f32p)))
         return out

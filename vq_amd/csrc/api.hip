@@ -257,6 +257,11 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
         return fail(VQHIP_ERR_INVALID_INPUT, "device row buffer must be 16-byte aligned");
     int engine = 0;
     VQ_TRY(pick_engine(engine_req, cs, metric, &engine));
+    // k > 256 on the grouped X32 screen keeps a 16-byte partial verdict per (row, subspace, group): past 4 GiB
+    // of them the exact scan is used instead (unless the caller asked for the screen by name)
+    if (engine == VQHIP_ENGINE_MFMA_BF16 && engine_req == VQHIP_ENGINE_AUTO && cs.k > 256 &&
+        (size_t)cs.m * cs.x32_groups * n * 16 > ((size_t)4 << 30))
+        engine = VQHIP_ENGINE_EXACT;
     VQ_TRY(cs.prepare(stream));
     const bool screened = (engine == VQHIP_ENGINE_MFMA || engine == VQHIP_ENGINE_MFMA_BF16);
     VQ_TRY(ws.ensure(cs.m, n, screened));
@@ -725,14 +730,14 @@ int vqhip_kmeans_create(const vqhip_dataset *ds, uint32_t m, uint32_t k, vqhip_k
     if (m == 0 || ds->d < m || ds->d % m != 0)
         return fail(VQHIP_ERR_INVALID_INPUT, "dimension (%u) must be divisible by m (%u)", ds->d, m);
     if (k == 0) return fail(VQHIP_ERR_INVALID_INPUT, "k must be greater than 0");
-    if (k > 256) return fail(VQHIP_ERR_UNSUPPORTED, "k=%u > 256: codes are one byte per subspace", k);
+    if (k > kMaxCentroids) return fail(VQHIP_ERR_UNSUPPORTED, "k=%u > 65536: codes are at most two bytes per subspace", k);
     VQ_TRY(require_gfx950());
     const uint32_t sd = ds->d / m;
     std::unique_ptr<vqhip_kmeans> km(new vqhip_kmeans());
     km->ds = ds;
     VQ_TRY(km->cs.init(m, k, sd));
     VQ_TRY(plan_update(m, k, sd, ds->n, &km->plan));
-    VQ_TRY(km->codes.alloc((size_t)ds->n * m));
+    VQ_TRY(km->codes.alloc((size_t)ds->n * m * code_bytes(k)));
     VQ_TRY(km->partial_sums.alloc(km->plan.partial_floats * km->plan.n_row_chunks * 4));
     VQ_TRY(km->partial_counts.alloc(km->plan.partial_counts * km->plan.n_row_chunks * 4));
     VQ_TRY(km->slab.alloc((size_t)m * k * (sd + 1) * 8));
@@ -816,6 +821,8 @@ int vqhip_kmeans_set_engine(vqhip_kmeans *km, int engine) {
     km->engine = engine;
     return VQHIP_OK;
 }
+
+uint32_t vqhip_code_bytes(uint32_t k) { return code_bytes(k); }
 
 int vqhip_kmeans_set_exact_update(vqhip_kmeans *km, int exact_update) {
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
@@ -1001,7 +1008,7 @@ int vqhip_kmeans_get_assignments(vqhip_kmeans *km, uint8_t *codes) {
     if (!km || !codes) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     hipStream_t s;
     VQ_TRY(current_stream(&s));
-    VQ_HIP(hipMemcpyAsync(codes, km->codes.p, (size_t)km->ds->n * km->cs.m, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipMemcpyAsync(codes, km->codes.p, (size_t)km->ds->n * km->cs.m * code_bytes(km->cs.k), hipMemcpyDeviceToHost, s));
     VQ_HIP(hipStreamSynchronize(s));
     return VQHIP_OK;
 }
@@ -1014,7 +1021,7 @@ int vqhip_pq_encoder_create(const float *codebooks, uint32_t m, uint32_t k, uint
     *out = nullptr;
     if (!codebooks) return fail(VQHIP_ERR_NULL_PTR, "codebooks is NULL");
     if (m == 0 || k == 0 || sub_dim == 0) return fail(VQHIP_ERR_INVALID_INPUT, "m, k and sub_dim must be positive");
-    if (k > 256) return fail(VQHIP_ERR_UNSUPPORTED, "k=%u > 256: codes are one byte per subspace", k);
+    if (k > kMaxCentroids) return fail(VQHIP_ERR_UNSUPPORTED, "k=%u > 65536: codes are at most two bytes per subspace", k);
     if (metric < VQHIP_SQUARED_EUCLIDEAN || metric > VQHIP_COSINE) return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", metric);
     VQ_TRY(require_gfx950());
     hipStream_t s;
@@ -1054,7 +1061,7 @@ int vqhip_pq_encode_device(vqhip_pq_encoder *enc, const void *dev_rows, uint64_t
     VQ_TRY(current_stream(&s));
     uint8_t *codes = reinterpret_cast<uint8_t *>(dev_codes);
     if (!codes) {  // f16-only output still needs the codes internally
-        VQ_TRY(enc->codes.ensure((size_t)n * enc->cs.m));
+        VQ_TRY(enc->codes.ensure((size_t)n * enc->cs.m * code_bytes(enc->cs.k)));
         codes = enc->codes.as<uint8_t>();
     }
     g_last_ws = &enc->ws;
@@ -1074,10 +1081,11 @@ int vqhip_pq_encode(vqhip_pq_encoder *enc, const float *rows, uint64_t n, uint8_
     hipStream_t s;
     VQ_TRY(current_stream(&s));
     const uint32_t m = enc->cs.m, d = enc->cs.m * enc->cs.sd;
+    const size_t cw = code_bytes(enc->cs.k);  // bytes per code: 1 (k <= 256) or 2
     static const char *no_small = getenv("VQHIP_NO_SMALL_PATH");
     if (n <= kSmallRows && !(no_small && no_small[0] == '1')) {
         // per-vector calls (Quantizer::quantize): one kernel over mapped pinned memory, exact arithmetic
-        const size_t in_b = (size_t)n * d * 4, code_b = ((size_t)n * m + 15) & ~(size_t)15, f16_b = (size_t)n * d * 2;
+        const size_t in_b = (size_t)n * d * 4, code_b = ((size_t)n * m * cw + 15) & ~(size_t)15, f16_b = (size_t)n * d * 2;
         VQ_TRY(enc->stage.ensure(in_b + code_b + f16_b));
         VQ_TRY(enc->cs.prepare(s));  // centroid norms (cosine)
         char *hb = static_cast<char *>(enc->stage.host), *db = static_cast<char *>(enc->stage.dev);
@@ -1087,7 +1095,7 @@ int vqhip_pq_encode(vqhip_pq_encoder *enc, const float *rows, uint64_t n, uint8_
                                       reinterpret_cast<uint8_t *>(db + in_b),
                                       f16_out ? reinterpret_cast<uint16_t *>(db + in_b + code_b) : nullptr, s));
         VQ_TRY(spin_wait(s));
-        if (codes) memcpy(codes, hb + in_b, (size_t)n * m);
+        if (codes) memcpy(codes, hb + in_b, (size_t)n * m * cw);
         if (f16_out) memcpy(f16_out, hb + in_b + code_b, f16_b);
         ThreadState &st = tls();
         st.last_engine = VQHIP_ENGINE_EXACT;
@@ -1100,13 +1108,13 @@ int vqhip_pq_encode(vqhip_pq_encoder *enc, const float *rows, uint64_t n, uint8_
     uint64_t chunk = std::max<uint64_t>(1, (1ull << 30) / ((uint64_t)d * 4));
     if (chunk > n) chunk = n;
     VQ_TRY(enc->xbuf.ensure((size_t)chunk * d * 4));
-    VQ_TRY(enc->codes.ensure((size_t)chunk * m));
+    VQ_TRY(enc->codes.ensure((size_t)chunk * m * cw));
     if (f16_out) VQ_TRY(enc->f16buf.ensure((size_t)chunk * d * 2));
     for (uint64_t r0 = 0; r0 < n; r0 += chunk) {
         const uint64_t nr = std::min(chunk, n - r0);
         VQ_HIP(hipMemcpyAsync(enc->xbuf.p, rows + r0 * d, (size_t)nr * d * 4, hipMemcpyHostToDevice, s));
         VQ_TRY(vqhip_pq_encode_device(enc, enc->xbuf.p, nr, enc->codes.p, f16_out ? enc->f16buf.p : nullptr));
-        if (codes) VQ_HIP(hipMemcpyAsync(codes + r0 * m, enc->codes.p, (size_t)nr * m, hipMemcpyDeviceToHost, s));
+        if (codes) VQ_HIP(hipMemcpyAsync(codes + r0 * m * cw, enc->codes.p, (size_t)nr * m * cw, hipMemcpyDeviceToHost, s));
         if (f16_out) VQ_HIP(hipMemcpyAsync(f16_out + r0 * d, enc->f16buf.p, (size_t)nr * d * 2, hipMemcpyDeviceToHost, s));
         VQ_HIP(hipStreamSynchronize(s));
     }
@@ -1125,6 +1133,7 @@ int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uin
     hipStream_t s;
     VQ_TRY(current_stream(&s));
     const uint32_t m = enc->cs.m, k = enc->cs.k, sd = enc->cs.sd, dim = m * sd;
+    if (k > 256) return fail(VQHIP_ERR_UNSUPPORTED, "ADC search scans one-byte codes: k=%u > 256", k);
     VQ_TRY(enc->adc_q.ensure((size_t)nq * dim * 4));
     VQ_TRY(enc->adc_lut.ensure((size_t)adc_query_batch() * m * k * 4));
     VQ_TRY(enc->adc_dist.ensure((size_t)adc_query_batch() * n * 4));
@@ -1183,11 +1192,19 @@ int vqhip_pq_decode(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n, flo
     hipStream_t s;
     VQ_TRY(current_stream(&s));
     const uint32_t m = enc->cs.m, d = enc->cs.m * enc->cs.sd;
-    for (uint64_t i = 0; i < n * m; ++i)
-        if (codes[i] >= enc->cs.k) return fail(VQHIP_ERR_INVALID_INPUT, "code %u >= k=%u", codes[i], enc->cs.k);
-    VQ_TRY(enc->codes.ensure((size_t)n * m));
+    const size_t cw = code_bytes(enc->cs.k);
+    for (uint64_t i = 0; i < n * m; ++i) {
+        uint32_t c = codes[i];
+        if (cw == 2) {
+            uint16_t w;
+            memcpy(&w, codes + 2 * i, 2);
+            c = w;
+        }
+        if (c >= enc->cs.k) return fail(VQHIP_ERR_INVALID_INPUT, "code %u >= k=%u", c, enc->cs.k);
+    }
+    VQ_TRY(enc->codes.ensure((size_t)n * m * cw));
     VQ_TRY(enc->f32buf.ensure((size_t)n * d * 4));
-    VQ_HIP(hipMemcpyAsync(enc->codes.p, codes, (size_t)n * m, hipMemcpyHostToDevice, s));
+    VQ_HIP(hipMemcpyAsync(enc->codes.p, codes, (size_t)n * m * cw, hipMemcpyHostToDevice, s));
     VQ_TRY(launch_decode_f32(enc->cs.view(), enc->codes.as<uint8_t>(), n, enc->f32buf.as<float>(), s));
     VQ_HIP(hipMemcpyAsync(out, enc->f32buf.p, (size_t)n * d * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipStreamSynchronize(s));

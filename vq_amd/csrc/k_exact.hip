@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kExactBlock) void k_assign_exact(
         const uint64_t row = wl_rows ? (uint64_t)wl_rows[(size_t)s * wl_stride + i] : i;
         const float *xrow = X + row * d + (size_t)s * sd;
         uint32_t best = scan_one<METRIC, SD, GENERIC>(xrow, sd, cbs, cnsq, k);
-        codes[row * m + s] = (uint8_t)best;
+        store_code(codes, row * m + s, best, k);
     }
 }
 
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(1024) void k_recheck_wave(
             bj = take ? oj : bj;
         }
         const bool blocked = __shfl((int)d0_nan, 0) != 0;
-        if (lane == 0) codes[row * m + s] = (uint8_t)((blocked || bj == NONE) ? 0u : bj);
+        if (lane == 0) store_code(codes, row * m + s, (blocked || bj == NONE) ? 0u : bj, k);
     }
 }
 

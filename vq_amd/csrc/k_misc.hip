@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_gather_f16(const float *__restrict__ cb
         const uint64_t row = e / gpr;
         const uint32_t col = (uint32_t)(e - row * gpr) * VEC;
         const uint32_t s = col / sd, t = col - s * sd;
-        const uint32_t code = codes[row * m + s];
+        const uint32_t code = load_code(codes, row * m + s, k);
         const float *src = cb + ((size_t)s * k + code) * sd + t;
         if constexpr (VEC == 8) {
             const float4 a = *reinterpret_cast<const float4 *>(src);
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_decode_f32(const float *__restrict__ cb
         const uint64_t row = e / d;
         const uint32_t col = (uint32_t)(e - row * d);
         const uint32_t s = col / sd, t = col - s * sd;
-        out[e] = cb[((size_t)s * k + codes[row * m + s]) * sd + t];
+        out[e] = cb[((size_t)s * k + load_code(codes, row * m + s, k)) * sd + t];
     }
 }
 

@@ -716,7 +716,9 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
     const float *__restrict__ meta, const uint32_t *__restrict__ sub_list, uint32_t n_sub,
     uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_seg,
     uint32_t n_seg, uint64_t wl_stride, int cosine, uint32_t k_real, const float *__restrict__ cen,
-    uint4 *__restrict__ part) {
+    uint4 *__restrict__ part, uint32_t groups_rt) {
+    // G > 0: compile-time group count (k <= 256); G == 0: k > 256, the count comes in groups_rt
+    const uint32_t groups = (G > 0) ? (uint32_t)G : groups_rt;
     constexpr int DPH = SD / 2;            // dims owned by a lane half
     constexpr int NMF = (6 * DPH + 7) / 8;  // MFMAs per 32x32 tile: 6 term pairs x DPH dims per lane half
     const uint32_t lane = threadIdx.x & 63;
@@ -724,12 +726,12 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;
     const uint32_t total_waves = gridDim.x * kWavesPerBlock;
-    const uint32_t n_virt = n_sub * G;  // (subspace, centroid group) pairs
+    const uint32_t n_virt = n_sub * groups;  // (subspace, centroid group) pairs
     const uint32_t n_chunks = total_waves / n_virt;
     if (gw >= n_chunks * n_virt) return;
     const uint32_t vv = gw % n_virt;
-    const uint32_t s = sub_list[vv / G];
-    const uint32_t grp = vv % G;
+    const uint32_t s = sub_list[vv / groups];
+    const uint32_t grp = vv % groups;
     const uint32_t chunk = gw / n_virt;
     const uint64_t n_steps = (n + 31) / 32;
     const uint64_t steps_per_chunk = (n_steps + n_chunks - 1) / n_chunks;
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
     __shared__ __attribute__((aligned(16))) float lds_cn[kWavesPerBlock][NT32 * 32];
     bf16x8 a[NT32][NMF];
     {
-        const uint32_t *base = prepA32 + ((size_t)s * (NT32 * G) + (size_t)grp * NT32) * NMF * 4 * 64 + lane;
+        const uint32_t *base = prepA32 + ((size_t)s * (NT32 * groups) + (size_t)grp * NT32) * NMF * 4 * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NT32; ++i)
 #pragma unroll
@@ -974,10 +976,10 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
             j = take ? rj[1] : rj[0];
             m1 = take ? b1 : a1;
         }
-        if constexpr (G > 1) {  // this group's verdict per row; the margin test happens after the groups are merged
+        if constexpr (G != 1) {  // this group's verdict per row; the margin test happens after the groups are merged
             const uint64_t prow = st * 32 + p;
             if (h == 0 && prow < n)
-                part[((size_t)s * G + grp) * n + prow] =
+                part[((size_t)s * groups + grp) * n + prow] =
                     make_uint4(__float_as_uint(m1), __float_as_uint(m2), j, __float_as_uint(xs));
             continue;
         }
@@ -1019,7 +1021,8 @@ __global__ __launch_bounds__(256) void k_merge_partials_x32(const uint4 *__restr
                                                             const float *__restrict__ cen, const float *__restrict__ meta,
                                                             int cosine, uint8_t *__restrict__ codes,
                                                             uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_count,
-                                                            uint64_t wl_stride) {
+                                                            uint64_t wl_stride, uint32_t k, uint32_t groups_rt) {
+    const uint32_t groups = (G > 0) ? (uint32_t)G : groups_rt;
     const uint32_t s = sub_list[blockIdx.y];
     const float *cs = cen + (size_t)s * (sd + 4);
     float cmax = cs[sd], tcoef = cs[sd + 1];
@@ -1034,13 +1037,13 @@ __global__ __launch_bounds__(256) void k_merge_partials_x32(const uint4 *__restr
         const uint64_t row = row0 + threadIdx.x;
         bool recheck = false;
         if (row < n) {
-            const uint4 p0 = part[((size_t)s * G) * n + row];
+            const uint4 p0 = part[((size_t)s * groups) * n + row];
             float m1 = __uint_as_float(p0.x), m2 = __uint_as_float(p0.y);
             uint32_t j = p0.z;
             const float xs = __uint_as_float(p0.w);
 #pragma unroll
-            for (int g = 1; g < G; ++g) {
-                const uint4 pg = part[((size_t)s * G + g) * n + row];
+            for (uint32_t g = 1; g < groups; ++g) {
+                const uint4 pg = part[((size_t)s * groups + g) * n + row];
                 const float b1 = __uint_as_float(pg.x), b2 = __uint_as_float(pg.y);
                 const float hi = fmaxf(m1, b1), lo2 = fminf(m2, b2);
                 const bool take = (b1 < m1) || (b1 == m1 && pg.z < j);
@@ -1053,7 +1056,7 @@ __global__ __launch_bounds__(256) void k_merge_partials_x32(const uint4 *__restr
             const float T = tcoef * (cosine ? xnorm : xn * xn) + 1e-35f * xn + 1e-37f;
             bool proven = (m2 - m1 > T) && (fabsf(m1) <= 3.0e38f) && (T <= 3.0e38f);
             if (cosine) proven = proven && (m1 < -T) && (xnorm > 4e-10f);
-            codes[row * m + s] = (uint8_t)j;
+            store_code(codes, row * m + s, j, k);
             recheck = !proven;
         }
         const unsigned long long mask = __ballot(recheck);
@@ -1560,10 +1563,11 @@ int launch_one(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) 
 }
 
 template <int SD, int NT32, int G = 1>
-int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) {
+int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stream, uint32_t groups_rt = 0) {
+    const uint32_t groups = (G > 0) ? (uint32_t)G : groups_rt;  // G == 0: run-time group count (k > 256)
     const uint64_t n_steps = (a.n + 31) / 32;
     const uint32_t waves_per_simd = (NT32 <= 4 && SD <= 16) ? 2 : 1;  // small A images leave room for two
-    const uint32_t n_virt = a.n_sub * G;
+    const uint32_t n_virt = a.n_sub * groups;
     uint64_t want_waves = (uint64_t)num_cus() * kWavesPerBlock * waves_per_simd;
     const uint64_t max_useful = n_steps * n_virt;
     if (want_waves > max_useful) want_waves = max_useful;
@@ -1581,16 +1585,16 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
         a.n_seg = 0;  // the merge kernel appends to the unsegmented list
     }
     hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32, G>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d,
-                       cb.m, cb.prepA32, cb.cn32, NT32 * G * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
+                       cb.m, cb.prepA32, cb.cn32, NT32 * groups * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
                        a.wl_seg, n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen,
-                       reinterpret_cast<uint4 *>(a.part));
+                       reinterpret_cast<uint4 *>(a.part), groups);
     VQ_LAUNCH_CHECK("k_assign_screen_bf16_x32");
-    if (G > 1) {
+    if (G != 1) {
         uint64_t mblocks = (a.n + 255) / 256;
         if (mblocks > (uint64_t)num_cus() * 8) mblocks = (uint64_t)num_cus() * 8;
         hipLaunchKernelGGL((k_merge_partials_x32<G>), dim3((uint32_t)mblocks, a.n_sub), dim3(256), 0, stream,
                            reinterpret_cast<const uint4 *>(a.part), a.n, cb.m, cb.sd, a.sub_list, cb.cen, cb.meta,
-                           a.metric == VQHIP_COSINE ? 1 : 0, a.codes, a.wl_rows, a.wl_count, a.wl_stride);
+                           a.metric == VQHIP_COSINE ? 1 : 0, a.codes, a.wl_rows, a.wl_count, a.wl_stride, cb.k, groups);
         VQ_LAUNCH_CHECK("k_merge_partials_x32");
     }
     return VQHIP_OK;
@@ -1607,7 +1611,7 @@ bool screen_bf16_uses_x32(uint32_t sd, uint32_t k) {
 // tiles of 32 centroids per wave and centroid groups for a shape (0 = no X32 form)
 void screen_bf16_x32_tiling(uint32_t sd, uint32_t k, uint32_t *nt32_per_group, uint32_t *groups) {
     *nt32_per_group = *groups = 0;
-    if (k == 0 || k > 256) return;
+    if (k == 0 || k > kMaxCentroids) return;
     const uint32_t nt = (k + 31) / 32;
     uint32_t cap;  // tiles whose A image fits next to the working set: NMF * cap * 4 registers
     switch (sd) {
@@ -1618,8 +1622,12 @@ void screen_bf16_x32_tiling(uint32_t sd, uint32_t k, uint32_t *nt32_per_group, u
     default: return;
     }
     const uint32_t per = nt < cap ? nt : cap;
+    const uint32_t g = (nt + per - 1) / per;
+    // k > 256 (two-byte codes): more groups of the same kernels, up to kX32MaxGroups; each group costs a
+    // screen pass and a 16-byte partial verdict per row, beyond that the exact scan is the better engine
+    if (k > 256 && g > kX32MaxGroups) return;
     *nt32_per_group = per;
-    *groups = (nt + per - 1) / per;
+    *groups = g;
 }
 
 bool screen_bf16_x32_supported(uint32_t sd, uint32_t k) {
@@ -1700,6 +1708,11 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
         VQ_X32(32, 1) VQ_X32(32, 2) VQ_X32(32, 3) VQ_X32(32, 4) VQ_X32G(32, 4, 2)
         VQ_X32(48, 1) VQ_X32(48, 2) VQ_X32G(48, 2, 2) VQ_X32G(48, 2, 3) VQ_X32G(48, 2, 4)
         VQ_X32(64, 1) VQ_X32(64, 2) VQ_X32G(64, 2, 2) VQ_X32G(64, 2, 3) VQ_X32G(64, 2, 4)
+        // k > 256: full groups, run-time count
+#define VQ_X32R(SDV, NTV) \
+    if (cb.sd == SDV && nt32 == NTV && cb.k > 256) return launch_one_x32<SDV, NTV, 0>(cb, a, stream, groups);
+        VQ_X32R(8, 8) VQ_X32R(12, 8) VQ_X32R(16, 8) VQ_X32R(24, 8) VQ_X32R(32, 4) VQ_X32R(48, 2) VQ_X32R(64, 2)
+#undef VQ_X32R
 #undef VQ_X32
 #undef VQ_X32G
     }

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64) void k_pq_encode_small(const float *__restrict_
     }
     const bool blocked = __shfl((int)d0_nan, 0) != 0;
     const uint32_t best = (blocked || bj == NONE) ? 0u : bj;
-    if (codes && lane == 0) codes[(size_t)row * m + s] = (uint8_t)best;
+    if (codes && lane == 0) store_code(codes, (size_t)row * m + s, best, k);
     if (f16_out) {
         const float *c = cbs + (size_t)best * sd;
         for (uint32_t t = lane; t < sd; t += 64)

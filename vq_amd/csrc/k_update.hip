@@ -36,18 +36,22 @@ constexpr uint32_t kLdsBudgetWords = 38912;  // 152 KiB of the CU's 160 KiB
 template <int VEC>
 __global__ __launch_bounds__(kAccBlock) void k_accumulate(
     const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m, uint32_t k, uint32_t sd,
-    uint32_t spc, uint64_t rows_per_chunk, const uint8_t *__restrict__ codes,
+    uint32_t spc, uint32_t kr, uint64_t rows_per_chunk, const uint8_t *__restrict__ codes,
     const uint8_t *__restrict__ active, float *__restrict__ partial_sums,
     uint32_t *__restrict__ partial_counts) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // cluster range of this workgroup: [k_lo, k_lo + kn).  kr == k (one range) whenever a whole subspace fits
+    // the LDS; otherwise blockIdx.z walks the ranges and rows whose code lies outside are skipped.
+    const uint32_t k_lo = blockIdx.z * kr;
+    const uint32_t kn = (k - k_lo < kr) ? (k - k_lo) : kr;
     const uint32_t s0 = blockIdx.y * spc;
     const uint32_t ns = (m - s0 < spc) ? (m - s0) : spc;
     const uint32_t W = ns * sd;  // floats of a row handled by this workgroup
     const uint32_t rstride = sd + 1;
-    float *sums = lds;                                                             // [ns][k][sd+1]
-    uint32_t *cnts = reinterpret_cast<uint32_t *>(lds + (size_t)spc * k * rstride);  // [ns][k]
-    for (uint32_t e = threadIdx.x; e < ns * k * rstride; e += kAccBlock) sums[e] = 0.0f;
-    for (uint32_t e = threadIdx.x; e < ns * k; e += kAccBlock) cnts[e] = 0u;
+    float *sums = lds;                                                              // [ns][kr][sd+1]
+    uint32_t *cnts = reinterpret_cast<uint32_t *>(lds + (size_t)spc * kr * rstride);  // [ns][kr]
+    for (uint32_t e = threadIdx.x; e < ns * kr * rstride; e += kAccBlock) sums[e] = 0.0f;
+    for (uint32_t e = threadIdx.x; e < ns * kr; e += kAccBlock) cnts[e] = 0u;
     __syncthreads();
 
     const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_chunk;
@@ -62,38 +66,44 @@ __global__ __launch_bounds__(kAccBlock) void k_accumulate(
     const uint32_t s = s0 + ls;
     const bool live = (rr < rpp) && (!active || active[s]);
     if (live) {
-        float *base = sums + (size_t)ls * k * rstride + t;
-        uint32_t *cbase = cnts + ls * k;
+        float *base = sums + (size_t)ls * kr * rstride + t;
+        uint32_t *cbase = cnts + ls * kr;
         const float *px = X + (size_t)s0 * sd + col;
-        const uint8_t *pc = codes + s;
         uint64_t row = r0 + rr;
         // two rows in flight per thread
         for (; row + rpp < r1; row += 2 * (uint64_t)rpp) {
             const uint64_t rowb = row + rpp;
-            const uint32_t ca = pc[row * m], cb2 = pc[rowb * m];
+            // codes relative to the range; out-of-range (unsigned wrap included) rows are another workgroup's
+            const uint32_t ca = load_code(codes, row * m + s, k) - k_lo, cb2 = load_code(codes, rowb * m + s, k) - k_lo;
+            const bool ina = ca < kn, inb = cb2 < kn;
             if constexpr (VEC == 4) {
                 const float4 va = *reinterpret_cast<const float4 *>(px + row * d);
                 const float4 vb = *reinterpret_cast<const float4 *>(px + rowb * d);
                 float *da = base + ca * rstride, *db = base + cb2 * rstride;
-                atomicAdd(da + 0, va.x);
-                atomicAdd(da + 1, va.y);
-                atomicAdd(da + 2, va.z);
-                atomicAdd(da + 3, va.w);
-                atomicAdd(db + 0, vb.x);
-                atomicAdd(db + 1, vb.y);
-                atomicAdd(db + 2, vb.z);
-                atomicAdd(db + 3, vb.w);
+                if (ina) {
+                    atomicAdd(da + 0, va.x);
+                    atomicAdd(da + 1, va.y);
+                    atomicAdd(da + 2, va.z);
+                    atomicAdd(da + 3, va.w);
+                }
+                if (inb) {
+                    atomicAdd(db + 0, vb.x);
+                    atomicAdd(db + 1, vb.y);
+                    atomicAdd(db + 2, vb.z);
+                    atomicAdd(db + 3, vb.w);
+                }
             } else {
-                atomicAdd(base + ca * rstride, px[row * d]);
-                atomicAdd(base + cb2 * rstride, px[rowb * d]);
+                if (ina) atomicAdd(base + ca * rstride, px[row * d]);
+                if (inb) atomicAdd(base + cb2 * rstride, px[rowb * d]);
             }
             if (t == 0) {
-                atomicAdd(cbase + ca, 1u);
-                atomicAdd(cbase + cb2, 1u);
+                if (ina) atomicAdd(cbase + ca, 1u);
+                if (inb) atomicAdd(cbase + cb2, 1u);
             }
         }
         for (; row < r1; row += rpp) {
-            const uint32_t ca = pc[row * m];
+            const uint32_t ca = load_code(codes, row * m + s, k) - k_lo;
+            if (ca >= kn) continue;
             if constexpr (VEC == 4) {
                 const float4 va = *reinterpret_cast<const float4 *>(px + row * d);
                 float *da = base + ca * rstride;
@@ -110,12 +120,15 @@ __global__ __launch_bounds__(kAccBlock) void k_accumulate(
     __syncthreads();
     // partial slab of this row chunk: sums [m][k][sd] (un-padded), counts [m][k]
     float *ps = partial_sums + ((size_t)blockIdx.x * m + s0) * k * sd;
-    for (uint32_t e = threadIdx.x; e < ns * k * sd; e += kAccBlock) {
-        const uint32_t rowi = e / sd, tt = e - rowi * sd;
-        ps[e] = sums[(size_t)rowi * rstride + tt];
+    for (uint32_t e = threadIdx.x; e < ns * kn * sd; e += kAccBlock) {
+        const uint32_t rowi = e / sd, tt = e - rowi * sd, lsi = rowi / kn, j = rowi - lsi * kn;
+        ps[((size_t)lsi * k + k_lo + j) * sd + tt] = sums[((size_t)lsi * kr + j) * rstride + tt];
     }
     uint32_t *pcnt = partial_counts + ((size_t)blockIdx.x * m + s0) * k;
-    for (uint32_t e = threadIdx.x; e < ns * k; e += kAccBlock) pcnt[e] = cnts[e];
+    for (uint32_t e = threadIdx.x; e < ns * kn; e += kAccBlock) {
+        const uint32_t lsi = e / kn, j = e - lsi * kn;
+        pcnt[(size_t)lsi * k + k_lo + j] = cnts[lsi * kr + j];
+    }
 }
 
 // Wave-owned accumulation (the fast path).  LDS float atomics run at ~1 lane per 3 cycles on
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
     auto load_x = [&](uint64_t row) {
         return (lane_on && row < r1) ? *reinterpret_cast<const float4 *>(px + row * d) : make_float4(0, 0, 0, 0);
     };
-    auto load_c = [&](uint64_t row) { return (lane_on && row < r1) ? (uint32_t)codes[row * m + s] : 0xFFFFFFFFu; };
+    auto load_c = [&](uint64_t row) { return (lane_on && row < r1) ? load_code(codes, row * m + s, k) : 0xFFFFFFFFu; };
 
     // HBM latency (~2 us under load) against one 1-KB load per wave limited the first version to
     // 2.1 TB/s; batches of PF steps are double-buffered so a wave keeps 2*PF KB in flight
@@ -314,19 +327,24 @@ int plan_update(uint32_t m, uint32_t k, uint32_t sd, uint64_t n, UpdatePlan *p) 
     p->m = m;
     p->k = k;
     p->sd = sd;
-    const uint64_t per_sub = (uint64_t)k * (sd + 2);  // padded sums + counts
-    if (per_sub > kLdsBudgetWords)
-        return fail(VQHIP_ERR_UNSUPPORTED,
-                    "k*(sub_dim+2)=%llu accumulator words exceed one CU's LDS (%u words)",
-                    (unsigned long long)per_sub, kLdsBudgetWords);
-    uint32_t spc = (uint32_t)(kLdsBudgetWords / per_sub);
-    if (spc > m) spc = m;
     if (sd > 1024) return fail(VQHIP_ERR_UNSUPPORTED, "sub_dim=%u > 1024 in the LDS update kernel", sd);
-    while (spc > 1 && (uint64_t)spc * sd > 1024) --spc;  // one workgroup pass covers >= 1 row
+    const uint64_t per_sub = (uint64_t)k * (sd + 2);  // padded sums + counts
+    uint32_t spc = 1;
+    p->k_range = k;
+    if (per_sub > kLdsBudgetWords) {
+        // a subspace's accumulators do not fit one CU's LDS: split its clusters into ranges, one workgroup
+        // (and one more pass over the rows) per range
+        p->k_range = kLdsBudgetWords / (sd + 2);
+    } else {
+        spc = (uint32_t)(kLdsBudgetWords / per_sub);
+        if (spc > m) spc = m;
+        while (spc > 1 && (uint64_t)spc * sd > 1024) --spc;  // one workgroup pass covers >= 1 row
+    }
+    p->n_k_ranges = (k + p->k_range - 1) / p->k_range;
     p->subs_per_chunk = spc;
     p->n_sub_chunks = (m + spc - 1) / spc;
     uint32_t target = (uint32_t)num_cus();
-    uint32_t rc = target / p->n_sub_chunks;
+    uint32_t rc = target / (p->n_sub_chunks * p->n_k_ranges);
     if (rc < 1) rc = 1;
     // at least ~512 rows per chunk so that the slab write-out stays a small fraction
     uint64_t max_rc = (n + 511) / 512;
@@ -399,8 +417,8 @@ int launch_accumulate(const UpdatePlan &p, const float *X, uint64_t n, uint32_t 
     const uint64_t rows_per_chunk = (n + p.n_row_chunks - 1) / p.n_row_chunks;
     if (rows_per_chunk * (uint64_t)p.subs_per_chunk * p.sd >= (1ull << 32))
         return fail(VQHIP_ERR_UNSUPPORTED, "row chunk too large for 32-bit item index");
-    const size_t lds_bytes = ((size_t)p.subs_per_chunk * p.k * (p.sd + 2)) * 4;
-    dim3 grid(p.n_row_chunks, p.n_sub_chunks);
+    const size_t lds_bytes = ((size_t)p.subs_per_chunk * p.k_range * (p.sd + 2)) * 4;
+    dim3 grid(p.n_row_chunks, p.n_sub_chunks, p.n_k_ranges);
     const bool vec4 = (p.sd % 4 == 0) && aligned;
     if (vec4) {
         static PerDeviceOnce attr_set4;
@@ -410,7 +428,7 @@ int launch_accumulate(const UpdatePlan &p, const float *X, uint64_t n, uint32_t 
             attr_set4.done();
         }
         hipLaunchKernelGGL(k_accumulate<4>, grid, dim3(kAccBlock), lds_bytes, stream, X, n, d, p.m,
-                           p.k, p.sd, p.subs_per_chunk, rows_per_chunk, codes, active, partial_sums,
+                           p.k, p.sd, p.subs_per_chunk, p.k_range, rows_per_chunk, codes, active, partial_sums,
                            partial_counts);
     } else {
         static PerDeviceOnce attr_set1;
@@ -420,7 +438,7 @@ int launch_accumulate(const UpdatePlan &p, const float *X, uint64_t n, uint32_t 
             attr_set1.done();
         }
         hipLaunchKernelGGL(k_accumulate<1>, grid, dim3(kAccBlock), lds_bytes, stream, X, n, d, p.m,
-                           p.k, p.sd, p.subs_per_chunk, rows_per_chunk, codes, active, partial_sums,
+                           p.k, p.sd, p.subs_per_chunk, p.k_range, rows_per_chunk, codes, active, partial_sums,
                            partial_counts);
     }
     VQ_LAUNCH_CHECK("k_accumulate");
@@ -465,49 +483,69 @@ int launch_gather_rows(const float *X, uint32_t d, uint32_t m, uint32_t k, uint3
 // latency-bound (N/k dependent adds per lane, 32 row gathers in flight), ~0.5 ms at C2.
 namespace {
 
-constexpr uint32_t kXsChunks = 1024;  // row chunks of the bucket passes
+constexpr uint32_t kXsChunks = 1024;     // row chunks of the bucket passes
+constexpr uint32_t kXsMaxK = 16384;      // hist / cursor words of one workgroup (64 KiB of LDS)
+// fewer chunks for large m*k so that the [chunks][m][k] offset table stays <= 256 MiB
+static uint32_t xs_chunk_cap(uint32_t m, uint32_t k) {
+    const uint64_t cap = (64ull << 20) / std::max<uint64_t>(1, (uint64_t)m * k);
+    return (uint32_t)std::min<uint64_t>(kXsChunks, std::max<uint64_t>(1, cap));
+}
 
 __global__ __launch_bounds__(256) void k_chunk_counts(const uint8_t *__restrict__ codes, uint64_t n,
                                                       uint32_t m, uint32_t k, uint64_t rows_per_chunk,
                                                       const uint8_t *__restrict__ active,
                                                       uint32_t *__restrict__ chunk_counts) {
-    __shared__ uint32_t hist[256];
+    extern __shared__ uint32_t hist[];  // [k]
     const uint32_t s = blockIdx.y;
-    hist[threadIdx.x] = 0;
+    for (uint32_t j = threadIdx.x; j < k; j += 256) hist[j] = 0;
     __syncthreads();
     if (!active || active[s]) {
         const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_chunk;
         uint64_t r1 = r0 + rows_per_chunk;
         if (r1 > n) r1 = n;
-        for (uint64_t r = r0 + threadIdx.x; r < r1; r += 256) atomicAdd(&hist[codes[r * m + s]], 1u);
+        for (uint64_t r = r0 + threadIdx.x; r < r1; r += 256) atomicAdd(&hist[load_code(codes, r * m + s, k)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < k) chunk_counts[((size_t)blockIdx.x * m + s) * k + threadIdx.x] = hist[threadIdx.x];
+    for (uint32_t j = threadIdx.x; j < k; j += 256) chunk_counts[((size_t)blockIdx.x * m + s) * k + j] = hist[j];
 }
 
 // chunk_counts [chunks][m][k] -> in place: write offset of (chunk, s, j) inside members[s][..];
 // start [m][k+1]: first member of cluster j (start[s][k] = rows of the subspace)
 __global__ __launch_bounds__(256) void k_bucket_offsets(uint32_t *__restrict__ chunk_counts, uint32_t n_chunks,
                                                         uint32_t m, uint32_t k, uint32_t *__restrict__ start) {
-    __shared__ uint32_t tot[256];
-    const uint32_t s = blockIdx.x, j = threadIdx.x;
-    uint32_t total = 0;
-    if (j < k)
+    extern __shared__ uint32_t tot[];  // [k] cluster totals, then their exclusive scan
+    __shared__ uint32_t seg[256];
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t j = tid; j < k; j += 256) {
+        uint32_t total = 0;
         for (uint32_t c = 0; c < n_chunks; ++c) total += chunk_counts[((size_t)c * m + s) * k + j];
-    tot[j] = (j < k) ? total : 0;
+        tot[j] = total;
+    }
     __syncthreads();
-    // exclusive scan over clusters (k <= 256)
+    // exclusive scan over clusters: thread `tid` owns the contiguous run [tid*per, tid*per + per)
+    const uint32_t per = (k + 255) / 256;
+    const uint32_t j0 = tid * per, j1 = (j0 + per < k) ? (j0 + per) : k;
+    uint32_t run_sum = 0;
+    for (uint32_t j = j0; j < j1; ++j) run_sum += tot[j];
+    seg[tid] = run_sum;
+    __syncthreads();
     for (uint32_t off = 1; off < 256; off <<= 1) {
-        const uint32_t t = (j >= off) ? tot[j - off] : 0u;
+        const uint32_t t = (tid >= off) ? seg[tid - off] : 0u;
         __syncthreads();
-        tot[j] += t;
+        seg[tid] += t;
         __syncthreads();
     }
-    const uint32_t first = tot[j] - total;
-    if (j < k) {
-        start[s * (k + 1) + j] = first;
-        if (j == k - 1) start[s * (k + 1) + k] = tot[j];
-        uint32_t run = first;
+    uint32_t first = seg[tid] - run_sum;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uint32_t total = tot[j];
+        tot[j] = first;
+        first += total;
+    }
+    if (tid == 255) start[s * (k + 1) + k] = seg[255];
+    __syncthreads();
+    for (uint32_t j = tid; j < k; j += 256) {
+        uint32_t run = tot[j];
+        start[s * (k + 1) + j] = run;
         for (uint32_t c = 0; c < n_chunks; ++c) {
             uint32_t *p = &chunk_counts[((size_t)c * m + s) * k + j];
             const uint32_t cnt = *p;
@@ -523,7 +561,7 @@ __global__ __launch_bounds__(64) void k_bucket_scatter(const uint8_t *__restrict
                                                        const uint8_t *__restrict__ active,
                                                        const uint32_t *__restrict__ offsets,
                                                        uint32_t *__restrict__ members, uint64_t members_stride) {
-    __shared__ uint32_t cur[256];
+    extern __shared__ uint32_t cur[];  // [k]
     const uint32_t s = blockIdx.y, lane = threadIdx.x;
     if (active && !active[s]) return;
     for (uint32_t j = lane; j < k; j += 64) cur[j] = offsets[((size_t)blockIdx.x * m + s) * k + j];
@@ -533,7 +571,7 @@ __global__ __launch_bounds__(64) void k_bucket_scatter(const uint8_t *__restrict
     uint32_t *dst = members + (size_t)s * members_stride;
     for (uint64_t base = r0; base < r1; base += 64) {
         const uint64_t row = base + lane;
-        const uint32_t code = (row < r1) ? (uint32_t)codes[row * m + s] : 0xFFFFFFFFu;
+        const uint32_t code = (row < r1) ? load_code(codes, row * m + s, k) : 0xFFFFFFFFu;
         uint32_t rank = 0, later = 0;
 #pragma unroll
         for (uint32_t q = 0; q < 64; ++q) {
@@ -587,26 +625,26 @@ __global__ __launch_bounds__(256) void k_chain_sums(const float *__restrict__ X,
 }  // namespace
 
 size_t exact_sums_workspace_bytes(uint32_t m, uint32_t k, uint64_t n) {
-    return ((size_t)m * n + (size_t)kXsChunks * m * k + (size_t)m * (k + 1)) * 4 + 256;
+    return ((size_t)m * n + (size_t)xs_chunk_cap(m, k) * m * k + (size_t)m * (k + 1)) * 4 + 256;
 }
 
 int launch_exact_sums(uint32_t m, uint32_t k, uint32_t sd, const float *X, uint64_t n, uint32_t d,
                       const uint8_t *codes, const uint8_t *active, void *workspace, size_t workspace_bytes,
                       double *slab, hipStream_t stream) {
-    if (k > 256) return fail(VQHIP_ERR_UNSUPPORTED, "exact update needs k <= 256");
+    if (k > kXsMaxK) return fail(VQHIP_ERR_UNSUPPORTED, "exact update needs k <= %u", kXsMaxK);
     if (workspace_bytes < exact_sums_workspace_bytes(m, k, n)) return fail(VQHIP_ERR_FAILURE, "exact-update workspace too small");
     uint32_t *members = reinterpret_cast<uint32_t *>(workspace);
     uint32_t *chunk_counts = members + (size_t)m * n;
-    uint32_t *start = chunk_counts + (size_t)kXsChunks * m * k;
-    uint32_t n_chunks = (uint32_t)std::min<uint64_t>(kXsChunks, (n + 255) / 256);
+    uint32_t *start = chunk_counts + (size_t)xs_chunk_cap(m, k) * m * k;
+    uint32_t n_chunks = (uint32_t)std::min<uint64_t>(xs_chunk_cap(m, k), (n + 255) / 256);
     if (n_chunks < 1) n_chunks = 1;
     const uint64_t rows_per_chunk = (n + n_chunks - 1) / n_chunks;
-    hipLaunchKernelGGL(k_chunk_counts, dim3(n_chunks, m), dim3(256), 0, stream, codes, n, m, k, rows_per_chunk, active,
+    hipLaunchKernelGGL(k_chunk_counts, dim3(n_chunks, m), dim3(256), (size_t)k * 4, stream, codes, n, m, k, rows_per_chunk, active,
                        chunk_counts);
     VQ_LAUNCH_CHECK("k_chunk_counts");
-    hipLaunchKernelGGL(k_bucket_offsets, dim3(m), dim3(256), 0, stream, chunk_counts, n_chunks, m, k, start);
+    hipLaunchKernelGGL(k_bucket_offsets, dim3(m), dim3(256), (size_t)k * 4, stream, chunk_counts, n_chunks, m, k, start);
     VQ_LAUNCH_CHECK("k_bucket_offsets");
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(n_chunks, m), dim3(64), 0, stream, codes, n, m, k, rows_per_chunk, active,
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(n_chunks, m), dim3(64), (size_t)k * 4, stream, codes, n, m, k, rows_per_chunk, active,
                        chunk_counts, members, n);
     VQ_LAUNCH_CHECK("k_bucket_scatter");
     const uint32_t total = m * k * sd;

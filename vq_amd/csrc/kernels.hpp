@@ -6,6 +6,21 @@
 
 namespace vqhip {
 
+// ---- code width --------------------------------------------------------------------
+// A code is one byte per (row, subspace) while k <= 256 and a little-endian u16 above; every buffer the
+// ABI types `uint8_t *codes` holds n*m*code_bytes(k) bytes. The width is a function of k alone so that no
+// kernel needs an extra argument for it.
+__host__ __device__ __forceinline__ uint32_t code_bytes(uint32_t k) { return k <= 256u ? 1u : 2u; }
+__device__ __forceinline__ uint32_t load_code(const uint8_t *codes, size_t i, uint32_t k) {
+    return k <= 256u ? (uint32_t)codes[i] : (uint32_t)reinterpret_cast<const uint16_t *>(codes)[i];
+}
+__device__ __forceinline__ void store_code(uint8_t *codes, size_t i, uint32_t j, uint32_t k) {
+    if (k <= 256u) codes[i] = (uint8_t)j;
+    else reinterpret_cast<uint16_t *>(codes)[i] = (uint16_t)j;
+}
+constexpr uint32_t kMaxCentroids = 65536;
+constexpr uint32_t kX32MaxGroups = 16;  // centroid groups of the bf16 X32 screen at k > 256
+
 // ---- prepared codebook ------------------------------------------------------------
 // Device-side view of m codebooks of k centroids of sub_dim floats, plus what the
 // assignment kernels derive from it once per codebook change.
@@ -85,6 +100,8 @@ int launch_distance_batch(int metric, const float *a, const float *b, uint64_t n
 struct UpdatePlan {
     uint32_t m = 0, k = 0, sd = 0;
     uint32_t subs_per_chunk = 0;  // subspaces whose accumulators share one workgroup's LDS
+    uint32_t k_range = 0;         // clusters per workgroup (= k unless k*(sd+2) words exceed the LDS)
+    uint32_t n_k_ranges = 1;
     uint32_t n_sub_chunks = 0;
     uint32_t n_row_chunks = 0;
     uint32_t owned_waves = 0;     // > 0: wave-owned (atomic-free) accumulate, subspaces per workgroup

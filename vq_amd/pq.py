@@ -221,10 +221,11 @@ class ProductQuantizer:
         return self._enc.encode(X, want_codes=False, want_f16=True)[1]
 
     def encode(self, X) -> np.ndarray:
-        """(n, dim) float32 -> (n, m) uint8 codes: ``best_idx`` per subspace (src/pq.rs:183-191)"""
+        """(n, dim) float32 -> (n, m) codes: ``best_idx`` per subspace (src/pq.rs:183-191); uint8 while
+        k <= 256, uint16 above"""
         X = self._check_batch(X)
         if X.shape[0] == 0:
-            return np.empty((0, self._m), np.uint8)
+            return np.empty((0, self._m), _lib.code_dtype(self._k))
         return self._enc.encode(X, want_codes=True, want_f16=False)[0]
 
     def search(self, codes, queries, topk: int = 10):
@@ -236,6 +237,8 @@ class ProductQuantizer:
             q = q[None, :]
         if q.shape[1] != self._dim:
             raise DimensionMismatch(self._dim, q.shape[1])
+        if self._k > 256:
+            raise InvalidParameter("k", "the ADC scan reads one-byte codes: k must be at most 256")
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         if codes.ndim != 2 or codes.shape[1] != self._m:
             raise DimensionMismatch(self._m, codes.shape[1] if codes.ndim == 2 else codes.size)
@@ -246,5 +249,5 @@ class ProductQuantizer:
         return self._enc.adc_search(codes, q, int(topk))
 
     def decode(self, codes) -> np.ndarray:
-        """(n, m) uint8 -> (n, dim) float32 centroids (un-rounded)"""
+        """(n, m) codes -> (n, dim) float32 centroids (un-rounded)"""
         return self._enc.decode(codes)
