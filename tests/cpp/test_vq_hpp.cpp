@@ -5,6 +5,8 @@
 //                                      Python mirror to compare (tests/test_cpp_host.py)
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cmath>
 #include <fstream>
 #include <iostream>
 
@@ -116,6 +118,28 @@ static int run(const char *in_path, const char *out_path) {
     put(leaf.data(), leaf.size() * 4);
     const auto tq = tree.quantize(X.data() + dim, dim);
     put(tq.data(), tq.size() * 2);
+
+    // more than 256 centroids: two-byte codes behind encode_wide, consistent with the f16 output
+    if (n >= 300) {
+        vq::ProductQuantizer wide(X.data(), n, dim, m, 300, 2, Distance::SquaredEuclidean, h[5]);
+        EXPECT(wide.num_centroids() == 300);
+        EXPECT(error_of([&] { wide.encode(X.data(), 4); }).find("encode_wide") != std::string::npos);
+        const std::size_t nw = std::min<std::size_t>(n, 200), sd = dim / m;
+        const auto wc = wide.encode_wide(X.data(), nw);
+        const auto wq = wide.quantize_batch(X.data(), nw);
+        bool same = wc.size() == nw * m, high = false;
+        for (std::size_t i = 0; same && i < nw; ++i)
+            for (std::size_t s2 = 0; s2 < m; ++s2) {
+                const std::uint32_t c = wc[i * m + s2];
+                if (c >= 300) { same = false; break; }
+                high = high || c > 255;
+                const float *cen = wide.codebooks().data() + (s2 * 300 + c) * sd;
+                for (std::size_t t = 0; t < sd; ++t)
+                    same = same && std::fabs(wq[i * dim + s2 * sd + t].to_f32() - cen[t]) <= std::fabs(cen[t]) * 0.0005f + 1e-7f;  // half rounding
+            }
+        EXPECT(same);
+        EXPECT(high);
+    }
 
     // k = N distinct rows: every row is its own centroid (tests/regression_tests.rs:357-363)
     std::vector<std::vector<float>> two = {{1, 2, 3, 4}, {5, 6, 7, 8}};
