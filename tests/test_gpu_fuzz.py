@@ -99,6 +99,80 @@ def test_fuzz_lloyd_step(oracle, seed):
     ds.close()
 
 
+WIDE_K = [257, 300, 511, 512, 777, 1024, 1500, 2048, 3000]
+
+
+@pytest.mark.parametrize("seed", range(24 * SCALE))
+def test_fuzz_pq_encode_wide(oracle, seed):
+    """k > 256: two-byte codes; the grouped X32 screen (AUTO) and the exact engine against the oracle"""
+    rng = np.random.default_rng(5000 + seed)
+    sd = int(rng.choice([3, 4, 8, 12, 16, 16, 24, 32, 48, 64]))
+    m = int(rng.choice([1, 2, 4]))
+    d = sd * m
+    k = int(rng.choice(WIDE_K))
+    n = int(rng.integers(1, 1500))
+    kind = KINDS[int(rng.integers(0, len(KINDS)))]
+    metric = int(rng.integers(0, 4))
+    X = _draw_data(rng, n, d, kind)
+    if rng.random() < 0.5 and n >= k:
+        cb = np.stack([X[rng.choice(n, k, replace=False), s * sd:(s + 1) * sd] for s in range(m)])
+    else:
+        cb = _draw_data(rng, m * k, sd, kind).reshape(m, k, sd)
+    if rng.random() < 0.3:
+        cb[:, k - 1] = cb[:, 0]
+    cb = np.ascontiguousarray(cb, F)
+    enc = _lib.PQEncoder(cb, metric)
+    want_c, want_f = oracle.pq_encode(metric, X, cb, threads=0)
+    for engine in (_lib.ENGINE_AUTO, _lib.ENGINE_EXACT):
+        enc.set_engine(engine)
+        codes, f16 = enc.encode(X)
+        assert codes.dtype == np.uint16
+        np.testing.assert_array_equal(codes.astype(np.uint32), want_c, err_msg=f"sd={sd} m={m} k={k} n={n} {kind} metric={metric} engine={engine}")
+        same = (f16.view(np.uint16) == want_f) | (np.isnan(f16) & np.isnan(want_f.view(np.float16)))
+        assert same.all()
+    enc.close()
+
+
+@pytest.mark.parametrize("seed", range(10 * SCALE))
+def test_fuzz_lloyd_step_wide(oracle, seed):
+    rng = np.random.default_rng(6000 + seed)
+    sd = int(rng.choice([2, 4, 8, 12, 16, 24, 32, 48, 64, 128]))
+    m = int(rng.choice([1, 2, 4]))
+    d = sd * m
+    k = int(rng.choice(WIDE_K))
+    n = int(rng.integers(k, 3 * k + 2000))
+    kind = KINDS[int(rng.integers(0, len(KINDS)))]
+    exact = bool(rng.random() < 0.5)
+    X = _draw_data(rng, n, d, kind)
+    init = np.stack([rng.choice(n, k, replace=False) for _ in range(m)]).astype(np.uint64)
+    ds = _lib.Dataset.from_host(X)
+    km = _lib.KMeans(ds, m, k)
+    km.set_exact_update(exact)
+    km.init_from_rows(init)
+    counts, changed = km.step()
+    cent = km.get_centroids()
+    assign = km.get_assignments()
+    for s in range(m):
+        c0 = X[init[s].astype(np.int64), s * sd:(s + 1) * sd]
+        c1, a_ref, n_ref, ch_ref = oracle.lloyd_step(X[:, s * sd:(s + 1) * sd], c0, threads=0)
+        msg = f"sd={sd} m={m} k={k} n={n} {kind} exact={exact}"
+        np.testing.assert_array_equal(assign[:, s].astype(np.uint32), a_ref, err_msg=msg)
+        np.testing.assert_array_equal(counts[s], n_ref, err_msg=msg)
+        ne = n_ref > 0
+        if exact:
+            assert cent[s][ne].tobytes() == c1[ne].tobytes(), msg
+            assert bool(changed[s]) == ch_ref
+        else:  # blocked f32 partial sums combined in f64: DESIGN.md "centroid tolerance"
+            # (relative to the column's magnitude: the summands, not the mean, set the rounding error)
+            with np.errstate(all="ignore"):
+                scale = np.maximum(1.0, np.abs(X[:, s * sd:(s + 1) * sd]).max(axis=0))[None, :]
+                err = np.abs(cent[s][ne] - c1[ne]) / scale
+            fin = np.isfinite(c1[ne])
+            assert (err[fin] <= 1e-5).all(), msg
+    km.close()
+    ds.close()
+
+
 @pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_fuzz_tsvq(oracle, seed):
     rng = np.random.default_rng(3000 + seed)
