@@ -136,8 +136,15 @@ def main():
         print("bench.py needs a MI355X (no GPU visible); there is no CPU fallback", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # VQ_BENCH_FORCE_COMM=1: keep the per-iteration RCCL all-reduce on for a single rank (measures what the
+    # collective path adds to an iteration without a second GPU)
+    force_comm = world == 1 and os.environ.get("VQ_BENCH_FORCE_COMM") == "1"
+    if world > 1 or force_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        if force_comm:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     _lib.load()
     _lib.set_device(local_rank)
@@ -156,7 +163,7 @@ def main():
         ds = _lib.Dataset.synthetic(n, DIM, DATA_SEED, rank * n)
 
         # ---- codebooks: a few (untimed) global Lloyd iterations from strided init rows ----
-        comm = Comm()
+        comm = Comm(force=force_comm)
         shard = HipShard(ds, M, K, rank * n, engine)
         skm = ShardedKMeans(shard, n_global, comm)
         init = np.array([[(j * (n_global // K) + s) % n_global for j in range(K)] for s in range(M)], np.int64)
@@ -315,7 +322,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(M, K, DIM, codebooks)
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_comm:
         dist.destroy_process_group()
 
 

@@ -899,7 +899,7 @@ int vqhip_kmeans_finalize(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) 
     hipStream_t s;
     VQ_TRY(current_stream(&s));
     VQ_TRY(kmeans_finalize_enqueue(km, s));
-    VQ_HIP(hipStreamSynchronize(s));
+    VQ_TRY(spin_wait(s));  // a parked thread wakes ~100 us late; an iteration is 0.1-10 ms
     kmeans_finalize_collect(km, counts, changed);
     return VQHIP_OK;
     VQ_API_END
@@ -926,7 +926,7 @@ int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
     if (!kmeans_graph_eligible(km)) {
         VQ_TRY(kmeans_accumulate_enqueue(km, s));
         VQ_TRY(kmeans_finalize_enqueue(km, s));
-        VQ_HIP(hipStreamSynchronize(s));
+        VQ_TRY(spin_wait(s));
         kmeans_finalize_collect(km, counts, changed);
         return VQHIP_OK;
     }
