@@ -28,6 +28,24 @@ def test_index_roundtrip_and_mmap(tmp_path):
         assert back.distance == Distance.cosine() and (back.m, back.k, back.dim, len(back)) == (4, 16, 12, 500)
 
 
+def test_index_with_more_than_256_centroids_keeps_two_byte_codes(tmp_path):
+    rng = np.random.default_rng(5)
+    m, k, sd, n = 3, 700, 2, 400
+    codes = rng.integers(0, k, (n, m))
+    codes[0] = k - 1
+    idx = PQIndex(rng.standard_normal((m, k, sd)).astype(F), codes)
+    assert idx.codes.dtype == np.dtype("<u2")
+    p = tmp_path / "wide.vqpq"
+    idx.save(p)
+    assert p.stat().st_size == idx.nbytes == 32 + m * k * sd * 4 + n * m * 2
+    for mm in (False, True):
+        back = PQIndex.load(p, mmap_codes=mm)
+        np.testing.assert_array_equal(np.asarray(back.codes), codes)
+        np.testing.assert_array_equal(back.reconstruct([0])[0], np.concatenate([idx.codebooks[s][k - 1] for s in range(m)]))
+    with pytest.raises(ValueError, match="out of range"):
+        PQIndex(idx.codebooks, np.full((2, m), k))
+
+
 def test_index_reconstruct_is_the_reference_quantize_output():
     idx = _index()
     rec = idx.reconstruct()

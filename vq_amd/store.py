@@ -14,7 +14,8 @@ File layout (little endian), stable and trivially readable from C / Rust:
     20  4   u32    k
     24  8   u64    n
     32  ..  f32    codebooks [m][k][dim/m]
-    ..  ..  u8     codes     [n][m]
+    ..  ..  u8     codes     [n][m]        (k <= 256)
+            u16    codes     [n][m]        (256 < k <= 65536, little endian; the library's code width)
 """
 from __future__ import annotations
 
@@ -28,18 +29,23 @@ MAGIC = b"VQPQIDX1"
 _HEADER = struct.Struct("<8sIIIIQ")
 
 
+def _code_dtype(k: int):
+    return np.dtype(np.uint8) if k <= 256 else np.dtype("<u2")
+
+
 class PQIndex:
     def __init__(self, codebooks: np.ndarray, codes: np.ndarray, distance: Distance | None = None):
         cb = np.ascontiguousarray(codebooks, dtype=np.float32)
         if cb.ndim != 3:
             raise ValueError("codebooks must have shape (m, k, sub_dim)")
-        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        if cb.shape[1] > 65536:
+            raise ValueError("codes are at most two bytes: k <= 65536")
+        codes = np.asarray(codes)
         if codes.ndim != 2 or codes.shape[1] != cb.shape[0]:
             raise ValueError(f"codes must have shape (n, {cb.shape[0]})")
-        if cb.shape[1] > 256:
-            raise ValueError("one-byte codes need k <= 256")
-        if codes.size and int(codes.max()) >= cb.shape[1]:
+        if codes.size and (int(codes.min()) < 0 or int(codes.max()) >= cb.shape[1]):
             raise ValueError("code out of range for the codebooks")
+        codes = np.ascontiguousarray(codes, dtype=_code_dtype(cb.shape[1]))
         self.codebooks, self.codes = cb, codes
         self.distance = distance if distance is not None else Distance.euclidean()
 
@@ -106,20 +112,21 @@ class PQIndex:
             magic, metric, dim, m, k, n = _HEADER.unpack(head)
             if magic != MAGIC:
                 raise ValueError("not a VQPQIDX1 file")
-            if m == 0 or k == 0 or k > 256 or dim == 0 or dim % m != 0 or metric > 3:
+            if m == 0 or k == 0 or k > 65536 or dim == 0 or dim % m != 0 or metric > 3:
                 raise ValueError("corrupt index header")
             sd = dim // m
             cb = np.frombuffer(f.read(m * k * sd * 4), dtype="<f4")
             if cb.size != m * k * sd:
                 raise ValueError("truncated codebooks")
             off = f.tell()
+            cdt = _code_dtype(k)
             if mmap_codes:
-                codes = np.memmap(path, dtype=np.uint8, mode="r", offset=off, shape=(n, m))
+                codes = np.memmap(path, dtype=cdt, mode="r", offset=off, shape=(n, m))
             else:
-                raw = f.read(n * m)
-                if len(raw) != n * m:
+                raw = f.read(n * m * cdt.itemsize)
+                if len(raw) != n * m * cdt.itemsize:
                     raise ValueError("truncated codes")
-                codes = np.frombuffer(raw, dtype=np.uint8).reshape(n, m)
+                codes = np.frombuffer(raw, dtype=cdt).reshape(n, m)
         names = ["squared_euclidean", "euclidean", "manhattan", "cosine"]
         self = cls.__new__(cls)
         self.codebooks = cb.reshape(m, k, sd).astype(np.float32)
