@@ -666,7 +666,8 @@ constexpr uint32_t kFsCols = 32;         // columns per workgroup (one 128-byte 
 constexpr uint32_t kFsMinRows = 16384;   // shorter nodes keep the plain sequential kernel
 
 struct FsTile {
-    uint32_t node, t;  // node id, tile index inside the node
+    uint32_t node, t;      // node id, tile index inside the node
+    uint32_t start, rows;  // position of the tile's first row in perm, rows in the tile (<= kFsTile)
 };
 struct FsSumm {
     int32_t d0, d1, lo0, hi0, lo1, hi1, e, flag;  // flag != 0: no usable summary
@@ -686,9 +687,10 @@ __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ 
                                                       const FsTile *__restrict__ tiles, NodeArrays na,
                                                       double *__restrict__ tile_sum) {
     __shared__ double part[32][kFsCols + 1];
-    const FsTile tl = tiles[blockIdx.x];
-    const uint32_t a = na.seg_start[tl.node], len = na.seg_len[tl.node];
-    const uint32_t c0 = blockIdx.y * kFsCols, q = threadIdx.x & 7, rr = threadIdx.x >> 3;
+    // 1-D grid, column block fastest: the d/32 workgroups that share a tile's rows (and DRAM pages) run together
+    const uint32_t ncb = d / kFsCols, tile_id = blockIdx.x / ncb, cblk = blockIdx.x - tile_id * ncb;
+    const FsTile tl = tiles[tile_id];
+    const uint32_t c0 = cblk * kFsCols, q = threadIdx.x & 7, rr = threadIdx.x >> 3;
     float mu[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 1) {
 #pragma unroll
@@ -697,9 +699,9 @@ __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ 
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
     for (uint32_t i = 0; i < kFsTile / 32; ++i) {
-        const uint32_t r = tl.t * kFsTile + rr + 32 * i;
-        if (r < len) {
-            const float4 v = *reinterpret_cast<const float4 *>(X + (size_t)perm[a + r] * d + c0 + 4 * q);
+        const uint32_t r = rr + 32 * i;
+        if (r < tl.rows) {
+            const float4 v = *reinterpret_cast<const float4 *>(X + (size_t)perm[tl.start + r] * d + c0 + 4 * q);
             acc[0] += (double)fs_value<MODE>(v.x, mu[0]);
             acc[1] += (double)fs_value<MODE>(v.y, mu[1]);
             acc[2] += (double)fs_value<MODE>(v.z, mu[2]);
@@ -712,7 +714,7 @@ __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ 
     if (threadIdx.x < kFsCols) {
         double s = 0.0;
         for (int r = 0; r < 32; ++r) s += part[r][threadIdx.x];
-        tile_sum[(size_t)blockIdx.x * d + c0 + threadIdx.x] = s;
+        tile_sum[(size_t)tile_id * d + c0 + threadIdx.x] = s;
     }
 }
 
@@ -742,14 +744,17 @@ struct FsAcc {  // transducer summary of a run of rows: for even / odd incoming 
     long long d[2], lo[2], hi[2];
 };
 
-// summaries of all tiles in parallel, under the binade guessed from the f64 prefix.  Phase 1: the
-// workgroup fetches its 512 x 32 tile with 16 independent 16-byte loads per thread (whole 128-byte
-// lines) and parks the addends column-major in LDS; phase 2: thread (column, segment) folds its 64
-// addends from LDS into the parity transducer.
+// summaries of all tiles in parallel, under the binade guessed from the f64 prefix.  Persistent workgroups
+// (two per CU: the 512 x 32 tile takes 66 KB of LDS) walk the (tile, column block) items.  Per item: the
+// 16 independent 16-byte loads per thread (whole 128-byte lines) fetched during the PREVIOUS item are
+// parked column-major in LDS, then thread (column, segment) folds its 64 addends from LDS into the parity
+// transducer.  The next item's loads are issued inside that fold -- perm indices first, the rows they
+// name half-way through -- so the two dependent HBM round trips hide behind the arithmetic (a workgroup
+// that did load, park, fold in sequence spent 2/3 of its time waiting: 265 -> 1xx us per pass at 1M x 128).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ X, uint32_t d,
                                                       const uint32_t *__restrict__ perm,
-                                                      const FsTile *__restrict__ tiles, NodeArrays na,
+                                                      const FsTile *__restrict__ tiles, uint32_t n_items, NodeArrays na,
                                                       const double *__restrict__ tile_pref,
                                                       FsSumm *__restrict__ summ, float *__restrict__ side,
                                                       uint32_t side_cap, uint32_t *__restrict__ side_count) {
@@ -758,61 +763,94 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
     FsAcc(*seg_acc)[kFsCols] = reinterpret_cast<FsAcc(*)[kFsCols]>(fs_lds + kFsCols * (kFsTile + 1) * 4);  // [8][32]
     __shared__ int seg_bad[8][kFsCols];
     __shared__ int col_slot[kFsCols];
-    const FsTile tl = tiles[blockIdx.x];
-    const uint32_t a = na.seg_start[tl.node], len = na.seg_len[tl.node];
-    const uint32_t row0 = tl.t * kFsTile, rows = min(kFsTile, len - row0);
-    const uint32_t c0 = blockIdx.y * kFsCols;
-    {   // phase 1
-        const uint32_t q = threadIdx.x & 7, rr = threadIdx.x >> 3;
-        float mu4[4] = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t ncb = d / kFsCols;
+    const uint32_t q = threadIdx.x & 7, rr = threadIdx.x >> 3;     // load role: 16-byte part q of rows rr + 32 i
+    const uint32_t cl = threadIdx.x & 31, seg = threadIdx.x >> 5;  // fold role: column cl, rows 64 seg ..
+    uint32_t item = blockIdx.x;
+    if (item >= n_items) return;
+    uint32_t prow[16];
+    float4 v[16];
+    float mu4[4] = {0.f, 0.f, 0.f, 0.f};
+    double pref;
+    auto issue_perm = [&](const FsTile &t, uint32_t it) {  // indices, means and the f64 guess of item `it`
+        const uint32_t tid = it / ncb, c0n = (it - tid * ncb) * kFsCols;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t r = rr + 32 * i;
+            prow[i] = perm[t.start + min(r, t.rows - 1u)];  // clamped, not predicated: rows past the end park as zeros
+        }
         if (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mu4[i] = na.centroid[(size_t)tl.node * d + c0 + 4 * q + i];
+            for (int i = 0; i < 4; ++i) mu4[i] = na.centroid[(size_t)t.node * d + c0n + 4 * q + i];
         }
-        uint32_t prow[16];
+        pref = tile_pref[(size_t)tid * d + c0n + cl];
+    };
+    auto issue_rows = [&](uint32_t it) {
+        const uint32_t tid = it / ncb, c0n = (it - tid * ncb) * kFsCols;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (size_t)prow[i] * d + c0n + 4 * q);
+    };
+    FsTile tl = tiles[item / ncb];
+    issue_perm(tl, item);
+    issue_rows(item);
+    uint32_t next = item + gridDim.x;
+    FsTile tl_next = tiles[(next < n_items ? next : item) / ncb];
+  for (;;) {
+    const uint32_t tile_id = item / ncb, c0 = (item - tile_id * ncb) * kFsCols;
+    const uint32_t rows = tl.rows;
+    {   // park the fetched rows (waits for the loads issued during the previous item)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const uint32_t r = rr + 32 * i;
-            prow[i] = (r < rows) ? perm[a + row0 + r] : 0u;
-        }
-        float4 v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (size_t)prow[i] * d + c0 + 4 * q);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t r = rr + 32 * i;
-            lds_v[4 * q + 0][r] = fs_value<MODE>(v[i].x, mu4[0]);
-            lds_v[4 * q + 1][r] = fs_value<MODE>(v[i].y, mu4[1]);
-            lds_v[4 * q + 2][r] = fs_value<MODE>(v[i].z, mu4[2]);
-            lds_v[4 * q + 3][r] = fs_value<MODE>(v[i].w, mu4[3]);
+            const bool live = r < rows;  // rows past the node's end park as +0: a zero addend leaves the transducer as it is
+            lds_v[4 * q + 0][r] = live ? fs_value<MODE>(v[i].x, mu4[0]) : 0.0f;
+            lds_v[4 * q + 1][r] = live ? fs_value<MODE>(v[i].y, mu4[1]) : 0.0f;
+            lds_v[4 * q + 2][r] = live ? fs_value<MODE>(v[i].z, mu4[2]) : 0.0f;
+            lds_v[4 * q + 3][r] = live ? fs_value<MODE>(v[i].w, mu4[3]) : 0.0f;
         }
     }
+    const uint32_t c = c0 + cl;
+    const float s_guess = (float)pref;
     __syncthreads();
-    const uint32_t cl = threadIdx.x & 31, c = c0 + cl, seg = threadIdx.x >> 5;
-    const float s_guess = (float)tile_pref[(size_t)blockIdx.x * d + c];
+    const bool has_next = next < n_items;  // uniform
+    const uint32_t next2 = next + gridDim.x;
+    FsTile tl_next2 = tl_next;
+    if (has_next) {
+        issue_perm(tl_next, next);
+        tl_next2 = tiles[(next2 < n_items ? next2 : next) / ncb];
+    }
     const uint32_t gb = __float_as_uint(s_guess), ge = (gb >> 23) & 0xFFu;
     const int e = (int)ge - 127;
     // scale = 2^(23-e): needs a normal guess and a representable power of two
     bool bad = (ge == 0u) || (ge == 255u) || (23 - e > 126) || (23 - e < -126);
     const float scale = bad ? 1.0f : __uint_as_float((uint32_t)(23 - e + 127) << 23);
+    const float scale2 = scale + scale;  // 2^(24-e): exact (23 - e <= 126 was checked)
     // per 64-row segment everything fits 32 bits: |q| < 2^24 is enforced (an addend of 2 s or more
     // cannot leave s in its binade), so |prefix| < 2^30
     int32_t dd[2] = {0, 0}, lo[2] = {0, 0}, hi[2] = {0, 0};
-    const uint32_t i0 = seg * 64, i1 = min(rows, i0 + 64);
-    for (uint32_t i = i0; i < i1; ++i) {
-        const float q = lds_v[cl][i] * scale;
-        const bool in_range = fabsf(q) < 16777216.0f;  // else |q| >= 2^24, inf or NaN: cannot stay in the binade
-        bad = bad || !in_range;
-        const float qq = in_range ? q : 0.0f;
-        // q = a + f with a = floor(q), 0 <= f < 1, classified EXACTLY: the fraction of |q| is exact in
-        // f32 (it is made of |q|'s own low bits), whereas q - floor(q) is not for -1 < q < 0 (1 + q
-        // needs bits below 2^-24: -0.49999997 would read as a tie).  For q < 0 with fraction ft of |q|:
-        // a = -floor|q| - (ft != 0), f = 1 - ft.
-        const float t = fabsf(qq), at = floorf(t), ft = t - at;
-        const bool neg = qq < 0.0f, frac = ft != 0.0f;
-        const int32_t ai = neg ? -(int32_t)at - (frac ? 1 : 0) : (int32_t)at;
-        const int32_t tie = ft == 0.5f ? 1 : 0;
-        const int32_t up = (neg ? (frac && ft < 0.5f) : (ft > 0.5f)) ? 1 : 0;
+    // 64 addends per thread, 8 LDS reads in flight; branch-free (the loop was latency-bound on one ds_read per
+    // iteration plus a divergent branch on the sign: 265 us per pass at 1M x 128)
+    const uint32_t i0 = seg * 64;
+    int badi = bad ? 1 : 0;
+    auto fold = [&](uint32_t ib0, uint32_t ib1) {
+#pragma unroll 1
+    for (uint32_t ib = ib0; ib < ib1; ib += 8) {
+      float qv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) qv[u] = lds_v[cl][i0 + ib + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        // q = a + f, a = floor(q), 0 <= f < 1, classified EXACTLY from 2q (exact: |q| < 2^24): with i2 = floor(2q)
+        // a = i2 >> 1, and f is above / at / below one half as (i2 odd, 2q not an integer) / (i2 odd, 2q an
+        // integer) / (i2 even).  (q - floor(q) itself is inexact for -1 < q < 0: -0.49999997 would read as a tie.)
+        const float q2 = qv[u] * scale2;
+        const bool in_range = fabsf(q2) < 33554432.0f;  // else |q| >= 2^24, inf or NaN: cannot stay in the binade
+        badi |= in_range ? 0 : 1;
+        const float qq = in_range ? q2 : 0.0f;
+        const float fl = floorf(qq);
+        const int32_t i2 = (int32_t)fl, sticky = qq != fl ? 1 : 0;
+        const int32_t ai = i2 >> 1, half = i2 & 1;
+        const int32_t up = half & sticky, tie = half & (sticky ^ 1);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int32_t base = dd[p] + ai;
@@ -821,7 +859,13 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
             lo[p] = min(lo[p], inc);
             hi[p] = max(hi[p], inc);
         }
+      }
     }
+    };
+    fold(0, 32);
+    if (has_next) issue_rows(next);  // the perm indices issued above have arrived by now
+    fold(32, 64);
+    bad = badi != 0;
     FsAcc acc;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -841,9 +885,10 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
             FsAcc h;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const int p2 = (int)((p + f.d[p]) & 1);
-                h.d[p] = f.d[p] + gg.d[p2];
-                const long long l2 = f.d[p] + gg.lo[p2], h2 = f.d[p] + gg.hi[p2];
+                const bool odd = ((p + f.d[p]) & 1) != 0;  // selects, not gg.d[p2]: a run-time index sends the struct to scratch
+                const long long gd = odd ? gg.d[1] : gg.d[0], gl = odd ? gg.lo[1] : gg.lo[0], gh = odd ? gg.hi[1] : gg.hi[0];
+                h.d[p] = f.d[p] + gd;
+                const long long l2 = f.d[p] + gl, h2 = f.d[p] + gh;
                 h.lo[p] = f.lo[p] < l2 ? f.lo[p] : l2;
                 h.hi[p] = f.hi[p] > h2 ? f.hi[p] : h2;
             }
@@ -877,15 +922,23 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
         o.hi1 = (int32_t)f.hi[1];
         o.e = e;
         o.flag = (anybad ? 1 : 0) | ((slot + 1) << 1);  // bit 0: unusable; bits 1..: side slot + 1
-        summ[(size_t)blockIdx.x * d + c] = o;
+        summ[(size_t)tile_id * d + c] = o;
     }
     __syncthreads();
+#pragma unroll 1
     for (uint32_t cc = 0; cc < kFsCols; ++cc) {  // rare: park the flagged columns (already in LDS)
         const int slot = col_slot[cc];
         if (slot < 0) continue;
         float *dst = side + (size_t)slot * kFsTile;
         for (uint32_t i = threadIdx.x; i < rows; i += 256) dst[i] = lds_v[cc][i];
     }
+    if (!has_next) break;
+    __syncthreads();  // lds_v, seg_acc and col_slot are rewritten by the next item
+    item = next;
+    next = next2;
+    tl = tl_next;
+    tl_next = tl_next2;
+  }
 }
 
 // the exact chain: one wave per (node, column).  The tile summaries are themselves parity
@@ -901,12 +954,13 @@ __device__ __forceinline__ FsPair fs_compose(const FsPair &f, const FsPair &g) {
     FsPair h;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const int p2 = (p + f.d[p]) & 1;
+        const bool odd = ((p + f.d[p]) & 1) != 0;  // selects: a run-time array index would send g to scratch
+        const int32_t gd = odd ? g.d[1] : g.d[0], gl = odd ? g.lo[1] : g.lo[0], gh = odd ? g.hi[1] : g.hi[0];
         // saturating enough: summaries are clamped to |.| <= 2^28 and a batch is stopped at the first
         // tile that leaves the binade, so valid prefixes stay below 2^25
-        h.d[p] = f.d[p] + g.d[p2];
-        h.lo[p] = min(f.lo[p], f.d[p] + g.lo[p2]);
-        h.hi[p] = max(f.hi[p], f.d[p] + g.hi[p2]);
+        h.d[p] = f.d[p] + gd;
+        h.lo[p] = min(f.lo[p], f.d[p] + gl);
+        h.hi[p] = max(f.hi[p], f.d[p] + gh);
     }
     return h;
 }
@@ -1288,7 +1342,8 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             const uint32_t nt = (nodes[id].len + kFsTile - 1) / kFsTile;
             tbase.push_back((uint32_t)tiles.size());
             tcount.push_back(nt);
-            for (uint32_t t = 0; t < nt; ++t) tiles.push_back({id, t});
+            for (uint32_t t = 0; t < nt; ++t)
+                tiles.push_back({id, t, nodes[id].start + t * kFsTile, std::min(kFsTile, nodes[id].len - t * kFsTile)});
         }
         if (!slow.empty()) {
             VQ_TRY(b_lvl_slow.ensure(slow.size() * 4));
@@ -1319,7 +1374,9 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             VQ_LAUNCH_CHECK("k_seg_colsum");
         }
         if (!fast.empty()) {
-            const dim3 tgrid((uint32_t)tiles.size(), d / kFsCols);
+            const uint32_t n_items = (uint32_t)tiles.size() * (d / kFsCols);
+            const dim3 tgrid(n_items);
+            const dim3 xgrid(std::min<uint32_t>(n_items, (uint32_t)num_cus() * 2));  // persistent: two workgroups fit a CU's LDS
             const FsTile *tl = b_fs_tiles.as<FsTile>();
             double *ts = b_fs_sum.as<double>();
             FsSumm *sm = b_fs_summ.as<FsSumm>();
@@ -1328,12 +1385,12 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             if (mode == 0) {
                 hipLaunchKernelGGL(k_fs_tile_sums<0>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts);
                 hipLaunchKernelGGL(k_fs_prefix, dim3((uint32_t)fast.size(), d / kFsCols), dim3(1024), 0, stream, d, fb, fc, ts);
-                hipLaunchKernelGGL(k_fs_transduce<0>, tgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1);
+                hipLaunchKernelGGL(k_fs_transduce<0>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, n_items, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1);
                 hipLaunchKernelGGL(k_fs_chain<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, b_fs_side.as<float>(), b_fs_fb.as<uint32_t>());
             } else {
                 hipLaunchKernelGGL(k_fs_tile_sums<1>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts);
                 hipLaunchKernelGGL(k_fs_prefix, dim3((uint32_t)fast.size(), d / kFsCols), dim3(1024), 0, stream, d, fb, fc, ts);
-                hipLaunchKernelGGL(k_fs_transduce<1>, tgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1);
+                hipLaunchKernelGGL(k_fs_transduce<1>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, n_items, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1);
                 hipLaunchKernelGGL(k_fs_chain<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, b_fs_side.as<float>(), b_fs_fb.as<uint32_t>());
             }
             VQ_LAUNCH_CHECK("k_fs_*");
