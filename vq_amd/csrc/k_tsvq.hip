@@ -1050,8 +1050,15 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                 const uint32_t first = r0 + (uint32_t)i * 64;
                 if (first >= len) break;
                 const uint32_t m = min(64u, len - first);
-                for (uint32_t l = 0; l < m; ++l)
-                    s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i]), (int)l));
+                if (m == 64u) {
+                    // constant lane numbers: two instructions per add, the chain runs at the add's own latency (the
+                    // counted loop spent ~45 cycles per add on its compare-and-branch)
+#pragma unroll
+                    for (int l = 0; l < 64; ++l) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i]), l));
+                } else {
+                    for (uint32_t l = 0; l < m; ++l)
+                        s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i]), (int)l));
+                }
             }
             t0 += 1;
         }
