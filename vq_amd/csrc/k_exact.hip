@@ -255,6 +255,129 @@ __global__ __launch_bounds__(1024) void k_recheck_wave(
     }
 }
 
+// (distance, index) minimum over the wave without LDS traffic: DPP exchanges inside the 16-lane rows, v_readlane
+// across them.  "Smaller distance, then smaller index" is commutative and associative, so any tree gives the
+// reference's first minimum.  The result is wave-uniform.  (__shfl_xor is ds_bpermute: ~100 cycles a step, and
+// its lgkmcnt waits would also serialise the scalar prefetch of the next entry's row.)
+template <int CTRL>
+__device__ __forceinline__ void argmin_dpp_step(float &bd, uint32_t &bj) {
+    // a lane without a candidate carries (+inf, 0xFFFFFFFF), which loses every comparison below by itself
+    const float od = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(bd), __float_as_int(bd), CTRL, 0xF, 0xF, false));
+    const uint32_t oj = (uint32_t)__builtin_amdgcn_update_dpp((int)bj, (int)bj, CTRL, 0xF, 0xF, false);
+    const bool take = (od < bd) | ((od == bd) & (oj < bj));
+    bd = take ? od : bd;
+    bj = take ? oj : bj;
+}
+__device__ __forceinline__ void argmin_wave(float &bd, uint32_t &bj) {
+    argmin_dpp_step<0xB1>(bd, bj);   // quad_perm [1,0,3,2]
+    argmin_dpp_step<0x4E>(bd, bj);   // quad_perm [2,3,0,1]
+    argmin_dpp_step<0x141>(bd, bj);  // row_half_mirror
+    argmin_dpp_step<0x140>(bd, bj);  // row_mirror: every lane of a 16-lane row now holds the row's minimum
+    float rd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bd), 0));
+    uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)bj, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const float od = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bd), r));
+        const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)bj, r);
+        const bool take = (od < rd) | ((od == rd) & (oj < rj));
+        rd = take ? od : rd;
+        rj = take ? oj : rj;
+    }
+    bd = rd;
+    bj = rj;
+}
+
+// Re-check over the X32 screen's wave-private segments with the sub-codebook RESIDENT IN REGISTERS: lane l keeps
+// centroids l, l+64, ... (KPL of them, KPL*SD <= 128 VGPRs) for the whole launch, so an entry costs its own
+// 4*SD-byte row -- a uniform address, fetched one entry ahead -- instead of the 4*k*SD bytes of centroids that
+// k_recheck_wave pulls through the L1 per entry (16 KB at k=256, sub_dim 16: clustered data, 2.7 % of the rows
+// re-checked, spent 0.27 ms there).  A segment is shared by `parts` waves (contiguous shares).  Same arithmetic,
+// same merge and NaN rule as k_recheck_wave.
+template <int METRIC, int SD, int KPL>
+__global__ __launch_bounds__(256) void k_recheck_resident(
+    const float *__restrict__ X, uint32_t d, uint32_t m, uint32_t k,
+    const float *__restrict__ cb, const float *__restrict__ cnsqrt,
+    const uint32_t *__restrict__ sub_list, const uint32_t *__restrict__ wl_rows, uint64_t wl_stride,
+    const uint32_t *__restrict__ wl_seg, uint32_t n_seg, uint32_t parts, uint8_t *__restrict__ codes) {
+    const uint32_t s = sub_list ? sub_list[blockIdx.y] : blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const uint32_t n_waves = gridDim.x * 4;
+    const float *cbs = cb + (size_t)s * k * SD;
+    const uint32_t NONE = 0xFFFFFFFFu;
+    float c[KPL][SD];
+    float cn[KPL];
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const uint32_t j = lane + 64u * i;
+        const float *src = cbs + (size_t)(j < k ? j : 0u) * SD;
+#pragma unroll
+        for (int t = 0; t < SD; t += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + t);
+            c[i][t] = v.x, c[i][t + 1] = v.y, c[i][t + 2] = v.z, c[i][t + 3] = v.w;
+        }
+        cn[i] = (METRIC == VQHIP_COSINE) ? cnsqrt[(size_t)s * k + (j < k ? j : 0u)] : 0.0f;
+    }
+    const uint32_t *rows_s = wl_rows + (size_t)s * wl_stride;
+    for (uint32_t unit = wave; unit < n_seg * parts; unit += n_waves) {
+        const uint32_t seg = unit / parts, part = unit - seg * parts;
+        const uint32_t *sg = wl_seg + ((size_t)s * n_seg + seg) * 2;
+        const uint32_t seg_first = sg[0], seg_count = sg[1];
+        const uint32_t share = (seg_count + parts - 1) / parts;
+        const uint32_t lo = part * share, hi = min(seg_count, lo + share);
+        for (uint32_t base = lo; base < hi; base += 64) {
+            const uint32_t nb = min(64u, hi - base);
+            // the batch's row ids, one per lane; entry e's id is read with v_readlane
+            const uint32_t my_row = rows_s[seg_first + base + min(lane, nb - 1)];
+            auto fetch = [&](uint32_t e, float (&x)[SD]) {
+                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)my_row, (int)e);
+                const float *xrow = X + (size_t)row * d + (size_t)s * SD;  // wave-uniform address
+#pragma unroll
+                for (int t = 0; t < SD; t += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(xrow + t);
+                    x[t] = v.x, x[t + 1] = v.y, x[t + 2] = v.z, x[t + 3] = v.w;
+                }
+            };
+            float xn[SD];
+            fetch(0, xn);
+            for (uint32_t e = 0; e < nb; ++e) {
+                float x[SD];
+#pragma unroll
+                for (int t = 0; t < SD; ++t) x[t] = xn[t];
+                if (e + 1 < nb) fetch(e + 1, xn);  // the next entry's row, in flight during this one's arithmetic
+                float na = 0.0f;
+                if constexpr (METRIC == VQHIP_COSINE) {
+                    float sa = -0.0f;
+#pragma unroll
+                    for (int t = 0; t < SD; ++t) {
+                        float p = x[t] * x[t];
+                        sa = sa + p;
+                    }
+                    na = sqrtf(sa);
+                }
+                float bd = __builtin_inff();
+                uint32_t bj = NONE;
+                bool d0_nan = false;
+#pragma unroll
+                for (int i = 0; i < KPL; ++i) {
+                    const uint32_t j = lane + 64u * i;
+                    const float dist = exact_dist_fixed<METRIC, SD>(x, c[i], na, cn[i]);
+                    const bool isnan_d = dist != dist;
+                    if (i == 0) d0_nan = isnan_d && (lane == 0);
+                    // selects, not branches (the four short-circuit tests cost more than the 48 flops they guard)
+                    const bool better = (j < k) & !isnan_d & ((bj == NONE) | (dist < bd));
+                    bd = better ? dist : bd;
+                    bj = better ? j : bj;
+                }
+                argmin_wave(bd, bj);
+                const bool blocked = __builtin_amdgcn_readlane((int)d0_nan, 0) != 0;
+                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)my_row, (int)e);
+                if (lane == 0) store_code(codes, (size_t)row * m + s, (blocked || bj == NONE) ? 0u : bj, k);
+            }
+        }
+    }
+}
+
 // One workgroup per subspace: squared norms, the screen's A-operand image, flags.
 __global__ __launch_bounds__(256) void k_prepare_codebook(const float *__restrict__ cb, uint32_t m,
                                                           uint32_t k, uint32_t sd, uint32_t nt,
@@ -392,6 +515,26 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
         const bool seg = (a.wl_seg != nullptr && a.n_seg > 0);
         const dim3 wgrid(seg ? a.n_seg : (uint32_t)num_cus() * 4, a.n_sub);
         const uint32_t *wls = seg ? a.wl_seg : nullptr;
+        if constexpr (METRIC != VQHIP_MANHATTAN) if (seg && cb.k <= 256 && (cb.sd == 8 || cb.sd == 12 || cb.sd == 16 || cb.sd == 24)) {
+            // register-resident sub-codebook; enough (segment, part) units for ~2 waves per SIMD
+            const uint32_t kpl = cb.k <= 64 ? 1u : cb.k <= 128 ? 2u : 4u;
+            const uint32_t target = (uint32_t)num_cus() * 8;
+            uint32_t parts = target / std::max(1u, a.n_seg * a.n_sub);
+            parts = std::min(std::max(parts, 1u), 4u);
+            const dim3 rgrid((a.n_seg * parts + 3) / 4, a.n_sub);
+#define VQ_RESIDENT(SDV, KPLV)                                                                                      \
+    if (cb.sd == SDV && kpl == KPLV) {                                                                              \
+        hipLaunchKernelGGL((k_recheck_resident<METRIC, SDV, KPLV>), rgrid, dim3(256), 0, stream, a.X, a.d, cb.m, cb.k, \
+                           cb.cb, cb.cnsqrt, a.sub_list, wlr, a.wl_stride, wls, a.n_seg, parts, a.codes);          \
+        VQ_LAUNCH_CHECK("k_recheck_resident");                                                                      \
+        return VQHIP_OK;                                                                                            \
+    }
+            VQ_RESIDENT(8, 1) VQ_RESIDENT(8, 2) VQ_RESIDENT(8, 4)
+            VQ_RESIDENT(12, 1) VQ_RESIDENT(12, 2) VQ_RESIDENT(12, 4)
+            VQ_RESIDENT(16, 1) VQ_RESIDENT(16, 2) VQ_RESIDENT(16, 4)
+            VQ_RESIDENT(24, 1) VQ_RESIDENT(24, 2) VQ_RESIDENT(24, 4)
+#undef VQ_RESIDENT
+        }
 #define VQ_RECHECK_CASE(SDV)                                                                   \
     case SDV:                                                                                  \
         hipLaunchKernelGGL((k_recheck_wave<METRIC, SDV>), wgrid, dim3(seg ? 1024 : 256), 0, stream, a.X, a.d, \
