@@ -305,7 +305,12 @@ __global__ __launch_bounds__(256) void k_recheck_resident(
     const uint32_t n_waves = gridDim.x * 4;
     const float *cbs = cb + (size_t)s * k * SD;
     const uint32_t NONE = 0xFFFFFFFFu;
-    float c[KPL][SD];
+    // squared-L2 / Euclidean with an even KPL: two centroids per instruction on the packed-f32 VALU ops
+    // (v_pk_add_f32 / v_pk_mul_f32 round each half like the scalar ops; the row comes in as a broadcast SGPR)
+    constexpr bool PK = (METRIC == VQHIP_SQUARED_EUCLIDEAN || METRIC == VQHIP_EUCLIDEAN) && (KPL % 2 == 0);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    float c[PK ? 1 : KPL][SD];
+    f2 cp[PK ? KPL / 2 : 1][SD];
     float cn[KPL];
 #pragma unroll
     for (int i = 0; i < KPL; ++i) {
@@ -314,7 +319,16 @@ __global__ __launch_bounds__(256) void k_recheck_resident(
 #pragma unroll
         for (int t = 0; t < SD; t += 4) {
             const float4 v = *reinterpret_cast<const float4 *>(src + t);
-            c[i][t] = v.x, c[i][t + 1] = v.y, c[i][t + 2] = v.z, c[i][t + 3] = v.w;
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (PK) {
+                    if (i % 2 == 0) cp[i / 2][t + u].x = e[u];
+                    else cp[i / 2][t + u].y = e[u];
+                } else {
+                    c[i][t + u] = e[u];
+                }
+            }
         }
         cn[i] = (METRIC == VQHIP_COSINE) ? cnsqrt[(size_t)s * k + (j < k ? j : 0u)] : 0.0f;
     }
@@ -358,16 +372,32 @@ __global__ __launch_bounds__(256) void k_recheck_resident(
                 float bd = __builtin_inff();
                 uint32_t bj = NONE;
                 bool d0_nan = false;
-#pragma unroll
-                for (int i = 0; i < KPL; ++i) {
+                auto consider = [&](int i, float dist) {  // centroid lane + 64 i, ascending i
                     const uint32_t j = lane + 64u * i;
-                    const float dist = exact_dist_fixed<METRIC, SD>(x, c[i], na, cn[i]);
                     const bool isnan_d = dist != dist;
                     if (i == 0) d0_nan = isnan_d && (lane == 0);
                     // selects, not branches (the four short-circuit tests cost more than the 48 flops they guard)
                     const bool better = (j < k) & !isnan_d & ((bj == NONE) | (dist < bd));
                     bd = better ? dist : bd;
                     bj = better ? j : bj;
+                };
+                if constexpr (PK) {
+#pragma unroll
+                    for (int p = 0; p < KPL / 2; ++p) {
+                        f2 acc = {0.0f, 0.0f};
+#pragma unroll
+                        for (int t = 0; t < SD; ++t) {  // same three roundings per element as exact_dist_fixed
+                            const f2 xx = {x[t], x[t]};
+                            const f2 diff = xx - cp[p][t];
+                            const f2 sq = diff * diff;
+                            acc = acc + sq;
+                        }
+                        consider(2 * p, (METRIC == VQHIP_EUCLIDEAN) ? sqrtf(acc.x) : acc.x);
+                        consider(2 * p + 1, (METRIC == VQHIP_EUCLIDEAN) ? sqrtf(acc.y) : acc.y);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < KPL; ++i) consider(i, exact_dist_fixed<METRIC, SD>(x, c[i], na, cn[i]));
                 }
                 argmin_wave(bd, bj);
                 const bool blocked = __builtin_amdgcn_readlane((int)d0_nan, 0) != 0;
