@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256) void k_recheck_resident(
     const float *__restrict__ X, uint32_t d, uint32_t m, uint32_t k,
     const float *__restrict__ cb, const float *__restrict__ cnsqrt,
     const uint32_t *__restrict__ sub_list, const uint32_t *__restrict__ wl_rows, uint64_t wl_stride,
-    const uint32_t *__restrict__ wl_seg, uint32_t n_seg, uint32_t parts, uint8_t *__restrict__ codes) {
+    const uint32_t *__restrict__ wl_seg, const uint32_t *__restrict__ wl_count, uint32_t n_seg, uint32_t parts,
+    uint8_t *__restrict__ codes) {
     const uint32_t s = sub_list ? sub_list[blockIdx.y] : blockIdx.y;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -335,8 +336,9 @@ __global__ __launch_bounds__(256) void k_recheck_resident(
     const uint32_t *rows_s = wl_rows + (size_t)s * wl_stride;
     for (uint32_t unit = wave; unit < n_seg * parts; unit += n_waves) {
         const uint32_t seg = unit / parts, part = unit - seg * parts;
-        const uint32_t *sg = wl_seg + ((size_t)s * n_seg + seg) * 2;
-        const uint32_t seg_first = sg[0], seg_count = sg[1];
+        // segmented lists, or (wl_seg == nullptr, n_seg == 1) the subspace's single list shared by `parts` waves
+        const uint32_t *sg = wl_seg ? wl_seg + ((size_t)s * n_seg + seg) * 2 : nullptr;
+        const uint32_t seg_first = sg ? sg[0] : 0u, seg_count = sg ? sg[1] : wl_count[s];
         const uint32_t share = (seg_count + parts - 1) / parts;
         const uint32_t lo = part * share, hi = min(seg_count, lo + share);
         for (uint32_t base = lo; base < hi; base += 64) {
@@ -545,17 +547,21 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
         const bool seg = (a.wl_seg != nullptr && a.n_seg > 0);
         const dim3 wgrid(seg ? a.n_seg : (uint32_t)num_cus() * 4, a.n_sub);
         const uint32_t *wls = seg ? a.wl_seg : nullptr;
-        if constexpr (METRIC != VQHIP_MANHATTAN) if (seg && cb.k <= 256 && (cb.sd == 8 || cb.sd == 12 || cb.sd == 16 || cb.sd == 24)) {
-            // register-resident sub-codebook; enough (segment, part) units for ~2 waves per SIMD
+        if constexpr (METRIC != VQHIP_MANHATTAN)
+        if (cb.k <= 256 && ((seg && (cb.sd == 8 || cb.sd == 12 || cb.sd == 16 || cb.sd == 24)) || (!seg && cb.sd == 32))) {
+            // register-resident sub-codebook; enough (segment, part) units for ~2 waves per SIMD.  The grouped
+            // sub_dim-32 screen and the fp32 screen leave one list per subspace: n_seg = 1, many parts.
             const uint32_t kpl = cb.k <= 64 ? 1u : cb.k <= 128 ? 2u : 4u;
             const uint32_t target = (uint32_t)num_cus() * 8;
-            uint32_t parts = target / std::max(1u, a.n_seg * a.n_sub);
-            parts = std::min(std::max(parts, 1u), 4u);
-            const dim3 rgrid((a.n_seg * parts + 3) / 4, a.n_sub);
+            const uint32_t nseg = seg ? a.n_seg : 1u;
+            uint32_t parts = target / std::max(1u, nseg * a.n_sub);
+            parts = std::max(parts, 1u);
+            if (seg) parts = std::min(parts, 4u);
+            const dim3 rgrid((nseg * parts + 3) / 4, a.n_sub);
 #define VQ_RESIDENT(SDV, KPLV)                                                                                      \
     if (cb.sd == SDV && kpl == KPLV) {                                                                              \
         hipLaunchKernelGGL((k_recheck_resident<METRIC, SDV, KPLV>), rgrid, dim3(256), 0, stream, a.X, a.d, cb.m, cb.k, \
-                           cb.cb, cb.cnsqrt, a.sub_list, wlr, a.wl_stride, wls, a.n_seg, parts, a.codes);          \
+                           cb.cb, cb.cnsqrt, a.sub_list, wlr, a.wl_stride, wls, wlc, nseg, parts, a.codes);        \
         VQ_LAUNCH_CHECK("k_recheck_resident");                                                                      \
         return VQHIP_OK;                                                                                            \
     }
@@ -563,6 +569,7 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
             VQ_RESIDENT(12, 1) VQ_RESIDENT(12, 2) VQ_RESIDENT(12, 4)
             VQ_RESIDENT(16, 1) VQ_RESIDENT(16, 2) VQ_RESIDENT(16, 4)
             VQ_RESIDENT(24, 1) VQ_RESIDENT(24, 2) VQ_RESIDENT(24, 4)
+            VQ_RESIDENT(32, 1) VQ_RESIDENT(32, 2) VQ_RESIDENT(32, 4)
 #undef VQ_RESIDENT
         }
 #define VQ_RECHECK_CASE(SDV)                                                                   \
