@@ -68,6 +68,55 @@ SHAPES = [  # (n, d, m, k)
 ]
 
 
+ANY_SD_SHAPES = [  # sub_dims without a compile-time kernel: rows staged through LDS (k_assign_exact_tiled)
+    (1500, 384, 1, 64),    # lbg_quantize on whole vectors (m = 1), 12 chunks of 32 dimensions
+    (2000, 100, 10, 256),  # sub_dim 10: fixed-length kernel, the neighbouring case
+    (1200, 63, 9, 100),    # sub_dim 7
+    (900, 99, 3, 300),     # sub_dim 33 (one full chunk + 1), two-byte codes, two centroid groups of 256
+    (700, 130, 1, 17),     # sub_dim 130
+    (640, 35, 1, 5),       # sub_dim 35, n a multiple of the 64-row tile
+    (65, 11, 1, 2),        # one row past a tile
+]
+
+
+@pytest.mark.parametrize("shape", ANY_SD_SHAPES)
+@pytest.mark.parametrize("kind", ["uniform", "normal", "lattice"])
+@pytest.mark.parametrize("metric", [O.SQUARED_EUCLIDEAN, O.EUCLIDEAN, O.MANHATTAN, O.COSINE])
+def test_encode_any_sub_dim_bit_exact(oracle, shape, kind, metric):
+    n, d, m, k = shape
+    X = _data(5, n, d, kind)
+    cb = _data(6, m * k, d // m, kind).reshape(m, k, d // m)
+    if kind == "lattice":
+        cb[:, k // 2] = cb[:, 0]
+        X[3] = 0  # a zero row: cosine's norm cut-off
+    enc = _lib.PQEncoder(cb, metric)
+    codes, f16 = enc.encode(X)
+    want_c, want_f = oracle.pq_encode(metric, X, cb, threads=0)
+    np.testing.assert_array_equal(codes.astype(np.uint32), want_c)
+    same = (f16.view(np.uint16) == want_f) | (np.isnan(f16) & np.isnan(want_f.view(np.float16)))
+    assert same.all()
+    enc.close()
+
+
+def test_lbg_whole_vectors_step_matches_oracle(oracle):
+    """m = 1, sub_dim = d = 200: one Lloyd step of plain lbg_quantize (vector.rs:390-461) with the exact update"""
+    n, d, k = 4000, 200, 37
+    X = _data(8, n, d, "normal")
+    init = np.array([[(j * (n // k)) % n for j in range(k)]], np.uint64)
+    ds = _lib.Dataset.from_host(X)
+    km = _lib.KMeans(ds, 1, k)
+    km.set_exact_update(True)
+    km.init_from_rows(init)
+    counts, changed = km.step()
+    c1, a_ref, n_ref, ch_ref = oracle.lloyd_step(X, X[init[0].astype(np.int64)], threads=0)
+    np.testing.assert_array_equal(km.get_assignments()[:, 0].astype(np.uint32), a_ref)
+    np.testing.assert_array_equal(counts[0], n_ref)
+    ne = n_ref > 0
+    assert km.get_centroids()[0][ne].tobytes() == c1[ne].tobytes()
+    km.close()
+    ds.close()
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("kind", ["uniform", "normal", "lattice", "clustered"])
 @pytest.mark.parametrize("metric", [O.SQUARED_EUCLIDEAN, O.EUCLIDEAN])

@@ -14,6 +14,7 @@
 // algorithmic bytes 4*d in + m out per row.  Centroids are wave-uniform (one subspace per
 // workgroup) so they arrive through the scalar cache and feed VALU ops as SGPR operands.
 #include "kernels.hpp"
+#include <type_traits>
 
 // The reference never contracts a*b+c (Rust has no implicit FMA).  Belt and braces with
 // -ffp-contract=off on the command line.
@@ -141,6 +142,140 @@ __global__ __launch_bounds__(kExactBlock) void k_assign_exact(
         uint32_t best = scan_one<METRIC, SD, GENERIC>(xrow, sd, cbs, cnsq, k);
         store_code(codes, row * m + s, best, k);
     }
+}
+
+// Exact scan for ANY sub_dim (the engine behind sub_dims without a compile-time instantiation, and behind
+// lbg_quantize on whole vectors, m = 1: src/core/vector.rs:390-395).  A lane cannot keep an arbitrary-length
+// sub-vector in registers, and re-reading it from memory once per centroid (what the run-time-length loop of
+// scan_one does) costs 4*k bytes of uncoalesced traffic per row element.  Here a workgroup owns 64 rows: the rows
+// are staged through LDS 32 dimensions at a time (coalesced 128-byte reads, transposed so that lane r reads its own
+// row conflict-free), the running distance of every (row, centroid) pair lives in LDS ([256 centroids][64 rows],
+// 64 KB), and wave q advances the pairs of centroids j = q, q+4, ... by one chunk: acc -> 32 x (x - c, squared,
+// added) -> acc, centroid elements wave-uniform scalar loads.  Every pair still sees its additions in ascending t
+// from the reference's start value, so the bits are scan_one's; the rows are read from HBM once per 256 centroids.
+constexpr uint32_t kTiledRows = 64, kTiledDims = 32, kTiledCentroids = 256;
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_assign_exact_tiled(
+    const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m, uint32_t k, uint32_t sd,
+    const float *__restrict__ cb, const float *__restrict__ cnsqrt, const uint32_t *__restrict__ sub_list,
+    uint8_t *__restrict__ codes) {
+    constexpr uint32_t TR = kTiledRows, TC = kTiledDims, KG = kTiledCentroids;
+    __shared__ float acc[KG][TR];
+    __shared__ float xs[TC][TR + 1];
+    const uint32_t s = sub_list ? sub_list[blockIdx.y] : blockIdx.y;
+    const uint32_t r = threadIdx.x & 63;
+    const uint32_t q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t row0 = (uint64_t)blockIdx.x * TR;
+    const float *cbs = cb + (size_t)s * k * sd;
+    const float *cnsq = cnsqrt ? cnsqrt + (size_t)s * k : nullptr;
+    const float init = (METRIC == VQHIP_COSINE) ? -0.0f : 0.0f;  // `.sum()` folds from -0.0, the L2 / L1 loops from 0.0
+    float sa = -0.0f, na = 0.0f;  // cosine: |x|^2 chain of this lane's row (wave 0 only)
+    uint32_t best = 0;
+    float best_dist = 0.0f;
+    for (uint32_t kg0 = 0; kg0 < k; kg0 += KG) {
+        const uint32_t kn = min(KG, k - kg0);
+        for (uint32_t jj = q; jj < kn; jj += 4) acc[jj][r] = init;
+        for (uint32_t t0 = 0; t0 < sd; t0 += TC) {
+            const uint32_t tc = min(TC, sd - t0);
+            __syncthreads();  // the previous chunk's readers are done with xs (and acc is initialised)
+#pragma unroll
+            for (uint32_t e = 0; e < TR * TC / 256; ++e) {
+                const uint32_t idx = threadIdx.x + 256 * e, row = idx / TC, col = idx % TC;
+                const uint64_t grow = row0 + row;
+                xs[col][row] = (grow < n && col < tc) ? X[grow * d + (size_t)s * sd + t0 + col] : 0.0f;
+            }
+            __syncthreads();
+            float xr[TC];
+#pragma unroll
+            for (uint32_t t = 0; t < TC; ++t) xr[t] = xs[t][r];
+            if (METRIC == VQHIP_COSINE && kg0 == 0 && q == 0) {
+#pragma unroll
+                for (uint32_t t = 0; t < TC; ++t)
+                    if (t < tc) {
+                        const float p = xr[t] * xr[t];
+                        sa = sa + p;
+                    }
+            }
+            // one (row, centroid) pair advanced by N dimensions, N a compile-time constant: only the reference's own
+            // operations, no per-dimension test (a run-time `t < tc` inside the unrolled loop cost two scalar
+            // instructions per dimension and kept the short last chunk at a third of the full chunks' rate)
+            auto advance = [&](float a, const float *__restrict__ c, auto nc) {
+                constexpr uint32_t N = decltype(nc)::value;
+#pragma unroll
+                for (uint32_t t = 0; t < N; ++t) {
+                    if constexpr (METRIC == VQHIP_SQUARED_EUCLIDEAN || METRIC == VQHIP_EUCLIDEAN) {
+                        const float diff = xr[t] - c[t];
+                        const float sq = diff * diff;
+                        a = a + sq;
+                    } else if constexpr (METRIC == VQHIP_MANHATTAN) {
+                        const float diff = xr[t] - c[t];
+                        a = a + fabsf(diff);
+                    } else {
+                        const float p = xr[t] * c[t];
+                        a = a + p;
+                    }
+                }
+                return a;
+            };
+            auto run_chunk = [&](auto nc) {
+                constexpr uint32_t N = decltype(nc)::value;
+                uint32_t jj = q;  // wave-uniform
+                if constexpr (N == TC) {
+                    for (; jj + 4 < kn; jj += 8) {  // two centroids per trip: both scalar loads are in flight together
+                        const float *c0 = cbs + (size_t)(kg0 + jj) * sd + t0, *c1 = c0 + (size_t)4 * sd;
+                        const float a0 = advance(acc[jj][r], c0, nc);
+                        const float a1 = advance(acc[jj + 4][r], c1, nc);
+                        acc[jj][r] = a0;
+                        acc[jj + 4][r] = a1;
+                    }
+                }
+                for (; jj < kn; jj += 4) acc[jj][r] = advance(acc[jj][r], cbs + (size_t)(kg0 + jj) * sd + t0, nc);
+            };
+#define VQ_TC(NV) \
+    case NV: run_chunk(std::integral_constant<uint32_t, NV>{}); break;
+            switch (tc) {
+                VQ_TC(1) VQ_TC(2) VQ_TC(3) VQ_TC(4) VQ_TC(5) VQ_TC(6) VQ_TC(7) VQ_TC(8)
+                VQ_TC(9) VQ_TC(10) VQ_TC(11) VQ_TC(12) VQ_TC(13) VQ_TC(14) VQ_TC(15) VQ_TC(16)
+                VQ_TC(17) VQ_TC(18) VQ_TC(19) VQ_TC(20) VQ_TC(21) VQ_TC(22) VQ_TC(23) VQ_TC(24)
+                VQ_TC(25) VQ_TC(26) VQ_TC(27) VQ_TC(28) VQ_TC(29) VQ_TC(30) VQ_TC(31)
+            default: run_chunk(std::integral_constant<uint32_t, TC>{}); break;
+            }
+#undef VQ_TC
+        }
+        __syncthreads();
+        if (q == 0) {  // this group's centroids in ascending order, strict '<' (scan_one's rule)
+            if (METRIC == VQHIP_COSINE && kg0 == 0) na = sqrtf(sa);
+            for (uint32_t jj = 0; jj < kn; ++jj) {
+                const uint32_t j = kg0 + jj;
+                const float a = acc[jj][r];
+                float dist;
+                if constexpr (METRIC == VQHIP_SQUARED_EUCLIDEAN || METRIC == VQHIP_MANHATTAN) {
+                    dist = a;
+                } else if constexpr (METRIC == VQHIP_EUCLIDEAN) {
+                    dist = sqrtf(a);
+                } else {  // src/core/distance.rs:107-119
+                    const float nb = cnsq[j];
+                    const float EPS = 1e-10f;
+                    if (na < EPS || nb < EPS) {
+                        dist = 1.0f;
+                    } else {
+                        const float denom = na * nb;
+                        const float qq = a / denom;
+                        const float v = 1.0f - qq;
+                        dist = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                    }
+                }
+                if (j == 0) {
+                    best_dist = dist;
+                } else if (dist < best_dist) {
+                    best_dist = dist;
+                    best = j;
+                }
+            }
+        }
+        __syncthreads();  // acc is re-initialised by the next centroid group
+    }
+    if (q == 0 && row0 + r < n) store_code(codes, (row0 + r) * m + s, best, k);
 }
 
 // Exact distance of one row to one centroid, compile-time length (same op order as scan_one).
@@ -601,17 +736,30 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
     switch (cb.sd) {
         VQ_EXACT_CASE(1)
         VQ_EXACT_CASE(2)
+        VQ_EXACT_CASE(3)
         VQ_EXACT_CASE(4)
+        VQ_EXACT_CASE(5)
+        VQ_EXACT_CASE(6)
         VQ_EXACT_CASE(8)
+        VQ_EXACT_CASE(10)
         VQ_EXACT_CASE(12)
         VQ_EXACT_CASE(16)
+        VQ_EXACT_CASE(20)
         VQ_EXACT_CASE(24)
         VQ_EXACT_CASE(32)
+        VQ_EXACT_CASE(40)
         VQ_EXACT_CASE(48)
         VQ_EXACT_CASE(64)
         VQ_EXACT_CASE(96)
         VQ_EXACT_CASE(128)
     default:
+        if (!wl) {  // any other sub_dim: rows staged through LDS (k_assign_exact_tiled)
+            const dim3 tgrid((uint32_t)((a.n + kTiledRows - 1) / kTiledRows), a.n_sub);
+            hipLaunchKernelGGL((k_assign_exact_tiled<METRIC>), tgrid, dim3(256), 0, stream, a.X, a.n, a.d, cb.m, cb.k,
+                               cb.sd, cb.cb, cb.cnsqrt, a.sub_list, a.codes);
+            VQ_LAUNCH_CHECK("k_assign_exact_tiled");
+            return VQHIP_OK;
+        }
         hipLaunchKernelGGL((k_assign_exact<METRIC, 1, true>), grid, dim3(kExactBlock), 0, stream,
                            a.X, a.n, a.d, cb.m, cb.k, cb.sd, cb.cb, cb.cnsqrt, a.sub_list, wlr, wlc,
                            a.wl_stride, a.codes);
