@@ -98,6 +98,30 @@ def test_encode_any_sub_dim_bit_exact(oracle, shape, kind, metric):
     enc.close()
 
 
+def test_sub_dim_beyond_1024_trains_and_encodes(oracle):
+    """whole 1536-dimensional vectors (m = 1): assignment through the LDS-tiled scan, update through the
+    bucket-and-chain sums (no LDS accumulator layout exists for sub_dim > 1024)"""
+    n, d, k = 1500, 1536, 12
+    X = _data(9, n, d, "normal")
+    init = np.array([[(j * (n // k)) % n for j in range(k)]], np.uint64)
+    ds = _lib.Dataset.from_host(X)
+    km = _lib.KMeans(ds, 1, k)
+    km.init_from_rows(init)
+    counts, changed = km.step()
+    c1, a_ref, n_ref, ch_ref = oracle.lloyd_step(X, X[init[0].astype(np.int64)], threads=0)
+    np.testing.assert_array_equal(km.get_assignments()[:, 0].astype(np.uint32), a_ref)
+    np.testing.assert_array_equal(counts[0], n_ref)
+    ne = n_ref > 0
+    cent = km.get_centroids()
+    err = np.abs(cent[0][ne] - c1[ne]) / np.maximum(1.0, np.abs(c1[ne]))
+    assert err.max() <= CENTROID_RTOL
+    assert bool(changed[0]) == ch_ref
+    km.close()
+    ds.close()
+    for metric in (O.SQUARED_EUCLIDEAN, O.COSINE, O.MANHATTAN):
+        _check_encode(oracle, X[:400], cent, metric, _lib.ENGINE_AUTO)
+
+
 def test_lbg_whole_vectors_step_matches_oracle(oracle):
     """m = 1, sub_dim = d = 200: one Lloyd step of plain lbg_quantize (vector.rs:390-461) with the exact update"""
     n, d, k = 4000, 200, 37

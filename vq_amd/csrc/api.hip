@@ -348,6 +348,7 @@ struct vqhip_kmeans {
     bool all_active = true;
     int engine = VQHIP_ENGINE_AUTO;
     int exact_update = 0;
+    bool sums_by_chains = false;  // sub_dim beyond the LDS update kernels: cluster sums always through launch_exact_sums
     bool accumulated = false;
     uint32_t *counts_host = nullptr;   // pinned [m*k]
     uint32_t *changed_host = nullptr;  // pinned [m]
@@ -736,10 +737,15 @@ int vqhip_kmeans_create(const vqhip_dataset *ds, uint32_t m, uint32_t k, vqhip_k
     std::unique_ptr<vqhip_kmeans> km(new vqhip_kmeans());
     km->ds = ds;
     VQ_TRY(km->cs.init(m, k, sd));
-    VQ_TRY(plan_update(m, k, sd, ds->n, &km->plan));
+    // sub_dim > 1024 (lbg_quantize on long whole vectors): no LDS accumulator layout; the bucket-and-chain sums of
+    // the reference-order update serve any length
+    km->sums_by_chains = sd > 1024;
+    if (!km->sums_by_chains) VQ_TRY(plan_update(m, k, sd, ds->n, &km->plan));
     VQ_TRY(km->codes.alloc((size_t)ds->n * m * code_bytes(k)));
-    VQ_TRY(km->partial_sums.alloc(km->plan.partial_floats * km->plan.n_row_chunks * 4));
-    VQ_TRY(km->partial_counts.alloc(km->plan.partial_counts * km->plan.n_row_chunks * 4));
+    if (!km->sums_by_chains) {
+        VQ_TRY(km->partial_sums.alloc(km->plan.partial_floats * km->plan.n_row_chunks * 4));
+        VQ_TRY(km->partial_counts.alloc(km->plan.partial_counts * km->plan.n_row_chunks * 4));
+    }
     VQ_TRY(km->slab.alloc((size_t)m * k * (sd + 1) * 8));
     VQ_TRY(km->counts.alloc((size_t)m * k * 4));
     VQ_TRY(km->changed.alloc((size_t)m * 4));
@@ -841,7 +847,7 @@ static int kmeans_accumulate_enqueue(vqhip_kmeans *km, hipStream_t s) {
     VQ_TRY(run_assign(km->cs, km->ws, ds->X, ds->n, ds->d, VQHIP_SQUARED_EUCLIDEAN, subs,
                       km->codes.as<uint8_t>(), km->engine, s));
     const uint8_t *act = km->all_active ? nullptr : km->active_dev.as<uint8_t>();
-    if (km->exact_update) {
+    if (km->exact_update || km->sums_by_chains) {
         size_t need = exact_sums_workspace_bytes(km->cs.m, km->cs.k, ds->n);
         VQ_TRY(km->xs_ws.ensure(need));
         VQ_TRY(launch_exact_sums(km->cs.m, km->cs.k, km->cs.sd, ds->X, ds->n, ds->d, km->codes.as<uint8_t>(), act,
@@ -912,7 +918,7 @@ int vqhip_kmeans_finalize(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) 
 static bool kmeans_graph_eligible(const vqhip_kmeans *km) {
     static const char *env = getenv("VQHIP_GRAPH");
     if (env && env[0] == '0') return false;
-    if (km->graph_failed || km->exact_update || g_prof.on) return false;
+    if (km->graph_failed || km->exact_update || km->sums_by_chains || g_prof.on) return false;
     if (env && env[0] == '1') return true;
     return (uint64_t)km->ds->n * km->cs.m <= (4ull << 20);
 }
