@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void k_assign_exact_tiled(
     constexpr uint32_t TR = kTiledRows, TC = kTiledDims, KG = kTiledCentroids;
     __shared__ float acc[KG][TR];
     __shared__ float xs[TC][TR + 1];
+    __shared__ float na_s[TR];  // cosine: |x| of the workgroup's rows
     const uint32_t s = sub_list ? sub_list[blockIdx.y] : blockIdx.y;
     const uint32_t r = threadIdx.x & 63;
     const uint32_t q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -242,19 +243,19 @@ __global__ __launch_bounds__(256) void k_assign_exact_tiled(
             }
 #undef VQ_TC
         }
+        if (METRIC == VQHIP_COSINE && kg0 == 0 && q == 0) na_s[r] = sqrtf(sa);  // |x|, shared with the other waves
         __syncthreads();
-        if (q == 0) {  // this group's centroids in ascending order, strict '<' (scan_one's rule)
-            if (METRIC == VQHIP_COSINE && kg0 == 0) na = sqrtf(sa);
-            for (uint32_t jj = 0; jj < kn; ++jj) {
-                const uint32_t j = kg0 + jj;
+        if constexpr (METRIC == VQHIP_EUCLIDEAN || METRIC == VQHIP_COSINE) {
+            // accumulators -> distances, every wave its own centroids (the division and the square root are the
+            // expensive part of a short sub-vector's scan; one wave doing all of them serialised the workgroup)
+            if (METRIC == VQHIP_COSINE) na = na_s[r];
+            for (uint32_t jj = q; jj < kn; jj += 4) {
                 const float a = acc[jj][r];
                 float dist;
-                if constexpr (METRIC == VQHIP_SQUARED_EUCLIDEAN || METRIC == VQHIP_MANHATTAN) {
-                    dist = a;
-                } else if constexpr (METRIC == VQHIP_EUCLIDEAN) {
+                if constexpr (METRIC == VQHIP_EUCLIDEAN) {
                     dist = sqrtf(a);
                 } else {  // src/core/distance.rs:107-119
-                    const float nb = cnsq[j];
+                    const float nb = cnsq[kg0 + jj];
                     const float EPS = 1e-10f;
                     if (na < EPS || nb < EPS) {
                         dist = 1.0f;
@@ -265,6 +266,14 @@ __global__ __launch_bounds__(256) void k_assign_exact_tiled(
                         dist = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
                     }
                 }
+                acc[jj][r] = dist;
+            }
+            __syncthreads();
+        }
+        if (q == 0) {  // this group's centroids in ascending order, strict '<' (scan_one's rule)
+            for (uint32_t jj = 0; jj < kn; ++jj) {
+                const uint32_t j = kg0 + jj;
+                const float dist = acc[jj][r];
                 if (j == 0) {
                     best_dist = dist;
                 } else if (dist < best_dist) {
