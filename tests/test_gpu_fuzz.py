@@ -199,7 +199,8 @@ def test_fuzz_tsvq(oracle, seed):
 
 @pytest.mark.parametrize("rep", range(SCALE))
 @pytest.mark.parametrize("kind", KINDS + ["nan_rows", "huge_then_small", "half_ulps"])
-@pytest.mark.parametrize("shape", [(40_000, 32, 4), (70_001, 64, 3), (120_000, 128, 2)])
+@pytest.mark.parametrize("shape", [(40_000, 32, 4), (70_001, 64, 3), (120_000, 128, 2), (50_000, 100, 3), (45_000, 36, 3),
+                                   (40_000, 4, 4)])  # the last three: a short last block of columns (d % 32 != 0)
 def test_tsvq_build_long_nodes_bit_identical(oracle, kind, shape, rep):
     """Nodes of >= 16384 rows take the tile-parallel exact emulation of the sequential column sums
     (k_fs_*): the tree must still be the oracle's bit for bit on data that stresses the binade /

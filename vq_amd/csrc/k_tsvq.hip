@@ -688,11 +688,13 @@ __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ 
                                                       double *__restrict__ tile_sum) {
     __shared__ double part[32][kFsCols + 1];
     // 1-D grid, column block fastest: the d/32 workgroups that share a tile's rows (and DRAM pages) run together
-    const uint32_t ncb = d / kFsCols, tile_id = blockIdx.x / ncb, cblk = blockIdx.x - tile_id * ncb;
+    // (d is a multiple of 4; the last column block may be short: its missing 16-byte parts are skipped)
+    const uint32_t ncb = (d + kFsCols - 1) / kFsCols, tile_id = blockIdx.x / ncb, cblk = blockIdx.x - tile_id * ncb;
     const FsTile tl = tiles[tile_id];
     const uint32_t c0 = cblk * kFsCols, q = threadIdx.x & 7, rr = threadIdx.x >> 3;
+    const bool col_ok = c0 + 4 * q < d;
     float mu[4] = {0.f, 0.f, 0.f, 0.f};
-    if (MODE == 1) {
+    if (MODE == 1 && col_ok) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) mu[i] = na.centroid[(size_t)tl.node * d + c0 + 4 * q + i];
     }
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ 
 #pragma unroll 4
     for (uint32_t i = 0; i < kFsTile / 32; ++i) {
         const uint32_t r = rr + 32 * i;
-        if (r < tl.rows) {
+        if (r < tl.rows && col_ok) {
             const float4 v = *reinterpret_cast<const float4 *>(X + (size_t)perm[tl.start + r] * d + c0 + 4 * q);
             acc[0] += (double)fs_value<MODE>(v.x, mu[0]);
             acc[1] += (double)fs_value<MODE>(v.y, mu[1]);
@@ -711,7 +713,7 @@ __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ 
 #pragma unroll
     for (int i = 0; i < 4; ++i) part[rr][4 * q + i] = acc[i];
     __syncthreads();
-    if (threadIdx.x < kFsCols) {
+    if (threadIdx.x < kFsCols && c0 + threadIdx.x < d) {
         double s = 0.0;
         for (int r = 0; r < 32; ++r) s += part[r][threadIdx.x];
         tile_sum[(size_t)tile_id * d + c0 + threadIdx.x] = s;
@@ -726,10 +728,13 @@ __global__ __launch_bounds__(1024) void k_fs_prefix(uint32_t d, const uint32_t *
     const uint32_t c = blockIdx.y * kFsCols + (threadIdx.x & 31), lt = threadIdx.x >> 5;
     const uint32_t base = tile_base[blockIdx.x], nt = n_tiles_of[blockIdx.x];
     const uint32_t chunk = (nt + 31) / 32, t0 = lt * chunk, t1 = min(nt, t0 + chunk);
+    const bool col_ok = c < d;
     double local = 0.0;
-    for (uint32_t t = t0; t < t1; ++t) local += tile_sum[(size_t)(base + t) * d + c];
+    if (col_ok)
+        for (uint32_t t = t0; t < t1; ++t) local += tile_sum[(size_t)(base + t) * d + c];
     part[lt][threadIdx.x & 31] = local;
     __syncthreads();
+    if (!col_ok) return;
     double run = 0.0;
     for (uint32_t q = 0; q < lt; ++q) run += part[q][threadIdx.x & 31];
     for (uint32_t t = t0; t < t1; ++t) {
@@ -763,7 +768,7 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
     FsAcc(*seg_acc)[kFsCols] = reinterpret_cast<FsAcc(*)[kFsCols]>(fs_lds + kFsCols * (kFsTile + 1) * 4);  // [8][32]
     __shared__ int seg_bad[8][kFsCols];
     __shared__ int col_slot[kFsCols];
-    const uint32_t ncb = d / kFsCols;
+    const uint32_t ncb = (d + kFsCols - 1) / kFsCols;  // the last column block may be short (d % 4 == 0)
     const uint32_t q = threadIdx.x & 7, rr = threadIdx.x >> 3;     // load role: 16-byte part q of rows rr + 32 i
     const uint32_t cl = threadIdx.x & 31, seg = threadIdx.x >> 5;  // fold role: column cl, rows 64 seg ..
     uint32_t item = blockIdx.x;
@@ -779,16 +784,20 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
             const uint32_t r = rr + 32 * i;
             prow[i] = perm[t.start + min(r, t.rows - 1u)];  // clamped, not predicated: rows past the end park as zeros
         }
+        // a short last column block: the missing parts / columns read the block's first ones instead (valid
+        // addresses, values never used: their summaries are not written)
+        const uint32_t cq = (c0n + 4 * q < d) ? c0n + 4 * q : c0n;
         if (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mu4[i] = na.centroid[(size_t)t.node * d + c0n + 4 * q + i];
+            for (int i = 0; i < 4; ++i) mu4[i] = na.centroid[(size_t)t.node * d + cq + i];
         }
-        pref = tile_pref[(size_t)tid * d + c0n + cl];
+        pref = tile_pref[(size_t)tid * d + ((c0n + cl < d) ? c0n + cl : c0n)];
     };
     auto issue_rows = [&](uint32_t it) {
         const uint32_t tid = it / ncb, c0n = (it - tid * ncb) * kFsCols;
+        const uint32_t cq = (c0n + 4 * q < d) ? c0n + 4 * q : c0n;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (size_t)prow[i] * d + c0n + 4 * q);
+        for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (size_t)prow[i] * d + cq);
     };
     FsTile tl = tiles[item / ncb];
     issue_perm(tl, item);
@@ -907,7 +916,7 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
             const long long margin = 1ll << 14;  // 0.2 % of the binade; the f64 guess is good to ~1e-5
             const bool leaves = (Sg > 0) ? (Sg + lo2 < (1ll << 23) + margin || Sg + hi2 > (1ll << 24) - margin)
                                          : (Sg + hi2 > -(1ll << 23) - margin || Sg + lo2 < -(1ll << 24) + margin);
-            if ((anybad || leaves) && side_cap) {
+            if ((anybad || leaves) && side_cap && c < d) {
                 const uint32_t got = atomicAdd(side_count, 1u);
                 if (got < side_cap) slot = (int)got;
             }
@@ -922,7 +931,7 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
         o.hi1 = (int32_t)f.hi[1];
         o.e = e;
         o.flag = (anybad ? 1 : 0) | ((slot + 1) << 1);  // bit 0: unusable; bits 1..: side slot + 1
-        summ[(size_t)tile_id * d + c] = o;
+        if (c < d) summ[(size_t)tile_id * d + c] = o;
     }
     __syncthreads();
 #pragma unroll 1
@@ -1328,7 +1337,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     static const char *nopark = getenv("VQHIP_TSVQ_NOPARK");
     const uint32_t side_cap = (nopark && nopark[0] == '1') ? 0u : 32768u;  // parked tiles per call (64 MB); beyond it the re-addition gathers
     static const char *seq_env = getenv("VQHIP_TSVQ_SEQSUM");  // =1: plain chain everywhere (A/B)
-    const bool can_fast = (d % kFsCols == 0) && !(seq_env && seq_env[0] == '1');
+    const bool can_fast = (d % 4 == 0) && !(seq_env && seq_env[0] == '1');  // 16-byte row parts
     const size_t fs_lds_bytes = (size_t)kFsCols * (kFsTile + 1) * 4 + 8 * kFsCols * sizeof(FsAcc);
     {
         static PerDeviceOnce fs_attr;
@@ -1381,7 +1390,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             VQ_LAUNCH_CHECK("k_seg_colsum");
         }
         if (!fast.empty()) {
-            const uint32_t n_items = (uint32_t)tiles.size() * (d / kFsCols);
+            const uint32_t n_items = (uint32_t)tiles.size() * ((d + kFsCols - 1) / kFsCols);
             const dim3 tgrid(n_items);
             const dim3 xgrid(std::min<uint32_t>(n_items, (uint32_t)num_cus() * 2));  // persistent: two workgroups fit a CU's LDS
             const FsTile *tl = b_fs_tiles.as<FsTile>();
@@ -1391,12 +1400,12 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             const dim3 cgrid((uint32_t)fast.size(), d);
             if (mode == 0) {
                 hipLaunchKernelGGL(k_fs_tile_sums<0>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts);
-                hipLaunchKernelGGL(k_fs_prefix, dim3((uint32_t)fast.size(), d / kFsCols), dim3(1024), 0, stream, d, fb, fc, ts);
+                hipLaunchKernelGGL(k_fs_prefix, dim3((uint32_t)fast.size(), (d + kFsCols - 1) / kFsCols), dim3(1024), 0, stream, d, fb, fc, ts);
                 hipLaunchKernelGGL(k_fs_transduce<0>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, n_items, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1);
                 hipLaunchKernelGGL(k_fs_chain<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, b_fs_side.as<float>(), b_fs_fb.as<uint32_t>());
             } else {
                 hipLaunchKernelGGL(k_fs_tile_sums<1>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts);
-                hipLaunchKernelGGL(k_fs_prefix, dim3((uint32_t)fast.size(), d / kFsCols), dim3(1024), 0, stream, d, fb, fc, ts);
+                hipLaunchKernelGGL(k_fs_prefix, dim3((uint32_t)fast.size(), (d + kFsCols - 1) / kFsCols), dim3(1024), 0, stream, d, fb, fc, ts);
                 hipLaunchKernelGGL(k_fs_transduce<1>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, n_items, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1);
                 hipLaunchKernelGGL(k_fs_chain<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, b_fs_side.as<float>(), b_fs_fb.as<uint32_t>());
             }
