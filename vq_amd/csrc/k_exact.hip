@@ -749,12 +749,31 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
         VQ_EXACT_CASE(4)
         VQ_EXACT_CASE(5)
         VQ_EXACT_CASE(6)
+        VQ_EXACT_CASE(7)
         VQ_EXACT_CASE(8)
+        VQ_EXACT_CASE(9)
         VQ_EXACT_CASE(10)
+        VQ_EXACT_CASE(11)
         VQ_EXACT_CASE(12)
+        VQ_EXACT_CASE(13)
+        VQ_EXACT_CASE(14)
+        VQ_EXACT_CASE(15)
         VQ_EXACT_CASE(16)
+        VQ_EXACT_CASE(17)
+        VQ_EXACT_CASE(18)
+        VQ_EXACT_CASE(19)
         VQ_EXACT_CASE(20)
+        VQ_EXACT_CASE(21)
+        VQ_EXACT_CASE(22)
+        VQ_EXACT_CASE(23)
         VQ_EXACT_CASE(24)
+        VQ_EXACT_CASE(25)
+        VQ_EXACT_CASE(26)
+        VQ_EXACT_CASE(27)
+        VQ_EXACT_CASE(28)
+        VQ_EXACT_CASE(29)
+        VQ_EXACT_CASE(30)
+        VQ_EXACT_CASE(31)
         VQ_EXACT_CASE(32)
         VQ_EXACT_CASE(40)
         VQ_EXACT_CASE(48)
