@@ -42,10 +42,10 @@ def _draw_data(rng, n, d, kind):
 @pytest.mark.parametrize("seed", range(40 * SCALE))
 def test_fuzz_pq_encode(oracle, seed):
     rng = np.random.default_rng(1000 + seed)
-    sd = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 8, 9, 11, 12, 16, 16, 24, 30, 32, 32, 33, 40, 48, 48, 64, 64, 100, 130]))
+    sd = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 8, 9, 10, 10, 11, 12, 14, 16, 16, 18, 20, 22, 24, 30, 32, 32, 33, 40, 48, 48, 64, 64, 100, 130]))
     m = int(rng.choice([1, 2, 3, 4, 8, 16]))
     d = sd * m
-    k = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 64, 100, 128, 200, 255, 256]))
+    k = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 64, 100, 128, 200, 225, 240, 255, 256, 256]))
     n = int(rng.integers(1, 3000))
     kind = KINDS[int(rng.integers(0, len(KINDS)))]
     metric = int(rng.integers(0, 4))
@@ -72,10 +72,10 @@ def test_fuzz_pq_encode(oracle, seed):
 @pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_fuzz_lloyd_step(oracle, seed):
     rng = np.random.default_rng(2000 + seed)
-    sd = int(rng.choice([2, 4, 7, 8, 12, 16, 24, 31, 32, 48, 64, 70]))
+    sd = int(rng.choice([2, 4, 6, 7, 8, 10, 12, 14, 16, 20, 24, 31, 32, 48, 64, 70]))
     m = int(rng.choice([1, 2, 4, 8]))
     d = sd * m
-    k = int(rng.choice([2, 16, 50, 128, 256]))
+    k = int(rng.choice([2, 16, 50, 128, 230, 256, 256]))
     n = int(rng.integers(k, 6000))
     kind = KINDS[int(rng.integers(0, len(KINDS)))]
     X = _draw_data(rng, n, d, kind)

@@ -65,6 +65,13 @@ SHAPES = [  # (n, d, m, k)
     (1300, 144, 3, 150),   # sub_dim 48: three groups, ragged k
     (1700, 128, 2, 256),   # sub_dim 64: four groups of 64 centroids
     (900, 64, 1, 50),      # sub_dim 64, one group
+    (2000, 100, 10, 256),  # sub_dim 10 on the zero-padded sub_dim-12 screen (GloVe-like 100 = 10 x 10)
+    (1500, 60, 10, 240),   # sub_dim 6 -> 8, k just inside the padded variants' range (> 224)
+    (1800, 42, 3, 256),    # sub_dim 14 -> 16
+    (1300, 120, 6, 256),   # sub_dim 20 -> 24 (16-byte parts)
+    (1100, 36, 2, 230),    # sub_dim 18 -> 24
+    (901, 44, 2, 256),     # sub_dim 22 -> 24; the last row's last sub-vector ends the buffer
+    (1200, 100, 10, 200),  # sub_dim 10 with k <= 224: no padded variant, exact engine
 ]
 
 

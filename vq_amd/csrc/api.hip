@@ -121,8 +121,9 @@ struct CodebookState {
             screen_bf16_x32_tiling(sd, k, &per, &x32_groups);
             const size_t tiles = (size_t)per * x32_groups;  // image padded to whole centroid groups
             VQ_TRY(prepA32.alloc((size_t)m * tiles * screen_bf16_x32_mfmas(sd) * 4 * 64 * 4));
-            VQ_TRY(cbc.alloc((size_t)m * k * sd * 4));
-            VQ_TRY(cen.alloc((size_t)m * (sd + 4) * 4));
+            const uint32_t sdp = x32_padded_sd(sd);  // >= sd: the screen kernel's sub_dim (zero padding)
+            VQ_TRY(cbc.alloc((size_t)m * k * sdp * 4));
+            VQ_TRY(cen.alloc((size_t)m * (sdp + 4) * 4));
             VQ_TRY(cn32.alloc((size_t)m * tiles * 32 * 4));
         }
         prepared = false;
@@ -152,7 +153,8 @@ struct CodebookState {
         VQ_TRY(launch_prepare_codebook(v, mfma_ok ? prepA.as<float>() : nullptr,
                                        mfma_ok ? prepCn.as<float>() : nullptr, meta.as<float>(),
                                        cnsqrt.as<float>(), stream));
-        const bool use32 = x32_ok && screen_bf16_uses_x32(sd, k);
+        // (the padded sub_dims have no cosine image: a cosine encoder of such a shape stays on the exact engine)
+        const bool use32 = x32_ok && screen_bf16_uses_x32(sd, k) && !(metric == VQHIP_COSINE && x32_padded_sd(sd) != sd);
         if (bf16_16 && !use32) VQ_TRY(launch_prepare_bf16(v, prepA16.as<uint32_t>(), stream));
         if (use32)
             VQ_TRY(launch_prepare_bf16_x32(v, prepA32.as<uint32_t>(), metric == VQHIP_COSINE ? 1 : 0, cbc.as<float>(),
@@ -224,6 +226,7 @@ static int pick_engine(int requested, const CodebookState &cs, int metric, int *
     const bool l2_metric = (metric == VQHIP_SQUARED_EUCLIDEAN || metric == VQHIP_EUCLIDEAN);
     // cosine has a screen too (s = -x.c/|c| on the X32 bf16 engine); Manhattan has no contraction form
     const bool cos_ok = (metric == VQHIP_COSINE) && cs.x32_ok && screen_bf16_uses_x32(cs.sd, cs.k) &&
+                        x32_padded_sd(cs.sd) == cs.sd &&
                         cs.metric == VQHIP_COSINE;
     if (requested == VQHIP_ENGINE_EXACT) {
         *engine = VQHIP_ENGINE_EXACT;

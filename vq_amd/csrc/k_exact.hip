@@ -725,9 +725,15 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
         return VQHIP_OK;
         switch (cb.sd) {
             VQ_RECHECK_CASE(4)
+            VQ_RECHECK_CASE(6)
             VQ_RECHECK_CASE(8)
+            VQ_RECHECK_CASE(10)
             VQ_RECHECK_CASE(12)
+            VQ_RECHECK_CASE(14)
             VQ_RECHECK_CASE(16)
+            VQ_RECHECK_CASE(18)
+            VQ_RECHECK_CASE(20)
+            VQ_RECHECK_CASE(22)
             VQ_RECHECK_CASE(24)
             VQ_RECHECK_CASE(32)
             VQ_RECHECK_CASE(48)

@@ -601,8 +601,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // sub-vectors of 16 dimensions shrink from |x| ~ 2.3 to ~ 1.15 (T / 4), data with a large common
 // offset by far more.  cen[s] = {mu[sd], max|c - mu|, margin coefficient, -, -}; cn32 = |c - mu|^2
 // (sequential f32 like k_prepare_codebook), padded with a large finite value.
+// sdp >= sd: sub_dim of the screen kernel that serves this codebook (x32_padded_sd); the copy and mu are
+// written sdp wide with zeros in the padding, where the screen's operands are zero too.
 __global__ __launch_bounds__(256) void k_center_codebook_x32(const float *__restrict__ cb, uint32_t m, uint32_t k,
-                                                             uint32_t sd, uint32_t cn_stride, uint32_t nmf,
+                                                             uint32_t sd, uint32_t sdp, uint32_t cn_stride, uint32_t nmf,
                                                              float *__restrict__ cbc, float *__restrict__ cen,
                                                              float *__restrict__ cn32) {
     __shared__ float s_mu[64];
@@ -610,7 +612,8 @@ __global__ __launch_bounds__(256) void k_center_codebook_x32(const float *__rest
     __shared__ int s_bad[256];
     const uint32_t s = blockIdx.x;
     const float *cbs = cb + (size_t)s * k * sd;
-    float *cen_s = cen + (size_t)s * (sd + 4);
+    float *cen_s = cen + (size_t)s * (sdp + 4);
+    if (threadIdx.x >= sd && threadIdx.x < sdp) cen_s[threadIdx.x] = 0.0f;
     // column means: 256 threads = (256/sd) row groups x sd columns, partial sums through LDS
     // (a single thread per column walking k dependent loads cost 25 us per launch)
     {
@@ -637,11 +640,12 @@ __global__ __launch_bounds__(256) void k_center_codebook_x32(const float *__rest
             float acc = -0.0f;
             for (uint32_t t = 0; t < sd; ++t) {
                 const float v = cbs[(size_t)j * sd + t] - s_mu[t];
-                cbc[((size_t)s * k + j) * sd + t] = v;
+                cbc[((size_t)s * k + j) * sdp + t] = v;
                 const float p = v * v;
                 acc = acc + p;
                 if (!(fabsf(v) <= 3.0e38f)) bad = 1;
             }
+            for (uint32_t t = sd; t < sdp; ++t) cbc[((size_t)s * k + j) * sdp + t] = 0.0f;
             if (!(acc <= 3.0e38f)) bad = 1;
             cn32[(size_t)s * cn_stride + j] = (acc <= 3.0e38f) ? acc + 0.0f : 3.0e38f;
             lmax = fmaxf(lmax, acc);
@@ -662,11 +666,11 @@ __global__ __launch_bounds__(256) void k_center_codebook_x32(const float *__rest
     if (threadIdx.x == 0) {
         // DESIGN.md "screen soundness": bf16 coefficient + 128 (index packing) + 16 (rounding of x - mu, c - mu)
         const float u = 5.9604644775390625e-08f;
-        const float coef = (8.0f * (float)sd + 16.0f + 2.0f * kBf16AssumedUlps * (float)nmf + 16.0f + 128.0f + 16.0f) * u;
-        cen_s[sd] = sqrtf(s_max[0]) * 1.0000005f + 1e-30f;
-        cen_s[sd + 1] = s_bad[0] ? __builtin_inff() : coef;
-        cen_s[sd + 2] = 0.0f;
-        cen_s[sd + 3] = 0.0f;
+        const float coef = (8.0f * (float)sdp + 16.0f + 2.0f * kBf16AssumedUlps * (float)nmf + 16.0f + 128.0f + 16.0f) * u;
+        cen_s[sdp] = sqrtf(s_max[0]) * 1.0000005f + 1e-30f;
+        cen_s[sdp + 1] = s_bad[0] ? __builtin_inff() : coef;
+        cen_s[sdp + 2] = 0.0f;
+        cen_s[sdp + 3] = 0.0f;
     }
 }
 
@@ -708,7 +712,10 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
 // of centroids; a wave then stops after merging its two lane halves and writes {min, second min,
 // argmin, |x - mu|^2} per row to `part`; k_merge_partials_x32 merges the groups, applies the margin
 // test and feeds the (unsegmented) re-check list.  G = 1 is the single-pass kernel.
-template <int SD, int NT32, int G = 1>
+// SDR < SD ("padded"): the data's sub_dim is SDR (even), the kernel works on SD dimensions whose last SD - SDR
+// are zero in both operands (k_center_codebook_x32 writes the copy SD wide): sub_dims 6, 10, 14, 18, 20, 22 ride
+// on the 8 / 12 / 16 / 24 kernels instead of the exact engine.
+template <int SD, int NT32, int G = 1, int SDR = SD>
 // k <= 128 at sub_dim <= 16: the A image is <= 96 registers, two waves fit a SIMD (0.30 vs 0.37 ms at C2 / k=128)
 __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_assign_screen_bf16_x32(
     const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m,
@@ -791,11 +798,31 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
         for (int q = 0; q < DPH; ++q) mu[q] = cs[DPH * h + q];
     }
 
-    const size_t col0 = (size_t)s * SD + (size_t)DPH * h;
+    const size_t col0 = (size_t)s * SDR + (size_t)DPH * h;
     auto load_x = [&](uint64_t row, float (&x)[DPH]) {
         if (row >= n) row = n - 1;
         const float *ptr = X + row * d + col0;
-        if constexpr (DPH % 4 == 0) {
+        if constexpr (SDR != SD) {
+            // the upper lane half runs past the sub-vector: those parts re-read its first part (a valid address)
+            // and are zeroed.  16-byte parts when the sub-vectors start on 16-byte boundaries, else 8-byte ones.
+            constexpr int VW = (SDR % 4 == 0 && DPH % 4 == 0) ? 4 : 2;
+#pragma unroll
+            for (int q = 0; q < DPH; q += VW) {
+                const bool live = (uint32_t)(DPH * h + q) < (uint32_t)SDR;
+                const float *pq = ptr + (live ? q : 0);
+                if constexpr (VW == 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(pq);
+                    x[q + 0] = live ? t.x : 0.0f;
+                    x[q + 1] = live ? t.y : 0.0f;
+                    x[q + 2] = live ? t.z : 0.0f;
+                    x[q + 3] = live ? t.w : 0.0f;
+                } else {
+                    const float2 t = *reinterpret_cast<const float2 *>(pq);
+                    x[q + 0] = live ? t.x : 0.0f;
+                    x[q + 1] = live ? t.y : 0.0f;
+                }
+            }
+        } else if constexpr (DPH % 4 == 0) {
 #pragma unroll
             for (int q = 0; q < DPH; q += 4) {
                 const float4 t = *reinterpret_cast<const float4 *>(ptr + q);
@@ -1562,7 +1589,7 @@ int launch_one(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) 
     return VQHIP_OK;
 }
 
-template <int SD, int NT32, int G = 1>
+template <int SD, int NT32, int G = 1, int SDR = SD>
 int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stream, uint32_t groups_rt = 0) {
     const uint32_t groups = (G > 0) ? (uint32_t)G : groups_rt;  // G == 0: run-time group count (k > 256)
     const uint64_t n_steps = (a.n + 31) / 32;
@@ -1584,7 +1611,7 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
         if (!a.part) return fail(VQHIP_ERR_FAILURE, "grouped screen without a partial-result buffer");
         a.n_seg = 0;  // the merge kernel appends to the unsegmented list
     }
-    hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32, G>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d,
+    hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32, G, SDR>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d,
                        cb.m, cb.prepA32, cb.cn32, NT32 * groups * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
                        a.wl_seg, n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen,
                        reinterpret_cast<uint4 *>(a.part), groups);
@@ -1609,9 +1636,25 @@ bool screen_bf16_uses_x32(uint32_t sd, uint32_t k) {
 }
 
 // tiles of 32 centroids per wave and centroid groups for a shape (0 = no X32 form)
-void screen_bf16_x32_tiling(uint32_t sd, uint32_t k, uint32_t *nt32_per_group, uint32_t *groups) {
+// sub_dim of the X32 kernel that serves `sd`: itself when instantiated, the next one up for the even sub_dims in
+// between (zero padding, see the kernel's SDR parameter), 0 when there is none
+uint32_t x32_padded_sd(uint32_t sd) {
+    switch (sd) {
+    case 8: case 12: case 16: case 24: case 32: case 48: case 64: return sd;
+    case 6: return 8;
+    case 10: return 12;
+    case 14: return 16;
+    case 18: case 20: case 22: return 24;
+    default: return 0;
+    }
+}
+
+void screen_bf16_x32_tiling(uint32_t sd_real, uint32_t k, uint32_t *nt32_per_group, uint32_t *groups) {
     *nt32_per_group = *groups = 0;
     if (k == 0 || k > kMaxCentroids) return;
+    const uint32_t sd = x32_padded_sd(sd_real);
+    if (sd == 0) return;
+    if (sd != sd_real && (k <= 224 || k > 256)) return;  // padded variants exist for the full 8-tile image only
     const uint32_t nt = (k + 31) / 32;
     uint32_t cap;  // tiles whose A image fits next to the working set: NMF * cap * 4 registers
     switch (sd) {
@@ -1635,7 +1678,8 @@ bool screen_bf16_x32_supported(uint32_t sd, uint32_t k) {
     screen_bf16_x32_tiling(sd, k, &per, &groups);
     return per != 0;
 }
-uint32_t screen_bf16_x32_mfmas(uint32_t sd) {
+uint32_t screen_bf16_x32_mfmas(uint32_t sd_real) {
+    const uint32_t sd = x32_padded_sd(sd_real) ? x32_padded_sd(sd_real) : sd_real;
     return (6 * (sd / 2) + 7) / 8;
 }
 // X32 images of a codebook.  Squared-L2 / Euclidean: centred copy (cbc), its norms (cn32) and {mu, max|c-mu|,
@@ -1647,13 +1691,15 @@ int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine
     screen_bf16_x32_tiling(v.sd, v.k, &per, &groups);
     const uint32_t nt32 = per * groups;  // image padded to whole groups (zero operands, never-winning norms)
     const float *src = v.cb;
+    const uint32_t sdp = x32_padded_sd(v.sd);
+    if (cosine && sdp != v.sd) return fail(VQHIP_ERR_UNSUPPORTED, "no cosine screen for the padded sub_dim %u", v.sd);
     if (!cosine) {
-        hipLaunchKernelGGL(k_center_codebook_x32, dim3(v.m), dim3(256), 0, stream, v.cb, v.m, v.k, v.sd, nt32 * 32,
+        hipLaunchKernelGGL(k_center_codebook_x32, dim3(v.m), dim3(256), 0, stream, v.cb, v.m, v.k, v.sd, sdp, nt32 * 32,
                            screen_bf16_x32_mfmas(v.sd), cbc, cen, cn32);
         VQ_LAUNCH_CHECK("k_center_codebook_x32");
-        src = cbc;
+        src = cbc;  // sdp wide
     }
-    hipLaunchKernelGGL(k_prepare_bf16_x32, dim3(v.m, 16), dim3(256), 0, stream, src, v.m, v.k, v.sd, nt32,
+    hipLaunchKernelGGL(k_prepare_bf16_x32, dim3(v.m, 16), dim3(256), 0, stream, src, v.m, v.k, cosine ? v.sd : sdp, nt32,
                        screen_bf16_x32_mfmas(v.sd), cosine, v.cnsqrt, prepA32);
     VQ_LAUNCH_CHECK("k_prepare_bf16_x32");
     return VQHIP_OK;
@@ -1708,6 +1754,12 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
         VQ_X32(32, 1) VQ_X32(32, 2) VQ_X32(32, 3) VQ_X32(32, 4) VQ_X32G(32, 4, 2)
         VQ_X32(48, 1) VQ_X32(48, 2) VQ_X32G(48, 2, 2) VQ_X32G(48, 2, 3) VQ_X32G(48, 2, 4)
         VQ_X32(64, 1) VQ_X32(64, 2) VQ_X32G(64, 2, 2) VQ_X32G(64, 2, 3) VQ_X32G(64, 2, 4)
+        // padded sub_dims (SDR < SD), full 8-tile image, squared-L2 / Euclidean
+#define VQ_X32P(SDV, SDRV) \
+    if (cb.sd == SDRV && nt32 == 8 && groups == 1 && a.metric != VQHIP_COSINE) \
+        return launch_one_x32<SDV, 8, 1, SDRV>(cb, a, stream);
+        VQ_X32P(8, 6) VQ_X32P(12, 10) VQ_X32P(16, 14) VQ_X32P(24, 18) VQ_X32P(24, 20) VQ_X32P(24, 22)
+#undef VQ_X32P
         // k > 256: full groups, run-time count
 #define VQ_X32R(SDV, NTV) \
     if (cb.sd == SDV && nt32 == NTV && cb.k > 256) return launch_one_x32<SDV, NTV, 0>(cb, a, stream, groups);
