@@ -72,6 +72,12 @@ SHAPES = [  # (n, d, m, k)
     (1100, 36, 2, 230),    # sub_dim 18 -> 24
     (901, 44, 2, 256),     # sub_dim 22 -> 24; the last row's last sub-vector ends the buffer
     (1200, 100, 10, 200),  # sub_dim 10 with k <= 224: no padded variant, exact engine
+    (1500, 35, 5, 256),    # sub_dim 7 -> 8 (odd: single-float parts, rows 4-byte aligned only)
+    (1400, 45, 3, 256),    # sub_dim 15 -> 16 (300 = 20 x 15)
+    (1200, 63, 3, 250),    # sub_dim 21 -> 24
+    (1100, 27, 3, 256),    # sub_dim 9 -> 12
+    (1000, 5, 1, 256),     # sub_dim 5 -> 8, m = 1
+    (999, 23, 1, 226),     # sub_dim 23 -> 24
 ]
 
 

@@ -153,8 +153,7 @@ struct CodebookState {
         VQ_TRY(launch_prepare_codebook(v, mfma_ok ? prepA.as<float>() : nullptr,
                                        mfma_ok ? prepCn.as<float>() : nullptr, meta.as<float>(),
                                        cnsqrt.as<float>(), stream));
-        // (the padded sub_dims have no cosine image: a cosine encoder of such a shape stays on the exact engine)
-        const bool use32 = x32_ok && screen_bf16_uses_x32(sd, k) && !(metric == VQHIP_COSINE && x32_padded_sd(sd) != sd);
+        const bool use32 = x32_ok && screen_bf16_uses_x32(sd, k);
         if (bf16_16 && !use32) VQ_TRY(launch_prepare_bf16(v, prepA16.as<uint32_t>(), stream));
         if (use32)
             VQ_TRY(launch_prepare_bf16_x32(v, prepA32.as<uint32_t>(), metric == VQHIP_COSINE ? 1 : 0, cbc.as<float>(),
@@ -226,7 +225,6 @@ static int pick_engine(int requested, const CodebookState &cs, int metric, int *
     const bool l2_metric = (metric == VQHIP_SQUARED_EUCLIDEAN || metric == VQHIP_EUCLIDEAN);
     // cosine has a screen too (s = -x.c/|c| on the X32 bf16 engine); Manhattan has no contraction form
     const bool cos_ok = (metric == VQHIP_COSINE) && cs.x32_ok && screen_bf16_uses_x32(cs.sd, cs.k) &&
-                        x32_padded_sd(cs.sd) == cs.sd &&
                         cs.metric == VQHIP_COSINE;
     if (requested == VQHIP_ENGINE_EXACT) {
         *engine = VQHIP_ENGINE_EXACT;

@@ -609,9 +609,10 @@ __global__ __launch_bounds__(256) void k_prepare_codebook(const float *__restric
         if (sd % 4 == 0 && sd >= 4 && sd <= 32) {
             const uint32_t dpg = sd / 4, pp = 8 / dpg, nm = (6 + pp - 1) / pp;
             coef16 = (8.0f * (float)sd + 16.0f + 2.0f * kBf16AssumedUlps * (float)nm + 16.0f) * u;
-        } else if (sd % 4 == 0) {
-            // no 16x16 variant for this sub_dim; the X32 kernels read [3] only as "codebook finite?" (cosine)
-            const uint32_t nm32 = (6 * (sd / 2) + 7) / 8;
+        } else {
+            // no 16x16 variant for this sub_dim; the X32 kernels (also the zero-padded ones) read [3] only as
+            // "codebook finite?" (cosine)
+            const uint32_t nm32 = (6 * ((sd + 1) / 2) + 7) / 8;
             coef16 = (8.0f * (float)sd + 16.0f + 2.0f * kBf16AssumedUlps * (float)nm32 + 16.0f) * u;
         }
         meta[s * 4 + 2] = s_bad[0] ? __builtin_inff() : coef16;
@@ -725,15 +726,25 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
         return VQHIP_OK;
         switch (cb.sd) {
             VQ_RECHECK_CASE(4)
+            VQ_RECHECK_CASE(5)
             VQ_RECHECK_CASE(6)
+            VQ_RECHECK_CASE(7)
             VQ_RECHECK_CASE(8)
+            VQ_RECHECK_CASE(9)
             VQ_RECHECK_CASE(10)
+            VQ_RECHECK_CASE(11)
             VQ_RECHECK_CASE(12)
+            VQ_RECHECK_CASE(13)
             VQ_RECHECK_CASE(14)
+            VQ_RECHECK_CASE(15)
             VQ_RECHECK_CASE(16)
+            VQ_RECHECK_CASE(17)
             VQ_RECHECK_CASE(18)
+            VQ_RECHECK_CASE(19)
             VQ_RECHECK_CASE(20)
+            VQ_RECHECK_CASE(21)
             VQ_RECHECK_CASE(22)
+            VQ_RECHECK_CASE(23)
             VQ_RECHECK_CASE(24)
             VQ_RECHECK_CASE(32)
             VQ_RECHECK_CASE(48)

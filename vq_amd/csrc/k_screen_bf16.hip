@@ -676,13 +676,15 @@ __global__ __launch_bounds__(256) void k_center_codebook_x32(const float *__rest
 
 // cosine != 0: the image holds -c/|c| (zero for |c| < 1e-10, whose distance is the constant 1.0,
 // src/core/distance.rs:113-115) so that the screen forms s_j = -|x| cos(x, c_j)
+// sd_src: row length of `cb` (the codebook as is for cosine, already sd wide for the centred copy); dimensions
+// from sd_src up to the kernel's sd are zero padding
 __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restrict__ cb, uint32_t m, uint32_t k,
-                                                          uint32_t sd, uint32_t nt32, uint32_t nmf, int cosine,
+                                                          uint32_t sd_src, uint32_t sd, uint32_t nt32, uint32_t nmf, int cosine,
                                                           const float *__restrict__ cnsqrt,
                                                           uint32_t *__restrict__ prepA32) {
     const uint32_t s = blockIdx.x;
     const uint32_t dph = sd / 2;
-    const float *cbs = cb + (size_t)s * k * sd;
+    const float *cbs = cb + (size_t)s * k * sd_src;
     const uint32_t total = nt32 * nmf * 4 * 64;
     for (uint32_t e = blockIdx.y * blockDim.x + threadIdx.x; e < total; e += gridDim.y * blockDim.x) {
         const uint32_t lane = e & 63, w = (e >> 6) & 3, f = (e >> 8) % nmf, i = (e >> 8) / nmf;
@@ -691,9 +693,9 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
         for (uint32_t hh = 0; hh < 2; ++hh) {
             const uint32_t flat = 8 * f + 2 * w + hh;  // k-slot of this lane half over all MFMAs
             const uint32_t pair = flat / dph, dd = flat - pair * dph;
-            if (pair < 6 && j < k) {
+            if (pair < 6 && j < k && h * dph + dd < sd_src) {
                 uint32_t parts[3];
-                const float c = cbs[(size_t)j * sd + h * dph + dd];
+                const float c = cbs[(size_t)j * sd_src + h * dph + dd];
                 float av = -2.0f * c;
                 if (cosine) {
                     const float nb = cnsqrt[(size_t)s * k + j];
@@ -713,8 +715,8 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
 // argmin, |x - mu|^2} per row to `part`; k_merge_partials_x32 merges the groups, applies the margin
 // test and feeds the (unsegmented) re-check list.  G = 1 is the single-pass kernel.
 // SDR < SD ("padded"): the data's sub_dim is SDR (even), the kernel works on SD dimensions whose last SD - SDR
-// are zero in both operands (k_center_codebook_x32 writes the copy SD wide): sub_dims 6, 10, 14, 18, 20, 22 ride
-// on the 8 / 12 / 16 / 24 kernels instead of the exact engine.
+// are zero in both operands (k_center_codebook_x32 writes the copy SD wide): every sub_dim from 5 to 23 rides on
+// the next of the 8 / 12 / 16 / 24 kernels instead of the exact engine.
 template <int SD, int NT32, int G = 1, int SDR = SD>
 // k <= 128 at sub_dim <= 16: the A image is <= 96 registers, two waves fit a SIMD (0.30 vs 0.37 ms at C2 / k=128)
 __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_assign_screen_bf16_x32(
@@ -804,8 +806,9 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
         const float *ptr = X + row * d + col0;
         if constexpr (SDR != SD) {
             // the upper lane half runs past the sub-vector: those parts re-read its first part (a valid address)
-            // and are zeroed.  16-byte parts when the sub-vectors start on 16-byte boundaries, else 8-byte ones.
-            constexpr int VW = (SDR % 4 == 0 && DPH % 4 == 0) ? 4 : 2;
+            // and are zeroed.  16-byte parts when the sub-vectors start on 16-byte boundaries, 8-byte ones for the
+            // other even sub_dims, single floats for the odd ones.
+            constexpr int VW = (SDR % 4 == 0 && DPH % 4 == 0) ? 4 : (SDR % 2 == 0) ? 2 : 1;
 #pragma unroll
             for (int q = 0; q < DPH; q += VW) {
                 const bool live = (uint32_t)(DPH * h + q) < (uint32_t)SDR;
@@ -816,10 +819,13 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
                     x[q + 1] = live ? t.y : 0.0f;
                     x[q + 2] = live ? t.z : 0.0f;
                     x[q + 3] = live ? t.w : 0.0f;
-                } else {
+                } else if constexpr (VW == 2) {
                     const float2 t = *reinterpret_cast<const float2 *>(pq);
                     x[q + 0] = live ? t.x : 0.0f;
                     x[q + 1] = live ? t.y : 0.0f;
+                } else {
+                    const float t = *pq;
+                    x[q] = live ? t : 0.0f;
                 }
             }
         } else if constexpr (DPH % 4 == 0) {
@@ -1641,10 +1647,10 @@ bool screen_bf16_uses_x32(uint32_t sd, uint32_t k) {
 uint32_t x32_padded_sd(uint32_t sd) {
     switch (sd) {
     case 8: case 12: case 16: case 24: case 32: case 48: case 64: return sd;
-    case 6: return 8;
-    case 10: return 12;
-    case 14: return 16;
-    case 18: case 20: case 22: return 24;
+    case 5: case 6: case 7: return 8;
+    case 9: case 10: case 11: return 12;
+    case 13: case 14: case 15: return 16;
+    case 17: case 18: case 19: case 20: case 21: case 22: case 23: return 24;
     default: return 0;
     }
 }
@@ -1692,14 +1698,13 @@ int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine
     const uint32_t nt32 = per * groups;  // image padded to whole groups (zero operands, never-winning norms)
     const float *src = v.cb;
     const uint32_t sdp = x32_padded_sd(v.sd);
-    if (cosine && sdp != v.sd) return fail(VQHIP_ERR_UNSUPPORTED, "no cosine screen for the padded sub_dim %u", v.sd);
     if (!cosine) {
         hipLaunchKernelGGL(k_center_codebook_x32, dim3(v.m), dim3(256), 0, stream, v.cb, v.m, v.k, v.sd, sdp, nt32 * 32,
                            screen_bf16_x32_mfmas(v.sd), cbc, cen, cn32);
         VQ_LAUNCH_CHECK("k_center_codebook_x32");
         src = cbc;  // sdp wide
     }
-    hipLaunchKernelGGL(k_prepare_bf16_x32, dim3(v.m, 16), dim3(256), 0, stream, src, v.m, v.k, cosine ? v.sd : sdp, nt32,
+    hipLaunchKernelGGL(k_prepare_bf16_x32, dim3(v.m, 16), dim3(256), 0, stream, src, v.m, v.k, cosine ? v.sd : sdp, sdp, nt32,
                        screen_bf16_x32_mfmas(v.sd), cosine, v.cnsqrt, prepA32);
     VQ_LAUNCH_CHECK("k_prepare_bf16_x32");
     return VQHIP_OK;
@@ -1754,11 +1759,13 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
         VQ_X32(32, 1) VQ_X32(32, 2) VQ_X32(32, 3) VQ_X32(32, 4) VQ_X32G(32, 4, 2)
         VQ_X32(48, 1) VQ_X32(48, 2) VQ_X32G(48, 2, 2) VQ_X32G(48, 2, 3) VQ_X32G(48, 2, 4)
         VQ_X32(64, 1) VQ_X32(64, 2) VQ_X32G(64, 2, 2) VQ_X32G(64, 2, 3) VQ_X32G(64, 2, 4)
-        // padded sub_dims (SDR < SD), full 8-tile image, squared-L2 / Euclidean
+        // padded sub_dims (SDR < SD), full 8-tile image
 #define VQ_X32P(SDV, SDRV) \
-    if (cb.sd == SDRV && nt32 == 8 && groups == 1 && a.metric != VQHIP_COSINE) \
+    if (cb.sd == SDRV && nt32 == 8 && groups == 1) \
         return launch_one_x32<SDV, 8, 1, SDRV>(cb, a, stream);
-        VQ_X32P(8, 6) VQ_X32P(12, 10) VQ_X32P(16, 14) VQ_X32P(24, 18) VQ_X32P(24, 20) VQ_X32P(24, 22)
+        VQ_X32P(8, 5) VQ_X32P(8, 6) VQ_X32P(8, 7) VQ_X32P(12, 9) VQ_X32P(12, 10) VQ_X32P(12, 11)
+        VQ_X32P(16, 13) VQ_X32P(16, 14) VQ_X32P(16, 15)
+        VQ_X32P(24, 17) VQ_X32P(24, 18) VQ_X32P(24, 19) VQ_X32P(24, 20) VQ_X32P(24, 21) VQ_X32P(24, 22) VQ_X32P(24, 23)
 #undef VQ_X32P
         // k > 256: full groups, run-time count
 #define VQ_X32R(SDV, NTV) \
