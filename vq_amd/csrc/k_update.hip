@@ -141,13 +141,43 @@ __global__ __launch_bounds__(kAccBlock) void k_accumulate(
 // Every cluster therefore receives its rows in ascending row order: the chunk's partial sum is
 // the reference's sequential f32 sum over the chunk (src/core/vector.rs:376-380), bit for bit
 // and run to run.
-template <int KS>
+// VW floats per lane: 4 (16-byte parts, sub_dim a multiple of 4), 2 (even sub_dims) or 1 (odd ones): the sub_dims
+// that the zero-padded screen serves (5..23) keep the atomic-free update this way.
+template <int VW> struct AccPart;
+template <> struct AccPart<4> {
+    using T = float4;
+    static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ T add(T a, const T &x) {
+        a.x = a.x + x.x;
+        a.y = a.y + x.y;
+        a.z = a.z + x.z;
+        a.w = a.w + x.w;
+        return a;
+    }
+};
+template <> struct AccPart<2> {
+    using T = float2;
+    static __device__ __forceinline__ T zero() { return make_float2(0.f, 0.f); }
+    static __device__ __forceinline__ T add(T a, const T &x) {
+        a.x = a.x + x.x;
+        a.y = a.y + x.y;
+        return a;
+    }
+};
+template <> struct AccPart<1> {
+    using T = float;
+    static __device__ __forceinline__ T zero() { return 0.0f; }
+    static __device__ __forceinline__ T add(T a, const T &x) { return a + x; }
+};
+
+template <int KS, int VW = 4>
 __global__ __launch_bounds__(512) void k_accumulate_owned(
     const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m, uint32_t k,
     uint32_t waves_per_block, uint64_t rows_per_chunk, const uint8_t *__restrict__ codes,
     const uint8_t *__restrict__ active, float *__restrict__ partial_sums,
     uint32_t *__restrict__ partial_counts) {
-    constexpr uint32_t SD = KS * 4;
+    using Part = typename AccPart<VW>::T;
+    constexpr uint32_t SD = KS * VW;
     constexpr uint32_t RPS = 64 / KS;  // rows per step; lanes >= RPS*KS idle when KS is not a power of two
     constexpr bool POW2 = (KS & (KS - 1)) == 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -170,16 +200,16 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
     const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_chunk;
     uint64_t r1 = r0 + rows_per_chunk;
     if (r1 > n) r1 = n;
-    const float *px = X + (size_t)s * SD + 4 * g;
+    const float *px = X + (size_t)s * SD + VW * g;
     auto load_x = [&](uint64_t row) {
-        return (lane_on && row < r1) ? *reinterpret_cast<const float4 *>(px + row * d) : make_float4(0, 0, 0, 0);
+        return (lane_on && row < r1) ? *reinterpret_cast<const Part *>(px + row * d) : AccPart<VW>::zero();
     };
     auto load_c = [&](uint64_t row) { return (lane_on && row < r1) ? load_code(codes, row * m + s, k) : 0xFFFFFFFFu; };
 
     // HBM latency (~2 us under load) against one 1-KB load per wave limited the first version to
     // 2.1 TB/s; batches of PF steps are double-buffered so a wave keeps 2*PF KB in flight
     constexpr uint32_t PF = 4;
-    float4 xb[PF];
+    Part xb[PF];
     uint32_t cb_[PF];
 #pragma unroll
     for (uint32_t i = 0; i < PF; ++i) {
@@ -187,7 +217,7 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
         cb_[i] = load_c(r0 + i * RPS + p);
     }
     for (uint64_t base = r0; base < r1; base += (uint64_t)PF * RPS) {
-        float4 xc[PF];
+        Part xc[PF];
         uint32_t cc[PF];
 #pragma unroll
         for (uint32_t i = 0; i < PF; ++i) {
@@ -201,7 +231,7 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
         }
 #pragma unroll
         for (uint32_t i = 0; i < PF; ++i) {
-            const float4 x = xc[i];
+            const Part x = xc[i];
             const uint32_t code = cc[i];
             const bool valid = code != 0xFFFFFFFFu;
             // rank among the step's rows (row q's code sits in lane q*KS)
@@ -212,16 +242,11 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
                 rank += (q < p && cq == code) ? 1u : 0u;
             }
             // xor-swizzled 16-byte slot so that the KS parts of different clusters spread over banks
-            float4 *slot = reinterpret_cast<float4 *>(sums + (size_t)(valid ? code : 0u) * SD) + swz(g, code);
+            Part *slot = reinterpret_cast<Part *>(sums + (size_t)(valid ? code : 0u) * SD) + swz(g, code);
             uint32_t pending = valid ? 1u : 0u;
             for (uint32_t r = 0; __any(pending != 0); ++r) {
                 if (pending && rank == r) {
-                    float4 a = *slot;
-                    a.x = a.x + x.x;
-                    a.y = a.y + x.y;
-                    a.z = a.z + x.z;
-                    a.w = a.w + x.w;
-                    *slot = a;
+                    *slot = AccPart<VW>::add(*slot, x);
                     if (g == 0) cnts[code] += 1u;
                     pending = 0;
                 }
@@ -233,8 +258,8 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
     float *ps = partial_sums + ((size_t)blockIdx.x * m + s) * k * SD;
     for (uint32_t e = lane; e < k * KS; e += 64) {
         const uint32_t j = e / KS, gg = e % KS;
-        const float4 v = reinterpret_cast<const float4 *>(sums + (size_t)j * SD)[swz(gg, j)];
-        reinterpret_cast<float4 *>(ps + (size_t)j * SD)[gg] = v;
+        const Part v = reinterpret_cast<const Part *>(sums + (size_t)j * SD)[swz(gg, j)];
+        reinterpret_cast<Part *>(ps + (size_t)j * SD)[gg] = v;
     }
     uint32_t *pcnt = partial_counts + ((size_t)blockIdx.x * m + s) * k;
     for (uint32_t e = lane; e < k; e += 64) pcnt[e] = cnts[e];
@@ -319,7 +344,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ X
 static bool owned_sub_dim(uint32_t sd) {
     switch (sd) {
     case 4: case 8: case 12: case 16: case 24: case 32: case 48: case 64: case 96: case 128: case 256: return true;
-    default: return false;
+    default: return sd >= 5 && sd <= 23;  // 8-byte / 4-byte parts (sub_dim 20 = 5 x 16 bytes is among the cases below)
     }
 }
 
@@ -373,20 +398,20 @@ int plan_update(uint32_t m, uint32_t k, uint32_t sd, uint64_t n, UpdatePlan *p) 
     return VQHIP_OK;
 }
 
-template <int KS>
+template <int KS, int VW = 4>
 static int launch_owned(const UpdatePlan &p, const float *X, uint64_t n, uint32_t d,
                         const uint8_t *codes, const uint8_t *active, float *partial_sums,
                         uint32_t *partial_counts, uint32_t wpb, hipStream_t stream) {
     static PerDeviceOnce attr_set;
     if (attr_set.needed()) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_accumulate_owned<KS>),
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_accumulate_owned<KS, VW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set.done();
     }
     const uint64_t rows_per_chunk = (n + p.n_row_chunks - 1) / p.n_row_chunks;
     const size_t lds_bytes = (size_t)wpb * ((p.k * (p.sd + 1) + 3u) & ~3u) * 4;
     dim3 grid(p.n_row_chunks, (p.m + wpb - 1) / wpb);
-    hipLaunchKernelGGL(k_accumulate_owned<KS>, grid, dim3(wpb * 64), lds_bytes, stream, X, n, d, p.m,
+    hipLaunchKernelGGL((k_accumulate_owned<KS, VW>), grid, dim3(wpb * 64), lds_bytes, stream, X, n, d, p.m,
                        p.k, wpb, rows_per_chunk, codes, active, partial_sums, partial_counts);
     VQ_LAUNCH_CHECK("k_accumulate_owned");
     return VQHIP_OK;
@@ -396,6 +421,19 @@ int launch_accumulate(const UpdatePlan &p, const float *X, uint64_t n, uint32_t 
                       const uint8_t *codes, const uint8_t *active, float *partial_sums,
                       uint32_t *partial_counts, hipStream_t stream) {
     const bool aligned = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    // narrower parts for the sub_dims of the zero-padded screen: 8-byte parts need d even (it is: m * even) and the
+    // base 8-byte aligned, single floats need nothing
+    if (p.owned_waves > 0 && (reinterpret_cast<uintptr_t>(X) & 7) == 0) {
+#define VQ_OWNED(SDV, KSV, VWV) \
+    case SDV: return launch_owned<KSV, VWV>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        switch (p.sd) {
+            VQ_OWNED(6, 3, 2) VQ_OWNED(10, 5, 2) VQ_OWNED(14, 7, 2) VQ_OWNED(18, 9, 2) VQ_OWNED(22, 11, 2)
+            VQ_OWNED(5, 5, 1) VQ_OWNED(7, 7, 1) VQ_OWNED(9, 9, 1) VQ_OWNED(11, 11, 1) VQ_OWNED(13, 13, 1)
+            VQ_OWNED(15, 15, 1) VQ_OWNED(17, 17, 1) VQ_OWNED(19, 19, 1) VQ_OWNED(21, 21, 1) VQ_OWNED(23, 23, 1)
+        default: break;
+        }
+#undef VQ_OWNED
+    }
     // wave-owned accumulators: sub_dim a power of two in [4, 256], one subspace's [k][sd+1]
     // words per wave
     if (aligned && p.owned_waves > 0) {
@@ -404,6 +442,7 @@ int launch_accumulate(const UpdatePlan &p, const float *X, uint64_t n, uint32_t 
         case 8: return launch_owned<2>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 12: return launch_owned<3>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 16: return launch_owned<4>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 20: return launch_owned<5>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 24: return launch_owned<6>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 48: return launch_owned<12>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 96: return launch_owned<24>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
