@@ -1660,7 +1660,14 @@ void screen_bf16_x32_tiling(uint32_t sd_real, uint32_t k, uint32_t *nt32_per_gro
     if (k == 0 || k > kMaxCentroids) return;
     const uint32_t sd = x32_padded_sd(sd_real);
     if (sd == 0) return;
-    if (sd != sd_real && (k <= 224 || k > 256)) return;  // padded variants exist for the full 8-tile image only
+    if (sd != sd_real) {
+        // padded variants exist for the full 8-tile image only: smaller codebooks are padded with never-winning
+        // centroids up to 256 as long as that costs at most twice the useful work
+        if (k <= 128 || k > 256) return;
+        *nt32_per_group = 8;
+        *groups = 1;
+        return;
+    }
     const uint32_t nt = (k + 31) / 32;
     uint32_t cap;  // tiles whose A image fits next to the working set: NMF * cap * 4 registers
     switch (sd) {
