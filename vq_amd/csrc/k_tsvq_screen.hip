@@ -48,8 +48,9 @@ __device__ __forceinline__ float dpp_add(float v) {
 constexpr int32_t kFlagBase = INT32_MIN;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int D, int LPR>
-__global__ __launch_bounds__(kWaves * 64) void k_tsvq_screen_descend(
+// WAVES per workgroup: 16 while a row's registers (3 x D/8 floats) fit 128 VGPRs, 8 or 4 for the long rows
+template <int D, int LPR, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
     const float *__restrict__ X, uint64_t n, const float *__restrict__ w_g, const int4 *__restrict__ info_g,
     const float *__restrict__ mu_g, uint32_t n_int, int32_t start_slot, float R, float coef_a, float coef_b,
     int32_t *__restrict__ leaf_out, uint2 *__restrict__ wl, uint32_t *__restrict__ wl_count) {
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_tsvq_screen_descend(
     int4 *lds_info = reinterpret_cast<int4 *>(lds + (size_t)n_int * D);        // [n_int]
     uint2 *lds_wl = reinterpret_cast<uint2 *>(lds_info + n_int);               // [kWaves][kWlBuf]
     {
-        constexpr uint32_t T = kWaves * 64;
+        constexpr uint32_t T = WAVES * 64;
         const uint32_t total = n_int * (D / 4);
         for (uint32_t e0 = 0; e0 < total; e0 += 4 * T) {  // 4 loads in flight per thread
             float4 v[4];
@@ -108,14 +109,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_tsvq_screen_descend(
     };
 
     const uint64_t n_tiles = (n + RPW - 1) / RPW;
-    const uint64_t tile_stride = (uint64_t)gridDim.x * kWaves;
+    const uint64_t tile_stride = (uint64_t)gridDim.x * WAVES;
     auto load_tile = [&](uint64_t tile, float4 (&xv)[NCH]) {
         const uint64_t r = tile * RPW + g;
         const float *px = X + ((r < n) ? r : (n - 1)) * D;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) xv[c] = *reinterpret_cast<const float4 *>(px + off[c]);
     };
-    uint64_t tile = (uint64_t)blockIdx.x * kWaves + wave;
+    uint64_t tile = (uint64_t)blockIdx.x * WAVES + wave;
     float4 xn[NCH];
     if (tile < n_tiles) load_tile(tile, xn);
     for (; tile < n_tiles; tile += tile_stride) {
@@ -288,17 +289,18 @@ static int launch_continue(const float *X, const float *centroids, const int32_t
 template <int D, int LPR>
 int launch_screen(const float *X, uint64_t n, const TsvqScreen &s, hipStream_t stream, int32_t *leaf) {
     constexpr int RPW = 64 / LPR;
+    constexpr int WAVES = (D >= 512) ? 4 : (D >= 256) ? 8 : kWaves;  // 512 / 256 / 128 VGPRs per lane
     const size_t lds_bytes = tsvq_screen_lds_bytes(s.n_int, s.n_nodes, D);
     static PerDeviceOnce attr_set;
     if (attr_set.needed()) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR>),
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR, WAVES>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set.done();
     }
     const uint64_t n_tiles = (n + RPW - 1) / RPW;
-    uint64_t grid = (n_tiles + kWaves - 1) / kWaves;
+    uint64_t grid = (n_tiles + WAVES - 1) / WAVES;
     if (grid > (uint64_t)num_cus()) grid = (uint64_t)num_cus();
-    hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR>), dim3((uint32_t)grid), dim3(kWaves * 64), lds_bytes, stream, X,
+    hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X,
                        n, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count);
     VQ_LAUNCH_CHECK("k_tsvq_screen_descend");
     return VQHIP_OK;
@@ -313,7 +315,7 @@ size_t tsvq_screen_lds_bytes(uint32_t n_int, uint32_t n_nodes, uint32_t d) {
 
 bool tsvq_screen_supported(uint32_t n_int, uint32_t n_nodes, uint32_t d, int metric) {
     if (metric != VQHIP_SQUARED_EUCLIDEAN && metric != VQHIP_EUCLIDEAN) return false;
-    if (!(d == 32 || d == 64 || d == 128 || d == 256)) return false;
+    if (!(d == 32 || d == 64 || d == 128 || d == 192 || d == 256 || d == 384 || d == 512 || d == 768)) return false;
     if (n_int == 0) return false;
     return tsvq_screen_lds_bytes(n_int, n_nodes, d) <= 160 * 1024;
 }
@@ -342,6 +344,13 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
         VQ_TRY((launch_screen<256, 8>(X, n, s, stream, leaf)));
         VQ_TRY(launch_continue<256>(X, centroids, left, right, euclid, s, leaf, stream));
         break;
+#define VQ_TSVQ_D(DV)                                                                     \
+    case DV:                                                                              \
+        VQ_TRY((launch_screen<DV, 8>(X, n, s, stream, leaf)));                            \
+        VQ_TRY(launch_continue<DV>(X, centroids, left, right, euclid, s, leaf, stream)); \
+        break;
+        VQ_TSVQ_D(192) VQ_TSVQ_D(384) VQ_TSVQ_D(512) VQ_TSVQ_D(768)  // embedding widths (the reference's eval: 384)
+#undef VQ_TSVQ_D
     default: return fail(VQHIP_ERR_UNSUPPORTED, "screened TSVQ descent: d=%u", d);
     }
     return VQHIP_OK;
