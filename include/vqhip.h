@@ -130,8 +130,7 @@ int vqhip_synth_uniform_host(float *out, uint64_t n, uint32_t d, uint64_t seed,
  * Every `codes` buffer below (host or device) is [n][m] of that width, i.e.
  * n * m * vqhip_code_bytes(k) bytes; the parameter stays `uint8_t *` for both.  Above 256 the bf16
  * screen runs in up to 16 centroid groups per subspace (sub_dim 8/12/16/24: k <= 4096, 32: 2048,
- * 48/64: 1024), the exact VALU engine serves every other shape; the ADC search takes one-byte codes
- * only. */
+ * 48/64: 1024), the exact VALU engine serves every other shape. */
 uint32_t vqhip_code_bytes(uint32_t k);
 
 /* ---- k-means (Lloyd / LBG) over all m subspaces at once -------------------------------

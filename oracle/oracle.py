@@ -98,6 +98,8 @@ class Oracle:
                                  C.c_int]
         L.vqo_adc_search.restype = C.c_int
         L.vqo_adc_search.argtypes = [C.c_int, _f32p, sz, sz, sz, C.POINTER(C.c_uint8), sz, _f32p, sz, sz, _u32p, _f32p]
+        L.vqo_adc_search16.restype = C.c_int
+        L.vqo_adc_search16.argtypes = [C.c_int, _f32p, sz, sz, sz, C.POINTER(C.c_uint16), sz, _f32p, sz, sz, _u32p, _f32p]
         L.vqo_pq_encode.restype = C.c_int
         L.vqo_pq_encode.argtypes = [C.c_int, _f32p, sz, sz, sz, sz, _f32p, _u32p, _u16p, C.c_int]
         L.vqo_tsvq_build.restype = C.c_int
@@ -234,13 +236,15 @@ class Oracle:
         """semantics of the code-based search (no reference counterpart): (idx u32, dist f32) [nq][topk]"""
         cb = self._f32(codebooks)
         m, k, sd = cb.shape
-        codes = np.ascontiguousarray(codes, np.uint8)
+        wide = k > 256  # two-byte codes, like the library
+        codes = np.ascontiguousarray(codes, np.uint16 if wide else np.uint8)
         q = self._f32(queries)
         n, nq = codes.shape[0], q.shape[0]
         idx = np.empty((nq, topk), np.uint32)
         dist = np.empty((nq, topk), np.float32)
-        rc = self.lib.vqo_adc_search(metric, _ptr(cb, _f32p), m, k, sd, codes.ctypes.data_as(C.POINTER(C.c_uint8)), n,
-                                     _ptr(q, _f32p), nq, topk, _ptr(idx, _u32p), _ptr(dist, _f32p))
+        fn = self.lib.vqo_adc_search16 if wide else self.lib.vqo_adc_search
+        cptr = codes.ctypes.data_as(C.POINTER(C.c_uint16 if wide else C.c_uint8))
+        rc = fn(metric, _ptr(cb, _f32p), m, k, sd, cptr, n, _ptr(q, _f32p), nq, topk, _ptr(idx, _u32p), _ptr(dist, _f32p))
         if rc:
             raise OracleError(rc, "adc_search")
         return idx, dist

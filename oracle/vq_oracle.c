@@ -572,10 +572,10 @@ static int adc_cmp(const void *pa, const void *pb) {
     return (a->i > b->i) - (a->i < b->i);
 }
 
-int vqo_adc_search(int metric, const float *codebooks, size_t m, size_t k, size_t sd,
-                   const uint8_t *codes, size_t n, const float *queries, size_t nq, size_t topk,
+static int adc_search_impl(int metric, const float *codebooks, size_t m, size_t k, size_t sd,
+                           const uint8_t *codes8, const uint16_t *codes16, size_t n, const float *queries, size_t nq, size_t topk,
                    uint32_t *idx_out, float *dist_out) {
-    if (metric == VQO_COSINE || topk == 0 || topk > n || m == 0 || k == 0 || k > 256)
+    if (metric == VQO_COSINE || topk == 0 || topk > n || m == 0 || k == 0 || (codes8 && k > 256) || k > 65536)
         return VQO_ERR_INVALID_PARAMETER;
     float *lut = (float *)malloc(m * k * sizeof(float));
     adc_pair *all = (adc_pair *)malloc(n * sizeof(adc_pair));
@@ -593,11 +593,13 @@ int vqo_adc_search(int metric, const float *codebooks, size_t m, size_t k, size_
                                                            : vqo_distance2(x + s * sd, c, sd);
             }
         for (size_t i = 0; i < n; ++i) {
-            float acc = lut[codes[i * m]];
+#define VQO_CODE(ii) (codes8 ? (size_t)codes8[ii] : (size_t)codes16[ii])
+            float acc = lut[VQO_CODE(i * m)];
             for (size_t s = 1; s < m; ++s) {
-                const float t = lut[s * k + codes[i * m + s]];
+                const float t = lut[s * k + VQO_CODE(i * m + s)];
                 acc = acc + t;
             }
+#undef VQO_CODE
             all[i].d = acc;
             all[i].i = (uint32_t)i;
         }
@@ -610,4 +612,17 @@ int vqo_adc_search(int metric, const float *codebooks, size_t m, size_t k, size_
     free(lut);
     free(all);
     return VQO_OK;
+}
+
+int vqo_adc_search(int metric, const float *codebooks, size_t m, size_t k, size_t sd,
+                   const uint8_t *codes, size_t n, const float *queries, size_t nq, size_t topk,
+                   uint32_t *idx_out, float *dist_out) {
+    return adc_search_impl(metric, codebooks, m, k, sd, codes, NULL, n, queries, nq, topk, idx_out, dist_out);
+}
+
+/* the same over two-byte codes (k up to 65536; the library's code width above 256 centroids) */
+int vqo_adc_search16(int metric, const float *codebooks, size_t m, size_t k, size_t sd,
+                     const uint16_t *codes, size_t n, const float *queries, size_t nq, size_t topk,
+                     uint32_t *idx_out, float *dist_out) {
+    return adc_search_impl(metric, codebooks, m, k, sd, NULL, codes, n, queries, nq, topk, idx_out, dist_out);
 }

@@ -150,6 +150,9 @@ int vqo_pq_encode(int metric, const float *rows, size_t n, size_t d, size_t m, s
 int vqo_adc_search(int metric, const float *codebooks, size_t m, size_t k, size_t sd,
                    const uint8_t *codes, size_t n, const float *queries, size_t nq, size_t topk,
                    uint32_t *idx_out, float *dist_out);
+int vqo_adc_search16(int metric, const float *codebooks, size_t m, size_t k, size_t sd,
+                     const uint16_t *codes, size_t n, const float *queries, size_t nq, size_t topk,
+                     uint32_t *idx_out, float *dist_out);
 
 int vqo_tsvq_build(const float *rows, size_t n, size_t d, size_t max_depth, size_t cap,
                    float *centroids, int32_t *left, int32_t *right, int32_t *n_nodes_out,

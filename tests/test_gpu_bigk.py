@@ -105,11 +105,21 @@ def test_screen_engines_without_a_wide_form_refuse():
         enc.close()
 
 
-def test_adc_search_needs_one_byte_codes():
-    cb = _data(5, 2 * 300, 8, "uniform").reshape(2, 300, 8)
-    enc = _lib.PQEncoder(cb, O.SQUARED_EUCLIDEAN)
-    with pytest.raises(_lib.FfiError):
-        enc.adc_search(np.zeros((10, 2), np.uint8), np.zeros((1, 16), F), 1)
+@pytest.mark.parametrize("metric", [O.SQUARED_EUCLIDEAN, O.EUCLIDEAN, O.MANHATTAN])
+@pytest.mark.parametrize("shape", [(5000, 16, 4, 300), (3000, 32, 2, 1024), (2500, 8, 8, 600)])
+def test_adc_search_over_two_byte_codes(oracle, shape, metric):
+    """the code-based search reads u16 codes above 256 centroids; fewer query tables share the LDS per pass"""
+    n, d, m, k = shape
+    cb = _data(5, m * k, d // m, "normal").reshape(m, k, d // m)
+    X = _data(6, n, d, "normal")
+    enc = _lib.PQEncoder(cb, metric)
+    codes, _ = enc.encode(X, want_f16=False)
+    assert codes.dtype == np.uint16
+    Q = _data(7, 19, d, "normal")
+    idx, dist = enc.adc_search(codes, Q, 10)
+    want_i, want_d = oracle.adc_search(metric, cb, codes, Q, 10)
+    np.testing.assert_array_equal(idx, want_i)
+    assert dist.tobytes() == want_d.tobytes()
     enc.close()
 
 
@@ -211,8 +221,9 @@ def test_product_quantizer_front_end_wide_k(oracle):
     q = pq.quantize(X[0])
     assert q.view(np.uint16).tobytes() == want_f[0].tobytes()
     assert pq.decode(codes).tobytes() == np.concatenate([cb[s][want_c[:, s]] for s in range(m)], axis=1).tobytes()
-    with pytest.raises(Exception):
-        pq.search(codes, X[:2], 5)
+    idx, dist = pq.search(codes, X[:2], 5)
+    want_i, want_d = oracle.adc_search(O.SQUARED_EUCLIDEAN, cb, codes, X[:2], 5)
+    np.testing.assert_array_equal(idx, want_i)
 
 
 def test_code_bytes_entry_point():

@@ -297,7 +297,7 @@ class PQEncoder(Handle):
         check(load().vqhip_pq_encoder_set_engine(self.raw, engine))
 
     def adc_search(self, codes, queries, topk: int):
-        """top-k rows of `codes` [n][m] u8 (numpy array, or (device_ptr, n)) per query by asymmetric
+        """top-k rows of `codes` [n][m] (u8, u16 above 256 centroids; numpy array, or (device_ptr, n)) per query by asymmetric
         distance; returns (idx uint32 [nq][topk], dist float32 [nq][topk])"""
         q = np.ascontiguousarray(queries, dtype=np.float32)
         if q.ndim == 1:
@@ -313,7 +313,7 @@ class PQEncoder(Handle):
             check(lib.vqhip_pq_adc_search_device(self.raw, C.c_void_p(dev_ptr), int(n), ptr(q, _f32p), nq, int(topk),
                                                  ptr(idx, _u32p), ptr(dist, _f32p)))
         else:
-            c = np.ascontiguousarray(codes, dtype=np.uint8)
+            c = np.ascontiguousarray(codes, dtype=code_dtype(self.k))
             check(lib.vqhip_pq_adc_search(self.raw, ptr(c, _u8p), c.shape[0], ptr(q, _f32p), nq, int(topk),
                                           ptr(idx, _u32p), ptr(dist, _f32p)))
         return idx, dist

@@ -1140,7 +1140,6 @@ int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uin
     hipStream_t s;
     VQ_TRY(current_stream(&s));
     const uint32_t m = enc->cs.m, k = enc->cs.k, sd = enc->cs.sd, dim = m * sd;
-    if (k > 256) return fail(VQHIP_ERR_UNSUPPORTED, "ADC search scans one-byte codes: k=%u > 256", k);
     VQ_TRY(enc->adc_q.ensure((size_t)nq * dim * 4));
     VQ_TRY(enc->adc_lut.ensure((size_t)adc_query_batch() * m * k * 4));
     VQ_TRY(enc->adc_dist.ensure((size_t)adc_query_batch() * n * 4));
@@ -1166,8 +1165,9 @@ int vqhip_pq_adc_search(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n,
     if (!enc || !codes) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     hipStream_t s;
     VQ_TRY(current_stream(&s));
-    VQ_TRY(enc->adc_codes.ensure((size_t)n * enc->cs.m));
-    VQ_HIP(hipMemcpyAsync(enc->adc_codes.p, codes, (size_t)n * enc->cs.m, hipMemcpyHostToDevice, s));
+    const size_t code_b = (size_t)n * enc->cs.m * code_bytes(enc->cs.k);
+    VQ_TRY(enc->adc_codes.ensure(code_b));
+    VQ_HIP(hipMemcpyAsync(enc->adc_codes.p, codes, code_b, hipMemcpyHostToDevice, s));
     return vqhip_pq_adc_search_device(enc, enc->adc_codes.p, n, queries, nq, topk, idx_out, dist_out);
     VQ_API_END
 }

@@ -98,12 +98,11 @@ __global__ __launch_bounds__(256) void k_adc_scan(const uint8_t *__restrict__ co
     }
     __syncthreads();
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-        const uint8_t *row = codes + i * m;
         float acc[kAdcQB];
 #pragma unroll
         for (uint32_t qq = 0; qq < kAdcQB; ++qq) acc[qq] = 0.0f;
         for (uint32_t s = 0; s < m; ++s) {
-            const uint32_t off = s * k + row[s];
+            const uint32_t off = s * k + load_code(codes, i * m + s, k);  // one byte per code, two above 256 centroids
 #pragma unroll
             for (uint32_t qq = 0; qq < kAdcQB; ++qq)
                 if (qq < nqb) acc[qq] = (s == 0) ? lds_lut[qq * tab + off] : acc[qq] + lds_lut[qq * tab + off];
@@ -313,8 +312,10 @@ int launch_adc_search(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int 
     if (metric == VQHIP_COSINE)
         return fail(VQHIP_ERR_UNSUPPORTED, "cosine distance is not a sum over subspaces: no ADC form");
     if (topk == 0 || topk > 1024 || topk > n) return fail(VQHIP_ERR_INVALID_INPUT, "topk must be in [1, min(n, 1024)]");
-    if ((size_t)kAdcQB * (m * k + kAdcBins) * 4 > 150 * 1024)
-        return fail(VQHIP_ERR_UNSUPPORTED, "ADC tables of %u queries (m=%u, k=%u) exceed the LDS", kAdcQB, m, k);
+    // queries per scan pass: as many tables as the LDS holds, at most kAdcQB
+    const size_t lds_budget = 150 * 1024;
+    uint32_t qb = (uint32_t)std::min<size_t>(kAdcQB, lds_budget / (((size_t)m * k + kAdcBins) * 4));
+    if (qb == 0) return fail(VQHIP_ERR_UNSUPPORTED, "one ADC table (m=%u, k=%u) exceeds the LDS", m, k);
     static PerDeviceOnce attr;
     if (attr.needed()) {
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_adc_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -333,8 +334,8 @@ int launch_adc_search(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int 
     uint32_t *sel = hist + kAdcQB * kAdcBins;
     uint32_t *cand_n = sel + 2 * kAdcQB;
     const size_t state_bytes = (size_t)(2 * kAdcQB + kAdcQB * kAdcBins + 2 * kAdcQB + kAdcQB) * 4;
-    for (uint32_t q0 = 0; q0 < nq; q0 += kAdcQB) {
-        const uint32_t nqb = (nq - q0 < kAdcQB) ? nq - q0 : kAdcQB;
+    for (uint32_t q0 = 0; q0 < nq; q0 += qb) {
+        const uint32_t nqb = (nq - q0 < qb) ? nq - q0 : qb;
         VQ_HIP(hipMemsetAsync(state_ws, 0, state_bytes, stream));
         hipLaunchKernelGGL(k_adc_lut, dim3(nqb, m), dim3(256), 0, stream, queries_dev + (size_t)q0 * m * sd, nqb, m, k, sd,
                            cb, l1, lut_ws, bounds);

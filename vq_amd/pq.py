@@ -229,7 +229,7 @@ class ProductQuantizer:
         return self._enc.encode(X, want_codes=True, want_f16=False)[0]
 
     def search(self, codes, queries, topk: int = 10):
-        """Asymmetric-distance search: the `topk` rows of `codes` (n, m) uint8
+        """Asymmetric-distance search: the `topk` rows of `codes` (n, m) (uint8, uint16 above 256 centroids)
         nearest to each query under this quantizer's metric, distances from per-subspace tables.
         Returns (indices uint32 (nq, topk), distances float32 (nq, topk)); ties by lower row."""
         q = np.ascontiguousarray(queries, dtype=np.float32)
@@ -237,9 +237,7 @@ class ProductQuantizer:
             q = q[None, :]
         if q.shape[1] != self._dim:
             raise DimensionMismatch(self._dim, q.shape[1])
-        if self._k > 256:
-            raise InvalidParameter("k", "the ADC scan reads one-byte codes: k must be at most 256")
-        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        codes = np.ascontiguousarray(codes, dtype=_lib.code_dtype(self._k))
         if codes.ndim != 2 or codes.shape[1] != self._m:
             raise DimensionMismatch(self._m, codes.shape[1] if codes.ndim == 2 else codes.size)
         if not 1 <= topk <= min(codes.shape[0], 1024):
