@@ -384,10 +384,15 @@ int plan_update(uint32_t m, uint32_t k, uint32_t sd, uint64_t n, UpdatePlan *p) 
         uint32_t w = (uint32_t)(kLdsBudgetWords / per_wave);
         if (w > 8) w = 8;
         if (w > m) w = m;
+        if (w > 0) w = (m + ((m + w - 1) / w) - 1) / ((m + w - 1) / w);  // same number of workgroups, evenly filled (m = 10: 5 + 5, not 8 + 2)
         p->owned_waves = w;
         if (w > 0) {
             uint32_t sub_groups = (m + w - 1) / w;
-            uint32_t rc2 = (uint32_t)num_cus() / sub_groups;
+            // small accumulators (short sub-vectors, few clusters) leave LDS for 2-4 workgroups per CU: more row
+            // chunks, so that the loads of several workgroups overlap
+            uint32_t per_cu = (uint32_t)(kLdsBudgetWords / (per_wave * w));
+            per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+            uint32_t rc2 = (uint32_t)num_cus() * per_cu / sub_groups;
             if (rc2 < 1) rc2 = 1;
             if (rc2 > max_rc) rc2 = (uint32_t)max_rc;
             p->n_row_chunks = rc2;
