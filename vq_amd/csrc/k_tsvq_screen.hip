@@ -156,7 +156,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
             const float delta = fmaf(-2.0f, acc, __int_as_float(inf.z));
             const float T = fmaf(t_b, __int_as_float(inf.w), t_a);
             const int32_t code = (delta < 0.0f) ? inf.x : inf.y;
-            const int32_t next = (fabsf(delta) > T) ? code : (kFlagBase + a);  // NaN / inf thresholds never pass
+            int32_t next = (fabsf(delta) > T) ? code : (kFlagBase + a);  // NaN / inf thresholds never pass
+            // a child slot beyond the LDS-resident levels: the exact continuation takes over at that node
+            next = (next >= (int32_t)n_int) ? (kFlagBase + next) : next;
             cur = (cur >= 0) ? next : cur;
             if (!__any(cur >= 0)) break;
         }
