@@ -431,13 +431,12 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     for (uint32_t i = 0; i < n_nodes; ++i) n_int += (left[i] >= 0 && right[i] >= 0) ? 1u : 0u;
     const char *off = getenv("VQHIP_TSVQ_EXACT");
     if ((off && off[0] == '1') || n_int == 0 || !tsvq_screen_supported(1, n_nodes, d, t->metric)) return VQHIP_OK;
-    // A tree too large for one CU's LDS is screened down to the level that fits: the two-child nodes are given
-    // slots in breadth-first order, the first n_lds of them live in LDS, and a row that reaches a later one is
-    // handed to the exact continuation there (the kernel treats slots >= n_lds as undecided).
+    // A tree too large for one CU's LDS: the two-child nodes are given slots in breadth-first order, the first
+    // n_lds of them (the levels nearest the root) live in LDS, the kernel reads the others' w / record from L2.
     uint32_t n_lds = n_int;
     while (n_lds > 1 && !tsvq_screen_supported(n_lds, n_nodes, d, t->metric)) --n_lds;
-    std::vector<float> w((size_t)n_lds * d);
-    std::vector<int32_t> info((size_t)n_lds * 4), slot_node(n_int), slot_of(n_nodes, -1);
+    std::vector<float> w((size_t)n_int * d);
+    std::vector<int32_t> info((size_t)n_int * 4), slot_node(n_int), slot_of(n_nodes, -1);
     const float *mu = centroids;  // root
     double r2max = 0.0;
     bool finite = true;
@@ -477,7 +476,7 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
             i = (l >= 0) ? l : r;
         }
     };
-    for (uint32_t sl = 0; sl < n_lds; ++sl) {
+    for (uint32_t sl = 0; sl < n_int; ++sl) {
         const int32_t i = slot_node[sl], l = left[i], r = right[i];
         int32_t *rec = info.data() + (size_t)sl * 4;
         double w2 = 0.0;
@@ -512,7 +511,7 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     t->scr.info = t->scr_info.as<int4>();
     t->scr.mu = t->scr_mu.as<float>();
     t->scr.wl_count = t->scr_count.as<uint32_t>();
-    t->scr.n_int = n_lds;  // slots resident in LDS; slot ids up to the tree's n_int exist in slot_node
+    t->scr.n_int = n_lds;  // slots resident in LDS; w / info / slot_node hold all of the tree's slots
     t->scr.n_nodes = n_nodes;
     // a non-finite tree sends every row to the exact continuation (T = NaN never passes)
     t->scr.R = finite ? (float)(std::sqrt(r2max) * 1.000001) : std::numeric_limits<float>::quiet_NaN();

@@ -54,6 +54,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
     const float *__restrict__ X, uint64_t n, const float *__restrict__ w_g, const int4 *__restrict__ info_g,
     const float *__restrict__ mu_g, uint32_t n_int, int32_t start_slot, float R, float coef_a, float coef_b,
     int32_t *__restrict__ leaf_out, uint2 *__restrict__ wl, uint32_t *__restrict__ wl_count) {
+    // n_int: slots resident in LDS (the levels nearest the root, breadth-first); w_g / info_g hold EVERY slot of the
+    // tree: a row standing at a deeper slot takes the same verdict from L2 instead (one more round trip per level)
     constexpr int CH = LPR * 4;       // floats per chunk (LPR lanes x float4)
     constexpr int NCH = D / CH;       // chunks per row = float4 values per lane
     constexpr int RPW = 64 / LPR;     // rows per wave step
@@ -139,11 +141,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
         if (tile + tile_stride < n_tiles) load_tile(tile + tile_stride, xn);  // in flight during the descent
         for (;;) {
             const int32_t a = cur > 0 ? cur : 0;
-            const int4 inf = lds_info[a];
-            const float *wp = lds_w + (size_t)a * D;
+            const bool deep = a >= (int32_t)n_int;
+            int4 inf;
             float4 wv[NCH];
+            if (!__any(deep)) {  // the usual case: whole wave inside the LDS-resident levels
+                inf = lds_info[a];
+                const float *wp = lds_w + (size_t)a * D;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
+                for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
+            } else if (deep) {
+                inf = info_g[a];
+                const float *wp = w_g + (size_t)a * D;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
+            } else {
+                inf = lds_info[a];
+                const float *wp = lds_w + (size_t)a * D;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
+            }
             // register-adjacent pairs -> v_pk_fma_f32 without operand shuffles
             f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
 #pragma unroll
@@ -156,9 +172,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
             const float delta = fmaf(-2.0f, acc, __int_as_float(inf.z));
             const float T = fmaf(t_b, __int_as_float(inf.w), t_a);
             const int32_t code = (delta < 0.0f) ? inf.x : inf.y;
-            int32_t next = (fabsf(delta) > T) ? code : (kFlagBase + a);  // NaN / inf thresholds never pass
-            // a child slot beyond the LDS-resident levels: the exact continuation takes over at that node
-            next = (next >= (int32_t)n_int) ? (kFlagBase + next) : next;
+            const int32_t next = (fabsf(delta) > T) ? code : (kFlagBase + a);  // NaN / inf thresholds never pass
             cur = (cur >= 0) ? next : cur;
             if (!__any(cur >= 0)) break;
         }
