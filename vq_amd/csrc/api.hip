@@ -435,7 +435,8 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     // n_lds of them (the levels nearest the root) live in LDS, the kernel reads the others' w / record from L2.
     uint32_t n_lds = n_int;
     while (n_lds > 1 && !tsvq_screen_supported(n_lds, n_nodes, d, t->metric)) --n_lds;
-    std::vector<float> w((size_t)n_int * d);
+    const uint32_t dp = tsvq_screen_width(d);  // >= d: width of the kernel's w / mu rows (zeros behind d)
+    std::vector<float> w((size_t)n_int * dp, 0.0f);
     std::vector<int32_t> info((size_t)n_int * 4), slot_node(n_int), slot_of(n_nodes, -1);
     const float *mu = centroids;  // root
     double r2max = 0.0;
@@ -482,7 +483,7 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
         double w2 = 0.0;
         for (uint32_t q = 0; q < d; ++q) {
             const float wv = centroids[(size_t)l * d + q] - centroids[(size_t)r * d + q];
-            w[(size_t)sl * d + q] = wv;
+            w[(size_t)sl * dp + q] = wv;
             w2 += (double)wv * (double)wv;
         }
         const float b = (float)(a2[l] - a2[r]);
@@ -501,7 +502,8 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     t->scr.slot_node = t->scr_slot_node.as<int32_t>();
     VQ_TRY(t->scr_w.alloc(w.size() * 4));
     VQ_TRY(t->scr_info.alloc(info.size() * 4));
-    VQ_TRY(t->scr_mu.alloc((size_t)d * 4));
+    VQ_TRY(t->scr_mu.alloc((size_t)dp * 4));
+    VQ_HIP(hipMemsetAsync(t->scr_mu.p, 0, (size_t)dp * 4, s));
     VQ_TRY(t->scr_count.alloc(4));
     VQ_HIP(hipMemcpyAsync(t->scr_w.p, w.data(), w.size() * 4, hipMemcpyHostToDevice, s));
     VQ_HIP(hipMemcpyAsync(t->scr_info.p, info.data(), info.size() * 4, hipMemcpyHostToDevice, s));

@@ -51,9 +51,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // WAVES per workgroup: 16 while a row's registers (3 x D/8 floats) fit 128 VGPRs, 8 or 4 for the long rows
 template <int D, int LPR, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
-    const float *__restrict__ X, uint64_t n, const float *__restrict__ w_g, const int4 *__restrict__ info_g,
-    const float *__restrict__ mu_g, uint32_t n_int, int32_t start_slot, float R, float coef_a, float coef_b,
-    int32_t *__restrict__ leaf_out, uint2 *__restrict__ wl, uint32_t *__restrict__ wl_count) {
+    const float *__restrict__ X, uint64_t n, uint32_t d_real, const float *__restrict__ w_g,
+    const int4 *__restrict__ info_g, const float *__restrict__ mu_g, uint32_t n_int, int32_t start_slot, float R,
+    float coef_a, float coef_b, int32_t *__restrict__ leaf_out, uint2 *__restrict__ wl,
+    uint32_t *__restrict__ wl_count) {
+    // d_real <= D (a multiple of 4): rows are d_real floats apart; w, mu are D wide with zeros behind d_real, and the
+    // 16-byte parts of a row behind d_real are read as zeros (from a valid address), so any such d rides on the
+    // next instantiated width
     // n_int: slots resident in LDS (the levels nearest the root, breadth-first); w_g / info_g hold EVERY slot of the
     // tree: a row standing at a deeper slot takes the same verdict from L2 instead (one more round trip per level)
     constexpr int CH = LPR * 4;       // floats per chunk (LPR lanes x float4)
@@ -114,9 +118,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
     const uint64_t tile_stride = (uint64_t)gridDim.x * WAVES;
     auto load_tile = [&](uint64_t tile, float4 (&xv)[NCH]) {
         const uint64_t r = tile * RPW + g;
-        const float *px = X + ((r < n) ? r : (n - 1)) * D;
+        const float *px = X + ((r < n) ? r : (n - 1)) * d_real;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) xv[c] = *reinterpret_cast<const float4 *>(px + off[c]);
+        for (int c = 0; c < NCH; ++c) {
+            const bool live = off[c] < d_real;
+            const float4 v = *reinterpret_cast<const float4 *>(px + (live ? off[c] : 0u));
+            xv[c] = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
     uint64_t tile = (uint64_t)blockIdx.x * WAVES + wave;
     float4 xn[NCH];
@@ -293,6 +301,47 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
     }
 }
 
+// the same continuation for a dimension without a k_tsvq_continue instantiation (padded screen widths): one lane per
+// entry, run-time-length loops in the reference's order; the entries are few
+__global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restrict__ X, uint32_t d,
+                                                           const float *__restrict__ centroids,
+                                                           const int32_t *__restrict__ left,
+                                                           const int32_t *__restrict__ right, int euclid,
+                                                           const int32_t *__restrict__ slot_node,
+                                                           const uint2 *__restrict__ wl,
+                                                           const uint32_t *__restrict__ wl_count,
+                                                           int32_t *__restrict__ leaf_out) {
+    const uint32_t count = *wl_count;
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < count; e += gridDim.x * 256) {
+        const uint2 ent = wl[e];
+        const float *x = X + (size_t)ent.x * d;
+        int32_t node = slot_node[ent.y];
+        for (;;) {
+            const int32_t l = left[node], r = right[node];
+            if (l >= 0 && r >= 0) {
+                const float *cl = centroids + (size_t)l * d, *cr = centroids + (size_t)r * d;
+                float al = -0.0f, ar = -0.0f;
+                for (uint32_t t = 0; t < d; ++t) {
+                    const float v = x[t];
+                    const float d1 = v - cl[t], d2 = v - cr[t];
+                    const float s1 = d1 * d1, s2 = d2 * d2;
+                    al = al + s1;
+                    ar = ar + s2;
+                }
+                const float dl = euclid ? sqrtf(al) : al, dr = euclid ? sqrtf(ar) : ar;
+                node = (dl <= dr) ? l : r;  // left on ties, tsvq.rs:122
+            } else if (l >= 0) {
+                node = l;
+            } else if (r >= 0) {
+                node = r;
+            } else {
+                break;
+            }
+        }
+        leaf_out[ent.x] = node;
+    }
+}
+
 template <int D>
 static int launch_continue(const float *X, const float *centroids, const int32_t *left, const int32_t *right,
                            int euclid, const TsvqScreen &s, int32_t *leaf, hipStream_t stream) {
@@ -303,7 +352,7 @@ static int launch_continue(const float *X, const float *centroids, const int32_t
 }
 
 template <int D, int LPR>
-int launch_screen(const float *X, uint64_t n, const TsvqScreen &s, hipStream_t stream, int32_t *leaf) {
+int launch_screen(const float *X, uint64_t n, uint32_t d_real, const TsvqScreen &s, hipStream_t stream, int32_t *leaf) {
     constexpr int RPW = 64 / LPR;
     constexpr int WAVES = (D >= 512) ? 4 : (D >= 256) ? 8 : kWaves;  // 512 / 256 / 128 VGPRs per lane
     const size_t lds_bytes = tsvq_screen_lds_bytes(s.n_int, s.n_nodes, D);
@@ -317,7 +366,7 @@ int launch_screen(const float *X, uint64_t n, const TsvqScreen &s, hipStream_t s
     uint64_t grid = (n_tiles + WAVES - 1) / WAVES;
     if (grid > (uint64_t)num_cus()) grid = (uint64_t)num_cus();
     hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X,
-                       n, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count);
+                       n, d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count);
     VQ_LAUNCH_CHECK("k_tsvq_screen_descend");
     return VQHIP_OK;
 }
@@ -329,11 +378,19 @@ size_t tsvq_screen_lds_bytes(uint32_t n_int, uint32_t n_nodes, uint32_t d) {
     return (size_t)n_int * d * 4 + (size_t)n_int * 16 + (size_t)kWaves * kWlBuf * 8;
 }
 
+// instantiated width that serves dimension d: d itself, or the next width up for other multiples of 4 (zero padding)
+uint32_t tsvq_screen_width(uint32_t d) {
+    if (d == 0 || d % 4 != 0) return 0;
+    for (uint32_t w : {32u, 64u, 128u, 192u, 256u, 384u, 512u, 768u})
+        if (d <= w) return w;
+    return 0;
+}
+
 bool tsvq_screen_supported(uint32_t n_int, uint32_t n_nodes, uint32_t d, int metric) {
     if (metric != VQHIP_SQUARED_EUCLIDEAN && metric != VQHIP_EUCLIDEAN) return false;
-    if (!(d == 32 || d == 64 || d == 128 || d == 192 || d == 256 || d == 384 || d == 512 || d == 768)) return false;
-    if (n_int == 0) return false;
-    return tsvq_screen_lds_bytes(n_int, n_nodes, d) <= 160 * 1024;
+    const uint32_t dp = tsvq_screen_width(d);
+    if (dp == 0 || n_int == 0) return false;
+    return tsvq_screen_lds_bytes(n_int, n_nodes, dp) <= 160 * 1024;
 }
 
 int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const int32_t *left,
@@ -343,31 +400,22 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
     if (n > 0xFFFFFFFFull) return fail(VQHIP_ERR_UNSUPPORTED, "screened TSVQ descent takes < 2^32 rows per call");
     VQ_HIP(hipMemsetAsync(s.wl_count, 0, 4, stream));
     const int euclid = metric == VQHIP_EUCLIDEAN ? 1 : 0;
-    switch (d) {
-    case 32:
-        VQ_TRY((launch_screen<32, 8>(X, n, s, stream, leaf)));
-        VQ_TRY(launch_continue<32>(X, centroids, left, right, euclid, s, leaf, stream));
+    const uint32_t dp = tsvq_screen_width(d);  // instantiated width serving d (d itself, or the next one up: zero padding)
+#define VQ_TSVQ_D(DV)                                                                              \
+    case DV:                                                                                       \
+        VQ_TRY((launch_screen<DV, 8>(X, n, d, s, stream, leaf)));                                  \
+        if (d == DV) VQ_TRY(launch_continue<DV>(X, centroids, left, right, euclid, s, leaf, stream)); \
         break;
-    case 64:
-        VQ_TRY((launch_screen<64, 8>(X, n, s, stream, leaf)));
-        VQ_TRY(launch_continue<64>(X, centroids, left, right, euclid, s, leaf, stream));
-        break;
-    case 128:
-        VQ_TRY((launch_screen<128, 8>(X, n, s, stream, leaf)));
-        VQ_TRY(launch_continue<128>(X, centroids, left, right, euclid, s, leaf, stream));
-        break;
-    case 256:
-        VQ_TRY((launch_screen<256, 8>(X, n, s, stream, leaf)));
-        VQ_TRY(launch_continue<256>(X, centroids, left, right, euclid, s, leaf, stream));
-        break;
-#define VQ_TSVQ_D(DV)                                                                     \
-    case DV:                                                                              \
-        VQ_TRY((launch_screen<DV, 8>(X, n, s, stream, leaf)));                            \
-        VQ_TRY(launch_continue<DV>(X, centroids, left, right, euclid, s, leaf, stream)); \
-        break;
-        VQ_TSVQ_D(192) VQ_TSVQ_D(384) VQ_TSVQ_D(512) VQ_TSVQ_D(768)  // embedding widths (the reference's eval: 384)
-#undef VQ_TSVQ_D
+    switch (dp) {
+        VQ_TSVQ_D(32) VQ_TSVQ_D(64) VQ_TSVQ_D(128) VQ_TSVQ_D(192) VQ_TSVQ_D(256)
+        VQ_TSVQ_D(384) VQ_TSVQ_D(512) VQ_TSVQ_D(768)  // embedding widths (the reference's eval: 384)
     default: return fail(VQHIP_ERR_UNSUPPORTED, "screened TSVQ descent: d=%u", d);
+    }
+#undef VQ_TSVQ_D
+    if (d != dp) {  // padded width: the undecided rows resume in the run-time-length kernel
+        hipLaunchKernelGGL(k_tsvq_continue_any, dim3(256), dim3(256), 0, stream, X, d, centroids, left, right, euclid,
+                           s.slot_node, s.wl, s.wl_count, leaf);
+        VQ_LAUNCH_CHECK("k_tsvq_continue_any");
     }
     return VQHIP_OK;
 }

@@ -169,6 +169,7 @@ struct TsvqScreen {
     uint32_t *wl_count = nullptr;
 };
 size_t tsvq_screen_lds_bytes(uint32_t n_int, uint32_t n_nodes, uint32_t d);
+uint32_t tsvq_screen_width(uint32_t d);  // instantiated width serving d (zero padding for other multiples of 4), 0 = none
 bool tsvq_screen_supported(uint32_t n_int, uint32_t n_nodes, uint32_t d, int metric);
 int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const int32_t *left,
                               const int32_t *right, int metric, const TsvqScreen &s, int32_t *leaf,
