@@ -714,10 +714,11 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
 // of centroids; a wave then stops after merging its two lane halves and writes {min, second min,
 // argmin, |x - mu|^2} per row to `part`; k_merge_partials_x32 merges the groups, applies the margin
 // test and feeds the (unsegmented) re-check list.  G = 1 is the single-pass kernel.
-// SDR < SD ("padded"): the data's sub_dim is SDR (even), the kernel works on SD dimensions whose last SD - SDR
-// are zero in both operands (k_center_codebook_x32 writes the copy SD wide): every sub_dim from 5 to 23 rides on
-// the next of the 8 / 12 / 16 / 24 kernels instead of the exact engine.
-template <int SD, int NT32, int G = 1, int SDR = SD>
+// PVW > 0 ("padded"): the data's sub_dim is the run-time sdr < SD, the kernel works on SD dimensions whose last
+// SD - sdr are zero in both operands (k_center_codebook_x32 writes the copy SD wide): a sub_dim between two
+// instantiated ones rides on the next one up instead of the exact engine.  PVW = floats per load part, as the
+// sub-vectors' alignment allows: 4 (sdr % 4 == 0), 2 (even sdr) or 1.
+template <int SD, int NT32, int G = 1, int PVW = 0>
 // k <= 128 at sub_dim <= 16: the A image is <= 96 registers, two waves fit a SIMD (0.30 vs 0.37 ms at C2 / k=128)
 __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_assign_screen_bf16_x32(
     const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m,
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
     const float *__restrict__ meta, const uint32_t *__restrict__ sub_list, uint32_t n_sub,
     uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_seg,
     uint32_t n_seg, uint64_t wl_stride, int cosine, uint32_t k_real, const float *__restrict__ cen,
-    uint4 *__restrict__ part, uint32_t groups_rt) {
+    uint4 *__restrict__ part, uint32_t groups_rt, uint32_t sdr) {
     // G > 0: compile-time group count (k <= 256); G == 0: k > 256, the count comes in groups_rt
     const uint32_t groups = (G > 0) ? (uint32_t)G : groups_rt;
     constexpr int DPH = SD / 2;            // dims owned by a lane half
@@ -800,19 +801,19 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
         for (int q = 0; q < DPH; ++q) mu[q] = cs[DPH * h + q];
     }
 
-    const size_t col0 = (size_t)s * SDR + (size_t)DPH * h;
+    const size_t col0 = (size_t)s * (PVW > 0 ? sdr : (uint32_t)SD) + (size_t)DPH * h;
+    const size_t sub0 = (size_t)s * (PVW > 0 ? sdr : (uint32_t)SD);  // first float of the sub-vector: always a valid part
     auto load_x = [&](uint64_t row, float (&x)[DPH]) {
         if (row >= n) row = n - 1;
         const float *ptr = X + row * d + col0;
-        if constexpr (SDR != SD) {
-            // the upper lane half runs past the sub-vector: those parts re-read its first part (a valid address)
-            // and are zeroed.  16-byte parts when the sub-vectors start on 16-byte boundaries, 8-byte ones for the
-            // other even sub_dims, single floats for the odd ones.
-            constexpr int VW = (SDR % 4 == 0 && DPH % 4 == 0) ? 4 : (SDR % 2 == 0) ? 2 : 1;
+        if constexpr (PVW > 0) {
+            // parts that run past the sub-vector re-read its first part (a valid address) and are zeroed
+            constexpr int VW = (PVW == 4 && DPH % 4 != 0) ? 2 : PVW;
+            const float *first = X + row * d + sub0;
 #pragma unroll
             for (int q = 0; q < DPH; q += VW) {
-                const bool live = (uint32_t)(DPH * h + q) < (uint32_t)SDR;
-                const float *pq = ptr + (live ? q : 0);
+                const bool live = (uint32_t)(DPH * h + q) < sdr;
+                const float *pq = live ? ptr + q : first;
                 if constexpr (VW == 4) {
                     const float4 t = *reinterpret_cast<const float4 *>(pq);
                     x[q + 0] = live ? t.x : 0.0f;
@@ -1595,7 +1596,7 @@ int launch_one(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) 
     return VQHIP_OK;
 }
 
-template <int SD, int NT32, int G = 1, int SDR = SD>
+template <int SD, int NT32, int G = 1, int PVW = 0>
 int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stream, uint32_t groups_rt = 0) {
     const uint32_t groups = (G > 0) ? (uint32_t)G : groups_rt;  // G == 0: run-time group count (k > 256)
     const uint64_t n_steps = (a.n + 31) / 32;
@@ -1617,16 +1618,16 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
         if (!a.part) return fail(VQHIP_ERR_FAILURE, "grouped screen without a partial-result buffer");
         a.n_seg = 0;  // the merge kernel appends to the unsegmented list
     }
-    hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32, G, SDR>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d,
+    hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32, G, PVW>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d,
                        cb.m, cb.prepA32, cb.cn32, NT32 * groups * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
                        a.wl_seg, n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen,
-                       reinterpret_cast<uint4 *>(a.part), groups);
+                       reinterpret_cast<uint4 *>(a.part), groups, cb.sd);
     VQ_LAUNCH_CHECK("k_assign_screen_bf16_x32");
     if (G != 1) {
         uint64_t mblocks = (a.n + 255) / 256;
         if (mblocks > (uint64_t)num_cus() * 8) mblocks = (uint64_t)num_cus() * 8;
         hipLaunchKernelGGL((k_merge_partials_x32<G>), dim3((uint32_t)mblocks, a.n_sub), dim3(256), 0, stream,
-                           reinterpret_cast<const uint4 *>(a.part), a.n, cb.m, cb.sd, a.sub_list, cb.cen, cb.meta,
+                           reinterpret_cast<const uint4 *>(a.part), a.n, cb.m, (uint32_t)SD, a.sub_list, cb.cen, cb.meta,
                            a.metric == VQHIP_COSINE ? 1 : 0, a.codes, a.wl_rows, a.wl_count, a.wl_stride, cb.k, groups);
         VQ_LAUNCH_CHECK("k_merge_partials_x32");
     }
@@ -1766,14 +1767,22 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
         VQ_X32(32, 1) VQ_X32(32, 2) VQ_X32(32, 3) VQ_X32(32, 4) VQ_X32G(32, 4, 2)
         VQ_X32(48, 1) VQ_X32(48, 2) VQ_X32G(48, 2, 2) VQ_X32G(48, 2, 3) VQ_X32G(48, 2, 4)
         VQ_X32(64, 1) VQ_X32(64, 2) VQ_X32G(64, 2, 2) VQ_X32G(64, 2, 3) VQ_X32G(64, 2, 4)
-        // padded sub_dims (SDR < SD), full 8-tile image
-#define VQ_X32P(SDV, SDRV) \
-    if (cb.sd == SDRV && nt32 == 8 && groups == 1) \
-        return launch_one_x32<SDV, 8, 1, SDRV>(cb, a, stream);
-        VQ_X32P(8, 5) VQ_X32P(8, 6) VQ_X32P(8, 7) VQ_X32P(12, 9) VQ_X32P(12, 10) VQ_X32P(12, 11)
-        VQ_X32P(16, 13) VQ_X32P(16, 14) VQ_X32P(16, 15)
-        VQ_X32P(24, 17) VQ_X32P(24, 18) VQ_X32P(24, 19) VQ_X32P(24, 20) VQ_X32P(24, 21) VQ_X32P(24, 22) VQ_X32P(24, 23)
+        // padded sub_dims (narrower than the kernel's SD), full image of 8 tiles; load parts by alignment
+        {
+            const uint32_t sdp = x32_padded_sd(cb.sd);
+            if (sdp != cb.sd) {
+                const int pvw = (cb.sd % 4 == 0) ? 4 : (cb.sd % 2 == 0) ? 2 : 1;
+#define VQ_X32P(SDV, NTV, GV)                                                                        \
+    if (sdp == SDV && nt32 == NTV && groups == GV) {                                                 \
+        if (pvw == 4) return launch_one_x32<SDV, NTV, GV, 4>(cb, a, stream);                         \
+        if (pvw == 2) return launch_one_x32<SDV, NTV, GV, 2>(cb, a, stream);                         \
+        return launch_one_x32<SDV, NTV, GV, 1>(cb, a, stream);                                       \
+    }
+                VQ_X32P(8, 8, 1) VQ_X32P(12, 8, 1) VQ_X32P(16, 8, 1) VQ_X32P(24, 8, 1)
 #undef VQ_X32P
+                return fail(VQHIP_ERR_UNSUPPORTED, "no padded bf16 screen for sub_dim=%u tiles=%u groups=%u", cb.sd, nt32, groups);
+            }
+        }
         // k > 256: full groups, run-time count
 #define VQ_X32R(SDV, NTV) \
     if (cb.sd == SDV && nt32 == NTV && cb.k > 256) return launch_one_x32<SDV, NTV, 0>(cb, a, stream, groups);
