@@ -80,6 +80,13 @@ SHAPES = [  # (n, d, m, k)
     (1100, 27, 3, 256),    # sub_dim 9 -> 12
     (1000, 5, 1, 256),     # sub_dim 5 -> 8, m = 1
     (999, 23, 1, 226),     # sub_dim 23 -> 24
+    (1500, 120, 4, 256),   # sub_dim 30 -> 32, two centroid groups (300 = 10 x 30)
+    (1200, 75, 3, 200),    # sub_dim 25 -> 32 (odd)
+    (1300, 80, 2, 256),    # sub_dim 40 -> 48, four groups
+    (1100, 100, 2, 256),   # sub_dim 50 -> 64
+    (1000, 180, 3, 130),   # sub_dim 60 -> 64
+    (900, 63, 1, 256),     # sub_dim 63 -> 64 (odd, m = 1)
+    (1000, 33, 1, 256),    # sub_dim 33 -> 48
 ]
 
 

@@ -746,8 +746,45 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
             VQ_RECHECK_CASE(22)
             VQ_RECHECK_CASE(23)
             VQ_RECHECK_CASE(24)
+            VQ_RECHECK_CASE(25)
+            VQ_RECHECK_CASE(26)
+            VQ_RECHECK_CASE(27)
+            VQ_RECHECK_CASE(28)
+            VQ_RECHECK_CASE(29)
+            VQ_RECHECK_CASE(30)
+            VQ_RECHECK_CASE(31)
             VQ_RECHECK_CASE(32)
+            VQ_RECHECK_CASE(33)
+            VQ_RECHECK_CASE(34)
+            VQ_RECHECK_CASE(35)
+            VQ_RECHECK_CASE(36)
+            VQ_RECHECK_CASE(37)
+            VQ_RECHECK_CASE(38)
+            VQ_RECHECK_CASE(39)
+            VQ_RECHECK_CASE(40)
+            VQ_RECHECK_CASE(41)
+            VQ_RECHECK_CASE(42)
+            VQ_RECHECK_CASE(43)
+            VQ_RECHECK_CASE(44)
+            VQ_RECHECK_CASE(45)
+            VQ_RECHECK_CASE(46)
+            VQ_RECHECK_CASE(47)
             VQ_RECHECK_CASE(48)
+            VQ_RECHECK_CASE(49)
+            VQ_RECHECK_CASE(50)
+            VQ_RECHECK_CASE(51)
+            VQ_RECHECK_CASE(52)
+            VQ_RECHECK_CASE(53)
+            VQ_RECHECK_CASE(54)
+            VQ_RECHECK_CASE(55)
+            VQ_RECHECK_CASE(56)
+            VQ_RECHECK_CASE(57)
+            VQ_RECHECK_CASE(58)
+            VQ_RECHECK_CASE(59)
+            VQ_RECHECK_CASE(60)
+            VQ_RECHECK_CASE(61)
+            VQ_RECHECK_CASE(62)
+            VQ_RECHECK_CASE(63)
             VQ_RECHECK_CASE(64)
         default: break;
         }

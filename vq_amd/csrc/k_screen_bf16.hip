@@ -1652,8 +1652,12 @@ uint32_t x32_padded_sd(uint32_t sd) {
     case 9: case 10: case 11: return 12;
     case 13: case 14: case 15: return 16;
     case 17: case 18: case 19: case 20: case 21: case 22: case 23: return 24;
-    default: return 0;
+    default: break;
     }
+    if (sd >= 25 && sd <= 31) return 32;
+    if (sd >= 33 && sd <= 47) return 48;
+    if (sd >= 49 && sd <= 63) return 64;
+    return 0;
 }
 
 void screen_bf16_x32_tiling(uint32_t sd_real, uint32_t k, uint32_t *nt32_per_group, uint32_t *groups) {
@@ -1665,8 +1669,8 @@ void screen_bf16_x32_tiling(uint32_t sd_real, uint32_t k, uint32_t *nt32_per_gro
         // padded variants exist for the full 8-tile image only: smaller codebooks are padded with never-winning
         // centroids up to 256 as long as that costs at most twice the useful work
         if (k <= 128 || k > 256) return;
-        *nt32_per_group = 8;
-        *groups = 1;
+        *nt32_per_group = (sd <= 24) ? 8 : (sd == 32) ? 4 : 2;  // 8 tiles in all: 1, 2 or 4 centroid groups
+        *groups = 8 / *nt32_per_group;
         return;
     }
     const uint32_t nt = (k + 31) / 32;
@@ -1779,6 +1783,7 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
         return launch_one_x32<SDV, NTV, GV, 1>(cb, a, stream);                                       \
     }
                 VQ_X32P(8, 8, 1) VQ_X32P(12, 8, 1) VQ_X32P(16, 8, 1) VQ_X32P(24, 8, 1)
+                VQ_X32P(32, 4, 2) VQ_X32P(48, 2, 4) VQ_X32P(64, 2, 4)
 #undef VQ_X32P
                 return fail(VQHIP_ERR_UNSUPPORTED, "no padded bf16 screen for sub_dim=%u tiles=%u groups=%u", cb.sd, nt32, groups);
             }

@@ -52,7 +52,7 @@ int bf16_mfma_selftest(float *ratio32, float *ratio16, int *trusted);
 bool screen_bf16_supported(uint32_t sd, uint32_t k);
 uint32_t screen_bf16_mfmas(uint32_t sd);
 int launch_prepare_bf16(const CodebookView &v, uint32_t *prepA16, hipStream_t stream);
-uint32_t x32_padded_sd(uint32_t sd);  // sub_dim of the X32 kernel serving `sd` (zero padding for 5..23), 0 = none
+uint32_t x32_padded_sd(uint32_t sd);  // sub_dim of the X32 kernel serving `sd` (zero padding for 5..63), 0 = none
 bool screen_bf16_x32_supported(uint32_t sd, uint32_t k);
 void screen_bf16_x32_tiling(uint32_t sd, uint32_t k, uint32_t *nt32_per_group, uint32_t *groups);
 bool screen_bf16_uses_x32(uint32_t sd, uint32_t k);
