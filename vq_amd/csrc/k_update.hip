@@ -344,7 +344,9 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ X
 static bool owned_sub_dim(uint32_t sd) {
     switch (sd) {
     case 4: case 8: case 12: case 16: case 24: case 32: case 48: case 64: case 96: case 128: case 256: return true;
-    default: return sd >= 5 && sd <= 23;  // 8-byte / 4-byte parts (sub_dim 20 = 5 x 16 bytes is among the cases below)
+    case 20: case 28: case 36: case 40: case 44: case 52: case 56: case 60: return true;  // 16-byte parts
+    case 26: case 30: return true;                                                         // 8-byte parts
+    default: return sd >= 5 && sd <= 23;                                                   // 8-byte / 4-byte parts
     }
 }
 
@@ -435,6 +437,7 @@ int launch_accumulate(const UpdatePlan &p, const float *X, uint64_t n, uint32_t 
             VQ_OWNED(6, 3, 2) VQ_OWNED(10, 5, 2) VQ_OWNED(14, 7, 2) VQ_OWNED(18, 9, 2) VQ_OWNED(22, 11, 2)
             VQ_OWNED(5, 5, 1) VQ_OWNED(7, 7, 1) VQ_OWNED(9, 9, 1) VQ_OWNED(11, 11, 1) VQ_OWNED(13, 13, 1)
             VQ_OWNED(15, 15, 1) VQ_OWNED(17, 17, 1) VQ_OWNED(19, 19, 1) VQ_OWNED(21, 21, 1) VQ_OWNED(23, 23, 1)
+            VQ_OWNED(26, 13, 2) VQ_OWNED(30, 15, 2)  // wider rows leave < 4 rows per wave step: the atomic kernel is faster there
         default: break;
         }
 #undef VQ_OWNED
@@ -449,6 +452,13 @@ int launch_accumulate(const UpdatePlan &p, const float *X, uint64_t n, uint32_t 
         case 16: return launch_owned<4>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 20: return launch_owned<5>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 24: return launch_owned<6>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 28: return launch_owned<7>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 36: return launch_owned<9>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 40: return launch_owned<10>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 44: return launch_owned<11>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 52: return launch_owned<13>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 56: return launch_owned<14>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
+        case 60: return launch_owned<15>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 48: return launch_owned<12>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 96: return launch_owned<24>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
         case 32: return launch_owned<8>(p, X, n, d, codes, active, partial_sums, partial_counts, p.owned_waves, stream);
