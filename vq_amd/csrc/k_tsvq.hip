@@ -621,6 +621,106 @@ __global__ __launch_bounds__(RB) void k_tsvq_descend_lds(const float *__restrict
     leaf_out[row0 + i] = node;
 }
 
+// The same walk with the row in REGISTERS (d = 32, 64, 96, 128): the LDS version holds 320 rows per CU at d = 128,
+// one wave per SIMD, and every level starts with a dependent chain of global loads (children, their centroids, for
+// cosine their norms) that nothing hides; with 128 + ~40 VGPRs three waves share a SIMD.  A lane reads its own row
+// (consecutive 16-byte parts of a line are asked for by consecutive instructions, so the L1 serves 7 of 8).
+template <int METRIC, int D>
+__global__ __launch_bounds__(256) void k_tsvq_descend_reg(const float *__restrict__ X, uint64_t n,
+                                                          const float *__restrict__ centroids,
+                                                          const float *__restrict__ cnorm,
+                                                          const int32_t *__restrict__ left,
+                                                          const int32_t *__restrict__ right,
+                                                          int32_t *__restrict__ leaf_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float x[D];
+    {
+        const float4 *px = reinterpret_cast<const float4 *>(X + i * D);
+#pragma unroll
+        for (int t4 = 0; t4 < D / 4; ++t4) {
+            const float4 v = px[t4];
+            x[4 * t4] = v.x, x[4 * t4 + 1] = v.y, x[4 * t4 + 2] = v.z, x[4 * t4 + 3] = v.w;
+        }
+    }
+    float na = 0.0f;
+    if (METRIC == VQHIP_COSINE) {
+        float sa = -0.0f;
+#pragma unroll
+        for (int t = 0; t < D; ++t) {
+            const float p = x[t] * x[t];
+            sa = sa + p;
+        }
+        na = sqrtf(sa);
+    }
+    int32_t node = 0;
+    for (;;) {
+        const int32_t l = left[node], r = right[node];
+        if (l >= 0 && r >= 0) {
+            const float4 *cl = reinterpret_cast<const float4 *>(centroids + (size_t)l * D);
+            const float4 *cr = reinterpret_cast<const float4 *>(centroids + (size_t)r * D);
+            float al = -0.0f, ar = -0.0f;
+#pragma unroll
+            for (int t4 = 0; t4 < D / 4; ++t4) {
+                const float4 a4 = cl[t4], b4 = cr[t4];
+                const float ca[4] = {a4.x, a4.y, a4.z, a4.w}, cb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float v = x[4 * t4 + u];
+                    if (METRIC == VQHIP_SQUARED_EUCLIDEAN || METRIC == VQHIP_EUCLIDEAN) {
+                        const float d1 = v - ca[u], d2 = v - cb[u];
+                        const float s1 = d1 * d1, s2 = d2 * d2;
+                        al = al + s1;
+                        ar = ar + s2;
+                    } else if (METRIC == VQHIP_MANHATTAN) {
+                        const float d1 = v - ca[u], d2 = v - cb[u];
+                        al = al + fabsf(d1);
+                        ar = ar + fabsf(d2);
+                    } else {
+                        const float p1 = v * ca[u], p2 = v * cb[u];
+                        al = al + p1;
+                        ar = ar + p2;
+                    }
+                }
+            }
+            float dl, dr;
+            if (METRIC == VQHIP_EUCLIDEAN) {
+                dl = sqrtf(al);
+                dr = sqrtf(ar);
+            } else if (METRIC == VQHIP_COSINE) {
+                const float nl = cnorm[l], nr = cnorm[r];
+                if (na < 1e-10f || nl < 1e-10f) {
+                    dl = 1.0f;
+                } else {
+                    const float den = na * nl;
+                    const float qq = al / den;
+                    const float v = 1.0f - qq;
+                    dl = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                }
+                if (na < 1e-10f || nr < 1e-10f) {
+                    dr = 1.0f;
+                } else {
+                    const float den = na * nr;
+                    const float qq = ar / den;
+                    const float v = 1.0f - qq;
+                    dr = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                }
+            } else {
+                dl = al;
+                dr = ar;
+            }
+            node = (dl <= dr) ? l : r;  // left on ties, tsvq.rs:122
+        } else if (l >= 0) {
+            node = l;
+        } else if (r >= 0) {
+            node = r;
+        } else {
+            break;
+        }
+    }
+    leaf_out[i] = node;
+}
+
 // sqrt(sum c^2) per node: cosine's norm_b depends on the node only (src/core/distance.rs:109)
 __global__ void k_tsvq_node_norms(const float *__restrict__ centroids, uint32_t n_nodes, uint32_t d,
                                   float *__restrict__ cnorm) {
@@ -1613,6 +1713,16 @@ static int dispatch_descend(const float *X, uint64_t n, uint32_t d, const float 
                             const int32_t *left, const int32_t *right, int32_t *leaf, hipStream_t stream, bool *done) {
     const size_t budget = 150 * 1024;
     *done = true;
+    const bool x_aligned = (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+#define VQ_DESCEND_REG(DV)                                                                                          \
+    if (d == DV && x_aligned) {                                                                                     \
+        hipLaunchKernelGGL((k_tsvq_descend_reg<METRIC, DV>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, \
+                           X, n, centroids, cnorm, left, right, leaf);                                              \
+        VQ_LAUNCH_CHECK("k_tsvq_descend_reg");                                                                      \
+        return VQHIP_OK;                                                                                            \
+    }
+    VQ_DESCEND_REG(32) VQ_DESCEND_REG(64) VQ_DESCEND_REG(96) VQ_DESCEND_REG(128)
+#undef VQ_DESCEND_REG
     if ((size_t)d * 256 * 4 <= budget) return launch_descend_lds<METRIC, 256>(X, n, d, centroids, cnorm, left, right, leaf, stream);
     if ((size_t)d * 128 * 4 <= budget) return launch_descend_lds<METRIC, 128>(X, n, d, centroids, cnorm, left, right, leaf, stream);
     if ((size_t)d * 64 * 4 <= budget) return launch_descend_lds<METRIC, 64>(X, n, d, centroids, cnorm, left, right, leaf, stream);
