@@ -87,6 +87,10 @@ SHAPES = [  # (n, d, m, k)
     (1000, 180, 3, 130),   # sub_dim 60 -> 64
     (900, 63, 1, 256),     # sub_dim 63 -> 64 (odd, m = 1)
     (1000, 33, 1, 256),    # sub_dim 33 -> 48
+    (2000, 128, 1, 256),   # sub_dim 128 (lbg_quantize on whole 128-d vectors): two 64-dimension chunks per tile
+    (1500, 192, 2, 100),   # sub_dim 96: the second chunk half empty, ragged k
+    (1800, 256, 2, 256),   # sub_dim 128, m = 2
+    (1200, 96, 1, 33),     # sub_dim 96, two centroid groups
 ]
 
 

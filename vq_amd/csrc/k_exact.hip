@@ -786,6 +786,8 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
             VQ_RECHECK_CASE(62)
             VQ_RECHECK_CASE(63)
             VQ_RECHECK_CASE(64)
+            VQ_RECHECK_CASE(96)
+            VQ_RECHECK_CASE(128)
         default: break;
         }
 #undef VQ_RECHECK_CASE

@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void k_center_codebook_x32(const float *__rest
                                                              uint32_t sd, uint32_t sdp, uint32_t cn_stride, uint32_t nmf,
                                                              float *__restrict__ cbc, float *__restrict__ cen,
                                                              float *__restrict__ cn32) {
-    __shared__ float s_mu[64];
+    __shared__ float s_mu[256];
     __shared__ float s_max[256];
     __shared__ int s_bad[256];
     const uint32_t s = blockIdx.x;
@@ -678,13 +678,16 @@ __global__ __launch_bounds__(256) void k_center_codebook_x32(const float *__rest
 // src/core/distance.rs:113-115) so that the screen forms s_j = -|x| cos(x, c_j)
 // sd_src: row length of `cb` (the codebook as is for cosine, already sd wide for the centred copy); dimensions
 // from sd_src up to the kernel's sd are zero padding
+// src_stride: floats between consecutive centroids of `cb` (a 64-dimension chunk of a wider sub-vector is prepared
+// with cb advanced to the chunk and sd_src = the chunk's live dimensions)
 __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restrict__ cb, uint32_t m, uint32_t k,
-                                                          uint32_t sd_src, uint32_t sd, uint32_t nt32, uint32_t nmf, int cosine,
+                                                          uint32_t sd_src, uint32_t src_stride, uint32_t sd, uint32_t nt32,
+                                                          uint32_t nmf, int cosine,
                                                           const float *__restrict__ cnsqrt,
                                                           uint32_t *__restrict__ prepA32) {
     const uint32_t s = blockIdx.x;
     const uint32_t dph = sd / 2;
-    const float *cbs = cb + (size_t)s * k * sd_src;
+    const float *cbs = cb + (size_t)s * k * src_stride;
     const uint32_t total = nt32 * nmf * 4 * 64;
     for (uint32_t e = blockIdx.y * blockDim.x + threadIdx.x; e < total; e += gridDim.y * blockDim.x) {
         const uint32_t lane = e & 63, w = (e >> 6) & 3, f = (e >> 8) % nmf, i = (e >> 8) / nmf;
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
             const uint32_t pair = flat / dph, dd = flat - pair * dph;
             if (pair < 6 && j < k && h * dph + dd < sd_src) {
                 uint32_t parts[3];
-                const float c = cbs[(size_t)j * sd_src + h * dph + dd];
+                const float c = cbs[(size_t)j * src_stride + h * dph + dd];
                 float av = -2.0f * c;
                 if (cosine) {
                     const float nb = cnsqrt[(size_t)s * k + j];
@@ -1100,6 +1103,147 @@ __global__ __launch_bounds__(256) void k_merge_partials_x32(const uint4 *__restr
             base = __builtin_amdgcn_readfirstlane(base);
             if (recheck) wl_rows[(size_t)s * wl_stride + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)row;
         }
+    }
+}
+
+// ---- wide sub-vectors (64 < sub_dim <= 64 NCH) -----------------------------------------------------
+// The operands of a 96- or 128-dimensional sub-vector do not fit a wave next to its accumulators, so they are
+// built and consumed 64 dimensions at a time: the NCH chunk products accumulate into ONE 32-centroid tile per
+// wave (A images of the tile's chunks resident: 96 NCH registers), a (row chunk, subspace) is shared by
+// ceil(k/32) waves, and the per-row partial verdicts go through k_merge_partials_x32 like the grouped screen's.
+// Plain MFMA builtins and a compare/select epilogue (16 values per lane): this kernel is for reach -- 10x over
+// the exact engine -- not tuned like the sub_dim <= 64 one.  sdr = the data's sub_dim (a multiple of 4).
+template <int NCH>
+__global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_wide(
+    const float *__restrict__ X, uint64_t n, uint32_t d, const uint32_t *__restrict__ prepA, size_t chunk_stride,
+    const float *__restrict__ prepCn, uint32_t cn_stride, const uint32_t *__restrict__ sub_list, uint32_t n_sub,
+    int cosine, uint32_t k_real, const float *__restrict__ cen, uint4 *__restrict__ part, uint32_t groups,
+    uint32_t sdr) {
+    constexpr int DPH = 32, NMF = 24, SDP = 64 * NCH;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t h = lane >> 5, p = lane & 31;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    const uint32_t n_virt = n_sub * groups;
+    const uint32_t n_chunks = total_waves / n_virt;
+    if (gw >= n_chunks * n_virt) return;
+    const uint32_t vv = gw % n_virt;
+    const uint32_t s = sub_list[vv / groups];
+    const uint32_t grp = vv % groups;
+    const uint32_t chunk = gw / n_virt;
+    const uint64_t n_steps = (n + 31) / 32;
+    const uint64_t steps_per_chunk = (n_steps + n_chunks - 1) / n_chunks;
+    const uint64_t st0 = (uint64_t)chunk * steps_per_chunk;
+    uint64_t st1 = st0 + steps_per_chunk;
+    if (st1 > n_steps) st1 = n_steps;
+    if (st0 >= st1) return;
+
+    bf16x8 a[NCH][NMF];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t *base = prepA + (size_t)c * chunk_stride + ((size_t)s * groups + grp) * NMF * 4 * 64 + lane;
+#pragma unroll
+        for (int f = 0; f < NMF; ++f) {
+            u32x4 v;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v[w] = base[(f * 4 + w) * 64];
+            a[c][f] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    // |c - mu|^2 (cosine: 0) of this lane's 16 centroids: register r <- centroid 32 grp + (r&3) + 8(r>>2) + 4h
+    float cnv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t idx = grp * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = (idx < cn_stride) ? prepCn[(size_t)s * cn_stride + idx] : 3.0e38f;
+        if (cosine) v = (idx < k_real) ? 0.0f : 3.0e38f;
+        cnv[r] = (v < 3.0e38f) ? v : 3.0e38f;
+    }
+    const float *cs = cen + (size_t)s * (SDP + 4);  // mu (zeros for cosine are not stored: skipped below)
+    const float pinf = __builtin_inff(), ninf = -__builtin_inff();
+    const size_t sub0 = (size_t)s * sdr;
+
+    for (uint64_t st = st0; st < st1; ++st) {
+        uint64_t row = st * 32 + p;
+        if (row >= n) row = n - 1;
+        const float *xrow = X + row * d + sub0;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = cnv[r];
+        float xs = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float x[DPH];
+#pragma unroll
+            for (int q = 0; q < DPH; q += 4) {
+                const uint32_t dim = 64 * c + DPH * h + q;
+                const bool live = dim < sdr;  // parts behind the sub-vector re-read its first part and count as zeros
+                const float4 t = *reinterpret_cast<const float4 *>(xrow + (live ? dim : 0u));
+                float4 mu4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!cosine) mu4 = *reinterpret_cast<const float4 *>(cs + dim);  // zero in the padding
+                x[q + 0] = live ? t.x - mu4.x : 0.0f;
+                x[q + 1] = live ? t.y - mu4.y : 0.0f;
+                x[q + 2] = live ? t.z - mu4.z : 0.0f;
+                x[q + 3] = live ? t.w - mu4.w : 0.0f;
+            }
+            uint32_t xp[3][DPH];
+#pragma unroll
+            for (int q = 0; q < DPH; ++q) {
+                uint32_t parts[3];
+                split3(x[q], parts);
+                xp[0][q] = parts[0];
+                xp[1][q] = parts[1];
+                xp[2][q] = parts[2];
+                xs = fmaf(x[q], x[q], xs);
+            }
+#pragma unroll
+            for (int f = 0; f < NMF; ++f) {
+                u32x4 v;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    uint32_t hw[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int flat = 8 * f + 2 * w + hh, pair = flat / DPH, dd = flat % DPH;  // 6 pairs x 32 dims = 24 x 8
+                        hw[hh] = xp[pair_x(pair)][dd];
+                    }
+                    v[w] = (hw[0] >> 16) | (hw[1] & 0xFFFF0000u);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c][f], __builtin_bit_cast(bf16x8, v), acc, 0, 0, 0);
+            }
+        }
+        // the lane's 16 values -> (min, second min, argmin); equal values keep the lower index and a zero gap
+        float m1 = pinf, m2 = pinf;
+        uint32_t ji = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r];
+            const uint32_t idx = (r & 3) + 8 * (r >> 2) + 4 * h;
+            m2 = __builtin_amdgcn_fmed3f(m1, m2, v);
+            const bool take = (v < m1) || (v == m1 && idx < ji);
+            ji = take ? idx : ji;
+            m1 = take ? v : m1;
+        }
+        uint32_t j = grp * 32 + ji;
+        {
+            const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m1), __float_as_uint(m1), false, false);
+            const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m2), __float_as_uint(m2), false, false);
+            const auto rj = __builtin_amdgcn_permlane32_swap(j, j, false, false);
+            const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(xs), __float_as_uint(xs), false, false);
+            const float a1 = __uint_as_float(r1[0]), b1 = __uint_as_float(r1[1]);
+            const float a2 = __uint_as_float(r2[0]), b2 = __uint_as_float(r2[1]);
+            xs = __uint_as_float(rx[0]) + __uint_as_float(rx[1]);
+            const float hi = __builtin_amdgcn_fmed3f(a1, b1, pinf);
+            const float lo2 = __builtin_amdgcn_fmed3f(a2, b2, ninf);
+            m2 = __builtin_amdgcn_fmed3f(lo2, hi, ninf);
+            const bool take = (b1 < a1) || (b1 == a1 && rj[1] < rj[0]);
+            j = take ? rj[1] : rj[0];
+            m1 = take ? b1 : a1;
+        }
+        const uint64_t prow = st * 32 + p;
+        if (h == 0 && prow < n)
+            part[((size_t)s * groups + grp) * n + prow] = make_uint4(__float_as_uint(m1), __float_as_uint(m2), j, __float_as_uint(xs));
     }
 }
 
@@ -1634,6 +1778,33 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
     return VQHIP_OK;
 }
 
+template <int NCH>
+int launch_wide(const CodebookView &cb, const AssignArgs &a, hipStream_t stream, uint32_t groups) {
+    if (!a.part) return fail(VQHIP_ERR_FAILURE, "wide screen without a partial-result buffer");
+    if (cb.sd % 4 != 0) return fail(VQHIP_ERR_UNSUPPORTED, "wide screen: sub_dim=%u", cb.sd);
+    const uint64_t n_steps = (a.n + 31) / 32;
+    const uint32_t n_virt = a.n_sub * groups;
+    uint64_t want_waves = (uint64_t)num_cus() * kWavesPerBlock;
+    const uint64_t max_useful = n_steps * n_virt;
+    if (want_waves > max_useful) want_waves = max_useful;
+    if (want_waves < n_virt) want_waves = n_virt;
+    uint32_t blocks = (uint32_t)((want_waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    while ((uint64_t)blocks * kWavesPerBlock < n_virt) ++blocks;
+    a.n_seg = 0;  // the merge kernel appends to the unsegmented list
+    const size_t chunk_stride = (size_t)cb.m * groups * 24 * 4 * 64;
+    hipLaunchKernelGGL((k_assign_screen_bf16_wide<NCH>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d, cb.prepA32,
+                       chunk_stride, cb.cn32, groups * 32, a.sub_list, a.n_sub, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen,
+                       reinterpret_cast<uint4 *>(a.part), groups, cb.sd);
+    VQ_LAUNCH_CHECK("k_assign_screen_bf16_wide");
+    uint64_t mblocks = (a.n + 255) / 256;
+    if (mblocks > (uint64_t)num_cus() * 8) mblocks = (uint64_t)num_cus() * 8;
+    hipLaunchKernelGGL((k_merge_partials_x32<0>), dim3((uint32_t)mblocks, a.n_sub), dim3(256), 0, stream,
+                       reinterpret_cast<const uint4 *>(a.part), a.n, cb.m, (uint32_t)(64 * NCH), a.sub_list, cb.cen, cb.meta,
+                       a.metric == VQHIP_COSINE ? 1 : 0, a.codes, a.wl_rows, a.wl_count, a.wl_stride, cb.k, groups);
+    VQ_LAUNCH_CHECK("k_merge_partials_x32");
+    return VQHIP_OK;
+}
+
 }  // namespace
 
 // true when launch_assign_screen_bf16 will take the X32 path (so only that image is needed)
@@ -1657,6 +1828,7 @@ uint32_t x32_padded_sd(uint32_t sd) {
     if (sd >= 25 && sd <= 31) return 32;
     if (sd >= 33 && sd <= 47) return 48;
     if (sd >= 49 && sd <= 63) return 64;
+    if (sd == 96 || sd == 128) return 128;  // two chunks of 64 dimensions (k_assign_screen_bf16_wide)
     return 0;
 }
 
@@ -1665,6 +1837,13 @@ void screen_bf16_x32_tiling(uint32_t sd_real, uint32_t k, uint32_t *nt32_per_gro
     if (k == 0 || k > kMaxCentroids) return;
     const uint32_t sd = x32_padded_sd(sd_real);
     if (sd == 0) return;
+    if (sd == 128) {  // wide kernel: one 32-centroid tile per wave, any k up to 16 groups
+        const uint32_t g = (k + 31) / 32;
+        if (g > kX32MaxGroups) return;
+        *nt32_per_group = 1;
+        *groups = g;
+        return;
+    }
     if (sd != sd_real) {
         // padded variants exist for the full 8-tile image only: smaller codebooks are padded with never-winning
         // centroids up to 256 as long as that costs at most twice the useful work
@@ -1716,8 +1895,19 @@ int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine
         VQ_LAUNCH_CHECK("k_center_codebook_x32");
         src = cbc;  // sdp wide
     }
-    hipLaunchKernelGGL(k_prepare_bf16_x32, dim3(v.m, 16), dim3(256), 0, stream, src, v.m, v.k, cosine ? v.sd : sdp, sdp, nt32,
-                       screen_bf16_x32_mfmas(v.sd), cosine, v.cnsqrt, prepA32);
+    if (sdp == 128) {  // wide sub-vectors: one image per 64-dimension chunk, chunk-major
+        const uint32_t stride = cosine ? v.sd : sdp;
+        const size_t chunk_stride = (size_t)v.m * nt32 * 24 * 4 * 64;
+        for (uint32_t c = 0; c < sdp / 64; ++c) {
+            const uint32_t live = v.sd > 64 * c ? std::min(64u, v.sd - 64 * c) : 0u;
+            hipLaunchKernelGGL(k_prepare_bf16_x32, dim3(v.m, 16), dim3(256), 0, stream, src + 64 * c, v.m, v.k, live, stride, 64u,
+                               nt32, 24u, cosine, v.cnsqrt, prepA32 + c * chunk_stride);
+        }
+        VQ_LAUNCH_CHECK("k_prepare_bf16_x32");
+        return VQHIP_OK;
+    }
+    hipLaunchKernelGGL(k_prepare_bf16_x32, dim3(v.m, 16), dim3(256), 0, stream, src, v.m, v.k, cosine ? v.sd : sdp,
+                       cosine ? v.sd : sdp, sdp, nt32, screen_bf16_x32_mfmas(v.sd), cosine, v.cnsqrt, prepA32);
     VQ_LAUNCH_CHECK("k_prepare_bf16_x32");
     return VQHIP_OK;
 }
@@ -1771,6 +1961,7 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
         VQ_X32(32, 1) VQ_X32(32, 2) VQ_X32(32, 3) VQ_X32(32, 4) VQ_X32G(32, 4, 2)
         VQ_X32(48, 1) VQ_X32(48, 2) VQ_X32G(48, 2, 2) VQ_X32G(48, 2, 3) VQ_X32G(48, 2, 4)
         VQ_X32(64, 1) VQ_X32(64, 2) VQ_X32G(64, 2, 2) VQ_X32G(64, 2, 3) VQ_X32G(64, 2, 4)
+        if (x32_padded_sd(cb.sd) == 128) return launch_wide<2>(cb, a, stream, groups);
         // padded sub_dims (narrower than the kernel's SD), full image of 8 tiles; load parts by alignment
         {
             const uint32_t sdp = x32_padded_sd(cb.sd);
