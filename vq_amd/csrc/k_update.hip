@@ -387,6 +387,7 @@ int plan_update(uint32_t m, uint32_t k, uint32_t sd, uint64_t n, UpdatePlan *p) 
         if (w > 8) w = 8;
         if (w > m) w = m;
         if (w > 0) w = (m + ((m + w - 1) / w) - 1) / ((m + w - 1) / w);  // same number of workgroups, evenly filled (m = 10: 5 + 5, not 8 + 2)
+        if (w < 2) w = 0;  // one wave per workgroup (m = 1, or accumulators filling the LDS): the atomic kernel's 16 waves win
         p->owned_waves = w;
         if (w > 0) {
             uint32_t sub_groups = (m + w - 1) / w;
