@@ -554,6 +554,100 @@ __global__ __launch_bounds__(256) void k_recheck_resident(
     }
 }
 
+// Re-check for long sub-vectors (the screens of sub_dim 48 .. 128 leave one list per subspace): k_recheck_wave pulls
+// the whole sub-codebook through the L1 for every entry (128 KB at sub_dim 128, k = 256).  Here a workgroup of 16
+// waves takes 16 entries at a time and stages the centroids through LDS in tiles of 64, once for all 16: lane l of
+// every wave evaluates centroid (tile + l) for its wave's entry, the entry's row sits in LDS too (broadcast reads).
+// Same arithmetic and merge rule as k_recheck_wave.
+template <int METRIC, int SD>
+__global__ __launch_bounds__(1024) void k_recheck_tiled(
+    const float *__restrict__ X, uint32_t d, uint32_t m, uint32_t k, const float *__restrict__ cb,
+    const float *__restrict__ cnsqrt, const uint32_t *__restrict__ sub_list, const uint32_t *__restrict__ wl_rows,
+    const uint32_t *__restrict__ wl_count, uint64_t wl_stride, uint8_t *__restrict__ codes) {
+    constexpr uint32_t TCN = 64, PITCH = SD + 4;  // 16-byte rows; the pad spreads the lanes' rows over the banks
+    __shared__ __attribute__((aligned(16))) float ct[TCN][PITCH];
+    __shared__ __attribute__((aligned(16))) float xs[16][SD];
+    const uint32_t s = sub_list ? sub_list[blockIdx.y] : blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t count = wl_count[s];
+    const float *cbs = cb + (size_t)s * k * SD;
+    const uint32_t NONE = 0xFFFFFFFFu;
+    for (uint32_t e0 = blockIdx.x * 16; e0 < count; e0 += gridDim.x * 16) {  // uniform per workgroup
+        const uint32_t e = e0 + wave;
+        const bool valid = e < count;
+        const uint32_t row = valid ? wl_rows[(size_t)s * wl_stride + e] : 0u;
+        __syncthreads();  // the previous batch is done with xs and ct
+        if (valid)
+            for (uint32_t t = lane; t < SD; t += 64) xs[wave][t] = X[(size_t)row * d + (size_t)s * SD + t];
+        float na = 0.0f;
+        float bd = __builtin_inff();
+        uint32_t bj = NONE;
+        bool d0_nan = false;
+        for (uint32_t j0 = 0; j0 < k; j0 += TCN) {
+            __syncthreads();  // xs written / previous tile consumed
+            for (uint32_t idx = threadIdx.x; idx < TCN * (SD / 4); idx += 1024) {
+                const uint32_t r = idx / (SD / 4), q = idx % (SD / 4);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j0 + r < k) v = *reinterpret_cast<const float4 *>(cbs + (size_t)(j0 + r) * SD + 4 * q);
+                *reinterpret_cast<float4 *>(&ct[r][4 * q]) = v;
+            }
+            __syncthreads();
+            if (METRIC == VQHIP_COSINE && j0 == 0) {
+                float sa = -0.0f;
+                for (uint32_t t = 0; t < SD; ++t) {
+                    const float p = xs[wave][t] * xs[wave][t];
+                    sa = sa + p;
+                }
+                na = sqrtf(sa);
+            }
+            const uint32_t j = j0 + lane;
+            float acc = (METRIC == VQHIP_COSINE) ? -0.0f : 0.0f;
+#pragma unroll 4
+            for (uint32_t t4 = 0; t4 < SD / 4; ++t4) {
+                const float4 xv = *reinterpret_cast<const float4 *>(&xs[wave][4 * t4]);
+                const float4 cv = *reinterpret_cast<const float4 *>(&ct[lane][4 * t4]);
+                const float xe[4] = {xv.x, xv.y, xv.z, xv.w}, ce[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (METRIC == VQHIP_SQUARED_EUCLIDEAN || METRIC == VQHIP_EUCLIDEAN) {
+                        const float diff = xe[u] - ce[u];
+                        const float sq = diff * diff;
+                        acc = acc + sq;
+                    } else if (METRIC == VQHIP_MANHATTAN) {
+                        const float diff = xe[u] - ce[u];
+                        acc = acc + fabsf(diff);
+                    } else {
+                        const float p = xe[u] * ce[u];
+                        acc = acc + p;
+                    }
+                }
+            }
+            float dist = acc;
+            if (METRIC == VQHIP_EUCLIDEAN) dist = sqrtf(acc);
+            if (METRIC == VQHIP_COSINE) {
+                const float nb = (j < k) ? cnsqrt[(size_t)s * k + j] : 1.0f;
+                const float EPS = 1e-10f;
+                if (na < EPS || nb < EPS) {
+                    dist = 1.0f;
+                } else {
+                    const float denom = na * nb;
+                    const float q = acc / denom;
+                    const float v = 1.0f - q;
+                    dist = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                }
+            }
+            const bool isnan_d = dist != dist;
+            if (j == 0) d0_nan = isnan_d;
+            const bool better = (j < k) & !isnan_d & ((bj == NONE) | (dist < bd));  // ascending j within the lane
+            bd = better ? dist : bd;
+            bj = better ? j : bj;
+        }
+        argmin_wave(bd, bj);
+        const bool blocked = __builtin_amdgcn_readlane((int)d0_nan, 0) != 0;
+        if (valid && lane == 0) store_code(codes, (size_t)row * m + s, (blocked || bj == NONE) ? 0u : bj, k);
+    }
+}
+
 // One workgroup per subspace: squared norms, the screen's A-operand image, flags.
 __global__ __launch_bounds__(256) void k_prepare_codebook(const float *__restrict__ cb, uint32_t m,
                                                           uint32_t k, uint32_t sd, uint32_t nt,
@@ -716,6 +810,18 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
             VQ_RESIDENT(24, 1) VQ_RESIDENT(24, 2) VQ_RESIDENT(24, 4)
             VQ_RESIDENT(32, 1) VQ_RESIDENT(32, 2) VQ_RESIDENT(32, 4)
 #undef VQ_RESIDENT
+        }
+        if (!seg && (cb.sd == 48 || cb.sd == 64 || cb.sd == 96 || cb.sd == 128)) {
+            const dim3 tgrid((uint32_t)num_cus(), a.n_sub);
+#define VQ_RECHECK_TILED(SDV)                                                                                        \
+    if (cb.sd == SDV) {                                                                                              \
+        hipLaunchKernelGGL((k_recheck_tiled<METRIC, SDV>), tgrid, dim3(1024), 0, stream, a.X, a.d, cb.m, cb.k, cb.cb, \
+                           cb.cnsqrt, a.sub_list, wlr, wlc, a.wl_stride, a.codes);                                    \
+        VQ_LAUNCH_CHECK("k_recheck_tiled");                                                                          \
+        return VQHIP_OK;                                                                                             \
+    }
+            VQ_RECHECK_TILED(48) VQ_RECHECK_TILED(64) VQ_RECHECK_TILED(96) VQ_RECHECK_TILED(128)
+#undef VQ_RECHECK_TILED
         }
 #define VQ_RECHECK_CASE(SDV)                                                                   \
     case SDV:                                                                                  \
