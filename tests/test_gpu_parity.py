@@ -91,6 +91,11 @@ SHAPES = [  # (n, d, m, k)
     (1500, 192, 2, 100),   # sub_dim 96: the second chunk half empty, ragged k
     (1800, 256, 2, 256),   # sub_dim 128, m = 2
     (1200, 96, 1, 33),     # sub_dim 96, two centroid groups
+    (1500, 100, 1, 256),   # sub_dim 100 (whole 100-d word vectors) on the 128-wide kernel
+    (1300, 160, 2, 200),   # sub_dim 80
+    (1100, 72, 1, 100),    # sub_dim 72
+    (1000, 240, 2, 256),   # sub_dim 120
+    (900, 112, 1, 64),     # sub_dim 112
 ]
 
 

@@ -1828,7 +1828,8 @@ uint32_t x32_padded_sd(uint32_t sd) {
     if (sd >= 25 && sd <= 31) return 32;
     if (sd >= 33 && sd <= 47) return 48;
     if (sd >= 49 && sd <= 63) return 64;
-    if (sd == 96 || sd == 128) return 128;  // two chunks of 64 dimensions (k_assign_screen_bf16_wide)
+    // two chunks of 64 dimensions (k_assign_screen_bf16_wide); the widths with a re-check instantiation
+    if (sd == 72 || sd == 80 || sd == 96 || sd == 100 || sd == 112 || sd == 120 || sd == 128) return 128;
     return 0;
 }
 
