@@ -96,6 +96,8 @@ SHAPES = [  # (n, d, m, k)
     (1100, 72, 1, 100),    # sub_dim 72
     (1000, 240, 2, 256),   # sub_dim 120
     (900, 112, 1, 64),     # sub_dim 112
+    (1200, 192, 1, 256),   # sub_dim 192: three chunks
+    (1000, 320, 2, 150),   # sub_dim 160
 ]
 
 

@@ -281,7 +281,7 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
     a.wl_seg = ws.wl_seg.as<uint32_t>();
     a.wl_seg_cap = AssignWorkspace::kSegCap;
     a.n_seg = 0;
-    if (engine == VQHIP_ENGINE_MFMA_BF16 && (cs.x32_groups > 1 || x32_padded_sd(cs.sd) == 128) &&
+    if (engine == VQHIP_ENGINE_MFMA_BF16 && (cs.x32_groups > 1 || x32_padded_sd(cs.sd) > 64) &&
         screen_bf16_uses_x32(cs.sd, cs.k)) {  // (the wide kernel goes through the partial verdicts even with one group)
         VQ_TRY(ws.part.ensure((size_t)cs.m * cs.x32_groups * n * 16));
         a.part = ws.part.p;

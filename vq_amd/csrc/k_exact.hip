@@ -811,7 +811,7 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
             VQ_RESIDENT(32, 1) VQ_RESIDENT(32, 2) VQ_RESIDENT(32, 4)
 #undef VQ_RESIDENT
         }
-        if (!seg && (cb.sd == 48 || cb.sd == 64 || (cb.sd >= 72 && cb.sd <= 128))) {
+        if (!seg && (cb.sd == 48 || cb.sd == 64 || (cb.sd >= 72 && cb.sd <= 192))) {
             const dim3 tgrid((uint32_t)num_cus(), a.n_sub);
 #define VQ_RECHECK_TILED(SDV)                                                                                        \
     if (cb.sd == SDV) {                                                                                              \
@@ -822,6 +822,7 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
     }
             VQ_RECHECK_TILED(48) VQ_RECHECK_TILED(64) VQ_RECHECK_TILED(72) VQ_RECHECK_TILED(80) VQ_RECHECK_TILED(96)
             VQ_RECHECK_TILED(100) VQ_RECHECK_TILED(112) VQ_RECHECK_TILED(120) VQ_RECHECK_TILED(128)
+            VQ_RECHECK_TILED(160) VQ_RECHECK_TILED(192)
 #undef VQ_RECHECK_TILED
         }
 #define VQ_RECHECK_CASE(SDV)                                                                   \

@@ -1830,6 +1830,7 @@ uint32_t x32_padded_sd(uint32_t sd) {
     if (sd >= 49 && sd <= 63) return 64;
     // two chunks of 64 dimensions (k_assign_screen_bf16_wide); the widths with a re-check instantiation
     if (sd == 72 || sd == 80 || sd == 96 || sd == 100 || sd == 112 || sd == 120 || sd == 128) return 128;
+    if (sd == 160 || sd == 192) return 192;  // three chunks
     return 0;
 }
 
@@ -1838,7 +1839,7 @@ void screen_bf16_x32_tiling(uint32_t sd_real, uint32_t k, uint32_t *nt32_per_gro
     if (k == 0 || k > kMaxCentroids) return;
     const uint32_t sd = x32_padded_sd(sd_real);
     if (sd == 0) return;
-    if (sd == 128) {  // wide kernel: one 32-centroid tile per wave, any k up to 16 groups
+    if (sd > 64) {  // wide kernel: one 32-centroid tile per wave, any k up to 16 groups
         const uint32_t g = (k + 31) / 32;
         if (g > kX32MaxGroups) return;
         *nt32_per_group = 1;
@@ -1896,7 +1897,7 @@ int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine
         VQ_LAUNCH_CHECK("k_center_codebook_x32");
         src = cbc;  // sdp wide
     }
-    if (sdp == 128) {  // wide sub-vectors: one image per 64-dimension chunk, chunk-major
+    if (sdp > 64) {  // wide sub-vectors: one image per 64-dimension chunk, chunk-major
         const uint32_t stride = cosine ? v.sd : sdp;
         const size_t chunk_stride = (size_t)v.m * nt32 * 24 * 4 * 64;
         for (uint32_t c = 0; c < sdp / 64; ++c) {
@@ -1963,6 +1964,7 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
         VQ_X32(48, 1) VQ_X32(48, 2) VQ_X32G(48, 2, 2) VQ_X32G(48, 2, 3) VQ_X32G(48, 2, 4)
         VQ_X32(64, 1) VQ_X32(64, 2) VQ_X32G(64, 2, 2) VQ_X32G(64, 2, 3) VQ_X32G(64, 2, 4)
         if (x32_padded_sd(cb.sd) == 128) return launch_wide<2>(cb, a, stream, groups);
+        if (x32_padded_sd(cb.sd) == 192) return launch_wide<3>(cb, a, stream, groups);
         // padded sub_dims (narrower than the kernel's SD), full image of 8 tiles; load parts by alignment
         {
             const uint32_t sdp = x32_padded_sd(cb.sd);
