@@ -98,6 +98,9 @@ SHAPES = [  # (n, d, m, k)
     (900, 112, 1, 64),     # sub_dim 112
     (1200, 192, 1, 256),   # sub_dim 192: three chunks
     (1000, 320, 2, 150),   # sub_dim 160
+    (1100, 84, 1, 256),    # sub_dim 84: run-time-length tiled re-check
+    (900, 132, 1, 100),    # sub_dim 132 -> 192
+    (800, 136, 2, 256),    # sub_dim 68
 ]
 
 

@@ -648,6 +648,102 @@ __global__ __launch_bounds__(1024) void k_recheck_tiled(
     }
 }
 
+// k_recheck_tiled for a run-time sub_dim (a multiple of 4; the widths of the wide screen without a compile-time
+// instantiation): the centroid tile is staged 64 dimensions at a time, the running distance of (entry, centroid)
+// stays in the lane across the dimension chunks, the entries' rows sit in dynamic LDS.
+template <int METRIC>
+__global__ __launch_bounds__(1024) void k_recheck_tiled_any(
+    const float *__restrict__ X, uint32_t d, uint32_t m, uint32_t k, uint32_t sd, const float *__restrict__ cb,
+    const float *__restrict__ cnsqrt, const uint32_t *__restrict__ sub_list, const uint32_t *__restrict__ wl_rows,
+    const uint32_t *__restrict__ wl_count, uint64_t wl_stride, uint8_t *__restrict__ codes) {
+    constexpr uint32_t TCN = 64, TD = 64, PITCH = TD + 4;
+    __shared__ __attribute__((aligned(16))) float ct[TCN][PITCH];
+    extern __shared__ __attribute__((aligned(16))) float xs_any[];  // [16][sd]
+    const uint32_t s = sub_list ? sub_list[blockIdx.y] : blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t count = wl_count[s];
+    const float *cbs = cb + (size_t)s * k * sd;
+    float *xw = xs_any + (size_t)wave * sd;
+    const uint32_t NONE = 0xFFFFFFFFu;
+    for (uint32_t e0 = blockIdx.x * 16; e0 < count; e0 += gridDim.x * 16) {
+        const uint32_t e = e0 + wave;
+        const bool valid = e < count;
+        const uint32_t row = valid ? wl_rows[(size_t)s * wl_stride + e] : 0u;
+        __syncthreads();
+        if (valid)
+            for (uint32_t t = lane; t < sd; t += 64) xw[t] = X[(size_t)row * d + (size_t)s * sd + t];
+        __syncthreads();
+        float na = 0.0f;
+        if (METRIC == VQHIP_COSINE) {
+            float sa = -0.0f;
+            for (uint32_t t = 0; t < sd; ++t) {
+                const float p = xw[t] * xw[t];
+                sa = sa + p;
+            }
+            na = sqrtf(sa);
+        }
+        float bd = __builtin_inff();
+        uint32_t bj = NONE;
+        bool d0_nan = false;
+        for (uint32_t j0 = 0; j0 < k; j0 += TCN) {
+            const uint32_t j = j0 + lane;
+            float acc = (METRIC == VQHIP_COSINE) ? -0.0f : 0.0f;
+            for (uint32_t t0 = 0; t0 < sd; t0 += TD) {
+                const uint32_t td = min(TD, sd - t0);  // a multiple of 4
+                __syncthreads();  // the previous chunk is consumed
+                for (uint32_t idx = threadIdx.x; idx < TCN * (TD / 4); idx += 1024) {
+                    const uint32_t r = idx / (TD / 4), q = idx % (TD / 4);
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (j0 + r < k && 4 * q < td) v = *reinterpret_cast<const float4 *>(cbs + (size_t)(j0 + r) * sd + t0 + 4 * q);
+                    *reinterpret_cast<float4 *>(&ct[r][4 * q]) = v;
+                }
+                __syncthreads();
+                for (uint32_t t4 = 0; t4 < td / 4; ++t4) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(&xw[t0 + 4 * t4]);
+                    const float4 cv = *reinterpret_cast<const float4 *>(&ct[lane][4 * t4]);
+                    const float xe[4] = {xv.x, xv.y, xv.z, xv.w}, ce[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (METRIC == VQHIP_SQUARED_EUCLIDEAN || METRIC == VQHIP_EUCLIDEAN) {
+                            const float diff = xe[u] - ce[u];
+                            const float sq = diff * diff;
+                            acc = acc + sq;
+                        } else if (METRIC == VQHIP_MANHATTAN) {
+                            const float diff = xe[u] - ce[u];
+                            acc = acc + fabsf(diff);
+                        } else {
+                            const float p = xe[u] * ce[u];
+                            acc = acc + p;
+                        }
+                    }
+                }
+            }
+            float dist = acc;
+            if (METRIC == VQHIP_EUCLIDEAN) dist = sqrtf(acc);
+            if (METRIC == VQHIP_COSINE) {
+                const float nb = (j < k) ? cnsqrt[(size_t)s * k + j] : 1.0f;
+                const float EPS = 1e-10f;
+                if (na < EPS || nb < EPS) {
+                    dist = 1.0f;
+                } else {
+                    const float denom = na * nb;
+                    const float q = acc / denom;
+                    const float v = 1.0f - q;
+                    dist = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                }
+            }
+            const bool isnan_d = dist != dist;
+            if (j == 0) d0_nan = isnan_d;
+            const bool better = (j < k) & !isnan_d & ((bj == NONE) | (dist < bd));
+            bd = better ? dist : bd;
+            bj = better ? j : bj;
+        }
+        argmin_wave(bd, bj);
+        const bool blocked = __builtin_amdgcn_readlane((int)d0_nan, 0) != 0;
+        if (valid && lane == 0) store_code(codes, (size_t)row * m + s, (blocked || bj == NONE) ? 0u : bj, k);
+    }
+}
+
 // One workgroup per subspace: squared norms, the screen's A-operand image, flags.
 __global__ __launch_bounds__(256) void k_prepare_codebook(const float *__restrict__ cb, uint32_t m,
                                                           uint32_t k, uint32_t sd, uint32_t nt,
@@ -824,6 +920,11 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
             VQ_RECHECK_TILED(100) VQ_RECHECK_TILED(112) VQ_RECHECK_TILED(120) VQ_RECHECK_TILED(128)
             VQ_RECHECK_TILED(160) VQ_RECHECK_TILED(192)
 #undef VQ_RECHECK_TILED
+            // any other multiple of 4 in the wide screen's range
+            hipLaunchKernelGGL((k_recheck_tiled_any<METRIC>), tgrid, dim3(1024), (size_t)16 * cb.sd * 4, stream, a.X, a.d, cb.m,
+                               cb.k, cb.sd, cb.cb, cb.cnsqrt, a.sub_list, wlr, wlc, a.wl_stride, a.codes);
+            VQ_LAUNCH_CHECK("k_recheck_tiled_any");
+            return VQHIP_OK;
         }
 #define VQ_RECHECK_CASE(SDV)                                                                   \
     case SDV:                                                                                  \

@@ -1828,9 +1828,9 @@ uint32_t x32_padded_sd(uint32_t sd) {
     if (sd >= 25 && sd <= 31) return 32;
     if (sd >= 33 && sd <= 47) return 48;
     if (sd >= 49 && sd <= 63) return 64;
-    // two chunks of 64 dimensions (k_assign_screen_bf16_wide); the widths with a re-check instantiation
-    if (sd == 72 || sd == 80 || sd == 96 || sd == 100 || sd == 112 || sd == 120 || sd == 128) return 128;
-    if (sd == 160 || sd == 192) return 192;  // three chunks
+    // two or three chunks of 64 dimensions (k_assign_screen_bf16_wide): any multiple of 4 (16-byte row parts)
+    if (sd > 64 && sd <= 128 && sd % 4 == 0) return 128;
+    if (sd > 128 && sd <= 192 && sd % 4 == 0) return 192;
     return 0;
 }
 
