@@ -45,7 +45,7 @@ def test_fuzz_pq_encode(oracle, seed):
     sd = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 8, 9, 10, 10, 11, 12, 14, 16, 16, 18, 20, 22, 24, 25, 28, 30, 32, 32, 33, 36, 40, 48, 48, 50, 57, 60, 64, 64, 68, 72, 80, 88, 96, 100, 112, 120, 128, 128, 130, 140, 176]))
     m = int(rng.choice([1, 2, 3, 4, 8, 16]))
     d = sd * m
-    k = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 64, 100, 128, 200, 225, 240, 255, 256, 256]))
+    k = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 64, 65, 100, 100, 128, 128, 200, 225, 240, 255, 256, 256]))
     n = int(rng.integers(1, 3000))
     kind = KINDS[int(rng.integers(0, len(KINDS)))]
     metric = int(rng.integers(0, 4))

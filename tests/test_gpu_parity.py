@@ -72,8 +72,11 @@ SHAPES = [  # (n, d, m, k)
     (1100, 36, 2, 230),    # sub_dim 18 -> 24
     (901, 44, 2, 256),     # sub_dim 22 -> 24; the last row's last sub-vector ends the buffer
     (1200, 100, 10, 200),  # sub_dim 10 with k = 200: the padded variant's image is filled up to 8 tiles
-    (1250, 30, 3, 128),    # sub_dim 10 with k <= 128: no padded variant, exact engine
-    (1300, 30, 3, 129),    # ... and the first k that has one
+    (1250, 30, 3, 128),    # sub_dim 10 with 64 < k <= 128: the 4-tile padded variant
+    (1300, 30, 3, 129),    # ... and the first k of the 8-tile one
+    (1200, 30, 3, 64),     # k <= 64: exact engine
+    (1100, 90, 3, 100),    # sub_dim 30 -> 32, one group of 4 tiles
+    (1000, 100, 2, 70),    # sub_dim 50 -> 64, two groups of 2 tiles
     (1500, 35, 5, 256),    # sub_dim 7 -> 8 (odd: single-float parts, rows 4-byte aligned only)
     (1400, 45, 3, 256),    # sub_dim 15 -> 16 (300 = 20 x 15)
     (1200, 63, 3, 250),    # sub_dim 21 -> 24

@@ -1847,9 +1847,14 @@ void screen_bf16_x32_tiling(uint32_t sd_real, uint32_t k, uint32_t *nt32_per_gro
         return;
     }
     if (sd != sd_real) {
-        // padded variants exist for the full 8-tile image only: smaller codebooks are padded with never-winning
-        // centroids up to 256 as long as that costs at most twice the useful work
-        if (k <= 128 || k > 256) return;
+        // padded variants exist for images of 8 and of 4 tiles: smaller codebooks are filled up with never-winning
+        // centroids as long as that costs at most twice the useful work
+        if (k <= 64 || k > 256) return;
+        if (k <= 128) {  // 4 tiles in all
+            *nt32_per_group = (sd <= 32) ? 4 : 2;
+            *groups = 4 / *nt32_per_group;
+            return;
+        }
         *nt32_per_group = (sd <= 24) ? 8 : (sd == 32) ? 4 : 2;  // 8 tiles in all: 1, 2 or 4 centroid groups
         *groups = 8 / *nt32_per_group;
         return;
@@ -1978,6 +1983,8 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
     }
                 VQ_X32P(8, 8, 1) VQ_X32P(12, 8, 1) VQ_X32P(16, 8, 1) VQ_X32P(24, 8, 1)
                 VQ_X32P(32, 4, 2) VQ_X32P(48, 2, 4) VQ_X32P(64, 2, 4)
+                VQ_X32P(8, 4, 1) VQ_X32P(12, 4, 1) VQ_X32P(16, 4, 1) VQ_X32P(24, 4, 1)  // 64 < k <= 128
+                VQ_X32P(32, 4, 1) VQ_X32P(48, 2, 2) VQ_X32P(64, 2, 2)
 #undef VQ_X32P
                 return fail(VQHIP_ERR_UNSUPPORTED, "no padded bf16 screen for sub_dim=%u tiles=%u groups=%u", cb.sd, nt32, groups);
             }
