@@ -226,8 +226,10 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
                                                        const int32_t *__restrict__ right, int euclid,
                                                        const int32_t *__restrict__ slot_node,
                                                        const uint2 *__restrict__ wl,
-                                                       const uint32_t *__restrict__ wl_count,
+                                                       const uint32_t *__restrict__ wl_count, uint32_t d_real,
                                                        int32_t *__restrict__ leaf_out) {
+    // d_real <= D: rows and centroids are d_real floats long; the pieces behind it count as zeros (a zero term
+    // leaves a running sum that already holds a real term unchanged, so the reference's bits are kept)
     constexpr int NQ = (D >= 64) ? D / 64 : 1;  // chunks of 16 lanes x V floats
     constexpr int V = D / NQ / 16;              // 2 (D = 32) or 4
     const uint32_t count = *wl_count;
@@ -238,23 +240,36 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
         const uint32_t e = e0 + slot;
         const bool valid = e < count;
         const uint2 ent = valid ? wl[e] : make_uint2(0u, 0u);
-        const float *px = X + (size_t)ent.x * D + j * V;
+        const float *px = X + (size_t)ent.x * d_real;
         float x[NQ][V];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) load_piece<V>(px + q * 16 * V, x[q]);
+        for (int q = 0; q < NQ; ++q) {
+            const uint32_t off = q * 16 * V + j * V;
+            load_piece<V>(px + (off < d_real ? off : 0u), x[q]);
+            if (off >= d_real) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) x[q][v] = 0.0f;
+            }
+        }
         int32_t node = valid ? slot_node[ent.y] : 0;
         bool walking = valid;
         while (__any(walking)) {
             const int32_t l = left[node], r = right[node];
             const bool both = (l >= 0) && (r >= 0);
-            const float *pl = centroids + (size_t)(both ? l : 0) * D + j * V;
-            const float *pr = centroids + (size_t)(both ? r : 0) * D + j * V;
+            const float *pl = centroids + (size_t)(both ? l : 0) * d_real;
+            const float *pr = centroids + (size_t)(both ? r : 0) * d_real;
             float s1[NQ][V], s2[NQ][V];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 float cl[V], cr[V];
-                load_piece<V>(pl + q * 16 * V, cl);
-                load_piece<V>(pr + q * 16 * V, cr);
+                const uint32_t off = q * 16 * V + j * V;
+                const bool live = off < d_real;
+                load_piece<V>(pl + (live ? off : 0u), cl);
+                load_piece<V>(pr + (live ? off : 0u), cr);
+                if (!live) {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) cl[v] = cr[v] = 0.0f;
+                }
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
                     const float d1 = x[q][v] - cl[v], d2 = x[q][v] - cr[v];
@@ -344,9 +359,9 @@ __global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restri
 
 template <int D>
 static int launch_continue(const float *X, const float *centroids, const int32_t *left, const int32_t *right,
-                           int euclid, const TsvqScreen &s, int32_t *leaf, hipStream_t stream) {
+                           int euclid, const TsvqScreen &s, int32_t *leaf, hipStream_t stream, uint32_t d_real) {
     hipLaunchKernelGGL(k_tsvq_continue<D>, dim3(1024), dim3(256), 0, stream, X, centroids, left, right, euclid,
-                       s.slot_node, s.wl, s.wl_count, leaf);
+                       s.slot_node, s.wl, s.wl_count, d_real, leaf);
     VQ_LAUNCH_CHECK("k_tsvq_continue");
     return VQHIP_OK;
 }
@@ -404,7 +419,7 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
 #define VQ_TSVQ_D(DV)                                                                              \
     case DV:                                                                                       \
         VQ_TRY((launch_screen<DV, 8>(X, n, d, s, stream, leaf)));                                  \
-        if (d == DV) VQ_TRY(launch_continue<DV>(X, centroids, left, right, euclid, s, leaf, stream)); \
+        if (DV >= 64 || d == DV) VQ_TRY(launch_continue<DV>(X, centroids, left, right, euclid, s, leaf, stream, d)); \
         break;
     switch (dp) {
         VQ_TSVQ_D(32) VQ_TSVQ_D(64) VQ_TSVQ_D(128) VQ_TSVQ_D(192) VQ_TSVQ_D(256)
@@ -412,7 +427,7 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
     default: return fail(VQHIP_ERR_UNSUPPORTED, "screened TSVQ descent: d=%u", d);
     }
 #undef VQ_TSVQ_D
-    if (d != dp) {  // padded width: the undecided rows resume in the run-time-length kernel
+    if (d != dp && dp < 64) {  // d < 32 (8-byte pieces in k_tsvq_continue): the run-time-length kernel
         hipLaunchKernelGGL(k_tsvq_continue_any, dim3(256), dim3(256), 0, stream, X, d, centroids, left, right, euclid,
                            s.slot_node, s.wl, s.wl_count, leaf);
         VQ_LAUNCH_CHECK("k_tsvq_continue_any");
