@@ -238,7 +238,7 @@ int vqhip_tsvq_encode(vqhip_tsvq *t, const float *rows, uint64_t n, int32_t *lea
 int vqhip_tsvq_encode_device(vqhip_tsvq *t, const void *dev_rows, uint64_t n, void *dev_leaf,
                              void *dev_f16_out);
 /* diagnostics of the last encode on this tree: *screened = 1 if the screened descent ran
- * (squared-L2 / Euclidean, d a multiple of 4 up to 768), *undecided = rows
+ * (squared-L2 / Euclidean, d a multiple of 4 up to 1024), *undecided = rows
  * handed to the exact continuation.  Synchronises the stream. */
 int vqhip_tsvq_last_stats(vqhip_tsvq *t, int *screened, uint64_t *undecided);
 

@@ -90,7 +90,8 @@ def test_descent_bit_identical(oracle, metric, kind):
 @pytest.mark.parametrize("kind", ["uniform", "normal", "lattice", "structured"])
 @pytest.mark.parametrize("shape", [(6000, 32, 9), (5000, 64, 7), (6000, 128, 8), (3000, 256, 5), (400, 128, 12),
                                    (3000, 384, 5), (2500, 192, 6), (2000, 512, 4), (2000, 768, 5),  # 384: the reference's eval
-                                   (5000, 100, 7), (4000, 300, 5), (3000, 20, 6), (3000, 200, 6), (2000, 4, 5)])  # zero-padded widths
+                                   (5000, 100, 7), (4000, 300, 5), (3000, 20, 6), (3000, 200, 6), (2000, 4, 5),  # zero-padded widths
+                                   (1500, 1024, 4), (1200, 1000, 5)])  # 1024 wide
 def test_screened_descent_bit_identical(oracle, metric, kind, shape):
     """Squared-L2 / Euclidean descent with d in {32,64,128,192,256,384,512,768}: one dot product per level decides
     the rows whose margin is provable, the rest resume from their node in exact arithmetic."""

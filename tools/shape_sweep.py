@@ -69,7 +69,7 @@ if __name__ == "__main__":
                          (1_000_000, 2, 1, 256), (1_000_000, 128, 1, 256)):
         for metric in (0, 3):
             pq_case(n, d, m, k, metric)
-    for (n, d, depth) in ((1_000_000, 128, 8), (1_000_000, 100, 8), (500_000, 384, 6), (1_000_000, 384, 5), (200_000, 768, 6), (200_000, 768, 5), (1_000_000, 7, 10),
+    for (n, d, depth) in ((1_000_000, 128, 8), (1_000_000, 100, 8), (500_000, 384, 6), (1_000_000, 384, 5), (200_000, 768, 6), (200_000, 768, 5), (100_000, 1024, 5), (1_000_000, 7, 10),
                           (1_000_000, 128, 12), (100_000, 128, 8)):
         for name in ("squared_euclidean", "cosine"):
             tsvq_case(n, d, depth, name)

@@ -396,7 +396,7 @@ size_t tsvq_screen_lds_bytes(uint32_t n_int, uint32_t n_nodes, uint32_t d) {
 // instantiated width that serves dimension d: d itself, or the next width up for other multiples of 4 (zero padding)
 uint32_t tsvq_screen_width(uint32_t d) {
     if (d == 0 || d % 4 != 0) return 0;
-    for (uint32_t w : {32u, 64u, 128u, 192u, 256u, 384u, 512u, 768u})
+    for (uint32_t w : {32u, 64u, 128u, 192u, 256u, 384u, 512u, 768u, 1024u})
         if (d <= w) return w;
     return 0;
 }
@@ -423,7 +423,7 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
         break;
     switch (dp) {
         VQ_TSVQ_D(32) VQ_TSVQ_D(64) VQ_TSVQ_D(128) VQ_TSVQ_D(192) VQ_TSVQ_D(256)
-        VQ_TSVQ_D(384) VQ_TSVQ_D(512) VQ_TSVQ_D(768)  // embedding widths (the reference's eval: 384)
+        VQ_TSVQ_D(384) VQ_TSVQ_D(512) VQ_TSVQ_D(768) VQ_TSVQ_D(1024)  // embedding widths (the reference's eval: 384)
     default: return fail(VQHIP_ERR_UNSUPPORTED, "screened TSVQ descent: d=%u", d);
     }
 #undef VQ_TSVQ_D
