@@ -179,6 +179,11 @@ CONFIGS = {
     "C2_k1024": lambda: pq_config("C2_k1024", 1_000_000, 128, 8, 1024, "l2", iters=3, encode_reps=3),
     "C2_k1024_exact": lambda: pq_config("C2_k1024_exact", 1_000_000, 128, 8, 1024, "l2", iters=3, encode_reps=3, engine=1),
     "C2_k4096": lambda: pq_config("C2_k4096", 1_000_000, 128, 8, 4096, "l2", iters=2, encode_reps=2),
+    # shapes off the BASELINE list that exercise the padded / wide screens and the wider TSVQ descents
+    "W100": lambda: pq_config("W100_1Mx100_m10", 1_000_000, 100, 10, 256, "l2", iters=3, encode_reps=3),
+    "W300": lambda: pq_config("W300_1Mx300_m10", 1_000_000, 300, 10, 256, "l2", iters=3, encode_reps=3),
+    "LBG128": lambda: pq_config("LBG128_1Mx128_m1", 1_000_000, 128, 1, 256, "l2", iters=3, encode_reps=3),
+    "T384": lambda: tsvq_config("T384_eval_shape_depth5", 1_000_000, 384, 5),
     "ADC": lambda: adc_config("ADC_C2", 1_000_000, 128, 8, 256, 64, 10),
     "E": lambda: pq_config("E_eval_shape", 1_000_000, 384, 16, 256, "euclidean", iters=5, encode_reps=3),
 }
