@@ -89,6 +89,11 @@ int vqhip_synchronize(void);
  * budget 32; *trusted = 1 iff both ratios are <= 16, otherwise ENGINE_AUTO uses the fp32 MFMA
  * screen and ENGINE_MFMA_BF16 is refused.  Any out-pointer may be NULL. */
 int vqhip_selftest(float *bf16_32x32x16_ratio, float *bf16_16x16x32_ratio, int *bf16_engine_trusted);
+/* Diagnostics: d[t] = the f32 result of ONE v_mfma_f32_32x32x16_bf16 for the dot product of the bf16
+ * vectors a[t][0..16) and b[t][0..16) (raw bf16 bit patterns) added to c[t] -- the instruction the
+ * screen's contraction runs on.  tests/ hold a bit-exact software model of its adder against this
+ * entry point (DESIGN.md "screen soundness").  Host buffers. */
+int vqhip_mfma_bf16_probe(const uint16_t *a, const uint16_t *b, const float *c, uint64_t trials, float *d);
 /* statistics of the most recent assign/encode launch of this thread: rows sent to the
  * exact re-check, and the engine used (VQHIP_ENGINE_EXACT / _MFMA) */
 int vqhip_last_assign_stats(uint64_t *rechecked, int *engine);
@@ -173,6 +178,43 @@ int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed);
 int vqhip_kmeans_accumulate(vqhip_kmeans *km);
 int vqhip_kmeans_partials(vqhip_kmeans *km, void **dev_slab, uint64_t *n_doubles);
 int vqhip_kmeans_finalize(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed);
+
+/* ---- row-sharded training over the GPUs of one node (RCCL over xGMI, below this ABI) ----------
+ * Generalises the reference's only parallel loop (rayon over rows in the assignment step,
+ * src/core/vector.rs:417-423): one process (or thread) per GPU holds a contiguous block of rows as
+ * its vqhip_dataset and runs the SAME sequence of calls; each Lloyd iteration exchanges exactly one
+ * buffer -- the f64 slab [m][k][d/m+1] of per-cluster sums and counts -- with ncclAllReduce(sum) on
+ * the calling thread's stream, after which every rank computes identical means and `changed` flags.
+ *   comm_unique_id : ncclGetUniqueId; rank 0 calls it, the host program hands the 128 bytes to the
+ *                    other ranks (environment, file, socket: the library does not care)
+ *   comm_create    : ncclCommInitRank on the calling thread's current device; collective over the
+ *                    ranks.  id == NULL with world == 1 makes a communicator whose collectives are
+ *                    the identity (RCCL is then not even loaded)
+ *   comm_adopt     : borrow a caller-owned ncclComm_t (e.g. the one a framework already holds)
+ * librccl is opened with dlopen at first use (VQHIP_RCCL_LIB overrides its path). */
+typedef struct vqhip_comm vqhip_comm;
+#define VQHIP_COMM_ID_BYTES 128
+int vqhip_comm_unique_id(uint8_t *id /* [VQHIP_COMM_ID_BYTES] out */);
+int vqhip_comm_create(const uint8_t *id, int world, int rank, vqhip_comm **out);
+int vqhip_comm_adopt(void *nccl_comm, vqhip_comm **out);
+int vqhip_comm_info(const vqhip_comm *comm, int *world, int *rank);
+int vqhip_comm_destroy(vqhip_comm *comm);
+/* in-place all-reduce of the slab between _accumulate and _finalize (NULL comm: no-op) */
+int vqhip_kmeans_allreduce(vqhip_kmeans *km, vqhip_comm *comm);
+/* = accumulate + allreduce + finalize: vqhip_kmeans_step for a sharded data set; counts are global */
+int vqhip_kmeans_step_sharded(vqhip_kmeans *km, vqhip_comm *comm, uint32_t *counts, uint8_t *changed);
+/* vqhip_kmeans_init_from_rows with GLOBAL row ids [m][k]: this rank owns rows [row_offset,
+ * row_offset + n); the owner of each row supplies its bits, one u32-sum all-reduce hands them to
+ * everyone (a float sum would lose the sign of -0.0) */
+int vqhip_kmeans_init_from_global_rows(vqhip_kmeans *km, vqhip_comm *comm, const uint64_t *global_rows,
+                                       uint64_t row_offset);
+/* vqhip_kmeans_patch_from_row with a GLOBAL row id (empty-cluster reseed, vector.rs:448-452) */
+int vqhip_kmeans_patch_from_global_row(vqhip_kmeans *km, vqhip_comm *comm, uint32_t s, uint32_t j,
+                                       uint64_t global_row, uint64_t row_offset);
+/* for hosts that run their own collective: bits_out [m][k][d/m] (host) = bit patterns of the owned
+ * rows among global_rows [m][k], zero words for rows of other ranks; ONE gather launch + ONE copy */
+int vqhip_kmeans_gather_owned_rows(vqhip_kmeans *km, const uint64_t *global_rows, uint64_t row_offset,
+                                   uint32_t *bits_out);
 
 /* empty-cluster reseed (vector.rs:448-452): the caller draws the row */
 int vqhip_kmeans_patch_centroid(vqhip_kmeans *km, uint32_t s, uint32_t j, const float *sub_row);

@@ -1,0 +1,136 @@
+"""ALL-ROWS oracle parity at BASELINE.json's full sizes.
+
+Every row of every configuration is compared with the CPU oracle (the restatement of
+src/pq.rs:177-196 and src/tsvq.rs:117-132), not a sample and not the library's own exact
+engine: the GPU box has 128 host threads, on which the OpenMP oracle encodes C2 in about a
+second.  Rows travel in chunks so host memory stays bounded (the C5 shard is 6.4 GB).
+
+  * C2  1M x 128,  m=8,  k=256, squared L2: codes + f16 reconstruction, and one full Lloyd
+        step (assignments, counts exact; centroids within the stated tolerance);
+  * C3  1M x 768,  m=96, k=256, cosine: codes;
+  * C5  one GPU's shard of the 8-GPU job, 12.5M x 128, m=16, k=256, squared L2: codes;
+  * C4  TSVQ depth 8 on 1M x 128: every leaf id and f16 reconstruction (tree equality is
+        held by tests/test_gpu_tsvq.py::test_config4_fullsize_depth8).
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from vq_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _trained_codebooks(ds, m, k, iters=2):
+    n = ds.n
+    km = _lib.KMeans(ds, m, k)
+    init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64)
+    km.init_from_rows(init)
+    for _ in range(iters):
+        km.step()
+    cb = km.get_centroids()
+    km.close()
+    return cb
+
+
+def _encode_all_rows_vs_oracle(oracle, n, d, m, k, metric, chunk, want_f16):
+    import torch
+
+    ds = _lib.Dataset.synthetic(n, d, seed=66)
+    cb = _trained_codebooks(ds, m, k)
+    enc = _lib.PQEncoder(cb, metric)
+    codes = torch.empty((n, m), dtype=torch.uint8, device="cuda")
+    f16 = torch.empty((n, d), dtype=torch.float16, device="cuda") if want_f16 else None
+    enc.encode_device(ds.device_ptr, n, codes.data_ptr(), f16.data_ptr() if want_f16 else None)
+    _lib.synchronize()
+    torch.cuda.synchronize()
+    rechecked, engine = _lib.last_assign_stats()
+    if metric != _lib.MANHATTAN:
+        assert engine == _lib.ENGINE_MFMA_BF16  # the path under test is the screened one
+    bad = 0
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        X = ds.read(r0, r1 - r0)
+        want, want16 = oracle.pq_encode(metric, X, cb, want_f16=want_f16, threads=0)
+        got = codes[r0:r1].cpu().numpy().astype(np.uint32)
+        bad += int((got != want).sum())
+        if want_f16:
+            got16 = f16[r0:r1].cpu().numpy().view(np.uint16)
+            bad += int((got16 != want16).sum())
+        del X, want, want16, got
+    enc.close()
+    ds.close()
+    assert bad == 0, f"{bad} codes / f16 values differ from the oracle over all {n} rows"
+    return rechecked
+
+
+def test_c2_all_rows_codes_and_f16(oracle):
+    """BASELINE configs[1]: every one of the 8M codes and 128M f16 values."""
+    r = _encode_all_rows_vs_oracle(oracle, 1_000_000, 128, 8, 256, _lib.SQUARED_EUCLIDEAN, 1_000_000, True)
+    assert r < 0.05 * 8_000_000
+
+
+def test_c2_all_rows_euclidean(oracle):
+    """the sqrt metric (Distance::Euclidean, the pyvq default) over all rows"""
+    _encode_all_rows_vs_oracle(oracle, 1_000_000, 128, 8, 256, _lib.EUCLIDEAN, 1_000_000, False)
+
+
+def test_c3_all_rows_cosine(oracle):
+    """BASELINE configs[2] at its full 1M x 768 (96M cosine codes)."""
+    _encode_all_rows_vs_oracle(oracle, 1_000_000, 768, 96, 256, _lib.COSINE, 250_000, False)
+
+
+def test_c5_shard_all_rows(oracle):
+    """BASELINE configs[4], the rows one of the 8 GPUs holds: 12.5M x 128, m=16 (200M codes)."""
+    _encode_all_rows_vs_oracle(oracle, 12_500_000, 128, 16, 256, _lib.SQUARED_EUCLIDEAN, 2_500_000, False)
+
+
+def test_c2_lloyd_step_all_rows(oracle):
+    """One full-size Lloyd iteration: all 8M training assignments and all counts equal the
+    oracle's (vector.rs:417-447); centroids within |d| <= 1e-5 max(1,|c|)."""
+    n, d, m, k = 1_000_000, 128, 8, 256
+    sd = d // m
+    ds = _lib.Dataset.synthetic(n, d, seed=66)
+    X = ds.read()
+    km = _lib.KMeans(ds, m, k)
+    init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64)
+    km.init_from_rows(init)
+    km.step()                      # move off the init rows so the second step is a generic one
+    c_in = km.get_centroids()
+    counts, changed = km.step()
+    assign = km.get_assignments()
+    c_out = km.get_centroids()
+    km.close()
+    ds.close()
+    for s in range(m):
+        c1, a_ref, n_ref, ch_ref = oracle.lloyd_step(X[:, s * sd:(s + 1) * sd], c_in[s], threads=0)
+        assert int((assign[:, s].astype(np.uint32) != a_ref).sum()) == 0
+        np.testing.assert_array_equal(counts[s], n_ref)
+        assert bool(changed[s]) == ch_ref
+        err = np.max(np.abs(c_out[s] - c1) / np.maximum(1.0, np.abs(c1)))
+        assert err <= 1e-5, f"subspace {s}: centroid deviation {err:g}"
+
+
+def test_c4_every_leaf(oracle):
+    """BASELINE configs[3]: every one of the 1M rows descends to the oracle's leaf and gets the
+    oracle's f16 reconstruction, for squared L2 and Euclidean (the screened descent) and
+    for cosine / Manhattan."""
+    from vq_amd import Distance, TSVQ
+
+    from vq_amd.tsvq import build_tree
+
+    n, d, depth = 1_000_000, 128, 8
+    ds = _lib.Dataset.synthetic(n, d, seed=66)
+    X = ds.read()
+    cent, left, right = build_tree(ds, depth)
+    ds.close()
+    tree = dict(centroids=cent, left=left, right=right)
+    for name, metric, f16 in (("squared_euclidean", O.SQUARED_EUCLIDEAN, True), ("euclidean", O.EUCLIDEAN, False),
+                              ("cosine", O.COSINE, False), ("manhattan", O.MANHATTAN, False)):
+        tq = TSVQ.from_tree(cent, left, right, Distance(name))
+        want_leaf, want16 = oracle.tsvq_encode(metric, X, tree, want_f16=f16, threads=0)
+        got = tq.leaf_ids(X)
+        assert int((got != want_leaf).sum()) == 0, name
+        if f16:
+            got16 = tq.quantize_batch(X).view(np.uint16)
+            assert int((got16 != want16).sum()) == 0

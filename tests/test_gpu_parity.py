@@ -196,7 +196,7 @@ def test_encode_l2_bit_exact(oracle, shape, kind, metric):
             _check_encode(oracle, X, cb, metric, _lib.ENGINE_MFMA)   # fp32 MFMA screen
         except _lib.FfiError as e:  # e.g. sub_dim 32 at k = 256: its A image exceeds the register budget
             assert "unavailable" in str(e)
-    if d // m in (4, 8, 12, 16, 24, 32, 48, 64):
+    if d // m in (8, 12, 16, 24, 32, 48, 64):  # (sub_dim 4: fp32 MFMA screen; the 16x16 bf16 variants left in round 2)
         _check_encode(oracle, X, cb, metric, _lib.ENGINE_MFMA_BF16)  # bf16-split screen
         assert _check_encode.last_stats[1] == _lib.ENGINE_MFMA_BF16
 

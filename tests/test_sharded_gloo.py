@@ -42,8 +42,18 @@ class OracleShard:
     def init_from_values(self, c):
         self.cent = np.array(c, F).reshape(self.m, self.k, self.sd)
 
-    def local_sub_row(self, s, global_row):
-        return self.X[global_row - self.row_offset, s * self.sd:(s + 1) * self.sd]
+    def owned_bits(self, rows):
+        out = np.zeros((self.m, self.k, self.sd), np.uint32)
+        for s in range(self.m):
+            for j in range(self.k):
+                out[s, j] = self.owned_sub_row_bits(s, int(rows[s, j]))
+        return out
+
+    def owned_sub_row_bits(self, s, global_row):
+        r = global_row - self.row_offset
+        if not 0 <= r < self.n_local:
+            return np.zeros(self.sd, np.uint32)
+        return self.X[r, s * self.sd:(s + 1) * self.sd].view(np.uint32).copy()
 
     def accumulate(self):
         slab = np.zeros((self.m, self.k, self.sd + 1), np.float64)
@@ -95,6 +105,42 @@ def _make_data():
     X = rng.random((601, 8), dtype=F)  # odd row count: uneven shards
     X[10] = X[3]  # duplicate rows -> a cluster that can never win -> forced reseed
     return X
+
+
+def _make_data4():
+    """world_size 4: 603 rows (shards of 151, 151, 151, 150), three duplicated init rows per
+    subspace (several reseeds in one iteration, drawn from different owners) and a -0.0 that
+    must survive the integer transport of an init row"""
+    rng = np.random.default_rng(321)
+    X = rng.random((603, 8), dtype=F)
+    X[10] = X[3]
+    X[400] = X[3]
+    X[599] = X[5]
+    X[100, 2] = F(-0.0)
+    return X
+
+
+INIT4 = np.array([[3, 10, 400, 100, 300, 602], [5, 599, 50, 150, 250, 451]])
+RESEED4 = [[7, 160, 320, 470, 8, 161, 321, 471, 9, 162], [11, 170, 330, 480, 12, 171, 331, 481, 13, 172]]
+
+
+def _worker4(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X = _make_data4()
+        n, m, k = X.shape[0], 2, 6
+        off, cnt = shard_rows(n, world, rank)
+        shard = OracleShard(X[off:off + cnt], m, k, off)
+        skm = ShardedKMeans(shard, n, Comm())
+        skm.init_from_global_rows(INIT4)
+        np.save(os.path.join(out_dir, f"init_{rank}.npy"), shard.get_centroids())
+        cb = skm.fit(7, seed=1, init_rows=INIT4, reseed_rows=RESEED4)
+        np.save(os.path.join(out_dir, f"cb_{rank}.npy"), cb)
+        np.save(os.path.join(out_dir, f"iters_{rank}.npy"), skm.iters)
+    finally:
+        dist.destroy_process_group()
 
 
 def _worker(rank, world, port, out_dir):
@@ -152,6 +198,34 @@ def test_two_rank_fit_equals_single_process_reference(tmp_path):
     cb_ref, it_ref = O.get().pq_fit(X, 2, 5, 6, init, reseed_rows=reseed)
     assert it0.tolist() == it_ref.tolist()
     assert np.max(np.abs(cb0 - cb_ref)) <= 1e-5
+
+
+@pytest.mark.timeout(300)
+def test_four_rank_uneven_shards_multi_reseed(tmp_path):
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker4, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    cbs = [np.load(tmp_path / f"cb_{r}.npy") for r in range(4)]
+    its = [np.load(tmp_path / f"iters_{r}.npy") for r in range(4)]
+    inits = [np.load(tmp_path / f"init_{r}.npy") for r in range(4)]
+    for r in range(1, 4):
+        assert cbs[r].tobytes() == cbs[0].tobytes()
+        np.testing.assert_array_equal(its[r], its[0])
+        assert inits[r].tobytes() == inits[0].tobytes()
+    X = _make_data4()
+    # the gathered init rows are the rows' own bits (incl. the sign of -0.0), whoever owns them
+    for s in range(2):
+        want = X[INIT4[s], s * 4:(s + 1) * 4]
+        assert inits[0][s].tobytes() == want.tobytes()
+    assert np.signbit(inits[0][0, 3, 2])  # row 100, column 2 = -0.0
+    import oracle as O
+
+    cb_ref, it_ref = O.get().pq_fit(X, 2, 6, 7, INIT4.astype(np.uint64), reseed_rows=np.array(RESEED4, np.uint64))
+    assert its[0].tolist() == it_ref.tolist()
+    assert np.max(np.abs(cbs[0] - cb_ref)) <= 1e-5
 
 
 def test_single_process_comm_is_noop():

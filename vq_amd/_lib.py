@@ -64,6 +64,16 @@ SIGNATURES = {
     "vqhip_kmeans_accumulate": (C.c_int, [_vp]),
     "vqhip_kmeans_partials": (C.c_int, [_vp, _vpp, _u64p]),
     "vqhip_kmeans_finalize": (C.c_int, [_vp, _u32p, _u8p]),
+    "vqhip_comm_unique_id": (C.c_int, [_u8p]),
+    "vqhip_comm_create": (C.c_int, [_u8p, C.c_int, C.c_int, _vpp]),
+    "vqhip_comm_adopt": (C.c_int, [_vp, _vpp]),
+    "vqhip_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vqhip_comm_destroy": (C.c_int, [_vp]),
+    "vqhip_kmeans_allreduce": (C.c_int, [_vp, _vp]),
+    "vqhip_kmeans_step_sharded": (C.c_int, [_vp, _vp, _u32p, _u8p]),
+    "vqhip_kmeans_init_from_global_rows": (C.c_int, [_vp, _vp, _u64p, C.c_uint64]),
+    "vqhip_kmeans_patch_from_global_row": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "vqhip_kmeans_gather_owned_rows": (C.c_int, [_vp, _u64p, C.c_uint64, _u32p]),
     "vqhip_kmeans_patch_centroid": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _f32p]),
     "vqhip_kmeans_patch_from_row": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint64]),
     "vqhip_kmeans_get_assignments": (C.c_int, [_vp, _u8p]),
@@ -83,6 +93,7 @@ SIGNATURES = {
     "vqhip_pq_adc_search": (C.c_int, [_vp, _u8p, C.c_uint64, _f32p, C.c_uint32, C.c_uint32, _u32p, _f32p]),
     "vqhip_pq_adc_search_device": (C.c_int, [_vp, _vp, C.c_uint64, _f32p, C.c_uint32, C.c_uint32, _u32p, _f32p]),
     "vqhip_selftest": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "vqhip_mfma_bf16_probe": (C.c_int, [_u16p, _u16p, _f32p, C.c_uint64, _f32p]),
     "vqhip_tsvq_last_stats": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
 }
 
@@ -267,6 +278,33 @@ class KMeans(Handle):
         check(load().vqhip_kmeans_finalize(self.raw, ptr(counts, _u32p), ptr(changed, _u8p)))
         return counts, changed.astype(bool)
 
+    # -- row-sharded training (RCCL below the ABI) ------------------------------------------
+    def allreduce(self, comm: "NativeComm | None"):
+        check(load().vqhip_kmeans_allreduce(self.raw, comm.raw if comm is not None else None))
+
+    def step_sharded(self, comm: "NativeComm | None"):
+        counts = np.empty((self.m, self.k), np.uint32)
+        changed = np.empty(self.m, np.uint8)
+        check(load().vqhip_kmeans_step_sharded(self.raw, comm.raw if comm is not None else None,
+                                               ptr(counts, _u32p), ptr(changed, _u8p)))
+        return counts, changed.astype(bool)
+
+    def init_from_global_rows(self, comm: "NativeComm | None", rows, row_offset: int):
+        r = np.ascontiguousarray(rows, dtype=np.uint64).reshape(self.m, self.k)
+        check(load().vqhip_kmeans_init_from_global_rows(self.raw, comm.raw if comm is not None else None,
+                                                        ptr(r, _u64p), int(row_offset)))
+
+    def patch_from_global_row(self, comm: "NativeComm | None", s: int, j: int, global_row: int, row_offset: int):
+        check(load().vqhip_kmeans_patch_from_global_row(self.raw, comm.raw if comm is not None else None,
+                                                        int(s), int(j), int(global_row), int(row_offset)))
+
+    def gather_owned_rows(self, rows, row_offset: int) -> np.ndarray:
+        """uint32 bit patterns [m][k][sd] of the owned rows among global ids `rows`, zeros elsewhere"""
+        r = np.ascontiguousarray(rows, dtype=np.uint64).reshape(self.m, self.k)
+        out = np.empty((self.m, self.k, self.sd), np.uint32)
+        check(load().vqhip_kmeans_gather_owned_rows(self.raw, ptr(r, _u64p), int(row_offset), ptr(out, _u32p)))
+        return out
+
     def patch_centroid(self, s: int, j: int, sub_row):
         r = f32c(sub_row).reshape(self.sd)
         check(load().vqhip_kmeans_patch_centroid(self.raw, s, j, ptr(r, _f32p)))
@@ -278,6 +316,32 @@ class KMeans(Handle):
         out = np.empty((self.ds.n, self.m), code_dtype(self.k))
         check(load().vqhip_kmeans_get_assignments(self.raw, ptr(out, _u8p)))
         return out
+
+
+class NativeComm(Handle):
+    """vqhip_comm: an RCCL communicator below the C ABI (one rank per GPU).  `uid` is the 128-byte id
+    rank 0 obtained from ``NativeComm.unique_id()``; world == 1 with uid None is the identity."""
+
+    _destroy = "vqhip_comm_destroy"
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * NativeComm.ID_BYTES)()
+        check(load().vqhip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, uid: bytes | None, world: int, rank: int):
+        h = C.c_void_p()
+        if uid is not None:
+            if len(uid) != self.ID_BYTES:
+                raise FfiError("the RCCL unique id is 128 bytes", ERR_INVALID_INPUT)
+            buf = (C.c_uint8 * self.ID_BYTES).from_buffer_copy(uid)
+            check(load().vqhip_comm_create(buf, int(world), int(rank), C.byref(h)))
+        else:
+            check(load().vqhip_comm_create(None, int(world), int(rank), C.byref(h)))
+        super().__init__(h)
+        self.world, self.rank = int(world), int(rank)
 
 
 class PQEncoder(Handle):
@@ -360,6 +424,17 @@ def selftest():
     a, b, t = C.c_float(0), C.c_float(0), C.c_int(0)
     check(load().vqhip_selftest(C.byref(a), C.byref(b), C.byref(t)))
     return float(a.value), float(b.value), bool(t.value)
+
+
+def mfma_bf16_probe(a_bits, b_bits, c) -> np.ndarray:
+    """d[t] of one v_mfma_f32_32x32x16_bf16 per trial: a_bits, b_bits uint16 [t][16], c float32 [t]"""
+    a = np.ascontiguousarray(a_bits, np.uint16).reshape(-1, 16)
+    b = np.ascontiguousarray(b_bits, np.uint16).reshape(-1, 16)
+    cc = np.ascontiguousarray(c, np.float32).reshape(-1)
+    assert a.shape == b.shape and a.shape[0] == cc.shape[0]
+    d = np.empty(cc.shape[0], np.float32)
+    check(load().vqhip_mfma_bf16_probe(ptr(a, _u16p), ptr(b, _u16p), ptr(cc, _f32p), cc.shape[0], ptr(d, _f32p)))
+    return d
 
 
 def synchronize():

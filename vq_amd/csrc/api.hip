@@ -84,10 +84,10 @@ int current_stream(hipStream_t *out) {
 // ------------------------------------------------------------------ codebook state ----
 struct CodebookState {
     uint32_t m = 0, k = 0, sd = 0, nt = 0, ks = 0;
-    bool mfma_ok = false, bf16_ok = false, bf16_16 = false;
+    bool mfma_ok = false, bf16_ok = false;
     bool prepared = false;
     int metric = VQHIP_SQUARED_EUCLIDEAN;  // what the prepared images are for (cosine differs)
-    DevBuf cb, prepA, prepCn, meta, cnsqrt, prepA16, prepA32, cbc, cen, cn32;
+    DevBuf cb, prepA, prepCn, meta, cnsqrt, prepA32, cbc, cen, cn32;
     bool x32_ok = false;
     uint32_t x32_groups = 0;  // > 1: centroid groups (sub_dim 32 / 48), partial verdicts merged per row
 
@@ -95,6 +95,10 @@ struct CodebookState {
         m = m_;
         k = k_;
         sd = sd_;
+        // the update / gather / prepare kernels index a codebook's m*k*(sub_dim+1) elements with 32 bits
+        if ((uint64_t)m * k * ((uint64_t)sd + 1) >= (1ull << 32))
+            return fail(VQHIP_ERR_UNSUPPORTED, "m*k*(sub_dim+1) = %llu exceeds 2^32-1 codebook elements",
+                        (unsigned long long)((uint64_t)m * k * ((uint64_t)sd + 1)));
         mfma_ok = screen_supported(sd, k);
         VQ_TRY(cb.alloc((size_t)m * k * sd * 4));
         VQ_TRY(cnsqrt.alloc((size_t)m * k * 4));
@@ -105,16 +109,15 @@ struct CodebookState {
             VQ_TRY(prepA.alloc((size_t)m * nt * ks * 64 * 4));
             VQ_TRY(prepCn.alloc((size_t)m * nt * 16 * 4));
         }
-        // bf16 engines (16x16 variants share the fp32 engine's tiling; X32 has its own shapes, e.g. sub_dim 24)
-        bf16_16 = mfma_ok && screen_bf16_supported(sd, k);
+        // bf16 engine (X32 kernels; their own tilings, e.g. sub_dim 24): only on a device whose bf16 MFMA
+        // matches the accumulation model the margin is derived from (k_selftest.hip)
         x32_ok = screen_bf16_x32_supported(sd, k);
-        if (bf16_16 || x32_ok) {  // only on a device whose bf16 MFMA passed the accumulation self-test
+        if (x32_ok) {
             int trusted = 0;
             VQ_TRY(bf16_mfma_selftest(nullptr, nullptr, &trusted));
-            if (!trusted) bf16_16 = x32_ok = false;
+            if (!trusted) x32_ok = false;
         }
-        bf16_ok = bf16_16 || x32_ok;
-        if (bf16_16) VQ_TRY(prepA16.alloc((size_t)m * nt * screen_bf16_mfmas(sd) * 4 * 64 * 4));
+        bf16_ok = x32_ok;
         x32_groups = 0;
         if (x32_ok) {
             uint32_t per = 0;
@@ -141,7 +144,6 @@ struct CodebookState {
         v.prepCn = mfma_ok ? prepCn.as<float>() : nullptr;
         v.meta = meta.as<float>();
         v.cnsqrt = cnsqrt.as<float>();
-        v.prepA16 = bf16_16 ? prepA16.as<uint32_t>() : nullptr;
         v.prepA32 = x32_ok ? prepA32.as<uint32_t>() : nullptr;
         v.cen = x32_ok ? cen.as<float>() : nullptr;
         v.cn32 = x32_ok ? cn32.as<float>() : nullptr;
@@ -153,9 +155,7 @@ struct CodebookState {
         VQ_TRY(launch_prepare_codebook(v, mfma_ok ? prepA.as<float>() : nullptr,
                                        mfma_ok ? prepCn.as<float>() : nullptr, meta.as<float>(),
                                        cnsqrt.as<float>(), stream));
-        const bool use32 = x32_ok && screen_bf16_uses_x32(sd, k);
-        if (bf16_16 && !use32) VQ_TRY(launch_prepare_bf16(v, prepA16.as<uint32_t>(), stream));
-        if (use32)
+        if (x32_ok)
             VQ_TRY(launch_prepare_bf16_x32(v, prepA32.as<uint32_t>(), metric == VQHIP_COSINE ? 1 : 0, cbc.as<float>(),
                                            cen.as<float>(), cn32.as<float>(), stream));
         prepared = true;
@@ -224,8 +224,7 @@ static thread_local ProfileState g_prof;
 static int pick_engine(int requested, const CodebookState &cs, int metric, int *engine) {
     const bool l2_metric = (metric == VQHIP_SQUARED_EUCLIDEAN || metric == VQHIP_EUCLIDEAN);
     // cosine has a screen too (s = -x.c/|c| on the X32 bf16 engine); Manhattan has no contraction form
-    const bool cos_ok = (metric == VQHIP_COSINE) && cs.x32_ok && screen_bf16_uses_x32(cs.sd, cs.k) &&
-                        cs.metric == VQHIP_COSINE;
+    const bool cos_ok = (metric == VQHIP_COSINE) && cs.x32_ok && cs.metric == VQHIP_COSINE;
     if (requested == VQHIP_ENGINE_EXACT) {
         *engine = VQHIP_ENGINE_EXACT;
     } else if (requested == VQHIP_ENGINE_MFMA) {
@@ -281,8 +280,7 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
     a.wl_seg = ws.wl_seg.as<uint32_t>();
     a.wl_seg_cap = AssignWorkspace::kSegCap;
     a.n_seg = 0;
-    if (engine == VQHIP_ENGINE_MFMA_BF16 && (cs.x32_groups > 1 || x32_padded_sd(cs.sd) > 64) &&
-        screen_bf16_uses_x32(cs.sd, cs.k)) {  // (the wide kernel goes through the partial verdicts even with one group)
+    if (engine == VQHIP_ENGINE_MFMA_BF16 && (cs.x32_groups > 1 || x32_padded_sd(cs.sd) > 64)) {  // (the wide kernel goes through the partial verdicts even with one group)
         VQ_TRY(ws.part.ensure((size_t)cs.m * cs.x32_groups * n * 16));
         a.part = ws.part.p;
     }
@@ -345,7 +343,7 @@ struct vqhip_kmeans {
     CodebookState cs;
     AssignWorkspace ws;
     UpdatePlan plan;
-    DevBuf codes, partial_sums, partial_counts, slab, counts, changed, active_dev, rows_tmp, xs_ws;
+    DevBuf codes, partial_sums, partial_counts, slab, counts, changed, active_dev, rows_tmp, xs_ws, gather_ws;
     std::vector<uint8_t> active;
     bool all_active = true;
     int engine = VQHIP_ENGINE_AUTO;
@@ -368,6 +366,10 @@ struct vqhip_kmeans {
         if (counts_host) (void)hipHostFree(counts_host);
         if (changed_host) (void)hipHostFree(changed_host);
     }
+};
+
+struct vqhip_comm {
+    Comm *c = nullptr;
 };
 
 // Pinned, device-mapped staging for the per-vector latency path (k_small.hip)
@@ -570,6 +572,14 @@ int vqhip_selftest(float *bf16_32x32x16_ratio, float *bf16_16x16x32_ratio, int *
     VQ_API_BEGIN
     VQ_TRY(require_gfx950());
     return bf16_mfma_selftest(bf16_32x32x16_ratio, bf16_16x16x32_ratio, bf16_engine_trusted);
+    VQ_API_END
+}
+
+int vqhip_mfma_bf16_probe(const uint16_t *a, const uint16_t *b, const float *c, uint64_t trials, float *d) {
+    VQ_API_BEGIN
+    if (trials && (!a || !b || !c || !d)) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    VQ_TRY(require_gfx950());
+    return mfma_bf16_probe(a, b, c, trials, d);
     VQ_API_END
 }
 
@@ -1036,6 +1046,142 @@ int vqhip_kmeans_get_assignments(vqhip_kmeans *km, uint8_t *codes) {
     return VQHIP_OK;
 }
 
+// ------------------------------------------------- row-sharded training (RCCL below the ABI) ----
+int vqhip_comm_unique_id(uint8_t *id) {
+    VQ_API_BEGIN
+    if (!id) return fail(VQHIP_ERR_NULL_PTR, "id is NULL");
+    return comm_unique_id(id);
+    VQ_API_END
+}
+
+int vqhip_comm_create(const uint8_t *id, int world, int rank, vqhip_comm **out) {
+    VQ_API_BEGIN
+    if (!out) return fail(VQHIP_ERR_NULL_PTR, "out is NULL");
+    *out = nullptr;
+    if (world > 1 && !id) return fail(VQHIP_ERR_NULL_PTR, "a communicator of %d ranks needs the unique id", world);
+    if (id) VQ_TRY(require_gfx950());  // ncclCommInitRank binds the calling thread's current device
+    std::unique_ptr<vqhip_comm> h(new vqhip_comm());
+    VQ_TRY(comm_create(id, world, rank, &h->c));
+    *out = h.release();
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_comm_adopt(void *nccl_comm, vqhip_comm **out) {
+    VQ_API_BEGIN
+    if (!out || !nccl_comm) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    *out = nullptr;
+    std::unique_ptr<vqhip_comm> h(new vqhip_comm());
+    VQ_TRY(comm_adopt(nccl_comm, &h->c));
+    *out = h.release();
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_comm_info(const vqhip_comm *comm, int *world, int *rank) {
+    comm_info(comm ? comm->c : nullptr, world, rank);
+    return VQHIP_OK;
+}
+
+int vqhip_comm_destroy(vqhip_comm *comm) {
+    if (comm) {
+        (void)comm_destroy(comm->c);
+        delete comm;
+    }
+    return VQHIP_OK;
+}
+
+int vqhip_kmeans_allreduce(vqhip_kmeans *km, vqhip_comm *comm) {
+    VQ_API_BEGIN
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (!km->accumulated) return fail(VQHIP_ERR_INVALID_INPUT, "allreduce without a preceding accumulate");
+    int world = 1;
+    comm_info(comm ? comm->c : nullptr, &world, nullptr);
+    if (world > 1 && km->exact_update)
+        return fail(VQHIP_ERR_UNSUPPORTED, "exact_update sums rows in one sequential chain: single GPU only");
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    return comm_allreduce_f64(comm ? comm->c : nullptr, km->slab.as<double>(),
+                              (size_t)km->cs.m * km->cs.k * (km->cs.sd + 1), s);
+    VQ_API_END
+}
+
+int vqhip_kmeans_step_sharded(vqhip_kmeans *km, vqhip_comm *comm, uint32_t *counts, uint8_t *changed) {
+    VQ_API_BEGIN
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_TRY(kmeans_accumulate_enqueue(km, s));
+    VQ_TRY(vqhip_kmeans_allreduce(km, comm));
+    VQ_TRY(kmeans_finalize_enqueue(km, s));
+    VQ_TRY(spin_wait(s));
+    kmeans_finalize_collect(km, counts, changed);
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+// bits of the owned rows among `global_rows` [m][k] into xs_ws (device u32 [m][k][sd]); zeros elsewhere
+static int gather_owned_enqueue(vqhip_kmeans *km, const uint64_t *global_rows, uint64_t row_offset, hipStream_t s) {
+    const size_t cnt = (size_t)km->cs.m * km->cs.k;
+    VQ_TRY(km->gather_ws.ensure(cnt * km->cs.sd * 4));
+    VQ_HIP(hipMemcpyAsync(km->rows_tmp.p, global_rows, cnt * 8, hipMemcpyHostToDevice, s));
+    return launch_gather_rows_owned(km->ds->X, km->ds->d, km->cs.m, km->cs.k, km->cs.sd, km->rows_tmp.as<uint64_t>(),
+                                    row_offset, km->ds->n, km->gather_ws.as<uint32_t>(), s);
+}
+
+int vqhip_kmeans_gather_owned_rows(vqhip_kmeans *km, const uint64_t *global_rows, uint64_t row_offset, uint32_t *bits_out) {
+    VQ_API_BEGIN
+    if (!km || !global_rows || !bits_out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    VQ_TRY(gather_owned_enqueue(km, global_rows, row_offset, s));
+    VQ_HIP(hipMemcpyAsync(bits_out, km->gather_ws.p, (size_t)km->cs.m * km->cs.k * km->cs.sd * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_kmeans_init_from_global_rows(vqhip_kmeans *km, vqhip_comm *comm, const uint64_t *global_rows, uint64_t row_offset) {
+    VQ_API_BEGIN
+    if (!km || !global_rows) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    const size_t words = (size_t)km->cs.m * km->cs.k * km->cs.sd;
+    VQ_TRY(gather_owned_enqueue(km, global_rows, row_offset, s));
+    VQ_TRY(comm_allreduce_u32(comm ? comm->c : nullptr, km->gather_ws.as<uint32_t>(), words, s));
+    VQ_HIP(hipMemcpyAsync(km->cs.cb.p, km->gather_ws.p, words * 4, hipMemcpyDeviceToDevice, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    km->cs.prepared = false;
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_kmeans_patch_from_global_row(vqhip_kmeans *km, vqhip_comm *comm, uint32_t sub, uint32_t j, uint64_t global_row,
+                                       uint64_t row_offset) {
+    VQ_API_BEGIN
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (sub >= km->cs.m || j >= km->cs.k) return fail(VQHIP_ERR_INVALID_INPUT, "centroid (%u,%u) out of range", sub, j);
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    const uint32_t sd = km->cs.sd;
+    VQ_TRY(km->gather_ws.ensure((size_t)km->cs.m * km->cs.k * sd * 4));
+    VQ_HIP(hipMemcpyAsync(km->rows_tmp.p, &global_row, 8, hipMemcpyHostToDevice, s));
+    // one (subspace, cluster) pair: the kernel's subspace 0 is column block `sub` of the rows
+    VQ_TRY(launch_gather_rows_owned(km->ds->X + (size_t)sub * sd, km->ds->d, 1, 1, sd, km->rows_tmp.as<uint64_t>(),
+                                    row_offset, km->ds->n, km->gather_ws.as<uint32_t>(), s));
+    VQ_TRY(comm_allreduce_u32(comm ? comm->c : nullptr, km->gather_ws.as<uint32_t>(), sd, s));
+    VQ_HIP(hipMemcpyAsync(km->cs.cb.as<float>() + ((size_t)sub * km->cs.k + j) * sd, km->gather_ws.p, (size_t)sd * 4,
+                          hipMemcpyDeviceToDevice, s));
+    VQ_HIP(hipStreamSynchronize(s));  // &global_row is a stack address
+    km->cs.prepared = false;
+    return VQHIP_OK;
+    VQ_API_END
+}
+
 // ----------------------------------------------------------------------- PQ encode ----
 int vqhip_pq_encoder_create(const float *codebooks, uint32_t m, uint32_t k, uint32_t sub_dim, int metric,
                             vqhip_pq_encoder **out) {
@@ -1276,11 +1422,24 @@ int vqhip_tsvq_create(const float *centroids, const int32_t *left, const int32_t
     if (!centroids || !left || !right) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     if (n_nodes == 0 || d == 0) return fail(VQHIP_ERR_INVALID_INPUT, "empty tree");
     if (metric < VQHIP_SQUARED_EUCLIDEAN || metric > VQHIP_COSINE) return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", metric);
-    for (uint32_t i = 0; i < n_nodes; ++i) {
-        // children must point forward (pre-order) so that the descent terminates
-        if ((left[i] >= 0 && (left[i] <= (int32_t)i || left[i] >= (int32_t)n_nodes)) ||
-            (right[i] >= 0 && (right[i] <= (int32_t)i || right[i] >= (int32_t)n_nodes)))
-            return fail(VQHIP_ERR_INVALID_INPUT, "node %u has an out-of-order child index", i);
+    {
+        // the arrays must describe ONE tree rooted at node 0: children point forward (pre-order, so the
+        // descent terminates), a node's two children differ, no node has two parents and every node but
+        // the root has one (the encoder's breadth-first images are sized by the node count)
+        std::vector<uint8_t> has_parent(n_nodes, 0);
+        for (uint32_t i = 0; i < n_nodes; ++i) {
+            const int32_t ch[2] = {left[i], right[i]};
+            if (ch[0] >= 0 && ch[0] == ch[1]) return fail(VQHIP_ERR_INVALID_INPUT, "node %u names node %d as both children", i, ch[0]);
+            for (int c = 0; c < 2; ++c) {
+                if (ch[c] < 0) continue;
+                if (ch[c] <= (int32_t)i || ch[c] >= (int32_t)n_nodes)
+                    return fail(VQHIP_ERR_INVALID_INPUT, "node %u has an out-of-order child index", i);
+                if (has_parent[ch[c]]) return fail(VQHIP_ERR_INVALID_INPUT, "node %d has two parents", ch[c]);
+                has_parent[ch[c]] = 1;
+            }
+        }
+        for (uint32_t i = 1; i < n_nodes; ++i)
+            if (!has_parent[i]) return fail(VQHIP_ERR_INVALID_INPUT, "node %u is not reachable from the root", i);
     }
     VQ_TRY(require_gfx950());
     hipStream_t s;

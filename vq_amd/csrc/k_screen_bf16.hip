@@ -12,23 +12,15 @@
 //     a.x ~= a1x1 + a2x1 + a1x2 + a3x1 + a2x2 + a1x3  (the three dropped cross terms are
 //                                                      < 2^-21 |a||x| per dimension)
 //
-// i.e. 6*sub_dim bf16 products per (row, centroid) = 3 v_mfma_f32_16x16x32_bf16 per 16x16 tile
-// at sub_dim 16 (48 cycles of matrix pipe instead of 128 cycles of the shared fp32 path), with
-// f32 accumulation.  Everything after the contraction (fused |c|^2 as the first MFMA's C
-// operand, in-register min / second-min / argmin, wave-64 merge, margin test, work list for the
-// exact re-check) is the same as in k_screen.hip; only the margin coefficient differs.
+// i.e. 6*sub_dim bf16 products per (row, centroid) on v_mfma_f32_32x32x16_bf16 with f32
+// accumulation, |c_j|^2 fused as the accumulator's initial value, an in-register
+// min / second-min / argmin, a margin test and a work list for the exact re-check.
+// Margin: DESIGN.md "screen soundness" (the per-MFMA accumulation bound eps_M comes from the
+// bit-exact model of the instruction's adder, tests/mfma_model.py, validated on the device).
 //
-// Margin (DESIGN.md "screen soundness", bf16 variant).  Per MFMA the hardware's accumulation of
-// 32 exact products + C deviates from the exact sum by at most eps_M * (|C| + sum|a_i b_i|);
-// eps_M is not documented, the probes profiles/r1/ubench_bf16_numerics.txt (25 M random sums,
-// wide exponent spreads) and ubench_bf16_adversarial.txt (dominant addend + many sub-ulp
-// addends, cancellation) never exceed 5.8 * 2^-24; the coefficient below assumes 16 * 2^-24.
-// Total: T = (8*sd + 16 + 32*NM + 16) * 2^-24 * (|x| + max|c|)^2  (+ subnormal slack), NM = MFMAs
-// per tile; rows that fail it are re-decided exactly, so codes stay bit-identical.
-//
-// One wave per SIMD (launch bound 1): the A images of one subspace (192 registers at k=256,
-// sub_dim=16) and |c|^2 (64) live in the accumulator half of the unified 512-entry register
-// file, the 64 accumulators and the epilogue in the architectural half.
+// The round-1 16x16x32 variants (registers / software-pipelined / A images in LDS with 2 and 4
+// waves per SIMD; 0.60 / 0.87 / 0.80 ms at C2 against 0.49 here) were removed in round 2; they
+// are in the history up to commit 65d0c95.
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -68,518 +60,6 @@ __host__ __device__ inline void split3(float v, uint32_t (&part)[3]) {
     part[0] = b0;
     part[1] = b1;
     part[2] = b2;
-}
-
-// A images: [m][NT][NM][4 dwords][64 lanes]; dword w of lane (g, c) holds k-slots 2w, 2w+1
-__global__ __launch_bounds__(256) void k_prepare_bf16(const float *__restrict__ cb, uint32_t m, uint32_t k,
-                                                      uint32_t sd, uint32_t nt, uint32_t nm,
-                                                      uint32_t *__restrict__ prepA16) {
-    const uint32_t s = blockIdx.x;
-    const uint32_t dpg = sd / 4, pp = 8 / dpg;
-    const float *cbs = cb + (size_t)s * k * sd;
-    const uint32_t total = nt * nm * 4 * 64;
-    for (uint32_t e = blockIdx.y * blockDim.x + threadIdx.x; e < total; e += gridDim.y * blockDim.x) {
-        const uint32_t lane = e & 63, w = (e >> 6) & 3, r = (e >> 8) % nm, i = (e >> 8) / nm;
-        const uint32_t g = lane >> 4, c = lane & 15, j = 16 * i + c;
-        uint32_t half[2] = {0u, 0u};
-        for (uint32_t h = 0; h < 2; ++h) {
-            const uint32_t slot = 2 * w + h;
-            const uint32_t pq = slot / dpg, dd = slot - pq * dpg;
-            const uint32_t pair = r * pp + pq;
-            if (pair < 6 && j < k) {
-                uint32_t parts[3];
-                split3(-2.0f * cbs[(size_t)j * sd + g * dpg + dd], parts);
-                half[h] = parts[pair_a((int)pair)] >> 16;
-            }
-        }
-        prepA16[(size_t)s * total + e] = half[0] | (half[1] << 16);
-    }
-}
-
-template <int SD, int NT>
-__global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16(
-    const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m,
-    const uint32_t *__restrict__ prepA16, const float *__restrict__ prepCn,
-    const float *__restrict__ meta, const uint32_t *__restrict__ sub_list, uint32_t n_sub,
-    uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_count,
-    uint64_t wl_stride) {
-    constexpr int DPG = SD / 4;                  // dims owned by a lane group
-    constexpr int PP = 8 / DPG;                  // term pairs per MFMA
-    constexpr int NM = (6 + PP - 1) / PP;        // MFMAs per 16x16 tile
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = lane >> 4, p = lane & 15;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;
-    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
-    const uint32_t n_chunks = total_waves / n_sub;
-    if (gw >= n_chunks * n_sub) return;
-    const uint32_t s = sub_list[gw % n_sub];
-    const uint32_t chunk = gw / n_sub;
-    const uint64_t n_tiles = (n + 15) / 16;
-    const uint64_t tiles_per_chunk = (n_tiles + n_chunks - 1) / n_chunks;
-    const uint64_t t0 = (uint64_t)chunk * tiles_per_chunk;
-    uint64_t t1 = t0 + tiles_per_chunk;
-    if (t1 > n_tiles) t1 = n_tiles;
-    if (t0 >= t1) return;
-
-    // codebook images of subspace s -> registers (A operands, read only by MFMAs: they can live
-    // in the accumulator half of the register file); |c|^2 -> a per-wave LDS row, read back as
-    // one broadcast ds_read_b128 per tile (keeping it in registers made hipcc park it in AGPRs
-    // and copy 64 registers back with v_accvgpr_read every tile)
-    __shared__ __attribute__((aligned(16))) float lds_cn[kWavesPerBlock][NT * 16];
-    bf16x8 a[NT][NM];
-    {
-        const u32x4 *pa = reinterpret_cast<const u32x4 *>(prepA16);  // not 16-B contiguous per lane: gather dwords
-        (void)pa;
-        const uint32_t *base = prepA16 + (size_t)s * NT * NM * 4 * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int r = 0; r < NM; ++r) {
-                u32x4 v;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) v[w] = base[((i * NM + r) * 4 + w) * 64];
-                a[i][r] = __builtin_bit_cast(bf16x8, v);
-            }
-        const float *pc = prepCn + (size_t)s * NT * 16;
-        for (uint32_t e = lane; e < NT * 16; e += 64) lds_cn[wave][e] = pc[e];
-    }
-    const f32x4 *cnp = reinterpret_cast<const f32x4 *>(&lds_cn[wave][4 * g]);
-    float pinf = __builtin_inff(), ninf = -__builtin_inff();
-    asm volatile("" : "+s"(pinf), "+s"(ninf));
-    const float cmax = meta[s * 4 + 0];
-    const float tcoef = meta[s * 4 + 2];
-
-    const size_t col0 = (size_t)s * SD + (size_t)DPG * g;
-    auto row_ptr = [&](uint64_t tile) {
-        uint64_t row = tile * 16 + p;
-        if (row >= n) row = n - 1;
-        return X + row * d + col0;
-    };
-    auto load_x = [&](const float *ptr, float (&x)[DPG]) {
-        if constexpr (DPG == 1) {
-            x[0] = ptr[0];
-        } else if constexpr (DPG == 2) {
-            const float2 t = *reinterpret_cast<const float2 *>(ptr);
-            x[0] = t.x;
-            x[1] = t.y;
-        } else {
-#pragma unroll
-            for (int q = 0; q < DPG; q += 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(ptr + q);
-                x[q + 0] = t.x;
-                x[q + 1] = t.y;
-                x[q + 2] = t.z;
-                x[q + 3] = t.w;
-            }
-        }
-    };
-
-    float xn_[DPG];
-    load_x(row_ptr(t0), xn_);
-    for (uint64_t tile = t0; tile < t1; ++tile) {
-        float x[DPG];
-#pragma unroll
-        for (int q = 0; q < DPG; ++q) x[q] = xn_[q];
-        if (tile + 1 < t1) load_x(row_ptr(tile + 1), xn_);
-
-        // split the row's DPG components into three bf16 slices each
-        uint32_t xp[3][DPG];  // high-half words
-        float xs = 0.0f;
-#pragma unroll
-        for (int q = 0; q < DPG; ++q) {
-            uint32_t parts[3];
-            split3(x[q], parts);
-            xp[0][q] = parts[0];
-            xp[1][q] = parts[1];
-            xp[2][q] = parts[2];
-            xs = fmaf(x[q], x[q], xs);
-        }
-        // B operands: slot (pq, dd) of MFMA r <- x part pair_x(r*PP+pq), dim dd
-        bf16x8 b[NM];
-#pragma unroll
-        for (int r = 0; r < NM; ++r) {
-            u32x4 v;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                uint32_t hw[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int slot = 2 * w + h, pq = slot / DPG, dd = slot % DPG, pair = r * PP + pq;
-                    hw[h] = (pair < 6) ? xp[pair_x(pair)][dd] : 0u;
-                }
-                v[w] = (hw[0] >> 16) | (hw[1] & 0xFFFF0000u);
-            }
-            b[r] = __builtin_bit_cast(bf16x8, v);
-        }
-
-        // The MFMAs are issued through inline asm so that the A images can be named as AGPR
-        // operands ("a"): with the builtin, hipcc keeps AGPRs only as spill space and copies 64
-        // registers back per tile (v_accvgpr_read).  Hazards hipcc does not pad for asm
-        // (cdna_hip_programming.md 5.7): VALU-written B operand -> MFMA read (s_nop 1 in front of
-        // the first MFMA of the tile); MFMA result -> VALU read (16 wait states after the last).
-        // pin: every B operand is final before the first MFMA (volatile asm statements keep their
-        // order), then 2 wait states for the VALU-write -> MFMA-read hazard
-#pragma unroll
-        for (int r = 0; r < NM; ++r) asm volatile("" : "+v"(b[r]));
-        asm volatile("s_nop 1");
-        // accumulators start as |c|^2: all 16 broadcast ds_read_b128 are issued back to back and
-        // waited for once (one read + wait in front of each MFMA exposed the LDS latency 16 times)
-        f32x4 acc[NT];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) acc[i] = cnp[4 * i];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) asm volatile("" : "+v"(acc[i]));
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "a"(a[i][0]), "v"(b[0]));
-#pragma unroll
-        for (int r = 1; r < NM; ++r)
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "a"(a[i][r]), "v"(b[r]));
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-
-        // ---- epilogue: identical to k_screen.hip ----
-        // four independent (min, second-min) chains, one per accumulator register, merged at the
-        // end: a single dependent chain of 128 v_med3_f32 stalls a lone wave on VALU latency
-        float q1[4] = {pinf, pinf, pinf, pinf}, q2[4] = {pinf, pinf, pinf, pinf};
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = acc[i][r];
-                q2[r] = __builtin_amdgcn_fmed3f(q1[r], q2[r], v);
-                q1[r] = __builtin_amdgcn_fmed3f(q1[r], v, ninf);
-            }
-        // merge (a1,a2)+(b1,b2): min1 = min(a1,b1); min2 = min(max(a1,b1), min(a2,b2))
-        auto merge2 = [&](float a1, float a2, float b1, float b2, float &o1, float &o2) {
-            const float hi = __builtin_amdgcn_fmed3f(a1, b1, pinf);
-            const float lo2 = __builtin_amdgcn_fmed3f(a2, b2, ninf);
-            o2 = __builtin_amdgcn_fmed3f(hi, lo2, ninf);
-            o1 = __builtin_amdgcn_fmed3f(a1, b1, ninf);
-        };
-        float u1, u2, w1, w2, m1, m2;
-        merge2(q1[0], q2[0], q1[1], q2[1], u1, u2);
-        merge2(q1[2], q2[2], q1[3], q2[3], w1, w2);
-        merge2(u1, u2, w1, w2, m1, m2);
-        uint32_t cr[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = NT - 1; i >= 0; --i)
-#pragma unroll
-            for (int r = 3; r >= 0; --r) cr[r] = (acc[i][r] == m1) ? (uint32_t)(4 * i + r) : cr[r];
-        const uint32_t c01 = cr[0] > cr[1] ? cr[0] : cr[1];
-        const uint32_t c23 = cr[2] > cr[3] ? cr[2] : cr[3];
-        const uint32_t creg = c01 > c23 ? c01 : c23;
-        uint32_t j = ((creg & ~3u) << 2) + (creg & 3u) + 4 * g;
-
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-            const float om1 = __shfl_xor(m1, off);
-            const float om2 = __shfl_xor(m2, off);
-            const uint32_t oj = (uint32_t)__shfl_xor((int)j, off);
-            xs += __shfl_xor(xs, off);
-            const float hi = __builtin_amdgcn_fmed3f(m1, om1, pinf);
-            const float lo2 = __builtin_amdgcn_fmed3f(m2, om2, ninf);
-            m2 = __builtin_amdgcn_fmed3f(lo2, hi, ninf);
-            const bool take = (om1 < m1) || (om1 == m1 && oj < j);
-            j = take ? oj : j;
-            m1 = __builtin_amdgcn_fmed3f(m1, om1, ninf);
-        }
-        const float xn = __builtin_sqrtf(xs) * 1.000001f + cmax;
-        const float bnd = xn * xn;
-        const float T = tcoef * bnd + 1e-35f * xn + 1e-37f;
-        const float gap = m2 - m1;
-        const bool proven = (gap > T) && (fabsf(m1) <= 3.0e38f) && (T <= 3.0e38f);
-
-        const uint64_t row = tile * 16 + p;
-        const bool writer = (g == 0) && (row < n);
-        if (writer) codes[row * m + s] = (uint8_t)j;
-        const bool recheck = writer && !proven;
-        const unsigned long long mask = __ballot(recheck);
-        if (mask != 0ull) {
-            const uint32_t cnt = (uint32_t)__popcll(mask);
-            const int leader = __ffsll((long long)mask) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&wl_count[s], cnt);
-            base = (uint32_t)__shfl((int)base, leader);
-            if (recheck) {
-                const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                wl_rows[(size_t)s * wl_stride + base + rank] = (uint32_t)row;
-            }
-        }
-    }
-}
-
-// ---- variant P: register-resident A, one wave per SIMD, software-pipelined by hand -------------
-// A lone in-order wave cannot overlap its own MFMAs with its own epilogue unless the two are
-// interleaved in program order.  Each loop step therefore works on TWO row tiles: for every
-// centroid tile i it issues the 3 MFMAs of row tile t+1 (results into `nxt`) and, right behind
-// them, reduces the 4 accumulator values of row tile t (`cur`, finished one step earlier) --
-// 48 cycles of matrix pipe against ~16 VALU instructions per slot.  The epilogue is single-pass:
-// min, second min and argmin are tracked together (compare + med3 + two selects per value) in
-// four independent chains, so no accumulator has to outlive its slot.  |c|^2 is read from LDS two
-// slots ahead straight into the next accumulators.
-struct PendingTile {
-    uint64_t tile;
-    float xs;
-};
-
-template <int SD, int NT, int NM>
-__device__ __forceinline__ void pipe_step(f32x4 (&cur)[NT], f32x4 (&nxt)[NT], const bf16x8 (&a)[NT][NM],
-                                          const bf16x8 (&b)[NM], const f32x4 *cnp, float pinf, float ninf,
-                                          float (&q1)[4], float (&q2)[4], uint32_t (&qi)[4]) {
-    // |c|^2 for all NT tiles first (broadcast ds_read_b128 straight into the next accumulators):
-    // they land while the B operands are being built
-#pragma unroll
-    for (int i = 0; i < NT; ++i) nxt[i] = cnp[4 * i];
-    // every B operand final before the first MFMA; 2 wait states VALU-write -> MFMA-read
-#pragma unroll
-    for (int r = 0; r < NM; ++r) asm volatile("" ::"v"(b[r]));
-    asm volatile("s_nop 1");
-    // NT*NM micro-slots: slot u issues MFMA (r = u / NT) of centroid tile (u % NT) -- the chained
-    // MFMAs of one accumulator are NT slots apart -- followed by its share of the 4*NT values of
-    // `cur` (value v of tile v/4, register v%4)
-    constexpr int SLOTS = NT * NM, VALS = 4 * NT;
-#pragma unroll
-    for (int u = 0; u < SLOTS; ++u) {
-        const int r = u / NT, i = u % NT;
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(nxt[i]) : "a"(a[i][r]), "v"(b[r]));
-        const int v0 = (u * VALS) / SLOTS, v1 = ((u + 1) * VALS) / SLOTS;
-#pragma unroll
-        for (int vv = v0; vv < v1; ++vv) {
-            const int ti = vv / 4, rr = vv % 4;
-            const float v = cur[ti][rr];
-            const bool lt = v < q1[rr];
-            q2[rr] = __builtin_amdgcn_fmed3f(q1[rr], q2[rr], v);
-            q1[rr] = lt ? v : q1[rr];
-            qi[rr] = lt ? (uint32_t)vv : qi[rr];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <int SD, int NT>
-__global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_pipe(
-    const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m,
-    const uint32_t *__restrict__ prepA16, const float *__restrict__ prepCn,
-    const float *__restrict__ meta, const uint32_t *__restrict__ sub_list, uint32_t n_sub,
-    uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_count,
-    uint64_t wl_stride) {
-    constexpr int DPG = SD / 4;
-    constexpr int PP = 8 / DPG;
-    constexpr int NM = (6 + PP - 1) / PP;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = lane >> 4, p = lane & 15;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;
-    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
-    const uint32_t n_chunks = total_waves / n_sub;
-    if (gw >= n_chunks * n_sub) return;
-    const uint32_t s = sub_list[gw % n_sub];
-    const uint32_t chunk = gw / n_sub;
-    const uint64_t n_tiles = (n + 15) / 16;
-    const uint64_t tiles_per_chunk = (n_tiles + n_chunks - 1) / n_chunks;
-    const uint64_t t0 = (uint64_t)chunk * tiles_per_chunk;
-    uint64_t t1 = t0 + tiles_per_chunk;
-    if (t1 > n_tiles) t1 = n_tiles;
-    if (t0 >= t1) return;
-
-    __shared__ __attribute__((aligned(16))) float lds_cn[kWavesPerBlock][NT * 16];
-    bf16x8 a[NT][NM];
-    {
-        const uint32_t *base = prepA16 + (size_t)s * NT * NM * 4 * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int r = 0; r < NM; ++r) {
-                u32x4 v;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) v[w] = base[((i * NM + r) * 4 + w) * 64];
-                a[i][r] = __builtin_bit_cast(bf16x8, v);
-            }
-        const float *pc = prepCn + (size_t)s * NT * 16;
-        for (uint32_t e = lane; e < NT * 16; e += 64) lds_cn[wave][e] = pc[e];
-    }
-    const f32x4 *cnp = reinterpret_cast<const f32x4 *>(&lds_cn[wave][4 * g]);
-    float pinf = __builtin_inff(), ninf = -__builtin_inff();
-    asm volatile("" : "+s"(pinf), "+s"(ninf));
-    const float cmax = meta[s * 4 + 0];
-    const float tcoef = meta[s * 4 + 2];
-
-    const size_t col0 = (size_t)s * SD + (size_t)DPG * g;
-    auto row_ptr = [&](uint64_t tile) {
-        uint64_t row = tile * 16 + p;
-        if (row >= n) row = n - 1;
-        return X + row * d + col0;
-    };
-    auto load_x = [&](const float *ptr, float (&x)[DPG]) {
-        if constexpr (DPG == 1) {
-            x[0] = ptr[0];
-        } else if constexpr (DPG == 2) {
-            const float2 t = *reinterpret_cast<const float2 *>(ptr);
-            x[0] = t.x;
-            x[1] = t.y;
-        } else {
-#pragma unroll
-            for (int q = 0; q < DPG; q += 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(ptr + q);
-                x[q + 0] = t.x;
-                x[q + 1] = t.y;
-                x[q + 2] = t.z;
-                x[q + 3] = t.w;
-            }
-        }
-    };
-    // B operands (+ partial |x|^2) of a row tile from its raw components
-    auto make_b = [&](const float (&x)[DPG], bf16x8 (&b)[NM], float &xs) {
-        uint32_t xp[3][DPG];
-        xs = 0.0f;
-#pragma unroll
-        for (int q = 0; q < DPG; ++q) {
-            uint32_t parts[3];
-            split3(x[q], parts);
-            xp[0][q] = parts[0];
-            xp[1][q] = parts[1];
-            xp[2][q] = parts[2];
-            xs = fmaf(x[q], x[q], xs);
-        }
-#pragma unroll
-        for (int r = 0; r < NM; ++r) {
-            u32x4 v;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                uint32_t hw[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int sl = 2 * w + h, pq = sl / DPG, dd = sl % DPG, pair = r * PP + pq;
-                    hw[h] = (pair < 6) ? xp[pair_x(pair)][dd] : 0u;
-                }
-                v[w] = (hw[0] >> 16) | (hw[1] & 0xFFFF0000u);
-            }
-            b[r] = __builtin_bit_cast(bf16x8, v);
-        }
-    };
-    // cross-lane merge, margin test and output of a finished row tile
-    auto finish = [&](const PendingTile &pt, float (&q1)[4], float (&q2)[4], uint32_t (&qi)[4]) {
-        auto merge2 = [&](float a1, float a2, uint32_t ai, float b1, float b2, uint32_t bi, float &o1, float &o2,
-                          uint32_t &oi) {
-            const float hi = __builtin_amdgcn_fmed3f(a1, b1, pinf);
-            const float lo2 = __builtin_amdgcn_fmed3f(a2, b2, ninf);
-            o2 = __builtin_amdgcn_fmed3f(hi, lo2, ninf);
-            const bool tb = b1 < a1;
-            o1 = tb ? b1 : a1;
-            oi = tb ? bi : ai;
-        };
-        float u1, u2, w1, w2, m1, m2;
-        uint32_t ui, wi, creg;
-        merge2(q1[0], q2[0], qi[0], q1[1], q2[1], qi[1], u1, u2, ui);
-        merge2(q1[2], q2[2], qi[2], q1[3], q2[3], qi[3], w1, w2, wi);
-        merge2(u1, u2, ui, w1, w2, wi, m1, m2, creg);
-        uint32_t j = ((creg & ~3u) << 2) + (creg & 3u) + 4 * g;
-        float xs = pt.xs;
-        // lanes l, l^16, l^32, l^48 hold the same row: merge with v_permlane16_swap /
-        // v_permlane32_swap (VALU, no LDS round trip).  swap(v, v) returns the even-row copy and
-        // the odd-row copy of v in BOTH lanes of a pair, so the merged result is identical in all
-        // four lanes without any select on the lane id.
-        auto xchg16 = [](uint32_t v, uint32_t &ev, uint32_t &od) {
-            const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-            ev = r[0];
-            od = r[1];
-        };
-        auto xchg32 = [](uint32_t v, uint32_t &ev, uint32_t &od) {
-            const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-            ev = r[0];
-            od = r[1];
-        };
-        auto lane_merge = [&](auto xchg) {
-            uint32_t a1u, b1u, a2u, b2u, aj, bj, axs, bxs;
-            xchg(__float_as_uint(m1), a1u, b1u);
-            xchg(__float_as_uint(m2), a2u, b2u);
-            xchg(j, aj, bj);
-            xchg(__float_as_uint(xs), axs, bxs);
-            const float a1 = __uint_as_float(a1u), b1 = __uint_as_float(b1u);
-            const float a2 = __uint_as_float(a2u), b2 = __uint_as_float(b2u);
-            xs = __uint_as_float(axs) + __uint_as_float(bxs);
-            const float hi = __builtin_amdgcn_fmed3f(a1, b1, pinf);
-            const float lo2 = __builtin_amdgcn_fmed3f(a2, b2, ninf);
-            m2 = __builtin_amdgcn_fmed3f(lo2, hi, ninf);
-            const bool take = (b1 < a1) || (b1 == a1 && bj < aj);
-            j = take ? bj : aj;
-            m1 = take ? b1 : a1;
-        };
-        lane_merge(xchg16);
-        lane_merge(xchg32);
-        const float xn = __builtin_sqrtf(xs) * 1.000001f + cmax;
-        const float bnd = xn * xn;
-        const float T = tcoef * bnd + 1e-35f * xn + 1e-37f;
-        const float gap = m2 - m1;
-        const bool proven = (gap > T) && (fabsf(m1) <= 3.0e38f) && (T <= 3.0e38f);
-        const uint64_t row = pt.tile * 16 + p;
-        const bool writer = (g == 0) && (row < n);
-        if (writer) codes[row * m + s] = (uint8_t)j;
-        const bool recheck = writer && !proven;
-        const unsigned long long mask = __ballot(recheck);
-        if (mask != 0ull) {
-            const uint32_t cnt = (uint32_t)__popcll(mask);
-            const int leader = __ffsll((long long)mask) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&wl_count[s], cnt);
-            base = (uint32_t)__shfl((int)base, leader);
-            if (recheck) {
-                const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                wl_rows[(size_t)s * wl_stride + base + rank] = (uint32_t)row;
-            }
-        }
-    };
-
-    f32x4 accA[NT], accB[NT];
-    float x0[DPG], x1[DPG];
-    bf16x8 b[NM];
-    PendingTile pend;
-    // prologue: MFMAs of the first tile into accA (reducing a dummy all-+inf `cur`)
-    load_x(row_ptr(t0), x0);
-    load_x(row_ptr(t0 + 1), x1);
-    {
-        float xs;
-        make_b(x0, b, xs);
-        pend.tile = t0;
-        pend.xs = xs;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) accB[i] = f32x4{pinf, pinf, pinf, pinf};
-        float q1[4] = {pinf, pinf, pinf, pinf}, q2[4] = {pinf, pinf, pinf, pinf};
-        uint32_t qi[4] = {0u, 0u, 0u, 0u};
-        pipe_step<SD, NT, NM>(accB, accA, a, b, cnp, pinf, ninf, q1, q2, qi);
-    }
-    // steady state, two steps per trip so that accA / accB keep static names.  A step computes
-    // the tile after the pending one even when that lies past the chunk (rows are clamped, the
-    // result is discarded).
-    for (uint64_t tile = t0; tile < t1; tile += 2) {
-        {   // reduce accA (tile), compute tile+1 into accB
-            float xs;
-            make_b(x1, b, xs);
-            load_x(row_ptr(tile + 2), x0);
-            float q1[4] = {pinf, pinf, pinf, pinf}, q2[4] = {pinf, pinf, pinf, pinf};
-            uint32_t qi[4] = {0u, 0u, 0u, 0u};
-            pipe_step<SD, NT, NM>(accA, accB, a, b, cnp, pinf, ninf, q1, q2, qi);
-            finish(pend, q1, q2, qi);
-            pend.tile = tile + 1;
-            pend.xs = xs;
-        }
-        if (tile + 1 >= t1) break;
-        {   // reduce accB (tile+1), compute tile+2 into accA
-            float xs;
-            make_b(x0, b, xs);
-            load_x(row_ptr(tile + 3), x1);
-            float q1[4] = {pinf, pinf, pinf, pinf}, q2[4] = {pinf, pinf, pinf, pinf};
-            uint32_t qi[4] = {0u, 0u, 0u, 0u};
-            pipe_step<SD, NT, NM>(accB, accA, a, b, cnp, pinf, ninf, q1, q2, qi);
-            finish(pend, q1, q2, qi);
-            pend.tile = tile + 2;
-            pend.xs = xs;
-        }
-    }
 }
 
 // ---- variant X32: 32x32x16 MFMA tiles, 32 rows per wave step ------------------------------------
@@ -1247,499 +727,6 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_wide(
     }
 }
 
-// ---- variant B: A images in LDS, two waves per SIMD -------------------------------------------
-// A workgroup of 8 waves serves up to two subspaces (4 waves each) and keeps their A images in
-// LDS (48 KB per subspace at k=256, sub_dim=16); every MFMA's A operand is one lane-linear
-// ds_read_b128 (conflict-free, 1 KiB).  Freed of the 192 A registers a wave needs ~170 VGPRs, so
-// two waves share each SIMD and the hardware overlaps one wave's MFMAs / LDS reads / waits with
-// the other's VALU epilogue -- which a lone in-order wave cannot do for itself.  The two
-// subspaces of a workgroup are adjacent, so at sub_dim 16 the workgroup consumes exactly one
-// 128-B line of every row.
-constexpr int kLdsWaves = 8;
-
-template <int SD, int NT>
-__global__ __launch_bounds__(kLdsWaves * 64, 2) void k_assign_screen_bf16_lds(
-    const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m,
-    const uint32_t *__restrict__ prepA16, const float *__restrict__ prepCn,
-    const float *__restrict__ meta, const uint32_t *__restrict__ sub_list, uint32_t n_sub,
-    uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_count,
-    uint64_t wl_stride) {
-    constexpr int DPG = SD / 4;
-    constexpr int PP = 8 / DPG;
-    constexpr int NM = (6 + PP - 1) / PP;
-    constexpr uint32_t IMG = NT * NM * 4 * 64;  // dwords of one subspace's A image
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_a[];  // [ns][IMG]
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = lane >> 4, p = lane & 15;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // subspace group of this workgroup
-    const uint32_t s_first = blockIdx.y * 2;
-    const uint32_t ns = (n_sub - s_first >= 2) ? 2u : 1u;
-    const uint32_t wps = kLdsWaves / ns;           // waves per subspace
-    const uint32_t ls = wave / wps, slot = wave % wps;
-    const uint32_t s = sub_list[s_first + ls];
-
-    // stage the A images (coalesced 16-B copies, image layout [tile][mfma][dword][lane] -> per
-    // (tile, mfma) a [lane][4 dwords] block so that a lane's operand is one 16-B read)
-    for (uint32_t q = 0; q < ns; ++q) {
-        const uint32_t sq = sub_list[s_first + q];
-        const uint32_t *src = prepA16 + (size_t)sq * IMG;
-        for (uint32_t e = threadIdx.x; e < IMG; e += kLdsWaves * 64) {
-            const uint32_t ln = e & 63, w = (e >> 6) & 3, blk = e >> 8;
-            lds_a[q * IMG + blk * 256 + ln * 4 + w] = src[e];
-        }
-    }
-    __syncthreads();
-    const u32x4 *la = reinterpret_cast<const u32x4 *>(lds_a + ls * IMG) + lane;  // + (i*NM + r)*64
-
-    f32x4 cn[NT];
-    {
-        const float *pc = prepCn + (size_t)s * NT * 16 + 4 * g;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) cn[i] = *reinterpret_cast<const f32x4 *>(pc + 16 * i);
-    }
-    float pinf = __builtin_inff(), ninf = -__builtin_inff();
-    asm volatile("" : "+s"(pinf), "+s"(ninf));
-    const float cmax = meta[s * 4 + 0];
-    const float tcoef = meta[s * 4 + 2];
-
-    // rows: the workgroup's chunk, tiles interleaved over the wps waves of a subspace
-    const uint64_t n_tiles = (n + 15) / 16;
-    const uint64_t tiles_per_chunk = (n_tiles + gridDim.x - 1) / gridDim.x;
-    const uint64_t t0 = (uint64_t)blockIdx.x * tiles_per_chunk + slot;
-    uint64_t t1 = (uint64_t)blockIdx.x * tiles_per_chunk + tiles_per_chunk;
-    if (t1 > n_tiles) t1 = n_tiles;
-    if (t0 >= t1) return;
-
-    const size_t col0 = (size_t)s * SD + (size_t)DPG * g;
-    auto row_ptr = [&](uint64_t tile) {
-        uint64_t row = tile * 16 + p;
-        if (row >= n) row = n - 1;
-        return X + row * d + col0;
-    };
-    auto load_x = [&](const float *ptr, float (&x)[DPG]) {
-        if constexpr (DPG == 1) {
-            x[0] = ptr[0];
-        } else if constexpr (DPG == 2) {
-            const float2 t = *reinterpret_cast<const float2 *>(ptr);
-            x[0] = t.x;
-            x[1] = t.y;
-        } else {
-#pragma unroll
-            for (int q = 0; q < DPG; q += 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(ptr + q);
-                x[q + 0] = t.x;
-                x[q + 1] = t.y;
-                x[q + 2] = t.z;
-                x[q + 3] = t.w;
-            }
-        }
-    };
-
-    float xn_[DPG];
-    load_x(row_ptr(t0), xn_);
-    for (uint64_t tile = t0; tile < t1; tile += wps) {
-        float x[DPG];
-#pragma unroll
-        for (int q = 0; q < DPG; ++q) x[q] = xn_[q];
-        if (tile + wps < t1) load_x(row_ptr(tile + wps), xn_);
-
-        uint32_t xp[3][DPG];
-        float xs = 0.0f;
-#pragma unroll
-        for (int q = 0; q < DPG; ++q) {
-            uint32_t parts[3];
-            split3(x[q], parts);
-            xp[0][q] = parts[0];
-            xp[1][q] = parts[1];
-            xp[2][q] = parts[2];
-            xs = fmaf(x[q], x[q], xs);
-        }
-        bf16x8 b[NM];
-#pragma unroll
-        for (int r = 0; r < NM; ++r) {
-            u32x4 v;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                uint32_t hw[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int sl = 2 * w + h, pq = sl / DPG, dd = sl % DPG, pair = r * PP + pq;
-                    hw[h] = (pair < 6) ? xp[pair_x(pair)][dd] : 0u;
-                }
-                v[w] = (hw[0] >> 16) | (hw[1] & 0xFFFF0000u);
-            }
-            b[r] = __builtin_bit_cast(bf16x8, v);
-        }
-
-        // the image is loop-invariant: without an opaque base hipcc hoists all 48 operand reads
-        // out of the tile loop (192 registers) and spills
-        const u32x4 *lat = la;
-        asm volatile("" : "+v"(lat));
-        f32x4 acc[NT];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, lat[(i * NM + 0) * 64]);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[0], cn[i], 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 1; r < NM; ++r)
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const bf16x8 ar = __builtin_bit_cast(bf16x8, lat[(i * NM + r) * 64]);
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar, b[r], acc[i], 0, 0, 0);
-            }
-
-        float q1[4] = {pinf, pinf, pinf, pinf}, q2[4] = {pinf, pinf, pinf, pinf};
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = acc[i][r];
-                q2[r] = __builtin_amdgcn_fmed3f(q1[r], q2[r], v);
-                q1[r] = __builtin_amdgcn_fmed3f(q1[r], v, ninf);
-            }
-        auto merge2 = [&](float a1, float a2, float b1, float b2, float &o1, float &o2) {
-            const float hi = __builtin_amdgcn_fmed3f(a1, b1, pinf);
-            const float lo2 = __builtin_amdgcn_fmed3f(a2, b2, ninf);
-            o2 = __builtin_amdgcn_fmed3f(hi, lo2, ninf);
-            o1 = __builtin_amdgcn_fmed3f(a1, b1, ninf);
-        };
-        float u1, u2, w1, w2, m1, m2;
-        merge2(q1[0], q2[0], q1[1], q2[1], u1, u2);
-        merge2(q1[2], q2[2], q1[3], q2[3], w1, w2);
-        merge2(u1, u2, w1, w2, m1, m2);
-        uint32_t cr[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int i = NT - 1; i >= 0; --i)
-#pragma unroll
-            for (int r = 3; r >= 0; --r) cr[r] = (acc[i][r] == m1) ? (uint32_t)(4 * i + r) : cr[r];
-        const uint32_t c01 = cr[0] > cr[1] ? cr[0] : cr[1];
-        const uint32_t c23 = cr[2] > cr[3] ? cr[2] : cr[3];
-        const uint32_t creg = c01 > c23 ? c01 : c23;
-        uint32_t j = ((creg & ~3u) << 2) + (creg & 3u) + 4 * g;
-
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-            const float om1 = __shfl_xor(m1, off);
-            const float om2 = __shfl_xor(m2, off);
-            const uint32_t oj = (uint32_t)__shfl_xor((int)j, off);
-            xs += __shfl_xor(xs, off);
-            const float hi = __builtin_amdgcn_fmed3f(m1, om1, pinf);
-            const float lo2 = __builtin_amdgcn_fmed3f(m2, om2, ninf);
-            m2 = __builtin_amdgcn_fmed3f(lo2, hi, ninf);
-            const bool take = (om1 < m1) || (om1 == m1 && oj < j);
-            j = take ? oj : j;
-            m1 = __builtin_amdgcn_fmed3f(m1, om1, ninf);
-        }
-        const float xn = __builtin_sqrtf(xs) * 1.000001f + cmax;
-        const float bnd = xn * xn;
-        const float T = tcoef * bnd + 1e-35f * xn + 1e-37f;
-        const float gap = m2 - m1;
-        const bool proven = (gap > T) && (fabsf(m1) <= 3.0e38f) && (T <= 3.0e38f);
-
-        const uint64_t row = tile * 16 + p;
-        const bool writer = (g == 0) && (row < n);
-        if (writer) codes[row * m + s] = (uint8_t)j;
-        const bool recheck = writer && !proven;
-        const unsigned long long mask = __ballot(recheck);
-        if (mask != 0ull) {
-            const uint32_t cnt = (uint32_t)__popcll(mask);
-            const int leader = __ffsll((long long)mask) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&wl_count[s], cnt);
-            base = (uint32_t)__shfl((int)base, leader);
-            if (recheck) {
-                const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                wl_rows[(size_t)s * wl_stride + base + rank] = (uint32_t)row;
-            }
-        }
-    }
-}
-
-// ---- variant B2: A images in LDS, 16 waves per workgroup (4 per SIMD), single-pass epilogue ----
-// With min / second-min / argmin tracked in one pass, an accumulator tile dies as soon as its 4
-// values are reduced, so a wave needs ~100 registers instead of 64 accumulators + 192 operand
-// registers: four waves share each SIMD and hide each other's LDS / HBM / cross-lane latencies.
-// A wave works on TWO 16-row tiles per step so that every A fragment read from LDS (1 KiB) feeds
-// two MFMAs.
-constexpr int kB2Waves = 16;
-
-template <int SD, int NT>
-__global__ __launch_bounds__(kB2Waves * 64, 4) void k_assign_screen_bf16_lds2(
-    const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m,
-    const uint32_t *__restrict__ prepA16, const float *__restrict__ prepCn,
-    const float *__restrict__ meta, const uint32_t *__restrict__ sub_list, uint32_t n_sub,
-    uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_count,
-    uint64_t wl_stride) {
-    constexpr int DPG = SD / 4;
-    constexpr int PP = 8 / DPG;
-    constexpr int NM = (6 + PP - 1) / PP;
-    constexpr uint32_t IMG = NT * NM * 4 * 64;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];  // [ns][IMG] images, then [ns][NT*16] |c|^2
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t g = lane >> 4, p = lane & 15;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t s_first = blockIdx.y * 2;
-    const uint32_t ns = (n_sub - s_first >= 2) ? 2u : 1u;
-    const uint32_t wps = kB2Waves / ns;
-    const uint32_t ls = wave / wps, slot = wave % wps;
-    const uint32_t s = sub_list[s_first + ls];
-    float *lds_cn = reinterpret_cast<float *>(lds_raw + 2 * IMG);
-
-    for (uint32_t q = 0; q < ns; ++q) {
-        const uint32_t sq = sub_list[s_first + q];
-        const uint32_t *src = prepA16 + (size_t)sq * IMG;
-        for (uint32_t e = threadIdx.x; e < IMG; e += kB2Waves * 64) {
-            const uint32_t ln = e & 63, w = (e >> 6) & 3, blk = e >> 8;
-            lds_raw[q * IMG + blk * 256 + ln * 4 + w] = src[e];
-        }
-        const float *pc = prepCn + (size_t)sq * NT * 16;
-        for (uint32_t e = threadIdx.x; e < NT * 16; e += kB2Waves * 64) lds_cn[q * NT * 16 + e] = pc[e];
-    }
-    __syncthreads();
-    const u32x4 *la = reinterpret_cast<const u32x4 *>(lds_raw + ls * IMG) + lane;
-    const f32x4 *cnp = reinterpret_cast<const f32x4 *>(lds_cn + ls * NT * 16 + 4 * g);
-    float pinf = __builtin_inff(), ninf = -__builtin_inff();
-    asm volatile("" : "+s"(pinf), "+s"(ninf));
-    const float cmax = meta[s * 4 + 0];
-    const float tcoef = meta[s * 4 + 2];
-
-    // rows: the workgroup's chunk in steps of 32 rows, steps interleaved over the wps waves
-    const uint64_t n_steps = (n + 31) / 32;
-    const uint64_t steps_per_chunk = (n_steps + gridDim.x - 1) / gridDim.x;
-    const uint64_t st0 = (uint64_t)blockIdx.x * steps_per_chunk + slot;
-    uint64_t st1 = (uint64_t)blockIdx.x * steps_per_chunk + steps_per_chunk;
-    if (st1 > n_steps) st1 = n_steps;
-
-    const size_t col0 = (size_t)s * SD + (size_t)DPG * g;
-    auto load_x = [&](uint64_t row, float (&x)[DPG]) {
-        if (row >= n) row = n - 1;
-        const float *ptr = X + row * d + col0;
-        if constexpr (DPG == 1) {
-            x[0] = ptr[0];
-        } else if constexpr (DPG == 2) {
-            const float2 t = *reinterpret_cast<const float2 *>(ptr);
-            x[0] = t.x;
-            x[1] = t.y;
-        } else {
-#pragma unroll
-            for (int q = 0; q < DPG; q += 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(ptr + q);
-                x[q + 0] = t.x;
-                x[q + 1] = t.y;
-                x[q + 2] = t.z;
-                x[q + 3] = t.w;
-            }
-        }
-    };
-    auto make_b = [&](const float (&x)[DPG], bf16x8 (&b)[NM], float &xs) {
-        uint32_t xp[3][DPG];
-        xs = 0.0f;
-#pragma unroll
-        for (int q = 0; q < DPG; ++q) {
-            uint32_t parts[3];
-            split3(x[q], parts);
-            xp[0][q] = parts[0];
-            xp[1][q] = parts[1];
-            xp[2][q] = parts[2];
-            xs = fmaf(x[q], x[q], xs);
-        }
-#pragma unroll
-        for (int r = 0; r < NM; ++r) {
-            u32x4 v;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                uint32_t hw[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int sl = 2 * w + h, pq = sl / DPG, dd = sl % DPG, pair = r * PP + pq;
-                    hw[h] = (pair < 6) ? xp[pair_x(pair)][dd] : 0u;
-                }
-                v[w] = (hw[0] >> 16) | (hw[1] & 0xFFFF0000u);
-            }
-            b[r] = __builtin_bit_cast(bf16x8, v);
-        }
-    };
-    auto finish = [&](uint64_t row, float xs, float (&q1)[4], float (&q2)[4], uint32_t (&qi)[4]) {
-        auto merge2 = [&](float a1, float a2, uint32_t ai, float b1, float b2, uint32_t bi, float &o1, float &o2,
-                          uint32_t &oi) {
-            const float hi = __builtin_amdgcn_fmed3f(a1, b1, pinf);
-            const float lo2 = __builtin_amdgcn_fmed3f(a2, b2, ninf);
-            o2 = __builtin_amdgcn_fmed3f(hi, lo2, ninf);
-            const bool tb = b1 < a1;
-            o1 = tb ? b1 : a1;
-            oi = tb ? bi : ai;
-        };
-        float u1, u2, w1, w2, m1, m2;
-        uint32_t ui, wi, creg;
-        merge2(q1[0], q2[0], qi[0], q1[1], q2[1], qi[1], u1, u2, ui);
-        merge2(q1[2], q2[2], qi[2], q1[3], q2[3], qi[3], w1, w2, wi);
-        merge2(u1, u2, ui, w1, w2, wi, m1, m2, creg);
-        uint32_t j = ((creg & ~3u) << 2) + (creg & 3u) + 4 * g;
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-            const float om1 = __shfl_xor(m1, off);
-            const float om2 = __shfl_xor(m2, off);
-            const uint32_t oj = (uint32_t)__shfl_xor((int)j, off);
-            xs += __shfl_xor(xs, off);
-            const float hi = __builtin_amdgcn_fmed3f(m1, om1, pinf);
-            const float lo2 = __builtin_amdgcn_fmed3f(m2, om2, ninf);
-            m2 = __builtin_amdgcn_fmed3f(lo2, hi, ninf);
-            const bool take = (om1 < m1) || (om1 == m1 && oj < j);
-            j = take ? oj : j;
-            m1 = __builtin_amdgcn_fmed3f(m1, om1, ninf);
-        }
-        const float xn = __builtin_sqrtf(xs) * 1.000001f + cmax;
-        const float bnd = xn * xn;
-        const float T = tcoef * bnd + 1e-35f * xn + 1e-37f;
-        const float gap = m2 - m1;
-        const bool proven = (gap > T) && (fabsf(m1) <= 3.0e38f) && (T <= 3.0e38f);
-        const bool writer = (g == 0) && (row < n);
-        if (writer) codes[row * m + s] = (uint8_t)j;
-        const bool recheck = writer && !proven;
-        const unsigned long long mask = __ballot(recheck);
-        if (mask != 0ull) {
-            const uint32_t cnt = (uint32_t)__popcll(mask);
-            const int leader = __ffsll((long long)mask) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&wl_count[s], cnt);
-            base = (uint32_t)__shfl((int)base, leader);
-            if (recheck) {
-                const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                wl_rows[(size_t)s * wl_stride + base + rank] = (uint32_t)row;
-            }
-        }
-    };
-
-    float xa_n[DPG], xb_n[DPG];
-    if (st0 < st1) {
-        load_x(st0 * 32 + p, xa_n);
-        load_x(st0 * 32 + 16 + p, xb_n);
-    }
-    for (uint64_t st = st0; st < st1; st += wps) {
-        float xa[DPG], xb[DPG];
-#pragma unroll
-        for (int q = 0; q < DPG; ++q) {
-            xa[q] = xa_n[q];
-            xb[q] = xb_n[q];
-        }
-        if (st + wps < st1) {
-            load_x((st + wps) * 32 + p, xa_n);
-            load_x((st + wps) * 32 + 16 + p, xb_n);
-        }
-        bf16x8 ba[NM], bb[NM];
-        float xsa, xsb;
-        make_b(xa, ba, xsa);
-        make_b(xb, bb, xsb);
-
-        float qa1[4] = {pinf, pinf, pinf, pinf}, qa2[4] = {pinf, pinf, pinf, pinf};
-        float qb1[4] = {pinf, pinf, pinf, pinf}, qb2[4] = {pinf, pinf, pinf, pinf};
-        uint32_t qai[4] = {0u, 0u, 0u, 0u}, qbi[4] = {0u, 0u, 0u, 0u};
-        const u32x4 *lat = la;
-        asm volatile("" : "+v"(lat));  // keep the (loop-invariant) image reads inside the loop
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const f32x4 c0 = cnp[4 * i];
-            f32x4 accA = c0, accB = c0;
-#pragma unroll
-            for (int r = 0; r < NM; ++r) {
-                const bf16x8 af = __builtin_bit_cast(bf16x8, lat[(i * NM + r) * 64]);
-                accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ba[r], accA, 0, 0, 0);
-                accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bb[r], accB, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float va = accA[r], vb = accB[r];
-                const bool lta = va < qa1[r], ltb = vb < qb1[r];
-                qa2[r] = __builtin_amdgcn_fmed3f(qa1[r], qa2[r], va);
-                qb2[r] = __builtin_amdgcn_fmed3f(qb1[r], qb2[r], vb);
-                qa1[r] = lta ? va : qa1[r];
-                qb1[r] = ltb ? vb : qb1[r];
-                qai[r] = lta ? (uint32_t)(4 * i + r) : qai[r];
-                qbi[r] = ltb ? (uint32_t)(4 * i + r) : qbi[r];
-            }
-        }
-        finish(st * 32 + p, xsa, qa1, qa2, qai);
-        finish(st * 32 + 16 + p, xsb, qb1, qb2, qbi);
-    }
-}
-
-template <int SD, int NT>
-int launch_one_lds2(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) {
-    constexpr int DPG = SD / 4, PP = 8 / DPG, NM = (6 + PP - 1) / PP;
-    const size_t img_bytes = (size_t)NT * NM * 4 * 64 * 4;
-    const uint32_t groups = (a.n_sub + 1) / 2;
-    const size_t lds = 2 * img_bytes + 2 * (size_t)NT * 16 * 4;
-    static PerDeviceOnce attr_set;
-    if (attr_set.needed()) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign_screen_bf16_lds2<SD, NT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set.done();
-    }
-    const uint64_t n_steps = (a.n + 31) / 32;
-    uint32_t chunks = (uint32_t)num_cus() / groups;   // one 16-wave workgroup per CU
-    if (chunks < 1) chunks = 1;
-    const uint64_t max_chunks = (n_steps + 7) / 8;
-    if (chunks > max_chunks) chunks = (uint32_t)max_chunks;
-    hipLaunchKernelGGL((k_assign_screen_bf16_lds2<SD, NT>), dim3(chunks, groups), dim3(kB2Waves * 64), lds, stream,
-                       a.X, a.n, a.d, cb.m, cb.prepA16, cb.prepCn, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
-                       a.wl_count, a.wl_stride);
-    VQ_LAUNCH_CHECK("k_assign_screen_bf16_lds2");
-    return VQHIP_OK;
-}
-
-template <int SD, int NT>
-int launch_one_lds(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) {
-    constexpr int DPG = SD / 4, PP = 8 / DPG, NM = (6 + PP - 1) / PP;
-    const size_t img_bytes = (size_t)NT * NM * 4 * 64 * 4;
-    const uint32_t groups = (a.n_sub + 1) / 2;
-    const size_t lds = 2 * img_bytes;
-    static PerDeviceOnce attr_set;
-    if (attr_set.needed()) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign_screen_bf16_lds<SD, NT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set.done();
-    }
-    // workgroups per CU by LDS (at most 2: the launch bound is 2 waves/SIMD of 8-wave groups)
-    uint32_t per_cu = (uint32_t)((150 * 1024) / (lds ? lds : 1));
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 2) per_cu = 2;
-    const uint64_t n_tiles = (a.n + 15) / 16;
-    uint32_t chunks = ((uint32_t)num_cus() * per_cu) / groups;
-    if (chunks < 1) chunks = 1;
-    // a chunk needs >= 4 tiles per subspace wave set to be worth a workgroup
-    const uint64_t max_chunks = (n_tiles + 3) / 4;
-    if (chunks > max_chunks) chunks = (uint32_t)max_chunks;
-    hipLaunchKernelGGL((k_assign_screen_bf16_lds<SD, NT>), dim3(chunks, groups), dim3(kLdsWaves * 64), lds, stream,
-                       a.X, a.n, a.d, cb.m, cb.prepA16, cb.prepCn, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
-                       a.wl_count, a.wl_stride);
-    VQ_LAUNCH_CHECK("k_assign_screen_bf16_lds");
-    return VQHIP_OK;
-}
-
-template <int SD, int NT>
-int launch_one(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) {
-    const uint64_t n_tiles = (a.n + 15) / 16;
-    uint64_t want_waves = (uint64_t)num_cus() * kWavesPerBlock;  // one wave per SIMD
-    const uint64_t max_useful = n_tiles * a.n_sub;
-    if (want_waves > max_useful) want_waves = max_useful;
-    if (want_waves < a.n_sub) want_waves = a.n_sub;
-    uint32_t blocks = (uint32_t)((want_waves + kWavesPerBlock - 1) / kWavesPerBlock);
-    while ((uint64_t)blocks * kWavesPerBlock < a.n_sub) ++blocks;
-    static const bool plain = getenv("VQHIP_BF16_PLAIN") != nullptr;  // un-pipelined register variant
-    if (plain)
-        hipLaunchKernelGGL((k_assign_screen_bf16<SD, NT>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d,
-                           cb.m, cb.prepA16, cb.prepCn, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
-                           a.wl_count, a.wl_stride);
-    else
-        hipLaunchKernelGGL((k_assign_screen_bf16_pipe<SD, NT>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n,
-                           a.d, cb.m, cb.prepA16, cb.prepCn, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
-                           a.wl_count, a.wl_stride);
-    VQ_LAUNCH_CHECK("k_assign_screen_bf16");
-    return VQHIP_OK;
-}
-
 template <int SD, int NT32, int G = 1, int PVW = 0>
 int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stream, uint32_t groups_rt = 0) {
     const uint32_t groups = (G > 0) ? (uint32_t)G : groups_rt;  // G == 0: run-time group count (k > 256)
@@ -1806,12 +793,6 @@ int launch_wide(const CodebookView &cb, const AssignArgs &a, hipStream_t stream,
 }
 
 }  // namespace
-
-// true when launch_assign_screen_bf16 will take the X32 path (so only that image is needed)
-bool screen_bf16_uses_x32(uint32_t sd, uint32_t k) {
-    const char *variant = getenv("VQHIP_BF16_VARIANT");
-    return (!variant || variant[0] == 'x') && screen_bf16_x32_supported(sd, k);
-}
 
 // tiles of 32 centroids per wave and centroid groups for a shape (0 = no X32 form)
 // sub_dim of the X32 kernel that serves `sd`: itself when instantiated, the next one up for the even sub_dims in
@@ -1919,42 +900,11 @@ int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine
     return VQHIP_OK;
 }
 
-namespace {
-}  // namespace
-
-uint32_t screen_bf16_mfmas(uint32_t sd) {
-    const uint32_t dpg = sd / 4, pp = 8 / dpg;
-    return (6 + pp - 1) / pp;
-}
-
-bool screen_bf16_supported(uint32_t sd, uint32_t k) {
-    if (!screen_supported(sd, k)) return false;
-    if (!(sd == 4 || sd == 8 || sd == 16 || sd == 32)) return false;
-    uint32_t nt, ks;
-    screen_tiling(sd, k, &nt, &ks);
-    // A images: nt * NM * 4 registers must leave room in the 512-entry file
-    return nt * screen_bf16_mfmas(sd) * 4 <= 256;
-}
-
-int launch_prepare_bf16(const CodebookView &v, uint32_t *prepA16, hipStream_t stream) {
-    if (v.m == 0) return VQHIP_OK;
-    hipLaunchKernelGGL(k_prepare_bf16, dim3(v.m, 16), dim3(256), 0, stream, v.cb, v.m, v.k, v.sd, v.nt,
-                       screen_bf16_mfmas(v.sd), prepA16);
-    VQ_LAUNCH_CHECK("k_prepare_bf16");
-    return VQHIP_OK;
-}
-
 int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipStream_t stream) {
     if (a.n == 0 || a.n_sub == 0) return VQHIP_OK;
-    const bool x32_ready = cb.prepA32 && screen_bf16_x32_supported(cb.sd, cb.k);
-    if (!x32_ready && !(screen_bf16_supported(cb.sd, cb.k) && cb.prepA16))
+    if (!(cb.prepA32 && screen_bf16_x32_supported(cb.sd, cb.k)))
         return fail(VQHIP_ERR_UNSUPPORTED, "no bf16 MFMA screen for sub_dim=%u k=%u", cb.sd, cb.k);
-    if (a.metric == VQHIP_COSINE && !(cb.prepA32 && screen_bf16_uses_x32(cb.sd, cb.k)))
-        return fail(VQHIP_ERR_UNSUPPORTED, "cosine screen needs the X32 variant (sub_dim 8 or 16)");
-    // A/B knob for profiling: VQHIP_BF16_VARIANT = x32 (default) | regs | lds | lds2
-    static const char *variant = getenv("VQHIP_BF16_VARIANT");
-    const int which = !variant ? 3 : (variant[0] == 'x' ? 3 : variant[0] == 'r' ? 0 : (strcmp(variant, "lds") == 0 ? 1 : 2));
-    if (which == 3 && cb.prepA32 && screen_bf16_x32_supported(cb.sd, cb.k)) {
+    {
         uint32_t nt32 = 0, groups = 0;
         screen_bf16_x32_tiling(cb.sd, cb.k, &nt32, &groups);
 #define VQ_X32(SDV, NTV) \
@@ -1997,17 +947,6 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
 #undef VQ_X32
 #undef VQ_X32G
     }
-#define VQ_CASE(SDV, NTV)                                                              \
-    if (cb.sd == SDV && cb.nt == NTV)                                                  \
-        return which == 0   ? launch_one<SDV, NTV>(cb, a, stream)                      \
-               : which == 1 ? launch_one_lds<SDV, NTV>(cb, a, stream)                  \
-               : which == 2 ? launch_one_lds2<SDV, NTV>(cb, a, stream)                 \
-                            : launch_one<SDV, NTV>(cb, a, stream);
-    VQ_CASE(4, 1) VQ_CASE(4, 2) VQ_CASE(4, 4) VQ_CASE(4, 8) VQ_CASE(4, 16)
-    VQ_CASE(8, 1) VQ_CASE(8, 2) VQ_CASE(8, 4) VQ_CASE(8, 8) VQ_CASE(8, 16)
-    VQ_CASE(16, 1) VQ_CASE(16, 2) VQ_CASE(16, 4) VQ_CASE(16, 8) VQ_CASE(16, 16)
-    VQ_CASE(32, 1) VQ_CASE(32, 2) VQ_CASE(32, 4) VQ_CASE(32, 8)
-#undef VQ_CASE
     return fail(VQHIP_ERR_UNSUPPORTED, "no bf16 screen instantiation for sub_dim=%u tiles=%u", cb.sd, cb.nt);
 }
 

@@ -120,6 +120,39 @@ __global__ __launch_bounds__(64) void k_selftest_bf16(uint32_t trials, uint32_t 
     atomicMax(worst_bits, __float_as_uint(worst));  // non-negative floats order like their bits
 }
 
+// Probe of ONE v_mfma_f32_32x32x16_bf16: trial t computes d[t] = C + sum_k a[t][k] * b[t][k] as the
+// diagonal element (t % 32, t % 32) of a 32x32 tile, i.e. 32 independent trials per instruction (row i
+// of A and column i of B belong to trial i; the off-diagonal products are computed and ignored).
+// Operand layout: lane l holds A[i = l % 32][k = 8 (l / 32) .. + 7] and B[k = 8 (l / 32) .. + 7][j = l % 32];
+// accumulator register r of lane l is D[(r & 3) + 8 (r >> 2) + 4 (l / 32)][l % 32].
+__global__ __launch_bounds__(64) void k_mfma_probe_32x32x16(const uint16_t *__restrict__ a, const uint16_t *__restrict__ b,
+                                                            const float *__restrict__ c, uint64_t trials,
+                                                            float *__restrict__ d) {
+    const uint32_t lane = threadIdx.x, idx = lane & 31, kb = lane >> 5;
+    for (uint64_t t0 = (uint64_t)blockIdx.x * 32; t0 < trials; t0 += (uint64_t)gridDim.x * 32) {
+        const uint64_t t = t0 + idx;
+        const bool live = t < trials;
+        bf16x8 av, bv;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            av[q] = live ? (short)a[t * 16 + 8 * kb + q] : (short)0;
+            bv[q] = live ? (short)b[t * 16 + 8 * kb + q] : (short)0;
+        }
+        f32x16 cv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t row = (r & 3) + 8 * (r >> 2) + 4 * kb;
+            cv[r] = (row == idx && live) ? c[t] : 0.0f;
+        }
+        const f32x16 dres = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, cv, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t row = (r & 3) + 8 * (r >> 2) + 4 * kb;
+            if (row == idx && live) d[t] = dres[r];
+        }
+    }
+}
+
 std::mutex g_mu;
 int g_state = 0;  // 0 not run, 1 trusted, 2 refused
 float g_ratio32 = -1.0f, g_ratio16 = -1.0f;
@@ -148,6 +181,26 @@ int bf16_mfma_selftest(float *ratio32, float *ratio16, int *trusted) {
     if (ratio32) *ratio32 = g_ratio32;
     if (ratio16) *ratio16 = g_ratio16;
     if (trusted) *trusted = (g_state == 1) ? 1 : 0;
+    return VQHIP_OK;
+}
+
+// host buffers in and out; the model of the instruction's adder (tests/mfma_model.py) is checked against this
+int mfma_bf16_probe(const uint16_t *a, const uint16_t *b, const float *c, uint64_t trials, float *d) {
+    if (trials == 0) return VQHIP_OK;
+    DevBuf da, db, dc, dd;
+    VQ_TRY(da.alloc((size_t)trials * 32));
+    VQ_TRY(db.alloc((size_t)trials * 32));
+    VQ_TRY(dc.alloc((size_t)trials * 4));
+    VQ_TRY(dd.alloc((size_t)trials * 4));
+    VQ_HIP(hipMemcpy(da.p, a, (size_t)trials * 32, hipMemcpyHostToDevice));
+    VQ_HIP(hipMemcpy(db.p, b, (size_t)trials * 32, hipMemcpyHostToDevice));
+    VQ_HIP(hipMemcpy(dc.p, c, (size_t)trials * 4, hipMemcpyHostToDevice));
+    uint64_t blocks = (trials + 31) / 32;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_mfma_probe_32x32x16, dim3((uint32_t)blocks), dim3(64), 0, nullptr, da.as<uint16_t>(),
+                       db.as<uint16_t>(), dc.as<float>(), trials, dd.as<float>());
+    VQ_LAUNCH_CHECK("k_mfma_probe_32x32x16");
+    VQ_HIP(hipMemcpy(d, dd.p, (size_t)trials * 4, hipMemcpyDeviceToHost));
     return VQHIP_OK;
 }
 

@@ -338,6 +338,21 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ X
     centroids[e] = X[rows[sj] * d + (size_t)s * sd + t];
 }
 
+// sharded form: `rows` are GLOBAL ids; a rank contributes the bits of the rows it owns
+// ([row_offset, row_offset + n_local)) and zero words for the rest, so that a u32 sum over the ranks
+// carries every value bit for bit (a float sum would turn -0.0 into +0.0)
+__global__ __launch_bounds__(256) void k_gather_rows_owned(const float *__restrict__ X, uint32_t d, uint32_t m,
+                                                           uint32_t k, uint32_t sd, const uint64_t *__restrict__ rows,
+                                                           uint64_t row_offset, uint64_t n_local,
+                                                           uint32_t *__restrict__ out_bits) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * k * sd) return;
+    const uint32_t t = e % sd, sj = e / sd, s = sj / k;
+    const uint64_t r = rows[sj];
+    const bool mine = r >= row_offset && r - row_offset < n_local;
+    out_bits[e] = mine ? __float_as_uint(X[(r - row_offset) * d + (size_t)s * sd + t]) : 0u;
+}
+
 }  // namespace
 
 // sub_dims with a wave-owned instantiation (KS = sd/4 lanes per row)
@@ -526,6 +541,15 @@ int launch_gather_rows(const float *X, uint32_t d, uint32_t m, uint32_t k, uint3
     hipLaunchKernelGGL(k_gather_rows, dim3((total + 255) / 256), dim3(256), 0, stream, X, d, m, k,
                        sd, rows, centroids);
     VQ_LAUNCH_CHECK("k_gather_rows");
+    return VQHIP_OK;
+}
+
+int launch_gather_rows_owned(const float *X, uint32_t d, uint32_t m, uint32_t k, uint32_t sd, const uint64_t *rows,
+                             uint64_t row_offset, uint64_t n_local, uint32_t *out_bits, hipStream_t stream) {
+    const uint32_t total = m * k * sd;
+    hipLaunchKernelGGL(k_gather_rows_owned, dim3((total + 255) / 256), dim3(256), 0, stream, X, d, m, k, sd, rows,
+                       row_offset, n_local, out_bits);
+    VQ_LAUNCH_CHECK("k_gather_rows_owned");
     return VQHIP_OK;
 }
 

@@ -33,7 +33,6 @@ struct CodebookView {
     const float *prepCn = nullptr;   // [m][nt*16]        |c|^2 (padding = +inf)
     const float *meta = nullptr;     // [m][4]            {max|c|, margin coefficient, -, -}
     const float *cnsqrt = nullptr;   // [m][k]            sqrt(sum c^2) (cosine's norm_b)
-    const uint32_t *prepA16 = nullptr;  // [m][nt][NM][4][64] packed bf16 slices of -2*c (bf16 screen)
     const uint32_t *prepA32 = nullptr;  // [m][ceil(k/32)][NMF][4][64] same, 32x32x16 MFMA lane order
     const float *cen = nullptr;      // [m][sd+4]  X32, L2: {mu[sd], max|c-mu|, margin coefficient, -, -}
     const float *cn32 = nullptr;     // [m][ceil(k/32)*32]  X32, L2: |c-mu|^2, finite padding
@@ -47,15 +46,13 @@ void screen_tiling(uint32_t sd, uint32_t k, uint32_t *nt, uint32_t *ks);
 constexpr float kBf16AssumedUlps = 32.0f;
 // one-time device measurement of that quantity (k_selftest.hip); trusted = measured <= half the budget
 int bf16_mfma_selftest(float *ratio32, float *ratio16, int *trusted);
+// d[t] = one v_mfma_f32_32x32x16_bf16 of (a[t][0..16), b[t][0..16), c[t]); host buffers (diagnostics)
+int mfma_bf16_probe(const uint16_t *a, const uint16_t *b, const float *c, uint64_t trials, float *d);
 
 // bf16-split screen (k_screen_bf16.hip)
-bool screen_bf16_supported(uint32_t sd, uint32_t k);
-uint32_t screen_bf16_mfmas(uint32_t sd);
-int launch_prepare_bf16(const CodebookView &v, uint32_t *prepA16, hipStream_t stream);
 uint32_t x32_padded_sd(uint32_t sd);  // sub_dim of the X32 kernel serving `sd` (zero padding for 5..63), 0 = none
 bool screen_bf16_x32_supported(uint32_t sd, uint32_t k);
 void screen_bf16_x32_tiling(uint32_t sd, uint32_t k, uint32_t *nt32_per_group, uint32_t *groups);
-bool screen_bf16_uses_x32(uint32_t sd, uint32_t k);
 uint32_t screen_bf16_x32_mfmas(uint32_t sd);
 int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine, float *cbc, float *cen,
                             float *cn32, hipStream_t stream);
@@ -131,6 +128,20 @@ int launch_finalize(uint32_t m, uint32_t k, uint32_t sd, const double *slab, con
 // centroids[s][j] = X[rows[s*k+j]][s*sd ..]
 int launch_gather_rows(const float *X, uint32_t d, uint32_t m, uint32_t k, uint32_t sd,
                        const uint64_t *rows, float *centroids, hipStream_t stream);
+
+// sharded init: bits of the owned rows among global ids `rows`, zero words elsewhere
+int launch_gather_rows_owned(const float *X, uint32_t d, uint32_t m, uint32_t k, uint32_t sd, const uint64_t *rows,
+                             uint64_t row_offset, uint64_t n_local, uint32_t *out_bits, hipStream_t stream);
+
+// ---- RCCL (comm.hip): the exchange step of row-sharded training --------------------------
+struct Comm;
+int comm_unique_id(uint8_t *id128);
+int comm_create(const uint8_t *id128, int world, int rank, Comm **out);  // id128 == NULL: one rank, no RCCL
+int comm_adopt(void *nccl_comm, Comm **out);
+void comm_info(const Comm *c, int *world, int *rank);
+int comm_destroy(Comm *c);
+int comm_allreduce_f64(Comm *c, double *buf, size_t count, hipStream_t stream);
+int comm_allreduce_u32(Comm *c, uint32_t *buf, size_t count, hipStream_t stream);
 
 // ---- TSVQ -----------------------------------------------------------------------------
 // build on a device-resident matrix; outputs are HOST arrays in pre-order (see vqhip.h)

@@ -49,7 +49,9 @@ def fit_codebooks(ds: "_lib.Dataset", m: int, k: int, max_iters: int, seed: int 
     ``lbg_quantize`` (src/core/vector.rs:396-460) with the device doing each iteration.
 
     ``init_rows`` [m][k] and ``reseed_rows`` (m sequences consumed in order) replace the
-    package's own RNG draws -- this is how identical draws give reference-identical results.
+    package's own RNG draws: identical draws give the reference's assignment codes bit for bit
+    and its centroids within ``1e-5 * max(1, |c|)`` per step -- bit for bit, iteration counts
+    included, with ``exact_update=True`` (sums in the reference's row order; single GPU).
     """
     n, d = ds.n, ds.d
     # validation order and messages: src/pq.rs:106-117 then src/core/vector.rs:396-410
@@ -244,6 +246,8 @@ class ProductQuantizer:
             raise InvalidParameter("topk", f"must be between 1 and min(n, 1024), got {topk}")
         if self._distance.name() == "cosine":
             raise InvalidParameter("distance", "cosine distance is not a sum over subspaces: no ADC form")
+        if codes.size and int(codes.max()) >= self._k:  # the scan indexes its LDS tables by code
+            raise InvalidParameter("codes", f"a code is outside [0, {self._k})")
         return self._enc.adc_search(codes, q, int(topk))
 
     def decode(self, codes) -> np.ndarray:

@@ -3,9 +3,13 @@
 The reference draws them from rand 0.9's ``StdRng`` (ChaCha12) via ``choose_multiple`` /
 ``choose`` (src/core/vector.rs:412-413, 448-452).  That stream cannot be reproduced or
 verified without a Rust toolchain, so it is NOT claimed here: this is the package's own
-documented generator (SplitMix64 + Floyd sampling).  Everything downstream of the draws is
-bit-faithful to the reference, and every entry point also accepts the draws from the caller
-(``init_rows=`` / ``reseed_rows=``), which is how a Rust shim keeps ``StdRng`` on its side.
+documented generator (SplitMix64 + Floyd sampling).  Downstream of the draws the assignment
+codes are bit-identical to the reference's; the centroids are bit-identical only with
+``exact_update=True`` (sums in the reference's row order) and otherwise within
+``1e-5 * max(1, |c|)`` per Lloyd step (f64-combined chunk sums), so the
+``< 1e-6`` convergence test -- and with it the iteration count -- can differ from the crate's
+at a boundary.  Every entry point also accepts the draws from the caller (``init_rows=`` /
+``reseed_rows=``), which is how a Rust shim keeps ``StdRng`` on its side.
 """
 from __future__ import annotations
 

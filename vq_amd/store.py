@@ -127,6 +127,10 @@ class PQIndex:
                 if len(raw) != n * m * cdt.itemsize:
                     raise ValueError("truncated codes")
                 codes = np.frombuffer(raw, dtype=cdt).reshape(n, m)
+        # k_adc_scan indexes the per-query LDS tables by code: a corrupt file must not get that far
+        for r0 in range(0, n, 1 << 22):
+            if codes[r0:r0 + (1 << 22)].size and int(codes[r0:r0 + (1 << 22)].max()) >= k:
+                raise ValueError(f"corrupt index: a code is outside [0, {k})")
         names = ["squared_euclidean", "euclidean", "manhattan", "cosine"]
         self = cls.__new__(cls)
         self.codebooks = cb.reshape(m, k, sd).astype(np.float32)
