@@ -133,7 +133,7 @@ def test_native_comm_in_process_single_rank():
     n, d, m, k = 50_000, 64, 4, 32
     X = np.random.default_rng(8).random((n, d), dtype=F)
     X[33] = X[2]
-    X[9, 5] = F(-0.0)
+    X[9, 37] = F(-0.0)  # column 5 of subspace 2
     init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.int64)
     init[1, 0], init[1, 1], init[2, 3] = 2, 33, 9
     ds = _lib.Dataset.from_host(X)

@@ -94,6 +94,8 @@ SIGNATURES = {
     "vqhip_pq_adc_search_device": (C.c_int, [_vp, _vp, C.c_uint64, _f32p, C.c_uint32, C.c_uint32, _u32p, _f32p]),
     "vqhip_selftest": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "vqhip_mfma_bf16_probe": (C.c_int, [_u16p, _u16p, _f32p, C.c_uint64, _f32p]),
+    "vqhip_mfma_bf16_model": (C.c_int, [_u16p, _u16p, _f32p, C.c_uint64, _f32p]),
+    "vqhip_mfma_bf16_model_check": (C.c_int, [C.c_uint64, C.c_uint64, _u64p, _u64p]),
     "vqhip_tsvq_last_stats": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
 }
 
@@ -435,6 +437,24 @@ def mfma_bf16_probe(a_bits, b_bits, c) -> np.ndarray:
     d = np.empty(cc.shape[0], np.float32)
     check(load().vqhip_mfma_bf16_probe(ptr(a, _u16p), ptr(b, _u16p), ptr(cc, _f32p), cc.shape[0], ptr(d, _f32p)))
     return d
+
+
+def mfma_bf16_model(a_bits, b_bits, c) -> np.ndarray:
+    """the library's software model of v_mfma_f32_32x32x16_bf16 (host arithmetic): same arguments as the probe"""
+    a = np.ascontiguousarray(a_bits, np.uint16).reshape(-1, 16)
+    b = np.ascontiguousarray(b_bits, np.uint16).reshape(-1, 16)
+    cc = np.ascontiguousarray(c, np.float32).reshape(-1)
+    assert a.shape == b.shape and a.shape[0] == cc.shape[0]
+    d = np.empty(cc.shape[0], np.float32)
+    check(load().vqhip_mfma_bf16_model(ptr(a, _u16p), ptr(b, _u16p), ptr(cc, _f32p), cc.shape[0], ptr(d, _f32p)))
+    return d
+
+
+def mfma_bf16_model_check(trials: int, seed: int = 1):
+    """(mismatches, first bad trial) of model == hardware over `trials` device-generated operand sets"""
+    bad, first = C.c_uint64(0), C.c_uint64(0)
+    check(load().vqhip_mfma_bf16_model_check(int(trials), int(seed), C.byref(bad), C.byref(first)))
+    return int(bad.value), int(first.value)
 
 
 def synchronize():

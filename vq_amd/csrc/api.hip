@@ -583,6 +583,21 @@ int vqhip_mfma_bf16_probe(const uint16_t *a, const uint16_t *b, const float *c, 
     VQ_API_END
 }
 
+int vqhip_mfma_bf16_model(const uint16_t *a, const uint16_t *b, const float *c, uint64_t trials, float *d) {
+    VQ_API_BEGIN
+    if (trials && (!a || !b || !c || !d)) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    mfma_bf16_model_host(a, b, c, trials, d);  // pure integer model of one instruction: needs no device
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_mfma_bf16_model_check(uint64_t trials, uint64_t seed, uint64_t *mismatches, uint64_t *first_bad_trial) {
+    VQ_API_BEGIN
+    VQ_TRY(require_gfx950());
+    return mfma_bf16_model_check(trials, seed, mismatches, first_bad_trial);
+    VQ_API_END
+}
+
 int vqhip_synchronize(void) {
     VQ_TRY(require_gfx950());
     hipStream_t s;
