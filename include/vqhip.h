@@ -103,6 +103,10 @@ int vqhip_mfma_bf16_model(const uint16_t *a, const uint16_t *b, const float *c, 
 /* model == hardware on `trials` operand sets generated on the device from `seed` (eight families that
  * reach every branch of the model); *mismatches must be 0, *first_bad_trial names the first failure. */
 int vqhip_mfma_bf16_model_check(uint64_t trials, uint64_t seed, uint64_t *mismatches, uint64_t *first_bad_trial);
+/* the same run, reporting up to `cap` failing trial numbers; and the operand set (a[16], b[16], *c) that the
+ * check generates for one (seed, trial), on the host: together they reproduce a reported failure */
+int vqhip_mfma_bf16_model_failures(uint64_t trials, uint64_t seed, uint64_t *trial_ids, uint32_t cap, uint64_t *n_failures);
+int vqhip_mfma_bf16_model_case(uint64_t seed, uint64_t trial, uint16_t *a, uint16_t *b, float *c);
 /* statistics of the most recent assign/encode launch of this thread: rows sent to the
  * exact re-check, and the engine used (VQHIP_ENGINE_EXACT / _MFMA) */
 int vqhip_last_assign_stats(uint64_t *rechecked, int *engine);

@@ -122,6 +122,35 @@ def family_top(rng, t):
     return a, b, c.astype(np.float32)
 
 
+def family_far(rng, t):
+    """C in [1, 2) (either sign), every product 16..39 binades below it: how far down the adder still sees the products"""
+    g = rng.integers(16, 37, t)
+    e = -(g[:, None] + rng.integers(0, 4, (t, 16)))
+    ea = np.floor_divide(e, 2)
+    sign_c = rng.integers(0, 2, t)
+    same = rng.random(t) < 0.5
+    sa = np.where(same[:, None], sign_c[:, None], rng.integers(0, 2, (t, 16)))
+    a = bf16(sa, ea, rng.integers(0, 128, (t, 16)))
+    b = bf16(np.zeros((t, 16), np.int64), e - ea, rng.integers(0, 128, (t, 16)))
+    c = f32_from(sign_c, np.zeros(t, np.int64), rng.integers(0, 1 << 23, t))
+    return a, b, c.astype(np.float32)
+
+
+def family_cancel1(rng, t):
+    """C just above a power of two, products of the opposite sign 7..14 binades below that take the sum under it:
+    the sum loses its leading bit and the bits below the aligned frame come into view"""
+    j = rng.integers(0, 8, t)
+    sign_c = rng.integers(0, 2, t)
+    e = -(7 + j[:, None] + rng.integers(0, 3, (t, 16)))
+    ea = np.floor_divide(e, 2)
+    a = bf16(np.broadcast_to(1 - sign_c[:, None], (t, 16)), ea, rng.integers(64, 128, (t, 16)))
+    b = bf16(np.zeros((t, 16), np.int64), e - ea, rng.integers(64, 128, (t, 16)))
+    live = rng.random((t, 16)) < 0.7
+    a = np.where(live, a, np.uint16(0))
+    c = f32_from(sign_c, np.zeros(t, np.int64), rng.integers(0, 1 << 12, t) << rng.integers(0, 8, t))
+    return a, b, c.astype(np.float32)
+
+
 def all_families(rng, scale=1.0):
     """(name, (a, b, c)) for every family; `scale` multiplies the trial counts of the discovery run"""
     n = lambda x: max(64, int(x * scale))
@@ -132,5 +161,6 @@ def all_families(rng, scale=1.0):
     fams += [("dense8_c0", family_dense(rng, n(30_000), 8, "zero")), ("dense20_ctop", family_dense(rng, n(30_000), 20, "top")),
              ("pos_small_8_30", family_same_sign_small(rng, n(40_000), 8, 30)),
              ("pos_small_20_28", family_same_sign_small(rng, n(20_000), 20, 28)), ("tiny", family_tiny(rng, n(30_000))),
-             ("carry", family_carry(rng, n(40_000))), ("cancel", family_cancel(rng, n(30_000))), ("top", family_top(rng, n(10_000)))]
+             ("carry", family_carry(rng, n(40_000))), ("cancel", family_cancel(rng, n(30_000))), ("top", family_top(rng, n(10_000))),
+             ("far", family_far(rng, n(60_000))), ("cancel1", family_cancel1(rng, n(60_000)))]
     return fams

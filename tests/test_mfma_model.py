@@ -1,6 +1,6 @@
 """The software model of v_mfma_f32_32x32x16_bf16's adder, without a GPU:
-  * tests/golden/mfma_hw_probe.npz holds REAL hardware results (7 000 operand sets, a seeded subsample of
-    the 570 000-probe discovery run on an MI355X, tools/mfma_discover.py): the library's C++ model
+  * tests/golden/mfma_hw_probe.npz holds REAL hardware results (7 800 operand sets, a seeded subsample of
+    the 810 000-probe discovery runs on an MI355X, tools/mfma_discover.py): the library's C++ model
     (vq_amd/csrc/mfma_model.hpp through vqhip_mfma_bf16_model) and the independent Python statement
     (tests/mfma_model.py) must both reproduce every bit;
   * on fresh operand sets of every family the two statements must agree with each other;
@@ -30,7 +30,7 @@ def lib():
 def test_models_reproduce_recorded_hardware_results(lib):
     z = np.load(GOLD)
     fams = sorted({k.rsplit("_", 1)[0] for k in z.files})
-    assert len(fams) == 14
+    assert len(fams) == 20  # 19 probe families + the 185 operand sets an earlier model got wrong
     for f in fams:
         a, b, c, d = z[f + "_a"], z[f + "_b"], z[f + "_c"], z[f + "_d"]
         assert same_bits(lib.mfma_bf16_model(a, b, c), d).all(), f

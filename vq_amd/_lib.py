@@ -96,6 +96,8 @@ SIGNATURES = {
     "vqhip_mfma_bf16_probe": (C.c_int, [_u16p, _u16p, _f32p, C.c_uint64, _f32p]),
     "vqhip_mfma_bf16_model": (C.c_int, [_u16p, _u16p, _f32p, C.c_uint64, _f32p]),
     "vqhip_mfma_bf16_model_check": (C.c_int, [C.c_uint64, C.c_uint64, _u64p, _u64p]),
+    "vqhip_mfma_bf16_model_failures": (C.c_int, [C.c_uint64, C.c_uint64, _u64p, C.c_uint32, _u64p]),
+    "vqhip_mfma_bf16_model_case": (C.c_int, [C.c_uint64, C.c_uint64, _u16p, _u16p, _f32p]),
     "vqhip_tsvq_last_stats": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
 }
 
@@ -455,6 +457,20 @@ def mfma_bf16_model_check(trials: int, seed: int = 1):
     bad, first = C.c_uint64(0), C.c_uint64(0)
     check(load().vqhip_mfma_bf16_model_check(int(trials), int(seed), C.byref(bad), C.byref(first)))
     return int(bad.value), int(first.value)
+
+
+def mfma_bf16_model_failures(trials: int, seed: int, cap: int = 4096):
+    """(number of failures, trial ids of the first `cap`) of the device-side model check"""
+    ids = np.zeros(cap, np.uint64)
+    n = C.c_uint64(0)
+    check(load().vqhip_mfma_bf16_model_failures(int(trials), int(seed), ptr(ids, _u64p), cap, C.byref(n)))
+    return int(n.value), ids[:min(int(n.value), cap)]
+
+
+def mfma_bf16_model_case(seed: int, trial: int):
+    a, b, c = np.zeros(16, np.uint16), np.zeros(16, np.uint16), np.zeros(1, np.float32)
+    check(load().vqhip_mfma_bf16_model_case(int(seed), int(trial), ptr(a, _u16p), ptr(b, _u16p), ptr(c, _f32p)))
+    return a, b, c
 
 
 def synchronize():

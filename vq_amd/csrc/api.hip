@@ -594,8 +594,22 @@ int vqhip_mfma_bf16_model(const uint16_t *a, const uint16_t *b, const float *c, 
 int vqhip_mfma_bf16_model_check(uint64_t trials, uint64_t seed, uint64_t *mismatches, uint64_t *first_bad_trial) {
     VQ_API_BEGIN
     VQ_TRY(require_gfx950());
-    return mfma_bf16_model_check(trials, seed, mismatches, first_bad_trial);
+    return mfma_bf16_model_check(trials, seed, mismatches, first_bad_trial, nullptr, 0);
     VQ_API_END
+}
+
+int vqhip_mfma_bf16_model_failures(uint64_t trials, uint64_t seed, uint64_t *trial_ids, uint32_t cap, uint64_t *n_failures) {
+    VQ_API_BEGIN
+    if (!trial_ids || !n_failures) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    VQ_TRY(require_gfx950());
+    return mfma_bf16_model_check(trials, seed, n_failures, nullptr, trial_ids, cap);
+    VQ_API_END
+}
+
+int vqhip_mfma_bf16_model_case(uint64_t seed, uint64_t trial, uint16_t *a, uint16_t *b, float *c) {
+    if (!a || !b || !c) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    mfma_bf16_model_case(seed, trial, a, b, c);
+    return VQHIP_OK;
 }
 
 int vqhip_synchronize(void) {

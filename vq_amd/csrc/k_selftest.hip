@@ -6,6 +6,7 @@
 // the model (k_mfma_model_check: generated operand sets over eight families, bit equality).  It also still
 // measures the worst error ratio of both bf16 MFMA shapes against exact f64 sums (reported by
 // vqhip_selftest).  A device that deviates is refused the bf16 engine (AUTO falls back to the fp32 MFMA screen).
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -20,13 +21,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ inline uint64_t mix64(uint64_t z) {
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-__device__ inline float bf16_value(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__host__ __device__ inline float bits_float(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__host__ __device__ inline uint32_t float_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+__host__ __device__ inline float bf16_value(uint16_t h) { return bits_float((uint32_t)h << 16); }
 __device__ inline uint16_t make_bf16(uint32_t sign, int exp2, uint32_t mant7) {  // (1 + mant7/128) * 2^exp2
     return (uint16_t)((sign << 15) | ((uint32_t)(exp2 + 127) << 7) | (mant7 & 127u));
 }
@@ -159,15 +170,15 @@ __global__ __launch_bounds__(64) void k_mfma_probe_32x32x16(const uint16_t *__re
 // mfma_model.hpp: dense sums over 2..44 binades, sparse sums, dominant C with sub-ulp addends, C with a
 // nearly full significand 5..10 binades above the products (33-bit sums), cancellation, operands at the
 // bottom of the range (subnormal inputs and results), at the top (overflow), and small negative C.
-__device__ inline uint16_t mk_bf16(uint32_t sign, int e_field, uint32_t mant7) {
+__host__ __device__ inline uint16_t mk_bf16(uint32_t sign, int e_field, uint32_t mant7) {
     e_field = e_field < 0 ? 0 : (e_field > 254 ? 254 : e_field);
     return (uint16_t)((sign << 15) | ((uint32_t)e_field << 7) | (mant7 & 127u));
 }
-__device__ inline float mk_f32(uint32_t sign, int e_field, uint32_t mant23) {
+__host__ __device__ inline float mk_f32(uint32_t sign, int e_field, uint32_t mant23) {
     e_field = e_field < 0 ? 0 : (e_field > 254 ? 254 : e_field);
-    return __uint_as_float((sign << 31) | ((uint32_t)e_field << 23) | (mant23 & 0x7FFFFFu));
+    return bits_float((sign << 31) | ((uint32_t)e_field << 23) | (mant23 & 0x7FFFFFu));
 }
-__device__ void model_case_operand(uint64_t seed, uint64_t trial, uint32_t k, uint16_t *a, uint16_t *b) {
+__host__ __device__ void model_case_operand(uint64_t seed, uint64_t trial, uint32_t k, uint16_t *a, uint16_t *b) {
     const uint32_t fam = (uint32_t)(trial & 7u);
     const uint64_t ht = mix64(seed ^ (trial * 0x9E3779B97F4A7C15ull));
     const uint64_t h = mix64(ht ^ ((uint64_t)(k + 1) << 40));
@@ -196,7 +207,7 @@ __device__ void model_case_operand(uint64_t seed, uint64_t trial, uint32_t k, ui
     *a = live ? mk_bf16(sa, ea, ma) : (uint16_t)0;
     *b = mk_bf16(sb, eb, mb);
 }
-__device__ float model_case_c(uint64_t seed, uint64_t trial) {
+__host__ __device__ float model_case_c(uint64_t seed, uint64_t trial) {
     const uint32_t fam = (uint32_t)(trial & 7u);
     const uint64_t ht = mix64(seed ^ (trial * 0x9E3779B97F4A7C15ull));
     const uint64_t h = mix64(ht ^ 0xC0FFEEull);
@@ -211,7 +222,7 @@ __device__ float model_case_c(uint64_t seed, uint64_t trial) {
             uint16_t a, b;
             model_case_operand(seed, trial, 0, &a, &b);
             const float p = bf16_value(a) * bf16_value(b);
-            return ((h >> 1) & 1u) ? -p : __uint_as_float(__float_as_uint(-p) ^ (uint32_t)((h >> 2) & 3u));
+            return ((h >> 1) & 1u) ? -p : bits_float(float_bits(-p) ^ (uint32_t)((h >> 2) & 3u));
         }
         case 5: return ((h >> 1) & 1u) ? 0.0f : mk_f32(sc, (int)((h >> 32) % 20), m23);  // incl. subnormal C
         case 6: return mk_f32(0, 240 + (int)((h >> 32) % 14), m23);
@@ -219,7 +230,8 @@ __device__ float model_case_c(uint64_t seed, uint64_t trial) {
     }
 }
 
-__global__ __launch_bounds__(64) void k_mfma_model_check(uint64_t trials, uint64_t seed, unsigned long long *out) {
+__global__ __launch_bounds__(64) void k_mfma_model_check(uint64_t trials, uint64_t seed, unsigned long long *out,
+                                                         unsigned long long *fail_ids, uint32_t fail_cap) {
     __shared__ float hw[32];
     const uint32_t lane = threadIdx.x, idx = lane & 31, kb = lane >> 5;
     unsigned long long bad = 0, first = ~0ull;
@@ -251,6 +263,10 @@ __global__ __launch_bounds__(64) void k_mfma_model_check(uint64_t trials, uint64
             if (!same) {
                 ++bad;
                 if (t < first) first = t;
+                if (fail_ids) {
+                    const unsigned long long slot = atomicAdd(&out[2], 1ull);
+                    if (slot < fail_cap) fail_ids[slot] = t;
+                }
             }
         }
         __syncthreads();
@@ -288,7 +304,7 @@ int bf16_mfma_selftest(float *ratio32, float *ratio16, int *trusted) {
         // 2^22 generated operand sets, every branch of the model, zero mismatches -- or the bf16 engine is
         // refused (AUTO then uses the fp32 MFMA screen).  The measured ratios above are reported only.
         uint64_t bad = 1, first = 0;
-        const int rc = mfma_bf16_model_check(1ull << 22, 0x5EEDull, &bad, &first);
+        const int rc = mfma_bf16_model_check(1ull << 22, 0x5EEDull, &bad, &first, nullptr, 0);
         if (rc != VQHIP_OK) return rc;
         g_state = (bad == 0 && g_ratio32 <= kBf16ModelUlps) ? 1 : 2;
     }
@@ -299,21 +315,33 @@ int bf16_mfma_selftest(float *ratio32, float *ratio16, int *trusted) {
 }
 
 // model == hardware over `trials` generated operand sets; *mismatches must come back 0
-int mfma_bf16_model_check(uint64_t trials, uint64_t seed, uint64_t *mismatches, uint64_t *first_bad) {
-    unsigned long long *dev = nullptr;
-    VQ_HIP(hipMalloc(&dev, 16));
-    const unsigned long long init[2] = {0ull, ~0ull};
-    VQ_HIP(hipMemcpy(dev, init, 16, hipMemcpyHostToDevice));
+int mfma_bf16_model_check(uint64_t trials, uint64_t seed, uint64_t *mismatches, uint64_t *first_bad, uint64_t *fail_ids,
+                          uint32_t fail_cap) {
+    DevBuf dev, ids;
+    VQ_TRY(dev.alloc(24));
+    if (fail_ids && fail_cap) VQ_TRY(ids.alloc((size_t)fail_cap * 8));
+    const unsigned long long init[3] = {0ull, ~0ull, 0ull};
+    VQ_HIP(hipMemcpy(dev.p, init, 24, hipMemcpyHostToDevice));
     uint64_t blocks = (trials + 31) / 32;
     if (blocks > 16384) blocks = 16384;
-    if (blocks) hipLaunchKernelGGL(k_mfma_model_check, dim3((uint32_t)blocks), dim3(64), 0, nullptr, trials, seed, dev);
-    unsigned long long res[2] = {0, 0};
-    const hipError_t e = hipMemcpy(res, dev, 16, hipMemcpyDeviceToHost);
-    (void)hipFree(dev);
-    if (e != hipSuccess) return fail(VQHIP_ERR_RUNTIME, "bf16 MFMA model check: %s", hipGetErrorString(e));
+    if (blocks)
+        hipLaunchKernelGGL(k_mfma_model_check, dim3((uint32_t)blocks), dim3(64), 0, nullptr, trials, seed,
+                           dev.as<unsigned long long>(), ids.as<unsigned long long>(), ids.p ? fail_cap : 0u);
+    unsigned long long res[3] = {0, 0, 0};
+    VQ_HIP(hipMemcpy(res, dev.p, 24, hipMemcpyDeviceToHost));
     if (mismatches) *mismatches = res[0];
     if (first_bad) *first_bad = res[1];
+    if (ids.p) {
+        const size_t n = (size_t)std::min<unsigned long long>(res[2], fail_cap);
+        if (n) VQ_HIP(hipMemcpy(fail_ids, ids.p, n * 8, hipMemcpyDeviceToHost));
+    }
     return VQHIP_OK;
+}
+
+// the operand set the device check generates for (seed, trial): for looking at a reported failure
+void mfma_bf16_model_case(uint64_t seed, uint64_t trial, uint16_t *a, uint16_t *b, float *c) {
+    for (uint32_t k = 0; k < 16; ++k) model_case_operand(seed, trial, k, &a[k], &b[k]);
+    *c = model_case_c(seed, trial);
 }
 
 // the software model itself, on the host (tests compare it with an independent Python statement)

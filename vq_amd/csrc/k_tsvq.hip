@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void k_tsvq_gather_f16(const float *__restrict
 // reference's bit pattern; only the schedule differs.
 constexpr uint32_t kFsTile = 512;        // rows per tile
 constexpr uint32_t kFsCols = 32;         // columns per workgroup (one 128-byte line per row)
-constexpr uint32_t kFsMinRows = 16384;   // shorter nodes keep the plain sequential kernel
+constexpr uint32_t kFsMinRows = 3072;    // shorter nodes keep the plain sequential kernel (every tile of a short node is re-added)
 
 struct FsTile {
     uint32_t node, t;      // node id, tile index inside the node
@@ -845,8 +845,50 @@ __global__ __launch_bounds__(1024) void k_fs_prefix(uint32_t d, const uint32_t *
     }
 }
 
+// Variance pass: its guess needs no pass over the rows.  The mean pass left S1 = sum (x - m0) and S2 = sum (x - m0)^2
+// per (tile, column), m0 = the node's first row (so that the moments are O(sigma) whatever the data's offset), and
+//     sum over the tile of (x - mu)^2  =  S2 - 2 delta S1 + rows delta^2,      delta = mu - m0,
+// evaluated in f64 -- good to ~1e-6 relative against the f32 (x - mu)^2 terms the chain will add, ample for a
+// binade guess.  Exclusive prefix over the node's tiles as in k_fs_prefix.
+__global__ __launch_bounds__(1024) void k_fs_prefix_var(const float *__restrict__ X, uint32_t d,
+                                                        const uint32_t *__restrict__ perm,
+                                                        const uint32_t *__restrict__ fast_nodes,
+                                                        const uint32_t *__restrict__ tile_base,
+                                                        const uint32_t *__restrict__ n_tiles_of, NodeArrays na,
+                                                        const double2 *__restrict__ tile_mom,
+                                                        double *__restrict__ tile_sum) {
+    __shared__ double part[32][kFsCols + 1];
+    const uint32_t c = blockIdx.y * kFsCols + (threadIdx.x & 31), lt = threadIdx.x >> 5;
+    const uint32_t node = fast_nodes[blockIdx.x];
+    const uint32_t base = tile_base[blockIdx.x], nt = n_tiles_of[blockIdx.x], len = na.seg_len[node];
+    const uint32_t chunk = (nt + 31) / 32, t0 = lt * chunk, t1 = min(nt, t0 + chunk);
+    const bool col_ok = c < d;
+    double delta = 0.0;
+    if (col_ok) delta = (double)na.centroid[(size_t)node * d + c] - (double)X[(size_t)perm[na.seg_start[node]] * d + c];
+    auto tile_q = [&](uint32_t t) {
+        const double2 m = tile_mom[(size_t)(base + t) * d + c];
+        const double rows = (double)min(kFsTile, len - t * kFsTile);
+        return m.y - 2.0 * delta * m.x + rows * delta * delta;
+    };
+    double local = 0.0;
+    if (col_ok)
+        for (uint32_t t = t0; t < t1; ++t) local += tile_q(t);
+    part[lt][threadIdx.x & 31] = local;
+    __syncthreads();
+    if (!col_ok) return;
+    double run = 0.0;
+    for (uint32_t q = 0; q < lt; ++q) run += part[q][threadIdx.x & 31];
+    for (uint32_t t = t0; t < t1; ++t) {
+        tile_sum[(size_t)(base + t) * d + c] = run;
+        run += tile_q(t);
+    }
+}
+
 struct FsAcc {  // transducer summary of a run of rows: for even / odd incoming S
     long long d[2], lo[2], hi[2];
+};
+struct FsSeg {  // the same for one 64-row segment: everything fits 32 bits (|q| < 2^24 is enforced)
+    int32_t d[2], lo[2], hi[2];
 };
 
 // summaries of all tiles in parallel, under the binade guessed from the f64 prefix.  Persistent workgroups
@@ -862,12 +904,14 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
                                                       const FsTile *__restrict__ tiles, uint32_t n_items, NodeArrays na,
                                                       const double *__restrict__ tile_pref,
                                                       FsSumm *__restrict__ summ, float *__restrict__ side,
-                                                      uint32_t side_cap, uint32_t *__restrict__ side_count) {
+                                                      uint32_t side_cap, uint32_t *__restrict__ side_count,
+                                                      double2 *__restrict__ tile_mom) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fs_lds[];
     float(*lds_v)[kFsTile + 1] = reinterpret_cast<float(*)[kFsTile + 1]>(fs_lds);             // [32][513]
-    FsAcc(*seg_acc)[kFsCols] = reinterpret_cast<FsAcc(*)[kFsCols]>(fs_lds + kFsCols * (kFsTile + 1) * 4);  // [8][32]
+    FsSeg(*seg_acc)[kFsCols] = reinterpret_cast<FsSeg(*)[kFsCols]>(fs_lds + kFsCols * (kFsTile + 1) * 4);  // [8][32]
     __shared__ int seg_bad[8][kFsCols];
     __shared__ int col_slot[kFsCols];
+    __shared__ float2 seg_mom[8][kFsCols];  // MODE 0: sum (x - m0), sum (x - m0)^2 of a segment (the variance pass's guess)
     const uint32_t ncb = (d + kFsCols - 1) / kFsCols;  // the last column block may be short (d % 4 == 0)
     const uint32_t q = threadIdx.x & 7, rr = threadIdx.x >> 3;     // load role: 16-byte part q of rows rr + 32 i
     const uint32_t cl = threadIdx.x & 31, seg = threadIdx.x >> 5;  // fold role: column cl, rows 64 seg ..
@@ -877,8 +921,11 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
     float4 v[16];
     float mu4[4] = {0.f, 0.f, 0.f, 0.f};
     double pref;
+    uint32_t row0 = 0;   // MODE 0: the node's first row; its values m0 centre the moments
+    float m0 = 0.0f, m0_next = 0.0f;
     auto issue_perm = [&](const FsTile &t, uint32_t it) {  // indices, means and the f64 guess of item `it`
         const uint32_t tid = it / ncb, c0n = (it - tid * ncb) * kFsCols;
+        if (MODE == 0) row0 = perm[na.seg_start[t.node]];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const uint32_t r = rr + 32 * i;
@@ -898,10 +945,12 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
         const uint32_t cq = (c0n + 4 * q < d) ? c0n + 4 * q : c0n;
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (size_t)prow[i] * d + cq);
+        if (MODE == 0) m0_next = X[(size_t)row0 * d + ((c0n + cl < d) ? c0n + cl : c0n)];
     };
     FsTile tl = tiles[item / ncb];
     issue_perm(tl, item);
     issue_rows(item);
+    m0 = m0_next;
     uint32_t next = item + gridDim.x;
     FsTile tl_next = tiles[(next < n_items ? next : item) / ncb];
   for (;;) {
@@ -933,15 +982,46 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
     // scale = 2^(23-e): needs a normal guess and a representable power of two
     bool bad = (ge == 0u) || (ge == 255u) || (23 - e > 126) || (23 - e < -126);
     const float scale = bad ? 1.0f : __uint_as_float((uint32_t)(23 - e + 127) << 23);
-    const float scale2 = scale + scale;  // 2^(24-e): exact (23 - e <= 126 was checked)
     // per 64-row segment everything fits 32 bits: |q| < 2^24 is enforced (an addend of 2 s or more
     // cannot leave s in its binade), so |prefix| < 2^30
     int32_t dd[2] = {0, 0}, lo[2] = {0, 0}, hi[2] = {0, 0};
-    // 64 addends per thread, 8 LDS reads in flight; branch-free (the loop was latency-bound on one ds_read per
-    // iteration plus a divergent branch on the sign: 265 us per pass at 1M x 128)
     const uint32_t i0 = seg * 64;
     int badi = bad ? 1 : 0;
-    auto fold = [&](uint32_t ib0, uint32_t ib1) {
+    // Fast fold, ONE stream: with q = x / ulp(s) and S = s / ulp(s) an integer, fl(s + x) / ulp = S + rne(q)
+    // whenever q is not exactly half-way between two integers -- whatever the parity of S.  So the two parity
+    // streams of the transducer coincide until a tie shows up, and a tie-free segment (all of them on continuous
+    // data; the test is exact: q - rne(q) = +-1/2) costs 10 VALU operations per addend instead of 27.  A segment
+    // that does hold a tie is folded again by the two-stream code below.
+    int32_t d1 = 0, lo1 = 0, hi1 = 0;
+    float tmax = 0.0f, sy = 0.0f, sy2 = 0.0f;
+    uint32_t imax = 0u;
+    auto fold1 = [&](uint32_t ib0, uint32_t ib1) {
+#pragma unroll 1
+    for (uint32_t ib = ib0; ib < ib1; ib += 8) {
+      float qv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) qv[u] = lds_v[cl][i0 + ib + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float qq = qv[u] * scale;                 // exact (power of two) unless it overflows: caught by imax
+        const float r = __builtin_rintf(qq);            // v_rndne_f32
+        tmax = fmaxf(tmax, fabsf(qq - r));              // qq - r is exact; a NaN is caught by imax
+        imax = max(imax, __float_as_uint(qq) & 0x7FFFFFFFu);
+        d1 += (int32_t)r;
+        lo1 = min(lo1, d1);
+        hi1 = max(hi1, d1);
+        if (MODE == 0) {                                // f32 moments of the segment around the node's first row
+            const float y = qv[u] - m0;
+            sy = sy + y;
+            sy2 = __builtin_fmaf(y, y, sy2);
+        }
+      }
+    }
+    };
+    // two streams (even / odd incoming S), exact tie handling; 64 addends per thread, 8 LDS reads in flight,
+    // branch-free
+    const float scale2 = scale + scale;  // 2^(24-e): exact (23 - e <= 126 was checked)
+    auto fold2 = [&](uint32_t ib0, uint32_t ib1) {
 #pragma unroll 1
     for (uint32_t ib = ib0; ib < ib1; ib += 8) {
       float qv[8];
@@ -971,25 +1051,54 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
       }
     }
     };
-    fold(0, 32);
+    fold1(0, 32);
     if (has_next) issue_rows(next);  // the perm indices issued above have arrived by now
-    fold(32, 64);
+    fold1(32, 64);
+    if (imax >= 0x4B800000u) badi = 1;  // |q| >= 2^24, inf or NaN: cannot stay in the binade
+    if (!badi && tmax == 0.5f) {         // a tie in this segment: the exact two-stream fold
+        fold2(0, 64);
+    } else {
+        dd[0] = dd[1] = d1;
+        lo[0] = lo[1] = lo1;
+        hi[0] = hi[1] = hi1;
+    }
     bad = badi != 0;
-    FsAcc acc;
+    FsSeg acc;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         acc.d[p] = dd[p];
         acc.lo[p] = lo[p];
         acc.hi[p] = hi[p];
     }
+    if (MODE == 0) seg_mom[seg][cl] = make_float2(sy, sy2);
     seg_acc[seg][cl] = acc;
     seg_bad[seg][cl] = bad ? 1 : 0;
     __syncthreads();
     if (seg == 0) {
-        FsAcc f = seg_acc[0][threadIdx.x];
+        auto widen = [](const FsSeg &x) {
+            FsAcc w;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                w.d[p] = x.d[p];
+                w.lo[p] = x.lo[p];
+                w.hi[p] = x.hi[p];
+            }
+            return w;
+        };
+        if (MODE == 0 && tile_mom && c < d) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int g = 0; g < 8; ++g) {
+                a1 += (double)seg_mom[g][threadIdx.x].x;
+                a2 += (double)seg_mom[g][threadIdx.x].y;
+            }
+            // rows past the node's end were parked as +0 and entered the moments as (0 - m0): take them out
+            const double pad = (double)(kFsTile - rows), m0d = (double)m0;
+            tile_mom[(size_t)tile_id * d + c] = make_double2(a1 + pad * m0d, a2 - pad * m0d * m0d);
+        }
+        FsAcc f = widen(seg_acc[0][threadIdx.x]);
         int anybad = seg_bad[0][threadIdx.x];
         for (int g = 1; g < 8; ++g) {  // f then g, in row order
-            const FsAcc gg = seg_acc[g][threadIdx.x];
+            const FsAcc gg = widen(seg_acc[g][threadIdx.x]);
             anybad |= seg_bad[g][threadIdx.x];
             FsAcc h;
 #pragma unroll
@@ -1047,6 +1156,7 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
     next = next2;
     tl = tl_next;
     tl_next = tl_next2;
+    m0 = m0_next;
   }
 }
 
@@ -1292,10 +1402,10 @@ struct TsvqBuildWs {
     int device = -1;
     DevBuf b_perm[2], b_nodeof[2], b_vals, b_flags, b_scan, b_bsums, b_hist, b_lvl;
     DevBuf b_seg_start, b_seg_len, b_split, b_nv, b_nleft, b_median, b_selp, b_selr, b_child, b_cent, b_var;
-    DevBuf b_fs_tiles, b_fs_nodes, b_fs_base, b_fs_nt, b_fs_sum, b_fs_summ, b_lvl_slow, b_fs_fb, b_fs_side;
+    DevBuf b_fs_tiles, b_fs_nodes, b_fs_base, b_fs_nt, b_fs_sum, b_fs_summ, b_lvl_slow, b_fs_fb, b_fs_side, b_fs_mom;
     char *arena_base = nullptr;
     size_t arena_cap = 0;
-    DevBuf *all[30] = {&b_perm[0], &b_perm[1], &b_nodeof[0], &b_nodeof[1], &b_vals, &b_flags, &b_scan, &b_bsums, &b_hist,
+    DevBuf *all[31] = {&b_fs_mom, &b_perm[0], &b_perm[1], &b_nodeof[0], &b_nodeof[1], &b_vals, &b_flags, &b_scan, &b_bsums, &b_hist,
                        &b_lvl, &b_seg_start, &b_seg_len, &b_split, &b_nv, &b_nleft, &b_median, &b_selp, &b_selr, &b_child,
                        &b_cent, &b_var, &b_fs_tiles, &b_fs_nodes, &b_fs_base, &b_fs_nt, &b_fs_sum, &b_fs_summ, &b_lvl_slow,
                        &b_fs_fb, &b_fs_side};
@@ -1431,7 +1541,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     // emulation (k_fs_*), the rest through the plain chain kernel
     DevBuf &b_fs_tiles = ws.b_fs_tiles, &b_fs_nodes = ws.b_fs_nodes, &b_fs_base = ws.b_fs_base, &b_fs_nt = ws.b_fs_nt,
            &b_fs_sum = ws.b_fs_sum, &b_fs_summ = ws.b_fs_summ, &b_lvl_slow = ws.b_lvl_slow, &b_fs_fb = ws.b_fs_fb,
-           &b_fs_side = ws.b_fs_side;
+           &b_fs_side = ws.b_fs_side, &b_fs_mom = ws.b_fs_mom;
     VQ_TRY(b_fs_fb.ensure(8));  // [0] tile re-additions (diagnostic), [1] side-buffer slots handed out
     VQ_HIP(hipMemsetAsync(b_fs_fb.p, 0, 8, stream));
     static const char *nopark = getenv("VQHIP_TSVQ_NOPARK");
@@ -1449,9 +1559,12 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             fs_attr.done();
         }
     }
+    std::vector<uint32_t> mom_fast;  // the emulated nodes of the last mean pass: its tile numbering is the moments'
     auto colsum = [&](int mode, const std::vector<uint32_t> &ids, const uint32_t *perm) -> int {
         std::vector<uint32_t> slow, fast;
         for (uint32_t id : ids) ((can_fast && nodes[id].len >= kFsMinRows) ? fast : slow).push_back(id);
+        const bool moments_match = (mode == 1) && (fast == mom_fast);
+        if (mode == 0) mom_fast = fast;
         std::vector<FsTile> tiles;
         std::vector<uint32_t> tbase, tcount;
         for (uint32_t id : fast) {
@@ -1472,6 +1585,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             VQ_TRY(b_fs_nt.ensure(fast.size() * 4));
             VQ_TRY(b_fs_sum.ensure(tiles.size() * (size_t)d * 8));
             VQ_TRY(b_fs_summ.ensure(tiles.size() * (size_t)d * sizeof(FsSumm)));
+            VQ_TRY(b_fs_mom.ensure(tiles.size() * (size_t)d * sizeof(double2)));
             VQ_TRY(b_fs_side.ensure((size_t)side_cap * kFsTile * 4));
             VQ_HIP(hipMemsetAsync(b_fs_fb.as<uint32_t>() + 1, 0, 4, stream));
             VQ_TRY(upload(b_fs_tiles.p, tiles.data(), tiles.size() * sizeof(FsTile)));
@@ -1498,15 +1612,23 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             FsSumm *sm = b_fs_summ.as<FsSumm>();
             const uint32_t *fn = b_fs_nodes.as<uint32_t>(), *fb = b_fs_base.as<uint32_t>(), *fc = b_fs_nt.as<uint32_t>();
             const dim3 cgrid((uint32_t)fast.size(), d);
+            double2 *mom = b_fs_mom.as<double2>();
+            const dim3 pgrid((uint32_t)fast.size(), (d + kFsCols - 1) / kFsCols);
             if (mode == 0) {
                 hipLaunchKernelGGL(k_fs_tile_sums<0>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts);
-                hipLaunchKernelGGL(k_fs_prefix, dim3((uint32_t)fast.size(), (d + kFsCols - 1) / kFsCols), dim3(1024), 0, stream, d, fb, fc, ts);
-                hipLaunchKernelGGL(k_fs_transduce<0>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, n_items, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1);
+                hipLaunchKernelGGL(k_fs_prefix, pgrid, dim3(1024), 0, stream, d, fb, fc, ts);
+                hipLaunchKernelGGL(k_fs_transduce<0>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, n_items, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1, mom);
                 hipLaunchKernelGGL(k_fs_chain<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, b_fs_side.as<float>(), b_fs_fb.as<uint32_t>());
             } else {
-                hipLaunchKernelGGL(k_fs_tile_sums<1>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts);
-                hipLaunchKernelGGL(k_fs_prefix, dim3((uint32_t)fast.size(), (d + kFsCols - 1) / kFsCols), dim3(1024), 0, stream, d, fb, fc, ts);
-                hipLaunchKernelGGL(k_fs_transduce<1>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, n_items, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1);
+                // the mean pass of the same node set left the moments: `fast` is the same list in both passes of a
+                // level unless some nodes of the level are leaves (then the tile table differs: fall back to a pass)
+                if (moments_match)
+                    hipLaunchKernelGGL(k_fs_prefix_var, pgrid, dim3(1024), 0, stream, X, d, perm, fn, fb, fc, na, mom, ts);
+                else {
+                    hipLaunchKernelGGL(k_fs_tile_sums<1>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts);
+                    hipLaunchKernelGGL(k_fs_prefix, pgrid, dim3(1024), 0, stream, d, fb, fc, ts);
+                }
+                hipLaunchKernelGGL(k_fs_transduce<1>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, n_items, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1, (double2 *)nullptr);
                 hipLaunchKernelGGL(k_fs_chain<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, b_fs_side.as<float>(), b_fs_fb.as<uint32_t>());
             }
             VQ_LAUNCH_CHECK("k_fs_*");

@@ -51,7 +51,9 @@ int bf16_mfma_selftest(float *ratio32, float *ratio16, int *trusted);
 int mfma_bf16_probe(const uint16_t *a, const uint16_t *b, const float *c, uint64_t trials, float *d);
 // software model of that instruction (mfma_model.hpp): on the host, and compared with the hardware on the device
 void mfma_bf16_model_host(const uint16_t *a, const uint16_t *b, const float *c, uint64_t trials, float *d);
-int mfma_bf16_model_check(uint64_t trials, uint64_t seed, uint64_t *mismatches, uint64_t *first_bad);
+int mfma_bf16_model_check(uint64_t trials, uint64_t seed, uint64_t *mismatches, uint64_t *first_bad, uint64_t *fail_ids,
+                          uint32_t fail_cap);
+void mfma_bf16_model_case(uint64_t seed, uint64_t trial, uint16_t *a, uint16_t *b, float *c);
 
 // bf16-split screen (k_screen_bf16.hip)
 uint32_t x32_padded_sd(uint32_t sd);  // sub_dim of the X32 kernel serving `sd` (zero padding for 5..63), 0 = none
