@@ -39,6 +39,17 @@ constexpr uint32_t DG = 16;          // dimensions per workgroup in the column-s
 constexpr uint32_t kTileRows = 480;  // rows per LDS tile: 15 loader waves x 32 rows
 constexpr uint32_t kTilePitch = kTileRows + 4;
 
+// One per tree level, in device memory: the level loop runs without the host (the planning kernels below fill it,
+// every other kernel of the level reads its counts from it and is launched over an upper bound).
+struct LevelInfo {
+    uint32_t first, count;    // the level's nodes are ids [first, first + count)  (children are numbered in order)
+    uint32_t n_split;         // nodes that split (more than one row, depth left): lvl_split[0 .. n_split)
+    uint32_t n_fast, n_slow;  // nodes by column-sum path (tile-parallel emulation / plain chain)
+    uint32_t n_tiles;         // tiles of the fast nodes
+    uint32_t error;           // != 0: a split dimension whose values are all NaN (the reference panics, src/tsvq.rs:77-78)
+    uint32_t pad;
+};
+
 struct NodeArrays {
     uint32_t *seg_start, *seg_len, *split_dim, *nv, *nleft;
     float *median;
@@ -71,12 +82,14 @@ template <int MODE>
 __global__ __launch_bounds__(1024) void k_seg_colsum(const float *__restrict__ X, uint32_t d,
                                                      const uint32_t *__restrict__ perm,
                                                      const uint32_t *__restrict__ lvl_node,
-                                                     NodeArrays na) {
+                                                     const LevelInfo *__restrict__ lv, NodeArrays na) {
     // column-major tiles: the consumer lane of a column reads 4 consecutive rows per ds_read_b128
     // (pitch 484 floats: the 16 columns start 36 banks apart -> conflict-free 16-byte reads)
     __shared__ __attribute__((aligned(16))) float tile[2][DG][kTilePitch];
+    if (blockIdx.x >= lv->n_slow) return;  // launched over an upper bound
     const uint32_t node = lvl_node[blockIdx.x];
     const uint32_t a = na.seg_start[node], n = na.seg_len[node];
+    if (MODE == 1 && n <= 1) return;       // a leaf: no variance pass (src/tsvq.rs:38-44)
     const uint32_t t0 = blockIdx.y * DG;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n_tiles = (n + kTileRows - 1) / kTileRows;
@@ -172,9 +185,9 @@ __global__ __launch_bounds__(1024) void k_seg_colsum(const float *__restrict__ X
 }
 
 // split dimension: NaN filtered, LAST maximum wins (Iterator::max_by), none -> 0 (tsvq.rs:59-66)
-__global__ void k_pick_split(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, uint32_t d, NodeArrays na) {
+__global__ void k_pick_split(const uint32_t *__restrict__ lvl_node, const LevelInfo *__restrict__ lv, uint32_t d, NodeArrays na) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= n_lvl) return;
+    if (li >= lv->n_split) return;
     const uint32_t node = lvl_node[li];
     const float *v = na.var + (size_t)node * d;
     uint32_t best_t = 0;
@@ -198,11 +211,13 @@ __global__ void k_pick_split(const uint32_t *__restrict__ lvl_node, uint32_t n_l
 __global__ __launch_bounds__(256) void k_gather_vals(const float *__restrict__ X, uint32_t d, uint32_t n,
                                                      const uint32_t *__restrict__ perm,
                                                      const uint32_t *__restrict__ node_of,
+                                                     const uint32_t *__restrict__ remap,
                                                      const uint32_t *__restrict__ lvl_node, NodeArrays na,
                                                      float *__restrict__ vals) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t li = node_of[i];
+    uint32_t li = node_of[i];
+    if (li != kInactive) li = remap[li];  // level-local node index -> index among the level's split nodes
     if (li == kInactive) return;
     const uint32_t node = lvl_node[li];
     const float x = X[(size_t)perm[i] * d + na.split_dim[node]];
@@ -211,9 +226,9 @@ __global__ __launch_bounds__(256) void k_gather_vals(const float *__restrict__ X
 }
 
 // ranks of the two order statistics the median needs (tsvq.rs:77-81)
-__global__ void k_select_init(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, NodeArrays na) {
+__global__ void k_select_init(const uint32_t *__restrict__ lvl_node, const LevelInfo *__restrict__ lv, NodeArrays na) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= n_lvl) return;
+    if (li >= lv->n_split) return;
     const uint32_t node = lvl_node[li];
     const uint32_t nv = na.nv[node];
     if (nv == 0) {
@@ -234,6 +249,7 @@ constexpr uint32_t kHistSlots = 8;
 __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ vals, uint32_t n,
                                                      uint32_t chunk,
                                                      const uint32_t *__restrict__ node_of,
+                                                     const uint32_t *__restrict__ remap,
                                                      const uint32_t *__restrict__ lvl_node, NodeArrays na,
                                                      uint32_t shift, uint32_t *__restrict__ hist) {
     __shared__ uint32_t tags[kHistSlots];
@@ -245,7 +261,8 @@ __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ v
     const uint32_t i0 = blockIdx.x * chunk;
     const uint32_t i1 = min(n, i0 + chunk);
     for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        const uint32_t li = node_of[i];
+        uint32_t li = node_of[i];
+        if (li != kInactive) li = remap[li];
         if (li == kInactive) continue;
         const float x = vals[i];
         if (x != x) continue;
@@ -276,10 +293,10 @@ __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ v
 
 // one wave per (node, which of the two ranks): lane l owns bins 4l..4l+3, a wave prefix scan finds
 // the bin holding the rank (the serial walk over 256 dependent loads cost 25 us per launch)
-__global__ __launch_bounds__(64) void k_select_pick(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl,
+__global__ __launch_bounds__(64) void k_select_pick(const uint32_t *__restrict__ lvl_node, const LevelInfo *__restrict__ lv,
                                                     NodeArrays na, uint32_t shift, uint32_t *__restrict__ hist) {
     const uint32_t idx = blockIdx.x, lane = threadIdx.x;
-    if (idx >= n_lvl * 2) return;
+    if (idx >= lv->n_split * 2) return;
     const uint32_t li = idx >> 1, sel = idx & 1;
     const uint32_t node = lvl_node[li];
     uint4 *h4 = reinterpret_cast<uint4 *>(hist + ((size_t)li * 2 + sel) * 256);
@@ -328,9 +345,9 @@ __global__ __launch_bounds__(64) void k_select_pick(const uint32_t *__restrict__
     }
 }
 
-__global__ void k_median(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, NodeArrays na) {
+__global__ void k_median(const uint32_t *__restrict__ lvl_node, const LevelInfo *__restrict__ lv, NodeArrays na) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= n_lvl) return;
+    if (li >= lv->n_split) return;
     const uint32_t node = lvl_node[li];
     const uint32_t nv = na.nv[node];
     if (nv == 0) {
@@ -349,11 +366,13 @@ __global__ void k_median(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, 
 
 __global__ __launch_bounds__(256) void k_flags(const float *__restrict__ vals, uint32_t n,
                                                const uint32_t *__restrict__ node_of,
+                                               const uint32_t *__restrict__ remap,
                                                const uint32_t *__restrict__ lvl_node, NodeArrays na,
                                                uint32_t *__restrict__ flags) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t li = node_of[i];
+    uint32_t li = node_of[i];
+    if (li != kInactive) li = remap[li];
     uint32_t f = 0;
     if (li != kInactive) f = (vals[i] <= na.median[lvl_node[li]]) ? 1u : 0u;  // NaN -> right
     flags[i] = f;
@@ -414,10 +433,10 @@ __global__ __launch_bounds__(256) void k_scan_apply(uint32_t *__restrict__ out, 
 }
 
 // lefts per node = P[a+len] - P[a] (P exclusive; the last element adds its own flag)
-__global__ void k_nleft(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, NodeArrays na,
+__global__ void k_nleft(const uint32_t *__restrict__ lvl_node, const LevelInfo *__restrict__ lv, NodeArrays na,
                         const uint32_t *__restrict__ P, const uint32_t *__restrict__ flags) {
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= n_lvl) return;
+    if (li >= lv->n_split) return;
     const uint32_t node = lvl_node[li];
     const uint32_t a = na.seg_start[node], len = na.seg_len[node];
     na.nleft[node] = (P[a + len - 1] + flags[a + len - 1]) - P[a];
@@ -426,13 +445,15 @@ __global__ void k_nleft(const uint32_t *__restrict__ lvl_node, uint32_t n_lvl, N
 // stable partition of every split node's segment (tsvq.rs:84-85)
 __global__ __launch_bounds__(256) void k_scatter(uint32_t n, const uint32_t *__restrict__ perm,
                                                  const uint32_t *__restrict__ node_of,
+                                                 const uint32_t *__restrict__ remap,
                                                  const uint32_t *__restrict__ lvl_node, NodeArrays na,
                                                  const uint32_t *__restrict__ P,
                                                  const uint32_t *__restrict__ flags,
                                                  uint32_t *__restrict__ perm2, uint32_t *__restrict__ node_of2) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t li = node_of[i];
+    uint32_t li = node_of[i];
+    if (li != kInactive) li = remap[li];
     if (li == kInactive) {
         perm2[i] = perm[i];
         node_of2[i] = kInactive;
@@ -763,7 +784,7 @@ __global__ __launch_bounds__(256) void k_tsvq_gather_f16(const float *__restrict
 // reference's bit pattern; only the schedule differs.
 constexpr uint32_t kFsTile = 512;        // rows per tile
 constexpr uint32_t kFsCols = 32;         // columns per workgroup (one 128-byte line per row)
-constexpr uint32_t kFsMinRows = 3072;    // shorter nodes keep the plain sequential kernel (every tile of a short node is re-added)
+constexpr uint32_t kFsMinRows = 16384;   // shorter nodes keep the plain sequential kernel (most tiles of a short node sit on a binade crossing and are re-added)
 
 struct FsTile {
     uint32_t node, t;      // node id, tile index inside the node
@@ -780,13 +801,18 @@ __device__ __forceinline__ float fs_value(float x, float mu) {
     return diff * diff;
 }
 
-// plain f64 sums per (tile, column): only used to guess the binade of the running sum at a tile
+// plain f64 sums per (tile, column): only used to guess the binade of the running sum at a tile.
+// samp > 1: only every samp-th group of 32 rows is read and the sum scaled up -- 1/samp of the traffic for a guess whose
+// relative error (~ sigma/mu / sqrt(rows read so far)) only moves the tiles next to a binade crossing into the
+// re-addition path of k_fs_chain; the sums themselves stay exact whatever the guess.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ X, uint32_t d,
                                                       const uint32_t *__restrict__ perm,
                                                       const FsTile *__restrict__ tiles, NodeArrays na,
-                                                      double *__restrict__ tile_sum) {
+                                                      double *__restrict__ tile_sum, uint32_t samp,
+                                                      const LevelInfo *__restrict__ lv) {
     __shared__ double part[32][kFsCols + 1];
+    if (blockIdx.x >= lv->n_tiles * ((d + kFsCols - 1) / kFsCols)) return;  // launched over an upper bound
     // 1-D grid, column block fastest: the d/32 workgroups that share a tile's rows (and DRAM pages) run together
     // (d is a multiple of 4; the last column block may be short: its missing 16-byte parts are skipped)
     const uint32_t ncb = (d + kFsCols - 1) / kFsCols, tile_id = blockIdx.x / ncb, cblk = blockIdx.x - tile_id * ncb;
@@ -800,7 +826,7 @@ __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ 
     }
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
-    for (uint32_t i = 0; i < kFsTile / 32; ++i) {
+    for (uint32_t i = 0; i < kFsTile / 32; i += samp) {
         const uint32_t r = rr + 32 * i;
         if (r < tl.rows && col_ok) {
             const float4 v = *reinterpret_cast<const float4 *>(X + (size_t)perm[tl.start + r] * d + c0 + 4 * q);
@@ -816,6 +842,12 @@ __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ 
     if (threadIdx.x < kFsCols && c0 + threadIdx.x < d) {
         double s = 0.0;
         for (int r = 0; r < 32; ++r) s += part[r][threadIdx.x];
+        if (samp > 1) {  // rows read: whole groups of 32 except possibly the last one of the tile
+            uint32_t read = 0;
+            for (uint32_t i = 0; i < kFsTile / 32; i += samp)
+                if (32 * i < tl.rows) read += min(32u, tl.rows - 32 * i);
+            s *= (double)tl.rows / (double)read;
+        }
         tile_sum[(size_t)tile_id * d + c0 + threadIdx.x] = s;
     }
 }
@@ -823,8 +855,10 @@ __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ 
 // exclusive prefix over the tiles of a node, per column, in place: 32 chunk lanes x 32 columns per
 // workgroup (chunk sums -> LDS -> offsets -> rewrite); only a guess is needed, so f64 order is free
 __global__ __launch_bounds__(1024) void k_fs_prefix(uint32_t d, const uint32_t *__restrict__ tile_base,
-                                                    const uint32_t *__restrict__ n_tiles_of, double *__restrict__ tile_sum) {
+                                                    const uint32_t *__restrict__ n_tiles_of, double *__restrict__ tile_sum,
+                                                    const LevelInfo *__restrict__ lv) {
     __shared__ double part[32][kFsCols + 1];
+    if (blockIdx.x >= lv->n_fast) return;
     const uint32_t c = blockIdx.y * kFsCols + (threadIdx.x & 31), lt = threadIdx.x >> 5;
     const uint32_t base = tile_base[blockIdx.x], nt = n_tiles_of[blockIdx.x];
     const uint32_t chunk = (nt + 31) / 32, t0 = lt * chunk, t1 = min(nt, t0 + chunk);
@@ -856,8 +890,10 @@ __global__ __launch_bounds__(1024) void k_fs_prefix_var(const float *__restrict_
                                                         const uint32_t *__restrict__ tile_base,
                                                         const uint32_t *__restrict__ n_tiles_of, NodeArrays na,
                                                         const double2 *__restrict__ tile_mom,
-                                                        double *__restrict__ tile_sum) {
+                                                        double *__restrict__ tile_sum,
+                                                        const LevelInfo *__restrict__ lv) {
     __shared__ double part[32][kFsCols + 1];
+    if (blockIdx.x >= lv->n_fast) return;
     const uint32_t c = blockIdx.y * kFsCols + (threadIdx.x & 31), lt = threadIdx.x >> 5;
     const uint32_t node = fast_nodes[blockIdx.x];
     const uint32_t base = tile_base[blockIdx.x], nt = n_tiles_of[blockIdx.x], len = na.seg_len[node];
@@ -901,7 +937,7 @@ struct FsSeg {  // the same for one 64-row segment: everything fits 32 bits (|q|
 template <int MODE>
 __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ X, uint32_t d,
                                                       const uint32_t *__restrict__ perm,
-                                                      const FsTile *__restrict__ tiles, uint32_t n_items, NodeArrays na,
+                                                      const FsTile *__restrict__ tiles, const LevelInfo *__restrict__ lv, NodeArrays na,
                                                       const double *__restrict__ tile_pref,
                                                       FsSumm *__restrict__ summ, float *__restrict__ side,
                                                       uint32_t side_cap, uint32_t *__restrict__ side_count,
@@ -913,6 +949,7 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
     __shared__ int col_slot[kFsCols];
     __shared__ float2 seg_mom[8][kFsCols];  // MODE 0: sum (x - m0), sum (x - m0)^2 of a segment (the variance pass's guess)
     const uint32_t ncb = (d + kFsCols - 1) / kFsCols;  // the last column block may be short (d % 4 == 0)
+    const uint32_t n_items = lv->n_tiles * ncb;
     const uint32_t q = threadIdx.x & 7, rr = threadIdx.x >> 3;     // load role: 16-byte part q of rows rr + 32 i
     const uint32_t cl = threadIdx.x & 31, seg = threadIdx.x >> 5;  // fold role: column cl, rows 64 seg ..
     uint32_t item = blockIdx.x;
@@ -1190,7 +1227,8 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                                                  const uint32_t *__restrict__ fast_nodes,
                                                  const uint32_t *__restrict__ tile_base, NodeArrays na,
                                                  const FsSumm *__restrict__ summ, const float *__restrict__ side,
-                                                 uint32_t *__restrict__ n_fallback) {
+                                                 uint32_t *__restrict__ n_fallback, const LevelInfo *__restrict__ lv) {
+    if (blockIdx.x >= lv->n_fast) return;
     const uint32_t node = fast_nodes[blockIdx.x], c = blockIdx.y, lane = threadIdx.x;
     const uint32_t a = na.seg_start[node], len = na.seg_len[node];
     const uint32_t nt = (len + kFsTile - 1) / kFsTile, base = tile_base[blockIdx.x];
@@ -1295,7 +1333,8 @@ template <int MODE>
 __global__ __launch_bounds__(64) void k_fs_check(const float *__restrict__ X, uint32_t d, const uint32_t *__restrict__ perm,
                                                  const uint32_t *__restrict__ fast_nodes,
                                                  const uint32_t *__restrict__ tile_base, NodeArrays na,
-                                                 const FsSumm *__restrict__ summ) {
+                                                 const FsSumm *__restrict__ summ, const LevelInfo *__restrict__ lv) {
+    if (blockIdx.x >= lv->n_fast) return;
     const uint32_t node = fast_nodes[blockIdx.x], c = blockIdx.y;
     if (threadIdx.x != 0) return;
     const uint32_t a = na.seg_start[node], len = na.seg_len[node];
@@ -1395,20 +1434,156 @@ int launch_tsvq_gather_table(const uint16_t *table, uint32_t d, const int32_t *l
     return VQHIP_OK;
 }
 
+// ---- device-side level planning -------------------------------------------------------------------
+// The host used to decide, level by level, which nodes split, which take the tile-parallel sums and what their
+// tile table looks like -- one stream synchronisation and ~15 small uploads per level (1.4 of 8.6 ms at 1M x 128,
+// depth 8).  Two single-workgroup kernels do it on the device instead; the host only launches, over upper bounds.
+
+// exclusive scan of one value per thread over the workgroup (1024 threads); returns the total
+__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *sh, uint32_t *total) {
+    const uint32_t t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = (t >= off) ? sh[t - off] : 0u;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    const uint32_t incl = sh[t];
+    *total = sh[1023];
+    __syncthreads();
+    return incl - v;
+}
+
+// start of a level: the split list (+ remap level-local -> split-local), the fast / slow lists and the tile table
+__global__ __launch_bounds__(1024) void k_plan_level(LevelInfo *__restrict__ lv, int can_split, int can_fast, NodeArrays na,
+                                                     uint32_t *__restrict__ lvl_split, uint32_t *__restrict__ remap,
+                                                     uint32_t *__restrict__ fast_nodes, uint32_t *__restrict__ slow_nodes,
+                                                     uint32_t *__restrict__ tile_base, uint32_t *__restrict__ n_tiles_of,
+                                                     FsTile *__restrict__ tiles) {
+    __shared__ uint32_t sh[1024];
+    const uint32_t first = lv->first, count = lv->count;
+    uint32_t n_split = 0, n_fast = 0, n_tiles = 0;
+    for (uint32_t b = 0; b < count; b += 1024) {
+        const uint32_t li = b + threadIdx.x;
+        const bool in = li < count;
+        const uint32_t node = first + li;
+        const uint32_t len = in ? na.seg_len[node] : 0u;
+        const uint32_t is_split = (in && can_split && len > 1) ? 1u : 0u;            // src/tsvq.rs:38-44
+        const uint32_t is_fast = (in && can_fast && len >= kFsMinRows) ? 1u : 0u;
+        const uint32_t nt = is_fast ? (len + kFsTile - 1) / kFsTile : 0u;
+        uint32_t tot_s, tot_f, tot_t;
+        const uint32_t ps = block_excl_scan(is_split, sh, &tot_s);
+        const uint32_t pf = block_excl_scan(is_fast, sh, &tot_f);
+        const uint32_t pt = block_excl_scan(nt, sh, &tot_t);
+        if (in) {
+            remap[li] = is_split ? n_split + ps : kInactive;
+            if (is_split) lvl_split[n_split + ps] = node;
+            if (is_fast) {
+                fast_nodes[n_fast + pf] = node;
+                tile_base[n_fast + pf] = n_tiles + pt;
+                n_tiles_of[n_fast + pf] = nt;
+            } else {
+                slow_nodes[(li - (n_fast + pf))] = node;  // nodes before li that are not fast: li - (fast before li)
+            }
+        }
+        n_split += tot_s;
+        n_fast += tot_f;
+        n_tiles += tot_t;
+    }
+    __threadfence();
+    __syncthreads();
+    // tile table: tile T belongs to the fast node f with tile_base[f] <= T < tile_base[f] + nt[f]
+    for (uint32_t T = threadIdx.x; T < n_tiles; T += 1024) {
+        uint32_t lo = 0, hi = n_fast;  // last f with tile_base[f] <= T
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (tile_base[mid] <= T) lo = mid; else hi = mid;
+        }
+        const uint32_t node = fast_nodes[lo], t = T - tile_base[lo];
+        const uint32_t len = na.seg_len[node];
+        FsTile tl;
+        tl.node = node;
+        tl.t = t;
+        tl.start = na.seg_start[node] + t * kFsTile;
+        tl.rows = min(kFsTile, len - t * kFsTile);
+        tiles[T] = tl;
+    }
+    if (threadIdx.x == 0) {
+        lv->n_split = n_split;
+        lv->n_fast = n_fast;
+        lv->n_slow = count - n_fast;
+        lv->n_tiles = n_tiles;
+    }
+}
+
+// end of a level: children of the split nodes from nleft / nv (src/tsvq.rs:88-108), numbered in order
+__global__ __launch_bounds__(1024) void k_plan_children(LevelInfo *__restrict__ lv, LevelInfo *__restrict__ lv_next,
+                                                        const uint32_t *__restrict__ lvl_split, NodeArrays na,
+                                                        int32_t *__restrict__ node_left, int32_t *__restrict__ node_right,
+                                                        uint32_t dcap) {
+    __shared__ uint32_t sh[1024];
+    const uint32_t n_split = lv->n_split, next_first = lv->first + lv->count;
+    uint32_t made = 0, err = 0;
+    for (uint32_t b = 0; b < n_split; b += 1024) {
+        const uint32_t j = b + threadIdx.x;
+        const bool in = j < n_split;
+        uint32_t node = 0, start = 0, len = 0, nl = 0;
+        if (in) {
+            node = lvl_split[j];
+            start = na.seg_start[node];
+            len = na.seg_len[node];
+            nl = na.nleft[node];
+            if (na.nv[node] == 0) err = 1;
+        }
+        const uint32_t nr = len - nl;
+        const uint32_t has_l = (in && nl != 0 && nl < len) ? 1u : 0u, has_r = (in && nr != 0 && nr < len) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t pos = block_excl_scan(has_l + has_r, sh, &tot);
+        if (in) {
+            const uint32_t il = made + pos, ir = il + has_l;
+            na.child_local[2 * node] = has_l ? il : kInactive;
+            na.child_local[2 * node + 1] = has_r ? ir : kInactive;
+            if (has_l && next_first + il < dcap) {
+                node_left[node] = (int32_t)(next_first + il);
+                na.seg_start[next_first + il] = start;
+                na.seg_len[next_first + il] = nl;
+            }
+            if (has_r && next_first + ir < dcap) {
+                node_right[node] = (int32_t)(next_first + ir);
+                na.seg_start[next_first + ir] = start + nl;
+                na.seg_len[next_first + ir] = nr;
+            }
+        }
+        made += tot;
+    }
+    sh[threadIdx.x] = err;
+    __syncthreads();
+    for (uint32_t off = 512; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] |= sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (sh[0]) lv->error = 1;
+        lv_next->first = next_first;
+        lv_next->count = (next_first + made <= dcap) ? made : 0u;  // cannot happen (dcap bounds the tree); no overrun if it did
+        if (next_first + made > dcap) lv->error = 2;
+    }
+}
+
 // ---- host driver of the build ------------------------------------------------------------
-// Device / pinned scratch of a build, kept per host thread between builds (28 buffers: their hipMalloc /
-// hipHostMalloc calls were 2-3 ms of a 13 ms build); dropped when it exceeds 1 GiB or the device changes.
+// Device scratch of a build, kept per host thread between builds (their hipMalloc calls were 2-3 ms of a
+// 13 ms build); dropped when it exceeds 1 GiB or the device changes.
 struct TsvqBuildWs {
     int device = -1;
-    DevBuf b_perm[2], b_nodeof[2], b_vals, b_flags, b_scan, b_bsums, b_hist, b_lvl;
-    DevBuf b_seg_start, b_seg_len, b_split, b_nv, b_nleft, b_median, b_selp, b_selr, b_child, b_cent, b_var;
-    DevBuf b_fs_tiles, b_fs_nodes, b_fs_base, b_fs_nt, b_fs_sum, b_fs_summ, b_lvl_slow, b_fs_fb, b_fs_side, b_fs_mom;
-    char *arena_base = nullptr;
-    size_t arena_cap = 0;
-    DevBuf *all[31] = {&b_fs_mom, &b_perm[0], &b_perm[1], &b_nodeof[0], &b_nodeof[1], &b_vals, &b_flags, &b_scan, &b_bsums, &b_hist,
-                       &b_lvl, &b_seg_start, &b_seg_len, &b_split, &b_nv, &b_nleft, &b_median, &b_selp, &b_selr, &b_child,
-                       &b_cent, &b_var, &b_fs_tiles, &b_fs_nodes, &b_fs_base, &b_fs_nt, &b_fs_sum, &b_fs_summ, &b_lvl_slow,
-                       &b_fs_fb, &b_fs_side};
+    DevBuf b_perm[2], b_nodeof[2], b_vals, b_flags, b_scan, b_bsums, b_hist, b_lvl, b_remap;
+    DevBuf b_seg_start, b_seg_len, b_split, b_nv, b_nleft, b_median, b_selp, b_selr, b_child, b_cent, b_var, b_left, b_right;
+    DevBuf b_fs_tiles, b_fs_nodes, b_fs_base, b_fs_nt, b_fs_sum, b_fs_summ, b_lvl_slow, b_fs_fb, b_fs_side, b_fs_mom, b_lv;
+    DevBuf *all[35] = {&b_perm[0], &b_perm[1], &b_nodeof[0], &b_nodeof[1], &b_vals, &b_flags, &b_scan, &b_bsums, &b_hist,
+                       &b_lvl, &b_remap, &b_seg_start, &b_seg_len, &b_split, &b_nv, &b_nleft, &b_median, &b_selp, &b_selr,
+                       &b_child, &b_cent, &b_var, &b_left, &b_right, &b_fs_tiles, &b_fs_nodes, &b_fs_base, &b_fs_nt, &b_fs_sum,
+                       &b_fs_summ, &b_lvl_slow, &b_fs_fb, &b_fs_side, &b_fs_mom, &b_lv};
     size_t total() const {
         size_t t = 0;
         for (const DevBuf *b : all) t += b->bytes;
@@ -1416,9 +1591,6 @@ struct TsvqBuildWs {
     }
     void release() {
         for (DevBuf *b : all) b->release();
-        if (arena_base) (void)hipHostFree(arena_base);
-        arena_base = nullptr;
-        arena_cap = 0;
     }
     ~TsvqBuildWs() { release(); }
 };
@@ -1428,17 +1600,12 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
                       hipStream_t stream) {
     if (n64 >= (1ull << 31)) return fail(VQHIP_ERR_UNSUPPORTED, "TSVQ build supports < 2^31 rows per device");
     const uint32_t n = (uint32_t)n64;
-    // BFS node storage
-    struct HostNode {
-        uint32_t start, len, depth_left;
-        int32_t left = -1, right = -1;
-    };
-    std::vector<HostNode> nodes;
-    nodes.push_back({0, n, max_depth, -1, -1});
     const uint64_t need_cap = (max_depth < 31) ? std::min<uint64_t>((1ull << (max_depth + 1)) - 1, 2ull * n - 1) : 2ull * n - 1;
     if (cap < need_cap)
         return fail(VQHIP_ERR_INVALID_INPUT, "node capacity %u < required %llu", cap, (unsigned long long)need_cap);
     const uint32_t dcap = (uint32_t)need_cap;
+    // levels: the root is level 0; a tree over n rows is at most n - 1 levels deep whatever max_depth says
+    const uint32_t n_levels = (uint32_t)std::min<uint64_t>((uint64_t)max_depth, (uint64_t)n - 1) + 1;
 
     static thread_local TsvqBuildWs ws;
     {
@@ -1453,103 +1620,71 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             if (w.total() > (1ull << 30)) w.release();
         }
     } ws_trim{ws};
-    DevBuf(&b_perm)[2] = ws.b_perm;
-    DevBuf(&b_nodeof)[2] = ws.b_nodeof;
-    DevBuf &b_vals = ws.b_vals, &b_flags = ws.b_flags, &b_scan = ws.b_scan, &b_bsums = ws.b_bsums, &b_hist = ws.b_hist,
-           &b_lvl = ws.b_lvl;
-    DevBuf &b_seg_start = ws.b_seg_start, &b_seg_len = ws.b_seg_len, &b_split = ws.b_split, &b_nv = ws.b_nv,
-           &b_nleft = ws.b_nleft, &b_median = ws.b_median, &b_selp = ws.b_selp, &b_selr = ws.b_selr, &b_child = ws.b_child,
-           &b_cent = ws.b_cent, &b_var = ws.b_var;
+    // widest level: min(2^level, n) nodes
+    auto level_width = [&](uint32_t L) -> uint32_t { return (L >= 31) ? n : (uint32_t)std::min<uint64_t>(1ull << L, n); };
+    const uint32_t wmax = level_width(n_levels - 1);
+    const uint32_t fast_max = n / kFsMinRows + 1, tiles_max = n / kFsTile + fast_max + 1;
     for (int q = 0; q < 2; ++q) {
-        VQ_TRY(b_perm[q].ensure((size_t)n * 4));
-        VQ_TRY(b_nodeof[q].ensure((size_t)n * 4));
+        VQ_TRY(ws.b_perm[q].ensure((size_t)n * 4));
+        VQ_TRY(ws.b_nodeof[q].ensure((size_t)n * 4));
     }
-    VQ_TRY(b_vals.ensure((size_t)n * 4));
-    VQ_TRY(b_flags.ensure((size_t)n * 4));
-    VQ_TRY(b_scan.ensure((size_t)n * 4));
+    VQ_TRY(ws.b_vals.ensure((size_t)n * 4));
+    VQ_TRY(ws.b_flags.ensure((size_t)n * 4));
+    VQ_TRY(ws.b_scan.ensure((size_t)n * 4));
     const uint32_t nblk = (n + 1023) / 1024;
-    VQ_TRY(b_bsums.ensure((size_t)nblk * 4));
-    VQ_TRY(b_seg_start.ensure((size_t)dcap * 4));
-    VQ_TRY(b_seg_len.ensure((size_t)dcap * 4));
-    VQ_TRY(b_split.ensure((size_t)dcap * 4));
-    VQ_TRY(b_nv.ensure((size_t)dcap * 4));
-    VQ_TRY(b_nleft.ensure((size_t)dcap * 4));
-    VQ_TRY(b_median.ensure((size_t)dcap * 4));
-    VQ_TRY(b_selp.ensure((size_t)dcap * 8));
-    VQ_TRY(b_selr.ensure((size_t)dcap * 8));
-    VQ_TRY(b_child.ensure((size_t)dcap * 8));
-    VQ_TRY(b_cent.ensure((size_t)dcap * d * 4));
-    VQ_TRY(b_var.ensure((size_t)dcap * d * 4));
+    VQ_TRY(ws.b_bsums.ensure((size_t)nblk * 4));
+    VQ_TRY(ws.b_lvl.ensure((size_t)wmax * 4));
+    VQ_TRY(ws.b_remap.ensure((size_t)wmax * 4));
+    VQ_TRY(ws.b_lvl_slow.ensure((size_t)wmax * 4));
+    VQ_TRY(ws.b_hist.ensure((size_t)wmax * 2 * 256 * 4));
+    VQ_TRY(ws.b_seg_start.ensure((size_t)dcap * 4));
+    VQ_TRY(ws.b_seg_len.ensure((size_t)dcap * 4));
+    VQ_TRY(ws.b_split.ensure((size_t)dcap * 4));
+    VQ_TRY(ws.b_nv.ensure((size_t)dcap * 4));
+    VQ_TRY(ws.b_nleft.ensure((size_t)dcap * 4));
+    VQ_TRY(ws.b_median.ensure((size_t)dcap * 4));
+    VQ_TRY(ws.b_selp.ensure((size_t)dcap * 8));
+    VQ_TRY(ws.b_selr.ensure((size_t)dcap * 8));
+    VQ_TRY(ws.b_child.ensure((size_t)dcap * 8));
+    VQ_TRY(ws.b_left.ensure((size_t)dcap * 4));
+    VQ_TRY(ws.b_right.ensure((size_t)dcap * 4));
+    VQ_TRY(ws.b_cent.ensure((size_t)dcap * d * 4));
+    VQ_TRY(ws.b_var.ensure((size_t)dcap * d * 4));
+    VQ_TRY(ws.b_lv.ensure((size_t)(n_levels + 1) * sizeof(LevelInfo)));
+    VQ_TRY(ws.b_fs_fb.ensure(8));  // [0] tile re-additions (diagnostic), [1] side-buffer slots handed out
     NodeArrays na;
-    na.seg_start = b_seg_start.as<uint32_t>();
-    na.seg_len = b_seg_len.as<uint32_t>();
-    na.split_dim = b_split.as<uint32_t>();
-    na.nv = b_nv.as<uint32_t>();
-    na.nleft = b_nleft.as<uint32_t>();
-    na.median = b_median.as<float>();
-    na.sel_prefix = b_selp.as<uint32_t>();
-    na.sel_rank = b_selr.as<uint32_t>();
-    na.child_local = b_child.as<uint32_t>();
-    na.centroid = b_cent.as<float>();
-    na.var = b_var.as<float>();
+    na.seg_start = ws.b_seg_start.as<uint32_t>();
+    na.seg_len = ws.b_seg_len.as<uint32_t>();
+    na.split_dim = ws.b_split.as<uint32_t>();
+    na.nv = ws.b_nv.as<uint32_t>();
+    na.nleft = ws.b_nleft.as<uint32_t>();
+    na.median = ws.b_median.as<float>();
+    na.sel_prefix = ws.b_selp.as<uint32_t>();
+    na.sel_rank = ws.b_selr.as<uint32_t>();
+    na.child_local = ws.b_child.as<uint32_t>();
+    na.centroid = ws.b_cent.as<float>();
+    na.var = ws.b_var.as<float>();
+    int32_t *node_left = ws.b_left.as<int32_t>(), *node_right = ws.b_right.as<int32_t>();
+    LevelInfo *lv = ws.b_lv.as<LevelInfo>();
 
-    hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, stream, b_perm[0].as<uint32_t>(),
-                       b_nodeof[0].as<uint32_t>(), n);
-    VQ_LAUNCH_CHECK("k_iota");
-    int cur = 0;
-    std::vector<uint32_t> level = {0};  // global node ids of the current level
-    const uint32_t dgroups = (d + DG - 1) / DG;
-
-    // small host -> device uploads (node lists, tile tables) go through one pinned arena so that they are
-    // truly asynchronous: no stream synchronisation just to keep a std::vector alive (9 levels x ~10 of
-    // them were ~1.5 ms of a 13 ms build); an upload that does not fit falls back to copy + synchronise
-    struct PinnedArena {
-        char *base = nullptr;
-        size_t cap = 0, off = 0;
-    } arena;
-    if (!ws.arena_base) {
-        void *pz = nullptr;
-        if (hipHostMalloc(&pz, 8u << 20, hipHostMallocDefault) == hipSuccess) {
-            ws.arena_base = static_cast<char *>(pz);
-            ws.arena_cap = 8u << 20;
-        } else {
-            (void)hipGetLastError();
-        }
-    }
-    arena.base = ws.arena_base;
-    arena.cap = ws.arena_cap;
-    bool upload_needs_sync = false;
-    auto upload = [&](void *dst, const void *src, size_t bytes) -> int {
-        const size_t at = (arena.off + 15) & ~(size_t)15;
-        if (arena.base && at + bytes <= arena.cap) {
-            memcpy(arena.base + at, src, bytes);
-            arena.off = at + bytes;
-            VQ_HIP(hipMemcpyAsync(dst, arena.base + at, bytes, hipMemcpyHostToDevice, stream));
-        } else {
-            VQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
-            upload_needs_sync = true;
-        }
-        return VQHIP_OK;
-    };
-    auto upload_fence = [&]() -> int {  // call before the source vectors of a fallback upload die
-        if (upload_needs_sync) VQ_HIP(hipStreamSynchronize(stream));
-        upload_needs_sync = false;
-        return VQHIP_OK;
-    };
-
-    // sequential-order column sums of a set of nodes: long nodes through the tile-parallel exact
-    // emulation (k_fs_*), the rest through the plain chain kernel
-    DevBuf &b_fs_tiles = ws.b_fs_tiles, &b_fs_nodes = ws.b_fs_nodes, &b_fs_base = ws.b_fs_base, &b_fs_nt = ws.b_fs_nt,
-           &b_fs_sum = ws.b_fs_sum, &b_fs_summ = ws.b_fs_summ, &b_lvl_slow = ws.b_lvl_slow, &b_fs_fb = ws.b_fs_fb,
-           &b_fs_side = ws.b_fs_side, &b_fs_mom = ws.b_fs_mom;
-    VQ_TRY(b_fs_fb.ensure(8));  // [0] tile re-additions (diagnostic), [1] side-buffer slots handed out
-    VQ_HIP(hipMemsetAsync(b_fs_fb.p, 0, 8, stream));
     static const char *nopark = getenv("VQHIP_TSVQ_NOPARK");
-    const uint32_t side_cap = (nopark && nopark[0] == '1') ? 0u : 32768u;  // parked tiles per call (64 MB); beyond it the re-addition gathers
+    const uint32_t side_cap = (nopark && nopark[0] == '1') ? 0u : 32768u;  // parked tiles per pass (64 MB); beyond it the re-addition gathers
     static const char *seq_env = getenv("VQHIP_TSVQ_SEQSUM");  // =1: plain chain everywhere (A/B)
     const bool can_fast = (d % 4 == 0) && !(seq_env && seq_env[0] == '1');  // 16-byte row parts
-    const size_t fs_lds_bytes = (size_t)kFsCols * (kFsTile + 1) * 4 + 8 * kFsCols * sizeof(FsAcc);
-    {
+    static const char *samp_env = getenv("VQHIP_TSVQ_SAMPLE");  // rows read for the mean pass's binade guess: 1/N (default 1/8)
+    const uint32_t fs_sample = samp_env ? (uint32_t)std::max(1, std::min(16, atoi(samp_env))) : 8u;
+    const size_t fs_lds_bytes = (size_t)kFsCols * (kFsTile + 1) * 4 + 8 * kFsCols * sizeof(FsSeg);
+    if (can_fast) {
+        VQ_TRY(ws.b_fs_tiles.ensure((size_t)tiles_max * sizeof(FsTile)));
+        VQ_TRY(ws.b_fs_nodes.ensure((size_t)fast_max * 4));
+        VQ_TRY(ws.b_fs_base.ensure((size_t)fast_max * 4));
+        VQ_TRY(ws.b_fs_nt.ensure((size_t)fast_max * 4));
+        if (n >= kFsMinRows) {
+            VQ_TRY(ws.b_fs_sum.ensure((size_t)tiles_max * d * 8));
+            VQ_TRY(ws.b_fs_summ.ensure((size_t)tiles_max * d * sizeof(FsSumm)));
+            VQ_TRY(ws.b_fs_mom.ensure((size_t)tiles_max * d * sizeof(double2)));
+            VQ_TRY(ws.b_fs_side.ensure((size_t)side_cap * kFsTile * 4));
+        }
         static PerDeviceOnce fs_attr;
         if (fs_attr.needed()) {
             VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fs_transduce<0>),
@@ -1558,234 +1693,177 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)fs_lds_bytes));
             fs_attr.done();
         }
+    } else {
+        VQ_TRY(ws.b_fs_tiles.ensure(16));
+        VQ_TRY(ws.b_fs_nodes.ensure(16));
+        VQ_TRY(ws.b_fs_base.ensure(16));
+        VQ_TRY(ws.b_fs_nt.ensure(16));
     }
-    std::vector<uint32_t> mom_fast;  // the emulated nodes of the last mean pass: its tile numbering is the moments'
-    auto colsum = [&](int mode, const std::vector<uint32_t> &ids, const uint32_t *perm) -> int {
-        std::vector<uint32_t> slow, fast;
-        for (uint32_t id : ids) ((can_fast && nodes[id].len >= kFsMinRows) ? fast : slow).push_back(id);
-        const bool moments_match = (mode == 1) && (fast == mom_fast);
-        if (mode == 0) mom_fast = fast;
-        std::vector<FsTile> tiles;
-        std::vector<uint32_t> tbase, tcount;
-        for (uint32_t id : fast) {
-            const uint32_t nt = (nodes[id].len + kFsTile - 1) / kFsTile;
-            tbase.push_back((uint32_t)tiles.size());
-            tcount.push_back(nt);
-            for (uint32_t t = 0; t < nt; ++t)
-                tiles.push_back({id, t, nodes[id].start + t * kFsTile, std::min(kFsTile, nodes[id].len - t * kFsTile)});
+    const bool have_fast = can_fast && n >= kFsMinRows;
+
+    // initial state: identity permutation, every row in node 0 (the root), no children anywhere
+    hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, stream, ws.b_perm[0].as<uint32_t>(),
+                       ws.b_nodeof[0].as<uint32_t>(), n);
+    VQ_LAUNCH_CHECK("k_iota");
+    VQ_HIP(hipMemsetAsync(ws.b_lv.p, 0, (size_t)(n_levels + 1) * sizeof(LevelInfo), stream));
+    VQ_HIP(hipMemsetAsync(ws.b_left.p, 0xFF, (size_t)dcap * 4, stream));
+    VQ_HIP(hipMemsetAsync(ws.b_right.p, 0xFF, (size_t)dcap * 4, stream));
+    VQ_HIP(hipMemsetAsync(ws.b_fs_fb.p, 0, 8, stream));
+    {
+        const uint32_t root[2] = {0u, n};  // seg_start[0], seg_len[0]; lv[0] = {first 0, count 1}
+        const uint32_t one = 1u;
+        VQ_HIP(hipMemcpyAsync(na.seg_start, &root[0], 4, hipMemcpyHostToDevice, stream));
+        VQ_HIP(hipMemcpyAsync(na.seg_len, &root[1], 4, hipMemcpyHostToDevice, stream));
+        VQ_HIP(hipMemcpyAsync(&lv[0].count, &one, 4, hipMemcpyHostToDevice, stream));
+        VQ_HIP(hipStreamSynchronize(stream));  // stack sources; also the only synchronisation before the final download
+    }
+    int cur = 0;
+    const uint32_t dgroups = (d + DG - 1) / DG, ncb = (d + kFsCols - 1) / kFsCols;
+    uint32_t *lvl_split = ws.b_lvl.as<uint32_t>(), *remap = ws.b_remap.as<uint32_t>(), *slow_nodes = ws.b_lvl_slow.as<uint32_t>();
+    const FsTile *tl = ws.b_fs_tiles.as<FsTile>();
+    double *ts = ws.b_fs_sum.as<double>();
+    FsSumm *sm = ws.b_fs_summ.as<FsSumm>();
+    double2 *mom = ws.b_fs_mom.as<double2>();
+    const uint32_t *fn = ws.b_fs_nodes.as<uint32_t>(), *fb = ws.b_fs_base.as<uint32_t>(), *fc = ws.b_fs_nt.as<uint32_t>();
+    float *side = ws.b_fs_side.as<float>();
+    uint32_t *fbk = ws.b_fs_fb.as<uint32_t>();
+
+    // sequential-order column sums of the level's nodes: long nodes through the tile-parallel exact emulation (k_fs_*),
+    // the rest through the plain chain kernel.  Grids are upper bounds; the kernels read the level's counts.
+    auto colsum = [&](int mode, const LevelInfo *lvp, uint32_t ub_nodes, const uint32_t *perm) -> int {
+        const uint32_t ub_fast = have_fast ? std::min(ub_nodes, fast_max) : 0u;
+        if (mode == 0)
+            hipLaunchKernelGGL(k_seg_colsum<0>, dim3(ub_nodes, dgroups), dim3(1024), 0, stream, X, d, perm, slow_nodes, lvp, na);
+        else
+            hipLaunchKernelGGL(k_seg_colsum<1>, dim3(ub_nodes, dgroups), dim3(1024), 0, stream, X, d, perm, slow_nodes, lvp, na);
+        VQ_LAUNCH_CHECK("k_seg_colsum");
+        if (ub_fast == 0) return VQHIP_OK;
+        const uint32_t ub_tiles = std::min(tiles_max, n / kFsTile + ub_fast);
+        const dim3 tgrid(ub_tiles * ncb), xgrid(std::min<uint32_t>(ub_tiles * ncb, (uint32_t)num_cus() * 2));  // persistent: two workgroups fit a CU's LDS
+        const dim3 pgrid(ub_fast, ncb), cgrid(ub_fast, d);
+        VQ_HIP(hipMemsetAsync(fbk + 1, 0, 4, stream));
+        if (mode == 0) {
+            hipLaunchKernelGGL(k_fs_tile_sums<0>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts, fs_sample, lvp);
+            hipLaunchKernelGGL(k_fs_prefix, pgrid, dim3(1024), 0, stream, d, fb, fc, ts, lvp);
+            hipLaunchKernelGGL(k_fs_transduce<0>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, lvp, na, ts, sm, side, side_cap, fbk + 1, mom);
+            hipLaunchKernelGGL(k_fs_chain<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp);
+        } else {
+            // the guess comes from the moments the mean pass of the same level left behind (same tile table: every node
+            // long enough for the emulation has more than one row, so it is a split node whenever the level splits)
+            hipLaunchKernelGGL(k_fs_prefix_var, pgrid, dim3(1024), 0, stream, X, d, perm, fn, fb, fc, na, mom, ts, lvp);
+            hipLaunchKernelGGL(k_fs_transduce<1>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, lvp, na, ts, sm, side, side_cap, fbk + 1, (double2 *)nullptr);
+            hipLaunchKernelGGL(k_fs_chain<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp);
         }
-        if (!slow.empty()) {
-            VQ_TRY(b_lvl_slow.ensure(slow.size() * 4));
-            VQ_TRY(upload(b_lvl_slow.p, slow.data(), slow.size() * 4));
-        }
-        if (!fast.empty()) {
-            VQ_TRY(b_fs_tiles.ensure(tiles.size() * sizeof(FsTile)));
-            VQ_TRY(b_fs_nodes.ensure(fast.size() * 4));
-            VQ_TRY(b_fs_base.ensure(fast.size() * 4));
-            VQ_TRY(b_fs_nt.ensure(fast.size() * 4));
-            VQ_TRY(b_fs_sum.ensure(tiles.size() * (size_t)d * 8));
-            VQ_TRY(b_fs_summ.ensure(tiles.size() * (size_t)d * sizeof(FsSumm)));
-            VQ_TRY(b_fs_mom.ensure(tiles.size() * (size_t)d * sizeof(double2)));
-            VQ_TRY(b_fs_side.ensure((size_t)side_cap * kFsTile * 4));
-            VQ_HIP(hipMemsetAsync(b_fs_fb.as<uint32_t>() + 1, 0, 4, stream));
-            VQ_TRY(upload(b_fs_tiles.p, tiles.data(), tiles.size() * sizeof(FsTile)));
-            VQ_TRY(upload(b_fs_nodes.p, fast.data(), fast.size() * 4));
-            VQ_TRY(upload(b_fs_base.p, tbase.data(), fast.size() * 4));
-            VQ_TRY(upload(b_fs_nt.p, tcount.data(), fast.size() * 4));
-        }
-        VQ_TRY(upload_fence());  // the host vectors above go out of scope
-        if (!slow.empty()) {
-            if (mode == 0)
-                hipLaunchKernelGGL(k_seg_colsum<0>, dim3((uint32_t)slow.size(), dgroups), dim3(1024), 0, stream, X, d, perm,
-                                   b_lvl_slow.as<uint32_t>(), na);
-            else
-                hipLaunchKernelGGL(k_seg_colsum<1>, dim3((uint32_t)slow.size(), dgroups), dim3(1024), 0, stream, X, d, perm,
-                                   b_lvl_slow.as<uint32_t>(), na);
-            VQ_LAUNCH_CHECK("k_seg_colsum");
-        }
-        if (!fast.empty()) {
-            const uint32_t n_items = (uint32_t)tiles.size() * ((d + kFsCols - 1) / kFsCols);
-            const dim3 tgrid(n_items);
-            const dim3 xgrid(std::min<uint32_t>(n_items, (uint32_t)num_cus() * 2));  // persistent: two workgroups fit a CU's LDS
-            const FsTile *tl = b_fs_tiles.as<FsTile>();
-            double *ts = b_fs_sum.as<double>();
-            FsSumm *sm = b_fs_summ.as<FsSumm>();
-            const uint32_t *fn = b_fs_nodes.as<uint32_t>(), *fb = b_fs_base.as<uint32_t>(), *fc = b_fs_nt.as<uint32_t>();
-            const dim3 cgrid((uint32_t)fast.size(), d);
-            double2 *mom = b_fs_mom.as<double2>();
-            const dim3 pgrid((uint32_t)fast.size(), (d + kFsCols - 1) / kFsCols);
-            if (mode == 0) {
-                hipLaunchKernelGGL(k_fs_tile_sums<0>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts);
-                hipLaunchKernelGGL(k_fs_prefix, pgrid, dim3(1024), 0, stream, d, fb, fc, ts);
-                hipLaunchKernelGGL(k_fs_transduce<0>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, n_items, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1, mom);
-                hipLaunchKernelGGL(k_fs_chain<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, b_fs_side.as<float>(), b_fs_fb.as<uint32_t>());
-            } else {
-                // the mean pass of the same node set left the moments: `fast` is the same list in both passes of a
-                // level unless some nodes of the level are leaves (then the tile table differs: fall back to a pass)
-                if (moments_match)
-                    hipLaunchKernelGGL(k_fs_prefix_var, pgrid, dim3(1024), 0, stream, X, d, perm, fn, fb, fc, na, mom, ts);
-                else {
-                    hipLaunchKernelGGL(k_fs_tile_sums<1>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts);
-                    hipLaunchKernelGGL(k_fs_prefix, pgrid, dim3(1024), 0, stream, d, fb, fc, ts);
-                }
-                hipLaunchKernelGGL(k_fs_transduce<1>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, n_items, na, ts, sm, b_fs_side.as<float>(), side_cap, b_fs_fb.as<uint32_t>() + 1, (double2 *)nullptr);
-                hipLaunchKernelGGL(k_fs_chain<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, b_fs_side.as<float>(), b_fs_fb.as<uint32_t>());
-            }
-            VQ_LAUNCH_CHECK("k_fs_*");
-            if (getenv("VQHIP_TSVQ_CHECK")) {
-                if (mode == 0) hipLaunchKernelGGL(k_fs_check<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm);
-                else hipLaunchKernelGGL(k_fs_check<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm);
-                VQ_HIP(hipStreamSynchronize(stream));
-            }
+        VQ_LAUNCH_CHECK("k_fs_*");
+        if (getenv("VQHIP_TSVQ_CHECK")) {
+            if (mode == 0) hipLaunchKernelGGL(k_fs_check<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, lvp);
+            else hipLaunchKernelGGL(k_fs_check<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, lvp);
+            VQ_HIP(hipStreamSynchronize(stream));
         }
         return VQHIP_OK;
     };
 
-    while (!level.empty()) {
-        const uint32_t n_lvl = (uint32_t)level.size();
-        VQ_TRY(b_lvl.ensure((size_t)n_lvl * 4));
-        // node segment info for this level
-        {
-            std::vector<uint32_t> st(n_lvl), ln(n_lvl);
-            for (uint32_t li = 0; li < n_lvl; ++li) {
-                st[li] = nodes[level[li]].start;
-                ln[li] = nodes[level[li]].len;
-            }
-            // nodes of a level are created consecutively -> contiguous id range
-            const uint32_t first = level[0];
-            VQ_TRY(upload(na.seg_start + first, st.data(), (size_t)n_lvl * 4));
-            VQ_TRY(upload(na.seg_len + first, ln.data(), (size_t)n_lvl * 4));
-            VQ_TRY(upload(b_lvl.p, level.data(), (size_t)n_lvl * 4));
-            VQ_TRY(upload_fence());  // host vectors go out of scope
+    uint32_t levels_run = 0;
+    for (uint32_t L = 0; L < n_levels; ++L) {
+        uint32_t ub_nodes = level_width(L);
+        if (ub_nodes > 1024) {
+            // wide levels: read the level's node count (one small copy + synchronisation) instead of launching the
+            // per-node grids over 2^L mostly absent nodes; also ends the loop when the tree has stopped growing
+            LevelInfo h;
+            VQ_HIP(hipMemcpyAsync(&h, &lv[L], sizeof(LevelInfo), hipMemcpyDeviceToHost, stream));
+            VQ_HIP(hipStreamSynchronize(stream));
+            if (h.count == 0) break;
+            ub_nodes = h.count;
         }
-        const uint32_t *lvl = b_lvl.as<uint32_t>();
-        uint32_t *perm = b_perm[cur].as<uint32_t>(), *node_of = b_nodeof[cur].as<uint32_t>();
+        ++levels_run;
+        const LevelInfo *lvp = &lv[L];
+        const bool can_split = L + 1 < n_levels || L < max_depth;  // depth left at this level (src/tsvq.rs:38)
+        const bool splits = L < max_depth;
+        (void)can_split;
+        uint32_t *perm = ws.b_perm[cur].as<uint32_t>(), *node_of = ws.b_nodeof[cur].as<uint32_t>();
+        hipLaunchKernelGGL(k_plan_level, dim3(1), dim3(1024), 0, stream, &lv[L], splits ? 1 : 0, can_fast ? 1 : 0, na, lvl_split, remap,
+                           ws.b_fs_nodes.as<uint32_t>(), slow_nodes, ws.b_fs_base.as<uint32_t>(), ws.b_fs_nt.as<uint32_t>(),
+                           ws.b_fs_tiles.as<FsTile>());
+        VQ_LAUNCH_CHECK("k_plan_level");
         // means of every node of the level (tsvq.rs:36)
-        VQ_TRY(colsum(0, level, perm));
-
-        // which nodes split? (tsvq.rs:38-44)
-        std::vector<uint32_t> split_nodes;
-        for (uint32_t id : level)
-            if (nodes[id].depth_left > 0 && nodes[id].len > 1) split_nodes.push_back(id);
-        if (split_nodes.empty()) break;
-        // the split nodes form the working level from here on: rebuild node_of for them only if
-        // some nodes of the level are leaves (their rows become inactive)
-        const uint32_t n_split = (uint32_t)split_nodes.size();
-        if (n_split != n_lvl) {
-            // remap level-local indices: leaves -> inactive.  Done on the host-known segment ranges.
-            std::vector<uint32_t> newidx(n_lvl, kInactive);
-            {
-                uint32_t q = 0;
-                for (uint32_t li = 0; li < n_lvl; ++li)
-                    if (nodes[level[li]].depth_left > 0 && nodes[level[li]].len > 1) newidx[li] = q++;
-            }
-            // tiny remap kernel via memset-style loops per leaf segment
-            for (uint32_t li = 0; li < n_lvl; ++li) {
-                const HostNode &hn = nodes[level[li]];
-                if (newidx[li] == kInactive) {
-                    VQ_HIP(hipMemsetAsync(node_of + hn.start, 0xFF, (size_t)hn.len * 4, stream));
-                } else if (newidx[li] != li) {
-                    // fill with the new index: use hipMemsetD32Async
-                    VQ_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(node_of + hn.start), (int)newidx[li], hn.len, stream));
-                }
-            }
-            VQ_TRY(upload(b_lvl.p, split_nodes.data(), (size_t)n_split * 4));
-            VQ_TRY(upload_fence());
-        }
+        VQ_TRY(colsum(0, lvp, ub_nodes, perm));
+        if (!splits) break;
         // variances + split dimension (tsvq.rs:46-66)
-        VQ_TRY(colsum(1, split_nodes, perm));
-        hipLaunchKernelGGL(k_pick_split, dim3((n_split + 63) / 64), dim3(64), 0, stream, lvl, n_split, d, na);
+        VQ_TRY(colsum(1, lvp, ub_nodes, perm));
+        const uint32_t nb64 = (ub_nodes + 63) / 64;
+        hipLaunchKernelGGL(k_pick_split, dim3(nb64), dim3(64), 0, stream, lvl_split, lvp, d, na);
         VQ_LAUNCH_CHECK("k_pick_split");
         // median (tsvq.rs:68-81)
-        hipLaunchKernelGGL(k_gather_vals, dim3((n + 255) / 256), dim3(256), 0, stream, X, d, n, perm, node_of, lvl, na,
-                           b_vals.as<float>());
+        hipLaunchKernelGGL(k_gather_vals, dim3((n + 255) / 256), dim3(256), 0, stream, X, d, n, perm, node_of, remap, lvl_split, na,
+                           ws.b_vals.as<float>());
         VQ_LAUNCH_CHECK("k_gather_vals");
-        hipLaunchKernelGGL(k_select_init, dim3((n_split + 63) / 64), dim3(64), 0, stream, lvl, n_split, na);
+        hipLaunchKernelGGL(k_select_init, dim3(nb64), dim3(64), 0, stream, lvl_split, lvp, na);
         VQ_LAUNCH_CHECK("k_select_init");
-        VQ_TRY(b_hist.ensure((size_t)std::min<uint64_t>(dcap, n) * 2 * 256 * 4));  // once, for the widest level
-        VQ_HIP(hipMemsetAsync(b_hist.p, 0, (size_t)n_split * 2 * 256 * 4, stream));
+        VQ_HIP(hipMemsetAsync(ws.b_hist.p, 0, (size_t)ub_nodes * 2 * 256 * 4, stream));
         for (int shift = 24; shift >= 0; shift -= 8) {
             const uint32_t hblocks = std::min<uint32_t>((n + 2047) / 2048, (uint32_t)num_cus() * 4);
             const uint32_t hchunk = (n + hblocks - 1) / hblocks;
-            hipLaunchKernelGGL(k_select_hist, dim3(hblocks), dim3(256), 0, stream, b_vals.as<float>(), n, hchunk,
-                               node_of, lvl, na, (uint32_t)shift, b_hist.as<uint32_t>());
+            hipLaunchKernelGGL(k_select_hist, dim3(hblocks), dim3(256), 0, stream, ws.b_vals.as<float>(), n, hchunk, node_of, remap,
+                               lvl_split, na, (uint32_t)shift, ws.b_hist.as<uint32_t>());
             VQ_LAUNCH_CHECK("k_select_hist");
-            hipLaunchKernelGGL(k_select_pick, dim3(n_split * 2), dim3(64), 0, stream, lvl, n_split, na,
-                               (uint32_t)shift, b_hist.as<uint32_t>());
+            hipLaunchKernelGGL(k_select_pick, dim3(ub_nodes * 2), dim3(64), 0, stream, lvl_split, lvp, na, (uint32_t)shift,
+                               ws.b_hist.as<uint32_t>());
             VQ_LAUNCH_CHECK("k_select_pick");
         }
-        hipLaunchKernelGGL(k_median, dim3((n_split + 63) / 64), dim3(64), 0, stream, lvl, n_split, na);
+        hipLaunchKernelGGL(k_median, dim3(nb64), dim3(64), 0, stream, lvl_split, lvp, na);
         VQ_LAUNCH_CHECK("k_median");
         // partition (tsvq.rs:84-85)
-        hipLaunchKernelGGL(k_flags, dim3((n + 255) / 256), dim3(256), 0, stream, b_vals.as<float>(), n, node_of, lvl,
-                           na, b_flags.as<uint32_t>());
+        hipLaunchKernelGGL(k_flags, dim3((n + 255) / 256), dim3(256), 0, stream, ws.b_vals.as<float>(), n, node_of, remap, lvl_split,
+                           na, ws.b_flags.as<uint32_t>());
         VQ_LAUNCH_CHECK("k_flags");
-        hipLaunchKernelGGL(k_scan_blocks, dim3(nblk), dim3(256), 0, stream, b_flags.as<uint32_t>(), n,
-                           b_scan.as<uint32_t>(), b_bsums.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_blocks, dim3(nblk), dim3(256), 0, stream, ws.b_flags.as<uint32_t>(), n,
+                           ws.b_scan.as<uint32_t>(), ws.b_bsums.as<uint32_t>());
         VQ_LAUNCH_CHECK("k_scan_blocks");
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, b_bsums.as<uint32_t>(), nblk);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, ws.b_bsums.as<uint32_t>(), nblk);
         VQ_LAUNCH_CHECK("k_scan_sums");
-        hipLaunchKernelGGL(k_scan_apply, dim3((n + 255) / 256), dim3(256), 0, stream, b_scan.as<uint32_t>(), n,
-                           b_bsums.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan_apply, dim3((n + 255) / 256), dim3(256), 0, stream, ws.b_scan.as<uint32_t>(), n,
+                           ws.b_bsums.as<uint32_t>());
         VQ_LAUNCH_CHECK("k_scan_apply");
-        hipLaunchKernelGGL(k_nleft, dim3((n_split + 63) / 64), dim3(64), 0, stream, lvl, n_split, na,
-                           b_scan.as<uint32_t>(), b_flags.as<uint32_t>());
+        hipLaunchKernelGGL(k_nleft, dim3(nb64), dim3(64), 0, stream, lvl_split, lvp, na, ws.b_scan.as<uint32_t>(),
+                           ws.b_flags.as<uint32_t>());
         VQ_LAUNCH_CHECK("k_nleft");
-        // children (tsvq.rs:88-108) -- decided on the host from nleft / nv
-        std::vector<uint32_t> nleft_all(nodes.size()), nv_all(nodes.size());
-        {
-            const uint32_t first = split_nodes.front(), last = split_nodes.back();
-            VQ_HIP(hipMemcpyAsync(nleft_all.data() + first, na.nleft + first, (size_t)(last - first + 1) * 4,
-                                  hipMemcpyDeviceToHost, stream));
-            VQ_HIP(hipMemcpyAsync(nv_all.data() + first, na.nv + first, (size_t)(last - first + 1) * 4,
-                                  hipMemcpyDeviceToHost, stream));
-            VQ_HIP(hipStreamSynchronize(stream));
-        }
-        std::vector<uint32_t> next;
-        std::vector<uint32_t> child_local((size_t)nodes.size() * 2, kInactive);
-        for (uint32_t id : split_nodes) {
-            if (nv_all[id] == 0)
-                return fail(VQHIP_ERR_INVALID_INPUT,
-                            "TSVQ: every value on a split dimension is NaN (the reference panics here, src/tsvq.rs:77-78)");
-            const uint32_t len = nodes[id].len, nl = nleft_all[id], nr = len - nl;
-            if (nl != 0 && nl < len) {
-                nodes[id].left = (int32_t)nodes.size();
-                child_local[2 * id] = (uint32_t)next.size();
-                next.push_back((uint32_t)nodes.size());
-                nodes.push_back({nodes[id].start, nl, nodes[id].depth_left - 1, -1, -1});
-            }
-            if (nr != 0 && nr < len) {
-                nodes[id].right = (int32_t)nodes.size();
-                child_local[2 * id + 1] = (uint32_t)next.size();
-                next.push_back((uint32_t)nodes.size());
-                nodes.push_back({nodes[id].start + nl, nr, nodes[id].depth_left - 1, -1, -1});
-            }
-        }
-        if (next.empty()) break;
-        if (nodes.size() > dcap) return fail(VQHIP_ERR_FAILURE, "TSVQ node count exceeded its bound");
-        {
-            const uint32_t first = split_nodes.front(), last = split_nodes.back();
-            VQ_TRY(upload(na.child_local + 2 * first, child_local.data() + 2 * first, (size_t)(last - first + 1) * 8));
-        }
-        hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, n, perm, node_of, lvl, na,
-                           b_scan.as<uint32_t>(), b_flags.as<uint32_t>(), b_perm[cur ^ 1].as<uint32_t>(),
-                           b_nodeof[cur ^ 1].as<uint32_t>());
+        // children (tsvq.rs:88-108)
+        hipLaunchKernelGGL(k_plan_children, dim3(1), dim3(1024), 0, stream, &lv[L], &lv[L + 1], lvl_split, na, node_left, node_right, dcap);
+        VQ_LAUNCH_CHECK("k_plan_children");
+        hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, n, perm, node_of, remap, lvl_split, na,
+                           ws.b_scan.as<uint32_t>(), ws.b_flags.as<uint32_t>(), ws.b_perm[cur ^ 1].as<uint32_t>(),
+                           ws.b_nodeof[cur ^ 1].as<uint32_t>());
         VQ_LAUNCH_CHECK("k_scatter");
-        VQ_TRY(upload_fence());  // child_local host vector
         cur ^= 1;
-        level.swap(next);
     }
 
-    if (getenv("VQHIP_TSVQ_DEBUG")) {
-        uint32_t fb = 0;
-        VQ_HIP(hipMemcpyAsync(&fb, b_fs_fb.p, 4, hipMemcpyDeviceToHost, stream));
-        VQ_HIP(hipStreamSynchronize(stream));
-        fprintf(stderr, "[vqhip] tsvq build: %u tile re-additions in the exact column sums\n", fb);
+    // level table -> host: node count, error flags; then the nodes
+    std::vector<LevelInfo> hlv(n_levels + 1);
+    VQ_HIP(hipMemcpyAsync(hlv.data(), lv, (size_t)(n_levels + 1) * sizeof(LevelInfo), hipMemcpyDeviceToHost, stream));
+    VQ_HIP(hipStreamSynchronize(stream));
+    uint32_t total = 0;
+    for (uint32_t L = 0; L < n_levels; ++L) {
+        if (hlv[L].error == 1)
+            return fail(VQHIP_ERR_INVALID_INPUT,
+                        "TSVQ: every value on a split dimension is NaN (the reference panics here, src/tsvq.rs:77-78)");
+        if (hlv[L].error) return fail(VQHIP_ERR_FAILURE, "TSVQ node count exceeded its bound");
+        if (hlv[L].count == 0) break;
+        total = hlv[L].first + hlv[L].count;
     }
-    // centroids of all nodes -> host, then BFS -> pre-order (the oracle's numbering)
-    const uint32_t total = (uint32_t)nodes.size();
+    (void)levels_run;
+    if (total == 0 || total > dcap) return fail(VQHIP_ERR_FAILURE, "TSVQ build produced %u nodes (bound %u)", total, dcap);
+    if (getenv("VQHIP_TSVQ_DEBUG")) {
+        uint32_t fbn = 0;
+        VQ_HIP(hipMemcpyAsync(&fbn, fbk, 4, hipMemcpyDeviceToHost, stream));
+        VQ_HIP(hipStreamSynchronize(stream));
+        fprintf(stderr, "[vqhip] tsvq build: %u tile re-additions in the exact column sums\n", fbn);
+    }
+    // nodes -> host, then BFS -> pre-order (the oracle's numbering)
     std::vector<float> cent((size_t)total * d);
+    std::vector<int32_t> hl(total), hr(total);
     VQ_HIP(hipMemcpyAsync(cent.data(), na.centroid, (size_t)total * d * 4, hipMemcpyDeviceToHost, stream));
+    VQ_HIP(hipMemcpyAsync(hl.data(), node_left, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+    VQ_HIP(hipMemcpyAsync(hr.data(), node_right, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
     VQ_HIP(hipStreamSynchronize(stream));
     std::vector<int32_t> order;  // pre-order list of BFS ids
     order.reserve(total);
@@ -1794,16 +1872,16 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         const int32_t id = stack.back();
         stack.pop_back();
         order.push_back(id);
-        if (nodes[id].right >= 0) stack.push_back(nodes[id].right);
-        if (nodes[id].left >= 0) stack.push_back(nodes[id].left);
+        if (hr[id] >= 0) stack.push_back(hr[id]);
+        if (hl[id] >= 0) stack.push_back(hl[id]);
     }
     std::vector<int32_t> newid(total, -1);
     for (uint32_t q = 0; q < order.size(); ++q) newid[order[q]] = (int32_t)q;
     for (uint32_t q = 0; q < order.size(); ++q) {
         const int32_t id = order[q];
         memcpy(centroids_out + (size_t)q * d, cent.data() + (size_t)id * d, (size_t)d * 4);
-        left_out[q] = nodes[id].left >= 0 ? newid[nodes[id].left] : -1;
-        right_out[q] = nodes[id].right >= 0 ? newid[nodes[id].right] : -1;
+        left_out[q] = hl[id] >= 0 ? newid[hl[id]] : -1;
+        right_out[q] = hr[id] >= 0 ? newid[hr[id]] : -1;
     }
     *n_nodes_out = (int32_t)order.size();
     return VQHIP_OK;
