@@ -165,7 +165,7 @@ struct CodebookState {
 
 // --------------------------------------------------------------- assign workspace ----
 struct AssignWorkspace {
-    DevBuf wl_rows, wl_count, sub_list, wl_seg, part;
+    DevBuf wl_rows, wl_count, sub_list, sub_pos, wl_seg, part;
     static constexpr uint32_t kSegCap = 4096;  // wave-private work-list segments per subspace
     uint32_t *seg_host = nullptr;               // pinned [m][kSegCap][2]
     uint32_t last_n_seg = 0;
@@ -182,6 +182,7 @@ struct AssignWorkspace {
     }
     int ensure(uint32_t m, uint64_t n, bool need_wl) {
         if (!sub_list.p || sub_list.bytes < (size_t)m * 4) VQ_TRY(sub_list.alloc((size_t)m * 4));
+        if (!sub_pos.p || sub_pos.bytes < (size_t)m * 4) VQ_TRY(sub_pos.alloc((size_t)m * 4));
         if (!wl_count.p || wl_m < m) {
             VQ_TRY(wl_count.alloc((size_t)m * 4));
             if (stats_host) (void)hipHostFree(stats_host);
@@ -201,10 +202,14 @@ struct AssignWorkspace {
         if (wl_m < m) wl_m = m;
         return VQHIP_OK;
     }
-    int set_sub_list(const std::vector<uint32_t> &subs, hipStream_t stream) {
+    int set_sub_list(const std::vector<uint32_t> &subs, uint32_t m, hipStream_t stream) {
         if (subs != sub_host) {
             // the previous list may still be read by queued kernels: order on the stream
+            std::vector<int32_t> pos(m, -1);  // subspace -> position in the list (the fused update's slab index)
+            for (size_t i = 0; i < subs.size(); ++i)
+                if (subs[i] < m) pos[subs[i]] = (int32_t)i;
             VQ_HIP(hipMemcpyAsync(sub_list.p, subs.data(), subs.size() * 4, hipMemcpyHostToDevice, stream));
+            VQ_HIP(hipMemcpyAsync(sub_pos.p, pos.data(), (size_t)m * 4, hipMemcpyHostToDevice, stream));
             VQ_HIP(hipStreamSynchronize(stream));
             sub_host = subs;
         }
@@ -247,10 +252,21 @@ static int pick_engine(int requested, const CodebookState &cs, int metric, int *
     return VQHIP_OK;
 }
 
+// Fused update of a training step: the screen adds the rows it proves into partial slabs, the rows it
+// re-checks are added by a list-driven pass behind the re-check.  in: buffers + capacity in slabs; out: used / chunks.
+struct FusedAcc {
+    float *sums = nullptr;
+    uint32_t *counts = nullptr;
+    uint32_t slab_cap = 0;   // slabs of [k][sd] available (one per (chunk, active subspace))
+    uint32_t n_patch = 16;   // list-driven chunks behind the screen's
+    bool used = false;       // out: the launch sequence took the fused path
+    uint32_t chunks = 0;     // out: chunks to reduce (screen + patch)
+};
+
 // assignment of every row of X [n][d] for the listed subspaces -> codes [n][m]
 static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, uint64_t n, uint32_t d,
                       int metric, const std::vector<uint32_t> &subs, uint8_t *codes, int engine_req,
-                      hipStream_t stream) {
+                      hipStream_t stream, FusedAcc *fused = nullptr) {
     if (n == 0 || subs.empty()) return VQHIP_OK;
     if (n >= (1ull << 32)) return fail(VQHIP_ERR_UNSUPPORTED, "more than 2^32-1 rows per device");
     if ((reinterpret_cast<uintptr_t>(X) & 15) != 0)
@@ -265,7 +281,7 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
     VQ_TRY(cs.prepare(stream));
     const bool screened = (engine == VQHIP_ENGINE_MFMA || engine == VQHIP_ENGINE_MFMA_BF16);
     VQ_TRY(ws.ensure(cs.m, n, screened));
-    VQ_TRY(ws.set_sub_list(subs, stream));
+    VQ_TRY(ws.set_sub_list(subs, cs.m, stream));
     AssignArgs a;
     a.X = X;
     a.n = n;
@@ -283,6 +299,13 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
     if (engine == VQHIP_ENGINE_MFMA_BF16 && (cs.x32_groups > 1 || x32_padded_sd(cs.sd) > 64)) {  // (the wide kernel goes through the partial verdicts even with one group)
         VQ_TRY(ws.part.ensure((size_t)cs.m * cs.x32_groups * n * 16));
         a.part = ws.part.p;
+    }
+    if (fused) fused->used = false;
+    if (fused && fused->sums && engine == VQHIP_ENGINE_MFMA_BF16 && metric != VQHIP_COSINE && cs.x32_groups == 1 &&
+        screen_bf16_fused_update_supported(cs.sd, cs.k) && fused->slab_cap / a.n_sub > fused->n_patch) {
+        a.acc_sums = fused->sums;
+        a.acc_counts = fused->counts;
+        a.acc_chunk_cap = fused->slab_cap / a.n_sub - fused->n_patch;
     }
     CodebookView v = cs.view();
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -302,6 +325,12 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
         else VQ_TRY(launch_assign_screen(v, a, stream));
         if (e1) VQ_HIP(hipEventRecord(e1, stream));
         VQ_TRY(launch_assign_exact(v, a, true, stream));
+        if (a.acc_sums) {  // the re-checked rows, now that their codes are final
+            VQ_TRY(launch_accumulate_listed(cs.m, cs.k, cs.sd, X, d, codes, a.sub_list, a.n_sub, a.wl_rows, a.wl_stride, a.wl_seg,
+                                            a.n_seg, a.acc_chunks, fused->n_patch, a.acc_sums, a.acc_counts, stream));
+            fused->used = true;
+            fused->chunks = a.acc_chunks + fused->n_patch;
+        }
         if (e2) VQ_HIP(hipEventRecord(e2, stream));
         ws.last_n_seg = a.n_seg;
         if (a.n_seg > 0)
@@ -348,6 +377,7 @@ struct vqhip_kmeans {
     bool all_active = true;
     int engine = VQHIP_ENGINE_AUTO;
     int exact_update = 0;
+    uint32_t fused_slabs = 0;     // > 0: partial buffers sized for the fused update (screen + list-driven slabs)
     bool sums_by_chains = false;  // sub_dim beyond the LDS update kernels: cluster sums always through launch_exact_sums
     bool accumulated = false;
     uint32_t *counts_host = nullptr;   // pinned [m*k]
@@ -799,8 +829,16 @@ int vqhip_kmeans_create(const vqhip_dataset *ds, uint32_t m, uint32_t k, vqhip_k
     if (!km->sums_by_chains) VQ_TRY(plan_update(m, k, sd, ds->n, &km->plan));
     VQ_TRY(km->codes.alloc((size_t)ds->n * m * code_bytes(k)));
     if (!km->sums_by_chains) {
-        VQ_TRY(km->partial_sums.alloc(km->plan.partial_floats * km->plan.n_row_chunks * 4));
-        VQ_TRY(km->partial_counts.alloc(km->plan.partial_counts * km->plan.n_row_chunks * 4));
+        size_t sums_b = km->plan.partial_floats * km->plan.n_row_chunks * 4, cnt_b = km->plan.partial_counts * km->plan.n_row_chunks * 4;
+        static const char *no_fused = getenv("VQHIP_FUSED_UPDATE");  // =0: always the separate accumulate pass (A/B)
+        if (km->cs.x32_ok && screen_bf16_fused_update_supported(sd, k) && !(no_fused && no_fused[0] == '0')) {
+            // fused update: one slab per (screen wave chunk or patch chunk, active subspace); <= 8 waves per CU
+            km->fused_slabs = (uint32_t)num_cus() * 8 + 16 * m;
+            sums_b = std::max(sums_b, (size_t)km->fused_slabs * k * sd * 4);
+            cnt_b = std::max(cnt_b, (size_t)km->fused_slabs * k * 4);
+        }
+        VQ_TRY(km->partial_sums.alloc(sums_b));
+        VQ_TRY(km->partial_counts.alloc(cnt_b));
     }
     VQ_TRY(km->slab.alloc((size_t)m * k * (sd + 1) * 8));
     VQ_TRY(km->counts.alloc((size_t)m * k * 4));
@@ -899,11 +937,21 @@ static int kmeans_accumulate_enqueue(vqhip_kmeans *km, hipStream_t s) {
         if (km->active[i]) subs.push_back(i);
     const vqhip_dataset *ds = km->ds;
     g_last_ws = &km->ws;
-    // assignment: always squared L2 (src/core/vector.rs:352-363)
+    // assignment: always squared L2 (src/core/vector.rs:352-363); with the update fused in where the shape allows
+    FusedAcc fused;
+    if (km->fused_slabs && !km->exact_update && !km->sums_by_chains) {
+        fused.sums = km->partial_sums.as<float>();
+        fused.counts = km->partial_counts.as<uint32_t>();
+        fused.slab_cap = km->fused_slabs;
+    }
     VQ_TRY(run_assign(km->cs, km->ws, ds->X, ds->n, ds->d, VQHIP_SQUARED_EUCLIDEAN, subs,
-                      km->codes.as<uint8_t>(), km->engine, s));
+                      km->codes.as<uint8_t>(), km->engine, s, &fused));
     const uint8_t *act = km->all_active ? nullptr : km->active_dev.as<uint8_t>();
-    if (km->exact_update || km->sums_by_chains) {
+    if (fused.used) {
+        VQ_TRY(launch_reduce_partials_pos(km->cs.m, km->cs.k, km->cs.sd, km->partial_sums.as<float>(),
+                                          km->partial_counts.as<uint32_t>(), fused.chunks, (uint32_t)subs.size(),
+                                          km->ws.sub_pos.as<int32_t>(), km->slab.as<double>(), s));
+    } else if (km->exact_update || km->sums_by_chains) {
         size_t need = exact_sums_workspace_bytes(km->cs.m, km->cs.k, ds->n);
         VQ_TRY(km->xs_ws.ensure(need));
         VQ_TRY(launch_exact_sums(km->cs.m, km->cs.k, km->cs.sd, ds->X, ds->n, ds->d, km->codes.as<uint8_t>(), act,

@@ -201,7 +201,13 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
 // SD - sdr are zero in both operands (k_center_codebook_x32 writes the copy SD wide): a sub_dim between two
 // instantiated ones rides on the next one up instead of the exact engine.  PVW = floats per load part, as the
 // sub-vectors' alignment allows: 4 (sdr % 4 == 0), 2 (even sdr) or 1.
-template <int SD, int NT32, int G = 1, int PVW = 0>
+// ACC ("fused update", training only): the wave also OWNS the per-cluster sums and counts of its (row chunk,
+// subspace) in LDS and adds every row it has just PROVEN -- the row's sub-vector is still in its registers -- so a
+// Lloyd iteration reads X once (src/core/vector.rs:432-447, 368-384).  Rows that go to the exact
+// re-check are left out here and added by k_accumulate_listed (k_update.hip) once their code is known.  Rows of one
+// 32-row step that share a cluster are serialised by rank (earlier rows first): rank = ticket - count-before-the-step,
+// the ticket from a returning LDS add on the cluster's counter -- which is the count the update needs anyway.
+template <int SD, int NT32, int G = 1, int PVW = 0, bool ACC = false>
 // k <= 128 at sub_dim <= 16: the A image is <= 96 registers, two waves fit a SIMD (0.30 vs 0.37 ms at C2 / k=128)
 __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_assign_screen_bf16_x32(
     const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m,
@@ -209,7 +215,9 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
     const float *__restrict__ meta, const uint32_t *__restrict__ sub_list, uint32_t n_sub,
     uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_seg,
     uint32_t n_seg, uint64_t wl_stride, int cosine, uint32_t k_real, const float *__restrict__ cen,
-    uint4 *__restrict__ part, uint32_t groups_rt, uint32_t sdr) {
+    uint4 *__restrict__ part, uint32_t groups_rt, uint32_t sdr, float *__restrict__ acc_sums,
+    uint32_t *__restrict__ acc_counts) {
+    static_assert(!ACC || (G == 1 && PVW == 0 && SD % 8 == 0), "fused update: single-pass kernels, lane halves of whole 16-byte parts");
     // G > 0: compile-time group count (k <= 256); G == 0: k > 256, the count comes in groups_rt
     const uint32_t groups = (G > 0) ? (uint32_t)G : groups_rt;
     constexpr int DPH = SD / 2;            // dims owned by a lane half
@@ -231,7 +239,30 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
     const uint64_t st0 = (uint64_t)chunk * steps_per_chunk;
     uint64_t st1 = st0 + steps_per_chunk;
     if (st1 > n_steps) st1 = n_steps;
-    if (st0 >= st1) return;
+    // fused update: this wave's [NT32*32][SD] sums + counts in LDS (it is their only writer) -> one partial slab
+    extern __shared__ __attribute__((aligned(16))) float acc_lds[];
+    float *sums = nullptr;
+    uint32_t *cnts = nullptr;
+    if constexpr (ACC) {
+        constexpr uint32_t kPerWave = NT32 * 32 * (SD + 1);
+        sums = acc_lds + (size_t)wave * kPerWave;
+        cnts = reinterpret_cast<uint32_t *>(sums + NT32 * 32 * SD);
+        for (uint32_t e = lane; e < NT32 * 32 * SD / 4; e += 64) reinterpret_cast<float4 *>(sums)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t e = lane; e < NT32 * 32; e += 64) cnts[e] = 0u;
+    }
+    auto write_partial = [&]() {
+        if constexpr (ACC) {
+            // slab of (row chunk, position of the subspace in the active list): [chunk][n_sub][k][SD]
+            float4 *ps = reinterpret_cast<float4 *>(acc_sums + ((size_t)chunk * n_sub + vv) * k_real * SD);
+            for (uint32_t e = lane; e < k_real * SD / 4; e += 64) ps[e] = reinterpret_cast<const float4 *>(sums)[e];
+            uint32_t *pc = acc_counts + ((size_t)chunk * n_sub + vv) * k_real;
+            for (uint32_t e = lane; e < k_real; e += 64) pc[e] = cnts[e];
+        }
+    };
+    if (st0 >= st1) {
+        write_partial();  // an empty chunk still owns a (zero) slab
+        return;
+    }
     // wave-private work-list segment: slots [seg_first, seg_first + rows of the chunk) of the
     // subspace's list, filled in row order without atomics (a returning global atomic stalls a
     // lone wave for ~3000 cycles); {first, count} is published once at the end
@@ -345,8 +376,12 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
     load_x(st0 * 32 + p, xn_);
     for (uint64_t st = st0; st < st1; ++st) {
         float x[DPH];
+        float xo[ACC ? DPH : 1];  // the row's own values (the screen works on x - mu)
 #pragma unroll
-        for (int q = 0; q < DPH; ++q) x[q] = xn_[q] - mu[q];
+        for (int q = 0; q < DPH; ++q) {
+            x[q] = xn_[q] - mu[q];
+            if constexpr (ACC) xo[q] = xn_[q];
+        }
         if (st + 1 < st1) load_x((st + 1) * 32 + p, xn_);
 
         // three bf16 slices of the lane's DPH components, packed two per dword
@@ -522,7 +557,33 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
             }
             seg_count += (uint32_t)__popcll(mask);
         }
+        if constexpr (ACC) {
+            const bool mine = proven && (row < n);  // both lane halves of the row agree
+            uint32_t rank = 0xFFFFFFFFu;
+            if (mine && h == 0) {
+                const uint32_t before = cnts[j];               // every lane reads before any lane adds (one wave, in order)
+                rank = atomicAdd(&cnts[j], 1u) - before;       // ds_add_rtn_u32: rows of one cluster get 0, 1, 2, ...
+            }
+            rank = __builtin_amdgcn_permlane32_swap(rank, rank, false, false)[0];  // the row's other half takes the same turn
+            float4 *slot = reinterpret_cast<float4 *>(sums + (size_t)(mine ? j : 0u) * SD + DPH * h);
+            for (uint32_t r = 0;; ++r) {
+                if (!__any(rank != 0xFFFFFFFFu && rank >= r)) break;
+                if (rank == r) {
+#pragma unroll
+                    for (int q = 0; q < DPH / 4; ++q) {
+                        float4 t = slot[q];
+                        t.x = t.x + xo[4 * q + 0];
+                        t.y = t.y + xo[4 * q + 1];
+                        t.z = t.z + xo[4 * q + 2];
+                        t.w = t.w + xo[4 * q + 3];
+                        slot[q] = t;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
+    write_partial();
     if (G == 1 && lane == 0) {
         uint32_t *sg = wl_seg + ((size_t)s * n_seg + chunk) * 2;
         sg[0] = seg_first;
@@ -727,7 +788,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_wide(
     }
 }
 
-template <int SD, int NT32, int G = 1, int PVW = 0>
+template <int SD, int NT32, int G = 1, int PVW = 0, bool ACC = false>
 int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stream, uint32_t groups_rt = 0) {
     const uint32_t groups = (G > 0) ? (uint32_t)G : groups_rt;  // G == 0: run-time group count (k > 256)
     const uint64_t n_steps = (a.n + 31) / 32;
@@ -749,10 +810,24 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
         if (!a.part) return fail(VQHIP_ERR_FAILURE, "grouped screen without a partial-result buffer");
         a.n_seg = 0;  // the merge kernel appends to the unsegmented list
     }
-    hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32, G, PVW>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d,
+    size_t dyn_lds = 0;
+    if constexpr (ACC) {
+        // one partial slab per (row chunk, subspace): the chunk count is this launch's wave geometry
+        if (n_chunks > a.acc_chunk_cap)
+            return fail(VQHIP_ERR_FAILURE, "fused update: %u row chunks exceed the partial-slab capacity %u", n_chunks, a.acc_chunk_cap);
+        a.acc_chunks = n_chunks;
+        dyn_lds = (size_t)kWavesPerBlock * NT32 * 32 * (SD + 1) * 4;
+        static PerDeviceOnce attr_set;
+        if (attr_set.needed()) {
+            VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign_screen_bf16_x32<SD, NT32, G, PVW, ACC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+            attr_set.done();
+        }
+    }
+    hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32, G, PVW, ACC>), dim3(blocks), dim3(kBlock), dyn_lds, stream, a.X, a.n, a.d,
                        cb.m, cb.prepA32, cb.cn32, NT32 * groups * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
                        a.wl_seg, n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen,
-                       reinterpret_cast<uint4 *>(a.part), groups, cb.sd);
+                       reinterpret_cast<uint4 *>(a.part), groups, cb.sd, ACC ? a.acc_sums : nullptr, ACC ? a.acc_counts : nullptr);
     VQ_LAUNCH_CHECK("k_assign_screen_bf16_x32");
     if (G != 1) {
         uint64_t mblocks = (a.n + 255) / 256;
@@ -858,6 +933,13 @@ void screen_bf16_x32_tiling(uint32_t sd_real, uint32_t k, uint32_t *nt32_per_gro
     *groups = g;
 }
 
+// shapes whose training assignment can carry the fused update (launch_assign_screen_bf16 with acc_sums set)
+bool screen_bf16_fused_update_supported(uint32_t sd, uint32_t k) {
+    uint32_t per, groups;
+    screen_bf16_x32_tiling(sd, k, &per, &groups);
+    return per != 0 && groups == 1 && k <= 256 && (sd == 8 || sd == 16 || sd == 24) && x32_padded_sd(sd) == sd;
+}
+
 bool screen_bf16_x32_supported(uint32_t sd, uint32_t k) {
     uint32_t per, groups;
     screen_bf16_x32_tiling(sd, k, &per, &groups);
@@ -907,6 +989,16 @@ int launch_assign_screen_bf16(const CodebookView &cb, const AssignArgs &a, hipSt
     {
         uint32_t nt32 = 0, groups = 0;
         screen_bf16_x32_tiling(cb.sd, cb.k, &nt32, &groups);
+        // fused update (training): the same kernels with the cluster sums of the proven rows kept in LDS
+        if (a.acc_sums && groups == 1 && a.metric != VQHIP_COSINE && cb.k <= 256) {
+#define VQ_X32A(SDV, NTV) \
+    if (cb.sd == SDV && nt32 == NTV) return launch_one_x32<SDV, NTV, 1, 0, true>(cb, a, stream);
+            VQ_X32A(16, 1) VQ_X32A(16, 2) VQ_X32A(16, 3) VQ_X32A(16, 4) VQ_X32A(16, 5) VQ_X32A(16, 6) VQ_X32A(16, 7) VQ_X32A(16, 8)
+            VQ_X32A(8, 1) VQ_X32A(8, 2) VQ_X32A(8, 3) VQ_X32A(8, 4) VQ_X32A(8, 5) VQ_X32A(8, 6) VQ_X32A(8, 7) VQ_X32A(8, 8)
+            VQ_X32A(24, 1) VQ_X32A(24, 2) VQ_X32A(24, 3) VQ_X32A(24, 4) VQ_X32A(24, 5) VQ_X32A(24, 6) VQ_X32A(24, 7) VQ_X32A(24, 8)
+#undef VQ_X32A
+            return fail(VQHIP_ERR_FAILURE, "fused update requested for a shape without a fused screen (sub_dim=%u)", cb.sd);
+        }
 #define VQ_X32(SDV, NTV) \
     if (cb.sd == SDV && nt32 == NTV && groups == 1) return launch_one_x32<SDV, NTV>(cb, a, stream);
 #define VQ_X32G(SDV, NTV, GV) \

@@ -265,6 +265,73 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
     for (uint32_t e = lane; e < k; e += 64) pcnt[e] = cnts[e];
 }
 
+// The fused screen (k_assign_screen_bf16_x32<..., ACC>) sums the rows it proves; the rows it hands to the exact
+// re-check are listed per (subspace, screen chunk) in row order (wl_seg / wl_rows).  Once the re-check has written
+// their codes, one wave per (patch chunk, subspace) walks its share of the segments in order and adds the listed
+// rows exactly like k_accumulate_owned (rank rounds, ascending row order inside a cluster) into one more partial
+// slab.  ~0.1 % of the rows on uniform data, a few per cent on tightly clustered data.
+template <int KS>
+__global__ __launch_bounds__(64) void k_accumulate_listed(
+    const float *__restrict__ X, uint32_t d, uint32_t m, uint32_t k, const uint8_t *__restrict__ codes,
+    const uint32_t *__restrict__ sub_list, const uint32_t *__restrict__ wl_rows, uint64_t wl_stride,
+    const uint32_t *__restrict__ wl_seg, uint32_t n_seg, uint32_t segs_per_patch, uint32_t first_chunk,
+    float *__restrict__ partial_sums, uint32_t *__restrict__ partial_counts) {
+    constexpr uint32_t SD = KS * 4, RPS = 64 / KS;
+    constexpr bool POW2 = (KS & (KS - 1)) == 0;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t s = sub_list[blockIdx.y];
+    float *sums = lds;
+    uint32_t *cnts = reinterpret_cast<uint32_t *>(sums + (size_t)k * SD);
+    for (uint32_t e = lane; e < k * SD; e += 64) sums[e] = 0.0f;
+    for (uint32_t e = lane; e < k; e += 64) cnts[e] = 0u;
+    const uint32_t p = lane / KS, g = lane % KS;
+    const bool lane_on = lane < RPS * KS;
+    auto swz = [](uint32_t gg, uint32_t c) { return POW2 ? (gg ^ (c & (KS - 1))) : ((gg + c) % KS); };
+    const uint32_t seg0 = blockIdx.x * segs_per_patch;
+    const uint32_t seg1 = min(n_seg, seg0 + segs_per_patch);
+    for (uint32_t seg = seg0; seg < seg1; ++seg) {
+        const uint32_t first = wl_seg[((size_t)s * n_seg + seg) * 2], count = wl_seg[((size_t)s * n_seg + seg) * 2 + 1];
+        for (uint32_t e0 = 0; e0 < count; e0 += RPS) {
+            const bool valid = lane_on && (e0 + p < count);
+            const uint32_t row = valid ? wl_rows[(size_t)s * wl_stride + first + e0 + p] : 0u;
+            const uint32_t code = valid ? (uint32_t)codes[(size_t)row * m + s] : 0xFFFFFFFFu;
+            const float4 x = valid ? *reinterpret_cast<const float4 *>(X + (size_t)row * d + (size_t)s * SD + 4 * g)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            uint32_t rank = 0;
+#pragma unroll
+            for (uint32_t q = 0; q + 1 < RPS; ++q) {
+                const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)code, (int)(q * KS));
+                rank += (q < p && cq == code) ? 1u : 0u;
+            }
+            float4 *slot = reinterpret_cast<float4 *>(sums + (size_t)(valid ? code : 0u) * SD) + swz(g, code);
+            uint32_t pending = valid ? 1u : 0u;
+            for (uint32_t r = 0; __any(pending != 0); ++r) {
+                if (pending && rank == r) {
+                    float4 t = *slot;
+                    t.x = t.x + x.x;
+                    t.y = t.y + x.y;
+                    t.z = t.z + x.z;
+                    t.w = t.w + x.w;
+                    *slot = t;
+                    if (g == 0) cnts[code] += 1u;
+                    pending = 0;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    // slab layout of the fused path: [chunk][position in the active list][k][SD]
+    const size_t slab_id = (size_t)(first_chunk + blockIdx.x) * gridDim.y + blockIdx.y;
+    float *ps = partial_sums + slab_id * k * SD;
+    for (uint32_t e = lane; e < k * KS; e += 64) {
+        const uint32_t j = e / KS, gg = e % KS;
+        reinterpret_cast<float4 *>(ps + (size_t)j * SD)[gg] = reinterpret_cast<const float4 *>(sums + (size_t)j * SD)[swz(gg, j)];
+    }
+    uint32_t *pcnt = partial_counts + slab_id * k;
+    for (uint32_t e = lane; e < k; e += 64) pcnt[e] = cnts[e];
+}
+
 // 32 slab elements x 8 chunk groups per workgroup; every element's chunks are summed in a
 // fixed order (group-strided, then groups ascending), so the result is reproducible.
 constexpr uint32_t kRedGroups = 8;
@@ -289,6 +356,42 @@ __global__ __launch_bounds__(256) void k_reduce_partials(
                 const uint32_t *p = partial_counts + sj;
                 unsigned long long cnt = 0;
                 for (uint32_t c = grp; c < n_row_chunks; c += kRedGroups) cnt += p[c * stride];
+                acc = (double)cnt;
+            }
+        }
+    }
+    part[grp][el] = acc;
+    __syncthreads();
+    if (grp == 0 && e < total) {
+        double r = part[0][el];
+        for (uint32_t g = 1; g < kRedGroups; ++g) r += part[g][el];
+        slab[e] = r;
+    }
+}
+
+// the same for the fused path's slabs [chunk][position in the active subspace list][k][sd]; sub_pos[s] = position or -1
+__global__ __launch_bounds__(256) void k_reduce_partials_pos(
+    const float *__restrict__ partial_sums, const uint32_t *__restrict__ partial_counts,
+    uint32_t n_chunks, uint32_t n_sub, const int32_t *__restrict__ sub_pos, uint32_t m, uint32_t k, uint32_t sd,
+    double *__restrict__ slab) {
+    __shared__ double part[kRedGroups][32];
+    const uint32_t total = m * k * (sd + 1);
+    const uint32_t el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const uint32_t e = blockIdx.x * 32 + el;
+    double acc = 0.0;
+    if (e < total) {
+        const uint32_t t = e % (sd + 1), sj = e / (sd + 1), s = sj / k, j = sj - s * k;
+        const int32_t pos = sub_pos[s];
+        if (pos >= 0) {
+            if (t < sd) {
+                const size_t stride = (size_t)n_sub * k * sd;
+                const float *p = partial_sums + ((size_t)pos * k + j) * sd + t;
+                for (uint32_t c = grp; c < n_chunks; c += kRedGroups) acc += (double)p[c * stride];
+            } else {
+                const size_t stride = (size_t)n_sub * k;
+                const uint32_t *p = partial_counts + (size_t)pos * k + j;
+                unsigned long long cnt = 0;
+                for (uint32_t c = grp; c < n_chunks; c += kRedGroups) cnt += p[c * stride];
                 acc = (double)cnt;
             }
         }
@@ -525,6 +628,15 @@ int launch_reduce_partials(const UpdatePlan &p, const float *partial_sums,
     return VQHIP_OK;
 }
 
+int launch_reduce_partials_pos(uint32_t m, uint32_t k, uint32_t sd, const float *partial_sums, const uint32_t *partial_counts,
+                               uint32_t n_chunks, uint32_t n_sub, const int32_t *sub_pos, double *slab, hipStream_t stream) {
+    const uint32_t total = m * k * (sd + 1);
+    hipLaunchKernelGGL(k_reduce_partials_pos, dim3((total + 31) / 32), dim3(256), 0, stream, partial_sums, partial_counts,
+                       n_chunks, n_sub, sub_pos, m, k, sd, slab);
+    VQ_LAUNCH_CHECK("k_reduce_partials_pos");
+    return VQHIP_OK;
+}
+
 int launch_finalize(uint32_t m, uint32_t k, uint32_t sd, const double *slab, const uint8_t *active,
                     float *centroids, uint32_t *counts, uint32_t *changed, int exact_div,
                     hipStream_t stream) {
@@ -541,6 +653,28 @@ int launch_gather_rows(const float *X, uint32_t d, uint32_t m, uint32_t k, uint3
     hipLaunchKernelGGL(k_gather_rows, dim3((total + 255) / 256), dim3(256), 0, stream, X, d, m, k,
                        sd, rows, centroids);
     VQ_LAUNCH_CHECK("k_gather_rows");
+    return VQHIP_OK;
+}
+
+int launch_accumulate_listed(uint32_t m, uint32_t k, uint32_t sd, const float *X, uint32_t d, const uint8_t *codes,
+                             const uint32_t *sub_list, uint32_t n_sub, const uint32_t *wl_rows, uint64_t wl_stride,
+                             const uint32_t *wl_seg, uint32_t n_seg, uint32_t first_chunk, uint32_t n_patch,
+                             float *partial_sums, uint32_t *partial_counts, hipStream_t stream) {
+    if (n_sub == 0 || n_patch == 0) return VQHIP_OK;
+    const uint32_t spp = (n_seg + n_patch - 1) / n_patch;
+    const size_t lds = (size_t)k * (sd + 1) * 4;
+    const dim3 grid(n_patch, n_sub);
+#define VQ_LISTED(KSV)                                                                                                  \
+    hipLaunchKernelGGL(k_accumulate_listed<KSV>, grid, dim3(64), lds, stream, X, d, m, k, codes, sub_list, wl_rows, wl_stride, \
+                       wl_seg, n_seg, spp, first_chunk, partial_sums, partial_counts)
+    switch (sd) {
+    case 8: VQ_LISTED(2); break;
+    case 16: VQ_LISTED(4); break;
+    case 24: VQ_LISTED(6); break;
+    default: return fail(VQHIP_ERR_UNSUPPORTED, "listed accumulate: sub_dim=%u", sd);
+    }
+#undef VQ_LISTED
+    VQ_LAUNCH_CHECK("k_accumulate_listed");
     return VQHIP_OK;
 }
 

@@ -58,6 +58,7 @@ void mfma_bf16_model_case(uint64_t seed, uint64_t trial, uint16_t *a, uint16_t *
 // bf16-split screen (k_screen_bf16.hip)
 uint32_t x32_padded_sd(uint32_t sd);  // sub_dim of the X32 kernel serving `sd` (zero padding for 5..63), 0 = none
 bool screen_bf16_x32_supported(uint32_t sd, uint32_t k);
+bool screen_bf16_fused_update_supported(uint32_t sd, uint32_t k);
 void screen_bf16_x32_tiling(uint32_t sd, uint32_t k, uint32_t *nt32_per_group, uint32_t *groups);
 uint32_t screen_bf16_x32_mfmas(uint32_t sd);
 int launch_prepare_bf16_x32(const CodebookView &v, uint32_t *prepA32, int cosine, float *cbc, float *cen,
@@ -85,6 +86,13 @@ struct AssignArgs {
     uint32_t wl_seg_cap = 0;
     void *part = nullptr;            // grouped X32 screen: [m][G][n] uint4 partial verdicts
     mutable uint32_t n_seg = 0;
+    // fused update (training, screen_bf16_fused_update_supported shapes): partial slabs [chunk][n_sub][k][sd] /
+    // [chunk][n_sub][k] that the screen fills with the sums / counts of the rows it proves; it reports the chunks it
+    // used (acc_chunk_cap = slabs available / n_sub)
+    float *acc_sums = nullptr;
+    uint32_t *acc_counts = nullptr;
+    uint32_t acc_chunk_cap = 0;
+    mutable uint32_t acc_chunks = 0;
 };
 
 // exact VALU scan of every centroid (reference op order); if use_worklist, only the rows
@@ -118,6 +126,15 @@ int plan_update(uint32_t m, uint32_t k, uint32_t sd, uint64_t n, UpdatePlan *pla
 int launch_accumulate(const UpdatePlan &p, const float *X, uint64_t n, uint32_t d,
                       const uint8_t *codes, const uint8_t *active, float *partial_sums,
                       uint32_t *partial_counts, hipStream_t stream);
+// the rows the screen handed to the exact re-check (segmented work lists), added into `n_patch` more partial slabs
+// behind the `first_chunk` the fused screen filled; codes must already hold the re-check's answers
+int launch_accumulate_listed(uint32_t m, uint32_t k, uint32_t sd, const float *X, uint32_t d, const uint8_t *codes,
+                             const uint32_t *sub_list, uint32_t n_sub, const uint32_t *wl_rows, uint64_t wl_stride,
+                             const uint32_t *wl_seg, uint32_t n_seg, uint32_t first_chunk, uint32_t n_patch,
+                             float *partial_sums, uint32_t *partial_counts, hipStream_t stream);
+// fixed-order f64 combination of the fused path's slabs [chunk][position in the active list][k][sd]
+int launch_reduce_partials_pos(uint32_t m, uint32_t k, uint32_t sd, const float *partial_sums, const uint32_t *partial_counts,
+                               uint32_t n_chunks, uint32_t n_sub, const int32_t *sub_pos, double *slab, hipStream_t stream);
 // fixed-order f64 combination of the partial slabs -> slab [m][k][sd+1] (last = count)
 int launch_reduce_partials(const UpdatePlan &p, const float *partial_sums,
                            const uint32_t *partial_counts, const uint8_t *active, double *slab,
