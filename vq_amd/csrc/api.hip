@@ -261,6 +261,8 @@ struct FusedAcc {
     uint32_t n_patch = 16;   // list-driven chunks behind the screen's
     bool used = false;       // out: the launch sequence took the fused path
     uint32_t chunks = 0;     // out: chunks to reduce (screen + patch)
+    const uint8_t *gate_active = nullptr;  // vqhip_kmeans_run: device-side gates handed to the screen
+    const uint32_t *gate_halt = nullptr;
 };
 
 // assignment of every row of X [n][d] for the listed subspaces -> codes [n][m]
@@ -306,6 +308,8 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
         a.acc_sums = fused->sums;
         a.acc_counts = fused->counts;
         a.acc_chunk_cap = fused->slab_cap / a.n_sub - fused->n_patch;
+        a.gate_active = fused->gate_active;
+        a.gate_halt = fused->gate_halt;
     }
     CodebookView v = cs.view();
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -373,6 +377,7 @@ struct vqhip_kmeans {
     AssignWorkspace ws;
     UpdatePlan plan;
     DevBuf codes, partial_sums, partial_counts, slab, counts, changed, active_dev, rows_tmp, xs_ws, gather_ws;
+    DevBuf run_state;  // vqhip_kmeans_run: [0] halt flag, [1 .. m] iterations executed per subspace
     std::vector<uint8_t> active;
     bool all_active = true;
     int engine = VQHIP_ENGINE_AUTO;
@@ -930,8 +935,9 @@ int vqhip_kmeans_set_exact_update(vqhip_kmeans *km, int exact_update) {
     return VQHIP_OK;
 }
 
-// queue assign + update of one Lloyd iteration on `s` (no host synchronisation: capturable)
-static int kmeans_accumulate_enqueue(vqhip_kmeans *km, hipStream_t s) {
+// queue assign + update of one Lloyd iteration on `s` (no host synchronisation: capturable); gated: inside a
+// device-driven run (vqhip_kmeans_run) every kernel that changes state checks the run's device flags
+static int kmeans_accumulate_enqueue(vqhip_kmeans *km, hipStream_t s, bool gated = false) {
     std::vector<uint32_t> subs;
     for (uint32_t i = 0; i < km->cs.m; ++i)
         if (km->active[i]) subs.push_back(i);
@@ -943,14 +949,20 @@ static int kmeans_accumulate_enqueue(vqhip_kmeans *km, hipStream_t s) {
         fused.sums = km->partial_sums.as<float>();
         fused.counts = km->partial_counts.as<uint32_t>();
         fused.slab_cap = km->fused_slabs;
+        if (gated) {
+            fused.gate_active = km->active_dev.as<uint8_t>();
+            fused.gate_halt = km->run_state.as<uint32_t>();
+        }
     }
     VQ_TRY(run_assign(km->cs, km->ws, ds->X, ds->n, ds->d, VQHIP_SQUARED_EUCLIDEAN, subs,
                       km->codes.as<uint8_t>(), km->engine, s, &fused));
+    if (gated && !fused.used) return fail(VQHIP_ERR_FAILURE, "device-driven run without the fused update");
     const uint8_t *act = km->all_active ? nullptr : km->active_dev.as<uint8_t>();
     if (fused.used) {
         VQ_TRY(launch_reduce_partials_pos(km->cs.m, km->cs.k, km->cs.sd, km->partial_sums.as<float>(),
                                           km->partial_counts.as<uint32_t>(), fused.chunks, (uint32_t)subs.size(),
-                                          km->ws.sub_pos.as<int32_t>(), km->slab.as<double>(), s));
+                                          km->ws.sub_pos.as<int32_t>(), km->slab.as<double>(), s, fused.gate_active,
+                                          fused.gate_halt));
     } else if (km->exact_update || km->sums_by_chains) {
         size_t need = exact_sums_workspace_bytes(km->cs.m, km->cs.k, ds->n);
         VQ_TRY(km->xs_ws.ensure(need));
@@ -984,15 +996,18 @@ int vqhip_kmeans_partials(vqhip_kmeans *km, void **dev_slab, uint64_t *n_doubles
 }
 
 // queue mean / convergence test + the read-back of counts and flags (capturable)
-static int kmeans_finalize_enqueue(vqhip_kmeans *km, hipStream_t s) {
-    const uint8_t *act = km->all_active ? nullptr : km->active_dev.as<uint8_t>();
+static int kmeans_finalize_enqueue(vqhip_kmeans *km, hipStream_t s, bool gated = false, bool read_back = true) {
+    const uint8_t *act = (km->all_active && !gated) ? nullptr : km->active_dev.as<uint8_t>();
     const uint32_t m = km->cs.m, k = km->cs.k;
     VQ_TRY(launch_finalize(m, k, km->cs.sd, km->slab.as<double>(), act, km->cs.cb.as<float>(),
-                           km->counts.as<uint32_t>(), km->changed.as<uint32_t>(), km->exact_update, s));
+                           km->counts.as<uint32_t>(), km->changed.as<uint32_t>(), km->exact_update, s,
+                           gated ? km->run_state.as<uint32_t>() : nullptr));
     km->cs.prepared = false;
     km->accumulated = false;
-    VQ_HIP(hipMemcpyAsync(km->counts_host, km->counts.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, s));
-    VQ_HIP(hipMemcpyAsync(km->changed_host, km->changed.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    if (read_back) {
+        VQ_HIP(hipMemcpyAsync(km->counts_host, km->counts.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, s));
+        VQ_HIP(hipMemcpyAsync(km->changed_host, km->changed.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    }
     return VQHIP_OK;
 }
 static void kmeans_finalize_collect(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
@@ -1087,6 +1102,119 @@ int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
     kmeans_finalize_collect(km, counts, changed);
     return VQHIP_OK;
     VQ_API_END
+}
+
+// Up to max_iters Lloyd iterations (src/core/vector.rs:415-458) with the loop's decisions taken on the device: the
+// iterations are queued back to back; a converged subspace stops being processed, an empty cluster in an active
+// subspace pauses the run after that iteration (every later queued kernel becomes a no-op) so that the caller can
+// draw the reseed rows.  Shapes without the fused update take the same decisions on the host, one step at a time.
+static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uint32_t *iters_done, uint32_t *counts,
+                           uint8_t *changed, int *paused) {
+    VQ_API_BEGIN
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    int world = 1;
+    comm_info(comm, &world, nullptr);
+    if (world > 1 && km->exact_update)
+        return fail(VQHIP_ERR_UNSUPPORTED, "exact_update sums rows in one sequential chain: single GPU only");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    const uint32_t m = km->cs.m, k = km->cs.k;
+    if (iters_done) memset(iters_done, 0, (size_t)m * 4);
+    if (paused) *paused = 0;
+    bool any_active = false;
+    for (uint32_t i = 0; i < m; ++i) any_active = any_active || km->active[i];
+    if (max_iters == 0 || !any_active) {
+        if (changed) memset(changed, 0, m);
+        return VQHIP_OK;
+    }
+    int engine = 0;
+    VQ_TRY(pick_engine(km->engine, km->cs, VQHIP_SQUARED_EUCLIDEAN, &engine));
+    static const char *host_loop_env = getenv("VQHIP_RUN_ON_HOST");  // =1: decisions on the host (A/B)
+    const bool device_loop = km->fused_slabs && !km->exact_update && !km->sums_by_chains && engine == VQHIP_ENGINE_MFMA_BF16 &&
+                             km->cs.x32_groups == 1 && km->ds->n < (1ull << 32) && !g_prof.on &&
+                             !(host_loop_env && host_loop_env[0] == '1');
+    if (!device_loop) {
+        std::vector<uint32_t> cnt((size_t)m * k);
+        std::vector<uint8_t> chg(m);
+        for (uint32_t it = 0; it < max_iters; ++it) {
+            bool any = false;
+            for (uint32_t i = 0; i < m; ++i) any = any || km->active[i];
+            if (!any) break;
+            if (world > 1) {
+                VQ_TRY(kmeans_accumulate_enqueue(km, s));
+                VQ_TRY(comm_allreduce_f64(comm, km->slab.as<double>(), (size_t)m * k * (km->cs.sd + 1), s));
+                VQ_TRY(kmeans_finalize_enqueue(km, s));
+                VQ_TRY(spin_wait(s));
+                kmeans_finalize_collect(km, cnt.data(), chg.data());
+            } else {
+                VQ_TRY(vqhip_kmeans_step(km, cnt.data(), chg.data()));
+            }
+            bool empty = false;
+            for (uint32_t i = 0; i < m; ++i) {
+                if (!km->active[i]) continue;
+                if (iters_done) iters_done[i] += 1;
+                for (uint32_t j = 0; j < k; ++j) empty = empty || cnt[(size_t)i * k + j] == 0;
+            }
+            if (counts) memcpy(counts, cnt.data(), cnt.size() * 4);
+            if (changed) memcpy(changed, chg.data(), m);
+            if (empty) {
+                if (paused) *paused = 1;
+                break;
+            }
+            std::vector<uint8_t> act(km->active.begin(), km->active.end());
+            bool flip = false;
+            for (uint32_t i = 0; i < m; ++i)
+                if (act[i] && !chg[i]) {
+                    act[i] = 0;
+                    flip = true;
+                }
+            if (flip) VQ_TRY(vqhip_kmeans_set_active(km, act.data()));
+        }
+        return VQHIP_OK;
+    }
+    VQ_TRY(km->run_state.ensure((size_t)(m + 1) * 4));
+    VQ_HIP(hipMemsetAsync(km->run_state.p, 0, (size_t)(m + 1) * 4, s));
+    uint32_t *halt = km->run_state.as<uint32_t>(), *iters = halt + 1;
+    for (uint32_t it = 0; it < max_iters; ++it) {
+        VQ_TRY(kmeans_accumulate_enqueue(km, s, true));
+        // row-sharded: the one exchange of the iteration (a paused run re-sums a slab nobody reads: all ranks pause alike)
+        VQ_TRY(comm_allreduce_f64(comm, km->slab.as<double>(), (size_t)m * k * (km->cs.sd + 1), s));
+        VQ_TRY(kmeans_finalize_enqueue(km, s, true, false));
+        VQ_TRY(launch_run_update(m, k, km->counts.as<uint32_t>(), km->changed.as<uint32_t>(), km->active_dev.as<uint8_t>(), iters,
+                                 halt, s));
+    }
+    std::vector<uint32_t> st(m + 1);
+    std::vector<uint8_t> act(m);
+    VQ_HIP(hipMemcpyAsync(km->counts_host, km->counts.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipMemcpyAsync(km->changed_host, km->changed.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipMemcpyAsync(st.data(), km->run_state.p, (size_t)(m + 1) * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipMemcpyAsync(act.data(), km->active_dev.p, m, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipStreamSynchronize(s));
+    kmeans_finalize_collect(km, counts, changed);  // flags of the last executed iteration, for the subspaces active in it
+    if (iters_done) memcpy(iters_done, st.data() + 1, (size_t)m * 4);
+    if (paused) *paused = st[0] ? 1 : 0;
+    bool all = true;
+    for (uint32_t i = 0; i < m; ++i) {
+        km->active[i] = act[i] ? 1 : 0;  // converged subspaces retired on the device (none on a pause: the caller decides)
+        all = all && km->active[i];
+    }
+    km->all_active = all;
+    km->ws.stats_pending = true;
+    g_last_ws = &km->ws;
+    tls().last_engine = km->ws.last_engine;
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_kmeans_run(vqhip_kmeans *km, uint32_t max_iters, uint32_t *iters_done, uint32_t *counts, uint8_t *changed,
+                     int *paused) {
+    return kmeans_run_impl(km, nullptr, max_iters, iters_done, counts, changed, paused);
+}
+
+int vqhip_kmeans_run_sharded(vqhip_kmeans *km, vqhip_comm *comm, uint32_t max_iters, uint32_t *iters_done, uint32_t *counts,
+                             uint8_t *changed, int *paused) {
+    return kmeans_run_impl(km, comm ? comm->c : nullptr, max_iters, iters_done, counts, changed, paused);
 }
 
 int vqhip_kmeans_patch_centroid(vqhip_kmeans *km, uint32_t s, uint32_t j, const float *sub_row) {

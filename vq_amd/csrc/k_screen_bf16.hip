@@ -201,6 +201,12 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
 // SD - sdr are zero in both operands (k_center_codebook_x32 writes the copy SD wide): a sub_dim between two
 // instantiated ones rides on the next one up instead of the exact engine.  PVW = floats per load part, as the
 // sub-vectors' alignment allows: 4 (sdr % 4 == 0), 2 (even sdr) or 1.
+// copies of the fused update's LDS sums per wave: 2 while four (or eight) waves' accumulators still fit a CU
+__host__ __device__ constexpr uint32_t x32_acc_copies(int sd, int nt32) {
+    const uint32_t waves = (nt32 <= 4 && sd <= 16) ? 8u : 4u;
+    return (waves * (uint32_t)nt32 * 32u * (2u * (uint32_t)sd + 1u) * 4u <= 140u * 1024u) ? 2u : 1u;
+}
+
 // ACC ("fused update", training only): the wave also OWNS the per-cluster sums and counts of its (row chunk,
 // subspace) in LDS and adds every row it has just PROVEN -- the row's sub-vector is still in its registers -- so a
 // Lloyd iteration reads X once (src/core/vector.rs:432-447, 368-384).  Rows that go to the exact
@@ -216,7 +222,10 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
     uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_seg,
     uint32_t n_seg, uint64_t wl_stride, int cosine, uint32_t k_real, const float *__restrict__ cen,
     uint4 *__restrict__ part, uint32_t groups_rt, uint32_t sdr, float *__restrict__ acc_sums,
-    uint32_t *__restrict__ acc_counts) {
+    uint32_t *__restrict__ acc_counts, const uint8_t *__restrict__ gate_active, const uint32_t *__restrict__ gate_halt) {
+    // device-side gates of vqhip_kmeans_run (iterations queued ahead of the host): a paused run or a subspace that
+    // has converged meanwhile does nothing (the work-list segments stay zeroed: the re-check finds them empty)
+    if (gate_halt && *gate_halt) return;
     static_assert(!ACC || (G == 1 && PVW == 0 && SD % 8 == 0), "fused update: single-pass kernels, lane halves of whole 16-byte parts");
     // G > 0: compile-time group count (k <= 256); G == 0: k > 256, the count comes in groups_rt
     const uint32_t groups = (G > 0) ? (uint32_t)G : groups_rt;
@@ -232,6 +241,7 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
     if (gw >= n_chunks * n_virt) return;
     const uint32_t vv = gw % n_virt;
     const uint32_t s = sub_list[vv / groups];
+    if (gate_active && !gate_active[s]) return;
     const uint32_t grp = vv % groups;
     const uint32_t chunk = gw / n_virt;
     const uint64_t n_steps = (n + 31) / 32;
@@ -243,20 +253,90 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
     extern __shared__ __attribute__((aligned(16))) float acc_lds[];
     float *sums = nullptr;
     uint32_t *cnts = nullptr;
+    // R = 2 copies of the sums where the LDS allows: the first two rows of a step that share a cluster go to different
+    // copies, so their read-modify-writes are independent (one LDS round trip instead of two); added up at the end
+    constexpr uint32_t R = x32_acc_copies(SD, NT32);
+    constexpr uint32_t kCopy = NT32 * 32 * SD;
     if constexpr (ACC) {
-        constexpr uint32_t kPerWave = NT32 * 32 * (SD + 1);
+        constexpr uint32_t kPerWave = NT32 * 32 * (R * SD + 1);
         sums = acc_lds + (size_t)wave * kPerWave;
-        cnts = reinterpret_cast<uint32_t *>(sums + NT32 * 32 * SD);
-        for (uint32_t e = lane; e < NT32 * 32 * SD / 4; e += 64) reinterpret_cast<float4 *>(sums)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        cnts = reinterpret_cast<uint32_t *>(sums + R * kCopy);
+        for (uint32_t e = lane; e < R * kCopy / 4; e += 64) reinterpret_cast<float4 *>(sums)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (uint32_t e = lane; e < NT32 * 32; e += 64) cnts[e] = 0u;
     }
     auto write_partial = [&]() {
         if constexpr (ACC) {
             // slab of (row chunk, position of the subspace in the active list): [chunk][n_sub][k][SD]
             float4 *ps = reinterpret_cast<float4 *>(acc_sums + ((size_t)chunk * n_sub + vv) * k_real * SD);
-            for (uint32_t e = lane; e < k_real * SD / 4; e += 64) ps[e] = reinterpret_cast<const float4 *>(sums)[e];
+            for (uint32_t e = lane; e < k_real * SD / 4; e += 64) {
+                float4 t = reinterpret_cast<const float4 *>(sums)[e];
+                if constexpr (R == 2) {
+                    const float4 u = reinterpret_cast<const float4 *>(sums + kCopy)[e];
+                    t.x = t.x + u.x;
+                    t.y = t.y + u.y;
+                    t.z = t.z + u.z;
+                    t.w = t.w + u.w;
+                }
+                ps[e] = t;
+            }
             uint32_t *pc = acc_counts + ((size_t)chunk * n_sub + vv) * k_real;
             for (uint32_t e = lane; e < k_real; e += 64) pc[e] = cnts[e];
+        }
+    };
+    // The update of step st runs INSIDE step st + 1 (an in-order wave cannot hide an LDS round trip behind its own
+    // dependent code): the ticket (count before + returning add) is issued at the end of st, the reads of the
+    // accumulator rows after the operand split of st + 1, the adds and writes after its first MFMA block.
+    bool pend_mine = false;
+    uint32_t pend_j = 0, pend_before = 0, pend_seq = 0, pend_rank = 0xFFFFFFFFu;
+    float pend_x[ACC ? DPH : 1];
+    float4 pend_t[ACC ? DPH / 4 : 1];
+    float4 *pend_slot = nullptr;
+#ifndef VQ_ACC_EXP
+#define VQ_ACC_EXP 0
+#endif
+    auto acc_issue = [&]() {   // ranks of the pending step's rows; start reading the rows of ranks 0 (and 1)
+        if constexpr (ACC && VQ_ACC_EXP < 1) {
+            uint32_t rank = (pend_mine && h == 0) ? pend_seq - pend_before : 0xFFFFFFFFu;
+            rank = __builtin_amdgcn_permlane32_swap(rank, rank, false, false)[0];  // the row's other half takes the same turn
+            pend_rank = rank;
+            const uint32_t copy = (R == 2 && rank == 1u) ? kCopy : 0u;
+            pend_slot = reinterpret_cast<float4 *>(sums + copy + (size_t)(pend_mine ? pend_j : 0u) * SD + DPH * h);
+            if (rank < R) {
+#pragma unroll
+                for (int q = 0; q < DPH / 4; ++q) pend_t[q] = pend_slot[q];
+            }
+        }
+    };
+    auto acc_commit = [&]() {  // add and write back; rows of rank >= R (three of a cluster in one step) take turns after
+        if constexpr (ACC && VQ_ACC_EXP < 1) {
+            if (pend_rank < R) {
+#pragma unroll
+                for (int q = 0; q < DPH / 4; ++q) {
+                    float4 t = pend_t[q];
+                    t.x = t.x + pend_x[4 * q + 0];
+                    t.y = t.y + pend_x[4 * q + 1];
+                    t.z = t.z + pend_x[4 * q + 2];
+                    t.w = t.w + pend_x[4 * q + 3];
+                    pend_slot[q] = t;
+                }
+            }
+            for (uint32_t r = R;; ++r) {
+                if (!__any(pend_rank != 0xFFFFFFFFu && pend_rank >= r)) break;
+                if (pend_rank == r) {
+#pragma unroll
+                    for (int q = 0; q < DPH / 4; ++q) {
+                        float4 t = pend_slot[q];
+                        t.x = t.x + pend_x[4 * q + 0];
+                        t.y = t.y + pend_x[4 * q + 1];
+                        t.z = t.z + pend_x[4 * q + 2];
+                        t.w = t.w + pend_x[4 * q + 3];
+                        pend_slot[q] = t;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            pend_mine = false;
+            pend_rank = 0xFFFFFFFFu;
         }
     };
     if (st0 >= st1) {
@@ -414,6 +494,11 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
         }
 #pragma unroll
         for (int f = 0; f < NMF; ++f) asm volatile("" ::"v"(b[f]));
+        if constexpr (ACC) {
+            __builtin_amdgcn_sched_barrier(0);
+            acc_issue();  // previous step's update: tickets are back, start the accumulator reads
+            __builtin_amdgcn_sched_barrier(0);
+        }
 
         float q1[4] = {pinf, pinf, pinf, pinf}, q2[4] = {pinf, pinf, pinf, pinf};
         // Four rotating accumulator tiles: in phase i the wave reduces tile i (finished a whole
@@ -462,6 +547,11 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
                 mfma(acc[1], 1, f);
         } else {
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+        }
+        if constexpr (ACC) {
+            __builtin_amdgcn_sched_barrier(0);
+            acc_commit();  // previous step's update: add, write back (in the shadow of the MFMAs just issued)
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < NT32; ++i) {
@@ -558,30 +648,20 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
             seg_count += (uint32_t)__popcll(mask);
         }
         if constexpr (ACC) {
-            const bool mine = proven && (row < n);  // both lane halves of the row agree
-            uint32_t rank = 0xFFFFFFFFu;
-            if (mine && h == 0) {
-                const uint32_t before = cnts[j];               // every lane reads before any lane adds (one wave, in order)
-                rank = atomicAdd(&cnts[j], 1u) - before;       // ds_add_rtn_u32: rows of one cluster get 0, 1, 2, ...
-            }
-            rank = __builtin_amdgcn_permlane32_swap(rank, rank, false, false)[0];  // the row's other half takes the same turn
-            float4 *slot = reinterpret_cast<float4 *>(sums + (size_t)(mine ? j : 0u) * SD + DPH * h);
-            for (uint32_t r = 0;; ++r) {
-                if (!__any(rank != 0xFFFFFFFFu && rank >= r)) break;
-                if (rank == r) {
+            // this step's ticket: issued now, used (and the sums updated) inside the next step
+            pend_mine = proven && (row < n);  // both lane halves of the row agree
+            pend_j = j;
 #pragma unroll
-                    for (int q = 0; q < DPH / 4; ++q) {
-                        float4 t = slot[q];
-                        t.x = t.x + xo[4 * q + 0];
-                        t.y = t.y + xo[4 * q + 1];
-                        t.z = t.z + xo[4 * q + 2];
-                        t.w = t.w + xo[4 * q + 3];
-                        slot[q] = t;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
+            for (int q = 0; q < DPH; ++q) pend_x[q] = xo[q];
+            if (VQ_ACC_EXP < 2 && pend_mine && h == 0) {
+                pend_before = cnts[j];              // every lane reads before any lane adds (one wave, in order)
+                pend_seq = atomicAdd(&cnts[j], 1u);  // ds_add_rtn_u32: the rows of one cluster get before, before + 1, ...
             }
         }
+    }
+    if constexpr (ACC) {  // the last step's update
+        acc_issue();
+        acc_commit();
     }
     write_partial();
     if (G == 1 && lane == 0) {
@@ -816,7 +896,7 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
         if (n_chunks > a.acc_chunk_cap)
             return fail(VQHIP_ERR_FAILURE, "fused update: %u row chunks exceed the partial-slab capacity %u", n_chunks, a.acc_chunk_cap);
         a.acc_chunks = n_chunks;
-        dyn_lds = (size_t)kWavesPerBlock * NT32 * 32 * (SD + 1) * 4;
+        dyn_lds = (size_t)kWavesPerBlock * NT32 * 32 * (x32_acc_copies(SD, NT32) * SD + 1) * 4;
         static PerDeviceOnce attr_set;
         if (attr_set.needed()) {
             VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign_screen_bf16_x32<SD, NT32, G, PVW, ACC>),
@@ -827,7 +907,8 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
     hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32, G, PVW, ACC>), dim3(blocks), dim3(kBlock), dyn_lds, stream, a.X, a.n, a.d,
                        cb.m, cb.prepA32, cb.cn32, NT32 * groups * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
                        a.wl_seg, n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen,
-                       reinterpret_cast<uint4 *>(a.part), groups, cb.sd, ACC ? a.acc_sums : nullptr, ACC ? a.acc_counts : nullptr);
+                       reinterpret_cast<uint4 *>(a.part), groups, cb.sd, ACC ? a.acc_sums : nullptr, ACC ? a.acc_counts : nullptr,
+                       a.gate_active, a.gate_halt);
     VQ_LAUNCH_CHECK("k_assign_screen_bf16_x32");
     if (G != 1) {
         uint64_t mblocks = (a.n + 255) / 256;

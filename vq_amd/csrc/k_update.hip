@@ -373,16 +373,19 @@ __global__ __launch_bounds__(256) void k_reduce_partials(
 __global__ __launch_bounds__(256) void k_reduce_partials_pos(
     const float *__restrict__ partial_sums, const uint32_t *__restrict__ partial_counts,
     uint32_t n_chunks, uint32_t n_sub, const int32_t *__restrict__ sub_pos, uint32_t m, uint32_t k, uint32_t sd,
-    double *__restrict__ slab) {
+    double *__restrict__ slab, const uint8_t *__restrict__ gate_active, const uint32_t *__restrict__ gate_halt) {
     __shared__ double part[kRedGroups][32];
+    if (gate_halt && *gate_halt) return;  // paused run: the slab keeps the pausing iteration's sums
     const uint32_t total = m * k * (sd + 1);
     const uint32_t el = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const uint32_t e = blockIdx.x * 32 + el;
     double acc = 0.0;
+    bool skip = false;
     if (e < total) {
         const uint32_t t = e % (sd + 1), sj = e / (sd + 1), s = sj / k, j = sj - s * k;
         const int32_t pos = sub_pos[s];
-        if (pos >= 0) {
+        skip = gate_active && !gate_active[s];  // converged inside a device-driven run: its slab stays as it is
+        if (pos >= 0 && !skip) {
             if (t < sd) {
                 const size_t stride = (size_t)n_sub * k * sd;
                 const float *p = partial_sums + ((size_t)pos * k + j) * sd + t;
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials_pos(
     if (grp == 0 && e < total) {
         double r = part[0][el];
         for (uint32_t g = 1; g < kRedGroups; ++g) r += part[g][el];
-        slab[e] = r;
+        if (!skip) slab[e] = r;
     }
 }
 
@@ -411,9 +414,11 @@ __global__ __launch_bounds__(256) void k_finalize(uint32_t m, uint32_t k, uint32
                                                   const uint8_t *__restrict__ active,
                                                   float *__restrict__ centroids,
                                                   uint32_t *__restrict__ counts,
-                                                  uint32_t *__restrict__ changed, int exact_div) {
+                                                  uint32_t *__restrict__ changed, int exact_div,
+                                                  const uint32_t *__restrict__ gate_halt) {
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
     if (e >= m * k * sd) return;
+    if (gate_halt && *gate_halt) return;  // paused run: centroids, counts and flags keep the pausing iteration's values
     const uint32_t sj = e / sd, t = e - sj * sd, s = sj / k;
     const bool act = !active || active[s];
     const double *row = slab + (size_t)sj * (sd + 1);
@@ -454,6 +459,33 @@ __global__ __launch_bounds__(256) void k_gather_rows_owned(const float *__restri
     const uint64_t r = rows[sj];
     const bool mine = r >= row_offset && r - row_offset < n_local;
     out_bits[e] = mine ? __float_as_uint(X[(r - row_offset) * d + (size_t)s * sd + t]) : 0u;
+}
+
+__global__ void k_clear_gated(uint32_t *__restrict__ words, uint32_t n, const uint32_t *__restrict__ gate_halt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !*gate_halt) words[i] = 0u;
+}
+
+// End of one iteration of a device-driven run (src/core/vector.rs:440-457 without the host): an active subspace with an
+// empty cluster pauses the run (the caller reseeds: the draw is the host's); otherwise subspaces whose centroids did
+// not move retire, the others count one more iteration.  One workgroup.
+__global__ __launch_bounds__(256) void k_run_update(uint32_t m, uint32_t k, const uint32_t *__restrict__ counts,
+                                                    const uint32_t *__restrict__ changed, uint8_t *__restrict__ active,
+                                                    uint32_t *__restrict__ iters, uint32_t *__restrict__ halt) {
+    __shared__ int any_empty;
+    if (*halt) return;
+    if (threadIdx.x == 0) any_empty = 0;
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < m * k; e += 256)
+        if (active[e / k] && counts[e] == 0u) any_empty = 1;
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < m; s += 256) {
+        if (!active[s]) continue;
+        iters[s] += 1u;
+        if (!any_empty && !changed[s]) active[s] = 0;  // converged (vector.rs:455-457); on a pause the host decides
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && any_empty) *halt = 1u;
 }
 
 }  // namespace
@@ -628,21 +660,34 @@ int launch_reduce_partials(const UpdatePlan &p, const float *partial_sums,
     return VQHIP_OK;
 }
 
+int launch_run_update(uint32_t m, uint32_t k, const uint32_t *counts, const uint32_t *changed, uint8_t *active,
+                      uint32_t *iters, uint32_t *halt, hipStream_t stream) {
+    hipLaunchKernelGGL(k_run_update, dim3(1), dim3(256), 0, stream, m, k, counts, changed, active, iters, halt);
+    VQ_LAUNCH_CHECK("k_run_update");
+    return VQHIP_OK;
+}
+
 int launch_reduce_partials_pos(uint32_t m, uint32_t k, uint32_t sd, const float *partial_sums, const uint32_t *partial_counts,
-                               uint32_t n_chunks, uint32_t n_sub, const int32_t *sub_pos, double *slab, hipStream_t stream) {
+                               uint32_t n_chunks, uint32_t n_sub, const int32_t *sub_pos, double *slab, hipStream_t stream,
+                               const uint8_t *gate_active, const uint32_t *gate_halt) {
     const uint32_t total = m * k * (sd + 1);
     hipLaunchKernelGGL(k_reduce_partials_pos, dim3((total + 31) / 32), dim3(256), 0, stream, partial_sums, partial_counts,
-                       n_chunks, n_sub, sub_pos, m, k, sd, slab);
+                       n_chunks, n_sub, sub_pos, m, k, sd, slab, gate_active, gate_halt);
     VQ_LAUNCH_CHECK("k_reduce_partials_pos");
     return VQHIP_OK;
 }
 
 int launch_finalize(uint32_t m, uint32_t k, uint32_t sd, const double *slab, const uint8_t *active,
                     float *centroids, uint32_t *counts, uint32_t *changed, int exact_div,
-                    hipStream_t stream) {
-    VQ_HIP(hipMemsetAsync(changed, 0, (size_t)m * sizeof(uint32_t), stream));
+                    hipStream_t stream, const uint32_t *gate_halt) {
+    if (gate_halt) {  // a paused run keeps the flags of the iteration that paused it
+        hipLaunchKernelGGL(k_clear_gated, dim3((m + 255) / 256), dim3(256), 0, stream, changed, m, gate_halt);
+        VQ_LAUNCH_CHECK("k_clear_gated");
+    } else {
+        VQ_HIP(hipMemsetAsync(changed, 0, (size_t)m * sizeof(uint32_t), stream));
+    }
     hipLaunchKernelGGL(k_finalize, dim3((m * k * sd + 255) / 256), dim3(256), 0, stream, m, k, sd, slab,
-                       active, centroids, counts, changed, exact_div);
+                       active, centroids, counts, changed, exact_div, gate_halt);
     VQ_LAUNCH_CHECK("k_finalize");
     return VQHIP_OK;
 }

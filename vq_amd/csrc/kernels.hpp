@@ -93,6 +93,9 @@ struct AssignArgs {
     uint32_t *acc_counts = nullptr;
     uint32_t acc_chunk_cap = 0;
     mutable uint32_t acc_chunks = 0;
+    // vqhip_kmeans_run: device flags checked by the fused screen (active [m] bytes, *halt != 0 = run paused)
+    const uint8_t *gate_active = nullptr;
+    const uint32_t *gate_halt = nullptr;
 };
 
 // exact VALU scan of every centroid (reference op order); if use_worklist, only the rows
@@ -134,7 +137,11 @@ int launch_accumulate_listed(uint32_t m, uint32_t k, uint32_t sd, const float *X
                              float *partial_sums, uint32_t *partial_counts, hipStream_t stream);
 // fixed-order f64 combination of the fused path's slabs [chunk][position in the active list][k][sd]
 int launch_reduce_partials_pos(uint32_t m, uint32_t k, uint32_t sd, const float *partial_sums, const uint32_t *partial_counts,
-                               uint32_t n_chunks, uint32_t n_sub, const int32_t *sub_pos, double *slab, hipStream_t stream);
+                               uint32_t n_chunks, uint32_t n_sub, const int32_t *sub_pos, double *slab, hipStream_t stream,
+                               const uint8_t *gate_active = nullptr, const uint32_t *gate_halt = nullptr);
+// end of one device-driven Lloyd iteration (vqhip_kmeans_run): pause on an empty cluster, retire converged subspaces
+int launch_run_update(uint32_t m, uint32_t k, const uint32_t *counts, const uint32_t *changed, uint8_t *active,
+                      uint32_t *iters, uint32_t *halt, hipStream_t stream);
 // fixed-order f64 combination of the partial slabs -> slab [m][k][sd+1] (last = count)
 int launch_reduce_partials(const UpdatePlan &p, const float *partial_sums,
                            const uint32_t *partial_counts, const uint8_t *active, double *slab,
@@ -147,7 +154,7 @@ size_t exact_sums_workspace_bytes(uint32_t m, uint32_t k, uint64_t n);
 // means + 1e-6 convergence test; exact_div: slab sums are f32-exact values -> f32 divide
 int launch_finalize(uint32_t m, uint32_t k, uint32_t sd, const double *slab, const uint8_t *active,
                     float *centroids, uint32_t *counts, uint32_t *changed, int exact_div,
-                    hipStream_t stream);
+                    hipStream_t stream, const uint32_t *gate_halt = nullptr);
 // centroids[s][j] = X[rows[s*k+j]][s*sd ..]
 int launch_gather_rows(const float *X, uint32_t d, uint32_t m, uint32_t k, uint32_t sd,
                        const uint64_t *rows, float *centroids, hipStream_t stream);

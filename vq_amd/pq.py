@@ -80,11 +80,16 @@ def fit_codebooks(ds: "_lib.Dataset", m: int, k: int, max_iters: int, seed: int 
         active = np.ones(m, dtype=bool)
         iters = np.zeros(m, dtype=np.int64)
         n_reseeds = 0
-        for _ in range(max_iters):  # vector.rs:415
-            if not active.any():
-                break
-            counts, changed = km.step()
-            iters[active] += 1
+        done = 0
+        while done < max_iters and active.any():  # vector.rs:415
+            # the loop's decisions are taken on the device (vqhip_kmeans_run): it comes back when the iterations are
+            # used up, when every subspace has converged, or PAUSED after an iteration that left a cluster empty
+            it, counts, changed, paused = km.run(max_iters - done)
+            iters += it.astype(np.int64)
+            done += max(1, int(it.max()))
+            if not paused:
+                active &= changed  # converged subspaces were retired on the device (vector.rs:455-457)
+                continue
             # empty clusters of active subspaces in (subspace, ascending j) order, vector.rs:448-452
             # (one vectorised scan: the per-subspace Python loop cost ~1 ms per iteration at m = 96)
             empties = np.argwhere((counts == 0) & active[:, None])

@@ -323,11 +323,14 @@ class NativeShardedKMeans:
         self.active[:] = True
         self.km.set_active(self.active)
         self.iters[:] = 0
-        for _ in range(max_iters):
-            if not self.active.any():
-                break
-            counts, changed = self.step()
-            self.iters[self.active] += 1
+        done = 0
+        while done < max_iters and self.active.any():
+            it, counts, changed, paused = self.km.run(max_iters - done, self.comm)  # vqhip_kmeans_run_sharded
+            self.iters += it.astype(np.int64)
+            done += max(1, int(it.max()))
+            if not paused:
+                self.active &= changed
+                continue
             for s, j in np.argwhere((counts == 0) & self.active[:, None]):
                 row = int(next(reseed_it[s])) if reseed_it is not None else rngs[s].choose(n)
                 self.km.patch_from_global_row(self.comm, int(s), int(j), row, self.row_offset)
