@@ -14,4 +14,10 @@ for rep in range(5):
     _lib.synchronize(); t0 = time.perf_counter()
     for _ in range(20): km.step()
     _lib.synchronize(); ts.append((time.perf_counter() - t0) / 20 * 1e3)
-print(os.environ.get("VQHIP_LIB_PATH", "default"), "kmeans ms/iter", " ".join(f"{x:.4f}" for x in ts), "min", min(ts))
+print(os.environ.get("VQHIP_LIB_PATH", "default"), "step loop: kmeans ms/iter", " ".join(f"{x:.4f}" for x in ts), "min", min(ts))
+ts = []
+for rep in range(5):
+    _lib.synchronize(); t0 = time.perf_counter()
+    it, _, _, paused = km.run(20)
+    _lib.synchronize(); ts.append((time.perf_counter() - t0) / max(1, int(it.max())) * 1e3)
+print("device-driven run(20): kmeans ms/iter", " ".join(f"{x:.4f}" for x in ts), "min", min(ts), "paused", paused, "iters", it)
