@@ -85,7 +85,8 @@ int current_stream(hipStream_t *out) {
 struct CodebookState {
     uint32_t m = 0, k = 0, sd = 0, nt = 0, ks = 0;
     bool mfma_ok = false, bf16_ok = false;
-    bool prepared = false;
+    bool prepared = false;  // false = the centroids changed: every image is stale
+    bool prepared_base = false, prepared_x32 = false;
     int metric = VQHIP_SQUARED_EUCLIDEAN;  // what the prepared images are for (cosine differs)
     DevBuf cb, prepA, prepCn, meta, cnsqrt, prepA32, cbc, cen, cn32;
     bool x32_ok = false;
@@ -149,15 +150,22 @@ struct CodebookState {
         v.cn32 = x32_ok ? cn32.as<float>() : nullptr;
         return v;
     }
-    int prepare(hipStream_t stream) {
-        if (prepared) return VQHIP_OK;
+    // need_base = false: only the X32 images (squared-L2 on the single-pass bf16 screen reads nothing else: the
+    // fp32 engine's image, the centroid norms and `meta` are for the other engines, cosine and the grouped merge)
+    int prepare(hipStream_t stream, bool need_base = true) {
         CodebookView v = view();
-        VQ_TRY(launch_prepare_codebook(v, mfma_ok ? prepA.as<float>() : nullptr,
-                                       mfma_ok ? prepCn.as<float>() : nullptr, meta.as<float>(),
-                                       cnsqrt.as<float>(), stream));
-        if (x32_ok)
+        if (!prepared) prepared_base = prepared_x32 = false;
+        if (need_base && !prepared_base) {
+            VQ_TRY(launch_prepare_codebook(v, mfma_ok ? prepA.as<float>() : nullptr,
+                                           mfma_ok ? prepCn.as<float>() : nullptr, meta.as<float>(),
+                                           cnsqrt.as<float>(), stream));
+            prepared_base = true;
+        }
+        if (x32_ok && !prepared_x32) {
             VQ_TRY(launch_prepare_bf16_x32(v, prepA32.as<uint32_t>(), metric == VQHIP_COSINE ? 1 : 0, cbc.as<float>(),
                                            cen.as<float>(), cn32.as<float>(), stream));
+            prepared_x32 = true;
+        }
         prepared = true;
         return VQHIP_OK;
     }
@@ -280,7 +288,9 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
     if (engine == VQHIP_ENGINE_MFMA_BF16 && engine_req == VQHIP_ENGINE_AUTO && cs.k > 256 &&
         (size_t)cs.m * cs.x32_groups * n * 16 > ((size_t)4 << 30))
         engine = VQHIP_ENGINE_EXACT;
-    VQ_TRY(cs.prepare(stream));
+    const bool x32_only = engine == VQHIP_ENGINE_MFMA_BF16 && cs.x32_groups == 1 && x32_padded_sd(cs.sd) <= 64 &&
+                          (metric == VQHIP_SQUARED_EUCLIDEAN || metric == VQHIP_EUCLIDEAN) && cs.metric != VQHIP_COSINE;
+    VQ_TRY(cs.prepare(stream, !x32_only));
     const bool screened = (engine == VQHIP_ENGINE_MFMA || engine == VQHIP_ENGINE_MFMA_BF16);
     VQ_TRY(ws.ensure(cs.m, n, screened));
     VQ_TRY(ws.set_sub_list(subs, cs.m, stream));

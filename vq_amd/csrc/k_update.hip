@@ -290,34 +290,78 @@ __global__ __launch_bounds__(64) void k_accumulate_listed(
     auto swz = [](uint32_t gg, uint32_t c) { return POW2 ? (gg ^ (c & (KS - 1))) : ((gg + c) % KS); };
     const uint32_t seg0 = blockIdx.x * segs_per_patch;
     const uint32_t seg1 = min(n_seg, seg0 + segs_per_patch);
-    for (uint32_t seg = seg0; seg < seg1; ++seg) {
-        const uint32_t first = wl_seg[((size_t)s * n_seg + seg) * 2], count = wl_seg[((size_t)s * n_seg + seg) * 2 + 1];
-        for (uint32_t e0 = 0; e0 < count; e0 += RPS) {
-            const bool valid = lane_on && (e0 + p < count);
-            const uint32_t row = valid ? wl_rows[(size_t)s * wl_stride + first + e0 + p] : 0u;
-            const uint32_t code = valid ? (uint32_t)codes[(size_t)row * m + s] : 0xFFFFFFFFu;
-            const float4 x = valid ? *reinterpret_cast<const float4 *>(X + (size_t)row * d + (size_t)s * SD + 4 * g)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-            uint32_t rank = 0;
+    // The lists are short (a handful of rows per segment on uniform data) and every entry is three dependent loads
+    // deep (segment header -> row number -> code and sub-vector): walked one segment at a time the wave spent its
+    // life waiting (33 us for 9 K rows).  So 64 segment headers are read at once, their entries numbered through a
+    // wave prefix sum, and the loads of 8 steps (128 entries) are issued level by level before any row is added.
+    constexpr int NB = 8;  // steps per batch
+    for (uint32_t g0 = seg0; g0 < seg1; g0 += 64) {
+        const uint32_t nq = min(64u, seg1 - g0);
+        uint32_t first = 0, count = 0;
+        if (lane < nq) {
+            const uint2 hd = *reinterpret_cast<const uint2 *>(wl_seg + ((size_t)s * n_seg + g0 + lane) * 2);
+            first = hd.x;
+            count = hd.y;
+        }
+        uint32_t incl = count;
 #pragma unroll
-            for (uint32_t q = 0; q + 1 < RPS; ++q) {
-                const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)code, (int)(q * KS));
-                rank += (q < p && cq == code) ? 1u : 0u;
-            }
-            float4 *slot = reinterpret_cast<float4 *>(sums + (size_t)(valid ? code : 0u) * SD) + swz(g, code);
-            uint32_t pending = valid ? 1u : 0u;
-            for (uint32_t r = 0; __any(pending != 0); ++r) {
-                if (pending && rank == r) {
-                    float4 t = *slot;
-                    t.x = t.x + x.x;
-                    t.y = t.y + x.y;
-                    t.z = t.z + x.z;
-                    t.w = t.w + x.w;
-                    *slot = t;
-                    if (g == 0) cnts[code] += 1u;
-                    pending = 0;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+            if ((int)lane >= off) incl += up;
+        }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+        const uint32_t shift = first - (incl - count);  // entry e of this segment sits at wl_rows[.. + e + shift]
+        for (uint32_t b0 = 0; b0 < total; b0 += NB * RPS) {
+            uint32_t row[NB], code[NB];
+            float4 x[NB];
+            bool valid[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const uint32_t e = b0 + (uint32_t)u * RPS + p;
+                valid[u] = lane_on && e < total;
+                // segment of entry e: the first q with incl_q > e; its `shift` turns e into a slot of the list
+                uint32_t sh = 0;
+                bool found = false;
+                for (uint32_t q = 0; q < nq; ++q) {
+                    const uint32_t iq = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)q);
+                    const uint32_t sq = (uint32_t)__builtin_amdgcn_readlane((int)shift, (int)q);
+                    if (!found && e < iq) {
+                        sh = sq;
+                        found = true;
+                    }
                 }
-                __builtin_amdgcn_wave_barrier();
+                row[u] = valid[u] ? wl_rows[(size_t)s * wl_stride + e + sh] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                code[u] = valid[u] ? (uint32_t)codes[(size_t)row[u] * m + s] : 0xFFFFFFFFu;
+                x[u] = valid[u] ? *reinterpret_cast<const float4 *>(X + (size_t)row[u] * d + (size_t)s * SD + 4 * g)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                if (b0 + (uint32_t)u * RPS >= total) break;
+                uint32_t rank = 0;
+#pragma unroll
+                for (uint32_t q = 0; q + 1 < RPS; ++q) {
+                    const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)code[u], (int)(q * KS));
+                    rank += (q < p && cq == code[u]) ? 1u : 0u;
+                }
+                float4 *slot = reinterpret_cast<float4 *>(sums + (size_t)(valid[u] ? code[u] : 0u) * SD) + swz(g, code[u]);
+                uint32_t pending = valid[u] ? 1u : 0u;
+                for (uint32_t r = 0; __any(pending != 0); ++r) {
+                    if (pending && rank == r) {
+                        float4 t = *slot;
+                        t.x = t.x + x[u].x;
+                        t.y = t.y + x[u].y;
+                        t.z = t.z + x[u].z;
+                        t.w = t.w + x[u].w;
+                        *slot = t;
+                        if (g == 0) cnts[code[u]] += 1u;
+                        pending = 0;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
     }
