@@ -35,9 +35,21 @@ namespace vqhip {
 namespace {
 
 constexpr uint32_t kInactive = 0xFFFFFFFFu;
-constexpr uint32_t DG = 16;          // dimensions per workgroup in the column-sum kernel
-constexpr uint32_t kTileRows = 480;  // rows per LDS tile: 15 loader waves x 32 rows
-constexpr uint32_t kTilePitch = kTileRows + 4;
+constexpr uint32_t kCsBlock = 20;  // rows the consumer of the column-sum kernel stages per register block (5 x ds_read_b128)
+constexpr uint32_t kCsAhead = 6;   // tiles a loader wave keeps in flight in registers
+
+// geometry of the plain column-sum kernel for DGT columns per workgroup (one consumer lane per column):
+// a loader wave covers 64 / DGT groups of 4 consecutive rows per step
+template <uint32_t DGT>
+struct CsGeom {
+    static constexpr uint32_t kGroups = 64 / DGT;                 // row groups per loader wave
+    static constexpr uint32_t kSteps = 1;                         // load steps per wave and tile
+    static constexpr uint32_t kWaveRows = 4 * kGroups * kSteps;   // rows one loader wave stages per tile
+    static constexpr uint32_t kTileRows = 15 * kWaveRows;         // 120 (DGT 32) / 240 (DGT 16)
+    static constexpr uint32_t kPitch = kTileRows + 4;             // 124 / 244 floats: the columns of 16 consecutive lanes start in distinct 16-byte bank groups
+    static constexpr uint32_t kBlocks = kTileRows / kCsBlock;     // 6 / 12: even, so the consumer's two register blocks alternate without a copy
+    static_assert(kTileRows % kCsBlock == 0 && kBlocks % 2 == 0, "consumer blocks");
+};
 
 // One per tree level, in device memory: the level loop runs without the host (the planning kernels below fill it,
 // every other kernel of the level reads its counts from it and is launched over an upper bound).
@@ -71,116 +83,147 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
 
 // MODE 0: out = (sequential sum of x) / n  -> centroid;  MODE 1: out = sequential sum (x-mu)^2
 //
-// Workgroup = 16 waves for one (node, 16-dimension group): waves 1..15 stream the node's rows
-// (gathered through `perm`, 64 B per row) into a 2-buffer LDS ring, wave 0 is the consumer
-// whose lanes 0..15 each own one dimension and add the staged rows in order.  Loads run two
-// tiles ahead of the consumer in registers (issue early, write to LDS one iteration later), so
-// an HBM miss (~2 us) is covered by two consumer tiles (~1 us each at 5 cycles per dependent
-// add).  The consumer reads 32 staged values at a time before adding them, so the LDS latency
-// is paid once per 32 rows, not per row.
-template <int MODE>
+// Workgroup = 16 waves for one (node, DGT-column group).  Wave 0 is the consumer: lane c owns column c and adds the
+// node's rows in order -- a chain of dependent v_add_f32, one per row, which is the floor of this kernel (about five
+// cycles per row with the staging reads).  Waves 1..15 are loaders: they gather the rows through `perm` into a
+// three-tile LDS ring, column-major, so that the consumer reads four consecutive rows of its column per ds_read_b128.
+//
+//   * a loader lane reads FOUR CONSECUTIVE ROWS of one column (four global_load_dword, each a set of coalesced row
+//     slices) and stores them with ONE ds_write_b128 -- the loaders share the consumer's SIMDs, so their VALU work is
+//     kept small;
+//   * kCsAhead tiles of loads are in flight per loader wave (the tile loop is unrolled by kCsAhead, so the register ring
+//     needs no moves) and the row indices are read one tile earlier still: an HBM gather takes several tile times
+//     (a tile of 120 rows is ~600 consumer cycles);
+//   * the ring holds tile ti (being added), ti+1 (complete) and ti+2 (being written): the consumer reads the first
+//     block of tile ti+1 before the barrier that ends tile ti, and within a tile it reads block b+1 before adding
+//     block b, so its add chain never waits for LDS.
+//   * rows past the node's end are staged as +0.0: after the first real row the running sum is never -0.0 (MODE 0
+//     starts from +0.0; MODE 1 adds squares), so adding +0.0 changes no bit and every tile is whole.
+template <int MODE, uint32_t DGT>
 __global__ __launch_bounds__(1024) void k_seg_colsum(const float *__restrict__ X, uint32_t d,
                                                      const uint32_t *__restrict__ perm,
                                                      const uint32_t *__restrict__ lvl_node,
                                                      const LevelInfo *__restrict__ lv, NodeArrays na) {
-    // column-major tiles: the consumer lane of a column reads 4 consecutive rows per ds_read_b128
-    // (pitch 484 floats: the 16 columns start 36 banks apart -> conflict-free 16-byte reads)
-    __shared__ __attribute__((aligned(16))) float tile[2][DG][kTilePitch];
+    using G = CsGeom<DGT>;
+    constexpr uint32_t S = G::kSteps, A = kCsAhead;
+    static_assert(A % 3 == 0, "the unrolled tile loop keeps the ring index static");
+    __shared__ __attribute__((aligned(16))) float tile[3][DGT][G::kPitch];
     if (blockIdx.x >= lv->n_slow) return;  // launched over an upper bound
     const uint32_t node = lvl_node[blockIdx.x];
     const uint32_t a = na.seg_start[node], n = na.seg_len[node];
     if (MODE == 1 && n <= 1) return;       // a leaf: no variance pass (src/tsvq.rs:38-44)
-    const uint32_t t0 = blockIdx.y * DG;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t n_tiles = (n + kTileRows - 1) / kTileRows;
+    const uint32_t t0 = blockIdx.y * DGT;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t g = lane / DGT, c = lane % DGT;
+    const uint32_t n_tiles = (n + G::kTileRows - 1) / G::kTileRows;
+    const uint32_t col = min(t0 + c, d - 1);  // columns past d are computed and dropped
     float acc = (MODE == 0) ? 0.0f : -0.0f;
-    const uint32_t q = lane & 3;
     if (wave == 0) __builtin_amdgcn_s_setprio(3);  // the consumer's add chain is the critical path
-    // variance pass: the loader lanes form (x - mean)^2 (same two roundings as tsvq.rs:47-55), the
-    // consumer only carries the ordered additions
-    float mu4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (MODE == 1 && wave != 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (t0 + 4 * q + i < d) mu4[i] = na.centroid[(size_t)node * d + t0 + 4 * q + i];
-    }
-    const bool vec_ok = (d % 4 == 0);
 
-    // loader lanes: 2 x (16 rows x 4 float4) per tile
-    auto fetch = [&](uint32_t tile_idx, float4 (&v)[2]) {
-        const uint32_t base = tile_idx * kTileRows + (wave - 1) * 32;
+    // ---- loader state ----
+    // variance pass: the loader lanes form (x - mean)^2 (same two roundings as tsvq.rs:47-55), the consumer only
+    // carries the ordered additions
+    const float mu = (MODE == 1) ? na.centroid[(size_t)node * d + col] : 0.0f;
+    const uint32_t wrow = (wave - 1) * G::kWaveRows + 4 * g;  // this lane's first row inside a tile (step 0)
+    const float *Xc = X + col;
+    uint32_t pn[S][4];        // row ids of the next tile to be requested
+    float4 ring[A][S];        // tiles in flight: tile t sits in ring[t % A]
+    auto load_ids = [&](uint32_t t) {
 #pragma unroll
-        for (uint32_t rep = 0; rep < 2; ++rep) {
-            const uint32_t idx = base + (lane >> 2) + rep * 16;
-            v[rep] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tile_idx < n_tiles && idx < n) {
-                const float *src = X + (size_t)perm[a + idx] * d + t0 + 4 * q;
-                if (vec_ok && t0 + 4 * q + 3 < d) {
-                    v[rep] = *reinterpret_cast<const float4 *>(src);
-                } else {
-                    if (t0 + 4 * q + 0 < d) v[rep].x = src[0];
-                    if (t0 + 4 * q + 1 < d) v[rep].y = src[1];
-                    if (t0 + 4 * q + 2 < d) v[rep].z = src[2];
-                    if (t0 + 4 * q + 3 < d) v[rep].w = src[3];
-                }
+        for (uint32_t s = 0; s < S; ++s)
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint32_t idx = min(t * G::kTileRows + wrow + s * 4 * G::kGroups + i, n - 1);  // clamped: staged as zero
+                pn[s][i] = perm[a + idx];
             }
+    };
+    auto request = [&](float4 (&v)[S]) {
+#pragma unroll
+        for (uint32_t s = 0; s < S; ++s) {
+            v[s].x = Xc[(size_t)pn[s][0] * d];
+            v[s].y = Xc[(size_t)pn[s][1] * d];
+            v[s].z = Xc[(size_t)pn[s][2] * d];
+            v[s].w = Xc[(size_t)pn[s][3] * d];
         }
     };
-    auto put = [&](uint32_t buf, const float4 (&v)[2]) {
+    auto stage = [&](uint32_t buf, uint32_t t, const float4 (&v)[S]) {
+        const bool whole = (t + 1) * G::kTileRows <= n;  // uniform
 #pragma unroll
-        for (uint32_t rep = 0; rep < 2; ++rep) {
-            const uint32_t row = (wave - 1) * 32 + (lane >> 2) + rep * 16;
-            float e[4] = {v[rep].x, v[rep].y, v[rep].z, v[rep].w};
+        for (uint32_t s = 0; s < S; ++s) {
+            const uint32_t row = wrow + s * 4 * G::kGroups;
+            float e[4] = {v[s].x, v[s].y, v[s].z, v[s].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (MODE == 1) {
-                    const float diff = e[i] - mu4[i];
+                    const float diff = e[i] - mu;
                     e[i] = diff * diff;
                 }
-                tile[buf][4 * q + i][row] = e[i];
+                if (!whole && t * G::kTileRows + row + i >= n) e[i] = 0.0f;
             }
+            *reinterpret_cast<float4 *>(&tile[buf][c][row]) = make_float4(e[0], e[1], e[2], e[3]);
         }
     };
 
-    float4 r1[2], r2[2];  // tiles ti+1 and ti+2 in flight (loader waves only)
+    // ---- consumer state: two register blocks of kCsBlock rows ----
+    float4 va[kCsBlock / 4], vb[kCsBlock / 4];
+    auto read_block = [&](uint32_t buf, uint32_t r, float4 (&v)[kCsBlock / 4]) {
+        const float *src = &tile[buf][c][r];
+#pragma unroll
+        for (uint32_t u = 0; u < kCsBlock / 4; ++u) v[u] = *reinterpret_cast<const float4 *>(src + 4 * u);
+    };
+    auto add_block = [&](const float4 (&v)[kCsBlock / 4]) {
+#pragma unroll
+        for (uint32_t u = 0; u < kCsBlock / 4; ++u) {
+            acc = acc + v[u].x;
+            acc = acc + v[u].y;
+            acc = acc + v[u].z;
+            acc = acc + v[u].w;
+        }
+    };
+
     if (wave != 0) {
-        float4 r0[2];
-        fetch(0, r0);
-        fetch(1, r1);
-        fetch(2, r2);
-        put(0, r0);
+        // tiles 0 .. A-1 requested, tiles 0 and 1 staged, tiles A and A+1 requested into the freed slots
+        load_ids(0);
+#pragma unroll
+        for (uint32_t t = 0; t < A; ++t) {
+            request(ring[t]);
+            load_ids(t + 1);
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < 2; ++t) {
+            stage(t, t, ring[t]);
+            request(ring[t]);
+            load_ids(A + t + 1);
+        }
     }
     __syncthreads();
-    for (uint32_t ti = 0; ti < n_tiles; ++ti) {
-        const uint32_t buf = ti & 1;
-        if (wave != 0) {
-            put(buf ^ 1, r1);  // tile ti+1 (loaded two iterations ago)
-            r1[0] = r2[0];
-            r1[1] = r2[1];
-            fetch(ti + 3, r2);
-        } else if (lane < DG) {
-            const uint32_t rows = min(kTileRows, n - ti * kTileRows);
-            const float *col = &tile[buf][lane][0];
-            uint32_t r = 0;
-            for (; r + 32 <= rows; r += 32) {
-                float4 v[8];
+    if (wave == 0) read_block(0, 0, va);
+    for (uint32_t ti0 = 0; ti0 < n_tiles; ti0 += A) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(col + r + 4 * u);
+        for (uint32_t j = 0; j < A; ++j) {
+            const uint32_t ti = ti0 + j;  // every wave runs all A steps: the barriers stay matched
+            if (wave != 0) {
+                const uint32_t slot = (j + 2) % A, buf = (j + 2) % 3;
+                stage(buf, ti + 2, ring[slot]);  // tile ti+2, requested A tiles ago
+                request(ring[slot]);             // tile ti+2+A
+                load_ids(ti + 3 + A);
+            } else if (ti < n_tiles) {
+                const uint32_t buf = j % 3, nbuf = (j + 1) % 3;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    acc = acc + v[u].x;
-                    acc = acc + v[u].y;
-                    acc = acc + v[u].z;
-                    acc = acc + v[u].w;
+                for (uint32_t b = 0; b < G::kBlocks; b += 2) {
+                    read_block(buf, (b + 1) * kCsBlock, vb);
+                    add_block(va);
+                    if (b + 2 < G::kBlocks) read_block(buf, (b + 2) * kCsBlock, va);
+                    else read_block(nbuf, 0, va);  // tile ti+1 is complete since the last barrier
+                    add_block(vb);
                 }
             }
-            for (; r < rows; ++r) acc = acc + col[r];
+            __syncthreads();
         }
-        __syncthreads();
     }
-    if (wave == 0 && lane < DG && t0 + lane < d) {
-        if (MODE == 0) na.centroid[(size_t)node * d + t0 + lane] = acc / (float)n;  // T::from_usize(n)
-        else na.var[(size_t)node * d + t0 + lane] = acc;
+    if (wave == 0 && t0 + c < d && g == 0) {
+        if (MODE == 0) na.centroid[(size_t)node * d + t0 + c] = acc / (float)n;  // T::from_usize(n)
+        else na.var[(size_t)node * d + t0 + c] = acc;
     }
 }
 
@@ -784,7 +827,7 @@ __global__ __launch_bounds__(256) void k_tsvq_gather_f16(const float *__restrict
 // reference's bit pattern; only the schedule differs.
 constexpr uint32_t kFsTile = 512;        // rows per tile
 constexpr uint32_t kFsCols = 32;         // columns per workgroup (one 128-byte line per row)
-constexpr uint32_t kFsMinRows = 16384;   // shorter nodes keep the plain sequential kernel (most tiles of a short node sit on a binade crossing and are re-added)
+constexpr uint32_t kFsMinRows = 16384;   // shorter nodes always keep the plain sequential kernel (most tiles of a short node sit on a binade crossing and are re-added)
 
 struct FsTile {
     uint32_t node, t;      // node id, tile index inside the node
@@ -956,13 +999,14 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
     if (item >= n_items) return;
     uint32_t prow[16];
     float4 v[16];
-    float mu4[4] = {0.f, 0.f, 0.f, 0.f};
-    double pref;
-    uint32_t row0 = 0;   // MODE 0: the node's first row; its values m0 centre the moments
+    // per-item metadata in three generations: _s = just requested (item after next), _n = next item, _c = current
+    float mu4_s[4] = {0.f, 0.f, 0.f, 0.f}, mu4[4] = {0.f, 0.f, 0.f, 0.f};
+    double pref_s = 0.0, pref = 0.0;
+    uint32_t row0_s = 0;  // MODE 0: the node's first row; its values m0 centre the moments
     float m0 = 0.0f, m0_next = 0.0f;
-    auto issue_perm = [&](const FsTile &t, uint32_t it) {  // indices, means and the f64 guess of item `it`
+    auto issue_perm = [&](const FsTile &t, uint32_t it) {  // indices, means and the f64 guess of item `it` -> prow, *_s
         const uint32_t tid = it / ncb, c0n = (it - tid * ncb) * kFsCols;
-        if (MODE == 0) row0 = perm[na.seg_start[t.node]];
+        if (MODE == 0) row0_s = perm[na.seg_start[t.node]];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const uint32_t r = rr + 32 * i;
@@ -973,23 +1017,32 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
         const uint32_t cq = (c0n + 4 * q < d) ? c0n + 4 * q : c0n;
         if (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mu4[i] = na.centroid[(size_t)t.node * d + cq + i];
+            for (int i = 0; i < 4; ++i) mu4_s[i] = na.centroid[(size_t)t.node * d + cq + i];
         }
-        pref = tile_pref[(size_t)tid * d + ((c0n + cl < d) ? c0n + cl : c0n)];
+        pref_s = tile_pref[(size_t)tid * d + ((c0n + cl < d) ? c0n + cl : c0n)];
     };
-    auto issue_rows = [&](uint32_t it) {
+    auto issue_rows = [&](uint32_t it, uint32_t row0) {  // the rows prow names -> v; the node's first row -> m0_next
         const uint32_t tid = it / ncb, c0n = (it - tid * ncb) * kFsCols;
         const uint32_t cq = (c0n + 4 * q < d) ? c0n + 4 * q : c0n;
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (size_t)prow[i] * d + cq);
         if (MODE == 0) m0_next = X[(size_t)row0 * d + ((c0n + cl < d) ? c0n + cl : c0n)];
     };
+    // Pipeline (round 2): the rows of item i+1 are requested as soon as item i has been parked in LDS -- they travel
+    // during the whole fold of item i -- and the row indices of item i+2 right behind them.  (Round 1 requested the
+    // rows half-way through the fold: each workgroup had loads in flight for under half of its time, 2.7 TB/s.)
     FsTile tl = tiles[item / ncb];
     issue_perm(tl, item);
-    issue_rows(item);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mu4[i] = mu4_s[i];
+    pref = pref_s;
+    issue_rows(item, row0_s);
     m0 = m0_next;
     uint32_t next = item + gridDim.x;
     FsTile tl_next = tiles[(next < n_items ? next : item) / ncb];
+    if (next < n_items) issue_perm(tl_next, next);
+    uint32_t next2 = next + gridDim.x;
+    FsTile tl_next2 = tiles[(next2 < n_items ? next2 : item) / ncb];
   for (;;) {
     const uint32_t tile_id = item / ncb, c0 = (item - tile_id * ncb) * kFsCols;
     const uint32_t rows = tl.rows;
@@ -1008,11 +1061,15 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
     const float s_guess = (float)pref;
     __syncthreads();
     const bool has_next = next < n_items;  // uniform
-    const uint32_t next2 = next + gridDim.x;
-    FsTile tl_next2 = tl_next;
+    float mu4_n[4] = {0.f, 0.f, 0.f, 0.f};
+    double pref_n = 0.0;
     if (has_next) {
-        issue_perm(tl_next, next);
-        tl_next2 = tiles[(next2 < n_items ? next2 : next) / ncb];
+        // metadata of the next item (requested an item ago), then its rows, then the indices of the one after
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mu4_n[i] = mu4_s[i];
+        pref_n = pref_s;
+        issue_rows(next, row0_s);
+        if (next2 < n_items) issue_perm(tl_next2, next2);
     }
     const uint32_t gb = __float_as_uint(s_guess), ge = (gb >> 23) & 0xFFu;
     const int e = (int)ge - 127;
@@ -1088,9 +1145,7 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
       }
     }
     };
-    fold1(0, 32);
-    if (has_next) issue_rows(next);  // the perm indices issued above have arrived by now
-    fold1(32, 64);
+    fold1(0, 64);
     if (imax >= 0x4B800000u) badi = 1;  // |q| >= 2^24, inf or NaN: cannot stay in the binade
     if (!badi && tmax == 0.5f) {         // a tie in this segment: the exact two-stream fold
         fold2(0, 64);
@@ -1191,9 +1246,14 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
     __syncthreads();  // lds_v, seg_acc and col_slot are rewritten by the next item
     item = next;
     next = next2;
+    next2 += gridDim.x;
     tl = tl_next;
     tl_next = tl_next2;
+    tl_next2 = tiles[(next2 < n_items ? next2 : item) / ncb];
     m0 = m0_next;
+    pref = pref_n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mu4[i] = mu4_n[i];
   }
 }
 
@@ -1457,7 +1517,7 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *sh, uint32_t *t
 }
 
 // start of a level: the split list (+ remap level-local -> split-local), the fast / slow lists and the tile table
-__global__ __launch_bounds__(1024) void k_plan_level(LevelInfo *__restrict__ lv, int can_split, int can_fast, NodeArrays na,
+__global__ __launch_bounds__(1024) void k_plan_level(LevelInfo *__restrict__ lv, int can_split, int can_fast, uint32_t fs_min_rows, NodeArrays na,
                                                      uint32_t *__restrict__ lvl_split, uint32_t *__restrict__ remap,
                                                      uint32_t *__restrict__ fast_nodes, uint32_t *__restrict__ slow_nodes,
                                                      uint32_t *__restrict__ tile_base, uint32_t *__restrict__ n_tiles_of,
@@ -1471,7 +1531,7 @@ __global__ __launch_bounds__(1024) void k_plan_level(LevelInfo *__restrict__ lv,
         const uint32_t node = first + li;
         const uint32_t len = in ? na.seg_len[node] : 0u;
         const uint32_t is_split = (in && can_split && len > 1) ? 1u : 0u;            // src/tsvq.rs:38-44
-        const uint32_t is_fast = (in && can_fast && len >= kFsMinRows) ? 1u : 0u;
+        const uint32_t is_fast = (in && can_fast && len >= fs_min_rows) ? 1u : 0u;
         const uint32_t nt = is_fast ? (len + kFsTile - 1) / kFsTile : 0u;
         uint32_t tot_s, tot_f, tot_t;
         const uint32_t ps = block_excl_scan(is_split, sh, &tot_s);
@@ -1623,7 +1683,13 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     // widest level: min(2^level, n) nodes
     auto level_width = [&](uint32_t L) -> uint32_t { return (L >= 31) ? n : (uint32_t)std::min<uint64_t>(1ull << L, n); };
     const uint32_t wmax = level_width(n_levels - 1);
-    const uint32_t fast_max = n / kFsMinRows + 1, tiles_max = n / kFsTile + fast_max + 1;
+    static const char *minrows_env = getenv("VQHIP_TSVQ_FAST_MIN_ROWS");  // nodes at least this long take the tile-parallel emulation
+    // The plain chain costs one dependent v_add_f32 per row and column chain (~4.9 ns per row, measured, whatever d is
+    // while its workgroups fit the chip); the emulation costs about what streaming the level's rows at ~1.7 TB/s does.
+    // A node of `len` rows is cheaper through the emulation when len * 4.9 ns > n * d * 4 B / 1.7 TB/s.
+    const uint32_t fs_model_rows = (uint32_t)std::min<double>(4.0e9, 4.8e-4 * (double)d * (double)n);
+    const uint32_t fs_min_rows = minrows_env ? (uint32_t)std::max(4096, atoi(minrows_env)) : std::max(kFsMinRows, fs_model_rows);
+    const uint32_t fast_max = n / fs_min_rows + 1, tiles_max = n / kFsTile + fast_max + 1;
     for (int q = 0; q < 2; ++q) {
         VQ_TRY(ws.b_perm[q].ensure((size_t)n * 4));
         VQ_TRY(ws.b_nodeof[q].ensure((size_t)n * 4));
@@ -1679,7 +1745,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         VQ_TRY(ws.b_fs_nodes.ensure((size_t)fast_max * 4));
         VQ_TRY(ws.b_fs_base.ensure((size_t)fast_max * 4));
         VQ_TRY(ws.b_fs_nt.ensure((size_t)fast_max * 4));
-        if (n >= kFsMinRows) {
+        if (n >= fs_min_rows) {
             VQ_TRY(ws.b_fs_sum.ensure((size_t)tiles_max * d * 8));
             VQ_TRY(ws.b_fs_summ.ensure((size_t)tiles_max * d * sizeof(FsSumm)));
             VQ_TRY(ws.b_fs_mom.ensure((size_t)tiles_max * d * sizeof(double2)));
@@ -1699,7 +1765,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         VQ_TRY(ws.b_fs_base.ensure(16));
         VQ_TRY(ws.b_fs_nt.ensure(16));
     }
-    const bool have_fast = can_fast && n >= kFsMinRows;
+    const bool have_fast = can_fast && n >= fs_min_rows;
 
     // initial state: identity permutation, every row in node 0 (the root), no children anywhere
     hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, stream, ws.b_perm[0].as<uint32_t>(),
@@ -1718,7 +1784,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         VQ_HIP(hipStreamSynchronize(stream));  // stack sources; also the only synchronisation before the final download
     }
     int cur = 0;
-    const uint32_t dgroups = (d + DG - 1) / DG, ncb = (d + kFsCols - 1) / kFsCols;
+    const uint32_t ncb = (d + kFsCols - 1) / kFsCols;
     uint32_t *lvl_split = ws.b_lvl.as<uint32_t>(), *remap = ws.b_remap.as<uint32_t>(), *slow_nodes = ws.b_lvl_slow.as<uint32_t>();
     const FsTile *tl = ws.b_fs_tiles.as<FsTile>();
     double *ts = ws.b_fs_sum.as<double>();
@@ -1732,10 +1798,18 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     // the rest through the plain chain kernel.  Grids are upper bounds; the kernels read the level's counts.
     auto colsum = [&](int mode, const LevelInfo *lvp, uint32_t ub_nodes, const uint32_t *perm) -> int {
         const uint32_t ub_fast = have_fast ? std::min(ub_nodes, fast_max) : 0u;
-        if (mode == 0)
-            hipLaunchKernelGGL(k_seg_colsum<0>, dim3(ub_nodes, dgroups), dim3(1024), 0, stream, X, d, perm, slow_nodes, lvp, na);
-        else
-            hipLaunchKernelGGL(k_seg_colsum<1>, dim3(ub_nodes, dgroups), dim3(1024), 0, stream, X, d, perm, slow_nodes, lvp, na);
+        // few nodes: 16 columns per workgroup (more chains in flight); many: 32 (fewer, fuller workgroups)
+        const uint32_t g16 = (d + 15) / 16, g32 = (d + 31) / 32;
+        static const char *narrow_env = getenv("VQHIP_TSVQ_NARROW_WGS");
+        const uint64_t narrow_max = narrow_env ? (uint64_t)atoi(narrow_env) : (uint64_t)num_cus();  // measured: 16-column workgroups pay only while they leave CUs idle otherwise
+        const bool narrow = (uint64_t)ub_nodes * g16 <= narrow_max;
+        if (narrow) {
+            if (mode == 0) hipLaunchKernelGGL((k_seg_colsum<0, 16>), dim3(ub_nodes, g16), dim3(1024), 0, stream, X, d, perm, slow_nodes, lvp, na);
+            else hipLaunchKernelGGL((k_seg_colsum<1, 16>), dim3(ub_nodes, g16), dim3(1024), 0, stream, X, d, perm, slow_nodes, lvp, na);
+        } else {
+            if (mode == 0) hipLaunchKernelGGL((k_seg_colsum<0, 32>), dim3(ub_nodes, g32), dim3(1024), 0, stream, X, d, perm, slow_nodes, lvp, na);
+            else hipLaunchKernelGGL((k_seg_colsum<1, 32>), dim3(ub_nodes, g32), dim3(1024), 0, stream, X, d, perm, slow_nodes, lvp, na);
+        }
         VQ_LAUNCH_CHECK("k_seg_colsum");
         if (ub_fast == 0) return VQHIP_OK;
         const uint32_t ub_tiles = std::min(tiles_max, n / kFsTile + ub_fast);
@@ -1781,7 +1855,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         const bool splits = L < max_depth;
         (void)can_split;
         uint32_t *perm = ws.b_perm[cur].as<uint32_t>(), *node_of = ws.b_nodeof[cur].as<uint32_t>();
-        hipLaunchKernelGGL(k_plan_level, dim3(1), dim3(1024), 0, stream, &lv[L], splits ? 1 : 0, can_fast ? 1 : 0, na, lvl_split, remap,
+        hipLaunchKernelGGL(k_plan_level, dim3(1), dim3(1024), 0, stream, &lv[L], splits ? 1 : 0, can_fast ? 1 : 0, fs_min_rows, na, lvl_split, remap,
                            ws.b_fs_nodes.as<uint32_t>(), slow_nodes, ws.b_fs_base.as<uint32_t>(), ws.b_fs_nt.as<uint32_t>(),
                            ws.b_fs_tiles.as<FsTile>());
         VQ_LAUNCH_CHECK("k_plan_level");
