@@ -107,7 +107,8 @@ def pmc_traffic(kernel_name):
     base = kernel_name.split("<")[0]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")), reverse=True):
         try:
-            d = json.load(open(path)).get(base)
+            summ = json.load(open(path))
+            d = summ.get(kernel_name.replace(" ", "")) or summ.get(base)  # the exact instantiation when the summary has it
             if d and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
                 kib = 2.0 * d["FETCH_SIZE"]["avg_per_launch"] + d["WRITE_SIZE"]["avg_per_launch"]
                 return kib * 1024.0, os.path.relpath(path, ROOT)
@@ -455,7 +456,7 @@ def main():
         kern_s = primary_ms / 1e3 / max(calls, 1)
         achieved = flop_per_row * n / kern_s / 1e12 if kern_s > 0 else 0.0
         sd = dim // m_
-        kernel_name = {2: f"k_assign_screen<{sd},16>", 3: f"k_assign_screen_bf16_x32<{sd},8>"}.get(used_engine, "k_assign_exact")
+        kernel_name = {2: f"k_assign_screen<{sd},16>", 3: f"k_assign_screen_bf16_x32<{sd},8,1,0,false>"}.get(used_engine, "k_assign_exact")
         traffic, traffic_src = pmc_traffic(kernel_name) if (n == N_PER_GPU and args.config == "C2") else (None, None)
         step_ms = dt / args.steps * 1e3
         km_ms = km_dt / km_iters * 1e3

@@ -23,9 +23,12 @@ summary = collections.defaultdict(dict)
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv"))):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(k_[A-Za-z_0-9]+)", r["Kernel_Name"])
+        m = re.search(r"(k_[A-Za-z_0-9]+)(<[^>]*>)?", r["Kernel_Name"])
         if m:
             agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if m.group(2):  # per instantiation too: "k_name<16,8,1,0,false>" (spaces and the u suffix of unsigned arguments dropped)
+                full = m.group(1) + re.sub(r"(\d)u\b", r"\1", m.group(2).replace(" ", ""))
+                agg[full][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         for c, x in v.items():
             summary[k][c] = {"avg_per_launch": sum(x) / len(x), "launches": len(x)}

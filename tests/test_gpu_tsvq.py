@@ -159,6 +159,96 @@ def test_screened_descent_adversarial(oracle):
     np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)
 
 
+@pytest.mark.parametrize("kind", ["uniform", "normal", "lattice", "structured"])
+@pytest.mark.parametrize("shape", [(6000, 32, 9), (6000, 128, 8), (3000, 384, 5), (2500, 192, 6), (2000, 768, 5),
+                                   (5000, 100, 7), (3000, 20, 6), (2000, 4, 5), (1500, 1024, 4), (30000, 128, 11)])
+def test_screened_cosine_descent_bit_identical(oracle, kind, shape):
+    """Cosine descent: two dot products with the children's unit vectors decide the rows whose margin is provable
+    (q_l >= q_r, or q_r < 0 where the clamp makes d_r = 1; strictly right only when 1 - q survives its rounding), the
+    rest resume in the reference's arithmetic (three sequential sums, EPSILON rule, clamp)."""
+    n, d, depth = shape
+    X = _data(35, n, d, kind)
+    Q = np.concatenate([_data(36, 5000, d, kind), X[:500], -_data(37, 300, d, kind)])
+    tree = oracle.tsvq_build(X, depth)
+    t = TSVQ.from_tree(tree["centroids"], tree["left"], tree["right"], Distance("cosine"))
+    want_leaf, want_f16 = oracle.tsvq_encode(3, Q, tree, threads=0)
+    np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)
+    screened, undecided = t.last_encode_stats()
+    assert screened
+    if kind in ("uniform", "normal") and d >= 20:
+        assert undecided < 0.25 * len(Q)
+    np.testing.assert_array_equal(t.quantize_batch(Q).view(np.uint16), want_f16)
+
+
+def test_screened_cosine_descent_adversarial(oracle):
+    """Rows parallel / anti-parallel / orthogonal to centroids (q = 1, q < 0 -> clamp ties -> left), equal cosines,
+    norms around the reference's EPSILON = 1e-10 and around the overflow of the squared norm, zero, denormal and
+    non-finite rows; trees with a zero, a tiny, a huge and a non-finite centroid."""
+    rng = np.random.default_rng(38)
+    n, d, depth = 4000, 64, 6
+    X = rng.standard_normal((n, d)).astype(F)
+    tree = oracle.tsvq_build(X, depth)
+    cent, left, right = tree["centroids"], tree["left"], tree["right"]
+    inner = np.where((left >= 0) & (right >= 0))[0]
+    cl, cr = cent[left[inner]].astype(np.float64), cent[right[inner]].astype(np.float64)
+    ul, ur = cl / np.linalg.norm(cl, axis=1, keepdims=True), cr / np.linalg.norm(cr, axis=1, keepdims=True)
+    bis = (ul + ur).astype(F)  # equal cosines up to rounding
+    Q = np.concatenate([bis, bis * F(3.5), -bis, cent, cent * F(-2), cent * F(1e-3), (ul - ur).astype(F),
+                        bis + F(1e-7), bis - F(1e-7),
+                        rng.standard_normal((300, d)).astype(F) * F(1e-11), rng.standard_normal((300, d)).astype(F) * F(2e-12),
+                        rng.standard_normal((300, d)).astype(F) * F(1.2e-11 / 8), rng.standard_normal((300, d)).astype(F) * F(1e-30),
+                        rng.standard_normal((300, d)).astype(F) * F(1e-41), rng.standard_normal((300, d)).astype(F) * F(1e18),
+                        rng.standard_normal((300, d)).astype(F) * F(2.3e18), rng.standard_normal((300, d)).astype(F) * F(1e30),
+                        np.zeros((3, d), F), rng.standard_normal((2000, d)).astype(F)])
+    Q[7, 5] = np.nan
+    Q[8, 9] = np.inf
+    Q[9, 1] = -np.inf
+    t = TSVQ.from_tree(cent, left, right, Distance("cosine"))
+    want_leaf, _ = oracle.tsvq_encode(3, Q, tree, want_f16=False, threads=0)
+    np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)
+    assert t.last_encode_stats()[0]
+    for edit in ("zero", "tiny", "huge", "nan", "inf", "negated"):
+        bad = {k: v.copy() for k, v in tree.items()}
+        c = bad["centroids"]
+        node = int(left[inner[1]])
+        if edit == "zero":
+            c[node] = 0
+        elif edit == "tiny":
+            c[node] *= F(1e-12)
+        elif edit == "huge":
+            c[node] *= F(1e19)
+        elif edit == "nan":
+            c[node, 2] = np.nan
+        elif edit == "inf":
+            c[node, 0] = np.inf
+        else:
+            c[int(right[inner[0]])] *= F(-1)
+        t = TSVQ.from_tree(c, left, right, Distance("cosine"))
+        want_leaf, _ = oracle.tsvq_encode(3, Q, bad, want_f16=False, threads=0)
+        np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf, err_msg=edit)
+
+
+def test_cosine_descent_fullsize_eval_shape():
+    """The reference's `make eval ALG=tsvq` shape under cosine (1M x 384, depth 5): every leaf of the screened descent
+    equals the all-exact walk of the same library (which the smaller cases pin to the oracle)."""
+    n, d, depth = 1_000_000, 384, 5
+    ds = _lib.Dataset.synthetic(n, d, seed=67)
+    cent, left, right = build_tree(ds, depth)
+    X = ds.read()
+    ds.close()
+    t = TSVQ.from_tree(cent, left, right, Distance("cosine"))
+    got = t.leaf_ids(X)
+    screened, undecided = t.last_encode_stats()
+    assert screened and undecided < 0.2 * n
+    os.environ["VQHIP_TSVQ_EXACT"] = "1"
+    try:
+        t_exact = TSVQ.from_tree(cent, left, right, Distance("cosine"))
+    finally:
+        del os.environ["VQHIP_TSVQ_EXACT"]
+    np.testing.assert_array_equal(got, t_exact.leaf_ids(X))
+    assert not t_exact.last_encode_stats()[0]
+
+
 def test_golden_tsvq_fixture():
     g = np.load(os.path.join(GOLD, "tsvq_depth5.npz"))
     ds = _lib.Dataset.from_host(g["X"])

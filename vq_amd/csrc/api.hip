@@ -465,7 +465,7 @@ struct vqhip_tsvq {
     int metric = VQHIP_EUCLIDEAN;
     DevBuf centroids, cnorm, left, right, xbuf, leafbuf, f16buf, table16;
     PinnedStage stage;
-    // screened descent (squared-L2 / Euclidean, k_tsvq_screen.hip); use_screen = false -> exact walk only
+    // screened descent (squared-L2 / Euclidean / cosine, k_tsvq_screen.hip); use_screen = false -> exact walk only
     bool use_screen = false, last_screened = false;
     TsvqScreen scr;
     DevBuf scr_w, scr_info, scr_mu, scr_wl, scr_count, scr_slot_node;
@@ -484,7 +484,15 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     uint32_t n_lds = n_int;
     while (n_lds > 1 && !tsvq_screen_supported(n_lds, n_nodes, d, t->metric)) --n_lds;
     const uint32_t dp = tsvq_screen_width(d);  // >= d: width of the kernel's w / mu rows (zeros behind d)
-    std::vector<float> w((size_t)n_int * dp, 0.0f);
+    const bool cosine = t->metric == VQHIP_COSINE;
+    const uint32_t nv = cosine ? 2u : 1u;  // vectors per slot
+    std::vector<float> cn32;               // cosine: the reference's f32 centroid norms, as the device computed them
+    if (cosine) {
+        cn32.resize(n_nodes);
+        VQ_HIP(hipMemcpyAsync(cn32.data(), t->cnorm.p, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, s));
+        VQ_HIP(hipStreamSynchronize(s));
+    }
+    std::vector<float> w((size_t)n_int * nv * dp, 0.0f);
     std::vector<int32_t> info((size_t)n_int * 4), slot_node(n_int), slot_of(n_nodes, -1);
     const float *mu = centroids;  // root
     double r2max = 0.0;
@@ -528,6 +536,42 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     for (uint32_t sl = 0; sl < n_int; ++sl) {
         const int32_t i = slot_node[sl], l = left[i], r = right[i];
         int32_t *rec = info.data() + (size_t)sl * 4;
+        if (cosine) {
+            // per child: c / nb with nb the REFERENCE's f32 norm of the centroid (cnorm, as the exact walk uses it; f64
+            // quotient rounded once), so the screen and the reference divide by the same number.  The slot's margin
+            // M = 2.0002 e_p + a_l + a_r + u  (DESIGN.md 4.4 "cosine descent"): e_p = (D/32 + 6.1) u for the screen's
+            // summation tree, a = (2.02 + 1.0003 |w o c| / nb) u for the reference's sequential dot product, w_i the
+            // number of roundings term i goes through.  A child whose norm the EPSILON rule or an overflowing squared
+            // norm could touch, or that is not finite, makes the slot exact-only (NaN margin).
+            bool usable = true;
+            double a_sum = 0.0;
+            for (uint32_t side = 0; side < 2; ++side) {
+                const int32_t ch = side == 0 ? l : r;
+                const float *c = centroids + (size_t)ch * d;
+                const double nb = (double)cn32[ch];
+                double c2 = 0.0, wc2 = 0.0;
+                for (uint32_t q = 0; q < d; ++q) {
+                    const double wq = (q == 0) ? (double)d : (double)(d - q + 1);  // additions behind term q, plus its product
+                    c2 += (double)c[q] * (double)c[q];
+                    wc2 += wq * wq * (double)c[q] * (double)c[q];
+                }
+                const double cn = std::sqrt(c2);
+                if (!(cn >= 1e-9 && cn <= 1e18) || !(nb >= 1e-9 && nb <= 1e18)) {
+                    usable = false;
+                    continue;
+                }
+                for (uint32_t q = 0; q < d; ++q) w[((size_t)sl * 2 + side) * dp + q] = (float)((double)c[q] / nb);
+                a_sum += 2.02 + 1.0003 * std::sqrt(wc2) / nb;
+            }
+            const double e_p = (double)dp / 32.0 + 6.1;
+            const double margin = (2.0002 * e_p + a_sum + 1.0) * 5.9604644775390625e-08 * 1.01;  // 1 %: the threshold's own f32 arithmetic
+            const float mf = usable ? (float)margin : std::numeric_limits<float>::quiet_NaN();
+            rec[0] = resolve(l);
+            rec[1] = resolve(r);
+            memcpy(&rec[2], &mf, 4);
+            rec[3] = 0;
+            continue;
+        }
         double w2 = 0.0;
         for (uint32_t q = 0; q < d; ++q) {
             const float wv = centroids[(size_t)l * d + q] - centroids[(size_t)r * d + q];
@@ -555,7 +599,7 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     VQ_TRY(t->scr_count.alloc(4));
     VQ_HIP(hipMemcpyAsync(t->scr_w.p, w.data(), w.size() * 4, hipMemcpyHostToDevice, s));
     VQ_HIP(hipMemcpyAsync(t->scr_info.p, info.data(), info.size() * 4, hipMemcpyHostToDevice, s));
-    VQ_HIP(hipMemcpyAsync(t->scr_mu.p, mu, (size_t)d * 4, hipMemcpyHostToDevice, s));
+    if (!cosine) VQ_HIP(hipMemcpyAsync(t->scr_mu.p, mu, (size_t)d * 4, hipMemcpyHostToDevice, s));  // cosine: y = x
     VQ_HIP(hipStreamSynchronize(s));  // w / info are stack-owned
     t->scr.w = t->scr_w.as<float>();
     t->scr.info = t->scr_info.as<int4>();
@@ -568,6 +612,12 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     // T = u * base * (coef_a * base + coef_b * |w|), base >= |x - mu| + R
     t->scr.coef_a = 1.1f * (2.0f * d + 20.0f);
     t->scr.coef_b = 1.1f * (2.0f * d + 16.0f);
+    if (cosine) {
+        // DESIGN.md 4.4 "cosine descent": T = M(slot) |x|^, the margin travels in the slot's record
+        t->scr.R = 0.0f;
+        t->scr.coef_a = 0.0f;
+        t->scr.coef_b = 0.0f;
+    }
     t->use_screen = true;
     return VQHIP_OK;
 }
@@ -1704,7 +1754,7 @@ int vqhip_tsvq_encode_device(vqhip_tsvq *t, const void *dev_rows, uint64_t n, vo
         t->last_screened = true;
         VQ_TRY(t->scr_wl.ensure((size_t)n * 8));
         t->scr.wl = t->scr_wl.as<uint2>();
-        VQ_TRY(launch_tsvq_screen_encode(X, n, t->d, t->centroids.as<float>(), t->left.as<int32_t>(),
+        VQ_TRY(launch_tsvq_screen_encode(X, n, t->d, t->centroids.as<float>(), t->cnorm.as<float>(), t->left.as<int32_t>(),
                                          t->right.as<int32_t>(), t->metric, t->scr, leaf, s));
     } else {
         VQ_TRY(launch_tsvq_encode(X, n, t->d, t->centroids.as<float>(), t->cnorm.as<float>(), t->left.as<int32_t>(),

@@ -1,4 +1,4 @@
-// TSVQ encode, squared-L2 / Euclidean: screened descent + exact continuation.
+// TSVQ encode, squared-L2 / Euclidean / cosine: screened descent + exact continuation.
 //
 // Reference: TSVQNode::find_leaf, src/tsvq.rs:117-132 -- at every node with two children the
 // row goes left iff fl(dist(x, c_l)) <= fl(dist(x, c_r)), both distances sequential un-fused
@@ -49,7 +49,17 @@ constexpr int32_t kFlagBase = INT32_MIN;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // WAVES per workgroup: 16 while a row's registers (3 x D/8 floats) fit 128 VGPRs, 8 or 4 for the long rows
-template <int D, int LPR, int WAVES>
+//
+// COS (Distance::CosineDistance, src/core/distance.rs:95-118): a slot holds the two UNIT vectors c_l/|c_l|, c_r/|c_r|
+// (c over the reference's own f32 norm of c; f64 on the host, rounded once) instead of w; per level P_l = x.c^_l and
+// P_r = x.c^_r, and with T = M(slot) |x|^
+//     left   iff  P_l - P_r > T  or  P_r < -T      (q_l >= q_r: 1-q and the clamp are monotone;  q_r < 0: d_r = 1 >= d_l)
+//     right  iff  P_r - P_l > T and  P_r >  T and P_l < 0.999 |x|^
+//                                                  (q_r - q_l > 2^-24 survives the rounding of 1-q; q_r > 0: d_r < 1; q_l < 1)
+// anything else is undecided (DESIGN.md 4.4 "cosine descent").  Rows whose norm is outside [1e-9, 1e18] (the
+// reference's EPSILON rule, overflow of the squared norm) or not finite make T NaN; slots with such a child carry a
+// NaN margin in info.z.
+template <int D, int LPR, int WAVES, bool COS>
 __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
     const float *__restrict__ X, uint64_t n, uint32_t d_real, const float *__restrict__ w_g,
     const int4 *__restrict__ info_g, const float *__restrict__ mu_g, uint32_t n_int, int32_t start_slot, float R,
@@ -63,13 +73,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
     constexpr int CH = LPR * 4;       // floats per chunk (LPR lanes x float4)
     constexpr int NCH = D / CH;       // chunks per row = float4 values per lane
     constexpr int RPW = 64 / LPR;     // rows per wave step
+    constexpr int NV = COS ? 2 : 1;   // vectors per slot
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *lds_w = lds;                                                       // [n_int][D]
-    int4 *lds_info = reinterpret_cast<int4 *>(lds + (size_t)n_int * D);        // [n_int]
+    float *lds_w = lds;                                                       // [n_int][NV][D]
+    int4 *lds_info = reinterpret_cast<int4 *>(lds + (size_t)n_int * NV * D);   // [n_int]
     uint2 *lds_wl = reinterpret_cast<uint2 *>(lds_info + n_int);               // [kWaves][kWlBuf]
     {
         constexpr uint32_t T = WAVES * 64;
-        const uint32_t total = n_int * (D / 4);
+        const uint32_t total = n_int * NV * (D / 4);
         for (uint32_t e0 = 0; e0 < total; e0 += 4 * T) {  // 4 loads in flight per thread
             float4 v[4];
 #pragma unroll
@@ -141,46 +152,60 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
             ysq0 = fmaf(y[c].z, y[c].z, ysq0);
             ysq1 = fmaf(y[c].w, y[c].w, ysq1);
         }
-        const float base = (__builtin_sqrtf(allreduce(ysq0 + ysq1)) + R) * 1.0001f;
-        // T = u * base * (coef_a * base + coef_b * |w|) + 1e-36
-        const float t_a = fmaf(5.9604644775390625e-08f * coef_a * base, base, 1e-36f);
-        const float t_b = 5.9604644775390625e-08f * coef_b * base;
+        const float ynorm = __builtin_sqrtf(allreduce(ysq0 + ysq1));
+        const float base = (ynorm + R) * 1.0001f;
+        // L2: T = u * base * (coef_a * base + coef_b * |w|) + 1e-36;   cosine: T = u * coef_a * |x|^ (+ the slot's NaN flag)
+        float t_a = fmaf(5.9604644775390625e-08f * coef_a * base, base, 1e-36f);
+        float t_b = 5.9604644775390625e-08f * coef_b * base;
+        if (COS) {  // t_a = |x|^ (>= the row's norm and the reference's f32 norm), NaN outside the screen's range
+            t_a = (ynorm >= 1e-9f && ynorm <= 1e18f) ? base : __builtin_nanf("");
+            t_b = 0.999f * t_a;
+        }
         int32_t cur = (row < n) ? start_slot : -1;
         if (tile + tile_stride < n_tiles) load_tile(tile + tile_stride, xn);  // in flight during the descent
         for (;;) {
             const int32_t a = cur > 0 ? cur : 0;
             const bool deep = a >= (int32_t)n_int;
             int4 inf;
-            float4 wv[NCH];
-            if (!__any(deep)) {  // the usual case: whole wave inside the LDS-resident levels
-                inf = lds_info[a];
-                const float *wp = lds_w + (size_t)a * D;
+            float P[NV];
+            const bool any_deep = __any(deep);
+            if (!any_deep || !deep) inf = lds_info[a];
+            else inf = info_g[a];
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
-            } else if (deep) {
-                inf = info_g[a];
-                const float *wp = w_g + (size_t)a * D;
+            for (int v = 0; v < NV; ++v) {
+                float4 wv[NCH];
+                if (!any_deep || !deep) {  // the usual case: whole wave inside the LDS-resident levels
+                    const float *wp = lds_w + ((size_t)a * NV + v) * D;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
+                    for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
+                } else {
+                    const float *wp = w_g + ((size_t)a * NV + v) * D;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
+                }
+                // register-adjacent pairs -> v_pk_fma_f32 without operand shuffles
+                f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    acc01 = __builtin_elementwise_fma(f32x2{y[c].x, y[c].y}, f32x2{wv[c].x, wv[c].y}, acc01);
+                    acc23 = __builtin_elementwise_fma(f32x2{y[c].z, y[c].w}, f32x2{wv[c].z, wv[c].w}, acc23);
+                }
+                acc01 = acc01 + acc23;
+                P[v] = allreduce(acc01.x + acc01.y);
+            }
+            // NaN / inf thresholds never pass
+            const float T = COS ? t_a * __int_as_float(inf.z) : fmaf(t_b, __int_as_float(inf.w), t_a);
+            int32_t next;
+            if (COS) {
+                const float dlt = P[0] - P[NV - 1];
+                const bool go_l = (dlt > T) || (P[NV - 1] < -T);
+                const bool go_r = (-dlt > T) && (P[NV - 1] > T) && (P[0] < t_b);  // q_l < 1: 1 - q_l stays positive
+                next = go_l ? inf.x : (go_r ? inf.y : (kFlagBase + a));
             } else {
-                inf = lds_info[a];
-                const float *wp = lds_w + (size_t)a * D;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
+                const float delta = fmaf(-2.0f, P[0], __int_as_float(inf.z));
+                const int32_t code = (delta < 0.0f) ? inf.x : inf.y;
+                next = (fabsf(delta) > T) ? code : (kFlagBase + a);
             }
-            // register-adjacent pairs -> v_pk_fma_f32 without operand shuffles
-            f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                acc01 = __builtin_elementwise_fma(f32x2{y[c].x, y[c].y}, f32x2{wv[c].x, wv[c].y}, acc01);
-                acc23 = __builtin_elementwise_fma(f32x2{y[c].z, y[c].w}, f32x2{wv[c].z, wv[c].w}, acc23);
-            }
-            acc01 = acc01 + acc23;
-            const float acc = allreduce(acc01.x + acc01.y);
-            const float delta = fmaf(-2.0f, acc, __int_as_float(inf.z));
-            const float T = fmaf(t_b, __int_as_float(inf.w), t_a);
-            const int32_t code = (delta < 0.0f) ? inf.x : inf.y;
-            const int32_t next = (fabsf(delta) > T) ? code : (kFlagBase + a);  // NaN / inf thresholds never pass
             cur = (cur >= 0) ? next : cur;
             if (!__any(cur >= 0)) break;
         }
@@ -219,9 +244,21 @@ __device__ __forceinline__ void load_piece(const float *__restrict__ p, float *o
     }
 }
 
-template <int D>
+// reference's cosine distance from its three sequential sums (src/core/distance.rs:95-118; cnorm = sqrt(sum c^2))
+__device__ __forceinline__ float cosine_from_sums(float dot, float na, float nb) {
+    if (na < 1e-10f || nb < 1e-10f) return 1.0f;
+    const float den = na * nb;
+    const float qq = dot / den;
+    const float v = 1.0f - qq;
+    return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);  // f32::clamp: NaN stays NaN
+}
+
+// COS: the two running sums are the dot products x.c_l, x.c_r (same order), the row's own squared norm is summed
+// once before the walk through the same lane chain
+template <int D, bool COS>
 __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__ X,
                                                        const float *__restrict__ centroids,
+                                                       const float *__restrict__ cnorm,
                                                        const int32_t *__restrict__ left,
                                                        const int32_t *__restrict__ right, int euclid,
                                                        const int32_t *__restrict__ slot_node,
@@ -253,6 +290,24 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
         }
         int32_t node = valid ? slot_node[ent.y] : 0;
         bool walking = valid;
+        float na = 0.0f;
+        if (COS) {
+            float sa = -0.0f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll 1
+                for (int hop = 0; hop < 16; ++hop) {
+                    float ta = dpp_move<0x121>(sa);  // row_ror:1
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const float p = x[q][v] * x[q][v];
+                        ta = ta + p;
+                    }
+                    if (j == (uint32_t)hop) sa = ta;
+                }
+            }
+            na = sqrtf(dpp_move<0x121>(sa));  // lane 15 -> lane 0
+        }
         while (__any(walking)) {
             const int32_t l = left[node], r = right[node];
             const bool both = (l >= 0) && (r >= 0);
@@ -272,9 +327,14 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
                 }
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
-                    const float d1 = x[q][v] - cl[v], d2 = x[q][v] - cr[v];
-                    s1[q][v] = d1 * d1;
-                    s2[q][v] = d2 * d2;
+                    if (COS) {
+                        s1[q][v] = x[q][v] * cl[v];
+                        s2[q][v] = x[q][v] * cr[v];
+                    } else {
+                        const float d1 = x[q][v] - cl[v], d2 = x[q][v] - cr[v];
+                        s1[q][v] = d1 * d1;
+                        s2[q][v] = d2 * d2;
+                    }
                 }
             }
             float al = -0.0f, ar = -0.0f;
@@ -298,7 +358,10 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
             }
             // lane 15 holds both distances
             float dl = dpp_move<0x121>(al), dr = dpp_move<0x121>(ar);  // now in lane 0
-            if (euclid) {
+            if (COS) {
+                dl = cosine_from_sums(dl, na, cnorm[both ? l : 0]);
+                dr = cosine_from_sums(dr, na, cnorm[both ? r : 0]);
+            } else if (euclid) {
                 dl = sqrtf(dl);
                 dr = sqrtf(dr);
             }
@@ -320,8 +383,9 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
 // entry, run-time-length loops in the reference's order; the entries are few
 __global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restrict__ X, uint32_t d,
                                                            const float *__restrict__ centroids,
+                                                           const float *__restrict__ cnorm,
                                                            const int32_t *__restrict__ left,
-                                                           const int32_t *__restrict__ right, int euclid,
+                                                           const int32_t *__restrict__ right, int euclid, int cosine,
                                                            const int32_t *__restrict__ slot_node,
                                                            const uint2 *__restrict__ wl,
                                                            const uint32_t *__restrict__ wl_count,
@@ -331,6 +395,15 @@ __global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restri
         const uint2 ent = wl[e];
         const float *x = X + (size_t)ent.x * d;
         int32_t node = slot_node[ent.y];
+        float na = 0.0f;
+        if (cosine) {
+            float sa = -0.0f;
+            for (uint32_t t = 0; t < d; ++t) {
+                const float p = x[t] * x[t];
+                sa = sa + p;
+            }
+            na = sqrtf(sa);
+        }
         for (;;) {
             const int32_t l = left[node], r = right[node];
             if (l >= 0 && r >= 0) {
@@ -338,12 +411,20 @@ __global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restri
                 float al = -0.0f, ar = -0.0f;
                 for (uint32_t t = 0; t < d; ++t) {
                     const float v = x[t];
-                    const float d1 = v - cl[t], d2 = v - cr[t];
-                    const float s1 = d1 * d1, s2 = d2 * d2;
+                    float s1, s2;
+                    if (cosine) {
+                        s1 = v * cl[t];
+                        s2 = v * cr[t];
+                    } else {
+                        const float d1 = v - cl[t], d2 = v - cr[t];
+                        s1 = d1 * d1;
+                        s2 = d2 * d2;
+                    }
                     al = al + s1;
                     ar = ar + s2;
                 }
-                const float dl = euclid ? sqrtf(al) : al, dr = euclid ? sqrtf(ar) : ar;
+                const float dl = cosine ? cosine_from_sums(al, na, cnorm[l]) : (euclid ? sqrtf(al) : al);
+                const float dr = cosine ? cosine_from_sums(ar, na, cnorm[r]) : (euclid ? sqrtf(ar) : ar);
                 node = (dl <= dr) ? l : r;  // left on ties, tsvq.rs:122
             } else if (l >= 0) {
                 node = l;
@@ -357,30 +438,31 @@ __global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restri
     }
 }
 
-template <int D>
-static int launch_continue(const float *X, const float *centroids, const int32_t *left, const int32_t *right,
-                           int euclid, const TsvqScreen &s, int32_t *leaf, hipStream_t stream, uint32_t d_real) {
-    hipLaunchKernelGGL(k_tsvq_continue<D>, dim3(1024), dim3(256), 0, stream, X, centroids, left, right, euclid,
+template <int D, bool COS>
+static int launch_continue(const float *X, const float *centroids, const float *cnorm, const int32_t *left,
+                           const int32_t *right, int euclid, const TsvqScreen &s, int32_t *leaf, hipStream_t stream,
+                           uint32_t d_real) {
+    hipLaunchKernelGGL((k_tsvq_continue<D, COS>), dim3(1024), dim3(256), 0, stream, X, centroids, cnorm, left, right, euclid,
                        s.slot_node, s.wl, s.wl_count, d_real, leaf);
     VQ_LAUNCH_CHECK("k_tsvq_continue");
     return VQHIP_OK;
 }
 
-template <int D, int LPR>
+template <int D, int LPR, bool COS>
 int launch_screen(const float *X, uint64_t n, uint32_t d_real, const TsvqScreen &s, hipStream_t stream, int32_t *leaf) {
     constexpr int RPW = 64 / LPR;
     constexpr int WAVES = (D >= 512) ? 4 : (D >= 256) ? 8 : kWaves;  // 512 / 256 / 128 VGPRs per lane
-    const size_t lds_bytes = tsvq_screen_lds_bytes(s.n_int, s.n_nodes, D);
+    const size_t lds_bytes = tsvq_screen_lds_bytes(s.n_int, COS ? 2 : 1, D);
     static PerDeviceOnce attr_set;
     if (attr_set.needed()) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR, WAVES>),
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR, WAVES, COS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set.done();
     }
     const uint64_t n_tiles = (n + RPW - 1) / RPW;
     uint64_t grid = (n_tiles + WAVES - 1) / WAVES;
     if (grid > (uint64_t)num_cus()) grid = (uint64_t)num_cus();
-    hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X,
+    hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES, COS>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X,
                        n, d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count);
     VQ_LAUNCH_CHECK("k_tsvq_screen_descend");
     return VQHIP_OK;
@@ -388,9 +470,9 @@ int launch_screen(const float *X, uint64_t n, uint32_t d_real, const TsvqScreen 
 
 }  // namespace
 
-size_t tsvq_screen_lds_bytes(uint32_t n_int, uint32_t n_nodes, uint32_t d) {
-    (void)n_nodes;
-    return (size_t)n_int * d * 4 + (size_t)n_int * 16 + (size_t)kWaves * kWlBuf * 8;
+// nv: vectors per slot (1: w = c_l - c_r for the L2 family; 2: the children's unit vectors for cosine)
+size_t tsvq_screen_lds_bytes(uint32_t n_int, uint32_t nv, uint32_t d) {
+    return (size_t)n_int * nv * d * 4 + (size_t)n_int * 16 + (size_t)kWaves * kWlBuf * 8;
 }
 
 // instantiated width that serves dimension d: d itself, or the next width up for other multiples of 4 (zero padding)
@@ -402,24 +484,33 @@ uint32_t tsvq_screen_width(uint32_t d) {
 }
 
 bool tsvq_screen_supported(uint32_t n_int, uint32_t n_nodes, uint32_t d, int metric) {
-    if (metric != VQHIP_SQUARED_EUCLIDEAN && metric != VQHIP_EUCLIDEAN) return false;
+    (void)n_nodes;
+    if (metric != VQHIP_SQUARED_EUCLIDEAN && metric != VQHIP_EUCLIDEAN && metric != VQHIP_COSINE) return false;
     const uint32_t dp = tsvq_screen_width(d);
     if (dp == 0 || n_int == 0) return false;
-    return tsvq_screen_lds_bytes(n_int, n_nodes, dp) <= 160 * 1024;
+    return tsvq_screen_lds_bytes(n_int, metric == VQHIP_COSINE ? 2 : 1, dp) <= 160 * 1024;
 }
 
-int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const int32_t *left,
-                              const int32_t *right, int metric, const TsvqScreen &s, int32_t *leaf,
+int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const float *cnorm,
+                              const int32_t *left, const int32_t *right, int metric, const TsvqScreen &s, int32_t *leaf,
                               hipStream_t stream) {
     if (n == 0) return VQHIP_OK;
     if (n > 0xFFFFFFFFull) return fail(VQHIP_ERR_UNSUPPORTED, "screened TSVQ descent takes < 2^32 rows per call");
     VQ_HIP(hipMemsetAsync(s.wl_count, 0, 4, stream));
     const int euclid = metric == VQHIP_EUCLIDEAN ? 1 : 0;
+    const bool cosine = metric == VQHIP_COSINE;
     const uint32_t dp = tsvq_screen_width(d);  // instantiated width serving d (d itself, or the next one up: zero padding)
 #define VQ_TSVQ_D(DV)                                                                              \
     case DV:                                                                                       \
-        VQ_TRY((launch_screen<DV, 8>(X, n, d, s, stream, leaf)));                                  \
-        if (DV >= 64 || d == DV) VQ_TRY(launch_continue<DV>(X, centroids, left, right, euclid, s, leaf, stream, d)); \
+        if (cosine) {                                                                              \
+            VQ_TRY((launch_screen<DV, 8, true>(X, n, d, s, stream, leaf)));                        \
+            if (DV >= 64 || d == DV)                                                               \
+                VQ_TRY((launch_continue<DV, true>(X, centroids, cnorm, left, right, euclid, s, leaf, stream, d))); \
+        } else {                                                                                   \
+            VQ_TRY((launch_screen<DV, 8, false>(X, n, d, s, stream, leaf)));                       \
+            if (DV >= 64 || d == DV)                                                               \
+                VQ_TRY((launch_continue<DV, false>(X, centroids, cnorm, left, right, euclid, s, leaf, stream, d))); \
+        }                                                                                          \
         break;
     switch (dp) {
         VQ_TSVQ_D(32) VQ_TSVQ_D(64) VQ_TSVQ_D(128) VQ_TSVQ_D(192) VQ_TSVQ_D(256)
@@ -428,8 +519,8 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
     }
 #undef VQ_TSVQ_D
     if (d != dp && dp < 64) {  // d < 32 (8-byte pieces in k_tsvq_continue): the run-time-length kernel
-        hipLaunchKernelGGL(k_tsvq_continue_any, dim3(256), dim3(256), 0, stream, X, d, centroids, left, right, euclid,
-                           s.slot_node, s.wl, s.wl_count, leaf);
+        hipLaunchKernelGGL(k_tsvq_continue_any, dim3(256), dim3(256), 0, stream, X, d, centroids, cnorm, left, right, euclid,
+                           cosine ? 1 : 0, s.slot_node, s.wl, s.wl_count, leaf);
         VQ_LAUNCH_CHECK("k_tsvq_continue_any");
     }
     return VQHIP_OK;

@@ -198,8 +198,8 @@ size_t adc_cand_bytes();
 
 // prepared per-node data of the screened squared-L2 / Euclidean descent (k_tsvq_screen.hip)
 struct TsvqScreen {
-    const float *w = nullptr;     // [n_int][d]  c_left - c_right of every two-child node
-    const int4 *info = nullptr;   // [n_int]     {code_l, code_r, bits(b), bits(|w|)}; code >= 0 slot, < 0 leaf -1-code
+    const float *w = nullptr;     // [n_int][d]  c_left - c_right of every two-child node; cosine: [n_int][2][d] unit vectors of the children
+    const int4 *info = nullptr;   // [n_int]     {code_l, code_r, bits(b), bits(|w|)}; code >= 0 slot, < 0 leaf -1-code; cosine: {.., .., bits(margin M, NaN = exact-only), 0}
     const int32_t *slot_node = nullptr;  // [n_int] node index of a slot
     int32_t start_slot = 0;       // slot the root resolves to
     const float *mu = nullptr;    // [d]         root centroid
@@ -209,11 +209,11 @@ struct TsvqScreen {
     uint2 *wl = nullptr;          // [n] undecided (row, node)
     uint32_t *wl_count = nullptr;
 };
-size_t tsvq_screen_lds_bytes(uint32_t n_int, uint32_t n_nodes, uint32_t d);
+size_t tsvq_screen_lds_bytes(uint32_t n_int, uint32_t nv, uint32_t d);
 uint32_t tsvq_screen_width(uint32_t d);  // instantiated width serving d (zero padding for other multiples of 4), 0 = none
 bool tsvq_screen_supported(uint32_t n_int, uint32_t n_nodes, uint32_t d, int metric);
-int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const int32_t *left,
-                              const int32_t *right, int metric, const TsvqScreen &s, int32_t *leaf,
+int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const float *cnorm,
+                              const int32_t *left, const int32_t *right, int metric, const TsvqScreen &s, int32_t *leaf,
                               hipStream_t stream);
 int launch_tsvq_gather_f16(const float *centroids, uint32_t d, const int32_t *leaf, uint64_t n, uint16_t *f16_out,
                            hipStream_t stream);
