@@ -162,22 +162,54 @@ def test_screened_descent_adversarial(oracle):
 @pytest.mark.parametrize("kind", ["uniform", "normal", "lattice", "structured"])
 @pytest.mark.parametrize("shape", [(6000, 32, 9), (6000, 128, 8), (3000, 384, 5), (2500, 192, 6), (2000, 768, 5),
                                    (5000, 100, 7), (3000, 20, 6), (2000, 4, 5), (1500, 1024, 4), (30000, 128, 11)])
-def test_screened_cosine_descent_bit_identical(oracle, kind, shape):
+@pytest.mark.parametrize("metric", [3, 2])
+def test_screened_cosine_manhattan_descent_bit_identical(oracle, kind, shape, metric):
     """Cosine descent: two dot products with the children's unit vectors decide the rows whose margin is provable
     (q_l >= q_r, or q_r < 0 where the clamp makes d_r = 1; strictly right only when 1 - q survives its rounding), the
-    rest resume in the reference's arithmetic (three sequential sums, EPSILON rule, clamp)."""
+    rest resume in the reference's arithmetic (three sequential sums, EPSILON rule, clamp).  Manhattan descent: both
+    L1 sums in a tree order, decided when they differ by more than the two orders' relative error bounds."""
     n, d, depth = shape
     X = _data(35, n, d, kind)
     Q = np.concatenate([_data(36, 5000, d, kind), X[:500], -_data(37, 300, d, kind)])
     tree = oracle.tsvq_build(X, depth)
-    t = TSVQ.from_tree(tree["centroids"], tree["left"], tree["right"], Distance("cosine"))
-    want_leaf, want_f16 = oracle.tsvq_encode(3, Q, tree, threads=0)
+    t = TSVQ.from_tree(tree["centroids"], tree["left"], tree["right"], Distance({3: "cosine", 2: "manhattan"}[metric]))
+    want_leaf, want_f16 = oracle.tsvq_encode(metric, Q, tree, threads=0)
     np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)
     screened, undecided = t.last_encode_stats()
     assert screened
     if kind in ("uniform", "normal") and d >= 20:
         assert undecided < 0.25 * len(Q)
     np.testing.assert_array_equal(t.quantize_batch(Q).view(np.uint16), want_f16)
+
+
+def test_screened_manhattan_descent_adversarial(oracle):
+    """Exact L1 ties (-> left), rows at centroids (distance 0), sums that overflow, denormal and non-finite rows,
+    a tree with non-finite centroids."""
+    rng = np.random.default_rng(39)
+    n, d, depth = 4000, 64, 6
+    X = rng.integers(-3, 4, (n, d)).astype(F)  # small integers: every L1 sum is exact, ties are real
+    tree = oracle.tsvq_build(X, depth)
+    cent, left, right = tree["centroids"], tree["left"], tree["right"]
+    inner = np.where((left >= 0) & (right >= 0))[0]
+    mid = ((cent[left[inner]].astype(np.float64) + cent[right[inner]]) / 2).astype(F)
+    Q = np.concatenate([mid, cent, X[:1500], rng.integers(-3, 4, (1500, d)).astype(F),
+                        rng.standard_normal((300, d)).astype(F) * F(1e37), rng.standard_normal((300, d)).astype(F) * F(3e38),
+                        rng.standard_normal((300, d)).astype(F) * F(1e-38), rng.standard_normal((300, d)).astype(F) * F(1e-42),
+                        np.zeros((3, d), F), rng.standard_normal((1000, d)).astype(F)])
+    Q[7, 5] = np.nan
+    Q[8, 9] = np.inf
+    Q[9, 1] = -np.inf
+    t = TSVQ.from_tree(cent, left, right, Distance("manhattan"))
+    want_leaf, _ = oracle.tsvq_encode(2, Q, tree, want_f16=False, threads=0)
+    np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)
+    assert t.last_encode_stats()[0]
+    bad = {k: v.copy() for k, v in tree.items()}
+    bad["centroids"][3, 2] = np.nan
+    bad["centroids"][5, 0] = np.inf
+    bad["centroids"][int(left[inner[1]])] *= F(1e38)
+    t = TSVQ.from_tree(bad["centroids"], left, right, Distance("manhattan"))
+    want_leaf, _ = oracle.tsvq_encode(2, Q, bad, want_f16=False, threads=0)
+    np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)
 
 
 def test_screened_cosine_descent_adversarial(oracle):
@@ -228,21 +260,22 @@ def test_screened_cosine_descent_adversarial(oracle):
         np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf, err_msg=edit)
 
 
-def test_cosine_descent_fullsize_eval_shape():
-    """The reference's `make eval ALG=tsvq` shape under cosine (1M x 384, depth 5): every leaf of the screened descent
-    equals the all-exact walk of the same library (which the smaller cases pin to the oracle)."""
+@pytest.mark.parametrize("metric", ["cosine", "manhattan"])
+def test_cosine_manhattan_descent_fullsize_eval_shape(metric):
+    """The reference's `make eval ALG=tsvq` shape under cosine / Manhattan (1M x 384, depth 5): every leaf of the
+    screened descent equals the all-exact walk of the same library (which the smaller cases pin to the oracle)."""
     n, d, depth = 1_000_000, 384, 5
     ds = _lib.Dataset.synthetic(n, d, seed=67)
     cent, left, right = build_tree(ds, depth)
     X = ds.read()
     ds.close()
-    t = TSVQ.from_tree(cent, left, right, Distance("cosine"))
+    t = TSVQ.from_tree(cent, left, right, Distance(metric))
     got = t.leaf_ids(X)
     screened, undecided = t.last_encode_stats()
     assert screened and undecided < 0.2 * n
     os.environ["VQHIP_TSVQ_EXACT"] = "1"
     try:
-        t_exact = TSVQ.from_tree(cent, left, right, Distance("cosine"))
+        t_exact = TSVQ.from_tree(cent, left, right, Distance(metric))
     finally:
         del os.environ["VQHIP_TSVQ_EXACT"]
     np.testing.assert_array_equal(got, t_exact.leaf_ids(X))

@@ -465,7 +465,7 @@ struct vqhip_tsvq {
     int metric = VQHIP_EUCLIDEAN;
     DevBuf centroids, cnorm, left, right, xbuf, leafbuf, f16buf, table16;
     PinnedStage stage;
-    // screened descent (squared-L2 / Euclidean / cosine, k_tsvq_screen.hip); use_screen = false -> exact walk only
+    // screened descent (k_tsvq_screen.hip); use_screen = false -> exact walk only
     bool use_screen = false, last_screened = false;
     TsvqScreen scr;
     DevBuf scr_w, scr_info, scr_mu, scr_wl, scr_count, scr_slot_node;
@@ -484,8 +484,8 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     uint32_t n_lds = n_int;
     while (n_lds > 1 && !tsvq_screen_supported(n_lds, n_nodes, d, t->metric)) --n_lds;
     const uint32_t dp = tsvq_screen_width(d);  // >= d: width of the kernel's w / mu rows (zeros behind d)
-    const bool cosine = t->metric == VQHIP_COSINE;
-    const uint32_t nv = cosine ? 2u : 1u;  // vectors per slot
+    const bool cosine = t->metric == VQHIP_COSINE, manhattan = t->metric == VQHIP_MANHATTAN;
+    const uint32_t nv = (cosine || manhattan) ? 2u : 1u;  // vectors per slot
     std::vector<float> cn32;               // cosine: the reference's f32 centroid norms, as the device computed them
     if (cosine) {
         cn32.resize(n_nodes);
@@ -536,6 +536,18 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     for (uint32_t sl = 0; sl < n_int; ++sl) {
         const int32_t i = slot_node[sl], l = left[i], r = right[i];
         int32_t *rec = info.data() + (size_t)sl * 4;
+        if (manhattan) {
+            // the children's centroids as they are; both L1 sums are within a relative gamma of the same exact sum of
+            // the reference's own terms: m = 2.01 (d + D/32 + 6) u (+1 % for the threshold's own arithmetic)
+            for (uint32_t side = 0; side < 2; ++side)
+                memcpy(&w[((size_t)sl * 2 + side) * dp], centroids + (size_t)(side == 0 ? l : r) * d, (size_t)d * 4);
+            const float mf = (float)(2.01 * ((double)d + (double)dp / 32.0 + 6.0) * 5.9604644775390625e-08 * 1.01);
+            rec[0] = resolve(l);
+            rec[1] = resolve(r);
+            memcpy(&rec[2], &mf, 4);
+            rec[3] = 0;
+            continue;
+        }
         if (cosine) {
             // per child: c / nb with nb the REFERENCE's f32 norm of the centroid (cnorm, as the exact walk uses it; f64
             // quotient rounded once), so the screen and the reference divide by the same number.  The slot's margin
@@ -599,7 +611,7 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     VQ_TRY(t->scr_count.alloc(4));
     VQ_HIP(hipMemcpyAsync(t->scr_w.p, w.data(), w.size() * 4, hipMemcpyHostToDevice, s));
     VQ_HIP(hipMemcpyAsync(t->scr_info.p, info.data(), info.size() * 4, hipMemcpyHostToDevice, s));
-    if (!cosine) VQ_HIP(hipMemcpyAsync(t->scr_mu.p, mu, (size_t)d * 4, hipMemcpyHostToDevice, s));  // cosine: y = x
+    if (!cosine && !manhattan) VQ_HIP(hipMemcpyAsync(t->scr_mu.p, mu, (size_t)d * 4, hipMemcpyHostToDevice, s));  // else y = x
     VQ_HIP(hipStreamSynchronize(s));  // w / info are stack-owned
     t->scr.w = t->scr_w.as<float>();
     t->scr.info = t->scr_info.as<int4>();
@@ -612,8 +624,8 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     // T = u * base * (coef_a * base + coef_b * |w|), base >= |x - mu| + R
     t->scr.coef_a = 1.1f * (2.0f * d + 20.0f);
     t->scr.coef_b = 1.1f * (2.0f * d + 16.0f);
-    if (cosine) {
-        // DESIGN.md 4.4 "cosine descent": T = M(slot) |x|^, the margin travels in the slot's record
+    if (cosine || manhattan) {
+        // DESIGN.md 4.4 "cosine descent" / "Manhattan descent": the margin travels in the slot's record
         t->scr.R = 0.0f;
         t->scr.coef_a = 0.0f;
         t->scr.coef_b = 0.0f;

@@ -1,4 +1,4 @@
-// TSVQ encode, squared-L2 / Euclidean / cosine: screened descent + exact continuation.
+// TSVQ encode, all four metrics: screened descent + exact continuation.
 //
 // Reference: TSVQNode::find_leaf, src/tsvq.rs:117-132 -- at every node with two children the
 // row goes left iff fl(dist(x, c_l)) <= fl(dist(x, c_r)), both distances sequential un-fused
@@ -59,7 +59,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // anything else is undecided (DESIGN.md 4.4 "cosine descent").  Rows whose norm is outside [1e-9, 1e18] (the
 // reference's EPSILON rule, overflow of the squared norm) or not finite make T NaN; slots with such a child carry a
 // NaN margin in info.z.
-template <int D, int LPR, int WAVES, bool COS>
+//
+// MAN (Distance::Manhattan, src/core/distance.rs:84-93): a slot holds the two children's centroids; both L1 distances
+// are summed per level by the row's 8 lanes (the terms fl(|x - c|) are the reference's own, only the order of the
+// additions differs).  All terms are non-negative, so both sums are within a RELATIVE gamma of the same exact sum:
+//     left   iff  S_l (1 + m) <= S_r,      right  iff  S_r (1 + m) < S_l,      m = 2.01 (d + D/32 + 6) u
+// and anything else -- or a sum that is not finite and below 1e37 -- is undecided.
+constexpr int kScrL2 = 0, kScrCos = 1, kScrMan = 2;
+template <int D, int LPR, int WAVES, int MODE>
 __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
     const float *__restrict__ X, uint64_t n, uint32_t d_real, const float *__restrict__ w_g,
     const int4 *__restrict__ info_g, const float *__restrict__ mu_g, uint32_t n_int, int32_t start_slot, float R,
@@ -73,7 +80,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
     constexpr int CH = LPR * 4;       // floats per chunk (LPR lanes x float4)
     constexpr int NCH = D / CH;       // chunks per row = float4 values per lane
     constexpr int RPW = 64 / LPR;     // rows per wave step
-    constexpr int NV = COS ? 2 : 1;   // vectors per slot
+    constexpr bool COS = MODE == kScrCos, MAN = MODE == kScrMan;
+    constexpr int NV = (COS || MAN) ? 2 : 1;   // vectors per slot
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *lds_w = lds;                                                       // [n_int][NV][D]
     int4 *lds_info = reinterpret_cast<int4 *>(lds + (size_t)n_int * NV * D);   // [n_int]
@@ -183,6 +191,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
                 }
+                if (MAN) {
+                    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;  // four chains per lane: depth NCH + 5 with the reductions
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        a0 = a0 + fabsf(y[c].x - wv[c].x);
+                        a1 = a1 + fabsf(y[c].y - wv[c].y);
+                        a2 = a2 + fabsf(y[c].z - wv[c].z);
+                        a3 = a3 + fabsf(y[c].w - wv[c].w);
+                    }
+                    P[v] = allreduce((a0 + a1) + (a2 + a3));
+                    continue;
+                }
                 // register-adjacent pairs -> v_pk_fma_f32 without operand shuffles
                 f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
 #pragma unroll
@@ -196,7 +216,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
             // NaN / inf thresholds never pass
             const float T = COS ? t_a * __int_as_float(inf.z) : fmaf(t_b, __int_as_float(inf.w), t_a);
             int32_t next;
-            if (COS) {
+            if (MAN) {
+                const float sl = P[0], sr = P[NV - 1], mrg = __int_as_float(inf.z);  // NaN margin: exact-only slot
+                const bool fin = (sl < 1e37f) && (sr < 1e37f);
+                const bool go_l = fin && (fmaf(sl, mrg, sl) <= sr * 0.99999988f);   // one rounding each, absorbed by the 1 % on m
+                const bool go_r = fin && (fmaf(sr, mrg, sr) < sl * 0.99999988f);
+                next = go_l ? inf.x : (go_r ? inf.y : (kFlagBase + a));
+            } else if (COS) {
                 const float dlt = P[0] - P[NV - 1];
                 const bool go_l = (dlt > T) || (P[NV - 1] < -T);
                 const bool go_r = (-dlt > T) && (P[NV - 1] > T) && (P[0] < t_b);  // q_l < 1: 1 - q_l stays positive
@@ -255,7 +281,7 @@ __device__ __forceinline__ float cosine_from_sums(float dot, float na, float nb)
 
 // COS: the two running sums are the dot products x.c_l, x.c_r (same order), the row's own squared norm is summed
 // once before the walk through the same lane chain
-template <int D, bool COS>
+template <int D, int MODE>
 __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__ X,
                                                        const float *__restrict__ centroids,
                                                        const float *__restrict__ cnorm,
@@ -269,6 +295,7 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
     // leaves a running sum that already holds a real term unchanged, so the reference's bits are kept)
     constexpr int NQ = (D >= 64) ? D / 64 : 1;  // chunks of 16 lanes x V floats
     constexpr int V = D / NQ / 16;              // 2 (D = 32) or 4
+    constexpr bool COS = MODE == kScrCos, MAN = MODE == kScrMan;
     const uint32_t count = *wl_count;
     const uint32_t lane = threadIdx.x & 63, j = lane & 15;
     const uint32_t slot = (blockIdx.x * 256 + threadIdx.x) >> 4;
@@ -330,6 +357,9 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
                     if (COS) {
                         s1[q][v] = x[q][v] * cl[v];
                         s2[q][v] = x[q][v] * cr[v];
+                    } else if (MAN) {
+                        s1[q][v] = fabsf(x[q][v] - cl[v]);
+                        s2[q][v] = fabsf(x[q][v] - cr[v]);
                     } else {
                         const float d1 = x[q][v] - cl[v], d2 = x[q][v] - cr[v];
                         s1[q][v] = d1 * d1;
@@ -385,12 +415,13 @@ __global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restri
                                                            const float *__restrict__ centroids,
                                                            const float *__restrict__ cnorm,
                                                            const int32_t *__restrict__ left,
-                                                           const int32_t *__restrict__ right, int euclid, int cosine,
+                                                           const int32_t *__restrict__ right, int euclid, int mode,
                                                            const int32_t *__restrict__ slot_node,
                                                            const uint2 *__restrict__ wl,
                                                            const uint32_t *__restrict__ wl_count,
                                                            int32_t *__restrict__ leaf_out) {
     const uint32_t count = *wl_count;
+    const bool cosine = mode == kScrCos, manh = mode == kScrMan;
     for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < count; e += gridDim.x * 256) {
         const uint2 ent = wl[e];
         const float *x = X + (size_t)ent.x * d;
@@ -415,6 +446,9 @@ __global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restri
                     if (cosine) {
                         s1 = v * cl[t];
                         s2 = v * cr[t];
+                    } else if (manh) {
+                        s1 = fabsf(v - cl[t]);
+                        s2 = fabsf(v - cr[t]);
                     } else {
                         const float d1 = v - cl[t], d2 = v - cr[t];
                         s1 = d1 * d1;
@@ -438,31 +472,31 @@ __global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restri
     }
 }
 
-template <int D, bool COS>
+template <int D, int MODE>
 static int launch_continue(const float *X, const float *centroids, const float *cnorm, const int32_t *left,
                            const int32_t *right, int euclid, const TsvqScreen &s, int32_t *leaf, hipStream_t stream,
                            uint32_t d_real) {
-    hipLaunchKernelGGL((k_tsvq_continue<D, COS>), dim3(1024), dim3(256), 0, stream, X, centroids, cnorm, left, right, euclid,
+    hipLaunchKernelGGL((k_tsvq_continue<D, MODE>), dim3(1024), dim3(256), 0, stream, X, centroids, cnorm, left, right, euclid,
                        s.slot_node, s.wl, s.wl_count, d_real, leaf);
     VQ_LAUNCH_CHECK("k_tsvq_continue");
     return VQHIP_OK;
 }
 
-template <int D, int LPR, bool COS>
+template <int D, int LPR, int MODE>
 int launch_screen(const float *X, uint64_t n, uint32_t d_real, const TsvqScreen &s, hipStream_t stream, int32_t *leaf) {
     constexpr int RPW = 64 / LPR;
     constexpr int WAVES = (D >= 512) ? 4 : (D >= 256) ? 8 : kWaves;  // 512 / 256 / 128 VGPRs per lane
-    const size_t lds_bytes = tsvq_screen_lds_bytes(s.n_int, COS ? 2 : 1, D);
+    const size_t lds_bytes = tsvq_screen_lds_bytes(s.n_int, MODE == kScrL2 ? 1 : 2, D);
     static PerDeviceOnce attr_set;
     if (attr_set.needed()) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR, WAVES, COS>),
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR, WAVES, MODE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set.done();
     }
     const uint64_t n_tiles = (n + RPW - 1) / RPW;
     uint64_t grid = (n_tiles + WAVES - 1) / WAVES;
     if (grid > (uint64_t)num_cus()) grid = (uint64_t)num_cus();
-    hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES, COS>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X,
+    hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES, MODE>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X,
                        n, d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count);
     VQ_LAUNCH_CHECK("k_tsvq_screen_descend");
     return VQHIP_OK;
@@ -485,10 +519,11 @@ uint32_t tsvq_screen_width(uint32_t d) {
 
 bool tsvq_screen_supported(uint32_t n_int, uint32_t n_nodes, uint32_t d, int metric) {
     (void)n_nodes;
-    if (metric != VQHIP_SQUARED_EUCLIDEAN && metric != VQHIP_EUCLIDEAN && metric != VQHIP_COSINE) return false;
+    if (metric != VQHIP_SQUARED_EUCLIDEAN && metric != VQHIP_EUCLIDEAN && metric != VQHIP_COSINE && metric != VQHIP_MANHATTAN)
+        return false;
     const uint32_t dp = tsvq_screen_width(d);
     if (dp == 0 || n_int == 0) return false;
-    return tsvq_screen_lds_bytes(n_int, metric == VQHIP_COSINE ? 2 : 1, dp) <= 160 * 1024;
+    return tsvq_screen_lds_bytes(n_int, (metric == VQHIP_COSINE || metric == VQHIP_MANHATTAN) ? 2 : 1, dp) <= 160 * 1024;
 }
 
 int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const float *cnorm,
@@ -498,18 +533,20 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
     if (n > 0xFFFFFFFFull) return fail(VQHIP_ERR_UNSUPPORTED, "screened TSVQ descent takes < 2^32 rows per call");
     VQ_HIP(hipMemsetAsync(s.wl_count, 0, 4, stream));
     const int euclid = metric == VQHIP_EUCLIDEAN ? 1 : 0;
-    const bool cosine = metric == VQHIP_COSINE;
+    const int mode = metric == VQHIP_COSINE ? kScrCos : metric == VQHIP_MANHATTAN ? kScrMan : kScrL2;
     const uint32_t dp = tsvq_screen_width(d);  // instantiated width serving d (d itself, or the next one up: zero padding)
+#define VQ_TSVQ_DM(DV, MV)                                                                         \
+    VQ_TRY((launch_screen<DV, 8, MV>(X, n, d, s, stream, leaf)));                                  \
+    if (DV >= 64 || d == DV)                                                                       \
+        VQ_TRY((launch_continue<DV, MV>(X, centroids, cnorm, left, right, euclid, s, leaf, stream, d)));
 #define VQ_TSVQ_D(DV)                                                                              \
     case DV:                                                                                       \
-        if (cosine) {                                                                              \
-            VQ_TRY((launch_screen<DV, 8, true>(X, n, d, s, stream, leaf)));                        \
-            if (DV >= 64 || d == DV)                                                               \
-                VQ_TRY((launch_continue<DV, true>(X, centroids, cnorm, left, right, euclid, s, leaf, stream, d))); \
+        if (mode == kScrCos) {                                                                     \
+            VQ_TSVQ_DM(DV, kScrCos)                                                                \
+        } else if (mode == kScrMan) {                                                              \
+            VQ_TSVQ_DM(DV, kScrMan)                                                                \
         } else {                                                                                   \
-            VQ_TRY((launch_screen<DV, 8, false>(X, n, d, s, stream, leaf)));                       \
-            if (DV >= 64 || d == DV)                                                               \
-                VQ_TRY((launch_continue<DV, false>(X, centroids, cnorm, left, right, euclid, s, leaf, stream, d))); \
+            VQ_TSVQ_DM(DV, kScrL2)                                                                 \
         }                                                                                          \
         break;
     switch (dp) {
@@ -518,9 +555,10 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
     default: return fail(VQHIP_ERR_UNSUPPORTED, "screened TSVQ descent: d=%u", d);
     }
 #undef VQ_TSVQ_D
+#undef VQ_TSVQ_DM
     if (d != dp && dp < 64) {  // d < 32 (8-byte pieces in k_tsvq_continue): the run-time-length kernel
         hipLaunchKernelGGL(k_tsvq_continue_any, dim3(256), dim3(256), 0, stream, X, d, centroids, cnorm, left, right, euclid,
-                           cosine ? 1 : 0, s.slot_node, s.wl, s.wl_count, leaf);
+                           mode, s.slot_node, s.wl, s.wl_count, leaf);
         VQ_LAUNCH_CHECK("k_tsvq_continue_any");
     }
     return VQHIP_OK;
