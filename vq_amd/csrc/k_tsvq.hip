@@ -25,6 +25,8 @@
 #include <hip/hip_fp16.h>
 
 #include <algorithm>
+#include <chrono>
+#include <utility>
 #include <vector>
 
 #include "kernels.hpp"
@@ -1667,6 +1669,23 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     // levels: the root is level 0; a tree over n rows is at most n - 1 levels deep whatever max_depth says
     const uint32_t n_levels = (uint32_t)std::min<uint64_t>((uint64_t)max_depth, (uint64_t)n - 1) + 1;
 
+    // VQHIP_TSVQ_TIMING=<ms>: host-side timeline of every build slower than <ms> (where did an outlier spend its time?)
+    static const char *timing_env = getenv("VQHIP_TSVQ_TIMING");
+    struct Marks {
+        double limit_ms = -1.0;
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        std::vector<std::pair<const char *, double>> v;
+        void mark(const char *what) {
+            if (limit_ms >= 0.0) v.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+        ~Marks() {
+            if (limit_ms < 0.0 || v.empty() || v.back().second < limit_ms) return;
+            fprintf(stderr, "[vqhip] tsvq build timeline (ms):");
+            for (auto &m : v) fprintf(stderr, " %s %.2f", m.first, m.second);
+            fprintf(stderr, "\n");
+        }
+    } marks;
+    marks.limit_ms = timing_env ? atof(timing_env) : -1.0;
     static thread_local TsvqBuildWs ws;
     {
         int dev = 0;
@@ -1783,6 +1802,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         VQ_HIP(hipMemcpyAsync(&lv[0].count, &one, 4, hipMemcpyHostToDevice, stream));
         VQ_HIP(hipStreamSynchronize(stream));  // stack sources; also the only synchronisation before the final download
     }
+    marks.mark("setup");
     int cur = 0;
     const uint32_t ncb = (d + kFsCols - 1) / kFsCols;
     uint32_t *lvl_split = ws.b_lvl.as<uint32_t>(), *remap = ws.b_remap.as<uint32_t>(), *slow_nodes = ws.b_lvl_slow.as<uint32_t>();
@@ -1846,6 +1866,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             LevelInfo h;
             VQ_HIP(hipMemcpyAsync(&h, &lv[L], sizeof(LevelInfo), hipMemcpyDeviceToHost, stream));
             VQ_HIP(hipStreamSynchronize(stream));
+            marks.mark("level-sync");
             if (h.count == 0) break;
             ub_nodes = h.count;
         }
@@ -1913,8 +1934,10 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
 
     // level table -> host: node count, error flags; then the nodes
     std::vector<LevelInfo> hlv(n_levels + 1);
+    marks.mark("launched");
     VQ_HIP(hipMemcpyAsync(hlv.data(), lv, (size_t)(n_levels + 1) * sizeof(LevelInfo), hipMemcpyDeviceToHost, stream));
     VQ_HIP(hipStreamSynchronize(stream));
+    marks.mark("kernels-done");
     uint32_t total = 0;
     for (uint32_t L = 0; L < n_levels; ++L) {
         if (hlv[L].error == 1)
@@ -1939,6 +1962,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     VQ_HIP(hipMemcpyAsync(hl.data(), node_left, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
     VQ_HIP(hipMemcpyAsync(hr.data(), node_right, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
     VQ_HIP(hipStreamSynchronize(stream));
+    marks.mark("downloaded");
     std::vector<int32_t> order;  // pre-order list of BFS ids
     order.reserve(total);
     std::vector<int32_t> stack = {0};
