@@ -986,7 +986,7 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
                                                       const double *__restrict__ tile_pref,
                                                       FsSumm *__restrict__ summ, float *__restrict__ side,
                                                       uint32_t side_cap, uint32_t *__restrict__ side_count,
-                                                      double2 *__restrict__ tile_mom) {
+                                                      double2 *__restrict__ tile_mom, float park_rel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fs_lds[];
     float(*lds_v)[kFsTile + 1] = reinterpret_cast<float(*)[kFsTile + 1]>(fs_lds);             // [32][513]
     FsSeg(*seg_acc)[kFsCols] = reinterpret_cast<FsSeg(*)[kFsCols]>(fs_lds + kFsCols * (kFsTile + 1) * 4);  // [8][32]
@@ -1216,7 +1216,15 @@ __global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ 
             const int32_t mag = (int32_t)((gb & 0x7FFFFFu) | 0x800000u);
             const long long Sg = (gb >> 31) ? -(long long)mag : (long long)mag;
             const long long lo2 = f.lo[0] < f.lo[1] ? f.lo[0] : f.lo[1], hi2 = f.hi[0] > f.hi[1] ? f.hi[0] : f.hi[1];
-            const long long margin = 1ll << 14;  // 0.2 % of the binade; the f64 guess is good to ~1e-5
+            // 0.2 % of the binade where the f64 guess is good to ~1e-5 (exact tile sums, the variance pass's moments).
+            // A guess from every r-th row is off by ~sigma sqrt(r N): three sigmas of that (park_rel = 3 sqrt(r / 512)
+            // sigma / mean for sigma / mean ~ 0.6, N = 512 (t + 1) rows so far) -- a tile whose guess is that close to
+            // a binade edge is likely to be re-added, and a parked tile is read back in one go instead of 512 gathers.
+            long long margin = 1ll << 14;
+            if (park_rel > 0.0f) {
+                const long long m2 = (long long)(park_rel * __builtin_amdgcn_rsqf((float)(tl.t + 1u)) * (float)(Sg < 0 ? -Sg : Sg));
+                margin = m2 > margin ? (m2 < (1ll << 22) ? m2 : (1ll << 22)) : margin;
+            }
             const bool leaves = (Sg > 0) ? (Sg + lo2 < (1ll << 23) + margin || Sg + hi2 > (1ll << 24) - margin)
                                          : (Sg + hi2 > -(1ll << 23) - margin || Sg + lo2 < -(1ll << 24) + margin);
             if ((anybad || leaves) && side_cap && c < d) {
@@ -1289,7 +1297,12 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                                                  const uint32_t *__restrict__ fast_nodes,
                                                  const uint32_t *__restrict__ tile_base, NodeArrays na,
                                                  const FsSumm *__restrict__ summ, const float *__restrict__ side,
-                                                 uint32_t *__restrict__ n_fallback, const LevelInfo *__restrict__ lv) {
+                                                 uint32_t *__restrict__ n_fallback, const LevelInfo *__restrict__ lv,
+                                                 uint32_t *__restrict__ dbg) {
+    // dbg (VQHIP_TSVQ_DEBUG): 8 counters of this (level, pass): chains, re-added tiles, most in one chain, and the
+    // first reason the re-added tile failed: unusable summary / other binade than guessed / prefix leaves the binade /
+    // running sum not a normal number
+    __shared__ __attribute__((aligned(16))) float stage[kFsTile];  // addends of the tile being re-added
     if (blockIdx.x >= lv->n_fast) return;
     const uint32_t node = fast_nodes[blockIdx.x], c = blockIdx.y, lane = threadIdx.x;
     const uint32_t a = na.seg_start[node], len = na.seg_len[node];
@@ -1298,13 +1311,42 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
     float s = (MODE == 0) ? 0.0f : -0.0f;
     uint32_t fallbacks = 0;
     uint32_t t0 = 0;  // first tile not yet applied
+    // Summaries of a batch sit 32 B x d apart (one cache line each): a restart behind a re-added tile would wait a
+    // full memory latency for them, and so would the re-addition for its 512 addends.  So the next batch (from the
+    // tile behind the failing one, or the following 64) is requested before the re-addition starts, a second batch is
+    // always in flight behind it, and the addends of the first tile the transducer PREDICTED to fail (it parked them,
+    // flag bits 1..) are requested at the start of the batch, next to the scan.
+    auto load_summ = [&](uint32_t tstart) {
+        FsSumm m;
+        m.flag = 1;
+        m.e = 0;
+        m.d0 = m.d1 = m.lo0 = m.lo1 = m.hi0 = m.hi1 = 0;
+        if (tstart + lane < nt) m = summ[(size_t)(base + tstart + lane) * d + c];
+        return m;
+    };
+    FsSumm cur = load_summ(0), spec = load_summ(64);
+    uint32_t spec_t = 64;
+    // dbg only: where the time of this chain goes (100 MHz ticks)
+    const uint64_t tk0 = dbg ? wall_clock64() : 0;
+    uint32_t tk_batch = 0, tk_wait_s = 0, tk_redo = 0, tk_wait_v = 0, n_batch = 0;
     while (t0 < nt) {
         const uint32_t cnt = min(64u, nt - t0);
-        FsSumm mine;
-        mine.flag = 1;
-        mine.e = 0;
-        mine.d0 = mine.d1 = mine.lo0 = mine.lo1 = mine.hi0 = mine.hi1 = 0;
-        if (lane < cnt) mine = summ[(size_t)(base + t0 + lane) * d + c];
+        const uint64_t tka = dbg ? wall_clock64() : 0;
+        const FsSumm mine = cur;
+        if (dbg) {
+            __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the summaries are here
+            tk_wait_s += (uint32_t)(wall_clock64() - tka);
+            ++n_batch;
+        }
+        const int myslot = (mine.flag >> 1) - 1;  // lanes past the node's tiles carry flag 1: no slot
+        const uint64_t pmask = __ballot(myslot >= 0);
+        const int pf = pmask ? (int)__builtin_ctzll(pmask) : -1;
+        float vp[8];
+        if (pf >= 0) {
+            const float *src = side + (size_t)__shfl(myslot, pf) * kFsTile;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vp[i] = src[i * 64 + lane];
+        }
         const uint32_t sb = __float_as_uint(s), se = (sb >> 23) & 0xFFu;
         const bool s_normal = (se != 0u) && (se != 255u);
         const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
@@ -1314,17 +1356,26 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
         incl.d[0] = mine.d0, incl.d[1] = mine.d1;
         incl.lo[0] = mine.lo0, incl.lo[1] = mine.lo1;
         incl.hi[0] = mine.hi0, incl.hi[1] = mine.hi1;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            FsPair prev;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                prev.d[p] = __shfl_up(incl.d[p], off);
-                prev.lo[p] = __shfl_up(incl.lo[p], off);
-                prev.hi[p] = __shfl_up(incl.hi[p], off);
-            }
-            if ((int)lane >= off) incl = fs_compose(prev, incl);
+        // in-row steps by DPP row_shr (lane i <- lane i - off of its 16-lane row), then the totals of rows 0 / 2 into
+        // rows 1 / 3 (row_bcast:15) and of lane 31 into rows 2 and 3 (row_bcast:31): six steps, no LDS round trips
+        // (ds_bpermute shuffles made a batch cost 1.15 us)
+#define VQ_FS_STEP(CTRL, COND)                                                                   \
+        {                                                                                        \
+            FsPair prev;                                                                         \
+            _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                      \
+                prev.d[p] = __builtin_amdgcn_update_dpp(0, incl.d[p], CTRL, 0xF, 0xF, true);     \
+                prev.lo[p] = __builtin_amdgcn_update_dpp(0, incl.lo[p], CTRL, 0xF, 0xF, true);   \
+                prev.hi[p] = __builtin_amdgcn_update_dpp(0, incl.hi[p], CTRL, 0xF, 0xF, true);   \
+            }                                                                                    \
+            if (COND) incl = fs_compose(prev, incl);                                             \
         }
+        VQ_FS_STEP(0x111, (lane & 15u) >= 1u)   // row_shr:1
+        VQ_FS_STEP(0x112, (lane & 15u) >= 2u)   // row_shr:2
+        VQ_FS_STEP(0x114, (lane & 15u) >= 4u)   // row_shr:4
+        VQ_FS_STEP(0x118, (lane & 15u) >= 8u)   // row_shr:8
+        VQ_FS_STEP(0x142, (lane & 16u) != 0u)   // row_bcast:15 -> rows 1 and 3
+        VQ_FS_STEP(0x143, lane >= 32u)          // row_bcast:31 -> rows 2 and 3
+#undef VQ_FS_STEP
         // delta from the batch start to the start of my tile, for the actual parity of S
         const int odd = S & 1;
         int32_t before = __shfl_up(incl.d[odd], 1);
@@ -1347,13 +1398,31 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
             s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2 & 0x7FFFFFu));
             t0 += good;
         }
-        if (good < cnt) {  // re-add tile t0 (the first that failed) in the reference's order
+        const bool redo = good < cnt;  // tile t0 (the first that failed) is re-added in the reference's order
+        const int32_t flag = __shfl(mine.flag, (int)(redo ? good : 0u));
+        const int32_t fe = __shfl(mine.e, (int)(redo ? good : 0u));
+        {   // the batches behind this one
+            const uint32_t nt0 = t0 + (redo ? 1u : 0u);
+            if (nt0 == spec_t) cur = spec;
+            else cur = load_summ(nt0);
+            spec_t = nt0 + 64;
+            spec = load_summ(spec_t);
+        }
+        if (dbg) tk_batch += (uint32_t)(wall_clock64() - tka);
+        const uint64_t tkr = dbg ? wall_clock64() : 0;
+        if (redo) {
             ++fallbacks;
-            const int32_t flag = __shfl(mine.flag, (int)good);
+            if (dbg && lane == 0) {
+                const int why = !s_normal ? 6 : (flag & 1) ? 3 : ((int)se - 127 != fe) ? 4 : 5;
+                atomicAdd(dbg + why, 1u);
+            }
             const uint32_t r0 = t0 * kFsTile;
             float v[8];
             const int slot = (flag >> 1) - 1;
-            if (slot >= 0) {  // parked by k_fs_transduce: contiguous
+            if ((int)good == pf) {  // the predicted tile: already here
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = vp[i];
+            } else if (slot >= 0) {  // parked by k_fs_transduce: contiguous
                 const float *src = side + (size_t)slot * kFsTile;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = src[i * 64 + lane];
@@ -1364,28 +1433,63 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                     v[i] = (r < len) ? fs_value<MODE>(X[(size_t)perm[a + r] * d + c], mu) : 0.0f;
                 }
             }
+            // The 512 additions in row order.  Through v_readlane each addend went VGPR -> SGPR -> v_add with the
+            // hazard wait in between: 29 cycles per addition, 7 us per tile (measured).  Staged in LDS instead, every
+            // lane reads the same four addends per ds_read_b128 (a broadcast) and carries the same running sum: the
+            // chain runs at the add's own latency (~10 cycles), the next 16 addends are read while these are added.
+            // Rows past the node's end are +0.0 (the sum is never -0.0 once a real row is in: no bit changes).
+            __syncthreads();  // one wave per block: orders the previous tile's reads before these writes
+            const uint32_t rows_here = min((uint32_t)kFsTile, len - r0);
+            if (dbg) {
+                __builtin_amdgcn_s_waitcnt(0);
+                tk_wait_v += (uint32_t)(wall_clock64() - tkr);
+            }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t first = r0 + (uint32_t)i * 64;
-                if (first >= len) break;
-                const uint32_t m = min(64u, len - first);
-                if (m == 64u) {
-                    // constant lane numbers: two instructions per add, the chain runs at the add's own latency (the
-                    // counted loop spent ~45 cycles per add on its compare-and-branch)
+            for (int i = 0; i < 8; ++i) stage[i * 64 + lane] = ((uint32_t)i * 64 + lane < rows_here) ? v[i] : 0.0f;  // a parked tile holds its real rows only
+            __syncthreads();
+            float4 qa[4], qb[4];
 #pragma unroll
-                    for (int l = 0; l < 64; ++l) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i]), l));
-                } else {
-                    for (uint32_t l = 0; l < m; ++l)
-                        s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i]), (int)l));
+            for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const float4 *>(stage + 4 * u);
+            for (uint32_t r = 0; r < rows_here; r += 32) {  // whole groups of 16: the tail adds zeros
+#pragma unroll
+                for (int u = 0; u < 4; ++u) qb[u] = *reinterpret_cast<const float4 *>(stage + ((r + 16 + 4 * u) & (kFsTile - 1)));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s = s + qa[u].x;
+                    s = s + qa[u].y;
+                    s = s + qa[u].z;
+                    s = s + qa[u].w;
+                }
+                if (r + 16 >= rows_here) break;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const float4 *>(stage + ((r + 32 + 4 * u) & (kFsTile - 1)));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s = s + qb[u].x;
+                    s = s + qb[u].y;
+                    s = s + qb[u].z;
+                    s = s + qb[u].w;
                 }
             }
             t0 += 1;
+            if (dbg) tk_redo += (uint32_t)(wall_clock64() - tkr);
+        }
+    }
+    if (dbg && lane == 0) {
+        const uint32_t tot = (uint32_t)(wall_clock64() - tk0);
+        if (atomicMax(dbg + 8, tot) < tot) {  // (racy between chains of similar length: diagnostic only)
+            dbg[9] = n_batch, dbg[10] = tk_batch, dbg[11] = tk_wait_s, dbg[12] = fallbacks, dbg[13] = tk_redo, dbg[14] = tk_wait_v;
         }
     }
     if (lane == 0) {
         if (MODE == 0) na.centroid[(size_t)node * d + c] = s / (float)len;  // T::from_usize(n)
         else na.var[(size_t)node * d + c] = s;
         if (n_fallback && fallbacks) atomicAdd(n_fallback, fallbacks);
+        if (dbg) {
+            atomicAdd(dbg + 0, 1u);
+            atomicAdd(dbg + 1, fallbacks);
+            atomicMax(dbg + 2, fallbacks);
+        }
     }
 }
 
@@ -1736,7 +1840,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     VQ_TRY(ws.b_cent.ensure((size_t)dcap * d * 4));
     VQ_TRY(ws.b_var.ensure((size_t)dcap * d * 4));
     VQ_TRY(ws.b_lv.ensure((size_t)(n_levels + 1) * sizeof(LevelInfo)));
-    VQ_TRY(ws.b_fs_fb.ensure(8));  // [0] tile re-additions (diagnostic), [1] side-buffer slots handed out
+    VQ_TRY(ws.b_fs_fb.ensure(8 + 64 * 2 * 64));  // [0] tile re-additions (diagnostic), [1] side-buffer slots handed out, [2..] VQHIP_TSVQ_DEBUG counters: 8 per (level < 64, pass)
     NodeArrays na;
     na.seg_start = ws.b_seg_start.as<uint32_t>();
     na.seg_len = ws.b_seg_len.as<uint32_t>();
@@ -1758,6 +1862,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     const bool can_fast = (d % 4 == 0) && !(seq_env && seq_env[0] == '1');  // 16-byte row parts
     static const char *samp_env = getenv("VQHIP_TSVQ_SAMPLE");  // rows read for the mean pass's binade guess: 1/N (default 1/8)
     const uint32_t fs_sample = samp_env ? (uint32_t)std::max(1, std::min(16, atoi(samp_env))) : 8u;
+    const float park_rel = fs_sample > 1 ? 3.0f * 0.6f * sqrtf((float)fs_sample / (float)kFsTile) : 0.0f;  // k_fs_transduce: parking margin
     const size_t fs_lds_bytes = (size_t)kFsCols * (kFsTile + 1) * 4 + 8 * kFsCols * sizeof(FsSeg);
     if (can_fast) {
         VQ_TRY(ws.b_fs_tiles.ensure((size_t)tiles_max * sizeof(FsTile)));
@@ -1793,7 +1898,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     VQ_HIP(hipMemsetAsync(ws.b_lv.p, 0, (size_t)(n_levels + 1) * sizeof(LevelInfo), stream));
     VQ_HIP(hipMemsetAsync(ws.b_left.p, 0xFF, (size_t)dcap * 4, stream));
     VQ_HIP(hipMemsetAsync(ws.b_right.p, 0xFF, (size_t)dcap * 4, stream));
-    VQ_HIP(hipMemsetAsync(ws.b_fs_fb.p, 0, 8, stream));
+    VQ_HIP(hipMemsetAsync(ws.b_fs_fb.p, 0, 8 + 64 * 2 * 64, stream));
     {
         const uint32_t root[2] = {0u, n};  // seg_start[0], seg_len[0]; lv[0] = {first 0, count 1}
         const uint32_t one = 1u;
@@ -1816,7 +1921,10 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
 
     // sequential-order column sums of the level's nodes: long nodes through the tile-parallel exact emulation (k_fs_*),
     // the rest through the plain chain kernel.  Grids are upper bounds; the kernels read the level's counts.
+    static const bool fs_debug = getenv("VQHIP_TSVQ_DEBUG") != nullptr;
     auto colsum = [&](int mode, const LevelInfo *lvp, uint32_t ub_nodes, const uint32_t *perm) -> int {
+        const uint32_t lvl_idx = (uint32_t)(lvp - lv);
+        uint32_t *dbg = (fs_debug && lvl_idx < 64) ? fbk + 2 + (lvl_idx * 2 + (uint32_t)mode) * 16 : nullptr;
         const uint32_t ub_fast = have_fast ? std::min(ub_nodes, fast_max) : 0u;
         // few nodes: 16 columns per workgroup (more chains in flight); many: 32 (fewer, fuller workgroups)
         const uint32_t g16 = (d + 15) / 16, g32 = (d + 31) / 32;
@@ -1839,14 +1947,14 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         if (mode == 0) {
             hipLaunchKernelGGL(k_fs_tile_sums<0>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts, fs_sample, lvp);
             hipLaunchKernelGGL(k_fs_prefix, pgrid, dim3(1024), 0, stream, d, fb, fc, ts, lvp);
-            hipLaunchKernelGGL(k_fs_transduce<0>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, lvp, na, ts, sm, side, side_cap, fbk + 1, mom);
-            hipLaunchKernelGGL(k_fs_chain<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp);
+            hipLaunchKernelGGL(k_fs_transduce<0>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, lvp, na, ts, sm, side, side_cap, fbk + 1, mom, park_rel);
+            hipLaunchKernelGGL(k_fs_chain<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
         } else {
             // the guess comes from the moments the mean pass of the same level left behind (same tile table: every node
             // long enough for the emulation has more than one row, so it is a split node whenever the level splits)
             hipLaunchKernelGGL(k_fs_prefix_var, pgrid, dim3(1024), 0, stream, X, d, perm, fn, fb, fc, na, mom, ts, lvp);
-            hipLaunchKernelGGL(k_fs_transduce<1>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, lvp, na, ts, sm, side, side_cap, fbk + 1, (double2 *)nullptr);
-            hipLaunchKernelGGL(k_fs_chain<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp);
+            hipLaunchKernelGGL(k_fs_transduce<1>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, lvp, na, ts, sm, side, side_cap, fbk + 1, (double2 *)nullptr, 0.0f);
+            hipLaunchKernelGGL(k_fs_chain<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
         }
         VQ_LAUNCH_CHECK("k_fs_*");
         if (getenv("VQHIP_TSVQ_CHECK")) {
@@ -1950,10 +2058,20 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     (void)levels_run;
     if (total == 0 || total > dcap) return fail(VQHIP_ERR_FAILURE, "TSVQ build produced %u nodes (bound %u)", total, dcap);
     if (getenv("VQHIP_TSVQ_DEBUG")) {
-        uint32_t fbn = 0;
-        VQ_HIP(hipMemcpyAsync(&fbn, fbk, 4, hipMemcpyDeviceToHost, stream));
+        uint32_t fbn[2 + 64 * 2 * 16];
+        VQ_HIP(hipMemcpyAsync(fbn, fbk, sizeof(fbn), hipMemcpyDeviceToHost, stream));
         VQ_HIP(hipStreamSynchronize(stream));
-        fprintf(stderr, "[vqhip] tsvq build: %u tile re-additions in the exact column sums\n", fbn);
+        fprintf(stderr, "[vqhip] tsvq build: %u tile re-additions in the exact column sums\n", fbn[0]);
+        for (uint32_t q = 0; q < 128; ++q) {
+            const uint32_t *c8 = fbn + 2 + q * 16;
+            if (c8[0])
+                fprintf(stderr, "[vqhip]   level %u %s: %u chains, %u tiles re-added (most in one chain %u): unusable summary %u, "
+                                "other binade than guessed %u, prefix leaves the binade %u, sum not normal %u\n",
+                        q / 2, (q & 1) ? "variance" : "mean", c8[0], c8[1], c8[2], c8[3], c8[4], c8[5], c8[6]);
+            if (c8[0])  // the slowest chain of the pass, 10 ns ticks of the 100 MHz clock
+                fprintf(stderr, "[vqhip]     slowest chain: %.1f us = %u batches %.1f us (waiting for summaries %.1f) + %u re-additions %.1f us (waiting for addends %.1f)\n",
+                        c8[8] * 0.01, c8[9], c8[10] * 0.01, c8[11] * 0.01, c8[12], c8[13] * 0.01, c8[14] * 0.01);
+        }
     }
     // nodes -> host, then BFS -> pre-order (the oracle's numbering)
     std::vector<float> cent((size_t)total * d);
