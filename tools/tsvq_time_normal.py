@@ -7,7 +7,7 @@ from vq_amd.tsvq import build_tree
 _lib.load(); _lib.set_device(0)
 n, d, depth = 1_000_000, 128, 8
 rng = np.random.default_rng(5)
-for kind in ("normal", "uniform-0.5", "uniform"):
+for kind in (sys.argv[1:] or ["normal", "uniform-0.5", "uniform"]):
     X = rng.standard_normal((n, d), dtype=np.float32) if kind == "normal" else rng.random((n, d), dtype=np.float32) - (np.float32(0.5) if kind == "uniform-0.5" else np.float32(0))
     ds = _lib.Dataset.from_host(X)
     ts = []
