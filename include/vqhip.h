@@ -56,6 +56,13 @@ extern "C" {
 #define VQHIP_EUCLIDEAN 1
 #define VQHIP_MANHATTAN 2
 #define VQHIP_COSINE 3
+/* Opt-in, UNPINNED: the cosine distance of the reference's `simd` build (which pyvq always uses,
+ * pyvq/Cargo.toml:13): `1.0 - hsd_sim_cosine_f32(a, b)` with no EPSILON rule and no clamp
+ * (src/core/distance.rs:97-105).  hsdlib's source is not part of the reference tree, so its summation order is
+ * unknown; this id keeps the scalar path's three sequential sums and changes only what is visible in the Rust
+ * source: d = 1 - dot / (|a| |b|), which may exceed 1, dip below 0 by rounding, and is NaN / inf for a zero norm
+ * (a NaN distance never wins the argmin, as in the reference's `<` scan).  Exact engines only (no screen). */
+#define VQHIP_COSINE_UNCLAMPED 4
 
 /* assignment engines (results are bit-identical; this is a speed/diagnostic knob) */
 #define VQHIP_ENGINE_AUTO 0  /* fastest available: bf16-split MFMA screen, fp32 MFMA screen, exact */

@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-SQUARED_EUCLIDEAN, EUCLIDEAN, MANHATTAN, COSINE = 0, 1, 2, 3
+SQUARED_EUCLIDEAN, EUCLIDEAN, MANHATTAN, COSINE, COSINE_UNCLAMPED = 0, 1, 2, 3, 4
 METRIC_IDS = {
     "squared_euclidean": SQUARED_EUCLIDEAN,
     "euclidean": EUCLIDEAN,

@@ -109,6 +109,27 @@ static float cosine_distance(const float *a, const float *b, size_t n) {
     return v;
 }
 
+/* the reference's `simd` build: `1.0 - similarity` with no EPSILON rule and no clamp (src/core/distance.rs:97-105).
+ * hsdlib's summation order is not in the reference tree: the three sums stay the scalar path's.  UNPINNED. */
+static float cosine_distance_unclamped(const float *a, const float *b, size_t n) {
+    float dot = -0.0f, sa = -0.0f, sb = -0.0f;
+    for (size_t i = 0; i < n; ++i) {
+        float p = a[i] * b[i];
+        dot = dot + p;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        float p = a[i] * a[i];
+        sa = sa + p;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        float p = b[i] * b[i];
+        sb = sb + p;
+    }
+    float denom = sqrtf(sa) * sqrtf(sb);
+    float q = dot / denom;
+    return 1.0f - q;
+}
+
 /* src/core/distance.rs:48-64 (length check is the caller's job here) */
 float vqo_distance(int metric, const float *a, const float *b, size_t n) {
     switch (metric) {
@@ -116,6 +137,7 @@ float vqo_distance(int metric, const float *a, const float *b, size_t n) {
     case VQO_EUCLIDEAN: return sqrtf(squared_euclidean(a, b, n)); /* distance.rs:58 */
     case VQO_MANHATTAN: return manhattan(a, b, n);
     case VQO_COSINE: return cosine_distance(a, b, n);
+    case VQO_COSINE_UNCLAMPED: return cosine_distance_unclamped(a, b, n);
     default: return NAN;
     }
 }
@@ -575,7 +597,7 @@ static int adc_cmp(const void *pa, const void *pb) {
 static int adc_search_impl(int metric, const float *codebooks, size_t m, size_t k, size_t sd,
                            const uint8_t *codes8, const uint16_t *codes16, size_t n, const float *queries, size_t nq, size_t topk,
                    uint32_t *idx_out, float *dist_out) {
-    if (metric == VQO_COSINE || topk == 0 || topk > n || m == 0 || k == 0 || (codes8 && k > 256) || k > 65536)
+    if (metric == VQO_COSINE || metric == VQO_COSINE_UNCLAMPED || topk == 0 || topk > n || m == 0 || k == 0 || (codes8 && k > 256) || k > 65536)
         return VQO_ERR_INVALID_PARAMETER;
     float *lut = (float *)malloc(m * k * sizeof(float));
     adc_pair *all = (adc_pair *)malloc(n * sizeof(adc_pair));

@@ -37,7 +37,8 @@ enum {
     VQO_SQUARED_EUCLIDEAN = 0,
     VQO_EUCLIDEAN = 1,
     VQO_MANHATTAN = 2,
-    VQO_COSINE = 3
+    VQO_COSINE = 3,
+    VQO_COSINE_UNCLAMPED = 4 /* opt-in, unpinned: the `simd` build's 1 - similarity (no EPSILON rule, no clamp) */
 };
 
 /* Status codes.  0 ok; the others mirror VqError variants (src/core/error.rs:4-28). */

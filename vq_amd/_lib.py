@@ -20,7 +20,7 @@ OK = 0
 ERR_NULL_PTR, ERR_INVALID_INPUT, ERR_NO_DEVICE, ERR_RUNTIME, ERR_UNSUPPORTED, ERR_FAILURE = (
     -1, -3, -4, -5, -6, -99)
 
-SQUARED_EUCLIDEAN, EUCLIDEAN, MANHATTAN, COSINE = 0, 1, 2, 3
+SQUARED_EUCLIDEAN, EUCLIDEAN, MANHATTAN, COSINE, COSINE_UNCLAMPED = 0, 1, 2, 3, 4
 ENGINE_AUTO, ENGINE_EXACT, ENGINE_MFMA, ENGINE_MFMA_BF16 = 0, 1, 2, 3
 
 _u8p = C.POINTER(C.c_uint8)

@@ -1468,7 +1468,7 @@ int vqhip_pq_encoder_create(const float *codebooks, uint32_t m, uint32_t k, uint
     if (!codebooks) return fail(VQHIP_ERR_NULL_PTR, "codebooks is NULL");
     if (m == 0 || k == 0 || sub_dim == 0) return fail(VQHIP_ERR_INVALID_INPUT, "m, k and sub_dim must be positive");
     if (k > kMaxCentroids) return fail(VQHIP_ERR_UNSUPPORTED, "k=%u > 65536: codes are at most two bytes per subspace", k);
-    if (metric < VQHIP_SQUARED_EUCLIDEAN || metric > VQHIP_COSINE) return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", metric);
+    if (metric < VQHIP_SQUARED_EUCLIDEAN || metric > VQHIP_COSINE_UNCLAMPED) return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", metric);
     VQ_TRY(require_gfx950());
     hipStream_t s;
     VQ_TRY(current_stream(&s));
@@ -1662,7 +1662,7 @@ int vqhip_distance_batch(int metric, const float *a, const float *b, uint64_t n,
     VQ_API_BEGIN
     if (n == 0) return VQHIP_OK;
     if (!a || !b || !out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
-    if (metric < VQHIP_SQUARED_EUCLIDEAN || metric > VQHIP_COSINE) return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", metric);
+    if (metric < VQHIP_SQUARED_EUCLIDEAN || metric > VQHIP_COSINE_UNCLAMPED) return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", metric);
     VQ_TRY(require_gfx950());
     hipStream_t s;
     VQ_TRY(current_stream(&s));
@@ -1698,7 +1698,7 @@ int vqhip_tsvq_create(const float *centroids, const int32_t *left, const int32_t
     *out = nullptr;
     if (!centroids || !left || !right) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     if (n_nodes == 0 || d == 0) return fail(VQHIP_ERR_INVALID_INPUT, "empty tree");
-    if (metric < VQHIP_SQUARED_EUCLIDEAN || metric > VQHIP_COSINE) return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", metric);
+    if (metric < VQHIP_SQUARED_EUCLIDEAN || metric > VQHIP_COSINE_UNCLAMPED) return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", metric);
     {
         // the arrays must describe ONE tree rooted at node 0: children point forward (pre-order, so the
         // descent terminates), a node's two children differ, no node has two parents and every node but

@@ -110,4 +110,22 @@ struct DevBuf {
 
 static inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// both cosine ids share every sum; they differ in the last step only
+__host__ __device__ constexpr bool vq_is_cos(int metric) { return metric == VQHIP_COSINE || metric == VQHIP_COSINE_UNCLAMPED; }
+// dot, |a|, |b| (the reference's three sequential sums, norms already square-rooted) -> distance.
+// VQHIP_COSINE: src/core/distance.rs:107-119 (EPSILON rule, f32::clamp keeps NaN); VQHIP_COSINE_UNCLAMPED: include/vqhip.h
+__host__ __device__ inline float vq_cosine_finish(int metric, float dot, float na, float nb) {
+    if (metric == VQHIP_COSINE_UNCLAMPED) {
+        const float denom = na * nb;
+        const float q = dot / denom;
+        return 1.0f - q;
+    }
+    const float EPS = 1e-10f;
+    if (na < EPS || nb < EPS) return 1.0f;
+    const float denom = na * nb;
+    const float q = dot / denom;  // correctly rounded
+    const float v = 1.0f - q;
+    return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+}
+
 }  // namespace vqhip

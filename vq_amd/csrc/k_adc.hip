@@ -309,7 +309,7 @@ int launch_adc_search(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int 
                       const float *queries_dev, uint32_t nq, uint32_t topk, float *lut_ws, float *dist_ws,
                       void *state_ws, unsigned long long *cand_ws, uint32_t *idx_out_dev, float *dist_out_dev,
                       hipStream_t stream) {
-    if (metric == VQHIP_COSINE)
+    if (vq_is_cos(metric))
         return fail(VQHIP_ERR_UNSUPPORTED, "cosine distance is not a sum over subspaces: no ADC form");
     if (topk == 0 || topk > 1024 || topk > n) return fail(VQHIP_ERR_INVALID_INPUT, "topk must be in [1, min(n, 1024)]");
     // queries per scan pass: as many tables as the LDS holds, at most kAdcQB

@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t scan_one(const float *__restrict__ xrow, uin
         for (int t = 0; t < SD; ++t) x[t] = xrow[t];
     }
     float na = 0.0f;
-    if constexpr (METRIC == VQHIP_COSINE) {
+    if constexpr (vq_is_cos(METRIC)) {
         float sa = -0.0f;  // `.sum()` folds from -0.0 (Rust 1.85); invisible after sqrt/compare
         if constexpr (GENERIC) {
             for (uint32_t t = 0; t < sd; ++t) {
@@ -104,15 +104,7 @@ __device__ __forceinline__ uint32_t scan_one(const float *__restrict__ xrow, uin
                 }
             }
             const float nb = cnsq[j];  // sqrt(sum c^2): depends on c only, hoisted
-            const float EPS = 1e-10f;
-            if (na < EPS || nb < EPS) {
-                dist = 1.0f;
-            } else {
-                float denom = na * nb;
-                float q = dot / denom;  // correctly rounded
-                float v = 1.0f - q;
-                dist = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);  // f32::clamp keeps NaN
-            }
+            dist = vq_cosine_finish(METRIC, dot, na, nb);
         }
         if (j == 0) {
             best_dist = dist;
@@ -169,7 +161,7 @@ __global__ __launch_bounds__(256) void k_assign_exact_tiled(
     const uint64_t row0 = (uint64_t)blockIdx.x * TR;
     const float *cbs = cb + (size_t)s * k * sd;
     const float *cnsq = cnsqrt ? cnsqrt + (size_t)s * k : nullptr;
-    const float init = (METRIC == VQHIP_COSINE) ? -0.0f : 0.0f;  // `.sum()` folds from -0.0, the L2 / L1 loops from 0.0
+    const float init = (vq_is_cos(METRIC)) ? -0.0f : 0.0f;  // `.sum()` folds from -0.0, the L2 / L1 loops from 0.0
     float sa = -0.0f, na = 0.0f;  // cosine: |x|^2 chain of this lane's row (wave 0 only)
     uint32_t best = 0;
     float best_dist = 0.0f;
@@ -189,7 +181,7 @@ __global__ __launch_bounds__(256) void k_assign_exact_tiled(
             float xr[TC];
 #pragma unroll
             for (uint32_t t = 0; t < TC; ++t) xr[t] = xs[t][r];
-            if (METRIC == VQHIP_COSINE && kg0 == 0 && q == 0) {
+            if (vq_is_cos(METRIC) && kg0 == 0 && q == 0) {
 #pragma unroll
                 for (uint32_t t = 0; t < TC; ++t)
                     if (t < tc) {
@@ -243,12 +235,12 @@ __global__ __launch_bounds__(256) void k_assign_exact_tiled(
             }
 #undef VQ_TC
         }
-        if (METRIC == VQHIP_COSINE && kg0 == 0 && q == 0) na_s[r] = sqrtf(sa);  // |x|, shared with the other waves
+        if (vq_is_cos(METRIC) && kg0 == 0 && q == 0) na_s[r] = sqrtf(sa);  // |x|, shared with the other waves
         __syncthreads();
-        if constexpr (METRIC == VQHIP_EUCLIDEAN || METRIC == VQHIP_COSINE) {
+        if constexpr (METRIC == VQHIP_EUCLIDEAN || vq_is_cos(METRIC)) {
             // accumulators -> distances, every wave its own centroids (the division and the square root are the
             // expensive part of a short sub-vector's scan; one wave doing all of them serialised the workgroup)
-            if (METRIC == VQHIP_COSINE) na = na_s[r];
+            if (vq_is_cos(METRIC)) na = na_s[r];
             for (uint32_t jj = q; jj < kn; jj += 4) {
                 const float a = acc[jj][r];
                 float dist;
@@ -256,15 +248,7 @@ __global__ __launch_bounds__(256) void k_assign_exact_tiled(
                     dist = sqrtf(a);
                 } else {  // src/core/distance.rs:107-119
                     const float nb = cnsq[kg0 + jj];
-                    const float EPS = 1e-10f;
-                    if (na < EPS || nb < EPS) {
-                        dist = 1.0f;
-                    } else {
-                        const float denom = na * nb;
-                        const float qq = a / denom;
-                        const float v = 1.0f - qq;
-                        dist = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                    }
+                    dist = vq_cosine_finish(METRIC, a, na, nb);
                 }
                 acc[jj][r] = dist;
             }
@@ -315,12 +299,7 @@ __device__ __forceinline__ float exact_dist_fixed(const float (&x)[SD], const fl
             float p = x[t] * c[t];
             dot = dot + p;
         }
-        const float EPS = 1e-10f;
-        if (na < EPS || nb < EPS) return 1.0f;
-        float denom = na * nb;
-        float q = dot / denom;
-        float v = 1.0f - q;
-        return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        return vq_cosine_finish(METRIC, dot, na, nb);
     }
 }
 
@@ -364,7 +343,7 @@ __global__ __launch_bounds__(1024) void k_recheck_wave(
 #pragma unroll
         for (int t = 0; t < SD; ++t) x[t] = xrow[t];
         float na = 0.0f;
-        if constexpr (METRIC == VQHIP_COSINE) {
+        if constexpr (vq_is_cos(METRIC)) {
             float sa = -0.0f;
 #pragma unroll
             for (int t = 0; t < SD; ++t) {
@@ -378,7 +357,7 @@ __global__ __launch_bounds__(1024) void k_recheck_wave(
         bool d0_nan = false;
         for (uint32_t j = lane; j < k; j += 64) {
             const float dist = exact_dist_fixed<METRIC, SD>(x, cbs + (size_t)j * SD, na,
-                                                            METRIC == VQHIP_COSINE ? cnsq[j] : 0.0f);
+                                                            vq_is_cos(METRIC) ? cnsq[j] : 0.0f);
             const bool isnan_d = dist != dist;
             if (j == 0) d0_nan = isnan_d;
             if (!isnan_d && (bj == NONE || dist < bd)) {
@@ -475,7 +454,7 @@ __global__ __launch_bounds__(256) void k_recheck_resident(
                 }
             }
         }
-        cn[i] = (METRIC == VQHIP_COSINE) ? cnsqrt[(size_t)s * k + (j < k ? j : 0u)] : 0.0f;
+        cn[i] = (vq_is_cos(METRIC)) ? cnsqrt[(size_t)s * k + (j < k ? j : 0u)] : 0.0f;
     }
     const uint32_t *rows_s = wl_rows + (size_t)s * wl_stride;
     for (uint32_t unit = wave; unit < n_seg * parts; unit += n_waves) {
@@ -506,7 +485,7 @@ __global__ __launch_bounds__(256) void k_recheck_resident(
                 for (int t = 0; t < SD; ++t) x[t] = xn[t];
                 if (e + 1 < nb) fetch(e + 1, xn);  // the next entry's row, in flight during this one's arithmetic
                 float na = 0.0f;
-                if constexpr (METRIC == VQHIP_COSINE) {
+                if constexpr (vq_is_cos(METRIC)) {
                     float sa = -0.0f;
 #pragma unroll
                     for (int t = 0; t < SD; ++t) {
@@ -592,7 +571,7 @@ __global__ __launch_bounds__(1024) void k_recheck_tiled(
                 *reinterpret_cast<float4 *>(&ct[r][4 * q]) = v;
             }
             __syncthreads();
-            if (METRIC == VQHIP_COSINE && j0 == 0) {
+            if (vq_is_cos(METRIC) && j0 == 0) {
                 float sa = -0.0f;
                 for (uint32_t t = 0; t < SD; ++t) {
                     const float p = xs[wave][t] * xs[wave][t];
@@ -601,7 +580,7 @@ __global__ __launch_bounds__(1024) void k_recheck_tiled(
                 na = sqrtf(sa);
             }
             const uint32_t j = j0 + lane;
-            float acc = (METRIC == VQHIP_COSINE) ? -0.0f : 0.0f;
+            float acc = (vq_is_cos(METRIC)) ? -0.0f : 0.0f;
 #pragma unroll 4
             for (uint32_t t4 = 0; t4 < SD / 4; ++t4) {
                 const float4 xv = *reinterpret_cast<const float4 *>(&xs[wave][4 * t4]);
@@ -624,17 +603,9 @@ __global__ __launch_bounds__(1024) void k_recheck_tiled(
             }
             float dist = acc;
             if (METRIC == VQHIP_EUCLIDEAN) dist = sqrtf(acc);
-            if (METRIC == VQHIP_COSINE) {
+            if (vq_is_cos(METRIC)) {
                 const float nb = (j < k) ? cnsqrt[(size_t)s * k + j] : 1.0f;
-                const float EPS = 1e-10f;
-                if (na < EPS || nb < EPS) {
-                    dist = 1.0f;
-                } else {
-                    const float denom = na * nb;
-                    const float q = acc / denom;
-                    const float v = 1.0f - q;
-                    dist = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                }
+                dist = vq_cosine_finish(METRIC, acc, na, nb);
             }
             const bool isnan_d = dist != dist;
             if (j == 0) d0_nan = isnan_d;
@@ -674,7 +645,7 @@ __global__ __launch_bounds__(1024) void k_recheck_tiled_any(
             for (uint32_t t = lane; t < sd; t += 64) xw[t] = X[(size_t)row * d + (size_t)s * sd + t];
         __syncthreads();
         float na = 0.0f;
-        if (METRIC == VQHIP_COSINE) {
+        if (vq_is_cos(METRIC)) {
             float sa = -0.0f;
             for (uint32_t t = 0; t < sd; ++t) {
                 const float p = xw[t] * xw[t];
@@ -687,7 +658,7 @@ __global__ __launch_bounds__(1024) void k_recheck_tiled_any(
         bool d0_nan = false;
         for (uint32_t j0 = 0; j0 < k; j0 += TCN) {
             const uint32_t j = j0 + lane;
-            float acc = (METRIC == VQHIP_COSINE) ? -0.0f : 0.0f;
+            float acc = (vq_is_cos(METRIC)) ? -0.0f : 0.0f;
             for (uint32_t t0 = 0; t0 < sd; t0 += TD) {
                 const uint32_t td = min(TD, sd - t0);  // a multiple of 4
                 __syncthreads();  // the previous chunk is consumed
@@ -720,17 +691,9 @@ __global__ __launch_bounds__(1024) void k_recheck_tiled_any(
             }
             float dist = acc;
             if (METRIC == VQHIP_EUCLIDEAN) dist = sqrtf(acc);
-            if (METRIC == VQHIP_COSINE) {
+            if (vq_is_cos(METRIC)) {
                 const float nb = (j < k) ? cnsqrt[(size_t)s * k + j] : 1.0f;
-                const float EPS = 1e-10f;
-                if (na < EPS || nb < EPS) {
-                    dist = 1.0f;
-                } else {
-                    const float denom = na * nb;
-                    const float q = acc / denom;
-                    const float v = 1.0f - q;
-                    dist = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                }
+                dist = vq_cosine_finish(METRIC, acc, na, nb);
             }
             const bool isnan_d = dist != dist;
             if (j == 0) d0_nan = isnan_d;
@@ -858,12 +821,7 @@ __device__ float exact_distance_rt(int metric, const float *__restrict__ a,
         sb = sb + p;
     }
     const float na = sqrtf(sa), nb = sqrtf(sb);
-    const float EPS = 1e-10f;
-    if (na < EPS || nb < EPS) return 1.0f;
-    float denom = na * nb;
-    float q = dot / denom;
-    float v = 1.0f - q;
-    return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    return vq_cosine_finish(metric, dot, na, nb);
 }
 
 __global__ __launch_bounds__(256) void k_distance_batch(int metric, const float *__restrict__ a,
@@ -1087,7 +1045,7 @@ int launch_distance_batch(int metric, const float *a, const float *b, uint64_t n
 int launch_assign_exact(const CodebookView &cb, const AssignArgs &a, bool use_worklist,
                         hipStream_t stream) {
     if (a.n == 0 || a.n_sub == 0) return VQHIP_OK;
-    if (a.metric == VQHIP_COSINE && !cb.cnsqrt)
+    if (vq_is_cos(a.metric) && !cb.cnsqrt)
         return fail(VQHIP_ERR_FAILURE, "cosine assignment needs prepared centroid norms");
     // work-list launches do not know their size on the host: a fixed grid strides over it
     uint64_t items = use_worklist ? (uint64_t)num_cus() * 4 * kExactBlock : a.n;
@@ -1102,6 +1060,7 @@ int launch_assign_exact(const CodebookView &cb, const AssignArgs &a, bool use_wo
     case VQHIP_EUCLIDEAN: return dispatch_exact<VQHIP_EUCLIDEAN>(cb, a, use_worklist, grid, stream);
     case VQHIP_MANHATTAN: return dispatch_exact<VQHIP_MANHATTAN>(cb, a, use_worklist, grid, stream);
     case VQHIP_COSINE: return dispatch_exact<VQHIP_COSINE>(cb, a, use_worklist, grid, stream);
+    case VQHIP_COSINE_UNCLAMPED: return dispatch_exact<VQHIP_COSINE_UNCLAMPED>(cb, a, use_worklist, grid, stream);
     default: return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", a.metric);
     }
 }

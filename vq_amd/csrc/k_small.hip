@@ -39,11 +39,7 @@ __device__ float small_distance(int metric, const float *__restrict__ x, const f
         const float p = x[t] * c[t];
         dot = dot + p;
     }
-    if (na < 1e-10f || nb < 1e-10f) return 1.0f;
-    const float denom = na * nb;
-    const float q = dot / denom;
-    const float v = 1.0f - q;
-    return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    return vq_cosine_finish(metric, dot, na, nb);
 }
 
 // one wave per (row, subspace): lane l scans centroids l, l+64, ... ascending with strict '<', the 64
@@ -59,7 +55,7 @@ __global__ __launch_bounds__(64) void k_pq_encode_small(const float *__restrict_
     for (uint32_t t = lane; t < sd; t += 64) xs[t] = xrow[t];
     __syncthreads();
     float na = 0.0f;
-    if (metric == VQHIP_COSINE) {
+    if (vq_is_cos(metric)) {
         float sa = -0.0f;
         for (uint32_t t = 0; t < sd; ++t) {
             const float p = xs[t] * xs[t];
@@ -74,7 +70,7 @@ __global__ __launch_bounds__(64) void k_pq_encode_small(const float *__restrict_
     bool d0_nan = false;
     for (uint32_t j = lane; j < k; j += 64) {
         const float dist = small_distance(metric, xs, cbs + (size_t)j * sd, sd, na,
-                                          metric == VQHIP_COSINE ? cnsqrt[(size_t)s * k + j] : 0.0f);
+                                          vq_is_cos(metric) ? cnsqrt[(size_t)s * k + j] : 0.0f);
         const bool isnan_d = dist != dist;
         if (j == 0) d0_nan = isnan_d;
         if (!isnan_d && (bj == NONE || dist < bd)) {
@@ -121,7 +117,7 @@ __global__ __launch_bounds__(64) void k_tsvq_encode_small(const float *__restric
         x[i] = (t < d) ? rows[(size_t)row * d + t] : 0.0f;
     }
     float na = 0.0f;
-    if (metric == VQHIP_COSINE) {
+    if (vq_is_cos(metric)) {
         float sa = -0.0f;
 #pragma unroll
         for (uint32_t i = 0; i < nch; ++i) {
@@ -145,7 +141,7 @@ __global__ __launch_bounds__(64) void k_tsvq_encode_small(const float *__restric
                 float tl = 0.0f, tr = 0.0f;
                 if (t < d) {
                     const float a = cl[t], b = cr[t];
-                    if (metric == VQHIP_COSINE) {
+                    if (vq_is_cos(metric)) {
                         tl = x[i] * a;
                         tr = x[i] * b;
                     } else {
@@ -177,24 +173,9 @@ __global__ __launch_bounds__(64) void k_tsvq_encode_small(const float *__restric
             if (metric == VQHIP_EUCLIDEAN) {
                 dl = sqrtf(al);
                 dr = sqrtf(ar);
-            } else if (metric == VQHIP_COSINE) {
-                const float nl = cnorm[l], nr = cnorm[r];
-                if (na < 1e-10f || nl < 1e-10f) {
-                    dl = 1.0f;
-                } else {
-                    const float den = na * nl;
-                    const float qq = al / den;
-                    const float v = 1.0f - qq;
-                    dl = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                }
-                if (na < 1e-10f || nr < 1e-10f) {
-                    dr = 1.0f;
-                } else {
-                    const float den = na * nr;
-                    const float qq = ar / den;
-                    const float v = 1.0f - qq;
-                    dr = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                }
+            } else if (vq_is_cos(metric)) {
+                dl = vq_cosine_finish(metric, al, na, cnorm[l]);
+                dr = vq_cosine_finish(metric, ar, na, cnorm[r]);
             }
             node = (dl <= dr) ? l : r;  // left on ties, tsvq.rs:122
         } else if (l >= 0) {

@@ -554,11 +554,7 @@ __device__ float dist_rt(int metric, const float *__restrict__ a, const float *_
         sb = sb + p;
     }
     const float na = sqrtf(sa), nb = sqrtf(sb);
-    if (na < 1e-10f || nb < 1e-10f) return 1.0f;
-    const float denom = na * nb;
-    const float q = dot / denom;
-    const float v = 1.0f - q;
-    return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    return vq_cosine_finish(metric, dot, na, nb);
 }
 
 __global__ __launch_bounds__(256) void k_tsvq_descend(const float *__restrict__ X, uint64_t n, uint32_t d,
@@ -611,7 +607,7 @@ __global__ __launch_bounds__(RB) void k_tsvq_descend_lds(const float *__restrict
     if (i >= rows) return;
     const float *x = xs + i;
     float na = 0.0f;
-    if (METRIC == VQHIP_COSINE) {
+    if (vq_is_cos(METRIC)) {
         float sa = -0.0f;
         for (uint32_t t = 0; t < d; ++t) {
             const float v = x[t * RB];
@@ -653,24 +649,9 @@ __global__ __launch_bounds__(RB) void k_tsvq_descend_lds(const float *__restrict
             if (METRIC == VQHIP_EUCLIDEAN) {
                 dl = sqrtf(al);
                 dr = sqrtf(ar);
-            } else if (METRIC == VQHIP_COSINE) {
-                const float nl = cnorm[l], nr = cnorm[r];
-                if (na < 1e-10f || nl < 1e-10f) {
-                    dl = 1.0f;
-                } else {
-                    const float den = na * nl;
-                    const float qq = al / den;
-                    const float v = 1.0f - qq;
-                    dl = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                }
-                if (na < 1e-10f || nr < 1e-10f) {
-                    dr = 1.0f;
-                } else {
-                    const float den = na * nr;
-                    const float qq = ar / den;
-                    const float v = 1.0f - qq;
-                    dr = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                }
+            } else if (vq_is_cos(METRIC)) {
+                dl = vq_cosine_finish(METRIC, al, na, cnorm[l]);
+                dr = vq_cosine_finish(METRIC, ar, na, cnorm[r]);
             } else {
                 dl = al;
                 dr = ar;
@@ -710,7 +691,7 @@ __global__ __launch_bounds__(256) void k_tsvq_descend_reg(const float *__restric
         }
     }
     float na = 0.0f;
-    if (METRIC == VQHIP_COSINE) {
+    if (vq_is_cos(METRIC)) {
         float sa = -0.0f;
 #pragma unroll
         for (int t = 0; t < D; ++t) {
@@ -753,24 +734,9 @@ __global__ __launch_bounds__(256) void k_tsvq_descend_reg(const float *__restric
             if (METRIC == VQHIP_EUCLIDEAN) {
                 dl = sqrtf(al);
                 dr = sqrtf(ar);
-            } else if (METRIC == VQHIP_COSINE) {
-                const float nl = cnorm[l], nr = cnorm[r];
-                if (na < 1e-10f || nl < 1e-10f) {
-                    dl = 1.0f;
-                } else {
-                    const float den = na * nl;
-                    const float qq = al / den;
-                    const float v = 1.0f - qq;
-                    dl = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                }
-                if (na < 1e-10f || nr < 1e-10f) {
-                    dr = 1.0f;
-                } else {
-                    const float den = na * nr;
-                    const float qq = ar / den;
-                    const float v = 1.0f - qq;
-                    dr = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                }
+            } else if (vq_is_cos(METRIC)) {
+                dl = vq_cosine_finish(METRIC, al, na, cnorm[l]);
+                dr = vq_cosine_finish(METRIC, ar, na, cnorm[r]);
             } else {
                 dl = al;
                 dr = ar;
@@ -2224,6 +2190,7 @@ int launch_tsvq_encode(const float *X, uint64_t n, uint32_t d, const float *cent
         case VQHIP_EUCLIDEAN: VQ_TRY(dispatch_descend<VQHIP_EUCLIDEAN>(X, n, d, centroids, cnorm, left, right, leaf, stream, &done)); break;
         case VQHIP_MANHATTAN: VQ_TRY(dispatch_descend<VQHIP_MANHATTAN>(X, n, d, centroids, cnorm, left, right, leaf, stream, &done)); break;
         case VQHIP_COSINE: VQ_TRY(dispatch_descend<VQHIP_COSINE>(X, n, d, centroids, cnorm, left, right, leaf, stream, &done)); break;
+        case VQHIP_COSINE_UNCLAMPED: VQ_TRY(dispatch_descend<VQHIP_COSINE_UNCLAMPED>(X, n, d, centroids, cnorm, left, right, leaf, stream, &done)); break;
         default: return fail(VQHIP_ERR_INVALID_INPUT, "unknown metric %d", metric);
         }
     }

@@ -14,12 +14,16 @@ _NAMES = {
     "cosine": _lib.COSINE,
     "cosine_distance": _lib.COSINE,
     "manhattan": _lib.MANHATTAN,
+    # opt-in, UNPINNED (include/vqhip.h): the reference's `simd` build, 1 - similarity without EPSILON rule or clamp
+    "cosine_unclamped": _lib.COSINE_UNCLAMPED,
+    "cosine_simd": _lib.COSINE_UNCLAMPED,
 }
 _CANON = {
     _lib.EUCLIDEAN: "euclidean",
     _lib.SQUARED_EUCLIDEAN: "squared_euclidean",
     _lib.MANHATTAN: "manhattan",
     _lib.COSINE: "cosine",
+    _lib.COSINE_UNCLAMPED: "cosine_unclamped",
 }
 
 
@@ -49,6 +53,12 @@ class Distance:
     @staticmethod
     def cosine() -> "Distance":
         return Distance("cosine")
+
+    @staticmethod
+    def cosine_unclamped() -> "Distance":
+        """The reference's `simd`-feature cosine, ``1 - similarity`` with no EPSILON rule and no clamp
+        (src/core/distance.rs:97-105).  Opt-in and unpinned: hsdlib's summation order is unknown."""
+        return Distance("cosine_unclamped")
 
     def name(self) -> str:
         """``Distance::name`` (src/core/distance.rs:21-28)"""
