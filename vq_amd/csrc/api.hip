@@ -1762,19 +1762,24 @@ int vqhip_tsvq_encode_device(vqhip_tsvq *t, const void *dev_rows, uint64_t n, vo
     }
     t->last_screened = false;
     const float *X = reinterpret_cast<const float *>(dev_rows);
+    uint16_t *out = reinterpret_cast<uint16_t *>(dev_f16_out);
+    const bool out_vec = out && t->d % 8 == 0 && (reinterpret_cast<uintptr_t>(dev_f16_out) & 15) == 0;
+    bool out_done = false;
     if (t->use_screen && n <= 0xFFFFFFFFull && (reinterpret_cast<uintptr_t>(dev_rows) & 15) == 0) {
         t->last_screened = true;
         VQ_TRY(t->scr_wl.ensure((size_t)n * 8));
         t->scr.wl = t->scr_wl.as<uint2>();
+        // the reconstruction rides on the descent when it can be written in 16-byte pieces
         VQ_TRY(launch_tsvq_screen_encode(X, n, t->d, t->centroids.as<float>(), t->cnorm.as<float>(), t->left.as<int32_t>(),
-                                         t->right.as<int32_t>(), t->metric, t->scr, leaf, s));
+                                         t->right.as<int32_t>(), t->metric, t->scr, leaf, s,
+                                         out_vec ? t->table16.as<uint16_t>() : nullptr, out_vec ? out : nullptr));
+        out_done = out_vec;
     } else {
         VQ_TRY(launch_tsvq_encode(X, n, t->d, t->centroids.as<float>(), t->cnorm.as<float>(), t->left.as<int32_t>(),
                                   t->right.as<int32_t>(), t->metric, leaf, s));
     }
-    if (dev_f16_out) {
-        uint16_t *out = reinterpret_cast<uint16_t *>(dev_f16_out);
-        if (t->d % 8 == 0 && (reinterpret_cast<uintptr_t>(dev_f16_out) & 15) == 0)
+    if (out && !out_done) {
+        if (out_vec)
             VQ_TRY(launch_tsvq_gather_table(t->table16.as<uint16_t>(), t->d, leaf, n, out, s));
         else
             VQ_TRY(launch_tsvq_gather_f16(t->centroids.as<float>(), t->d, leaf, n, out, s));

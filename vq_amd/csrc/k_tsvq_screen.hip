@@ -71,7 +71,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
     const float *__restrict__ X, uint64_t n, uint32_t d_real, const float *__restrict__ w_g,
     const int4 *__restrict__ info_g, const float *__restrict__ mu_g, uint32_t n_int, int32_t start_slot, float R,
     float coef_a, float coef_b, int32_t *__restrict__ leaf_out, uint2 *__restrict__ wl,
-    uint32_t *__restrict__ wl_count) {
+    uint32_t *__restrict__ wl_count, const uint4 *__restrict__ table16, uint4 *__restrict__ f16_out) {
+    // table16 / f16_out (optional, d_real % 8 == 0): the f16 node table [n_nodes][d_real] and the reconstruction
+    // [n][d_real]; a row that reaches its leaf here is written here (its 8 lanes copy consecutive 16-byte pieces), so
+    // the leaf ids do not travel through HBM to a gather kernel and back
     // d_real <= D (a multiple of 4): rows are d_real floats apart; w, mu are D wide with zeros behind d_real, and the
     // 16-byte parts of a row behind d_real are read as zeros (from a valid address), so any such d rides on the
     // next instantiated width
@@ -236,6 +239,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
             if (!__any(cur >= 0)) break;
         }
         if (j == 0 && cur < 0 && cur > kFlagBase / 2 && row < n) leaf_out[row] = -1 - cur;
+        if (f16_out && cur < 0 && cur > kFlagBase / 2 && row < n) {
+            const uint32_t pieces = d_real / 8;
+            const uint4 *src = table16 + (size_t)(-1 - cur) * pieces;
+            uint4 *dst = f16_out + row * pieces;
+            for (uint32_t q = j; q < pieces; q += LPR) dst[q] = src[q];
+        }
         const bool push = (j == 0) && (cur <= kFlagBase / 2);
         const uint64_t mask = __ballot(push);
         if (mask) {
@@ -290,7 +299,8 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
                                                        const int32_t *__restrict__ slot_node,
                                                        const uint2 *__restrict__ wl,
                                                        const uint32_t *__restrict__ wl_count, uint32_t d_real,
-                                                       int32_t *__restrict__ leaf_out) {
+                                                       int32_t *__restrict__ leaf_out, const uint4 *__restrict__ table16,
+                                                       uint4 *__restrict__ f16_out) {
     // d_real <= D: rows and centroids are d_real floats long; the pieces behind it count as zeros (a zero term
     // leaves a running sum that already holds a real term unchanged, so the reference's bits are kept)
     constexpr int NQ = (D >= 64) ? D / 64 : 1;  // chunks of 16 lanes x V floats
@@ -406,6 +416,12 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
             }
         }
         if (valid && j == 0) leaf_out[ent.x] = node;
+        if (valid && f16_out) {  // the entry's 16 lanes copy the leaf's f16 row
+            const uint32_t pieces = d_real / 8;
+            const uint4 *src = table16 + (size_t)node * pieces;
+            uint4 *dst = f16_out + (size_t)ent.x * pieces;
+            for (uint32_t q = j; q < pieces; q += 16) dst[q] = src[q];
+        }
     }
 }
 
@@ -419,7 +435,8 @@ __global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restri
                                                            const int32_t *__restrict__ slot_node,
                                                            const uint2 *__restrict__ wl,
                                                            const uint32_t *__restrict__ wl_count,
-                                                           int32_t *__restrict__ leaf_out) {
+                                                           int32_t *__restrict__ leaf_out, const uint4 *__restrict__ table16,
+                                                           uint4 *__restrict__ f16_out) {
     const uint32_t count = *wl_count;
     const bool cosine = mode == kScrCos, manh = mode == kScrMan;
     for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < count; e += gridDim.x * 256) {
@@ -469,21 +486,26 @@ __global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restri
             }
         }
         leaf_out[ent.x] = node;
+        if (f16_out) {
+            const uint32_t pieces = d / 8;
+            for (uint32_t q = 0; q < pieces; ++q) f16_out[(size_t)ent.x * pieces + q] = table16[(size_t)node * pieces + q];
+        }
     }
 }
 
 template <int D, int MODE>
 static int launch_continue(const float *X, const float *centroids, const float *cnorm, const int32_t *left,
                            const int32_t *right, int euclid, const TsvqScreen &s, int32_t *leaf, hipStream_t stream,
-                           uint32_t d_real) {
+                           uint32_t d_real, const uint4 *table16, uint4 *f16_out) {
     hipLaunchKernelGGL((k_tsvq_continue<D, MODE>), dim3(1024), dim3(256), 0, stream, X, centroids, cnorm, left, right, euclid,
-                       s.slot_node, s.wl, s.wl_count, d_real, leaf);
+                       s.slot_node, s.wl, s.wl_count, d_real, leaf, table16, f16_out);
     VQ_LAUNCH_CHECK("k_tsvq_continue");
     return VQHIP_OK;
 }
 
 template <int D, int LPR, int MODE>
-int launch_screen(const float *X, uint64_t n, uint32_t d_real, const TsvqScreen &s, hipStream_t stream, int32_t *leaf) {
+int launch_screen(const float *X, uint64_t n, uint32_t d_real, const TsvqScreen &s, hipStream_t stream, int32_t *leaf,
+                  const uint4 *table16, uint4 *f16_out) {
     constexpr int RPW = 64 / LPR;
     constexpr int WAVES = (D >= 512) ? 4 : (D >= 256) ? 8 : kWaves;  // 512 / 256 / 128 VGPRs per lane
     const size_t lds_bytes = tsvq_screen_lds_bytes(s.n_int, MODE == kScrL2 ? 1 : 2, D);
@@ -497,7 +519,7 @@ int launch_screen(const float *X, uint64_t n, uint32_t d_real, const TsvqScreen 
     uint64_t grid = (n_tiles + WAVES - 1) / WAVES;
     if (grid > (uint64_t)num_cus()) grid = (uint64_t)num_cus();
     hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES, MODE>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X,
-                       n, d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count);
+                       n, d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count, table16, f16_out);
     VQ_LAUNCH_CHECK("k_tsvq_screen_descend");
     return VQHIP_OK;
 }
@@ -528,17 +550,22 @@ bool tsvq_screen_supported(uint32_t n_int, uint32_t n_nodes, uint32_t d, int met
 
 int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const float *cnorm,
                               const int32_t *left, const int32_t *right, int metric, const TsvqScreen &s, int32_t *leaf,
-                              hipStream_t stream) {
+                              hipStream_t stream, const uint16_t *table16_h, uint16_t *f16_out_h) {
     if (n == 0) return VQHIP_OK;
+    // optional fused reconstruction (f16 node table -> f16 rows): needs whole 16-byte pieces
+    const uint4 *table16 = reinterpret_cast<const uint4 *>(table16_h);
+    uint4 *f16_out = reinterpret_cast<uint4 *>(f16_out_h);
+    if (f16_out && (!table16 || d % 8 != 0 || (reinterpret_cast<uintptr_t>(f16_out_h) & 15) != 0))
+        return fail(VQHIP_ERR_INVALID_INPUT, "fused f16 output needs d %% 8 == 0 and a 16-byte aligned buffer");
     if (n > 0xFFFFFFFFull) return fail(VQHIP_ERR_UNSUPPORTED, "screened TSVQ descent takes < 2^32 rows per call");
     VQ_HIP(hipMemsetAsync(s.wl_count, 0, 4, stream));
     const int euclid = metric == VQHIP_EUCLIDEAN ? 1 : 0;
     const int mode = metric == VQHIP_COSINE ? kScrCos : metric == VQHIP_MANHATTAN ? kScrMan : kScrL2;
     const uint32_t dp = tsvq_screen_width(d);  // instantiated width serving d (d itself, or the next one up: zero padding)
 #define VQ_TSVQ_DM(DV, MV)                                                                         \
-    VQ_TRY((launch_screen<DV, 8, MV>(X, n, d, s, stream, leaf)));                                  \
+    VQ_TRY((launch_screen<DV, 8, MV>(X, n, d, s, stream, leaf, table16, f16_out)));                \
     if (DV >= 64 || d == DV)                                                                       \
-        VQ_TRY((launch_continue<DV, MV>(X, centroids, cnorm, left, right, euclid, s, leaf, stream, d)));
+        VQ_TRY((launch_continue<DV, MV>(X, centroids, cnorm, left, right, euclid, s, leaf, stream, d, table16, f16_out)));
 #define VQ_TSVQ_D(DV)                                                                              \
     case DV:                                                                                       \
         if (mode == kScrCos) {                                                                     \
@@ -558,7 +585,7 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
 #undef VQ_TSVQ_DM
     if (d != dp && dp < 64) {  // d < 32 (8-byte pieces in k_tsvq_continue): the run-time-length kernel
         hipLaunchKernelGGL(k_tsvq_continue_any, dim3(256), dim3(256), 0, stream, X, d, centroids, cnorm, left, right, euclid,
-                           mode, s.slot_node, s.wl, s.wl_count, leaf);
+                           mode, s.slot_node, s.wl, s.wl_count, leaf, table16, f16_out);
         VQ_LAUNCH_CHECK("k_tsvq_continue_any");
     }
     return VQHIP_OK;

@@ -214,7 +214,7 @@ uint32_t tsvq_screen_width(uint32_t d);  // instantiated width serving d (zero p
 bool tsvq_screen_supported(uint32_t n_int, uint32_t n_nodes, uint32_t d, int metric);
 int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const float *centroids, const float *cnorm,
                               const int32_t *left, const int32_t *right, int metric, const TsvqScreen &s, int32_t *leaf,
-                              hipStream_t stream);
+                              hipStream_t stream, const uint16_t *table16 = nullptr, uint16_t *f16_out = nullptr);
 int launch_tsvq_gather_f16(const float *centroids, uint32_t d, const int32_t *leaf, uint64_t n, uint16_t *f16_out,
                            hipStream_t stream);
 int launch_tsvq_node_norms(const float *centroids, uint32_t n_nodes, uint32_t d, float *cnorm, hipStream_t stream);
