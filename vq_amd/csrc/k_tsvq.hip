@@ -230,26 +230,42 @@ __global__ __launch_bounds__(1024) void k_seg_colsum(const float *__restrict__ X
 }
 
 // split dimension: NaN filtered, LAST maximum wins (Iterator::max_by), none -> 0 (tsvq.rs:59-66)
-__global__ void k_pick_split(const uint32_t *__restrict__ lvl_node, const LevelInfo *__restrict__ lv, uint32_t d, NodeArrays na) {
-    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per node: lane l scans dimensions l, l + 64, ... in ascending order (later wins a tie), the lanes are
+// merged with "larger value, then larger dimension" -- the same winner as the sequential scan
+__global__ __launch_bounds__(256) void k_pick_split(const uint32_t *__restrict__ lvl_node, const LevelInfo *__restrict__ lv, uint32_t d, NodeArrays na) {
+    const uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (li >= lv->n_split) return;
     const uint32_t node = lvl_node[li];
     const float *v = na.var + (size_t)node * d;
     uint32_t best_t = 0;
-    bool have = false;
+    int have = 0;
     float best = 0.0f;
-    for (uint32_t t = 0; t < d; ++t) {
+    for (uint32_t t = lane; t < d; t += 64) {
         const float x = v[t];
         if (x != x) continue;
         if (!have || !(x < best)) {
             best = x;
             best_t = t;
-            have = true;
+            have = 1;
         }
     }
-    na.split_dim[node] = best_t;
-    na.nv[node] = na.seg_len[node];  // non-NaN count: k_gather_vals subtracts the NaNs
-    na.sel_prefix[2 * node] = na.sel_prefix[2 * node + 1] = 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off);
+        const uint32_t ot = (uint32_t)__shfl_xor((int)best_t, off);
+        const int oh = __shfl_xor(have, off);
+        const bool take = oh && (!have || ob > best || (ob == best && ot > best_t));
+        if (take) {
+            best = ob;
+            best_t = ot;
+            have = 1;
+        }
+    }
+    if (lane == 0) {
+        na.split_dim[node] = have ? best_t : 0u;
+        na.nv[node] = na.seg_len[node];  // non-NaN count: k_gather_vals subtracts the NaNs
+        na.sel_prefix[2 * node] = na.sel_prefix[2 * node + 1] = 0;
+    }
 }
 
 // vals[i] = X[perm[i]][split_dim(node of i)]; nv[node] ends as the non-NaN count
@@ -2016,7 +2032,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         // variances + split dimension (tsvq.rs:46-66)
         VQ_TRY(colsum(1, lvp, ub_nodes, perm));
         const uint32_t nb64 = (ub_nodes + 63) / 64;
-        hipLaunchKernelGGL(k_pick_split, dim3(nb64), dim3(64), 0, stream, lvl_split, lvp, d, na);
+        hipLaunchKernelGGL(k_pick_split, dim3((ub_nodes + 3) / 4), dim3(256), 0, stream, lvl_split, lvp, d, na);
         VQ_LAUNCH_CHECK("k_pick_split");
         // median (tsvq.rs:68-81)
         hipLaunchKernelGGL(k_gather_vals, dim3((n + 255) / 256), dim3(256), 0, stream, X, d, n, perm, node_of, remap, lvl_split, na,
