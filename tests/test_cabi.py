@@ -80,6 +80,32 @@ def test_null_and_shape_checks_do_not_need_a_gpu(built):
     assert lib.vqhip_kmeans_create(None, 2, 2, ctypes.byref(h)) == built.ERR_NULL_PTR
 
 
+def test_tsvq_create_rejects_arrays_that_are_not_one_tree(built):
+    """shared children, two parents, unreachable nodes and backward edges are refused before any device
+    work (the encoder's breadth-first images are sized by the node count)."""
+    lib = built.load()
+    cent = np.zeros((4, 2), np.float32)
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    f32p = ctypes.POINTER(ctypes.c_float)
+
+    def create(left, right, metric=0):
+        l, r = np.array(left, np.int32), np.array(right, np.int32)
+        h = ctypes.c_void_p()
+        rc = lib.vqhip_tsvq_create(cent.ctypes.data_as(f32p), l.ctypes.data_as(i32p), r.ctypes.data_as(i32p), len(l), 2, metric,
+                                   ctypes.byref(h))
+        return rc, built.last_error()
+
+    for left, right, word in (([1, -1, -1, -1], [1, -1, -1, -1], "both children"),    # one node as both children
+                              ([1, 3, 3, -1], [2, -1, -1, -1], "two parents"),         # a shared grandchild
+                              ([1, -1, -1, -1], [2, -1, -1, -1], "not reachable"),     # node 3 hangs loose
+                              ([1, 0, -1, -1], [2, 3, -1, -1], "out-of-order"),        # an edge back to the root
+                              ([1, -1, -1, -1], [9, -1, -1, -1], "out-of-order")):     # past the end
+        rc, msg = create(left, right)
+        assert rc == built.ERR_INVALID_INPUT and word in msg, (left, right, rc, msg)
+    rc, msg = create([1, -1, -1, -1], [2, 3, -1, -1], metric=7)
+    assert rc == built.ERR_INVALID_INPUT and "metric" in msg
+
+
 def test_synthetic_generator_host_twin(built):
     a = built.synth_uniform_host(100, 16, seed=66, row_offset=0)
     b = built.synth_uniform_host(40, 16, seed=66, row_offset=60)
