@@ -318,8 +318,26 @@ def main():
         init = strided_init(n_global, m_, k_)
 
         # ---- codebooks: a few (untimed) global Lloyd iterations from strided init rows; then the timed iterations ----
-        if args.collective == "native":
-            ncomm = native_comm_from_torch(force=force_comm)  # identity communicator for one rank
+        use_native = args.collective == "native"
+        ncomm = None
+        if use_native:
+            # the library's own RCCL communicator; if any rank cannot create it (RCCL missing, init error) every rank
+            # falls back to torch.distributed's all-reduce of the same slab -- same bits, one more launch per iteration
+            ok = 1
+            try:
+                ncomm = native_comm_from_torch(force=force_comm)  # identity communicator for one rank
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: native communicator unavailable ({e}); falling back to torch.distributed", file=sys.stderr)
+                ok = 0
+            if world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                use_native = False
+                if ncomm is not None:
+                    ncomm.close()
+        if use_native:
             collective = "rccl below the C ABI (vqhip_kmeans_run_sharded)" if (world > 1 or force_comm) else "none"
             km = _lib.KMeans(ds, m_, k_)
             km.set_engine(engine)
