@@ -1779,6 +1779,21 @@ struct TsvqBuildWs {
                        &b_lvl, &b_remap, &b_seg_start, &b_seg_len, &b_split, &b_nv, &b_nleft, &b_median, &b_selp, &b_selr,
                        &b_child, &b_cent, &b_var, &b_left, &b_right, &b_fs_tiles, &b_fs_nodes, &b_fs_base, &b_fs_nt, &b_fs_sum,
                        &b_fs_summ, &b_lvl_slow, &b_fs_fb, &b_fs_side, &b_fs_mom, &b_lv};
+    // pinned host staging of the node download.  A pageable destination of a few MB is pinned by the runtime for the
+    // copy; when that memory is later unmapped (a std::vector or numpy array of 4 MB goes back to the OS) the driver
+    // invalidates the mapping by evicting and restoring the process' queues, and the next kernel launched -- the next
+    // build's first -- starts 10-30 ms late (the round-1 "depth-12 anomaly", profiles/r2/tsvq_anomaly.txt)
+    void *h_stage = nullptr;
+    size_t h_bytes = 0;
+    int ensure_host(size_t need) {
+        if (need <= h_bytes) return VQHIP_OK;
+        if (h_stage) (void)hipHostFree(h_stage);
+        h_stage = nullptr;
+        h_bytes = 0;
+        VQ_HIP(hipHostMalloc(&h_stage, need, hipHostMallocDefault));
+        h_bytes = need;
+        return VQHIP_OK;
+    }
     size_t total() const {
         size_t t = 0;
         for (const DevBuf *b : all) t += b->bytes;
@@ -1786,6 +1801,9 @@ struct TsvqBuildWs {
     }
     void release() {
         for (DevBuf *b : all) b->release();
+        if (h_stage) (void)hipHostFree(h_stage);
+        h_stage = nullptr;
+        h_bytes = 0;
     }
     ~TsvqBuildWs() { release(); }
 };
@@ -1924,6 +1942,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     }
     const bool have_fast = can_fast && n >= fs_min_rows;
 
+    marks.mark("allocated");
     // initial state: identity permutation, every row in node 0 (the root), no children anywhere
     hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, stream, ws.b_perm[0].as<uint32_t>(),
                        ws.b_nodeof[0].as<uint32_t>(), n);
@@ -1936,12 +1955,14 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         hipLaunchKernelGGL(k_fs_policy, dim3(n_cblk), dim3(1024), 0, stream, X, n, d, ws.b_fs_fb.as<uint32_t>() + 2 + 64 * 2 * 16);
         VQ_LAUNCH_CHECK("k_fs_policy");
     }
+    marks.mark("queued");
     {
         const uint32_t root[2] = {0u, n};  // seg_start[0], seg_len[0]; lv[0] = {first 0, count 1}
         const uint32_t one = 1u;
         VQ_HIP(hipMemcpyAsync(na.seg_start, &root[0], 4, hipMemcpyHostToDevice, stream));
         VQ_HIP(hipMemcpyAsync(na.seg_len, &root[1], 4, hipMemcpyHostToDevice, stream));
         VQ_HIP(hipMemcpyAsync(&lv[0].count, &one, 4, hipMemcpyHostToDevice, stream));
+        marks.mark("uploaded");
         VQ_HIP(hipStreamSynchronize(stream));  // stack sources; also the only synchronisation before the final download
     }
     marks.mark("setup");
@@ -2119,11 +2140,14 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         }
     }
     // nodes -> host, then BFS -> pre-order (the oracle's numbering)
-    std::vector<float> cent((size_t)total * d);
-    std::vector<int32_t> hl(total), hr(total);
-    VQ_HIP(hipMemcpyAsync(cent.data(), na.centroid, (size_t)total * d * 4, hipMemcpyDeviceToHost, stream));
-    VQ_HIP(hipMemcpyAsync(hl.data(), node_left, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
-    VQ_HIP(hipMemcpyAsync(hr.data(), node_right, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+    const size_t cent_bytes = (size_t)total * d * 4, idx_bytes = (((size_t)total * 4) + 15) & ~(size_t)15;
+    VQ_TRY(ws.ensure_host(cent_bytes + 2 * idx_bytes));
+    const float *cent = static_cast<const float *>(ws.h_stage);
+    const int32_t *hl = reinterpret_cast<const int32_t *>(static_cast<const char *>(ws.h_stage) + cent_bytes);
+    const int32_t *hr = reinterpret_cast<const int32_t *>(static_cast<const char *>(ws.h_stage) + cent_bytes + idx_bytes);
+    VQ_HIP(hipMemcpyAsync(ws.h_stage, na.centroid, cent_bytes, hipMemcpyDeviceToHost, stream));
+    VQ_HIP(hipMemcpyAsync(const_cast<int32_t *>(hl), node_left, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+    VQ_HIP(hipMemcpyAsync(const_cast<int32_t *>(hr), node_right, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
     VQ_HIP(hipStreamSynchronize(stream));
     marks.mark("downloaded");
     std::vector<int32_t> order;  // pre-order list of BFS ids
@@ -2140,7 +2164,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     for (uint32_t q = 0; q < order.size(); ++q) newid[order[q]] = (int32_t)q;
     for (uint32_t q = 0; q < order.size(); ++q) {
         const int32_t id = order[q];
-        memcpy(centroids_out + (size_t)q * d, cent.data() + (size_t)id * d, (size_t)d * 4);
+        memcpy(centroids_out + (size_t)q * d, cent + (size_t)id * d, (size_t)d * 4);
         left_out[q] = hl[id] >= 0 ? newid[hl[id]] : -1;
         right_out[q] = hr[id] >= 0 ? newid[hr[id]] : -1;
     }
