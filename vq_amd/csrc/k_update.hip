@@ -513,17 +513,30 @@ __global__ void k_clear_gated(uint32_t *__restrict__ words, uint32_t n, const ui
 // End of one iteration of a device-driven run (src/core/vector.rs:440-457 without the host): an active subspace with an
 // empty cluster pauses the run (the caller reseeds: the draw is the host's); otherwise subspaces whose centroids did
 // not move retire, the others count one more iteration.  One workgroup.
-__global__ __launch_bounds__(256) void k_run_update(uint32_t m, uint32_t k, const uint32_t *__restrict__ counts,
-                                                    const uint32_t *__restrict__ changed, uint8_t *__restrict__ active,
-                                                    uint32_t *__restrict__ iters, uint32_t *__restrict__ halt) {
+__global__ __launch_bounds__(1024) void k_run_update(uint32_t m, uint32_t k, const uint32_t *__restrict__ counts,
+                                                     const uint32_t *__restrict__ changed, uint8_t *__restrict__ active,
+                                                     uint32_t *__restrict__ iters, uint32_t *__restrict__ halt) {
     __shared__ int any_empty;
     if (*halt) return;
     if (threadIdx.x == 0) any_empty = 0;
     __syncthreads();
-    for (uint32_t e = threadIdx.x; e < m * k; e += 256)
-        if (active[e / k] && counts[e] == 0u) any_empty = 1;
+    // four counts per thread and round, all requested before any is looked at (the kernel is a chain of memory
+    // latencies: 16 us with 256 threads and one load per round at C2's 2048 counts)
+    for (uint32_t e0 = threadIdx.x; e0 < m * k; e0 += 4 * 1024) {
+        uint32_t c[4];
+        uint8_t a[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t e = e0 + u * 1024;
+            c[u] = (e < m * k) ? counts[e] : 1u;
+            a[u] = (e < m * k) ? active[e / k] : (uint8_t)0;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u)
+            if (a[u] && c[u] == 0u) any_empty = 1;
+    }
     __syncthreads();
-    for (uint32_t s = threadIdx.x; s < m; s += 256) {
+    for (uint32_t s = threadIdx.x; s < m; s += 1024) {
         if (!active[s]) continue;
         iters[s] += 1u;
         if (!any_empty && !changed[s]) active[s] = 0;  // converged (vector.rs:455-457); on a pause the host decides
@@ -706,7 +719,7 @@ int launch_reduce_partials(const UpdatePlan &p, const float *partial_sums,
 
 int launch_run_update(uint32_t m, uint32_t k, const uint32_t *counts, const uint32_t *changed, uint8_t *active,
                       uint32_t *iters, uint32_t *halt, hipStream_t stream) {
-    hipLaunchKernelGGL(k_run_update, dim3(1), dim3(256), 0, stream, m, k, counts, changed, active, iters, halt);
+    hipLaunchKernelGGL(k_run_update, dim3(1), dim3(1024), 0, stream, m, k, counts, changed, active, iters, halt);
     VQ_LAUNCH_CHECK("k_run_update");
     return VQHIP_OK;
 }
