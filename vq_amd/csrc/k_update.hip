@@ -433,12 +433,33 @@ __global__ __launch_bounds__(256) void k_reduce_partials_pos(
             if (t < sd) {
                 const size_t stride = (size_t)n_sub * k * sd;
                 const float *p = partial_sums + ((size_t)pos * k + j) * sd + t;
-                for (uint32_t c = grp; c < n_chunks; c += kRedGroups) acc += (double)p[c * stride];
+                // six partials requested at a time, added in the same order as one by one (the f64 sum's order is part
+                // of the result's low bits): the loop was a chain of memory latencies
+                for (uint32_t c0 = grp; c0 < n_chunks; c0 += 6 * kRedGroups) {
+                    float v[6];
+#pragma unroll
+                    for (uint32_t u = 0; u < 6; ++u) {
+                        const uint32_t c = c0 + u * kRedGroups;
+                        v[u] = (c < n_chunks) ? p[c * stride] : 0.0f;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 6; ++u)
+                        if (c0 + u * kRedGroups < n_chunks) acc += (double)v[u];
+                }
             } else {
                 const size_t stride = (size_t)n_sub * k;
                 const uint32_t *p = partial_counts + (size_t)pos * k + j;
                 unsigned long long cnt = 0;
-                for (uint32_t c = grp; c < n_chunks; c += kRedGroups) cnt += p[c * stride];
+                for (uint32_t c0 = grp; c0 < n_chunks; c0 += 6 * kRedGroups) {
+                    uint32_t v[6];
+#pragma unroll
+                    for (uint32_t u = 0; u < 6; ++u) {
+                        const uint32_t c = c0 + u * kRedGroups;
+                        v[u] = (c < n_chunks) ? p[c * stride] : 0u;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 6; ++u) cnt += v[u];
+                }
                 acc = (double)cnt;
             }
         }
