@@ -1320,14 +1320,16 @@ __device__ __forceinline__ FsPair fs_compose(const FsPair &f, const FsPair &g) {
     return h;
 }
 
-template <int MODE>
+// DBG (VQHIP_TSVQ_DEBUG): the instantiation with the counters and timers; the production one carries none of it
+template <int MODE, bool DBG>
 __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, uint32_t d,
                                                  const uint32_t *__restrict__ perm,
                                                  const uint32_t *__restrict__ fast_nodes,
                                                  const uint32_t *__restrict__ tile_base, NodeArrays na,
                                                  const FsSumm *__restrict__ summ, const float *__restrict__ side,
                                                  uint32_t *__restrict__ n_fallback, const LevelInfo *__restrict__ lv,
-                                                 uint32_t *__restrict__ dbg) {
+                                                 uint32_t *__restrict__ dbg_arg) {
+    uint32_t *const dbg = DBG ? dbg_arg : nullptr;  // folds every `if (dbg)` below away when !DBG
     // dbg (VQHIP_TSVQ_DEBUG): 8 counters of this (level, pass): chains, re-added tiles, most in one chain, and the
     // first reason the re-added tile failed: unusable summary / other binade than guessed / prefix leaves the binade /
     // running sum not a normal number
@@ -2007,13 +2009,15 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             hipLaunchKernelGGL(k_fs_tile_sums<0>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts, fs_sample, policy, lvp);
             hipLaunchKernelGGL(k_fs_prefix, pgrid, dim3(1024), 0, stream, d, fb, fc, ts, lvp);
             hipLaunchKernelGGL(k_fs_transduce<0>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, lvp, na, ts, sm, side, side_cap, fbk + 1, mom, park_rel, policy);
-            hipLaunchKernelGGL(k_fs_chain<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
+            if (dbg) hipLaunchKernelGGL((k_fs_chain<0, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
+            else hipLaunchKernelGGL((k_fs_chain<0, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
         } else {
             // the guess comes from the moments the mean pass of the same level left behind (same tile table: every node
             // long enough for the emulation has more than one row, so it is a split node whenever the level splits)
             hipLaunchKernelGGL(k_fs_prefix_var, pgrid, dim3(1024), 0, stream, X, d, perm, fn, fb, fc, na, mom, ts, lvp);
             hipLaunchKernelGGL(k_fs_transduce<1>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, lvp, na, ts, sm, side, side_cap, fbk + 1, (double2 *)nullptr, 0.0f, (const uint32_t *)nullptr);
-            hipLaunchKernelGGL(k_fs_chain<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
+            if (dbg) hipLaunchKernelGGL((k_fs_chain<1, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
+            else hipLaunchKernelGGL((k_fs_chain<1, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
         }
         VQ_LAUNCH_CHECK("k_fs_*");
         if (getenv("VQHIP_TSVQ_CHECK")) {
