@@ -197,6 +197,34 @@ def test_fuzz_tsvq(oracle, seed):
     np.testing.assert_array_equal(t.quantize_batch(Q).view(np.uint16), want_f16)
 
 
+@pytest.mark.parametrize("seed", range(32 * SCALE))
+def test_fuzz_tsvq_descent_screens(oracle, seed):
+    """The screened descents of all four metrics (one or two screened sums per level, proven margins, exact
+    continuation) on random widths -- instantiated and zero-padded ones --, depths, data kinds and query families:
+    same distribution, rescaled by a power of ten, negated (cosines of the other sign), the tree's own centroids and
+    their neighbours (ties, zero distances)."""
+    rng = np.random.default_rng(7000 + seed)
+    d = int(rng.choice([4, 8, 12, 20, 32, 48, 64, 100, 128, 192, 256, 300, 384, 512, 768]))
+    n = int(rng.integers(2, 4000))
+    depth = int(rng.integers(1, 10))
+    kind = KINDS[int(rng.integers(0, len(KINDS)))]
+    X = _draw_data(rng, n, d, kind)
+    tree = oracle.tsvq_build(X, depth)
+    cent = tree["centroids"]
+    scale = F(10.0 ** int(rng.integers(-12, 13)))
+    Q = np.concatenate([_draw_data(rng, 600, d, kind), X[:150], _draw_data(rng, 200, d, kind) * scale,
+                        -_draw_data(rng, 200, d, kind), cent[:200], cent[:200] * F(1.0000001), cent[:100] * F(-1),
+                        np.zeros((1, d), F)])
+    names = ["squared_euclidean", "euclidean", "manhattan", "cosine"]
+    for metric in rng.permutation(4)[:2]:
+        metric = int(metric)
+        t = TSVQ.from_tree(cent, tree["left"], tree["right"], Distance(names[metric]))
+        want_leaf, want_f16 = oracle.tsvq_encode(metric, Q, tree, threads=0)
+        msg = f"seed={seed} d={d} n={n} depth={depth} {kind} metric={metric}"
+        np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf, err_msg=msg)
+        np.testing.assert_array_equal(t.quantize_batch(Q).view(np.uint16), want_f16, err_msg=msg)
+
+
 @pytest.mark.parametrize("rep", range(SCALE))
 @pytest.mark.parametrize("kind", KINDS + ["nan_rows", "huge_then_small", "half_ulps"])
 @pytest.mark.parametrize("shape", [(40_000, 32, 4), (70_001, 64, 3), (120_000, 128, 2), (50_000, 100, 3), (45_000, 36, 3),
