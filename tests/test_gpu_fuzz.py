@@ -197,6 +197,71 @@ def test_fuzz_tsvq(oracle, seed):
     np.testing.assert_array_equal(t.quantize_batch(Q).view(np.uint16), want_f16)
 
 
+@pytest.mark.parametrize("seed", range(12 * SCALE))
+def test_fuzz_device_driven_run_equals_step_loop(seed):
+    """vqhip_kmeans_run (fused update, decisions on the device, pauses for reseeds) against the host-driven step loop
+    on random shapes -- fused and non-fused sub_dims, k from 2 to 256 --, data kinds, duplicate initial rows (empty
+    clusters -> pauses) and iteration budgets: identical iteration counts and pause counts, each path reproducible run
+    to run, codebooks equal within the update's summation tolerance (bit-equal while no subspace has retired: after
+    that the step loop re-packs the active subspaces over the waves while the run keeps its launch geometry and gates,
+    so the rows are grouped into other partial sums)."""
+    rng = np.random.default_rng(9000 + seed)
+    sd = int(rng.choice([4, 8, 12, 16, 24, 32, 10, 7]))
+    m = int(rng.integers(1, 9))
+    k = int(rng.choice([2, 5, 16, 64, 100, 256]))
+    n = int(rng.integers(max(2 * k, 300), 30_000))
+    d = m * sd
+    kind = KINDS[int(rng.integers(0, len(KINDS)))]
+    X = _draw_data(rng, n, d, kind)
+    if rng.random() < 0.5:
+        X = (np.round(X * 4) / 4).astype(F)  # coarse grid: early convergence of some subspaces
+    init = np.stack([rng.choice(n, k, replace=False) for _ in range(m)]).astype(np.uint64)
+    for _ in range(int(rng.integers(0, 4))):  # duplicate initial centroids -> empty clusters in the first iteration
+        s_, a_, b_ = int(rng.integers(0, m)), int(rng.integers(0, k)), int(rng.integers(0, k))
+        if a_ != b_:
+            X[init[s_, a_]] = X[init[s_, b_]]
+    ds = _lib.Dataset.from_host(X)
+    reseed = [[int(x) for x in rng.integers(0, n, 4096)] for _ in range(m)]
+    max_iters = int(rng.integers(1, 25))
+
+    def fit(use_run):
+        km = _lib.KMeans(ds, m, k)
+        km.init_from_rows(init)
+        active = np.ones(m, bool)
+        iters = np.zeros(m, np.int64)
+        its = [iter(r) for r in reseed]
+        pauses, done = 0, 0
+        while done < max_iters and active.any():
+            if use_run:
+                it, counts, changed, paused = km.run(max_iters - done)
+                iters += it
+                done += max(1, int(it.max()))
+            else:
+                counts, changed = km.step()
+                iters[active] += 1
+                done += 1
+                paused = bool(((counts == 0) & active[:, None]).any())
+            if paused:
+                pauses += 1
+                for s, j in np.argwhere((counts == 0) & active[:, None]):
+                    km.patch_from_row(int(s), int(j), next(its[s]))
+            active &= changed.astype(bool)
+            km.set_active(active)
+        cb = km.get_centroids()
+        km.close()
+        return cb, iters, pauses
+
+    cb_run, it_run, p_run = fit(True)
+    cb_step, it_step, p_step = fit(False)
+    cb_run2, it_run2, _ = fit(True)
+    ds.close()
+    msg = f"seed={seed} n={n} m={m} k={k} sd={sd} {kind} max_iters={max_iters}"
+    assert it_run.tolist() == it_step.tolist() and p_run == p_step, msg
+    assert cb_run.tobytes() == cb_run2.tobytes() and it_run.tolist() == it_run2.tolist(), "run is not reproducible: " + msg
+    scale = np.abs(cb_step).max() + 1e-30
+    assert np.abs(cb_run.astype(np.float64) - cb_step).max() <= 2e-5 * scale, msg
+
+
 @pytest.mark.parametrize("seed", range(32 * SCALE))
 def test_fuzz_tsvq_descent_screens(oracle, seed):
     """The screened descents of all four metrics (one or two screened sums per level, proven margins, exact

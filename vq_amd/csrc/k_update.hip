@@ -175,7 +175,11 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
     const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m, uint32_t k,
     uint32_t waves_per_block, uint64_t rows_per_chunk, const uint8_t *__restrict__ codes,
     const uint8_t *__restrict__ active, float *__restrict__ partial_sums,
-    uint32_t *__restrict__ partial_counts) {
+    uint32_t *__restrict__ partial_counts, uint32_t row_split) {
+    // row_split > 1 (few subspaces): waves_per_block / row_split subspaces per workgroup, and row_split waves per
+    // subspace, each adding its own part of the chunk's rows into its own slab -- a full workgroup where m alone
+    // would leave one or two waves (m = 1 used to fall back to the LDS-atomic kernel, whose sums depend on the order
+    // the atomics happen to land in)
     using Part = typename AccPart<VW>::T;
     constexpr uint32_t SD = KS * VW;
     constexpr uint32_t RPS = 64 / KS;  // rows per step; lanes >= RPS*KS idle when KS is not a power of two
@@ -183,7 +187,8 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t s = blockIdx.y * waves_per_block + wave;
+    const uint32_t subs_per_block = waves_per_block / row_split;
+    const uint32_t s = blockIdx.y * subs_per_block + wave % subs_per_block, part = wave / subs_per_block;
     if (s >= m) return;                       // no barrier below: waves are independent
     if (active && !active[s]) return;
     const uint32_t per_wave = (k * (SD + 1) + 3u) & ~3u;  // keeps every wave's base 16-byte aligned
@@ -197,9 +202,11 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
     // 16-byte slot of part gg of cluster c: xor swizzle (power-of-two KS) or rotation, so that the
     // KS parts of different clusters spread over the banks
     auto swz = [](uint32_t gg, uint32_t c) { return POW2 ? (gg ^ (c & (KS - 1))) : ((gg + c) % KS); };
-    const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_chunk;
-    uint64_t r1 = r0 + rows_per_chunk;
-    if (r1 > n) r1 = n;
+    const uint64_t rows_per_part = (rows_per_chunk + row_split - 1) / row_split;
+    uint64_t r0 = (uint64_t)blockIdx.x * rows_per_chunk + part * rows_per_part;
+    uint64_t r1 = min((uint64_t)blockIdx.x * rows_per_chunk + min((uint64_t)(part + 1) * rows_per_part, rows_per_chunk), n);
+    if (r0 > r1) r0 = r1;
+    const uint32_t slab = blockIdx.x * row_split + part;
     const float *px = X + (size_t)s * SD + VW * g;
     auto load_x = [&](uint64_t row) {
         return (lane_on && row < r1) ? *reinterpret_cast<const Part *>(px + row * d) : AccPart<VW>::zero();
@@ -255,13 +262,13 @@ __global__ __launch_bounds__(512) void k_accumulate_owned(
         }
     }
     // partial slab of this (row chunk, subspace): un-swizzle on the way out
-    float *ps = partial_sums + ((size_t)blockIdx.x * m + s) * k * SD;
+    float *ps = partial_sums + ((size_t)slab * m + s) * k * SD;
     for (uint32_t e = lane; e < k * KS; e += 64) {
         const uint32_t j = e / KS, gg = e % KS;
         const Part v = reinterpret_cast<const Part *>(sums + (size_t)j * SD)[swz(gg, j)];
         reinterpret_cast<Part *>(ps + (size_t)j * SD)[gg] = v;
     }
-    uint32_t *pcnt = partial_counts + ((size_t)blockIdx.x * m + s) * k;
+    uint32_t *pcnt = partial_counts + ((size_t)slab * m + s) * k;
     for (uint32_t e = lane; e < k; e += 64) pcnt[e] = cnts[e];
 }
 
@@ -613,20 +620,27 @@ int plan_update(uint32_t m, uint32_t k, uint32_t sd, uint64_t n, UpdatePlan *p) 
         uint64_t per_wave = ((uint64_t)k * (sd + 1) + 3) & ~3ull;
         uint32_t w = (uint32_t)(kLdsBudgetWords / per_wave);
         if (w > 8) w = 8;
+        const uint32_t w_fit = w;  // waves whose accumulators fit (<= 8)
         if (w > m) w = m;
         if (w > 0) w = (m + ((m + w - 1) / w) - 1) / ((m + w - 1) / w);  // same number of workgroups, evenly filled (m = 10: 5 + 5, not 8 + 2)
-        if (w < 2) w = 0;  // one wave per workgroup (m = 1, or accumulators filling the LDS): the atomic kernel's 16 waves win
-        p->owned_waves = w;
+        // few subspaces: the other waves of the workgroup take further parts of the rows (own slab each)
+        uint32_t split = (w > 0) ? w_fit / w : 1u;
+        if (split < 1) split = 1;
+        if (w * split < 2) w = 0;  // accumulators filling the LDS: one wave per workgroup, the atomic kernel's 16 waves win
+        p->owned_row_split = split;
+        p->owned_waves = w * split;
         if (w > 0) {
             uint32_t sub_groups = (m + w - 1) / w;
             // small accumulators (short sub-vectors, few clusters) leave LDS for 2-4 workgroups per CU: more row
             // chunks, so that the loads of several workgroups overlap
-            uint32_t per_cu = (uint32_t)(kLdsBudgetWords / (per_wave * w));
+            uint32_t per_cu = (uint32_t)(kLdsBudgetWords / (per_wave * w * split));
             per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
             uint32_t rc2 = (uint32_t)num_cus() * per_cu / sub_groups;
             if (rc2 < 1) rc2 = 1;
-            if (rc2 > max_rc) rc2 = (uint32_t)max_rc;
-            p->n_row_chunks = rc2;
+            const uint64_t max_rc2 = (max_rc + split - 1) / split;  // ~512 rows per wave, not per workgroup
+            if (rc2 > max_rc2) rc2 = (uint32_t)max_rc2;
+            if (rc2 < 1) rc2 = 1;
+            p->n_row_chunks = rc2 * split;  // slabs
         }
     }
     p->partial_floats = (size_t)m * k * sd;
@@ -644,11 +658,12 @@ static int launch_owned(const UpdatePlan &p, const float *X, uint64_t n, uint32_
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set.done();
     }
-    const uint64_t rows_per_chunk = (n + p.n_row_chunks - 1) / p.n_row_chunks;
+    const uint32_t split = p.owned_row_split, subs = wpb / split, chunks = p.n_row_chunks / split;  // n_row_chunks counts slabs
+    const uint64_t rows_per_chunk = (n + chunks - 1) / chunks;
     const size_t lds_bytes = (size_t)wpb * ((p.k * (p.sd + 1) + 3u) & ~3u) * 4;
-    dim3 grid(p.n_row_chunks, (p.m + wpb - 1) / wpb);
+    dim3 grid(chunks, (p.m + subs - 1) / subs);
     hipLaunchKernelGGL((k_accumulate_owned<KS, VW>), grid, dim3(wpb * 64), lds_bytes, stream, X, n, d, p.m,
-                       p.k, wpb, rows_per_chunk, codes, active, partial_sums, partial_counts);
+                       p.k, wpb, rows_per_chunk, codes, active, partial_sums, partial_counts, split);
     VQ_LAUNCH_CHECK("k_accumulate_owned");
     return VQHIP_OK;
 }

@@ -119,7 +119,8 @@ struct UpdatePlan {
     uint32_t n_k_ranges = 1;
     uint32_t n_sub_chunks = 0;
     uint32_t n_row_chunks = 0;
-    uint32_t owned_waves = 0;     // > 0: wave-owned (atomic-free) accumulate, subspaces per workgroup
+    uint32_t owned_waves = 0;     // > 0: wave-owned (atomic-free) accumulate, waves per workgroup = subspaces x row splits
+    uint32_t owned_row_split = 1; // waves of a workgroup that share a subspace, each with its own part of the chunk's rows and its own slab
     size_t partial_floats = 0;    // per row chunk: m*k*sd sums
     size_t partial_counts = 0;    // per row chunk: m*k counts
 };
