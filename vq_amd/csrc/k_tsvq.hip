@@ -928,8 +928,10 @@ __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ 
 // workgroup (chunk sums -> LDS -> offsets -> rewrite); only a guess is needed, so f64 order is free
 __global__ __launch_bounds__(1024) void k_fs_prefix(uint32_t d, const uint32_t *__restrict__ tile_base,
                                                     const uint32_t *__restrict__ n_tiles_of, double *__restrict__ tile_sum,
-                                                    const LevelInfo *__restrict__ lv) {
+                                                    const LevelInfo *__restrict__ lv, uint32_t *__restrict__ side_count) {
     __shared__ double part[32][kFsCols + 1];
+    // the side buffer's slot counter of this pass (k_fs_transduce hands slots out; the previous pass's chain is done)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *side_count = 0u;
     if (blockIdx.x >= lv->n_fast) return;
     const uint32_t c = blockIdx.y * kFsCols + (threadIdx.x & 31), lt = threadIdx.x >> 5;
     const uint32_t base = tile_base[blockIdx.x], nt = n_tiles_of[blockIdx.x];
@@ -963,8 +965,9 @@ __global__ __launch_bounds__(1024) void k_fs_prefix_var(const float *__restrict_
                                                         const uint32_t *__restrict__ n_tiles_of, NodeArrays na,
                                                         const double2 *__restrict__ tile_mom,
                                                         double *__restrict__ tile_sum,
-                                                        const LevelInfo *__restrict__ lv) {
+                                                        const LevelInfo *__restrict__ lv, uint32_t *__restrict__ side_count) {
     __shared__ double part[32][kFsCols + 1];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *side_count = 0u;  // as in k_fs_prefix
     if (blockIdx.x >= lv->n_fast) return;
     const uint32_t c = blockIdx.y * kFsCols + (threadIdx.x & 31), lt = threadIdx.x >> 5;
     const uint32_t node = fast_nodes[blockIdx.x];
@@ -2004,17 +2007,16 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         const uint32_t ub_tiles = std::min(tiles_max, n / kFsTile + ub_fast);
         const dim3 tgrid(ub_tiles * ncb), xgrid(std::min<uint32_t>(ub_tiles * ncb, (uint32_t)num_cus() * 2));  // persistent: two workgroups fit a CU's LDS
         const dim3 pgrid(ub_fast, ncb), cgrid(ub_fast, d);
-        VQ_HIP(hipMemsetAsync(fbk + 1, 0, 4, stream));
         if (mode == 0) {
             hipLaunchKernelGGL(k_fs_tile_sums<0>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts, fs_sample, policy, lvp);
-            hipLaunchKernelGGL(k_fs_prefix, pgrid, dim3(1024), 0, stream, d, fb, fc, ts, lvp);
+            hipLaunchKernelGGL(k_fs_prefix, pgrid, dim3(1024), 0, stream, d, fb, fc, ts, lvp, fbk + 1);
             hipLaunchKernelGGL(k_fs_transduce<0>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, lvp, na, ts, sm, side, side_cap, fbk + 1, mom, park_rel, policy);
             if (dbg) hipLaunchKernelGGL((k_fs_chain<0, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
             else hipLaunchKernelGGL((k_fs_chain<0, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
         } else {
             // the guess comes from the moments the mean pass of the same level left behind (same tile table: every node
             // long enough for the emulation has more than one row, so it is a split node whenever the level splits)
-            hipLaunchKernelGGL(k_fs_prefix_var, pgrid, dim3(1024), 0, stream, X, d, perm, fn, fb, fc, na, mom, ts, lvp);
+            hipLaunchKernelGGL(k_fs_prefix_var, pgrid, dim3(1024), 0, stream, X, d, perm, fn, fb, fc, na, mom, ts, lvp, fbk + 1);
             hipLaunchKernelGGL(k_fs_transduce<1>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, lvp, na, ts, sm, side, side_cap, fbk + 1, (double2 *)nullptr, 0.0f, (const uint32_t *)nullptr);
             if (dbg) hipLaunchKernelGGL((k_fs_chain<1, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
             else hipLaunchKernelGGL((k_fs_chain<1, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
