@@ -468,7 +468,7 @@ struct vqhip_tsvq {
     // screened descent (k_tsvq_screen.hip); use_screen = false -> exact walk only
     bool use_screen = false, last_screened = false;
     TsvqScreen scr;
-    DevBuf scr_w, scr_info, scr_mu, scr_wl, scr_count, scr_slot_node;
+    DevBuf scr_w, scr_info, scr_mu, scr_wl, scr_count, scr_slot_node, scr_node_slot;
 };
 
 // Per-node data of the screened descent, from the host copy of the tree (f64, rounded once).
@@ -604,6 +604,9 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     VQ_TRY(t->scr_slot_node.alloc((size_t)n_int * 4));
     VQ_HIP(hipMemcpyAsync(t->scr_slot_node.p, slot_node.data(), (size_t)n_int * 4, hipMemcpyHostToDevice, s));
     t->scr.slot_node = t->scr_slot_node.as<int32_t>();
+    VQ_TRY(t->scr_node_slot.alloc((size_t)n_nodes * 4));
+    VQ_HIP(hipMemcpyAsync(t->scr_node_slot.p, slot_of.data(), (size_t)n_nodes * 4, hipMemcpyHostToDevice, s));
+    t->scr.node_slot = t->scr_node_slot.as<int32_t>();
     VQ_TRY(t->scr_w.alloc(w.size() * 4));
     VQ_TRY(t->scr_info.alloc(info.size() * 4));
     VQ_TRY(t->scr_mu.alloc((size_t)dp * 4));

@@ -300,9 +300,14 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
                                                        const uint2 *__restrict__ wl,
                                                        const uint32_t *__restrict__ wl_count, uint32_t d_real,
                                                        int32_t *__restrict__ leaf_out, const uint4 *__restrict__ table16,
-                                                       uint4 *__restrict__ f16_out) {
+                                                       uint4 *__restrict__ f16_out, const float *__restrict__ w_g,
+                                                       const int4 *__restrict__ info_g, const int32_t *__restrict__ node_slot) {
     // d_real <= D: rows and centroids are d_real floats long; the pieces behind it count as zeros (a zero term
     // leaves a running sum that already holds a real term unchanged, so the reference's bits are kept)
+    // w_g / info_g / node_slot (cosine and Manhattan: their work lists are several per cent of the rows): below the
+    // node an entry was flagged at, every level is first put to the SAME screen test as in k_tsvq_screen_descend
+    // (two sums over the entry's 16 lanes, two accumulators per lane: the summation depth D/32 + 5 the margin was
+    // proven for) and only an undecided level pays the sequential chain -- 1.1 exact levels per entry instead of ~3
     constexpr int NQ = (D >= 64) ? D / 64 : 1;  // chunks of 16 lanes x V floats
     constexpr int V = D / NQ / 16;              // 2 (D = 32) or 4
     constexpr bool COS = MODE == kScrCos, MAN = MODE == kScrMan;
@@ -345,9 +350,84 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
             }
             na = sqrtf(dpp_move<0x121>(sa));  // lane 15 -> lane 0
         }
+        // screen thresholds of the row (cosine: |x|^ = 1.0001 x the reference's own f32 norm, in all 16 lanes)
+        float t_a = 0.0f, t_b = 0.0f;
+        if (COS && w_g) {
+            const float nb = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((lane & 48u) << 2), __float_as_int(na)));
+            t_a = (nb >= 1e-9f && nb <= 1e18f) ? nb * 1.0001f : __builtin_nanf("");
+            t_b = 0.999f * t_a;
+        }
+        bool fresh = true;  // the flagged node itself: the screen has already failed there
         while (__any(walking)) {
             const int32_t l = left[node], r = right[node];
             const bool both = (l >= 0) && (r >= 0);
+            int verdict = -1;  // 1 / 0: the screen proves left / right at this level
+            if ((COS || MAN) && w_g) {
+                const bool try_screen = walking && both && !fresh;
+                if (__any(try_screen)) {
+                    const int32_t sl = try_screen ? node_slot[node] : 0;
+                    const float *wl_ = w_g + (size_t)sl * 2 * D, *wr_ = wl_ + D;
+                    float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        float cl[V], cr[V];
+                        const uint32_t off = q * 16 * V + j * V;  // w rows are D wide, zeros behind d_real
+                        load_piece<V>(wl_ + off, cl);
+                        load_piece<V>(wr_ + off, cr);
+#pragma unroll
+                        for (int v = 0; v < V; ++v) {
+                            if (COS) {
+                                if (((q * V + v) & 1) == 0) {
+                                    a0 = fmaf(x[q][v], cl[v], a0);
+                                    b0 = fmaf(x[q][v], cr[v], b0);
+                                } else {
+                                    a1 = fmaf(x[q][v], cl[v], a1);
+                                    b1 = fmaf(x[q][v], cr[v], b1);
+                                }
+                            } else {
+                                if (((q * V + v) & 1) == 0) {
+                                    a0 = a0 + fabsf(x[q][v] - cl[v]);
+                                    b0 = b0 + fabsf(x[q][v] - cr[v]);
+                                } else {
+                                    a1 = a1 + fabsf(x[q][v] - cl[v]);
+                                    b1 = b1 + fabsf(x[q][v] - cr[v]);
+                                }
+                            }
+                        }
+                    }
+                    auto reduce16 = [](float v) {
+                        v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+                        v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+                        v = dpp_add<0x141>(v);  // row_half_mirror
+                        v = dpp_add<0x140>(v);  // row_mirror
+                        return v;
+                    };
+                    const float P_l = reduce16(a0 + a1), P_r = reduce16(b0 + b1);
+                    const float mrg = __int_as_float(info_g[sl].z);  // NaN: exact-only slot
+                    bool go_l, go_r;
+                    if (COS) {
+                        const float T = t_a * mrg, dlt = P_l - P_r;
+                        go_l = (dlt > T) || (P_r < -T);
+                        go_r = (-dlt > T) && (P_r > T) && (P_l < t_b);
+                    } else {
+                        const bool fin = (P_l < 1e37f) && (P_r < 1e37f);
+                        go_l = fin && (fmaf(P_l, mrg, P_l) <= P_r * 0.99999988f);
+                        go_r = fin && (fmaf(P_r, mrg, P_r) < P_l * 0.99999988f);
+                    }
+                    if (try_screen && (go_l || go_r)) verdict = go_l ? 1 : 0;
+                }
+            }
+            fresh = false;
+            const bool need_exact = walking && both && verdict < 0;
+            if (!__any(need_exact)) {  // every entry of the wave was decided by the screen (or passes through)
+                if (walking) {
+                    if (both) node = verdict ? l : r;
+                    else if (l >= 0) node = l;
+                    else if (r >= 0) node = r;
+                    else walking = false;
+                }
+                continue;
+            }
             const float *pl = centroids + (size_t)(both ? l : 0) * d_real;
             const float *pr = centroids + (size_t)(both ? r : 0) * d_real;
             float s1[NQ][V], s2[NQ][V];
@@ -408,6 +488,7 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
             int go_left = (dl <= dr) ? 1 : 0;  // left on ties, tsvq.rs:122
             // broadcast lane 0's verdict to its 16 lanes (row_shr chain would cost more than one readlane set)
             go_left = __builtin_amdgcn_ds_bpermute((int)((lane & 48u) << 2), go_left);
+            if (verdict >= 0) go_left = verdict;
             if (walking) {
                 if (both) node = go_left ? l : r;
                 else if (l >= 0) node = l;
@@ -497,8 +578,10 @@ template <int D, int MODE>
 static int launch_continue(const float *X, const float *centroids, const float *cnorm, const int32_t *left,
                            const int32_t *right, int euclid, const TsvqScreen &s, int32_t *leaf, hipStream_t stream,
                            uint32_t d_real, const uint4 *table16, uint4 *f16_out) {
+    const bool rescreen = (MODE != kScrL2) && s.node_slot != nullptr;  // the L2 family's lists are short
     hipLaunchKernelGGL((k_tsvq_continue<D, MODE>), dim3(1024), dim3(256), 0, stream, X, centroids, cnorm, left, right, euclid,
-                       s.slot_node, s.wl, s.wl_count, d_real, leaf, table16, f16_out);
+                       s.slot_node, s.wl, s.wl_count, d_real, leaf, table16, f16_out, rescreen ? s.w : nullptr,
+                       rescreen ? s.info : nullptr, rescreen ? s.node_slot : nullptr);
     VQ_LAUNCH_CHECK("k_tsvq_continue");
     return VQHIP_OK;
 }

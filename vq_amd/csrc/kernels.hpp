@@ -202,6 +202,7 @@ struct TsvqScreen {
     const float *w = nullptr;     // [n_int][d]  c_left - c_right of every two-child node; cosine: [n_int][2][d] unit vectors of the children
     const int4 *info = nullptr;   // [n_int]     {code_l, code_r, bits(b), bits(|w|)}; code >= 0 slot, < 0 leaf -1-code; cosine: {.., .., bits(margin M, NaN = exact-only), 0}
     const int32_t *slot_node = nullptr;  // [n_int] node index of a slot
+    const int32_t *node_slot = nullptr;  // [n_nodes] slot of a two-child node, -1 otherwise (the continuation's re-screen)
     int32_t start_slot = 0;       // slot the root resolves to
     const float *mu = nullptr;    // [d]         root centroid
     uint32_t n_int = 0, n_nodes = 0;
