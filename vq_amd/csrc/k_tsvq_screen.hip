@@ -301,10 +301,11 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
                                                        const uint32_t *__restrict__ wl_count, uint32_t d_real,
                                                        int32_t *__restrict__ leaf_out, const uint4 *__restrict__ table16,
                                                        uint4 *__restrict__ f16_out, const float *__restrict__ w_g,
-                                                       const int4 *__restrict__ info_g, const int32_t *__restrict__ node_slot) {
+                                                       const int4 *__restrict__ info_g, const int32_t *__restrict__ node_slot,
+                                                       const float *__restrict__ mu_g, float R, float coef_a, float coef_b) {
     // d_real <= D: rows and centroids are d_real floats long; the pieces behind it count as zeros (a zero term
     // leaves a running sum that already holds a real term unchanged, so the reference's bits are kept)
-    // w_g / info_g / node_slot (cosine and Manhattan: their work lists are several per cent of the rows): below the
+    // w_g / info_g / node_slot: below the
     // node an entry was flagged at, every level is first put to the SAME screen test as in k_tsvq_screen_descend
     // (two sums over the entry's 16 lanes, two accumulators per lane: the summation depth D/32 + 5 the margin was
     // proven for) and only an undecided level pays the sequential chain -- 1.1 exact levels per entry instead of ~3
@@ -350,8 +351,32 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
             }
             na = sqrtf(dpp_move<0x121>(sa));  // lane 15 -> lane 0
         }
-        // screen thresholds of the row (cosine: |x|^ = 1.0001 x the reference's own f32 norm, in all 16 lanes)
+        // screen thresholds of the row (cosine: |x|^ = 1.0001 x the reference's own f32 norm, in all 16 lanes;
+        // squared L2 / Euclidean: y = x - mu and T's two row terms exactly as in k_tsvq_screen_descend)
         float t_a = 0.0f, t_b = 0.0f;
+        float y[(!COS && !MAN) ? NQ : 1][V];
+        if (!COS && !MAN && w_g) {
+            float q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float mu[V];
+                load_piece<V>(mu_g + q * 16 * V + j * V, mu);  // D wide, zeros behind d_real
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    y[q][v] = x[q][v] - mu[v];
+                    if (((q * V + v) & 1) == 0) q0 = fmaf(y[q][v], y[q][v], q0);
+                    else q1 = fmaf(y[q][v], y[q][v], q1);
+                }
+            }
+            float ys = q0 + q1;
+            ys = dpp_add<0xB1>(ys);
+            ys = dpp_add<0x4E>(ys);
+            ys = dpp_add<0x141>(ys);
+            ys = dpp_add<0x140>(ys);
+            const float base = (__builtin_sqrtf(ys) + R) * 1.0001f;
+            t_a = fmaf(5.9604644775390625e-08f * coef_a * base, base, 1e-36f);
+            t_b = 5.9604644775390625e-08f * coef_b * base;
+        }
         if (COS && w_g) {
             const float nb = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((lane & 48u) << 2), __float_as_int(na)));
             t_a = (nb >= 1e-9f && nb <= 1e18f) ? nb * 1.0001f : __builtin_nanf("");
@@ -362,6 +387,33 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
             const int32_t l = left[node], r = right[node];
             const bool both = (l >= 0) && (r >= 0);
             int verdict = -1;  // 1 / 0: the screen proves left / right at this level
+            if (!COS && !MAN && w_g) {
+                const bool try_screen = walking && both && !fresh;
+                if (__any(try_screen)) {
+                    const int32_t sl = try_screen ? node_slot[node] : 0;
+                    const float *wp = w_g + (size_t)sl * D;
+                    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        float wv[V];
+                        load_piece<V>(wp + q * 16 * V + j * V, wv);
+#pragma unroll
+                        for (int v = 0; v < V; ++v) {
+                            if (((q * V + v) & 1) == 0) a0 = fmaf(y[q][v], wv[v], a0);
+                            else a1 = fmaf(y[q][v], wv[v], a1);
+                        }
+                    }
+                    float acc = a0 + a1;
+                    acc = dpp_add<0xB1>(acc);
+                    acc = dpp_add<0x4E>(acc);
+                    acc = dpp_add<0x141>(acc);
+                    acc = dpp_add<0x140>(acc);
+                    const int4 inf = info_g[sl];
+                    const float delta = fmaf(-2.0f, acc, __int_as_float(inf.z));
+                    const float T = fmaf(t_b, __int_as_float(inf.w), t_a);  // NaN / inf thresholds never pass
+                    if (try_screen && fabsf(delta) > T) verdict = (delta < 0.0f) ? 1 : 0;
+                }
+            }
             if ((COS || MAN) && w_g) {
                 const bool try_screen = walking && both && !fresh;
                 if (__any(try_screen)) {
@@ -578,10 +630,10 @@ template <int D, int MODE>
 static int launch_continue(const float *X, const float *centroids, const float *cnorm, const int32_t *left,
                            const int32_t *right, int euclid, const TsvqScreen &s, int32_t *leaf, hipStream_t stream,
                            uint32_t d_real, const uint4 *table16, uint4 *f16_out) {
-    const bool rescreen = (MODE != kScrL2) && s.node_slot != nullptr;  // the L2 family's lists are short
+    const bool rescreen = s.node_slot != nullptr;
     hipLaunchKernelGGL((k_tsvq_continue<D, MODE>), dim3(1024), dim3(256), 0, stream, X, centroids, cnorm, left, right, euclid,
                        s.slot_node, s.wl, s.wl_count, d_real, leaf, table16, f16_out, rescreen ? s.w : nullptr,
-                       rescreen ? s.info : nullptr, rescreen ? s.node_slot : nullptr);
+                       rescreen ? s.info : nullptr, rescreen ? s.node_slot : nullptr, s.mu, s.R, s.coef_a, s.coef_b);
     VQ_LAUNCH_CHECK("k_tsvq_continue");
     return VQHIP_OK;
 }
