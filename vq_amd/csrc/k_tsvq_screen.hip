@@ -198,10 +198,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
                     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;  // four chains per lane: depth NCH + 5 with the reductions
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) {
-                        a0 = a0 + fabsf(y[c].x - wv[c].x);
-                        a1 = a1 + fabsf(y[c].y - wv[c].y);
-                        a2 = a2 + fabsf(y[c].z - wv[c].z);
-                        a3 = a3 + fabsf(y[c].w - wv[c].w);
+                        // the differences two at a time (v_pk_add_f32), |.| as a source modifier of the additions
+                        const f32x2 d01 = f32x2{y[c].x, y[c].y} - f32x2{wv[c].x, wv[c].y};
+                        const f32x2 d23 = f32x2{y[c].z, y[c].w} - f32x2{wv[c].z, wv[c].w};
+                        a0 = a0 + fabsf(d01.x);
+                        a1 = a1 + fabsf(d01.y);
+                        a2 = a2 + fabsf(d23.x);
+                        a3 = a3 + fabsf(d23.y);
                     }
                     P[v] = allreduce((a0 + a1) + (a2 + a3));
                     continue;
