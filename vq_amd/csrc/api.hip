@@ -31,8 +31,12 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// per-device facts, published once per device: std::call_once (threads of different handles may make their first call
+// at the same time)
 static int g_num_cus[64];
-static int g_dev_ok[64];  // 0 unknown, 1 gfx950, -1 other
+static int g_dev_ok[64];  // 0 unknown (probe failed), 1 gfx950, -1 other
+static char g_dev_arch[64][64];
+static std::once_flag g_dev_once[64];
 
 int require_gfx950() {
     int ndev = 0;
@@ -43,16 +47,16 @@ int require_gfx950() {
     int dev = 0;
     VQ_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(VQHIP_ERR_NO_DEVICE, "device index %d out of range", dev);
-    if (g_dev_ok[dev] == 0) {
+    std::call_once(g_dev_once[dev], [dev]() {
         hipDeviceProp_t prop;
-        VQ_HIP(hipGetDeviceProperties(&prop, dev));
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return;  // g_dev_ok stays 0: reported below
         g_num_cus[dev] = prop.multiProcessorCount;
+        strncpy(g_dev_arch[dev], prop.gcnArchName, sizeof(g_dev_arch[dev]) - 1);
         g_dev_ok[dev] = (strncmp(prop.gcnArchName, "gfx950", 6) == 0) ? 1 : -1;
-        if (g_dev_ok[dev] < 0)
-            tls().last_error = std::string("device is ") + prop.gcnArchName + ", libvqhip is built for gfx950 only";
-    }
+    });
+    if (g_dev_ok[dev] == 0) return fail(VQHIP_ERR_NO_DEVICE, "could not read the properties of HIP device %d", dev);
     if (g_dev_ok[dev] < 0)
-        return fail(VQHIP_ERR_NO_DEVICE, "current HIP device is not gfx950; libvqhip targets MI355X only");
+        return fail(VQHIP_ERR_NO_DEVICE, "current HIP device is %s, not gfx950; libvqhip targets MI355X only", g_dev_arch[dev]);
     return VQHIP_OK;
 }
 
