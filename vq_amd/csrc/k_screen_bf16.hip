@@ -507,21 +507,26 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
         // the phase -- no LDS wait in front of an MFMA).
         f32x16 acc[4];
         // reduce 16 values of a finished tile, interleaved with the NMF MFMAs of the next tile.
-        // A lone wave issues one VALU instruction per ~6 cycles, so the epilogue is cut to THREE
-        // instructions per value with no compare/select (and no VCC traffic): the value's index
-        // (6 bits, an inline constant) replaces the 6 low mantissa bits, then
-        //     q2 = med3(q1, q2, pk);  q1 = min(q1, pk)
-        // track the two smallest packed values; the winner's index is read back from q1's low
-        // bits.  The perturbation (< 2^-18 relative) is paid for in the margin (+128 * 2^-24).
-        // Values 64..127 reuse the 6-bit codes; which half won is recovered from a snapshot of q1
+        // A lone wave issues one VALU instruction per ~4.4 cycles and the epilogue is most of the step's instructions,
+        // so it is cut to 2.5 per value, none of them a compare / select (no VCC traffic): the value's index (6 bits,
+        // an inline constant) replaces the 6 low mantissa bits (v_and_or_b32), then TWO packed values a, b enter a
+        // chain's (q1 <= q2 = the two smallest so far) in three instructions:
+        //     t = med3(q1, a, b);  q1 = min3(q1, a, b);  q2 = min(q2, t)
+        // (q1 <= q2 and min(q1, a, b) <= q1, so the smallest of {q1, q2, a, b} is min3(q1, a, b) and the next one is
+        // the smaller of q2 and the median of {q1, a, b}) -- the same two values the one-at-a-time form
+        // q2 = med3(q1, q2, v); q1 = min(q1, v) leaves, at 1.5 instead of 2 instructions per value.  The winner's
+        // index is read back from q1's low bits.  The perturbation (< 2^-18 relative) is paid for in the margin
+        // (+128 * 2^-24).  Values 64..127 reuse the 6-bit codes; which half won is recovered from a snapshot of q1
         // taken after the first 64 values.
-        auto reduce4 = [&](const f32x16 &fin, int ifin, int g4) {
+        auto reduce8 = [&](const f32x16 &fin, int ifin, int g8) {  // values 8 g8 .. 8 g8 + 7 of the tile: two per chain
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint32_t code = (uint32_t)((16 * ifin + 4 * g4 + r) & 63);
-                const float pk = __uint_as_float((__float_as_uint(fin[4 * g4 + r]) & idx_mask) | code);
-                q2[r] = __builtin_amdgcn_fmed3f(q1[r], q2[r], pk);
-                q1[r] = __builtin_amdgcn_fmed3f(q1[r], pk, ninf);
+                const uint32_t ca = (uint32_t)((16 * ifin + 8 * g8 + r) & 63), cb = (uint32_t)((16 * ifin + 8 * g8 + 4 + r) & 63);
+                const float pa = __uint_as_float((__float_as_uint(fin[8 * g8 + r]) & idx_mask) | ca);
+                const float pb = __uint_as_float((__float_as_uint(fin[8 * g8 + 4 + r]) & idx_mask) | cb);
+                const float t = __builtin_amdgcn_fmed3f(q1[r], pa, pb);
+                q1[r] = __builtin_fminf(__builtin_fminf(q1[r], pa), pb);  // v_min3_f32
+                q2[r] = __builtin_fminf(q2[r], t);
             }
         };
         // A operands are named as AGPRs while they fit (256); the image of sub_dim 24 at k = 256 is 288
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
 #pragma unroll
                 for (int f = 0; f < (NMF > kGroups ? NMF : kGroups); ++f) {
                     if (i + 2 < NT32 && f < NMF) mfma(acc[(i + 2) & 3], (i + 2 < NT32) ? i + 2 : 0, f);
-                    if (f < kGroups) reduce4(acc[i & 3], i, f);
+                    if (f < kGroups && (f & 1)) reduce8(acc[i & 3], i, f >> 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {  // longer chains (sub_dim 24): reduce group g follows MFMA ceil((g+1) NMF / 4) - 1
@@ -573,8 +578,8 @@ __global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_ass
                 for (int f = 0; f < NMF; ++f) {
                     if (i + 2 < NT32) mfma(acc[(i + 2) & 3], (i + 2 < NT32) ? i + 2 : 0, f);
 #pragma unroll
-                    for (int g4 = 0; g4 < kGroups; ++g4)
-                        if (f == ((g4 + 1) * NMF + kGroups - 1) / kGroups - 1) reduce4(acc[i & 3], i, g4);
+                    for (int g8 = 0; g8 < kGroups / 2; ++g8)
+                        if (f == ((g8 + 1) * NMF + kGroups / 2 - 1) / (kGroups / 2) - 1) reduce8(acc[i & 3], i, g8);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
