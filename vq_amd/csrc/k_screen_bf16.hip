@@ -67,9 +67,9 @@ __host__ __device__ inline void split3(float v, uint32_t (&part)[3]) {
 // stores, work-list append) costing a third of the kernel.  With v_mfma_f32_32x32x16_bf16 a lane's
 // column is one of 32 rows and its 16 accumulator registers are 16 centroids, so (a) a wave step
 // covers 32 rows, (b) only lanes l and l+32 share a row -- ONE v_permlane32_swap level -- and (c)
-// the tail is paid once per 32 rows.  The epilogue stays single-pass (compare + med3 + two selects
-// per value) and is interleaved by hand with the next centroid tile's MFMA chain (a chain of
-// 32x32x16 MFMAs on one accumulator issues back to back at full rate).
+// the tail is paid once per 32 rows.  The epilogue stays single-pass (index tag + pairwise med3 / min3 update,
+// 2.5 VALU instructions per value, see reduce8) and is interleaved by hand with the next centroid tile's MFMA chain
+// (a chain of 32x32x16 MFMAs on one accumulator issues back to back at full rate).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // A image for the 32x32x16 form: [m][NT32][NMF][4 dwords][64 lanes]; lane (h = l>>5, c = l&31),
