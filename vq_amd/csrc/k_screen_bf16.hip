@@ -202,8 +202,11 @@ __global__ __launch_bounds__(256) void k_prepare_bf16_x32(const float *__restric
 // instantiated ones rides on the next one up instead of the exact engine.  PVW = floats per load part, as the
 // sub-vectors' alignment allows: 4 (sdr % 4 == 0), 2 (even sdr) or 1.
 // copies of the fused update's LDS sums per wave: 2 while four (or eight) waves' accumulators still fit a CU
+// A image of NT32 tiles at sub_dim SD: NT32 x ceil(3 SD / 8) MFMA operands of 4 registers.  Up to 96 registers two
+// waves fit a SIMD (k <= 128 at sub_dim 16: 0.30 vs 0.37 ms at C2 / k = 128; k <= 256 at sub_dim 8 -- C3 and C5)
+__host__ __device__ constexpr bool x32_two_waves(int sd, int nt32) { return nt32 * ((6 * (sd / 2) + 7) / 8) * 4 <= 96; }
 __host__ __device__ constexpr uint32_t x32_acc_copies(int sd, int nt32) {
-    const uint32_t waves = (nt32 <= 4 && sd <= 16) ? 8u : 4u;
+    const uint32_t waves = x32_two_waves(sd, nt32) ? 8u : 4u;
     return (waves * (uint32_t)nt32 * 32u * (2u * (uint32_t)sd + 1u) * 4u <= 140u * 1024u) ? 2u : 1u;
 }
 
@@ -214,8 +217,7 @@ __host__ __device__ constexpr uint32_t x32_acc_copies(int sd, int nt32) {
 // 32-row step that share a cluster are serialised by rank (earlier rows first): rank = ticket - count-before-the-step,
 // the ticket from a returning LDS add on the cluster's counter -- which is the count the update needs anyway.
 template <int SD, int NT32, int G = 1, int PVW = 0, bool ACC = false>
-// k <= 128 at sub_dim <= 16: the A image is <= 96 registers, two waves fit a SIMD (0.30 vs 0.37 ms at C2 / k=128)
-__global__ __launch_bounds__(kBlock, (NT32 <= 4 && SD <= 16) ? 2 : 1) void k_assign_screen_bf16_x32(
+__global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_assign_screen_bf16_x32(
     const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m,
     const uint32_t *__restrict__ prepA32, const float *__restrict__ prepCn, uint32_t cn_stride,
     const float *__restrict__ meta, const uint32_t *__restrict__ sub_list, uint32_t n_sub,
@@ -877,7 +879,7 @@ template <int SD, int NT32, int G = 1, int PVW = 0, bool ACC = false>
 int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stream, uint32_t groups_rt = 0) {
     const uint32_t groups = (G > 0) ? (uint32_t)G : groups_rt;  // G == 0: run-time group count (k > 256)
     const uint64_t n_steps = (a.n + 31) / 32;
-    const uint32_t waves_per_simd = (NT32 <= 4 && SD <= 16) ? 2 : 1;  // small A images leave room for two
+    const uint32_t waves_per_simd = x32_two_waves(SD, NT32) ? 2 : 1;  // small A images leave room for two
     const uint32_t n_virt = a.n_sub * groups;
     uint64_t want_waves = (uint64_t)num_cus() * kWavesPerBlock * waves_per_simd;
     const uint64_t max_useful = n_steps * n_virt;
