@@ -158,16 +158,30 @@ def other_configs(_lib, torch, engine):
         ds = _lib.Dataset.synthetic(n, d, DATA_SEED, 0)
         km = _lib.KMeans(ds, m, k)
         km.set_engine(engine)
-        km.init_from_rows(strided_init(n, m, k).astype(np.uint64))
+        init = strided_init(n, m, k).astype(np.uint64)
+        km.init_from_rows(init)
         km.run(TRAIN_ITERS)
-        km.run(10)
-        _lib.synchronize()
+        cb = km.get_centroids()
         iters = 10
+
+        def restart():  # every timed run is the first `iters` iterations of a fit: all m subspaces execute all of them
+            km.init_from_rows(init)
+            km.set_active(np.ones(m, np.uint8))
+
+        for _ in range(2):
+            restart()
+            km.run(iters)
+        restart()
+        _lib.synchronize()
         t0 = time.perf_counter()
         it, _, _, paused = km.run(iters)
         _lib.synchronize()
-        km_ms = (time.perf_counter() - t0) * 1e3 / max(1, int(it.max()))
-        cb = km.get_centroids()
+        km_dt = time.perf_counter() - t0
+        it = np.asarray(it, np.int64)
+        km_iters = max(1, int(it.max()))
+        km_ms = km_dt * 1e3 / km_iters
+        km_active = float(it.sum()) / km_iters  # subspaces that executed, averaged over the timed iterations
+        km_valid = bool(not paused and int(it.min()) == int(it.max()) == iters)
         km.close()
         enc = _lib.PQEncoder(cb, metric)
         enc.set_engine(engine)
@@ -195,8 +209,12 @@ def other_configs(_lib, torch, engine):
                 "step_frac": flop / (step_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "recheck_avg_launch_ms": recheck_ms / max(calls, 1), "flop_per_launch": flop}),
             "kmeans_ms_per_iter": km_ms, "kmeans_iter_per_s": 1e3 / km_ms,
-            "kmeans_roofline": mfma_roofline(flop, km_ms, extra={
-                "flop_per_iter": flop, "note": "whole Lloyd iteration (assign + fused update + reduce + finalize), decisions on the device"}),
+            "kmeans_iters_timed": [int(it.min()), int(it.max())], "kmeans_active_subspaces": km_active,
+            "kmeans_paused": bool(paused), "kmeans_valid": km_valid,
+            "kmeans_roofline": mfma_roofline(flop * km_active / m, km_ms, extra={
+                "flop_per_iter": flop * km_active / m,
+                "note": "whole Lloyd iteration (assign + fused update + reduce + finalize), decisions on the device; flop scaled by "
+                        "the subspaces that executed"}),
         }
         enc.close()
         ds.close()
@@ -216,6 +234,22 @@ def other_configs(_lib, torch, engine):
         _lib.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
     build_ms = sorted(ts)[len(ts) // 2]
+    # the hard case for the build's exact column sums: zero-mean rows (real embeddings are)
+    g = torch.Generator(device="cuda").manual_seed(DATA_SEED)
+    Xz = torch.randn((n, d), device="cuda", generator=g).contiguous()
+    torch.cuda.synchronize()
+    dsz = _lib.Dataset.from_device(Xz.data_ptr(), n, d)
+    build_tree(dsz, depth)
+    tz = []
+    for _ in range(3):
+        _lib.synchronize()
+        t0 = time.perf_counter()
+        build_tree(dsz, depth)
+        _lib.synchronize()
+        tz.append((time.perf_counter() - t0) * 1e3)
+    build_ms_zero_mean = sorted(tz)[len(tz) // 2]
+    dsz.close()
+    del Xz
     split_levels = depth
     build_bytes = 4.0 * n * d * (2 * split_levels + 1)  # mean + variance pass per split level, one leaf-mean pass
     t = TSVQ.from_tree(cent, left, right, Distance.euclidean())
@@ -242,6 +276,8 @@ def other_configs(_lib, torch, engine):
         "rows": n, "dim": d, "depth": depth, "nodes": int(len(left)),
         "build_ms": build_ms, "build_ms_all": ts,
         "build_roofline": hbm_roofline(build_bytes, build_ms, {"note": "4*N*D bytes x (2 passes x 8 split levels + 1 leaf-mean pass)"}),
+        "build_ms_zero_mean": build_ms_zero_mean, "build_ms_zero_mean_all": tz,
+        "build_roofline_zero_mean": hbm_roofline(build_bytes, build_ms_zero_mean, {"note": "same shape on N(0,1) rows"}),
         "encode_vectors_per_s": n / (enc_ms * 1e-3), "encode_ms_per_step": enc_ms,
         "encode_roofline": hbm_roofline((4.0 * d + 2.0 * d) * n, enc_ms, {"note": "4*D bytes in + 2*D bytes (f16 reconstruction) out per vector"}),
     }
@@ -249,178 +285,381 @@ def other_configs(_lib, torch, engine):
     return out
 
 
-def main():
+def free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])
+
+
+def launch_ranks(n_ranks: int, argv, worker=None, grace_s: float = 20.0) -> int:
+    """`python bench.py --gpus N` without a launcher: start N FRESH rank processes, one per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, the same command line), relay rank 0's one JSON line
+    to stdout and return non-zero if any rank failed.  This process never imports torch or loads libvqhip, so it
+    never initialises a GPU, and it never exec()s: the ranks are children (the pool forbids exec from a process that
+    has touched the GPU, and a parent that held a HIP context would share its devices with the ranks)."""
+    import subprocess
+    import threading
+
+    worker = worker or [sys.executable, os.path.abspath(__file__)]
+    port = free_port()
+    procs, lines = [], []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "VQ_BENCH_LAUNCHER": str(os.getpid())})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+        procs.append(subprocess.Popen(list(worker) + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr))
+
+    def pump():
+        for raw in procs[0].stdout:
+            lines.append(raw.decode("utf-8", "replace").rstrip("\n"))
+
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    failed_at, rc = None, 0
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.1)
+        bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if bad and failed_at is None:
+            failed_at, rc = time.monotonic(), bad[0]
+        if failed_at is not None and time.monotonic() - failed_at > grace_s:
+            for p in procs:  # a rank died: its peers may wait in a collective for ever -- stop exactly the PIDs we started
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    t.join(timeout=5.0)
+    for p in procs:
+        if p.returncode != 0 and rc == 0:
+            rc = p.returncode
+    js = [ln for ln in lines if ln.startswith("{")]
+    if rc == 0 and not js:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 3
+    if js:
+        print(js[-1], flush=True)
+    return rc
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="C2", help="workload (default: the metric's, C2)")
-    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: the workload's rows PER GPU (default); strong: the workload's rows in all, sharded over the GPUs")
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (weak) / in all (strong); default: the workload's")
     ap.add_argument("--kmeans-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C3 / C4 block")
-    ap.add_argument("--collective", choices=["native", "torch"], default="native",
-                    help="multi-GPU all-reduce below the C ABI (vqhip_kmeans_run_sharded) or through torch.distributed")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C3 / C4 block (N=1) and the strong-scaling / C5 blocks (N>1)")
+    ap.add_argument("--collective", choices=["native", "torch", "gloo"], default="native",
+                    help="multi-GPU all-reduce: below the C ABI (vqhip_kmeans_run_sharded, RCCL), through torch.distributed "
+                         "nccl (= RCCL), or through gloo with the slab staged on the host (ranks may then share a GPU: tests)")
     ap.add_argument("--engine", choices=["auto", "exact", "mfma", "bf16"], default="auto")
-    args = ap.parse_args()
-    wl = WORKLOADS[args.config]
-    n, dim, m_, k_ = (args.rows or wl["rows"]), wl["dim"], wl["m"], wl["k"]
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and (args.gpus > 1 or os.environ.get("VQ_BENCH_SPAWN") == "1"):
+        # no launcher around us: be the launcher (before torch / libvqhip are imported: this process stays off the GPU)
+        sys.exit(launch_ranks(args.gpus, argv))
+    sys.exit(worker(args))
+
+
+class Ranks:
+    """control plane of the run: barrier, max over ranks, object broadcast.  A gloo group on the host (no second RCCL
+    communicator next to the library's), or none for one rank."""
+
+    def __init__(self, world, rank):
+        self.world, self.rank, self.dist = world, rank, None
+        if world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def reduce(self, x: float, op="max") -> float:
+        if not self.dist:
+            return x
+        import torch
+
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op={"max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN, "sum": self.dist.ReduceOp.SUM}[op])
+        return float(t.item())
+
+    def bcast(self, obj):
+        if not self.dist:
+            return obj
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+def measure(args, ranks, wl_name, scaling, *, torch, _lib, engine, ncomm, collective, steps, warmup, want_f16=True, group=None):
+    """One workload on this rank's shard: codebooks from TRAIN_ITERS global Lloyd iterations, then the timed k-means
+    iterations (every timed run starts from the same initial centroids, so all m subspaces execute every iteration)
+    and the timed encode passes.  Returns (dict for the line, codebooks, handles to keep)."""
+    import numpy as np
+
+    from vq_amd.sharded import HipShard, ShardedKMeans, shard_rows
+
+    wl = WORKLOADS[wl_name]
+    world, rank = ranks.world, ranks.rank
+    dim, m_, k_ = wl["dim"], wl["m"], wl["k"]
+    rows = args.rows if (args.rows and wl_name == args.config) else wl["rows"]
+    if scaling == "weak":
+        n_global, n, offset = rows * world, rows, rank * rows
+    else:
+        n_global = rows
+        offset, n = shard_rows(n_global, world, rank)
+    ds = _lib.Dataset.synthetic(n, dim, DATA_SEED, offset)
+    init = strided_init(n_global, m_, k_)
+    sync = torch.cuda.synchronize
+    out = {"rows_global": n_global, "rows_this_rank": n, "dim": dim, "m": m_, "k": k_, "scaling": scaling}
+    iters_req = args.kmeans_iters
+
+    if collective in ("native", "none"):
+        km = _lib.KMeans(ds, m_, k_)
+        km.set_engine(engine)
+        km.init_from_global_rows(ncomm, init, offset)
+        km.run(TRAIN_ITERS, ncomm)
+        codebooks = km.get_centroids()
+        for _ in range(3):  # untimed: the first ~30 iterations of a process run 10 % slow (clocks ramping up from idle)
+            km.run(10, ncomm)
+
+        def restart():
+            km.init_from_global_rows(ncomm, init, offset)
+            km.set_active(np.ones(m_, np.uint8))
+
+        restart()
+        km.run(iters_req, ncomm)
+        restart()
+        sync()
+        ranks.barrier()
+        t0 = time.perf_counter()
+        it, counts, _, paused = km.run(iters_req, ncomm)
+        sync()
+        ranks.barrier()
+        km_dt = time.perf_counter() - t0
+        it = np.asarray(it, np.int64)
+        # the collective alone: HIP events around vqhip_kmeans_allreduce on the library's stream (= torch's current one)
+        ar_ms = None
+        if ncomm is not None and (ncomm.info()[0] > 1 or os.environ.get("VQ_BENCH_FORCE_COMM") == "1"):
+            km.accumulate()
+            for _ in range(3):
+                km.allreduce(ncomm)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 20
+            sync()
+            ranks.barrier()
+            e0.record()
+            for _ in range(reps):
+                km.allreduce(ncomm)
+            e1.record()
+            sync()
+            ar_ms = ranks.reduce(e0.elapsed_time(e1) / reps, "max")
+            km.finalize()
+        km.close()
+    else:  # the all-reduce through torch.distributed (nccl = RCCL; gloo stages the slab on the host)
+        from vq_amd.sharded import Comm
+
+        comm = Comm(force=True, group=group)
+        shard = HipShard(ds, m_, k_, offset, engine)
+        skm = ShardedKMeans(shard, n_global, comm)
+        skm.init_from_global_rows(init)
+        for _ in range(TRAIN_ITERS):
+            skm.step()
+        codebooks = shard.get_centroids()
+        for _ in range(10):
+            skm.step()
+        skm.init_from_global_rows(init)
+        sync()
+        ranks.barrier()
+        t0 = time.perf_counter()
+        counts = None
+        for _ in range(iters_req):
+            counts, _ = skm.step()
+        sync()
+        ranks.barrier()
+        km_dt = time.perf_counter() - t0
+        it, paused, ar_ms = np.full(m_, iters_req, np.int64), False, None
+        shard.close()
+        _lib.set_stream(torch.cuda.current_stream().cuda_stream)
+    km_dt = ranks.reduce(km_dt, "max")
+    km_iters = max(1, int(it.max()))
+    # a run that paused on an empty cluster or retired subspaces did less than m subspaces x iterations of work:
+    # the per-iteration flop is scaled by the subspaces that really executed (VERDICT r2 item 6)
+    active_avg = float(it.sum()) / km_iters
+    km_ms = km_dt / km_iters * 1e3
+    flop_row = 2.0 * k_ * dim
+    out.update({
+        "kmeans_ms_per_iter": km_ms, "kmeans_iter_per_s": km_iters / km_dt,
+        "kmeans_iters_requested": iters_req, "kmeans_iters_timed": [int(it.min()), int(it.max())],
+        "kmeans_active_subspaces": active_avg, "kmeans_paused": bool(paused),
+        "kmeans_valid": bool(not paused and int(it.min()) == int(it.max()) == iters_req),
+        "kmeans_counts_sum_per_subspace": [int(counts[0].sum()), int(counts[-1].sum())] if counts is not None else None,
+        "kmeans_allreduce_ms": ar_ms,
+        "codebooks_abs_sum": float(np.abs(codebooks.astype(np.float64)).sum()),  # same on every rank; ~equal for any sharding
+        "kmeans_roofline": mfma_roofline(flop_row * n * active_avg / m_, km_ms, extra={
+            "flop_per_iter_per_gpu": flop_row * n * active_avg / m_,
+            "note": "per GPU: 2*N*k*D flop of one Lloyd iteration (assign + fused update + all-reduce + finalize) x the fraction "
+                    "of subspaces that executed / its wall time; X is read once per iteration (4*N*D bytes, SURVEY.md 8(d))"}),
+    })
+
+    # ---- encode: the timed region -------------------------------------------------------
+    enc = _lib.PQEncoder(codebooks, _lib.SQUARED_EUCLIDEAN)
+    enc.set_engine(engine)
+    codes = torch.empty((n, m_), dtype=torch.uint8, device="cuda")
+    xptr = ds.device_ptr
+    for _ in range(warmup):
+        enc.encode_device(xptr, n, codes.data_ptr(), None)
+    sync()
+    ranks.barrier()
+    _lib.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        enc.encode_device(xptr, n, codes.data_ptr(), None)
+    sync()
+    ranks.barrier()
+    dt = time.perf_counter() - t0
+    calls, primary_ms, recheck_ms = _lib.profile_collect()
+    _lib.set_profiling(False)
+    rechecked, used_engine = _lib.last_assign_stats()
+    dt = ranks.reduce(dt, "max")
+    kern_ms = ranks.reduce(primary_ms / max(calls, 1), "max")
+    step_ms = dt / steps * 1e3
+    sd = dim // m_
+    kernel_name = {2: f"k_assign_screen<{sd},16>", 3: f"k_assign_screen_bf16_x32<{sd},8,1,0,false>"}.get(used_engine, "k_assign_exact")
+    out.update({
+        "encode_vectors_per_s": n_global * steps / dt, "encode_ms_per_step": step_ms,
+        "encode_engine": {1: "exact", 2: "fp32_mfma_screen+exact_recheck", 3: "bf16x3_mfma_screen+exact_recheck"}.get(used_engine, str(used_engine)),
+        "recheck_fraction": rechecked / float(max(1, n * m_)),
+        "encode_roofline": mfma_roofline(flop_row * n, kern_ms, kernel=kernel_name, extra={
+            "step_frac": flop_row * n / (step_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "recheck_avg_launch_ms": recheck_ms / max(calls, 1), "flop_per_launch": flop_row * n,
+            "algorithmic_bytes_per_launch": (4.0 * dim + m_) * n}),
+        "codes_checksum_rank0": int(codes.to(torch.int64).sum().item()),
+    })
+    if want_f16:  # same pass with the reference-shaped f16 reconstruction written too
+        f16 = torch.empty((n, dim), dtype=torch.float16, device="cuda")
+        for _ in range(2):
+            enc.encode_device(xptr, n, codes.data_ptr(), f16.data_ptr())
+        sync()
+        t0 = time.perf_counter()
+        reps = max(3, steps // 4)
+        for _ in range(reps):
+            enc.encode_device(xptr, n, codes.data_ptr(), f16.data_ptr())
+        sync()
+        out["encode_f16_out_vectors_per_s_per_gpu"] = n * reps / (time.perf_counter() - t0)
+        del f16
+    return out, codebooks, (ds, enc, codes)
+
+
+def worker(args) -> int:
     # stdout carries exactly ONE line, the JSON: native libraries that write to fd 1 (RCCL prints a version banner when a
     # communicator is created) are sent to stderr for the whole run
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
-    from vq_amd import _lib
-    from vq_amd.sharded import Comm, HipShard, ShardedKMeans, native_comm_from_torch
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment", file=sys.stderr)
+        return 2
+
+    import numpy as np
+    import torch
+
+    from vq_amd import _lib
+
     if not torch.cuda.is_available():
         print("bench.py needs a MI355X (no GPU visible); there is no CPU fallback", file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(local_rank)
+        return 2
+    # VQ_BENCH_SHARE_GPU=1: every rank on device 0 (tests of the N > 1 plumbing on a one-GPU box; RCCL refuses two ranks
+    # on one device, so only with --collective gloo)
+    share = os.environ.get("VQ_BENCH_SHARE_GPU") == "1"
+    if share and world > 1 and args.collective != "gloo":
+        print("bench.py: VQ_BENCH_SHARE_GPU=1 needs --collective gloo (RCCL wants one GPU per rank)", file=sys.stderr)
+        return 2
+    device = 0 if share else local_rank
+    if device >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} wants GPU {device}, {torch.cuda.device_count()} visible", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(device)
+    ranks = Ranks(world, rank)
     # VQ_BENCH_FORCE_COMM=1: keep the per-iteration RCCL all-reduce on for a single rank (measures what the
     # collective path adds to an iteration without a second GPU)
     force_comm = world == 1 and os.environ.get("VQ_BENCH_FORCE_COMM") == "1"
-    if world > 1 or force_comm:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29512")
-        if force_comm:
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     _lib.load()
-    _lib.set_device(local_rank)
+    _lib.set_device(device)
     stream = torch.cuda.Stream()
     engine = {"auto": _lib.ENGINE_AUTO, "exact": _lib.ENGINE_EXACT, "mfma": _lib.ENGINE_MFMA,
               "bf16": _lib.ENGINE_MFMA_BF16}[args.engine]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    collective = "none"
     with torch.cuda.stream(stream):
         _lib.set_stream(stream.cuda_stream)
-        n_global = n * world
-        ds = _lib.Dataset.synthetic(n, dim, DATA_SEED, rank * n)
-        init = strided_init(n_global, m_, k_)
-
-        # ---- codebooks: a few (untimed) global Lloyd iterations from strided init rows; then the timed iterations ----
-        use_native = args.collective == "native"
-        ncomm = None
-        if use_native:
-            # the library's own RCCL communicator; if any rank cannot create it (RCCL missing, init error) every rank
-            # falls back to torch.distributed's all-reduce of the same slab -- same bits, one more launch per iteration
-            ok = 1
+        # ---- the collective: the library's own RCCL communicator (one per process; the control plane is gloo) ----
+        collective, ncomm, rccl_world, rccl_rank, group = "none", None, 1, 0, None
+        want = args.collective if (world > 1 or force_comm) else "none"
+        if want == "native":
+            ok, err = 1, ""
             try:
-                ncomm = native_comm_from_torch(force=force_comm)  # identity communicator for one rank
+                uid = ranks.bcast(_lib.NativeComm.unique_id() if rank == 0 else None)
+                ncomm = _lib.NativeComm(uid, world, rank)
+                rccl_world, rccl_rank = ncomm.info()
             except Exception as e:  # noqa: BLE001
-                print(f"[bench] rank {rank}: native communicator unavailable ({e}); falling back to torch.distributed", file=sys.stderr)
-                ok = 0
-            if world > 1:
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = int(flag.item())
-            if not ok:
-                use_native = False
+                ok, err = 0, str(e)
+                print(f"[bench] rank {rank}: native communicator unavailable ({e})", file=sys.stderr)
+            if ranks.reduce(float(ok), "min") < 1:  # every rank falls back together
                 if ncomm is not None:
                     ncomm.close()
-        if use_native:
-            collective = "rccl below the C ABI (vqhip_kmeans_run_sharded)" if (world > 1 or force_comm) else "none"
-            km = _lib.KMeans(ds, m_, k_)
-            km.set_engine(engine)
-            km.init_from_global_rows(ncomm, init, rank * n)
-            km.run(TRAIN_ITERS, ncomm)
-            codebooks = km.get_centroids()
-            for _ in range(3):  # untimed: the first ~30 iterations of a process run 10 % slow (clocks ramping up from idle)
-                km.run(10, ncomm)
-            torch.cuda.synchronize()
-            barrier()
-            t0 = time.perf_counter()
-            it, _, _, paused = km.run(args.kmeans_iters, ncomm)
-            torch.cuda.synchronize()
-            barrier()
-            km_dt = time.perf_counter() - t0
-            km_iters = max(1, int(it.max()))
-            km.close()
-            ncomm.close()
-        else:
-            comm = Comm(force=force_comm)
-            collective = "torch.distributed nccl" if comm.on else "none"
-            shard = HipShard(ds, m_, k_, rank * n, engine)
-            skm = ShardedKMeans(shard, n_global, comm)
-            skm.init_from_global_rows(init)
-            for _ in range(TRAIN_ITERS):
-                skm.step()
-            codebooks = shard.get_centroids()
-            for _ in range(30):
-                skm.step()
-            torch.cuda.synchronize()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.kmeans_iters):
-                skm.step()
-            torch.cuda.synchronize()
-            barrier()
-            km_dt = time.perf_counter() - t0
-            km_iters = args.kmeans_iters
-            shard.close()
-            _lib.set_stream(stream.cuda_stream)
-        km_t = torch.tensor([km_dt], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(km_t, op=dist.ReduceOp.MAX)
-        km_dt = float(km_t.item())
+                ncomm, want = None, "torch"
+            else:
+                collective = "native"
+        if want in ("torch", "gloo"):
+            import torch.distributed as dist
 
-        # ---- encode: the timed region -------------------------------------------------------
-        enc = _lib.PQEncoder(codebooks, _lib.SQUARED_EUCLIDEAN)
-        enc.set_engine(engine)
-        codes = torch.empty((n, m_), dtype=torch.uint8, device="cuda")
-        f16 = torch.empty((n, dim), dtype=torch.float16, device="cuda")
-        xptr = ds.device_ptr
-        for _ in range(args.warmup):
-            enc.encode_device(xptr, n, codes.data_ptr(), None)
-        torch.cuda.synchronize()
-        barrier()
-        _lib.set_profiling(True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            enc.encode_device(xptr, n, codes.data_ptr(), None)
-        torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
-        calls, primary_ms, recheck_ms = _lib.profile_collect()
-        _lib.set_profiling(False)
-        rechecked, used_engine = _lib.last_assign_stats()
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+            if not dist.is_initialized():  # one forced rank
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(free_port()))
+                dist.init_process_group("gloo", rank=0, world_size=1)
+                ranks.dist = dist
+            collective = want
+            if want == "torch":  # the data-plane group: nccl (= RCCL)
+                try:
+                    group = dist.new_group(backend="nccl", device_id=torch.device("cuda", device))
+                    rccl_world, rccl_rank = dist.get_world_size(group), dist.get_rank(group)
+                except Exception as e:  # noqa: BLE001
+                    print(f"[bench] rank {rank}: no nccl group ({e})", file=sys.stderr)
+                    return 4
+        if collective == "none" and ncomm is None:
+            ncomm = _lib.NativeComm(None, 1, 0)  # identity communicator
 
-        # ---- same pass with the reference-shaped f16 reconstruction written too -------------
-        for _ in range(2):
-            enc.encode_device(xptr, n, codes.data_ptr(), f16.data_ptr())
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = max(3, args.steps // 4)
-        for _ in range(reps):
-            enc.encode_device(xptr, n, codes.data_ptr(), f16.data_ptr())
-        torch.cuda.synchronize()
-        dt_f16 = (time.perf_counter() - t0) / reps
-
-        checksum = int(codes.to(torch.int64).sum().item())
-        del f16
+        main_out, codebooks, keep = measure(args, ranks, args.config, args.scaling, torch=torch, _lib=_lib, engine=engine,
+                                            ncomm=ncomm, collective=collective, steps=args.steps, warmup=args.warmup, group=group)
+        ds, enc, codes = keep
+        n, dim, m_, k_ = main_out["rows_this_rank"], main_out["dim"], main_out["m"], main_out["k"]
 
         extras = {}
         if rank == 0 and world == 1 and args.config == "C2":
@@ -463,74 +702,77 @@ def main():
             del Xc
         enc.close()
         ds.close()
-        del codes
+        del codes, keep
+        torch.cuda.empty_cache()
+
+        # ---- N > 1: the same job strong-scaled, and BASELINE configs[4] (12.5M x 128 rows per GPU, m = 16) -------------
+        blocks = {}
+        if world > 1 and not args.no_configs:
+            def block(name, wl_name, scaling):
+                try:
+                    o, _, kp = measure(args, ranks, wl_name, scaling, torch=torch, _lib=_lib, engine=engine, ncomm=ncomm,
+                                       collective=collective, steps=max(5, args.steps // 2), warmup=2, want_f16=False, group=group)
+                    kp[1].close()
+                    kp[0].close()
+                    del kp
+                    torch.cuda.empty_cache()
+                    blocks[name] = o
+                except Exception as e:  # noqa: BLE001  (every rank runs the same code: they fail or pass together)
+                    blocks[name] = {"error": str(e)}
+
+            if not (args.config == "C2" and args.scaling == "strong"):
+                block("strong_C2", "C2", "strong")
+            if args.config != "C5":
+                block("weak_C5", "C5", "weak")
         configs = None
         if rank == 0 and world == 1 and not args.no_configs:
             configs = other_configs(_lib, torch, engine)
 
+    rc = 0
     if rank == 0:
-        value = n_global * args.steps / dt
-        flop_per_row = 2.0 * k_ * dim  # the -2.x.c contraction only
-        kern_s = primary_ms / 1e3 / max(calls, 1)
-        achieved = flop_per_row * n / kern_s / 1e12 if kern_s > 0 else 0.0
-        sd = dim // m_
-        kernel_name = {2: f"k_assign_screen<{sd},16>", 3: f"k_assign_screen_bf16_x32<{sd},8,1,0,false>"}.get(used_engine, "k_assign_exact")
-        traffic, traffic_src = pmc_traffic(kernel_name) if (n == N_PER_GPU and args.config == "C2") else (None, None)
-        step_ms = dt / args.steps * 1e3
-        km_ms = km_dt / km_iters * 1e3
+        o = main_out
+        wl = WORKLOADS[args.config]
+        traffic, traffic_src = (pmc_traffic(o["encode_roofline"]["kernel"])
+                                if (n == N_PER_GPU and args.config == "C2") else (None, None))
+        roof = dict(o["encode_roofline"])
+        roof.update({
+            "note": "achieved = algorithmic 2*k*D flop per row / device time of the screen kernel (HIP events on the "
+                    "launch stream, max over ranks); with the bf16-split engine the contraction runs as 6 bf16 products per fp32 "
+                    "product on the bf16 matrix pipe and the kernel is VALU-bound (epilogue), see DESIGN.md 4.1; "
+                    "step_frac = the same work over the whole driver-timed step (screen + exact re-check)",
+            "traffic": traffic, "traffic_source": traffic_src})
         line = {
             "metric": "pq_encode_vectors_per_s",
-            "value": value,
+            "value": o["encode_vectors_per_s"],
             "unit": "vectors/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": step_ms,
+            "ms_per_step": o["encode_ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"PQ m={m_} k={k_} L2 encode on {n}x{dim} f32 rows per GPU, device-resident "
-                            f"({wl['label']}); codes out (1 byte per subspace)",
-                "rows_per_gpu": n, "dim": dim, "m": m_, "k": k_, "sub_dim": sd,
-                "engine": {1: "exact", 2: "fp32_mfma_screen+exact_recheck",
-                           3: "bf16x3_mfma_screen+exact_recheck"}.get(used_engine, str(used_engine)),
-                "recheck_fraction": rechecked / float(n * m_),
+                "workload": f"PQ m={m_} k={k_} L2 encode on {o['rows_global']}x{dim} f32 rows in all, {n} on this GPU, device-resident "
+                            f"({wl['label']}; {args.scaling} scaling); codes out (1 byte per subspace)",
+                "rows_per_gpu": n, "rows_global": o["rows_global"], "dim": dim, "m": m_, "k": k_, "sub_dim": dim // m_,
+                "engine": o["encode_engine"], "recheck_fraction": o["recheck_fraction"],
                 "codebooks": f"{TRAIN_ITERS} Lloyd iterations from strided init rows",
             },
-            "roofline": {
-                "bound": "mfma",
-                "kernel": kernel_name,
-                "note": "achieved = algorithmic 2*k*D flop per row / device time of the screen kernel (HIP events on the "
-                        "launch stream); with the bf16-split engine the contraction runs as 6 bf16 products per fp32 "
-                        "product on the bf16 matrix pipe and the kernel is VALU-bound (epilogue), see DESIGN.md 4.1; "
-                        "step_frac = the same work over the whole driver-timed step (screen + exact re-check)",
-                "achieved": achieved,
-                "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "step_frac": flop_per_row * n / (step_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                "flop_per_launch": flop_per_row * n,
-                "avg_launch_ms": kern_s * 1e3,
-                "recheck_avg_launch_ms": recheck_ms / max(calls, 1),
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": (4.0 * dim + m_) * n,
-            },
-            "kmeans_iter_per_s": km_iters / km_dt,
-            "kmeans_ms_per_iter": km_ms,
-            "kmeans_rows_global": n_global,
-            "kmeans_collective": collective,
-            "kmeans_roofline": mfma_roofline(flop_per_row * n_global / world, km_ms, extra={
-                "flop_per_iter_per_gpu": flop_per_row * n,
-                "note": "per GPU: 2*N*k*D flop of one Lloyd iteration (assign + fused update + all-reduce + finalize) / its wall "
-                        "time; X is read once per iteration (4*N*D bytes, SURVEY.md 8(d))"}),
-            "encode_f16_out_vectors_per_s_per_gpu": n / dt_f16,
-            "codes_checksum_rank0": checksum,
+            "roofline": roof,
+            "kmeans_rows_global": o["rows_global"],
+            "kmeans_collective": {"native": "rccl below the C ABI (vqhip_kmeans_run_sharded)", "torch": "torch.distributed nccl",
+                                  "gloo": "torch.distributed gloo (host-staged)", "none": "none"}[collective],
+            "rccl_world": rccl_world, "rccl_rank": rccl_rank,
         }
+        for key in ("kmeans_iter_per_s", "kmeans_ms_per_iter", "kmeans_iters_requested", "kmeans_iters_timed",
+                    "kmeans_active_subspaces", "kmeans_paused", "kmeans_valid", "kmeans_counts_sum_per_subspace",
+                    "kmeans_allreduce_ms", "codebooks_abs_sum", "kmeans_roofline", "encode_f16_out_vectors_per_s_per_gpu", "codes_checksum_rank0"):
+            line[key] = o.get(key)
         line.update(extras)
+        line.update(blocks)
         if configs is not None:
             line["configs"] = configs
         r32, r16, trusted = _lib.selftest()
@@ -539,8 +781,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.config == "C2":
             line["cpu_baseline"] = cpu_baseline(m_, k_, dim, codebooks)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
-    if world > 1 or force_comm:
-        dist.destroy_process_group()
+        if not o["kmeans_valid"]:
+            print("[bench] the timed k-means run paused or retired subspaces: kmeans_* fields are scaled by the subspaces "
+                  "that executed (kmeans_active_subspaces)", file=sys.stderr)
+    if ncomm is not None:
+        ncomm.close()
+    ranks.close()
+    return rc
 
 
 if __name__ == "__main__":

@@ -174,6 +174,11 @@ int vqhip_kmeans_get_centroids(vqhip_kmeans *km, float *centroids);
 /* which subspaces still iterate (each converges on its own, src/pq.rs:121 + vector.rs:455);
  * active [m] of 0/1.  Default: all active. */
 int vqhip_kmeans_set_active(vqhip_kmeans *km, const uint8_t *active);
+/* the set as the library holds it now: what _set_active last wrote, minus the subspaces vqhip_kmeans_run retired
+ * since (it retires a converged subspace in the iteration it converges, vector.rs:455-457).  A host that mirrors the
+ * set must re-read it after every _run / _run_sharded: a subspace may have retired iterations BEFORE the one that
+ * paused the run, and `counts` of a subspace that did not execute the last iteration are 0, not "empty clusters". */
+int vqhip_kmeans_get_active(const vqhip_kmeans *km, uint8_t *active);
 int vqhip_kmeans_set_engine(vqhip_kmeans *km, int engine);
 /* exact_update != 0: cluster means are the reference's sequential f32 sums in row order
  * (bit-identical to mean_vector_by_indices, vector.rs:368-384) instead of the default
@@ -192,9 +197,10 @@ int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed);
 /* The loop of lbg_quantize (vector.rs:415-458) without a host round trip per iteration: up to max_iters iterations
  * are queued back to back and the loop's decisions are taken on the device -- a subspace whose centroids did not move
  * (`changed` false, vector.rs:455-457) stops being processed, and an empty cluster in an active subspace PAUSES the run
- * after that iteration (*paused = 1) because the reseed row is the caller's draw (vector.rs:448-452): patch the empty
- * clusters (counts == 0), retire the subspaces with changed == 0 (vqhip_kmeans_set_active) and call again with the
- * iterations that are left.  Out (all optional): iters_done [m] iterations executed per subspace in this call; counts
+ * after that iteration (*paused = 1) because the reseed row is the caller's draw (vector.rs:448-452): read the active
+ * set (vqhip_kmeans_get_active: subspaces that converged in an EARLIER iteration of this call are already retired and
+ * their counts read 0), patch the empty clusters (counts == 0) of the subspaces still active, retire those of them with
+ * changed == 0 (vqhip_kmeans_set_active) and call again with the iterations that are left.  Out (all optional): iters_done [m] iterations executed per subspace in this call; counts
  * [m][k] and changed [m] of the last executed iteration.  Without a pause the converged subspaces are already retired
  * when the call returns.  Shapes without the fused update take the same decisions on the host, one step at a time. */
 int vqhip_kmeans_run(vqhip_kmeans *km, uint32_t max_iters, uint32_t *iters_done, uint32_t *counts, uint8_t *changed,

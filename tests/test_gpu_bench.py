@@ -1,0 +1,56 @@
+"""bench.py end to end on the GPU box: the self-launch path and the N > 1 plumbing with two ranks
+sharing the one GPU (RCCL refuses two ranks on one device, so the collective there is gloo with the slab staged on
+the host: everything else -- sharding, global init rows, barriers, max-over-ranks timing, the relay of rank 0's
+line -- is the code an 8-GPU run executes)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(argv, env=None, timeout=900):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                       timeout=timeout, env=e)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+SMALL = ["--steps", "2", "--warmup", "1", "--kmeans-iters", "3", "--no-cpu-baseline", "--no-configs"]
+
+
+def test_one_rank_through_the_spawn_path():
+    line = _bench(["--gpus", "1", "--rows", "200000"] + SMALL, env={"VQ_BENCH_SPAWN": "1"})
+    assert line["n_gpus"] == 1 and line["rccl_world"] == 1 and line["scaling"] == "weak"
+    assert line["kmeans_valid"] and line["kmeans_iters_timed"] == [3, 3] and line["kmeans_active_subspaces"] == 8.0
+    assert line["kmeans_counts_sum_per_subspace"] == [200000, 200000]
+    assert line["value"] > 1e7 and 0 < line["roofline"]["frac"] < 1.2
+    direct = _bench(["--gpus", "1", "--rows", "200000"] + SMALL)
+    assert direct["codes_checksum_rank0"] == line["codes_checksum_rank0"]
+    assert direct["codebooks_abs_sum"] == line["codebooks_abs_sum"]
+
+
+def test_two_ranks_sharing_the_gpu_weak_and_strong():
+    env = {"VQ_BENCH_SHARE_GPU": "1"}
+    one = _bench(["--gpus", "1", "--rows", "200001"] + SMALL)
+    strong = _bench(["--gpus", "2", "--collective", "gloo", "--scaling", "strong", "--rows", "200001"] + SMALL, env=env)
+    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong"
+    assert strong["config"]["rows_global"] == 200001 and strong["config"]["rows_per_gpu"] == 100001  # rank 0 of an uneven split
+    assert strong["kmeans_counts_sum_per_subspace"] == [200001, 200001]  # the all-reduce summed both shards
+    # same global job, two shards: the codebooks agree up to the summation order of the f64 slabs
+    assert abs(strong["codebooks_abs_sum"] - one["codebooks_abs_sum"]) <= 1e-6 * one["codebooks_abs_sum"]
+    weak = _bench(["--gpus", "2", "--collective", "gloo", "--rows", "100000"] + SMALL, env=env)
+    assert weak["scaling"] == "weak" and weak["config"]["rows_global"] == 200000
+    assert weak["kmeans_counts_sum_per_subspace"] == [200000, 200000]
+    assert weak["value"] > 0 and weak["kmeans_valid"]

@@ -610,3 +610,53 @@ def test_device_driven_run_retires_converged_subspaces():
     assert (it2[1:] == 0).all()
     km.close()
     ds.close()
+
+
+def _late_empty_case():
+    """13 rows, m = 3, k = 4, sub_dim 8 (fused update: the device-driven loop).  Subspace 0: four groups of IDENTICAL
+    rows, one init row per group -> the first iteration moves nothing and the subspace retires in iteration 1.
+    Subspace 1: a 1-D layout (found with the oracle) whose cluster 0 loses all members in iteration 3 -- two
+    iterations AFTER subspace 0 retired, so its counts read 0 for a retired subspace when the run pauses.
+    Subspace 2: noise, keeps iterating."""
+    pts = np.array([-26, -25, -24, -20, -20, -6, -4, 0, 2, 17, 18, 19, 25], F)
+    n, sd = len(pts), 8
+    X = np.zeros((n, 3 * sd), F)
+    X[:, :sd] = (np.arange(n) % 4)[:, None] * 8.0 + np.arange(sd)[None, :]
+    X[:, sd] = pts
+    X[:, 2 * sd:] = np.random.default_rng(9).random((n, sd), dtype=F)
+    init = np.array([[0, 1, 2, 3], [10, 2, 3, 12], [0, 4, 8, 12]], np.uint64)
+    reseed = np.array([[5, 6, 7, 8], [11, 1, 0, 4], [9, 10, 2, 3]], np.uint64)
+    return X, init, reseed, 4
+
+
+@pytest.mark.parametrize("path", ["fit_codebooks", "native_sharded_1rank", "host_loop"])
+def test_pause_after_an_earlier_subspace_retired(path, oracle):
+    """a subspace that converged iterations before another one pauses the run has counts == 0 in the
+    paused return; the host loop must not take them for empty clusters (it used to re-seed all k centroids of the
+    converged subspace).  fit_codebooks / NativeShardedKMeans.fit against the oracle's lbg loop, same draws."""
+    from vq_amd.pq import fit_codebooks
+    from vq_amd.sharded import NativeShardedKMeans
+
+    X, init, reseed, k = _late_empty_case()
+    m, max_iters = 3, 12
+    cb_ref, it_ref = oracle.pq_fit(X, m, k, max_iters, init, reseed)
+    assert it_ref[0] == 1 and it_ref[1] > 3  # the situation the test is about
+    ds = _lib.Dataset.from_host(X)
+    if path == "native_sharded_1rank":  # ("host_loop": the exact engine takes vqhip_kmeans_run's host-driven branch)
+        comm = _lib.NativeComm(None, 1, 0)
+        skm = NativeShardedKMeans(ds, m, k, X.shape[0], 0, comm)
+        cb = skm.fit(max_iters, init_rows=init, reseed_rows=reseed.tolist())
+        iters = skm.iters
+        skm.close()
+        comm.close()
+    else:
+        stats = {}
+        cb = fit_codebooks(ds, m, k, max_iters, init_rows=init, reseed_rows=reseed.tolist(),
+                           engine=_lib.ENGINE_EXACT if path == "host_loop" else _lib.ENGINE_AUTO, stats=stats)
+        iters = stats["iters"]
+        used = sum(oracle.lloyd(X[:, s * 8:(s + 1) * 8], k, max_iters, init[s], reseed[s])[2] for s in range(m))
+        assert stats["reseeds"] == used >= 1
+    ds.close()
+    assert iters.tolist() == it_ref.tolist()
+    assert cb[0].tobytes() == cb_ref[0].tobytes()  # identical rows: the means are exact
+    np.testing.assert_allclose(cb, cb_ref, rtol=0, atol=1e-5 * max(1.0, float(np.abs(cb_ref).max())))

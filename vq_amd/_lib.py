@@ -58,6 +58,7 @@ SIGNATURES = {
     "vqhip_kmeans_init_from_rows": (C.c_int, [_vp, _u64p]),
     "vqhip_kmeans_get_centroids": (C.c_int, [_vp, _f32p]),
     "vqhip_kmeans_set_active": (C.c_int, [_vp, _u8p]),
+    "vqhip_kmeans_get_active": (C.c_int, [_vp, _u8p]),
     "vqhip_kmeans_set_engine": (C.c_int, [_vp, C.c_int]),
     "vqhip_kmeans_set_exact_update": (C.c_int, [_vp, C.c_int]),
     "vqhip_kmeans_step": (C.c_int, [_vp, _u32p, _u8p]),
@@ -257,6 +258,12 @@ class KMeans(Handle):
         a = np.ascontiguousarray(active, dtype=np.uint8).reshape(self.m)
         check(load().vqhip_kmeans_set_active(self.raw, ptr(a, _u8p)))
 
+    def get_active(self) -> np.ndarray:
+        """bool [m]: the library's own active set (``run`` retires converged subspaces on the device)"""
+        a = np.zeros(self.m, np.uint8)
+        check(load().vqhip_kmeans_get_active(self.raw, ptr(a, _u8p)))
+        return a.astype(bool)
+
     def set_engine(self, engine: int):
         check(load().vqhip_kmeans_set_engine(self.raw, engine))
 
@@ -363,6 +370,13 @@ class NativeComm(Handle):
             check(load().vqhip_comm_create(None, int(world), int(rank), C.byref(h)))
         super().__init__(h)
         self.world, self.rank = int(world), int(rank)
+
+    def info(self) -> tuple[int, int]:
+        """(world, rank) as the library reports them (read back from RCCL's ncclCommCount / ncclCommUserRank when the
+        communicator is a real one)"""
+        w, r = C.c_int(0), C.c_int(0)
+        check(load().vqhip_comm_info(self.raw, C.byref(w), C.byref(r)))
+        return int(w.value), int(r.value)
 
 
 class PQEncoder(Handle):

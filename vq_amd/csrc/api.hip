@@ -999,6 +999,12 @@ int vqhip_kmeans_set_active(vqhip_kmeans *km, const uint8_t *active) {
     return VQHIP_OK;
 }
 
+int vqhip_kmeans_get_active(const vqhip_kmeans *km, uint8_t *active) {
+    if (!km || !active) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    for (uint32_t s = 0; s < km->cs.m; ++s) active[s] = km->active[s] ? 1 : 0;
+    return VQHIP_OK;
+}
+
 int vqhip_kmeans_set_engine(vqhip_kmeans *km, int engine) {
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     if (engine < VQHIP_ENGINE_AUTO || engine > VQHIP_ENGINE_MFMA_BF16) return fail(VQHIP_ERR_INVALID_INPUT, "unknown engine %d", engine);

@@ -118,6 +118,16 @@ int comm_create(const uint8_t *id128, int world, int rank, Comm **out) {
             return fail(VQHIP_ERR_RUNTIME, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, api->GetErrorString(r));
         }
         c->owned = true;
+        // what vqhip_comm_info reports is what RCCL itself says about the communicator, not the arguments
+        int w = 0, rk = -1;
+        r = api->CommCount(c->comm, &w);
+        if (r == ncclSuccess) r = api->CommUserRank(c->comm, &rk);
+        if (r != ncclSuccess || w != world || rk != rank) {
+            (void)api->CommDestroy(c->comm);
+            delete c;
+            return fail(VQHIP_ERR_RUNTIME, "communicator reports rank %d of %d, asked for rank %d of %d (%s)", rk, w, rank, world,
+                        r == ncclSuccess ? "mismatch" : api->GetErrorString(r));
+        }
     }
     *out = c;
     return VQHIP_OK;

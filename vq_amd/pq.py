@@ -87,11 +87,13 @@ def fit_codebooks(ds: "_lib.Dataset", m: int, k: int, max_iters: int, seed: int 
             it, counts, changed, paused = km.run(max_iters - done)
             iters += it.astype(np.int64)
             done += max(1, int(it.max()))
+            # the library's own set: subspaces that converged inside this call were retired on the device
+            # (vector.rs:455-457) -- also those that converged iterations BEFORE a pause, whose `counts` read 0
+            active = km.get_active()
             if not paused:
-                active &= changed  # converged subspaces were retired on the device (vector.rs:455-457)
                 continue
-            # empty clusters of active subspaces in (subspace, ascending j) order, vector.rs:448-452
-            # (one vectorised scan: the per-subspace Python loop cost ~1 ms per iteration at m = 96)
+            # empty clusters of the subspaces that executed the pausing iteration, in (subspace, ascending j) order,
+            # vector.rs:448-452 (one vectorised scan: the per-subspace Python loop cost ~1 ms per iteration at m = 96)
             empties = np.argwhere((counts == 0) & active[:, None])
             for s, j in empties:
                 if reseed_iters is not None:

@@ -70,28 +70,37 @@ def owner_of(n_global: int, world: int, row: int) -> int:
 
 
 class Comm:
-    """torch.distributed wrapper that degrades to a no-op for a single process."""
+    """torch.distributed wrapper that degrades to a no-op for a single process.  `group`: the process group the
+    collectives run on (default: the default group)."""
 
-    def __init__(self, force: bool = False):
+    def __init__(self, force: bool = False, group=None):
         """force=True keeps the collectives on for a 1-rank group (used to exercise RCCL on one GPU)"""
         import torch.distributed as dist
 
-        self.dist = dist
-        self.on = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
-        self.rank = dist.get_rank() if self.on else 0
-        self.world = dist.get_world_size() if self.on else 1
+        self.dist, self.group = dist, group
+        up = dist.is_available() and dist.is_initialized()
+        self.on = up and (dist.get_world_size(group) > 1 or force)
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.backend = dist.get_backend(group) if self.on else None
 
     def all_reduce_sum(self, t):
-        if self.on:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        if not self.on:
+            return
+        if self.backend == "gloo" and t.is_cuda:  # host-staged (CPU ranks' transport; tests and one-GPU boxes)
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def broadcast(self, t, src: int):
         if self.on:
-            self.dist.broadcast(t, src=src)
+            self.dist.broadcast(t, src=src, group=self.group)
 
     def barrier(self):
         if self.on:
-            self.dist.barrier()
+            self.dist.barrier(group=self.group)
 
 
 class ShardedKMeans:
@@ -123,8 +132,7 @@ class ShardedKMeans:
     def _collective_device(self):
         if not self.comm.on:
             return None
-        backend = self.comm.dist.get_backend()
-        if backend == "nccl":
+        if self.comm.backend == "nccl":
             import torch
 
             return torch.device("cuda", torch.cuda.current_device())
@@ -328,8 +336,10 @@ class NativeShardedKMeans:
             it, counts, changed, paused = self.km.run(max_iters - done, self.comm)  # vqhip_kmeans_run_sharded
             self.iters += it.astype(np.int64)
             done += max(1, int(it.max()))
+            # the library's set: converged subspaces retire on the device, also iterations BEFORE a pause (their
+            # `counts` then read 0 and must not be taken for empty clusters)
+            self.active = self.km.get_active()
             if not paused:
-                self.active &= changed
                 continue
             for s, j in np.argwhere((counts == 0) & self.active[:, None]):
                 row = int(next(reseed_it[s])) if reseed_it is not None else rngs[s].choose(n)
