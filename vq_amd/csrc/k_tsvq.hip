@@ -809,16 +809,17 @@ __global__ __launch_bounds__(256) void k_tsvq_gather_f16(const float *__restrict
 // (exponent of s, S + min > 2^23 strictly, S + max < 2^24) and re-adds a tile row by row whenever the
 // check fails (binade crossings, the first tiles, cancellation, NaN/inf).  Every result is the
 // reference's bit pattern; only the schedule differs.
-constexpr uint32_t kFsTile = 512;        // rows per tile
+constexpr uint32_t kFsTile = 512;        // rows per tile: the unit of the f64 binade guess
+constexpr uint32_t kFsSeg = 64;                          // rows per segment summary = rows of one re-addition
+constexpr uint32_t kFsBlk = 128;                         // rows per wave item of k_fs_fold (two segments)
+constexpr uint32_t kFsSegsPerTile = kFsTile / kFsSeg;    // 8
+constexpr uint32_t kFsBlksPerTile = kFsTile / kFsBlk;    // 4
 constexpr uint32_t kFsCols = 32;         // columns per workgroup (one 128-byte line per row)
 constexpr uint32_t kFsMinRows = 16384;   // shorter nodes always keep the plain sequential kernel (most tiles of a short node sit on a binade crossing and are re-added)
 
 struct FsTile {
     uint32_t node, t;      // node id, tile index inside the node
     uint32_t start, rows;  // position of the tile's first row in perm, rows in the tile (<= kFsTile)
-};
-struct FsSumm {
-    int32_t d0, d1, lo0, hi0, lo1, hi1, e, flag;  // flag != 0: no usable summary
 };
 
 template <int MODE>
@@ -924,595 +925,696 @@ __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ 
     }
 }
 
-// exclusive prefix over the tiles of a node, per column, in place: 32 chunk lanes x 32 columns per
-// workgroup (chunk sums -> LDS -> offsets -> rewrite); only a guess is needed, so f64 order is free
-__global__ __launch_bounds__(1024) void k_fs_prefix(uint32_t d, const uint32_t *__restrict__ tile_base,
-                                                    const uint32_t *__restrict__ n_tiles_of, double *__restrict__ tile_sum,
-                                                    const LevelInfo *__restrict__ lv, uint32_t *__restrict__ side_count) {
+// exclusive prefix over the tiles of a node, per column (f64 sums in, f32 prefix out): 32 chunk lanes x 32 columns per
+// workgroup (chunk sums -> LDS -> offsets -> prefix); only a guess is needed, so f64 order is free.
+// VAR: the variance pass's guess needs no pass over the rows -- the mean pass left S1 = sum x and S2 = sum x^2 per (tile,
+// column), and sum over the tile of (x - mu)^2 = S2 - 2 mu S1 + rows mu^2, in f64 (the f32 block sums behind S1 / S2 make
+// it good to ~1e-7 (1 + mu^2 / sigma^2) relative: ample for a binade guess unless the offset dwarfs the spread, where
+// it merely costs re-additions).
+template <bool VAR>
+__global__ __launch_bounds__(1024) void k_fs_prefix(uint32_t d, const uint32_t *__restrict__ fast_nodes, const uint32_t *__restrict__ tile_base,
+                                                    const uint32_t *__restrict__ n_tiles_of, NodeArrays na, const double *__restrict__ tile_sum,
+                                                    const double2 *__restrict__ tile_mom,
+                                                    float *__restrict__ tile_pref, const LevelInfo *__restrict__ lv,
+                                                    uint32_t *__restrict__ side_count) {
     __shared__ double part[32][kFsCols + 1];
-    // the side buffer's slot counter of this pass (k_fs_transduce hands slots out; the previous pass's chain is done)
+    // the side buffer's slot counter of this pass (k_fs_fold hands slots out; the previous pass's chain is done)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *side_count = 0u;
     if (blockIdx.x >= lv->n_fast) return;
     const uint32_t c = blockIdx.y * kFsCols + (threadIdx.x & 31), lt = threadIdx.x >> 5;
     const uint32_t base = tile_base[blockIdx.x], nt = n_tiles_of[blockIdx.x];
     const uint32_t chunk = (nt + 31) / 32, t0 = lt * chunk, t1 = min(nt, t0 + chunk);
     const bool col_ok = c < d;
-    double local = 0.0;
-    if (col_ok)
-        for (uint32_t t = t0; t < t1; ++t) local += tile_sum[(size_t)(base + t) * d + c];
-    part[lt][threadIdx.x & 31] = local;
-    __syncthreads();
-    if (!col_ok) return;
-    double run = 0.0;
-    for (uint32_t q = 0; q < lt; ++q) run += part[q][threadIdx.x & 31];
-    for (uint32_t t = t0; t < t1; ++t) {
-        double *p = tile_sum + (size_t)(base + t) * d + c;
-        const double v = *p;
-        *p = run;
-        run += v;
-    }
-}
-
-// Variance pass: its guess needs no pass over the rows.  The mean pass left S1 = sum (x - m0) and S2 = sum (x - m0)^2
-// per (tile, column), m0 = the node's first row (so that the moments are O(sigma) whatever the data's offset), and
-//     sum over the tile of (x - mu)^2  =  S2 - 2 delta S1 + rows delta^2,      delta = mu - m0,
-// evaluated in f64 -- good to ~1e-6 relative against the f32 (x - mu)^2 terms the chain will add, ample for a
-// binade guess.  Exclusive prefix over the node's tiles as in k_fs_prefix.
-__global__ __launch_bounds__(1024) void k_fs_prefix_var(const float *__restrict__ X, uint32_t d,
-                                                        const uint32_t *__restrict__ perm,
-                                                        const uint32_t *__restrict__ fast_nodes,
-                                                        const uint32_t *__restrict__ tile_base,
-                                                        const uint32_t *__restrict__ n_tiles_of, NodeArrays na,
-                                                        const double2 *__restrict__ tile_mom,
-                                                        double *__restrict__ tile_sum,
-                                                        const LevelInfo *__restrict__ lv, uint32_t *__restrict__ side_count) {
-    __shared__ double part[32][kFsCols + 1];
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *side_count = 0u;  // as in k_fs_prefix
-    if (blockIdx.x >= lv->n_fast) return;
-    const uint32_t c = blockIdx.y * kFsCols + (threadIdx.x & 31), lt = threadIdx.x >> 5;
-    const uint32_t node = fast_nodes[blockIdx.x];
-    const uint32_t base = tile_base[blockIdx.x], nt = n_tiles_of[blockIdx.x], len = na.seg_len[node];
-    const uint32_t chunk = (nt + 31) / 32, t0 = lt * chunk, t1 = min(nt, t0 + chunk);
-    const bool col_ok = c < d;
-    double delta = 0.0;
-    if (col_ok) delta = (double)na.centroid[(size_t)node * d + c] - (double)X[(size_t)perm[na.seg_start[node]] * d + c];
-    auto tile_q = [&](uint32_t t) {
+    const uint32_t node = fast_nodes[blockIdx.x], len = na.seg_len[node];
+    const double mu = (VAR && col_ok) ? (double)na.centroid[(size_t)node * d + c] : 0.0;
+    auto tile_v = [&](uint32_t t) -> double {
+        if (!VAR) return tile_sum[(size_t)(base + t) * d + c];
         const double2 m = tile_mom[(size_t)(base + t) * d + c];
         const double rows = (double)min(kFsTile, len - t * kFsTile);
-        return m.y - 2.0 * delta * m.x + rows * delta * delta;
+        return m.y - 2.0 * mu * m.x + rows * mu * mu;
     };
+    // (eight independent loads at a time: the loop is a chain of memory round trips otherwise -- 36 us at the root of 1M rows)
     double local = 0.0;
     if (col_ok)
-        for (uint32_t t = t0; t < t1; ++t) local += tile_q(t);
+        for (uint32_t t = t0; t < t1; t += 8) {
+            double v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) v[u] = (t + u < t1) ? tile_v(t + u) : 0.0;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) local += v[u];
+        }
     part[lt][threadIdx.x & 31] = local;
     __syncthreads();
     if (!col_ok) return;
     double run = 0.0;
     for (uint32_t q = 0; q < lt; ++q) run += part[q][threadIdx.x & 31];
-    for (uint32_t t = t0; t < t1; ++t) {
-        tile_sum[(size_t)(base + t) * d + c] = run;
-        run += tile_q(t);
+    for (uint32_t t = t0; t < t1; t += 8) {
+        double v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) v[u] = (t + u < t1) ? tile_v(t + u) : 0.0;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            if (t + u < t1) tile_pref[(size_t)(base + t + u) * d + c] = (float)run;  // only the binade is wanted
+            run += v[u];
+        }
     }
 }
 
-struct FsAcc {  // transducer summary of a run of rows: for even / odd incoming S
-    long long d[2], lo[2], hi[2];
-};
-struct FsSeg {  // the same for one 64-row segment: everything fits 32 bits (|q| < 2^24 is enforced)
-    int32_t d[2], lo[2], hi[2];
-};
-
-// summaries of all tiles in parallel, under the binade guessed from the f64 prefix.  Persistent workgroups
-// (two per CU: the 512 x 32 tile takes 66 KB of LDS) walk the (tile, column block) items.  Per item: the
-// 16 independent 16-byte loads per thread (whole 128-byte lines) fetched during the PREVIOUS item are
-// parked column-major in LDS, then thread (column, segment) folds its 64 addends from LDS into the parity
-// transducer.  The next item's loads are issued inside that fold -- perm indices first, the rows they
-// name half-way through -- so the two dependent HBM round trips hide behind the arithmetic (a workgroup
-// that did load, park, fold in sequence spent 2/3 of its time waiting: 265 -> 1xx us per pass at 1M x 128).
-template <int MODE>
-__global__ __launch_bounds__(256) void k_fs_transduce(const float *__restrict__ X, uint32_t d,
-                                                      const uint32_t *__restrict__ perm,
-                                                      const FsTile *__restrict__ tiles, const LevelInfo *__restrict__ lv, NodeArrays na,
-                                                      const double *__restrict__ tile_pref,
-                                                      FsSumm *__restrict__ summ, float *__restrict__ side,
-                                                      uint32_t side_cap, uint32_t *__restrict__ side_count,
-                                                      double2 *__restrict__ tile_mom, float park_rel_arg,
-                                                      const uint32_t *__restrict__ policy) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char fs_lds[];
-    float(*lds_v)[kFsTile + 1] = reinterpret_cast<float(*)[kFsTile + 1]>(fs_lds);             // [32][513]
-    FsSeg(*seg_acc)[kFsCols] = reinterpret_cast<FsSeg(*)[kFsCols]>(fs_lds + kFsCols * (kFsTile + 1) * 4);  // [8][32]
-    __shared__ int seg_bad[8][kFsCols];
-    __shared__ int col_slot[kFsCols];
-    __shared__ float2 seg_mom[8][kFsCols];  // MODE 0: sum (x - m0), sum (x - m0)^2 of a segment (the variance pass's guess)
-    const uint32_t ncb = (d + kFsCols - 1) / kFsCols;  // the last column block may be short (d % 4 == 0)
-    const uint32_t n_items = lv->n_tiles * ncb;
-    const uint32_t q = threadIdx.x & 7, rr = threadIdx.x >> 3;     // load role: 16-byte part q of rows rr + 32 i
-    const uint32_t cl = threadIdx.x & 31, seg = threadIdx.x >> 5;  // fold role: column cl, rows 64 seg ..
-    uint32_t item = blockIdx.x;
-    if (item >= n_items) return;
-    uint32_t prow[16];
-    float4 v[16];
-    // per-item metadata in three generations: _s = just requested (item after next), _n = next item, _c = current
-    float mu4_s[4] = {0.f, 0.f, 0.f, 0.f}, mu4[4] = {0.f, 0.f, 0.f, 0.f};
-    double pref_s = 0.0, pref = 0.0;
-    uint32_t row0_s = 0;  // MODE 0: the node's first row; its values m0 centre the moments
-    float m0 = 0.0f, m0_next = 0.0f;
-    auto issue_perm = [&](const FsTile &t, uint32_t it) {  // indices, means and the f64 guess of item `it` -> prow, *_s
-        const uint32_t tid = it / ncb, c0n = (it - tid * ncb) * kFsCols;
-        if (MODE == 0) row0_s = perm[na.seg_start[t.node]];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t r = rr + 32 * i;
-            prow[i] = perm[t.start + min(r, t.rows - 1u)];  // clamped, not predicated: rows past the end park as zeros
-        }
-        // a short last column block: the missing parts / columns read the block's first ones instead (valid
-        // addresses, values never used: their summaries are not written)
-        const uint32_t cq = (c0n + 4 * q < d) ? c0n + 4 * q : c0n;
-        if (MODE == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mu4_s[i] = na.centroid[(size_t)t.node * d + cq + i];
-        }
-        pref_s = tile_pref[(size_t)tid * d + ((c0n + cl < d) ? c0n + cl : c0n)];
-    };
-    auto issue_rows = [&](uint32_t it, uint32_t row0) {  // the rows prow names -> v; the node's first row -> m0_next
-        const uint32_t tid = it / ncb, c0n = (it - tid * ncb) * kFsCols;
-        const uint32_t cq = (c0n + 4 * q < d) ? c0n + 4 * q : c0n;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const float4 *>(X + (size_t)prow[i] * d + cq);
-        if (MODE == 0) m0_next = X[(size_t)row0 * d + ((c0n + cl < d) ? c0n + cl : c0n)];
-    };
-    // Pipeline (round 2): the rows of item i+1 are requested as soon as item i has been parked in LDS -- they travel
-    // during the whole fold of item i -- and the row indices of item i+2 right behind them.  (Round 1 requested the
-    // rows half-way through the fold: each workgroup had loads in flight for under half of its time, 2.7 TB/s.)
-    FsTile tl = tiles[item / ncb];
-    issue_perm(tl, item);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) mu4[i] = mu4_s[i];
-    pref = pref_s;
-    issue_rows(item, row0_s);
-    m0 = m0_next;
-    uint32_t next = item + gridDim.x;
-    FsTile tl_next = tiles[(next < n_items ? next : item) / ncb];
-    if (next < n_items) issue_perm(tl_next, next);
-    uint32_t next2 = next + gridDim.x;
-    FsTile tl_next2 = tiles[(next2 < n_items ? next2 : item) / ncb];
-  for (;;) {
-    const uint32_t tile_id = item / ncb, c0 = (item - tile_id * ncb) * kFsCols;
-    const uint32_t rows = tl.rows;
-    {   // park the fetched rows (waits for the loads issued during the previous item)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t r = rr + 32 * i;
-            const bool live = r < rows;  // rows past the node's end park as +0: a zero addend leaves the transducer as it is
-            lds_v[4 * q + 0][r] = live ? fs_value<MODE>(v[i].x, mu4[0]) : 0.0f;
-            lds_v[4 * q + 1][r] = live ? fs_value<MODE>(v[i].y, mu4[1]) : 0.0f;
-            lds_v[4 * q + 2][r] = live ? fs_value<MODE>(v[i].z, mu4[2]) : 0.0f;
-            lds_v[4 * q + 3][r] = live ? fs_value<MODE>(v[i].w, mu4[3]) : 0.0f;
-        }
-    }
-    const uint32_t c = c0 + cl;
-    const float s_guess = (float)pref;
-    __syncthreads();
-    const bool has_next = next < n_items;  // uniform
-    float mu4_n[4] = {0.f, 0.f, 0.f, 0.f};
-    double pref_n = 0.0;
-    if (has_next) {
-        // metadata of the next item (requested an item ago), then its rows, then the indices of the one after
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mu4_n[i] = mu4_s[i];
-        pref_n = pref_s;
-        issue_rows(next, row0_s);
-        if (next2 < n_items) issue_perm(tl_next2, next2);
-    }
-    const uint32_t gb = __float_as_uint(s_guess), ge = (gb >> 23) & 0xFFu;
-    const int e = (int)ge - 127;
-    // scale = 2^(23-e): needs a normal guess and a representable power of two
-    bool bad = (ge == 0u) || (ge == 255u) || (23 - e > 126) || (23 - e < -126);
-    const float scale = bad ? 1.0f : __uint_as_float((uint32_t)(23 - e + 127) << 23);
-    // per 64-row segment everything fits 32 bits: |q| < 2^24 is enforced (an addend of 2 s or more
-    // cannot leave s in its binade), so |prefix| < 2^30
-    int32_t dd[2] = {0, 0}, lo[2] = {0, 0}, hi[2] = {0, 0};
-    const uint32_t i0 = seg * 64;
-    int badi = bad ? 1 : 0;
-    // Fast fold, ONE stream: with q = x / ulp(s) and S = s / ulp(s) an integer, fl(s + x) / ulp = S + rne(q)
-    // whenever q is not exactly half-way between two integers -- whatever the parity of S.  So the two parity
-    // streams of the transducer coincide until a tie shows up, and a tie-free segment (all of them on continuous
-    // data; the test is exact: q - rne(q) = +-1/2) costs 10 VALU operations per addend instead of 27.  A segment
-    // that does hold a tie is folded again by the two-stream code below.
-    int32_t d1 = 0, lo1 = 0, hi1 = 0;
-    float tmax = 0.0f, sy = 0.0f, sy2 = 0.0f;
-    uint32_t imax = 0u;
-    auto fold1 = [&](uint32_t ib0, uint32_t ib1) {
-#pragma unroll 1
-    for (uint32_t ib = ib0; ib < ib1; ib += 8) {
-      float qv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) qv[u] = lds_v[cl][i0 + ib + u];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float qq = qv[u] * scale;                 // exact (power of two) unless it overflows: caught by imax
-        const float r = __builtin_rintf(qq);            // v_rndne_f32
-        tmax = fmaxf(tmax, fabsf(qq - r));              // qq - r is exact; a NaN is caught by imax
-        imax = max(imax, __float_as_uint(qq) & 0x7FFFFFFFu);
-        d1 += (int32_t)r;
-        lo1 = min(lo1, d1);
-        hi1 = max(hi1, d1);
-        if (MODE == 0) {                                // f32 moments of the segment around the node's first row
-            const float y = qv[u] - m0;
-            sy = sy + y;
-            sy2 = __builtin_fmaf(y, y, sy2);
-        }
-      }
-    }
-    };
-    // two streams (even / odd incoming S), exact tie handling; 64 addends per thread, 8 LDS reads in flight,
-    // branch-free
-    const float scale2 = scale + scale;  // 2^(24-e): exact (23 - e <= 126 was checked)
-    auto fold2 = [&](uint32_t ib0, uint32_t ib1) {
-#pragma unroll 1
-    for (uint32_t ib = ib0; ib < ib1; ib += 8) {
-      float qv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) qv[u] = lds_v[cl][i0 + ib + u];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        // q = a + f, a = floor(q), 0 <= f < 1, classified EXACTLY from 2q (exact: |q| < 2^24): with i2 = floor(2q)
-        // a = i2 >> 1, and f is above / at / below one half as (i2 odd, 2q not an integer) / (i2 odd, 2q an
-        // integer) / (i2 even).  (q - floor(q) itself is inexact for -1 < q < 0: -0.49999997 would read as a tie.)
-        const float q2 = qv[u] * scale2;
-        const bool in_range = fabsf(q2) < 33554432.0f;  // else |q| >= 2^24, inf or NaN: cannot stay in the binade
-        badi |= in_range ? 0 : 1;
-        const float qq = in_range ? q2 : 0.0f;
-        const float fl = floorf(qq);
-        const int32_t i2 = (int32_t)fl, sticky = qq != fl ? 1 : 0;
-        const int32_t ai = i2 >> 1, half = i2 & 1;
-        const int32_t up = half & sticky, tie = half & (sticky ^ 1);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int32_t base = dd[p] + ai;
-            const int32_t inc = base + (up | (tie & (p + base)));  // tie: round to the even S
-            dd[p] = inc;
-            lo[p] = min(lo[p], inc);
-            hi[p] = max(hi[p], inc);
-        }
-      }
-    }
-    };
-    fold1(0, 64);
-    if (imax >= 0x4B800000u) badi = 1;  // |q| >= 2^24, inf or NaN: cannot stay in the binade
-    if (!badi && tmax == 0.5f) {         // a tie in this segment: the exact two-stream fold
-        fold2(0, 64);
-    } else {
-        dd[0] = dd[1] = d1;
-        lo[0] = lo[1] = lo1;
-        hi[0] = hi[1] = hi1;
-    }
-    bad = badi != 0;
-    FsSeg acc;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        acc.d[p] = dd[p];
-        acc.lo[p] = lo[p];
-        acc.hi[p] = hi[p];
-    }
-    if (MODE == 0) seg_mom[seg][cl] = make_float2(sy, sy2);
-    seg_acc[seg][cl] = acc;
-    seg_bad[seg][cl] = bad ? 1 : 0;
-    __syncthreads();
-    if (seg == 0) {
-        auto widen = [](const FsSeg &x) {
-            FsAcc w;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                w.d[p] = x.d[p];
-                w.lo[p] = x.lo[p];
-                w.hi[p] = x.hi[p];
-            }
-            return w;
-        };
-        if (MODE == 0 && tile_mom && c < d) {
-            double a1 = 0.0, a2 = 0.0;
-            for (int g = 0; g < 8; ++g) {
-                a1 += (double)seg_mom[g][threadIdx.x].x;
-                a2 += (double)seg_mom[g][threadIdx.x].y;
-            }
-            // rows past the node's end were parked as +0 and entered the moments as (0 - m0): take them out
-            const double pad = (double)(kFsTile - rows), m0d = (double)m0;
-            tile_mom[(size_t)tile_id * d + c] = make_double2(a1 + pad * m0d, a2 - pad * m0d * m0d);
-        }
-        FsAcc f = widen(seg_acc[0][threadIdx.x]);
-        int anybad = seg_bad[0][threadIdx.x];
-        for (int g = 1; g < 8; ++g) {  // f then g, in row order
-            const FsAcc gg = widen(seg_acc[g][threadIdx.x]);
-            anybad |= seg_bad[g][threadIdx.x];
-            FsAcc h;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const bool odd = ((p + f.d[p]) & 1) != 0;  // selects, not gg.d[p2]: a run-time index sends the struct to scratch
-                const long long gd = odd ? gg.d[1] : gg.d[0], gl = odd ? gg.lo[1] : gg.lo[0], gh = odd ? gg.hi[1] : gg.hi[0];
-                h.d[p] = f.d[p] + gd;
-                const long long l2 = f.d[p] + gl, h2 = f.d[p] + gh;
-                h.lo[p] = f.lo[p] < l2 ? f.lo[p] : l2;
-                h.hi[p] = f.hi[p] > h2 ? f.hi[p] : h2;
-            }
-            f = h;
-        }
-        const long long lim = 1ll << 28;
-        if (f.hi[0] > lim || f.hi[1] > lim || f.lo[0] < -lim || f.lo[1] < -lim) anybad = 1;
-        // Will the chain have to re-add this tile?  Predict it from the guessed S (margin 2^14 of the
-        // 2^23-wide binade) and, if so, park the tile's addends column-contiguous in the side buffer:
-        // the re-addition then reads 2 KB instead of gathering 4 bytes from each of 512 rows.
-        int slot = -1;
-        {
-            const int32_t mag = (int32_t)((gb & 0x7FFFFFu) | 0x800000u);
-            const long long Sg = (gb >> 31) ? -(long long)mag : (long long)mag;
-            const long long lo2 = f.lo[0] < f.lo[1] ? f.lo[0] : f.lo[1], hi2 = f.hi[0] > f.hi[1] ? f.hi[0] : f.hi[1];
-            // 0.2 % of the binade where the f64 guess is good to ~1e-5 (exact tile sums, the variance pass's moments).
-            // A guess from every r-th row is off by ~sigma sqrt(r N): three sigmas of that (park_rel = 3 sqrt(r / 512)
-            // sigma / mean for sigma / mean ~ 0.6, N = 512 (t + 1) rows so far) -- a tile whose guess is that close to
-            // a binade edge is likely to be re-added, and a parked tile is read back in one go instead of 512 gathers.
-            long long margin = 1ll << 14;
-            const float park_rel = (policy && !policy[c0 / kFsCols]) ? 0.0f : park_rel_arg;  // exact sums for this column block
-            if (park_rel > 0.0f) {
-                const long long m2 = (long long)(park_rel * __builtin_amdgcn_rsqf((float)(tl.t + 1u)) * (float)(Sg < 0 ? -Sg : Sg));
-                margin = m2 > margin ? (m2 < (1ll << 22) ? m2 : (1ll << 22)) : margin;
-            }
-            const bool leaves = (Sg > 0) ? (Sg + lo2 < (1ll << 23) + margin || Sg + hi2 > (1ll << 24) - margin)
-                                         : (Sg + hi2 > -(1ll << 23) - margin || Sg + lo2 < -(1ll << 24) + margin);
-            if ((anybad || leaves) && side_cap && c < d) {
-                const uint32_t got = atomicAdd(side_count, 1u);
-                if (got < side_cap) slot = (int)got;
-            }
-        }
-        col_slot[threadIdx.x] = slot;
-        FsSumm o;
-        o.d0 = (int32_t)f.d[0];
-        o.d1 = (int32_t)f.d[1];
-        o.lo0 = (int32_t)f.lo[0];
-        o.hi0 = (int32_t)f.hi[0];
-        o.lo1 = (int32_t)f.lo[1];
-        o.hi1 = (int32_t)f.hi[1];
-        o.e = e;
-        o.flag = (anybad ? 1 : 0) | ((slot + 1) << 1);  // bit 0: unusable; bits 1..: side slot + 1
-        if (c < d) summ[(size_t)tile_id * d + c] = o;
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (uint32_t cc = 0; cc < kFsCols; ++cc) {  // rare: park the flagged columns (already in LDS)
-        const int slot = col_slot[cc];
-        if (slot < 0) continue;
-        float *dst = side + (size_t)slot * kFsTile;
-        for (uint32_t i = threadIdx.x; i < rows; i += 256) dst[i] = lds_v[cc][i];
-    }
-    if (!has_next) break;
-    __syncthreads();  // lds_v, seg_acc and col_slot are rewritten by the next item
-    item = next;
-    next = next2;
-    next2 += gridDim.x;
-    tl = tl_next;
-    tl_next = tl_next2;
-    tl_next2 = tiles[(next2 < n_items ? next2 : item) / ncb];
-    m0 = m0_next;
-    pref = pref_n;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) mu4[i] = mu4_n[i];
-  }
+// LDS exchange inside ONE wave (k_fs_fold and k_fs_chain run one-wave workgroups): the LDS serves a wave's instructions
+// in order, so all that is needed is that the compiler keeps the order and waits for the LDS counter.  __syncthreads()
+// would also wait for every global load in flight (s_waitcnt vmcnt(0)) -- the rows of the next block, the next batches
+// of summaries, the parked addends: exactly the loads these kernels issue early to hide their latency.
+__device__ __forceinline__ void fs_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
 }
 
-// the exact chain: one wave per (node, column).  The tile summaries are themselves parity
-// transducers, so 64 tiles at a time are composed with a wave scan: lane l learns the exact S
-// entering tile t0+l (as if every earlier tile of the batch held), checks its own tile (same
-// binade as the guess, prefixes inside it), and the first lane that fails marks where the batch
-// stops: the tiles before it are applied in one step, that tile is re-added row by row in the
-// reference's order (the additions run through v_readlane), and the scan resumes behind it.
-struct FsPair {
-    int32_t d[2], lo[2], hi[2];
+// ---- 64-row segment summaries (round 3) -----------------------------------------------------------------------------
+// A tile of 512 rows stays the unit of the f64 binade guess (k_fs_tile_sums / k_fs_prefix*), but the transducer
+// summaries are kept per SEGMENT of 64 rows, each under its own guess, and the chain re-adds 64 rows -- not 512 -- when
+// a summary does not hold.  The failing fraction goes with the square root of the rows a summary spans and the cost
+// of a re-addition with the rows themselves: zero-mean columns, whose running sum is a random walk that keeps
+// re-crossing binade edges (45-63 % of the 512-row tiles failed, 2.4 us each: 20.5 ms per build at 1M x 128), fail
+// ~10 % of their segments at 0.3 us each.
+//
+// A summary is 16 bytes, [segment][column] (a wave writes whole 512-byte runs): {d, lo, hi, ef} of the stream for an even
+// incoming S; ef = bit 0 unusable, bit 1 "the odd stream differs" (a run with an exact tie: that stream sits in the
+// second array, same index), bits 2-9 the binade + 128, bits 10.. the side-buffer slot + 1 of a parked segment.
+struct FsS {
+    int32_t d, lo, hi, ef;
 };
-__device__ __forceinline__ FsPair fs_compose(const FsPair &f, const FsPair &g) {  // f first, then g
-    FsPair h;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const bool odd = ((p + f.d[p]) & 1) != 0;  // selects: a run-time array index would send g to scratch
-        const int32_t gd = odd ? g.d[1] : g.d[0], gl = odd ? g.lo[1] : g.lo[0], gh = odd ? g.hi[1] : g.hi[0];
-        // saturating enough: summaries are clamped to |.| <= 2^28 and a batch is stopped at the first
-        // tile that leaves the binade, so valid prefixes stay below 2^25
-        h.d[p] = f.d[p] + gd;
-        h.lo[p] = min(f.lo[p], f.d[p] + gl);
-        h.hi[p] = max(f.hi[p], f.d[p] + gh);
-    }
+__device__ __forceinline__ int32_t fs_ef(int bad, int two, int e, int slot) {
+    return (bad ? 1 : 0) | (two ? 2 : 0) | (((e + 128) & 0xFF) << 2) | ((slot + 1) << 10);
+}
+__device__ __forceinline__ int fs_ef_e(int32_t ef) { return ((ef >> 2) & 0xFF) - 128; }
+__device__ __forceinline__ int fs_ef_slot(int32_t ef) { return (int)((uint32_t)ef >> 10) - 1; }
+
+struct FsT {  // parity transducer of a run of rows: stream 0 for an even incoming S, stream 1 for an odd one
+    int32_t d0, d1, lo0, lo1, hi0, hi1;
+};
+// f first, then g (scalars throughout: an array indexed by the parity becomes a scratch access)
+__device__ __forceinline__ FsT fs_compose(const FsT &f, const FsT &g) {
+    FsT h;
+    const bool o0 = (f.d0 & 1) != 0, o1 = ((1 + f.d1) & 1) != 0;
+    const int32_t gd0 = o0 ? g.d1 : g.d0, gl0 = o0 ? g.lo1 : g.lo0, gh0 = o0 ? g.hi1 : g.hi0;
+    const int32_t gd1 = o1 ? g.d1 : g.d0, gl1 = o1 ? g.lo1 : g.lo0, gh1 = o1 ? g.hi1 : g.hi0;
+    h.d0 = f.d0 + gd0;
+    h.lo0 = min(f.lo0, f.d0 + gl0);
+    h.hi0 = max(f.hi0, f.d0 + gh0);
+    h.d1 = f.d1 + gd1;
+    h.lo1 = min(f.lo1, f.d1 + gl1);
+    h.hi1 = max(f.hi1, f.d1 + gh1);
     return h;
 }
 
-// DBG (VQHIP_TSVQ_DEBUG): the instantiation with the counters and timers; the production one carries none of it
+// Segment summaries of all rows of the level's long nodes, in one streamed read of the rows (through `perm`), with
+// nothing but 8 KB of partial summaries in LDS: one wave per task = one 512-row tile x 32 columns (one 128-byte line
+// per row), walked in four blocks of 128 rows.
+//   * lane (g, q) = (lane / 8, lane % 8) loads the 16-byte part q of the 16 CONSECUTIVE rows 16 g .. 16 g + 15 of a block
+//     (the eight lanes of a row ask for one whole line), keeps them in registers and folds each of its 4 columns over
+//     its 16 rows into the parity transducer; the four lanes that hold a segment's rows of a column leave their runs in
+//     LDS (one array per field: 16-byte stores, no bank conflicts) and lane (segment, column) composes them in row order;
+//   * the binade guess of a segment: the tile's f64 prefix plus the EXACT f32 sum of the tile's rows in front of the
+//     segment -- the wave carries it from block to block, and a cross-lane reduction supplies the block's first half;
+//   * the rows of block i + 1 travel while block i is folded, the row indices of block i + 2 behind them; waves are
+//     independent (one-wave workgroups, no workgroup barrier), eight per CU with 16 KB in flight each.
+// The 512 x 32 tile staged column-major in LDS (round 2) ran two workgroups per CU at 2.4-3.0 TB/s.
+template <int MODE>
+__global__ __launch_bounds__(64, 2) void k_fs_fold(const float *__restrict__ X, uint32_t d, const uint32_t *__restrict__ perm,
+                                                   const FsTile *__restrict__ tiles, const LevelInfo *__restrict__ lv, NodeArrays na,
+                                                   const float *__restrict__ tile_pref, FsS *__restrict__ summ,
+                                                   FsS *__restrict__ summ_odd, float *__restrict__ side, uint32_t side_cap,
+                                                   uint32_t *__restrict__ side_count, double2 *__restrict__ tile_mom,
+                                                   float park_rel_arg, const uint32_t *__restrict__ policy) {
+    __shared__ __attribute__((aligned(16))) int32_t p_d0[8][kFsCols], p_d1[8][kFsCols], p_lo0[8][kFsCols], p_lo1[8][kFsCols],
+        p_hi0[8][kFsCols], p_hi1[8][kFsCols], p_bad[8][kFsCols], p_gb[8][kFsCols];
+    __shared__ __attribute__((aligned(16))) float p_s1[8][kFsCols], p_s2[8][kFsCols];
+    __shared__ int pslot[2][kFsCols];
+    const uint32_t ncb = (d + kFsCols - 1) / kFsCols;  // the last column block may be short (d % 4 == 0)
+    const uint32_t n_tasks = lv->n_tiles * ncb;
+    const uint32_t lane = threadIdx.x, q = lane & 7u, g = lane >> 3;  // load / fold role
+    const uint32_t cl = lane & 31u, sg = lane >> 5;                   // compose role: column cl of segment sg
+    if (blockIdx.x >= n_tasks) return;
+    // this wave's tasks are blockIdx.x + k gridDim.x (column block fastest: the waves that share rows run together);
+    // local item i = 4 k + b is block b of its k-th task
+    const uint32_t my_tasks = (n_tasks - blockIdx.x + gridDim.x - 1) / gridDim.x, n_local = my_tasks * kFsBlksPerTile;
+    struct Where {
+        FsTile tl;
+        uint32_t tile_id, b, c0, cq;
+    };
+    auto where = [&](uint32_t i) {
+        Where w;
+        const uint32_t task = blockIdx.x + (i / kFsBlksPerTile) * gridDim.x;
+        w.b = i % kFsBlksPerTile;
+        w.tile_id = task / ncb;
+        w.c0 = (task - w.tile_id * ncb) * kFsCols;
+        w.tl = tiles[w.tile_id];
+        // a short last column block: the missing parts read the block's first part instead (valid addresses, values
+        // never used: their summaries are not written)
+        w.cq = (w.c0 + 4 * q < d) ? w.c0 + 4 * q : w.c0;
+        return w;
+    };
+    uint32_t prow[16];
+    float4 vn[16];  // rows in flight
+    float4 mu_n = make_float4(0.f, 0.f, 0.f, 0.f), pref_n = mu_n;  // one 16-byte load each, used as loaded (a conversion or a
+                                                                   // register shuffle behind a load waits for it -- and for the row loads in front of it)
+    auto issue_perm = [&](const Where &w) {  // row indices of the block (clamped: rows past the node's end fold as +0)
+        const uint32_t first = min(kFsBlk * w.b, w.tl.rows - 1u);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) prow[i] = perm[w.tl.start + min(first + 16 * g + (uint32_t)i, w.tl.rows - 1u)];
+    };
+    auto issue_rows = [&](const Where &w) {  // the rows prow names and the block's per-column data
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vn[i] = *reinterpret_cast<const float4 *>(X + (size_t)prow[i] * d + w.cq);
+        pref_n = *reinterpret_cast<const float4 *>(tile_pref + (size_t)w.tile_id * d + w.cq);
+        if (MODE == 1) mu_n = *reinterpret_cast<const float4 *>(na.centroid + (size_t)w.tl.node * d + w.cq);
+    };
+    uint32_t item = 0;
+    Where cur = where(0);
+    issue_perm(cur);
+    issue_rows(cur);
+    Where nxt = where(n_local > 1 ? 1u : 0u);
+    if (n_local > 1) issue_perm(nxt);
+    float run[4] = {0.f, 0.f, 0.f, 0.f};  // exact f32 sum of the tile's rows in front of this block, per column
+    uint32_t chunk_base = 0, chunk_left = 0;  // this wave's unused side-buffer slots
+    double mom1 = 0.0, mom2 = 0.0;            // mean pass, lanes of segment 0: sum x and sum x^2 of the tile's column cl so far
+    for (;;) {
+        // ---- this block's rows out of the load registers (waits for them), the next block's requested ----
+        const uint32_t blk_first = kFsBlk * cur.b;
+        const bool live_item = blk_first < cur.tl.rows;  // uniform; a node's last tile may end before this block
+        const uint32_t rows_blk = live_item ? min(kFsBlk, cur.tl.rows - blk_first) : 0u;
+        float w[16][4], mu[4], pref[4];
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};  // plain sums: the guesses of the segments behind
+        float sq[4] = {0.f, 0.f, 0.f, 0.f};  // mean pass: sums of squares (the variance pass's guess, k_fs_prefix_var)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mu[j] = (&mu_n.x)[j], pref[j] = (&pref_n.x)[j];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool live = 16 * g + (uint32_t)i < rows_blk;
+            const float x[4] = {vn[i].x, vn[i].y, vn[i].z, vn[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w[i][j] = live ? fs_value<MODE>(x[j], mu[j]) : 0.0f;
+                ps[j] += w[i][j];
+                if (MODE == 0) sq[j] = __builtin_fmaf(w[i][j], w[i][j], sq[j]);
+            }
+        }
+        const bool has_next = item + 1 < n_local;  // uniform
+        Where nxt2 = where(item + 2 < n_local ? item + 2 : item);
+        if (has_next) {
+            issue_rows(nxt);
+            if (item + 2 < n_local) issue_perm(nxt2);
+        }
+        if (cur.b == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) run[j] = 0.0f;
+        }
+        if (live_item) {
+            if (MODE == 0) {  // (stored at once: the registers are free again before the fold)
+                *reinterpret_cast<float4 *>(&p_s1[g][4 * q]) = make_float4(ps[0], ps[1], ps[2], ps[3]);
+                *reinterpret_cast<float4 *>(&p_s2[g][4 * q]) = make_float4(sq[0], sq[1], sq[2], sq[3]);
+            }
+            float scale[4];
+            int32_t gbad[4], gbits[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = ps[j];
+                t += __shfl_xor(t, 8);
+                t += __shfl_xor(t, 16);                         // the sum of this lane's segment
+                const float other = __shfl_xor(t, 32);          // ... and of the block's other segment
+                const float t0 = (g >= 4) ? other : t;          // segment 0's sum on every lane
+                const float guess = pref[j] + run[j] + (g >= 4 ? t0 : 0.0f);
+                run[j] += t0 + ((g >= 4) ? t : other);          // the same value on every lane that holds the column
+                const uint32_t gb = __float_as_uint(guess), ex = (gb >> 23) & 0xFFu;
+                const int e = (int)ex - 127;
+                // scale = 2^(23-e): needs a normal guess and a representable power of two
+                const bool bad = (ex == 0u) || (ex == 255u) || (23 - e > 126) || (23 - e < -126);
+                scale[j] = bad ? 1.0f : __uint_as_float((uint32_t)(23 - e + 127) << 23);
+                gbad[j] = bad ? 1 : 0, gbits[j] = (int32_t)gb;
+            }
+            // ---- fold: 16 rows x 4 columns per lane -----------------------------------------------------------
+            int32_t od0[4], od1[4], olo0[4], olo1[4], ohi0[4], ohi1[4], obad[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // Fast fold, ONE stream: with q = x / ulp(s) and S = s / ulp(s) an integer, fl(s + x) / ulp = S + rne(q)
+                // whenever q is not exactly half-way between two integers -- whatever the parity of S (the test is
+                // exact: q - rne(q) = +-1/2); a run that does hold a tie is folded again by the two-stream code.
+                int32_t d1 = 0, lo1 = 0, hi1 = 0;
+                float tmax = 0.0f;
+                uint32_t imax = 0u;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float qq = w[i][j] * scale[j];   // exact (power of two) unless it overflows: caught by imax
+                    const float r = __builtin_rintf(qq);   // v_rndne_f32
+                    tmax = fmaxf(tmax, fabsf(qq - r));     // qq - r is exact; a NaN is caught by imax
+                    imax = max(imax, __float_as_uint(qq) & 0x7FFFFFFFu);
+                    d1 += (int32_t)r;
+                    lo1 = min(lo1, d1);
+                    hi1 = max(hi1, d1);
+                }
+                obad[j] = gbad[j] | (imax >= 0x4B800000u ? 1 : 0);  // |q| >= 2^24, inf or NaN: cannot stay in the binade
+                od0[j] = od1[j] = d1, olo0[j] = olo1[j] = lo1, ohi0[j] = ohi1[j] = hi1;
+                if (!obad[j] && tmax == 0.5f) {
+                    // two streams (even / odd incoming S), exact tie handling.  q = a + f, a = floor(q), 0 <= f < 1,
+                    // classified EXACTLY from 2q (exact: |q| < 2^24): with i2 = floor(2q), a = i2 >> 1 and f is above /
+                    // at / below one half as (i2 odd, 2q not an integer) / (i2 odd, 2q an integer) / (i2 even).
+                    const float scale2 = scale[j] + scale[j];
+                    int32_t dA = 0, dB = 0, loA = 0, loB = 0, hiA = 0, hiB = 0;  // A: even incoming S, B: odd
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float qq = w[i][j] * scale2;
+                        const float fl = floorf(qq);
+                        const int32_t i2 = (int32_t)fl, sticky = qq != fl ? 1 : 0;
+                        const int32_t ai = i2 >> 1, half = i2 & 1;
+                        const int32_t up = half & sticky, tie = half & (sticky ^ 1);
+                        const int32_t bA = dA + ai, bB = dB + ai;
+                        dA = bA + (up | (tie & bA));        // tie: round to the even S
+                        dB = bB + (up | (tie & (1 + bB)));
+                        loA = min(loA, dA), hiA = max(hiA, dA);
+                        loB = min(loB, dB), hiB = max(hiB, dB);
+                    }
+                    od0[j] = dA, od1[j] = dB, olo0[j] = loA, olo1[j] = loB, ohi0[j] = hiA, ohi1[j] = hiB;
+                }
+            }
+            *reinterpret_cast<int4 *>(&p_d0[g][4 * q]) = make_int4(od0[0], od0[1], od0[2], od0[3]);
+            *reinterpret_cast<int4 *>(&p_d1[g][4 * q]) = make_int4(od1[0], od1[1], od1[2], od1[3]);
+            *reinterpret_cast<int4 *>(&p_lo0[g][4 * q]) = make_int4(olo0[0], olo0[1], olo0[2], olo0[3]);
+            *reinterpret_cast<int4 *>(&p_lo1[g][4 * q]) = make_int4(olo1[0], olo1[1], olo1[2], olo1[3]);
+            *reinterpret_cast<int4 *>(&p_hi0[g][4 * q]) = make_int4(ohi0[0], ohi0[1], ohi0[2], ohi0[3]);
+            *reinterpret_cast<int4 *>(&p_hi1[g][4 * q]) = make_int4(ohi1[0], ohi1[1], ohi1[2], ohi1[3]);
+            *reinterpret_cast<int4 *>(&p_bad[g][4 * q]) = make_int4(obad[0], obad[1], obad[2], obad[3]);
+            *reinterpret_cast<int4 *>(&p_gb[g][4 * q]) = make_int4(gbits[0], gbits[1], gbits[2], gbits[3]);
+            fs_wave_lds_sync();
+            // ---- compose the segment's four runs in row order; predict; write ---------------------------------
+            const uint32_t c = cur.c0 + cl;
+            const bool seg_live = kFsSeg * sg < rows_blk;
+            int slot = -1;
+            {
+                FsT f;
+                f.d0 = p_d0[4 * sg][cl], f.d1 = p_d1[4 * sg][cl], f.lo0 = p_lo0[4 * sg][cl], f.lo1 = p_lo1[4 * sg][cl];
+                f.hi0 = p_hi0[4 * sg][cl], f.hi1 = p_hi1[4 * sg][cl];
+                int anybad = p_bad[4 * sg][cl];
+                const uint32_t gb = (uint32_t)p_gb[4 * sg][cl];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+                    FsT gk;
+                    gk.d0 = p_d0[4 * sg + k][cl], gk.d1 = p_d1[4 * sg + k][cl], gk.lo0 = p_lo0[4 * sg + k][cl];
+                    gk.lo1 = p_lo1[4 * sg + k][cl], gk.hi0 = p_hi0[4 * sg + k][cl], gk.hi1 = p_hi1[4 * sg + k][cl];
+                    anybad |= p_bad[4 * sg + k][cl] | ((uint32_t)p_gb[4 * sg + k][cl] != gb ? 1 : 0);
+                    f = fs_compose(f, gk);
+                }
+                const int32_t lim = 1 << 28;
+                if (f.hi0 > lim || f.hi1 > lim || f.lo0 < -lim || f.lo1 < -lim) anybad = 1;
+                // Will the chain have to re-add this segment?  Predict it from the guessed S and, if so, park the
+                // segment's addends contiguously in the side buffer: the chain fetches 256 bytes ahead of time instead
+                // of gathering 4 bytes from each of 64 rows through `perm` when it gets there.
+                bool leaves = false;
+                if (seg_live && c < d && side_cap) {
+                    leaves = anybad != 0;
+                    if (!anybad) {
+                        const int32_t mag = (int32_t)((gb & 0x7FFFFFu) | 0x800000u);
+                        const int32_t Sg = (gb >> 31) ? -mag : mag;
+                        const int32_t lo2 = min(f.lo0, f.lo1), hi2 = max(f.hi0, f.hi1);
+                        // 0.2 % of the binade where the guess is good to ~1e-5 (exact tile sums, the variance pass's
+                        // moments); a guess from every r-th row is off by ~sigma sqrt(r N): three sigmas of that
+                        int32_t margin = 1 << 14;
+                        const float park_rel = (policy && !policy[cur.c0 / kFsCols]) ? 0.0f : park_rel_arg;
+                        if (park_rel > 0.0f) {
+                            const float m2 = park_rel * __builtin_amdgcn_rsqf((float)(cur.tl.t + 1u)) * (float)mag;
+                            margin = m2 > (float)margin ? (m2 < 4194304.0f ? (int32_t)m2 : (1 << 22)) : margin;
+                        }
+                        leaves = (Sg > 0) ? (Sg + lo2 < (1 << 23) + margin || Sg + hi2 > (1 << 24) - margin)
+                                          : (Sg + hi2 > -(1 << 23) - margin || Sg + lo2 < -(1 << 24) + margin);
+                    }
+                }
+                // slots come out of a wave-private chunk of 64 (one atomic per chunk: a counter bumped per segment, or
+                // even per block, serialised the waves on zero-mean data; the rest of a wave's last chunk stays unused)
+                const uint64_t pm = __ballot(leaves);
+                if (pm) {
+                    const uint32_t want = (uint32_t)__builtin_popcountll(pm);
+                    if (want > chunk_left) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(side_count, 64u);
+                        chunk_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        chunk_left = 64u;
+                    }
+                    const uint32_t mine = chunk_base + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
+                    if (leaves && mine < side_cap) slot = (int)mine;
+                    chunk_base += want;
+                    chunk_left -= want;
+                }
+                if (seg_live && c < d) {
+                    const bool two = f.d0 != f.d1 || f.lo0 != f.lo1 || f.hi0 != f.hi1;
+                    const size_t at = ((size_t)cur.tile_id * kFsSegsPerTile + 2 * cur.b + sg) * d + c;
+                    FsS o;
+                    o.d = f.d0, o.lo = f.lo0, o.hi = f.hi0;
+                    o.ef = fs_ef(anybad, two, (int)((gb >> 23) & 0xFFu) - 127, slot);
+                    summ[at] = o;
+                    if (two) {
+                        FsS o2;
+                        o2.d = f.d1, o2.lo = f.lo1, o2.hi = f.hi1, o2.ef = 0;
+                        summ_odd[at] = o2;
+                    }
+                }
+            }
+            pslot[sg][cl] = slot;
+            if (MODE == 0 && sg == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    mom1 += (double)p_s1[k][cl];
+                    mom2 += (double)p_s2[k][cl];
+                }
+            }
+            fs_wave_lds_sync();
+            // ---- park the flagged segments (rare): this lane's 16 rows of the column, 64 bytes --------------------
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sl = pslot[g >> 2][4 * q + j];
+                if (sl >= 0) {
+                    float4 *dst = reinterpret_cast<float4 *>(side + (size_t)sl * kFsSeg + 16 * (g & 3u));
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) dst[i4] = make_float4(w[4 * i4][j], w[4 * i4 + 1][j], w[4 * i4 + 2][j], w[4 * i4 + 3][j]);
+                }
+            }
+        }
+        if (MODE == 0 && tile_mom && (cur.b == kFsBlksPerTile - 1)) {  // the tile's last block: its sums out, reset
+            if (sg == 0 && cur.c0 + cl < d) tile_mom[(size_t)cur.tile_id * d + cur.c0 + cl] = make_double2(mom1, mom2);
+            mom1 = mom2 = 0.0;
+        }
+        if (!has_next) break;
+        ++item;
+        cur = nxt;
+        nxt = nxt2;
+    }
+}
+
+// the exact chain: one wave per (node, column).  The segment summaries are themselves parity transducers: every lane
+// composes kFsSpl consecutive ones (they must share a binade), a wave scan composes the lanes, lane l learns the exact
+// S entering its first segment (as if everything before it in the batch held) and checks its run (same binade as the
+// guesses, every prefix strictly inside it).  The first lane that fails marks where the scan stops: the lanes before
+// it are applied in one step, that lane's segments are walked one by one -- applied, or their 64 rows re-added in the
+// reference's order -- and the scan resumes behind it over the SAME registers (lanes already consumed scan as the
+// identity): no summary is loaded twice.  The next batch of 256 summaries is requested before the current one is
+// scanned, and so are the addends of the first kFsAhead segments the fold kernel predicted to fail (it parked them
+// contiguously): a re-addition costs its 64 additions, not a memory round trip.
+constexpr int kFsSpl = 4;     // segments per lane and batch
+constexpr int kFsAhead = 8;   // parked segments whose addends travel together (two such groups: one complete, one in flight)
+
+__device__ __forceinline__ void fs_scan_incl(FsT &v, uint32_t lane) {
+    // in-row steps by DPP row_shr (lane i <- lane i - off of its 16-lane row), then the totals of rows 0 / 2 into
+    // rows 1 / 3 (row_bcast:15) and of lane 31 into rows 2 and 3 (row_bcast:31): six steps, no LDS round trips
+#define VQ_FS_DPP(X, CTRL) __builtin_amdgcn_update_dpp(0, X, CTRL, 0xF, 0xF, true)
+#define VQ_FS_STEP(CTRL, COND)                                                                         \
+    {                                                                                                  \
+        FsT p;                                                                                         \
+        p.d0 = VQ_FS_DPP(v.d0, CTRL), p.lo0 = VQ_FS_DPP(v.lo0, CTRL), p.hi0 = VQ_FS_DPP(v.hi0, CTRL);  \
+        p.d1 = VQ_FS_DPP(v.d1, CTRL), p.lo1 = VQ_FS_DPP(v.lo1, CTRL), p.hi1 = VQ_FS_DPP(v.hi1, CTRL);  \
+        if (COND) v = fs_compose(p, v);                                                                \
+    }
+    VQ_FS_STEP(0x111, (lane & 15u) >= 1u)   // row_shr:1
+    VQ_FS_STEP(0x112, (lane & 15u) >= 2u)   // row_shr:2
+    VQ_FS_STEP(0x114, (lane & 15u) >= 4u)   // row_shr:4
+    VQ_FS_STEP(0x118, (lane & 15u) >= 8u)   // row_shr:8
+    VQ_FS_STEP(0x142, (lane & 16u) != 0u)   // row_bcast:15 -> rows 1 and 3
+    VQ_FS_STEP(0x143, lane >= 32u)          // row_bcast:31 -> rows 2 and 3
+#undef VQ_FS_STEP
+#undef VQ_FS_DPP
+}
+
+// does a run with prefixes lo .. hi (relative to S) stay strictly inside the binade of S = +-[2^23, 2^24)?  Strictly on
+// the zero side: a sum that rounds to exactly +-2^23 on this grid may have had a smaller magnitude, which the finer
+// grid below represents differently (it may also be exact -- then the segment is merely re-added)
+__device__ __forceinline__ bool fs_inside(int32_t S, int32_t lo, int32_t hi) {
+    return (S > 0) ? (S + lo > (1 << 23) && S + hi <= (1 << 24) - 1) : (S + hi < -(1 << 23) && S + lo >= -((1 << 24) - 1));
+}
+
+// DBG (VQHIP_TSVQ_DEBUG): the instantiation with the counters; the production one carries none of it
 template <int MODE, bool DBG>
 __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, uint32_t d,
                                                  const uint32_t *__restrict__ perm,
                                                  const uint32_t *__restrict__ fast_nodes,
                                                  const uint32_t *__restrict__ tile_base, NodeArrays na,
-                                                 const FsSumm *__restrict__ summ, const float *__restrict__ side,
-                                                 uint32_t *__restrict__ n_fallback, const LevelInfo *__restrict__ lv,
-                                                 uint32_t *__restrict__ dbg_arg) {
+                                                 const FsS *__restrict__ summ, const FsS *__restrict__ summ_odd,
+                                                 const float *__restrict__ side, uint32_t *__restrict__ n_fallback,
+                                                 const LevelInfo *__restrict__ lv, uint32_t *__restrict__ dbg_arg) {
     uint32_t *const dbg = DBG ? dbg_arg : nullptr;  // folds every `if (dbg)` below away when !DBG
-    // dbg (VQHIP_TSVQ_DEBUG): 8 counters of this (level, pass): chains, re-added tiles, most in one chain, and the
-    // first reason the re-added tile failed: unusable summary / other binade than guessed / prefix leaves the binade /
-    // running sum not a normal number
-    __shared__ __attribute__((aligned(16))) float stage[kFsTile];  // addends of the tile being re-added
+    // dbg: 8 counters of this (level, pass): chains, re-added segments, most in one chain, and the first reason the
+    // re-added segment failed: unusable summary / other binade than guessed / prefix leaves the binade / sum not normal
+    __shared__ int plist[64 * kFsSpl];                            // side slots of the batch's parked segments, in order
     if (blockIdx.x >= lv->n_fast) return;
     const uint32_t node = fast_nodes[blockIdx.x], c = blockIdx.y, lane = threadIdx.x;
     const uint32_t a = na.seg_start[node], len = na.seg_len[node];
-    const uint32_t nt = (len + kFsTile - 1) / kFsTile, base = tile_base[blockIdx.x];
+    const uint32_t nseg = (len + kFsSeg - 1) / kFsSeg;
+    const size_t seg0 = (size_t)tile_base[blockIdx.x] * kFsSegsPerTile;
+    const FsS *sp = summ + seg0 * d + c, *sp2 = summ_odd + seg0 * d + c;
     const float mu = (MODE == 1) ? na.centroid[(size_t)node * d + c] : 0.0f;
     float s = (MODE == 0) ? 0.0f : -0.0f;
     uint32_t fallbacks = 0;
-    uint32_t t0 = 0;  // first tile not yet applied
-    // Summaries of a batch sit 32 B x d apart (one cache line each): a restart behind a re-added tile would wait a
-    // full memory latency for them, and so would the re-addition for its 512 addends.  So the next batch (from the
-    // tile behind the failing one, or the following 64) is requested before the re-addition starts, a second batch is
-    // always in flight behind it, and the addends of the first tile the transducer PREDICTED to fail (it parked them,
-    // flag bits 1..) are requested at the start of the batch, next to the scan.
-    auto load_summ = [&](uint32_t tstart) {
-        FsSumm m;
-        m.flag = 1;
-        m.e = 0;
-        m.d0 = m.d1 = m.lo0 = m.lo1 = m.hi0 = m.hi1 = 0;
-        if (tstart + lane < nt) m = summ[(size_t)(base + tstart + lane) * d + c];
-        return m;
+    // UNCONDITIONAL loads (index clamped): a load under `if (t < nseg)` is followed by the merge with the other branch's
+    // value, i.e. by s_waitcnt vmcnt(0) right behind the load -- every batch then cost four serial memory round trips
+    // (~3 us).  What lies past the node's end is marked unusable when the registers are consumed.
+    auto load4 = [&](uint32_t tstart, FsS (&m)[kFsSpl]) {
+#pragma unroll
+        for (int j = 0; j < kFsSpl; ++j) m[j] = sp[(size_t)min(tstart + kFsSpl * lane + (uint32_t)j, nseg - 1u) * d];
     };
-    FsSumm cur = load_summ(0), spec = load_summ(64);
-    uint32_t spec_t = 64;
-    // dbg only: where the time of this chain goes (100 MHz ticks)
-    const uint64_t tk0 = dbg ? wall_clock64() : 0;
-    uint32_t tk_batch = 0, tk_wait_s = 0, tk_redo = 0, tk_wait_v = 0, n_batch = 0;
-    while (t0 < nt) {
-        const uint32_t cnt = min(64u, nt - t0);
-        const uint64_t tka = dbg ? wall_clock64() : 0;
-        const FsSumm mine = cur;
-        if (dbg) {
-            __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): the summaries are here
-            tk_wait_s += (uint32_t)(wall_clock64() - tka);
-            ++n_batch;
-        }
-        const int myslot = (mine.flag >> 1) - 1;  // lanes past the node's tiles carry flag 1: no slot
-        const uint64_t pmask = __ballot(myslot >= 0);
-        const int pf = pmask ? (int)__builtin_ctzll(pmask) : -1;
-        float vp[8];
-        if (pf >= 0) {
-            const float *src = side + (size_t)__shfl(myslot, pf) * kFsTile;
+    // summaries of the next batches in flight behind the one being scanned (a batch's scan is shorter than a memory round
+    // trip): a set is consumed two iterations after its loads were issued
+    constexpr uint32_t kBatch = 64 * kFsSpl;
+    FsS cur[kFsSpl], nx1[kFsSpl], nx2[kFsSpl];
+    load4(0, cur);
+    load4(kBatch, nx1);
+    load4(2 * kBatch, nx2);
+    for (uint32_t t0 = 0; t0 < nseg; t0 += kBatch) {
+        const uint32_t cnt = min(kBatch, nseg - t0), nl = (cnt + kFsSpl - 1) / kFsSpl;  // segments / lanes of this batch
+        FsS m[kFsSpl];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) vp[i] = src[i * 64 + lane];
+        for (int j = 0; j < kFsSpl; ++j) {
+            m[j] = cur[j], cur[j] = nx1[j], nx1[j] = nx2[j];
+            if (t0 + kFsSpl * lane + (uint32_t)j >= nseg) m[j].d = m[j].lo = m[j].hi = 0, m[j].ef = 1;  // past the node's end: unusable
         }
-        const uint32_t sb = __float_as_uint(s), se = (sb >> 23) & 0xFFu;
-        const bool s_normal = (se != 0u) && (se != 255u);
-        const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
-        const int32_t S = (sb >> 31) ? -mag : mag;
-        // exclusive scan of the tile transducers over the lanes (Hillis-Steele on inclusive, then shift)
-        FsPair incl;
-        incl.d[0] = mine.d0, incl.d[1] = mine.d1;
-        incl.lo[0] = mine.lo0, incl.lo[1] = mine.lo1;
-        incl.hi[0] = mine.hi0, incl.hi[1] = mine.hi1;
-        // in-row steps by DPP row_shr (lane i <- lane i - off of its 16-lane row), then the totals of rows 0 / 2 into
-        // rows 1 / 3 (row_bcast:15) and of lane 31 into rows 2 and 3 (row_bcast:31): six steps, no LDS round trips
-        // (ds_bpermute shuffles made a batch cost 1.15 us)
-#define VQ_FS_STEP(CTRL, COND)                                                                   \
-        {                                                                                        \
-            FsPair prev;                                                                         \
-            _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                      \
-                prev.d[p] = __builtin_amdgcn_update_dpp(0, incl.d[p], CTRL, 0xF, 0xF, true);     \
-                prev.lo[p] = __builtin_amdgcn_update_dpp(0, incl.lo[p], CTRL, 0xF, 0xF, true);   \
-                prev.hi[p] = __builtin_amdgcn_update_dpp(0, incl.hi[p], CTRL, 0xF, 0xF, true);   \
-            }                                                                                    \
-            if (COND) incl = fs_compose(prev, incl);                                             \
+        load4(t0 + 3 * kBatch, nx2);  // (into the set the shift has just freed: no register move waits for this load)
+        // the odd streams (runs with an exact tie: rare), else a copy of the even ones
+        FsS m2[kFsSpl];
+        bool two_l = false;
+#pragma unroll
+        for (int j = 0; j < kFsSpl; ++j) {
+            m2[j] = m[j];
+            two_l = two_l || ((m[j].ef & 3) == 2);
         }
-        VQ_FS_STEP(0x111, (lane & 15u) >= 1u)   // row_shr:1
-        VQ_FS_STEP(0x112, (lane & 15u) >= 2u)   // row_shr:2
-        VQ_FS_STEP(0x114, (lane & 15u) >= 4u)   // row_shr:4
-        VQ_FS_STEP(0x118, (lane & 15u) >= 8u)   // row_shr:8
-        VQ_FS_STEP(0x142, (lane & 16u) != 0u)   // row_bcast:15 -> rows 1 and 3
-        VQ_FS_STEP(0x143, lane >= 32u)          // row_bcast:31 -> rows 2 and 3
-#undef VQ_FS_STEP
-        // delta from the batch start to the start of my tile, for the actual parity of S
-        const int odd = S & 1;
-        int32_t before = __shfl_up(incl.d[odd], 1);
-        if (lane == 0) before = 0;
-        const int32_t Sin = S + before;
-        const int podd = Sin & 1;
-        const int32_t lo = podd ? mine.lo1 : mine.lo0, hi = podd ? mine.hi1 : mine.hi0;
-        // every prefix must stay STRICTLY inside the binade on the zero side: a sum that rounds to exactly
-        // +-2^23 on this grid may have had a smaller magnitude, which the finer grid below represents
-        // differently (it may also be exact -- then the tile is merely re-added)
-        bool ok = s_normal && (lane < cnt) && ((mine.flag & 1) == 0) && ((int)se - 127 == mine.e);
-        ok = ok && ((S > 0) ? (Sin + lo > (1 << 23) && Sin + hi <= (1 << 24) - 1)
-                            : (Sin + hi < -(1 << 23) && Sin + lo >= -((1 << 24) - 1)));
-        const uint64_t bad_mask = __ballot(!ok) | (cnt < 64 ? (~0ull << cnt) : 0ull);
-        const uint32_t good = bad_mask ? (uint32_t)__builtin_ctzll(bad_mask) : 64u;  // tiles t0 .. t0+good-1 hold
-        if (good > 0) {
-            const int32_t total = __shfl(incl.d[odd], (int)good - 1);
-            const int32_t S2 = S + total;
-            const uint32_t m2 = (uint32_t)(S2 < 0 ? -S2 : S2);
-            s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2 & 0x7FFFFFu));
-            t0 += good;
+        const bool two = __ballot(two_l) != 0ull;
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < kFsSpl; ++j)
+                if ((m[j].ef & 3) == 2) {
+                    const FsS o = sp2[(size_t)(t0 + kFsSpl * lane + (uint32_t)j) * d];
+                    m2[j].d = o.d, m2[j].lo = o.lo, m2[j].hi = o.hi;
+                }
         }
-        const bool redo = good < cnt;  // tile t0 (the first that failed) is re-added in the reference's order
-        const int32_t flag = __shfl(mine.flag, (int)(redo ? good : 0u));
-        const int32_t fe = __shfl(mine.e, (int)(redo ? good : 0u));
-        {   // the batches behind this one
-            const uint32_t nt0 = t0 + (redo ? 1u : 0u);
-            if (nt0 == spec_t) cur = spec;
-            else cur = load_summ(nt0);
-            spec_t = nt0 + 64;
-            spec = load_summ(spec_t);
+        // ---- parked segments of the batch, in segment order: slots into LDS, the first kFsAhead requested ----
+        uint32_t pk = 0;  // this lane's parked segments, bit j
+#pragma unroll
+        for (int j = 0; j < kFsSpl; ++j) pk |= (fs_ef_slot(m[j].ef) >= 0) ? (1u << j) : 0u;
+        const uint32_t pc = (uint32_t)__builtin_popcount(pk);
+        uint32_t pincl = pc;  // inclusive prefix of pc over the lanes
+        {
+#define VQ_FS_ADD(CTRL, COND) { const int32_t t = __builtin_amdgcn_update_dpp(0, (int32_t)pincl, CTRL, 0xF, 0xF, true); if (COND) pincl += (uint32_t)t; }
+            VQ_FS_ADD(0x111, (lane & 15u) >= 1u)
+            VQ_FS_ADD(0x112, (lane & 15u) >= 2u)
+            VQ_FS_ADD(0x114, (lane & 15u) >= 4u)
+            VQ_FS_ADD(0x118, (lane & 15u) >= 8u)
+            VQ_FS_ADD(0x142, (lane & 16u) != 0u)
+            VQ_FS_ADD(0x143, lane >= 32u)
+#undef VQ_FS_ADD
         }
-        if (dbg) tk_batch += (uint32_t)(wall_clock64() - tka);
-        const uint64_t tkr = dbg ? wall_clock64() : 0;
-        if (redo) {
-            ++fallbacks;
-            if (dbg && lane == 0) {
-                const int why = !s_normal ? 6 : (flag & 1) ? 3 : ((int)se - 127 != fe) ? 4 : 5;
-                atomicAdd(dbg + why, 1u);
+        const uint32_t pbefore = pincl - pc, ptotal = (uint32_t)__builtin_amdgcn_readlane((int)pincl, 63);
+        if (ptotal) {  // uniform
+            fs_wave_lds_sync();  // the previous batch's reads of plist are done
+            uint32_t r = pbefore;
+#pragma unroll
+            for (int j = 0; j < kFsSpl; ++j)
+                if (pk & (1u << j)) plist[r++] = fs_ef_slot(m[j].ef);
+            fs_wave_lds_sync();
+        }
+        // addends of the parked segments, kFsAhead at a time: group A is complete (plain registers: reading it waits for
+        // nothing), group B in flight behind it; when the walk passes A's last rank B becomes A and the next group is
+        // requested.  The batch starts with its first group in B.
+        float pa[kFsAhead], pb[kFsAhead];
+        int32_t pa_base = -kFsAhead;  // rank held by pa[0]
+        auto request_b = [&](uint32_t base) {
+#pragma unroll
+            for (int k = 0; k < kFsAhead; ++k) {
+                pb[k] = 0.0f;
+                if (base + (uint32_t)k < ptotal) pb[k] = side[(size_t)plist[base + (uint32_t)k] * kFsSeg + lane];
             }
-            const uint32_t r0 = t0 * kFsTile;
-            float v[8];
-            const int slot = (flag >> 1) - 1;
-            if ((int)good == pf) {  // the predicted tile: already here
+        };
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = vp[i];
-            } else if (slot >= 0) {  // parked by k_fs_transduce: contiguous
-                const float *src = side + (size_t)slot * kFsTile;
+        for (int k = 0; k < kFsAhead; ++k) pa[k] = 0.0f;
+        request_b(0);
+        // ---- this lane's run: its segments composed, usable iff all are and share a binade ----
+        FsT mine;
+        mine.d0 = m[0].d, mine.lo0 = m[0].lo, mine.hi0 = m[0].hi, mine.d1 = m2[0].d, mine.lo1 = m2[0].lo, mine.hi1 = m2[0].hi;
+        int lane_bad = m[0].ef & 1;
+        const int lane_e = fs_ef_e(m[0].ef);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = src[i * 64 + lane];
+        for (int j = 1; j < kFsSpl; ++j) {
+            FsT gj;
+            gj.d0 = m[j].d, gj.lo0 = m[j].lo, gj.hi0 = m[j].hi, gj.d1 = m2[j].d, gj.lo1 = m2[j].lo, gj.hi1 = m2[j].hi;
+            lane_bad |= (m[j].ef & 1) | (fs_ef_e(m[j].ef) != lane_e ? 1 : 0);
+            if (two) {
+                mine = fs_compose(mine, gj);
             } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const uint32_t r = r0 + (uint32_t)i * 64 + lane;
-                    v[i] = (r < len) ? fs_value<MODE>(X[(size_t)perm[a + r] * d + c], mu) : 0.0f;
-                }
+                mine.lo0 = min(mine.lo0, mine.d0 + gj.lo0);
+                mine.hi0 = max(mine.hi0, mine.d0 + gj.hi0);
+                mine.d0 = mine.d0 + gj.d0;
+                mine.d1 = mine.d0, mine.lo1 = mine.lo0, mine.hi1 = mine.hi0;
             }
-            // The 512 additions in row order.  Through v_readlane each addend went VGPR -> SGPR -> v_add with the
-            // hazard wait in between: 29 cycles per addition, 7 us per tile (measured).  Staged in LDS instead, every
-            // lane reads the same four addends per ds_read_b128 (a broadcast) and carries the same running sum: the
-            // chain runs at the add's own latency (~10 cycles), the next 16 addends are read while these are added.
-            // Rows past the node's end are +0.0 (the sum is never -0.0 once a real row is in: no bit changes).
-            __syncthreads();  // one wave per block: orders the previous tile's reads before these writes
-            const uint32_t rows_here = min((uint32_t)kFsTile, len - r0);
-            if (dbg) {
-                __builtin_amdgcn_s_waitcnt(0);
-                tk_wait_v += (uint32_t)(wall_clock64() - tkr);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) stage[i * 64 + lane] = ((uint32_t)i * 64 + lane < rows_here) ? v[i] : 0.0f;  // a parked tile holds its real rows only
-            __syncthreads();
-            float4 qa[4], qb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const float4 *>(stage + 4 * u);
-            for (uint32_t r = 0; r < rows_here; r += 32) {  // whole groups of 16: the tail adds zeros
-#pragma unroll
-                for (int u = 0; u < 4; ++u) qb[u] = *reinterpret_cast<const float4 *>(stage + ((r + 16 + 4 * u) & (kFsTile - 1)));
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    s = s + qa[u].x;
-                    s = s + qa[u].y;
-                    s = s + qa[u].z;
-                    s = s + qa[u].w;
-                }
-                if (r + 16 >= rows_here) break;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) qa[u] = *reinterpret_cast<const float4 *>(stage + ((r + 32 + 4 * u) & (kFsTile - 1)));
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    s = s + qb[u].x;
-                    s = s + qb[u].y;
-                    s = s + qb[u].z;
-                    s = s + qb[u].w;
-                }
-            }
-            t0 += 1;
-            if (dbg) tk_redo += (uint32_t)(wall_clock64() - tkr);
         }
-    }
-    if (dbg && lane == 0) {
-        const uint32_t tot = (uint32_t)(wall_clock64() - tk0);
-        if (atomicMax(dbg + 8, tot) < tot) {  // (racy between chains of similar length: diagnostic only)
-            dbg[9] = n_batch, dbg[10] = tk_batch, dbg[11] = tk_wait_s, dbg[12] = fallbacks, dbg[13] = tk_redo, dbg[14] = tk_wait_v;
+        // ---- lane `good` does not hold as a whole: its segments one by one, applied or re-added ----
+        auto step_lane = [&](uint32_t good) {
+            const uint32_t pb_g = (uint32_t)__builtin_amdgcn_readlane((int)pbefore, (int)good),
+                           pk_g = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)good);
+#pragma unroll
+            for (int j = 0; j < kFsSpl; ++j) {
+                const uint32_t seg = t0 + kFsSpl * good + (uint32_t)j;
+                if (seg < nseg) {  // uniform
+                    const int32_t gd0 = __builtin_amdgcn_readlane(m[j].d, (int)good), glo0 = __builtin_amdgcn_readlane(m[j].lo, (int)good),
+                                  ghi0 = __builtin_amdgcn_readlane(m[j].hi, (int)good), gef = __builtin_amdgcn_readlane(m[j].ef, (int)good);
+                    int32_t gd1 = gd0, glo1 = glo0, ghi1 = ghi0;
+                    if (two) {
+                        gd1 = __builtin_amdgcn_readlane(m2[j].d, (int)good), glo1 = __builtin_amdgcn_readlane(m2[j].lo, (int)good);
+                        ghi1 = __builtin_amdgcn_readlane(m2[j].hi, (int)good);
+                    }
+                    const uint32_t sb1 = __float_as_uint(s), se1 = (sb1 >> 23) & 0xFFu;
+                    const int32_t mag1 = (int32_t)((sb1 & 0x7FFFFFu) | 0x800000u);
+                    const int32_t S1 = (sb1 >> 31) ? -mag1 : mag1;
+                    const bool odd1 = (S1 & 1) != 0;
+                    const bool holds = (se1 != 0u) && (se1 != 255u) && !(gef & 1) && ((int)se1 - 127 == fs_ef_e(gef)) &&
+                                       fs_inside(S1, odd1 ? glo1 : glo0, odd1 ? ghi1 : ghi0);
+                    if (holds) {
+                        const int32_t S2 = S1 + (odd1 ? gd1 : gd0);
+                        const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
+                        s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se1 << 23) | (m2a & 0x7FFFFFu));
+                    } else {
+                        ++fallbacks;
+                        if (dbg && lane == 0) {
+                            const int why = (se1 == 0u || se1 == 255u) ? 6 : (gef & 1) ? 3 : ((int)se1 - 127 != fs_ef_e(gef)) ? 4 : 5;
+                            atomicAdd(dbg + why, 1u);
+                        }
+                        const uint32_t r0 = seg * kFsSeg, rows_here = min(kFsSeg, len - r0);
+                        const int slot = fs_ef_slot(gef);
+                        float vv;
+                        if (slot >= 0) {  // parked by k_fs_fold: contiguous, requested a group ahead
+                            const int32_t rank = (int32_t)(pb_g + (uint32_t)__builtin_popcount(pk_g & ((1u << j) - 1u)));
+                            while (rank >= pa_base + kFsAhead) {  // uniform
+#pragma unroll
+                                for (int k = 0; k < kFsAhead; ++k) pa[k] = pb[k];
+                                pa_base += kFsAhead;
+                                request_b((uint32_t)(pa_base + kFsAhead));
+                            }
+                            const int32_t at = rank - pa_base;
+                            vv = pa[0];
+#pragma unroll
+                            for (int k = 1; k < kFsAhead; ++k) vv = (at == k) ? pa[k] : vv;
+                        } else {
+                            vv = (lane < rows_here) ? fs_value<MODE>(X[(size_t)perm[a + r0 + lane] * d + c], mu) : 0.0f;
+                            if (dbg && lane == 0) atomicAdd(dbg + 7, 1u);
+                        }
+                        if (lane >= rows_here) vv = 0.0f;  // rows past the node's end: +0.0 (the sum is never -0.0 once a real row is in)
+                        // The 64 additions in row order, the addends handed from lane to SGPR sixteen at a time AHEAD of
+                        // the additions that use them: a v_readlane next to its v_add pays the VALU-writes-SGPR hazard on
+                        // every addition (29 cycles each, measured); with the reads a group ahead the chain runs at the
+                        // add's own latency (~10 cycles) and needs neither LDS staging nor its round trip.
+                        float tq[16], tn[16];
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) tq[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), k));
+#pragma unroll
+                        for (int grp = 0; grp < 4; ++grp) {
+                            if (grp < 3) {
+#pragma unroll
+                                for (int k = 0; k < 16; ++k) tn[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), 16 * (grp + 1) + k));
+                            }
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) s = s + tq[k];
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) tq[k] = tn[k];
+                        }
+                    }
+                }
+            }
+        };
+        const uint64_t past = nl < 64 ? (~0ull << nl) : 0ull;  // lanes behind the batch's last
+        if (!two) {
+            // One stream (no exact tie anywhere in the batch: every batch of continuous data): the deltas simply add, so ONE
+            // scan serves the whole batch -- behind a lane that did not hold, the S entering lane l is the S the walk
+            // arrived at plus the deltas of the lanes in between.
+            int32_t incl = mine.d0;
+#define VQ_FS_ADD(CTRL, COND) { const int32_t t = __builtin_amdgcn_update_dpp(0, incl, CTRL, 0xF, 0xF, true); if (COND) incl += t; }
+            VQ_FS_ADD(0x111, (lane & 15u) >= 1u)
+            VQ_FS_ADD(0x112, (lane & 15u) >= 2u)
+            VQ_FS_ADD(0x114, (lane & 15u) >= 4u)
+            VQ_FS_ADD(0x118, (lane & 15u) >= 8u)
+            VQ_FS_ADD(0x142, (lane & 16u) != 0u)
+            VQ_FS_ADD(0x143, lane >= 32u)
+#undef VQ_FS_ADD
+            int32_t before = __shfl_up(incl, 1);
+            if (lane == 0) before = 0;
+            const bool lane_ok = (lane < nl) && !lane_bad;
+            uint32_t start = 0;   // first lane of the batch not yet applied
+            int32_t base_d = 0;   // inclusive delta of lane start - 1
+            for (;;) {
+                const uint32_t sb = __float_as_uint(s), se = (sb >> 23) & 0xFFu;
+                const bool s_normal = (se != 0u) && (se != 255u);
+                const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
+                const int32_t S = (sb >> 31) ? -mag : mag;
+                const bool ok = s_normal && lane_ok && ((int)se - 127 == lane_e) && fs_inside(S + before - base_d, mine.lo0, mine.hi0);
+                const uint64_t below = start ? ((~0ull) >> (64 - start)) : 0ull;
+                const uint64_t bad_mask = (__ballot(!ok) | past) & ~below;
+                const uint32_t good = bad_mask ? (uint32_t)__builtin_ctzll(bad_mask) : 64u;  // lanes start .. good-1 hold (uniform)
+                if (good > start) {
+                    const int32_t S2 = S + __builtin_amdgcn_readlane(incl, (int)good - 1) - base_d;
+                    const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
+                    s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2a & 0x7FFFFFu));
+                }
+                if (good >= nl) break;
+                step_lane(good);
+                base_d = __builtin_amdgcn_readlane(incl, (int)good);
+                start = good + 1;
+                if (start >= nl) break;
+            }
+        } else {
+            // exact ties in the batch: which stream a lane's run takes depends on the parity of the S entering it, so the
+            // scan is repeated behind every lane that did not hold (lanes already consumed scan as the identity)
+            uint32_t start = 0;
+            for (;;) {
+                const uint32_t sb = __float_as_uint(s), se = (sb >> 23) & 0xFFu;
+                const bool s_normal = (se != 0u) && (se != 255u);
+                const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
+                const int32_t S = (sb >> 31) ? -mag : mag;
+                const bool in = lane >= start;
+                FsT v;
+                v.d0 = in ? mine.d0 : 0, v.d1 = in ? mine.d1 : 0, v.lo0 = in ? mine.lo0 : 0, v.lo1 = in ? mine.lo1 : 0;
+                v.hi0 = in ? mine.hi0 : 0, v.hi1 = in ? mine.hi1 : 0;
+                fs_scan_incl(v, lane);
+                const int32_t incl_d = (S & 1) ? v.d1 : v.d0;  // delta from position `start`, for the actual parity of S
+                int32_t before = __shfl_up(incl_d, 1);
+                if (lane == 0) before = 0;
+                const int32_t Sin = S + before;
+                const bool podd = (Sin & 1) != 0;
+                bool ok = s_normal && (lane < nl) && !lane_bad && ((int)se - 127 == lane_e);
+                ok = ok && fs_inside(Sin, podd ? mine.lo1 : mine.lo0, podd ? mine.hi1 : mine.hi0);
+                const uint64_t below = start ? ((~0ull) >> (64 - start)) : 0ull;
+                const uint64_t bad_mask = (__ballot(!ok) | past) & ~below;
+                const uint32_t good = bad_mask ? (uint32_t)__builtin_ctzll(bad_mask) : 64u;
+                if (good > start) {
+                    const int32_t S2 = S + __builtin_amdgcn_readlane(incl_d, (int)good - 1);
+                    const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
+                    s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2a & 0x7FFFFFu));
+                }
+                if (good >= nl) break;
+                step_lane(good);
+                start = good + 1;
+                if (start >= nl) break;
+            }
         }
     }
     if (lane == 0) {
@@ -1527,64 +1629,42 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
     }
 }
 
-// debug aid (VQHIP_TSVQ_CHECK=1): per (node, column) walk the tiles one by one, compare the summary-applied
+// debug aid (VQHIP_TSVQ_CHECK=1): per (node, column) walk the segments one by one, compare the summary-applied
 // sum with the row-by-row sum and report the first disagreement
 template <int MODE>
 __global__ __launch_bounds__(64) void k_fs_check(const float *__restrict__ X, uint32_t d, const uint32_t *__restrict__ perm,
                                                  const uint32_t *__restrict__ fast_nodes,
                                                  const uint32_t *__restrict__ tile_base, NodeArrays na,
-                                                 const FsSumm *__restrict__ summ, const LevelInfo *__restrict__ lv) {
+                                                 const FsS *__restrict__ summ, const FsS *__restrict__ summ_odd,
+                                                 const LevelInfo *__restrict__ lv) {
     if (blockIdx.x >= lv->n_fast) return;
     const uint32_t node = fast_nodes[blockIdx.x], c = blockIdx.y;
     if (threadIdx.x != 0) return;
     const uint32_t a = na.seg_start[node], len = na.seg_len[node];
-    const uint32_t nt = (len + kFsTile - 1) / kFsTile, base = tile_base[blockIdx.x];
+    const uint32_t nseg = (len + kFsSeg - 1) / kFsSeg;
+    const size_t seg0 = (size_t)tile_base[blockIdx.x] * kFsSegsPerTile;
     const float mu = (MODE == 1) ? na.centroid[(size_t)node * d + c] : 0.0f;
     float s = (MODE == 0) ? 0.0f : -0.0f;
-    for (uint32_t t = 0; t < nt; ++t) {
-        const FsSumm sm = summ[(size_t)(base + t) * d + c];
+    for (uint32_t t = 0; t < nseg; ++t) {
+        const FsS sm = summ[(seg0 + t) * d + c];
+        FsS so = sm;
+        if ((sm.ef & 3) == 2) so = summ_odd[(seg0 + t) * d + c];
         float seq = s;
-        const uint32_t r0 = t * kFsTile, r1 = min(len, r0 + kFsTile);
+        const uint32_t r0 = t * kFsSeg, r1 = min(len, r0 + kFsSeg);
         for (uint32_t r = r0; r < r1; ++r) seq = seq + fs_value<MODE>(X[(size_t)perm[a + r] * d + c], mu);
         const uint32_t sb = __float_as_uint(s), se = (sb >> 23) & 0xFFu;
-        bool ok = ((sm.flag & 1) == 0) && se != 0u && se != 255u && ((int)se - 127 == sm.e);
-        float fast = seq;
-        if (ok) {
+        if (((sm.ef & 1) == 0) && se != 0u && se != 255u && ((int)se - 127 == fs_ef_e(sm.ef))) {
             const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
             const int32_t S = (sb >> 31) ? -mag : mag;
-            const int odd = S & 1;
-            const int32_t D = odd ? sm.d1 : sm.d0, lo = odd ? sm.lo1 : sm.lo0, hi = odd ? sm.hi1 : sm.hi0;
-            ok = (S > 0) ? (S + lo > (1 << 23) && S + hi <= (1 << 24) - 1) : (S + hi < -(1 << 23) && S + lo >= -((1 << 24) - 1));
-            if (ok) {
+            const bool odd = (S & 1) != 0;
+            const int32_t D = odd ? so.d : sm.d, lo = odd ? so.lo : sm.lo, hi = odd ? so.hi : sm.hi;
+            if (fs_inside(S, lo, hi)) {
                 const int32_t S2 = S + D;
                 const uint32_t m2 = (uint32_t)(S2 < 0 ? -S2 : S2);
-                fast = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2 & 0x7FFFFFu));
+                const float fast = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2 & 0x7FFFFFu));
                 if (__float_as_uint(fast) != __float_as_uint(seq)) {
-                    printf("[fs_check] mode %d node %u col %u tile %u: s=%.9g (S=%d odd=%d e=%d) summary D=%d lo=%d hi=%d -> %.9g, row by row %.9g\n",
-                           MODE, node, c, t, s, S, odd, sm.e, D, lo, hi, fast, seq);
-                    // find the first element where the transducer deviates
-                    float run = s;
-                    int32_t Sr = S;
-                    const float scale = __uint_as_float((uint32_t)(23 - sm.e + 127) << 23);
-                    for (uint32_t r = r0; r < r1; ++r) {
-                        const float v = fs_value<MODE>(X[(size_t)perm[a + r] * d + c], mu);
-                        run = run + v;
-                        const float q = v * scale;
-                        const float tt = fabsf(q), at = floorf(tt), ft = tt - at;
-                        const bool neg = q < 0.0f, frac = ft != 0.0f;
-                        const int32_t ai = neg ? -(int32_t)at - (frac ? 1 : 0) : (int32_t)at;
-                        const int32_t tie = ft == 0.5f, up = (neg ? (frac && ft < 0.5f) : (ft > 0.5f));
-                        const int32_t bse = Sr + ai;
-                        Sr = bse + (up | (tie & bse));
-                        const uint32_t rb = __float_as_uint(run);
-                        const int32_t rm = (int32_t)((rb & 0x7FFFFFu) | 0x800000u);
-                        const int32_t Rr = (rb >> 31) ? -rm : rm;
-                        if (Rr != Sr || ((rb >> 23) & 0xFFu) != se) {
-                            printf("[fs_check]   first deviation at row %u: v=%.9g q=%.9g ai=%d up=%d tie=%d  transducer S=%d, float S=%d (exp %u vs %u)\n",
-                                   r - r0, v, q, ai, up, tie, Sr, Rr, (rb >> 23) & 0xFFu, se);
-                            break;
-                        }
-                    }
+                    printf("[fs_check] mode %d node %u col %u segment %u: s=%.9g (S=%d odd=%d e=%d) summary D=%d lo=%d hi=%d -> %.9g, row by row %.9g\n",
+                           MODE, node, c, t, s, S, (int)odd, fs_ef_e(sm.ef), D, lo, hi, fast, seq);
                     return;
                 }
             }
@@ -1779,10 +1859,10 @@ struct TsvqBuildWs {
     int device = -1;
     DevBuf b_perm[2], b_nodeof[2], b_vals, b_flags, b_scan, b_bsums, b_hist, b_lvl, b_remap;
     DevBuf b_seg_start, b_seg_len, b_split, b_nv, b_nleft, b_median, b_selp, b_selr, b_child, b_cent, b_var, b_left, b_right;
-    DevBuf b_fs_tiles, b_fs_nodes, b_fs_base, b_fs_nt, b_fs_sum, b_fs_summ, b_lvl_slow, b_fs_fb, b_fs_side, b_fs_mom, b_lv;
-    DevBuf *all[35] = {&b_perm[0], &b_perm[1], &b_nodeof[0], &b_nodeof[1], &b_vals, &b_flags, &b_scan, &b_bsums, &b_hist,
+    DevBuf b_fs_tiles, b_fs_nodes, b_fs_base, b_fs_nt, b_fs_sum, b_fs_pref, b_fs_summ2, b_fs_summ, b_lvl_slow, b_fs_fb, b_fs_side, b_fs_mom, b_lv;
+    DevBuf *all[37] = {&b_perm[0], &b_perm[1], &b_nodeof[0], &b_nodeof[1], &b_vals, &b_flags, &b_scan, &b_bsums, &b_hist,
                        &b_lvl, &b_remap, &b_seg_start, &b_seg_len, &b_split, &b_nv, &b_nleft, &b_median, &b_selp, &b_selr,
-                       &b_child, &b_cent, &b_var, &b_left, &b_right, &b_fs_tiles, &b_fs_nodes, &b_fs_base, &b_fs_nt, &b_fs_sum,
+                       &b_child, &b_cent, &b_var, &b_left, &b_right, &b_fs_tiles, &b_fs_nodes, &b_fs_base, &b_fs_nt, &b_fs_sum, &b_fs_pref, &b_fs_summ2,
                        &b_fs_summ, &b_lvl_slow, &b_fs_fb, &b_fs_side, &b_fs_mom, &b_lv};
     // pinned host staging of the node download.  A pageable destination of a few MB is pinned by the runtime for the
     // copy; when that memory is later unmapped (a std::vector or numpy array of 4 MB goes back to the OS) the driver
@@ -1909,7 +1989,6 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     LevelInfo *lv = ws.b_lv.as<LevelInfo>();
 
     static const char *nopark = getenv("VQHIP_TSVQ_NOPARK");
-    const uint32_t side_cap = (nopark && nopark[0] == '1') ? 0u : 32768u;  // parked tiles per pass (64 MB); beyond it the re-addition gathers
     static const char *seq_env = getenv("VQHIP_TSVQ_SEQSUM");  // =1: plain chain everywhere (A/B)
     const bool can_fast = (d % 4 == 0) && !(seq_env && seq_env[0] == '1');  // 16-byte row parts
     static const char *samp_env = getenv("VQHIP_TSVQ_SAMPLE");  // rows read for the mean pass's binade guess: 1/N (default 1/8)
@@ -1918,8 +1997,12 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     // applies to every column
     const uint32_t n_cblk = (d + kFsCols - 1) / kFsCols;
     const bool adaptive_sampling = !samp_env && can_fast && n_cblk <= 1024;
-    const float park_rel = fs_sample > 1 ? 3.0f * 0.6f * sqrtf((float)fs_sample / (float)kFsTile) : 0.0f;  // k_fs_transduce: parking margin
-    const size_t fs_lds_bytes = (size_t)kFsCols * (kFsTile + 1) * 4 + 8 * kFsCols * sizeof(FsSeg);
+    const float park_rel = fs_sample > 1 ? 3.0f * 0.6f * sqrtf((float)fs_sample / (float)kFsTile) : 0.0f;  // k_fs_fold: parking margin
+    // segment summaries [segment slot][column]: eight slots per tile, a node's segments contiguous
+    const size_t seg_slots = (size_t)tiles_max * kFsSegsPerTile;
+    // parked segments per pass (256 bytes each; beyond the cap the re-addition gathers its rows, two dependent loads): half
+    // of all segments (zero-mean columns park up to a third at the deeper levels), 256 MB at most
+    const uint32_t side_cap = (nopark && nopark[0] == '1') ? 0u : (uint32_t)std::min<uint64_t>(seg_slots * d / 2 + 1, 1ull << 20);
     if (can_fast) {
         VQ_TRY(ws.b_fs_tiles.ensure((size_t)tiles_max * sizeof(FsTile)));
         VQ_TRY(ws.b_fs_nodes.ensure((size_t)fast_max * 4));
@@ -1927,17 +2010,11 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         VQ_TRY(ws.b_fs_nt.ensure((size_t)fast_max * 4));
         if (n >= fs_min_rows) {
             VQ_TRY(ws.b_fs_sum.ensure((size_t)tiles_max * d * 8));
-            VQ_TRY(ws.b_fs_summ.ensure((size_t)tiles_max * d * sizeof(FsSumm)));
+            VQ_TRY(ws.b_fs_pref.ensure((size_t)tiles_max * d * 4));
             VQ_TRY(ws.b_fs_mom.ensure((size_t)tiles_max * d * sizeof(double2)));
-            VQ_TRY(ws.b_fs_side.ensure((size_t)side_cap * kFsTile * 4));
-        }
-        static PerDeviceOnce fs_attr;
-        if (fs_attr.needed()) {
-            VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fs_transduce<0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fs_lds_bytes));
-            VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fs_transduce<1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fs_lds_bytes));
-            fs_attr.done();
+            VQ_TRY(ws.b_fs_summ.ensure(seg_slots * d * sizeof(FsS)));
+            VQ_TRY(ws.b_fs_summ2.ensure(seg_slots * d * sizeof(FsS)));
+            VQ_TRY(ws.b_fs_side.ensure(std::max<size_t>((size_t)side_cap * kFsSeg * 4, 16)));
         }
     } else {
         VQ_TRY(ws.b_fs_tiles.ensure(16));
@@ -1976,8 +2053,9 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     uint32_t *lvl_split = ws.b_lvl.as<uint32_t>(), *remap = ws.b_remap.as<uint32_t>(), *slow_nodes = ws.b_lvl_slow.as<uint32_t>();
     const FsTile *tl = ws.b_fs_tiles.as<FsTile>();
     double *ts = ws.b_fs_sum.as<double>();
-    FsSumm *sm = ws.b_fs_summ.as<FsSumm>();
+    float *tp = ws.b_fs_pref.as<float>();
     double2 *mom = ws.b_fs_mom.as<double2>();
+    FsS *sm = ws.b_fs_summ.as<FsS>(), *sm2 = ws.b_fs_summ2.as<FsS>();
     const uint32_t *fn = ws.b_fs_nodes.as<uint32_t>(), *fb = ws.b_fs_base.as<uint32_t>(), *fc = ws.b_fs_nt.as<uint32_t>();
     float *side = ws.b_fs_side.as<float>();
     uint32_t *fbk = ws.b_fs_fb.as<uint32_t>();
@@ -2005,26 +2083,29 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         VQ_LAUNCH_CHECK("k_seg_colsum");
         if (ub_fast == 0) return VQHIP_OK;
         const uint32_t ub_tiles = std::min(tiles_max, n / kFsTile + ub_fast);
-        const dim3 tgrid(ub_tiles * ncb), xgrid(std::min<uint32_t>(ub_tiles * ncb, (uint32_t)num_cus() * 2));  // persistent: two workgroups fit a CU's LDS
+        // k_fs_fold: persistent single-wave workgroups, two per SIMD (the kernel's register budget)
+        const dim3 tgrid(ub_tiles * ncb), xgrid(std::min<uint32_t>(ub_tiles * ncb, (uint32_t)num_cus() * 8));
         const dim3 pgrid(ub_fast, ncb), cgrid(ub_fast, d);
         if (mode == 0) {
+            // the binade guesses: f64 sums of every 8th group of rows of each tile where k_fs_policy allows (|mean| >= sigma),
+            // of every row elsewhere; prefix over the node's tiles
             hipLaunchKernelGGL(k_fs_tile_sums<0>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts, fs_sample, policy, lvp);
-            hipLaunchKernelGGL(k_fs_prefix, pgrid, dim3(1024), 0, stream, d, fb, fc, ts, lvp, fbk + 1);
-            hipLaunchKernelGGL(k_fs_transduce<0>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, lvp, na, ts, sm, side, side_cap, fbk + 1, mom, park_rel, policy);
-            if (dbg) hipLaunchKernelGGL((k_fs_chain<0, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
-            else hipLaunchKernelGGL((k_fs_chain<0, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
+            hipLaunchKernelGGL(k_fs_prefix<false>, pgrid, dim3(1024), 0, stream, d, fn, fb, fc, na, ts, mom, tp, lvp, fbk + 1);
+            hipLaunchKernelGGL(k_fs_fold<0>, xgrid, dim3(64), 0, stream, X, d, perm, tl, lvp, na, tp, sm, sm2, side, side_cap, fbk + 1, mom, park_rel, policy);
+            if (dbg) hipLaunchKernelGGL((k_fs_chain<0, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg);
+            else hipLaunchKernelGGL((k_fs_chain<0, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg);
         } else {
-            // the guess comes from the moments the mean pass of the same level left behind (same tile table: every node
+            // the guess comes from the sums the mean pass of the same level left behind (same tile table: every node
             // long enough for the emulation has more than one row, so it is a split node whenever the level splits)
-            hipLaunchKernelGGL(k_fs_prefix_var, pgrid, dim3(1024), 0, stream, X, d, perm, fn, fb, fc, na, mom, ts, lvp, fbk + 1);
-            hipLaunchKernelGGL(k_fs_transduce<1>, xgrid, dim3(256), fs_lds_bytes, stream, X, d, perm, tl, lvp, na, ts, sm, side, side_cap, fbk + 1, (double2 *)nullptr, 0.0f, (const uint32_t *)nullptr);
-            if (dbg) hipLaunchKernelGGL((k_fs_chain<1, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
-            else hipLaunchKernelGGL((k_fs_chain<1, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, side, fbk, lvp, dbg);
+            hipLaunchKernelGGL(k_fs_prefix<true>, pgrid, dim3(1024), 0, stream, d, fn, fb, fc, na, ts, mom, tp, lvp, fbk + 1);
+            hipLaunchKernelGGL(k_fs_fold<1>, xgrid, dim3(64), 0, stream, X, d, perm, tl, lvp, na, tp, sm, sm2, side, side_cap, fbk + 1, (double2 *)nullptr, 0.0f, (const uint32_t *)nullptr);
+            if (dbg) hipLaunchKernelGGL((k_fs_chain<1, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg);
+            else hipLaunchKernelGGL((k_fs_chain<1, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg);
         }
         VQ_LAUNCH_CHECK("k_fs_*");
         if (getenv("VQHIP_TSVQ_CHECK")) {
-            if (mode == 0) hipLaunchKernelGGL(k_fs_check<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, lvp);
-            else hipLaunchKernelGGL(k_fs_check<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, lvp);
+            if (mode == 0) hipLaunchKernelGGL(k_fs_check<0>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, lvp);
+            else hipLaunchKernelGGL(k_fs_check<1>, cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, lvp);
             VQ_HIP(hipStreamSynchronize(stream));
         }
         return VQHIP_OK;
@@ -2126,7 +2207,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         uint32_t fbn[2 + 64 * 2 * 16];
         VQ_HIP(hipMemcpyAsync(fbn, fbk, sizeof(fbn), hipMemcpyDeviceToHost, stream));
         VQ_HIP(hipStreamSynchronize(stream));
-        fprintf(stderr, "[vqhip] tsvq build: %u tile re-additions in the exact column sums\n", fbn[0]);
+        fprintf(stderr, "[vqhip] tsvq build: %u re-added 64-row segments in the exact column sums\n", fbn[0]);
         if (policy) {
             uint32_t pol[1024];
             VQ_HIP(hipMemcpy(pol, policy, (size_t)n_cblk * 4, hipMemcpyDeviceToHost));
@@ -2137,12 +2218,9 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         for (uint32_t q = 0; q < 128; ++q) {
             const uint32_t *c8 = fbn + 2 + q * 16;
             if (c8[0])
-                fprintf(stderr, "[vqhip]   level %u %s: %u chains, %u tiles re-added (most in one chain %u): unusable summary %u, "
-                                "other binade than guessed %u, prefix leaves the binade %u, sum not normal %u\n",
-                        q / 2, (q & 1) ? "variance" : "mean", c8[0], c8[1], c8[2], c8[3], c8[4], c8[5], c8[6]);
-            if (c8[0])  // the slowest chain of the pass, 10 ns ticks of the 100 MHz clock
-                fprintf(stderr, "[vqhip]     slowest chain: %.1f us = %u batches %.1f us (waiting for summaries %.1f) + %u re-additions %.1f us (waiting for addends %.1f)\n",
-                        c8[8] * 0.01, c8[9], c8[10] * 0.01, c8[11] * 0.01, c8[12], c8[13] * 0.01, c8[14] * 0.01);
+                fprintf(stderr, "[vqhip]   level %u %s: %u chains, %u segments re-added (most in one chain %u): unusable summary %u, "
+                                "other binade than guessed %u, prefix leaves the binade %u, sum not normal %u; %u gathered (not parked)\n",
+                        q / 2, (q & 1) ? "variance" : "mean", c8[0], c8[1], c8[2], c8[3], c8[4], c8[5], c8[6], c8[7]);
         }
     }
     // nodes -> host, then BFS -> pre-order (the oracle's numbering)
