@@ -268,47 +268,18 @@ __global__ __launch_bounds__(256) void k_pick_split(const uint32_t *__restrict__
     }
 }
 
-// vals[i] = X[perm[i]][split_dim(node of i)]; nv[node] ends as the non-NaN count
-__global__ __launch_bounds__(256) void k_gather_vals(const float *__restrict__ X, uint32_t d, uint32_t n,
-                                                     const uint32_t *__restrict__ perm,
-                                                     const uint32_t *__restrict__ node_of,
-                                                     const uint32_t *__restrict__ remap,
-                                                     const uint32_t *__restrict__ lvl_node, NodeArrays na,
-                                                     float *__restrict__ vals) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    uint32_t li = node_of[i];
-    if (li != kInactive) li = remap[li];  // level-local node index -> index among the level's split nodes
-    if (li == kInactive) return;
-    const uint32_t node = lvl_node[li];
-    const float x = X[(size_t)perm[i] * d + na.split_dim[node]];
-    vals[i] = x;
-    if (x != x) atomicSub(&na.nv[node], 1u);  // nv starts at seg_len (k_pick_split); NaNs are rare
-}
-
-// ranks of the two order statistics the median needs (tsvq.rs:77-81)
-__global__ void k_select_init(const uint32_t *__restrict__ lvl_node, const LevelInfo *__restrict__ lv, NodeArrays na) {
-    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= lv->n_split) return;
-    const uint32_t node = lvl_node[li];
-    const uint32_t nv = na.nv[node];
-    if (nv == 0) {
-        na.sel_rank[2 * node] = na.sel_rank[2 * node + 1] = 0;
-        return;
-    }
-    const uint32_t h = nv / 2;
-    na.sel_rank[2 * node + 0] = (nv % 2 == 0) ? h - 1 : h;
-    na.sel_rank[2 * node + 1] = h;
-}
-
 // one radix-select round: histogram of the byte at `shift` among keys matching the prefix.
 // Positions are grouped by node, so a workgroup's contiguous chunk touches very few nodes:
 // histograms are privatised in LDS (8 slots keyed by the level-local node index, claimed with
 // a CAS) and flushed once; the rare slot collision falls back to a global atomic.  Unprivatised,
 // the root level is 1M atomics on 512 words (0.64 ms per round).
 constexpr uint32_t kHistSlots = 8;
-__global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ vals, uint32_t n,
-                                                     uint32_t chunk,
+// GATHER: the first round (shift 24).  The values are not there yet: vals[i] = X[perm[i]][split_dim(node of i)] is formed
+// here (and written for the later rounds, the median test and the partition), NaNs are taken off nv[node] (k_pick_split
+// set it to the segment length); no prefix has been chosen yet, so every key counts for both ranks.
+template <bool GATHER>
+__global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ X, uint32_t d, const uint32_t *__restrict__ perm,
+                                                     float *__restrict__ vals, uint32_t n, uint32_t chunk,
                                                      const uint32_t *__restrict__ node_of,
                                                      const uint32_t *__restrict__ remap,
                                                      const uint32_t *__restrict__ lvl_node, NodeArrays na,
@@ -323,11 +294,18 @@ __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ v
     const uint32_t i1 = min(n, i0 + chunk);
     for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256) {
         uint32_t li = node_of[i];
-        if (li != kInactive) li = remap[li];
+        if (li != kInactive) li = remap[li];  // level-local node index -> index among the level's split nodes
         if (li == kInactive) continue;
-        const float x = vals[i];
-        if (x != x) continue;
         const uint32_t node = lvl_node[li];
+        float x;
+        if (GATHER) {
+            x = X[(size_t)perm[i] * d + na.split_dim[node]];
+            vals[i] = x;
+            if (x != x) atomicSub(&na.nv[node], 1u);  // nv starts at seg_len (k_pick_split); NaNs are rare
+        } else {
+            x = vals[i];
+        }
+        if (x != x) continue;
         const uint32_t key = order_key(x);
         const uint32_t slot = li & (kHistSlots - 1);
         uint32_t owner = tags[slot];
@@ -336,8 +314,8 @@ __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ v
             owner = (old == kInactive) ? li : old;
         }
 #pragma unroll
-        for (uint32_t sel = 0; sel < 2; ++sel)
-            if ((key & hi_mask) == na.sel_prefix[2 * node + sel]) {
+        for (uint32_t sel = 0; sel < 2u; ++sel)
+            if (GATHER || (key & hi_mask) == na.sel_prefix[2 * node + sel]) {
                 const uint32_t bin = (key >> shift) & 255u;
                 if (owner == li) atomicAdd(&lh[slot][sel][bin], 1u);
                 else atomicAdd(&hist[((size_t)li * 2 + sel) * 256 + bin], 1u);
@@ -354,6 +332,8 @@ __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ v
 
 // one wave per (node, which of the two ranks): lane l owns bins 4l..4l+3, a wave prefix scan finds
 // the bin holding the rank (the serial walk over 256 dependent loads cost 25 us per launch)
+// FIRST (shift 24): the ranks of the two order statistics the median needs come from nv (tsvq.rs:77-81).
+template <bool FIRST>
 __global__ __launch_bounds__(64) void k_select_pick(const uint32_t *__restrict__ lvl_node, const LevelInfo *__restrict__ lv,
                                                     NodeArrays na, uint32_t shift, uint32_t *__restrict__ hist) {
     const uint32_t idx = blockIdx.x, lane = threadIdx.x;
@@ -363,7 +343,13 @@ __global__ __launch_bounds__(64) void k_select_pick(const uint32_t *__restrict__
     uint4 *h4 = reinterpret_cast<uint4 *>(hist + ((size_t)li * 2 + sel) * 256);
     const uint4 c = h4[lane];
     h4[lane] = make_uint4(0u, 0u, 0u, 0u);  // ready for the next round
-    const uint32_t rank = na.sel_rank[2 * node + sel];
+    uint32_t rank;
+    if (FIRST) {
+        const uint32_t nv = na.nv[node], h = nv / 2;
+        rank = (nv == 0) ? 0u : (sel == 0 ? ((nv % 2 == 0) ? h - 1 : h) : h);
+    } else {
+        rank = na.sel_rank[2 * node + sel];
+    }
     const uint32_t mine = c.x + c.y + c.z + c.w;
     uint32_t incl = mine;
 #pragma unroll
@@ -402,53 +388,52 @@ __global__ __launch_bounds__(64) void k_select_pick(const uint32_t *__restrict__
     }
     if (lane == 0) {
         na.sel_rank[2 * node + sel] = new_rank;
-        na.sel_prefix[2 * node + sel] |= b << shift;
+        if (FIRST) na.sel_prefix[2 * node + sel] = b << shift;
+        else na.sel_prefix[2 * node + sel] |= b << shift;
     }
 }
 
-__global__ void k_median(const uint32_t *__restrict__ lvl_node, const LevelInfo *__restrict__ lv, NodeArrays na) {
-    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= lv->n_split) return;
-    const uint32_t node = lvl_node[li];
+__device__ __forceinline__ float median_of(const NodeArrays &na, uint32_t node) {  // tsvq.rs:77-81 from the two selected keys
     const uint32_t nv = na.nv[node];
-    if (nv == 0) {
-        na.median[node] = 0.0f;
-        return;
-    }
+    if (nv == 0) return 0.0f;
     const float lo = key_to_float(na.sel_prefix[2 * node + 0]);
     const float hi = key_to_float(na.sel_prefix[2 * node + 1]);
     if (nv % 2 == 0) {
         const float s2 = lo + hi;
-        na.median[node] = s2 / 2.0f;
-    } else {
-        na.median[node] = hi;
+        return s2 / 2.0f;
     }
+    return hi;
 }
 
-__global__ __launch_bounds__(256) void k_flags(const float *__restrict__ vals, uint32_t n,
-                                               const uint32_t *__restrict__ node_of,
-                                               const uint32_t *__restrict__ remap,
-                                               const uint32_t *__restrict__ lvl_node, NodeArrays na,
-                                               uint32_t *__restrict__ flags) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    uint32_t li = node_of[i];
-    if (li != kInactive) li = remap[li];
-    uint32_t f = 0;
-    if (li != kInactive) f = (vals[i] <= na.median[lvl_node[li]]) ? 1u : 0u;  // NaN -> right
-    flags[i] = f;
-}
-
-// exclusive scan of u32 flags: 1024 elements per block
-__global__ __launch_bounds__(256) void k_scan_blocks(const uint32_t *__restrict__ in, uint32_t n,
-                                                     uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums) {
+// partition flags (left = value <= the node's median, NaN -> right; tsvq.rs:84-85) and their exclusive scan inside
+// blocks of 1024 positions; block totals for k_scan_sums.  (The median of a node is formed here, by every thread that
+// needs it, from the two selected keys: one launch instead of k_median + k_flags + k_scan_blocks.)
+__global__ __launch_bounds__(256) void k_flags_scan(const float *__restrict__ vals, uint32_t n,
+                                                    const uint32_t *__restrict__ node_of,
+                                                    const uint32_t *__restrict__ remap,
+                                                    const uint32_t *__restrict__ lvl_node, NodeArrays na,
+                                                    uint32_t *__restrict__ flags, uint32_t *__restrict__ out,
+                                                    uint32_t *__restrict__ block_sums) {
     __shared__ uint32_t sh[256];
     const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
     uint32_t v[4], s = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        v[q] = (base + q < n) ? in[base + q] : 0u;
-        s += v[q];
+        const uint32_t i = base + q;
+        uint32_t f = 0;
+        if (i < n) {
+            uint32_t li = node_of[i];
+            if (li != kInactive) li = remap[li];
+            if (li != kInactive) {
+                const uint32_t node = lvl_node[li];
+                const float med = median_of(na, node);
+                f = (vals[i] <= med) ? 1u : 0u;  // NaN -> right
+                if (i == na.seg_start[node]) na.median[node] = med;
+            }
+            flags[i] = f;
+        }
+        v[q] = f;
+        s += f;
     }
     sh[threadIdx.x] = s;
     __syncthreads();
@@ -487,28 +472,12 @@ __global__ __launch_bounds__(1024) void k_scan_sums(uint32_t *__restrict__ block
         carry += tot;
     }
 }
-__global__ __launch_bounds__(256) void k_scan_apply(uint32_t *__restrict__ out, uint32_t n,
-                                                    const uint32_t *__restrict__ block_sums) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] += block_sums[i >> 10];
-}
-
-// lefts per node = P[a+len] - P[a] (P exclusive; the last element adds its own flag)
-__global__ void k_nleft(const uint32_t *__restrict__ lvl_node, const LevelInfo *__restrict__ lv, NodeArrays na,
-                        const uint32_t *__restrict__ P, const uint32_t *__restrict__ flags) {
-    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= lv->n_split) return;
-    const uint32_t node = lvl_node[li];
-    const uint32_t a = na.seg_start[node], len = na.seg_len[node];
-    na.nleft[node] = (P[a + len - 1] + flags[a + len - 1]) - P[a];
-}
-
 // stable partition of every split node's segment (tsvq.rs:84-85)
 __global__ __launch_bounds__(256) void k_scatter(uint32_t n, const uint32_t *__restrict__ perm,
                                                  const uint32_t *__restrict__ node_of,
                                                  const uint32_t *__restrict__ remap,
                                                  const uint32_t *__restrict__ lvl_node, NodeArrays na,
-                                                 const uint32_t *__restrict__ P,
+                                                 const uint32_t *__restrict__ Pb, const uint32_t *__restrict__ bsums,
                                                  const uint32_t *__restrict__ flags,
                                                  uint32_t *__restrict__ perm2, uint32_t *__restrict__ node_of2) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -522,7 +491,8 @@ __global__ __launch_bounds__(256) void k_scatter(uint32_t n, const uint32_t *__r
     }
     const uint32_t node = lvl_node[li];
     const uint32_t a = na.seg_start[node];
-    const uint32_t lr = P[i] - P[a];
+    // exclusive scan of the flags = the in-block scan + the scanned block totals (k_flags_scan, k_scan_sums)
+    const uint32_t lr = (Pb[i] + bsums[i >> 10]) - (Pb[a] + bsums[a >> 10]);
     const uint32_t f = flags[i];
     const uint32_t pos = f ? (a + lr) : (a + na.nleft[node] + (i - a - lr));
     perm2[pos] = perm[i];
@@ -1802,7 +1772,8 @@ __global__ __launch_bounds__(1024) void k_plan_level(LevelInfo *__restrict__ lv,
 __global__ __launch_bounds__(1024) void k_plan_children(LevelInfo *__restrict__ lv, LevelInfo *__restrict__ lv_next,
                                                         const uint32_t *__restrict__ lvl_split, NodeArrays na,
                                                         int32_t *__restrict__ node_left, int32_t *__restrict__ node_right,
-                                                        uint32_t dcap) {
+                                                        uint32_t dcap, const uint32_t *__restrict__ Pb,
+                                                        const uint32_t *__restrict__ bsums, const uint32_t *__restrict__ flags) {
     __shared__ uint32_t sh[1024];
     const uint32_t n_split = lv->n_split, next_first = lv->first + lv->count;
     uint32_t made = 0, err = 0;
@@ -1814,7 +1785,10 @@ __global__ __launch_bounds__(1024) void k_plan_children(LevelInfo *__restrict__ 
             node = lvl_split[j];
             start = na.seg_start[node];
             len = na.seg_len[node];
-            nl = na.nleft[node];
+            // lefts of the node = scan(end) - scan(start), the exclusive scan completed with the block totals on the fly
+            const uint32_t e = start + len - 1;
+            nl = (Pb[e] + bsums[e >> 10] + flags[e]) - (Pb[start] + bsums[start >> 10]);
+            na.nleft[node] = nl;
             if (na.nv[node] == 0) err = 1;
         }
         const uint32_t nr = len - nl;
@@ -2139,48 +2113,41 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         if (!splits) break;
         // variances + split dimension (tsvq.rs:46-66)
         VQ_TRY(colsum(1, lvp, ub_nodes, perm));
-        const uint32_t nb64 = (ub_nodes + 63) / 64;
         hipLaunchKernelGGL(k_pick_split, dim3((ub_nodes + 3) / 4), dim3(256), 0, stream, lvl_split, lvp, d, na);
         VQ_LAUNCH_CHECK("k_pick_split");
         // median (tsvq.rs:68-81)
-        hipLaunchKernelGGL(k_gather_vals, dim3((n + 255) / 256), dim3(256), 0, stream, X, d, n, perm, node_of, remap, lvl_split, na,
-                           ws.b_vals.as<float>());
-        VQ_LAUNCH_CHECK("k_gather_vals");
-        hipLaunchKernelGGL(k_select_init, dim3(nb64), dim3(64), 0, stream, lvl_split, lvp, na);
-        VQ_LAUNCH_CHECK("k_select_init");
+        // median (tsvq.rs:68-81): 4-round radix select of the two middle order statistics; the first round gathers the
+        // split dimension's values
         VQ_HIP(hipMemsetAsync(ws.b_hist.p, 0, (size_t)ub_nodes * 2 * 256 * 4, stream));
-        for (int shift = 24; shift >= 0; shift -= 8) {
+        {
             const uint32_t hblocks = std::min<uint32_t>((n + 2047) / 2048, (uint32_t)num_cus() * 4);
             const uint32_t hchunk = (n + hblocks - 1) / hblocks;
-            hipLaunchKernelGGL(k_select_hist, dim3(hblocks), dim3(256), 0, stream, ws.b_vals.as<float>(), n, hchunk, node_of, remap,
-                               lvl_split, na, (uint32_t)shift, ws.b_hist.as<uint32_t>());
-            VQ_LAUNCH_CHECK("k_select_hist");
-            hipLaunchKernelGGL(k_select_pick, dim3(ub_nodes * 2), dim3(64), 0, stream, lvl_split, lvp, na, (uint32_t)shift,
-                               ws.b_hist.as<uint32_t>());
-            VQ_LAUNCH_CHECK("k_select_pick");
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                if (shift == 24) {
+                    hipLaunchKernelGGL(k_select_hist<true>, dim3(hblocks), dim3(256), 0, stream, X, d, perm, ws.b_vals.as<float>(), n, hchunk,
+                                       node_of, remap, lvl_split, na, (uint32_t)shift, ws.b_hist.as<uint32_t>());
+                    hipLaunchKernelGGL(k_select_pick<true>, dim3(ub_nodes * 2), dim3(64), 0, stream, lvl_split, lvp, na, (uint32_t)shift,
+                                       ws.b_hist.as<uint32_t>());
+                } else {
+                    hipLaunchKernelGGL(k_select_hist<false>, dim3(hblocks), dim3(256), 0, stream, X, d, perm, ws.b_vals.as<float>(), n, hchunk,
+                                       node_of, remap, lvl_split, na, (uint32_t)shift, ws.b_hist.as<uint32_t>());
+                    hipLaunchKernelGGL(k_select_pick<false>, dim3(ub_nodes * 2), dim3(64), 0, stream, lvl_split, lvp, na, (uint32_t)shift,
+                                       ws.b_hist.as<uint32_t>());
+                }
+                VQ_LAUNCH_CHECK("k_select_*");
+            }
         }
-        hipLaunchKernelGGL(k_median, dim3(nb64), dim3(64), 0, stream, lvl_split, lvp, na);
-        VQ_LAUNCH_CHECK("k_median");
-        // partition (tsvq.rs:84-85)
-        hipLaunchKernelGGL(k_flags, dim3((n + 255) / 256), dim3(256), 0, stream, ws.b_vals.as<float>(), n, node_of, remap, lvl_split,
-                           na, ws.b_flags.as<uint32_t>());
-        VQ_LAUNCH_CHECK("k_flags");
-        hipLaunchKernelGGL(k_scan_blocks, dim3(nblk), dim3(256), 0, stream, ws.b_flags.as<uint32_t>(), n,
-                           ws.b_scan.as<uint32_t>(), ws.b_bsums.as<uint32_t>());
-        VQ_LAUNCH_CHECK("k_scan_blocks");
+        // partition (tsvq.rs:84-85): flags + in-block scan, block totals, children (tsvq.rs:88-108), stable scatter
+        hipLaunchKernelGGL(k_flags_scan, dim3(nblk), dim3(256), 0, stream, ws.b_vals.as<float>(), n, node_of, remap, lvl_split, na,
+                           ws.b_flags.as<uint32_t>(), ws.b_scan.as<uint32_t>(), ws.b_bsums.as<uint32_t>());
+        VQ_LAUNCH_CHECK("k_flags_scan");
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, ws.b_bsums.as<uint32_t>(), nblk);
         VQ_LAUNCH_CHECK("k_scan_sums");
-        hipLaunchKernelGGL(k_scan_apply, dim3((n + 255) / 256), dim3(256), 0, stream, ws.b_scan.as<uint32_t>(), n,
-                           ws.b_bsums.as<uint32_t>());
-        VQ_LAUNCH_CHECK("k_scan_apply");
-        hipLaunchKernelGGL(k_nleft, dim3(nb64), dim3(64), 0, stream, lvl_split, lvp, na, ws.b_scan.as<uint32_t>(),
-                           ws.b_flags.as<uint32_t>());
-        VQ_LAUNCH_CHECK("k_nleft");
-        // children (tsvq.rs:88-108)
-        hipLaunchKernelGGL(k_plan_children, dim3(1), dim3(1024), 0, stream, &lv[L], &lv[L + 1], lvl_split, na, node_left, node_right, dcap);
+        hipLaunchKernelGGL(k_plan_children, dim3(1), dim3(1024), 0, stream, &lv[L], &lv[L + 1], lvl_split, na, node_left, node_right, dcap,
+                           ws.b_scan.as<uint32_t>(), ws.b_bsums.as<uint32_t>(), ws.b_flags.as<uint32_t>());
         VQ_LAUNCH_CHECK("k_plan_children");
         hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, n, perm, node_of, remap, lvl_split, na,
-                           ws.b_scan.as<uint32_t>(), ws.b_flags.as<uint32_t>(), ws.b_perm[cur ^ 1].as<uint32_t>(),
+                           ws.b_scan.as<uint32_t>(), ws.b_bsums.as<uint32_t>(), ws.b_flags.as<uint32_t>(), ws.b_perm[cur ^ 1].as<uint32_t>(),
                            ws.b_nodeof[cur ^ 1].as<uint32_t>());
         VQ_LAUNCH_CHECK("k_scatter");
         cur ^= 1;
