@@ -598,8 +598,8 @@ def worker(args) -> int:
         return 2
     # VQ_BENCH_SHARE_GPU=1: every rank on device 0 (tests of the N > 1 plumbing on a one-GPU box; RCCL refuses two ranks
     # on one device, so only with --collective gloo)
-    share = os.environ.get("VQ_BENCH_SHARE_GPU") == "1"
-    if share and world > 1 and args.collective != "gloo":
+    share = os.environ.get("VQ_BENCH_SHARE_GPU") in ("1", "force")  # "force": let RCCL itself refuse (or take) a shared device
+    if os.environ.get("VQ_BENCH_SHARE_GPU") == "1" and world > 1 and args.collective != "gloo":
         print("bench.py: VQ_BENCH_SHARE_GPU=1 needs --collective gloo (RCCL wants one GPU per rank)", file=sys.stderr)
         return 2
     device = 0 if share else local_rank

@@ -11,6 +11,13 @@ second.  Rows travel in chunks so host memory stays bounded (the C5 shard is 6.4
   * C5  one GPU's shard of the 8-GPU job, 12.5M x 128, m=16, k=256, squared L2: codes;
   * C4  TSVQ depth 8 on 1M x 128: every leaf id and f16 reconstruction (tree equality is
         held by tests/test_gpu_tsvq.py::test_config4_fullsize_depth8).
+
+Round 3 ("parity soft spots"):
+  * C2 on CLUSTERED rows (bench.py's mixture of 256 tight Gaussians: > 2 % of the (row, subspace) pairs go through the
+    exact re-check and the list-driven update): all codes and one Lloyd step;
+  * vqhip_kmeans_run -- the device-gated loop bench.py and fit_codebooks use -- for 10 iterations at C2 against the
+    oracle's loop from the same initial rows;
+  * a 2.5M-row chunk of the C5 shard under Distance::Euclidean with the f16 reconstruction.
 """
 import numpy as np
 import pytest
@@ -160,3 +167,105 @@ def test_c4_zero_mean_rows_build_and_every_leaf(oracle):
         got = tq.leaf_ids(X)
         assert int((got != want_leaf).sum()) == 0, name
         assert tq.last_encode_stats()[0]
+
+
+def _clustered_rows(n, d, k, seed=66):
+    """bench.py's clustered data: k centres in [0,1)^d, rows = centre + 0.02 N(0,1) (near-tied centroids inside a blob)"""
+    import torch
+
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    centers = torch.rand((k, d), device="cuda", generator=g)
+    which = torch.randint(0, k, (n,), device="cuda", generator=g)
+    X = (centers[which] + 0.02 * torch.randn((n, d), device="cuda", generator=g)).contiguous()
+    torch.cuda.synchronize()
+    return X
+
+
+def test_c2_clustered_rows_codes_and_lloyd_step(oracle):
+    """The recheck-heavy regime at full size against the ORACLE (round 2 checked it library-vs-library only): every code of
+    an encode pass, and every assignment / count / centroid of a Lloyd step whose update runs through the fused
+    accumulation PLUS k_accumulate_listed for the re-checked rows."""
+    import torch
+
+    n, d, m, k = 1_000_000, 128, 8, 256
+    sd = d // m
+    Xd = _clustered_rows(n, d, k)
+    ds = _lib.Dataset.from_device(Xd.data_ptr(), n, d)
+    X = Xd.cpu().numpy()
+    km = _lib.KMeans(ds, m, k)
+    init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64)
+    km.init_from_rows(init)
+    for _ in range(3):
+        km.step()
+    c_in = km.get_centroids()
+    counts, changed = km.step()
+    rechecked, engine = _lib.last_assign_stats()
+    assert engine == _lib.ENGINE_MFMA_BF16 and rechecked >= 0.02 * n * m, rechecked  # the regime this test is about
+    assign = km.get_assignments()
+    c_out = km.get_centroids()
+    km.close()
+    for s in range(m):
+        c1, a_ref, n_ref, ch_ref = oracle.lloyd_step(X[:, s * sd:(s + 1) * sd], c_in[s], threads=0)
+        assert int((assign[:, s].astype(np.uint32) != a_ref).sum()) == 0
+        np.testing.assert_array_equal(counts[s], n_ref)
+        assert bool(changed[s]) == ch_ref
+        err = np.max(np.abs(c_out[s] - c1) / np.maximum(1.0, np.abs(c1)))
+        assert err <= 1e-5, f"subspace {s}: centroid deviation {err:g}"
+    enc = _lib.PQEncoder(c_out, _lib.SQUARED_EUCLIDEAN)
+    codes = torch.empty((n, m), dtype=torch.uint8, device="cuda")
+    enc.encode_device(Xd.data_ptr(), n, codes.data_ptr(), None)
+    _lib.synchronize()
+    assert _lib.last_assign_stats()[0] >= 0.02 * n * m
+    want, _ = oracle.pq_encode(O.SQUARED_EUCLIDEAN, X, c_out, want_f16=False, threads=0)
+    assert int((codes.cpu().numpy().astype(np.uint32) != want).sum()) == 0
+    enc.close()
+    ds.close()
+
+
+def test_c2_kmeans_run_10_iterations(oracle):
+    """vqhip_kmeans_run (iterations queued back to back, decisions on the device) at C2 for 10 iterations from the
+    bench's strided initial rows, against the oracle's Lloyd loop from the same rows (vector.rs:415-458): iteration
+    counts equal, final inertia within 0.1 % (trajectories may part at boundary rows: the centroid tolerance), and
+    every assignment of the LAST iteration equal to the oracle's given the run's own centroids going into it."""
+    n, d, m, k, iters = 1_000_000, 128, 8, 256, 10
+    sd = d // m
+    ds = _lib.Dataset.synthetic(n, d, seed=66)
+    X = ds.read()
+    km = _lib.KMeans(ds, m, k)
+    init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64)
+    km.init_from_rows(init)
+    it, _, _, paused = km.run(iters - 1)
+    assert not paused and it.tolist() == [iters - 1] * m
+    c_before = km.get_centroids()
+    it, counts, changed, paused = km.run(1)
+    assert not paused and it.tolist() == [1] * m
+    assign = km.get_assignments()
+    c_gpu = km.get_centroids()
+    km.close()
+    ds.close()
+
+    def inertia(xs, cs, a):
+        diff = xs - cs[a]
+        return float(np.einsum("ij,ij->", diff, diff, dtype=np.float64))
+
+    for s in range(m):
+        xs = X[:, s * sd:(s + 1) * sd]
+        # the last iteration, from the run's own centroids: exact assignments and counts, centroids within tolerance
+        c1, a_ref, n_ref, ch_ref = oracle.lloyd_step(xs, c_before[s], threads=0)
+        assert int((assign[:, s].astype(np.uint32) != a_ref).sum()) == 0
+        np.testing.assert_array_equal(counts[s], n_ref)
+        assert bool(changed[s]) == ch_ref
+        assert np.max(np.abs(c_gpu[s] - c1) / np.maximum(1.0, np.abs(c1))) <= 1e-5
+        # the whole trajectory: the oracle's loop from the same initial rows
+        c_ref, it_ref, _ = oracle.lloyd(xs, k, iters, init[s], threads=0)
+        assert it_ref == iters
+        i_gpu = inertia(xs, c_gpu[s], a_ref)
+        _, a_end, _, _ = oracle.lloyd_step(xs, c_ref, threads=0)
+        i_ref = inertia(xs, c_ref, a_end)
+        assert abs(i_gpu - i_ref) <= 1e-3 * i_ref, (s, i_gpu, i_ref)
+
+
+def test_c5_chunk_euclidean_with_f16(oracle):
+    """BASELINE configs[4]'s shape (d = 128, m = 16: sub_dim 8, two waves per SIMD) under Distance::Euclidean -- the sqrt
+    collapses near-ties onto the earlier index -- with the f16 reconstruction, on 2.5M rows of the shard."""
+    _encode_all_rows_vs_oracle(oracle, 2_500_000, 128, 16, 256, _lib.EUCLIDEAN, 1_250_000, True)

@@ -1,6 +1,6 @@
-"""Full-size GPU checks at BASELINE.json's configurations, through size-independent
-properties (the oracle cannot scan 1M x 128 x 256 in test time) plus an oracle spot check on
-a random sample of rows.
+"""Full-size GPU checks at BASELINE.json's configurations through size-independent properties, plus an oracle
+spot check on a random sample of rows.  (Every row against the oracle: tests/test_gpu_allrows.py -- the GPU box's 128
+host threads scan 1M x 128 x 256 in about a second.)
 
   * engine agreement: MFMA screen + exact re-check == exact scan, bit for bit, on every row;
   * idempotence / k = N identity: encoding the codebook rows returns each row's own index;
