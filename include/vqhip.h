@@ -213,6 +213,8 @@ int vqhip_kmeans_run(vqhip_kmeans *km, uint32_t max_iters, uint32_t *iters_done,
  *   finalize:   means, 1e-6 convergence test, new centroids (identical on every rank after
  *               an all-reduce) */
 int vqhip_kmeans_accumulate(vqhip_kmeans *km);
+/* (the slab entries of subspaces that are not active -- retired, or gated off inside vqhip_kmeans_run[_sharded] -- are
+ * undefined: nothing rewrites them, and a sharded run's all-reduce keeps summing what was there) */
 int vqhip_kmeans_partials(vqhip_kmeans *km, void **dev_slab, uint64_t *n_doubles);
 int vqhip_kmeans_finalize(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed);
 

@@ -177,7 +177,7 @@ struct CodebookState {
 
 // --------------------------------------------------------------- assign workspace ----
 struct AssignWorkspace {
-    DevBuf wl_rows, wl_count, sub_list, sub_pos, wl_seg, part;
+    DevBuf wl_rows, wl_count, sub_list, sub_pos, wl_seg, part, codes_t;
     static constexpr uint32_t kSegCap = 4096;  // wave-private work-list segments per subspace
     uint32_t *seg_host = nullptr;               // pinned [m][kSegCap][2]
     uint32_t last_n_seg = 0;
@@ -315,6 +315,17 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
     if (engine == VQHIP_ENGINE_MFMA_BF16 && (cs.x32_groups > 1 || x32_padded_sd(cs.sd) > 64)) {  // (the wide kernel goes through the partial verdicts even with one group)
         VQ_TRY(ws.part.ensure((size_t)cs.m * cs.x32_groups * n * 16));
         a.part = ws.part.p;
+    }
+    // many subspaces: the single-pass bf16 screen writes its codes subspace-major into a scratch and a transposition
+    // forms [n][m] (k_screen_bf16.hip): at m = 96 the byte stores m apart were 1.46 GB of write traffic for 96 MB of codes
+    static const char *ct_env = getenv("VQHIP_CODES_TRANSPOSE");  // =0: never, =1: whenever the shape allows (A/B)
+    const bool ct_shape = engine == VQHIP_ENGINE_MFMA_BF16 && cs.x32_groups == 1 && x32_padded_sd(cs.sd) <= 64 && cs.k <= 256 &&
+                          cs.m % 4 == 0 && (size_t)256 * (cs.m + 4) + cs.m <= 60 * 1024 && (reinterpret_cast<uintptr_t>(codes) & 3) == 0;
+    if (ct_shape && !(ct_env && ct_env[0] == '0') && (cs.m >= 16 || (ct_env && ct_env[0] == '1'))) {
+        const uint64_t pitch = (n + 255) / 256 * 256;
+        VQ_TRY(ws.codes_t.ensure((size_t)cs.m * pitch));
+        a.codes_t = ws.codes_t.as<uint8_t>();
+        a.codes_t_pitch = pitch;
     }
     if (fused) fused->used = false;
     if (fused && fused->sums && engine == VQHIP_ENGINE_MFMA_BF16 && metric != VQHIP_COSINE && cs.x32_groups == 1 &&
@@ -1216,9 +1227,27 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
     int engine = 0;
     VQ_TRY(pick_engine(km->engine, km->cs, VQHIP_SQUARED_EUCLIDEAN, &engine));
     static const char *host_loop_env = getenv("VQHIP_RUN_ON_HOST");  // =1: decisions on the host (A/B)
-    const bool device_loop = km->fused_slabs && !km->exact_update && !km->sums_by_chains && engine == VQHIP_ENGINE_MFMA_BF16 &&
-                             km->cs.x32_groups == 1 && km->ds->n < (1ull << 32) && !g_prof.on &&
-                             !(host_loop_env && host_loop_env[0] == '1');
+    uint32_t n_active = 0;
+    for (uint32_t i = 0; i < m; ++i) n_active += km->active[i] ? 1u : 0u;
+    // the device-driven loop needs the fused update: exactly run_assign's predicate (engine, one centroid group, a slab
+    // per (chunk, active subspace) beyond the list-driven ones), evaluated BEFORE anything is queued -- otherwise the
+    // host-driven loop below serves the shape
+    bool device_loop = km->fused_slabs && !km->exact_update && !km->sums_by_chains && engine == VQHIP_ENGINE_MFMA_BF16 &&
+                       km->cs.x32_groups == 1 && screen_bf16_fused_update_supported(km->cs.sd, k) &&
+                       km->fused_slabs / n_active > FusedAcc().n_patch && km->ds->n != 0 && km->ds->n < (1ull << 32) &&
+                       !g_prof.on && !(host_loop_env && host_loop_env[0] == '1');
+    if (world > 1) {
+        // every rank must queue the same number of all-reduces: the decision depends on per-rank state (environment,
+        // profiling hooks, the local row count), so the ranks agree on it -- device loop only if ALL of them can
+        VQ_TRY(km->gather_ws.ensure(4));
+        const uint32_t mine = device_loop ? 1u : 0u;
+        uint32_t all = 0;
+        VQ_HIP(hipMemcpyAsync(km->gather_ws.p, &mine, 4, hipMemcpyHostToDevice, s));
+        VQ_TRY(comm_allreduce_u32(comm, km->gather_ws.as<uint32_t>(), 1, s));
+        VQ_HIP(hipMemcpyAsync(&all, km->gather_ws.p, 4, hipMemcpyDeviceToHost, s));
+        VQ_HIP(hipStreamSynchronize(s));
+        device_loop = all == (uint32_t)world;
+    }
     if (!device_loop) {
         std::vector<uint32_t> cnt((size_t)m * k);
         std::vector<uint8_t> chg(m);

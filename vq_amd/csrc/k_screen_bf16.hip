@@ -224,7 +224,8 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows, uint32_t *__restrict__ wl_seg,
     uint32_t n_seg, uint64_t wl_stride, int cosine, uint32_t k_real, const float *__restrict__ cen,
     uint4 *__restrict__ part, uint32_t groups_rt, uint32_t sdr, float *__restrict__ acc_sums,
-    uint32_t *__restrict__ acc_counts, const uint8_t *__restrict__ gate_active, const uint32_t *__restrict__ gate_halt) {
+    uint32_t *__restrict__ acc_counts, const uint8_t *__restrict__ gate_active, const uint32_t *__restrict__ gate_halt,
+    uint8_t *__restrict__ codes_t, uint64_t codes_t_pitch) {
     // device-side gates of vqhip_kmeans_run (iterations queued ahead of the host): a paused run or a subspace that
     // has converged meanwhile does nothing (the work-list segments stay zeroed: the re-check finds them empty)
     if (gate_halt && *gate_halt) return;
@@ -644,7 +645,12 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
         if (cosine) proven = proven && (m1 < -T) && (xnorm > 4e-10f);
         const uint64_t row = st * 32 + p;
         const bool writer = (h == 0) && (row < n);
-        if (writer) codes[row * m + s] = (uint8_t)j;
+        if (writer) {
+            // [m][pitch] scratch when the caller transposes behind this kernel: the wave's 32 codes of a step are 32
+            // contiguous bytes there, one byte in each of 32 rows (m bytes apart) in the final layout
+            if (codes_t) codes_t[(size_t)s * codes_t_pitch + row] = (uint8_t)j;
+            else codes[row * m + s] = (uint8_t)j;
+        }
         const bool recheck = writer && !proven;
         const unsigned long long mask = __ballot(recheck);
         if (mask != 0ull) {
@@ -875,6 +881,48 @@ __global__ __launch_bounds__(kBlock, 1) void k_assign_screen_bf16_wide(
     }
 }
 
+// codes_t [m][pitch] (a subspace's codes contiguous) -> codes [n][m], 256 rows per workgroup through LDS.  Subspaces the
+// screen did not process (not in sub_list, or retired on the device inside vqhip_kmeans_run) keep the bytes they have.
+__global__ __launch_bounds__(256) void k_codes_transpose(const uint8_t *__restrict__ ct, uint64_t pitch, uint8_t *__restrict__ codes,
+                                                         uint64_t n, uint32_t m, const uint32_t *__restrict__ sub_list,
+                                                         uint32_t n_sub, const uint8_t *__restrict__ gate_active,
+                                                         const uint32_t *__restrict__ gate_halt) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t tr_lds[];  // [256][m + 4] codes, then [m] activity flags
+    if (gate_halt && *gate_halt) return;  // a paused run: the screen wrote nothing
+    const uint32_t tp = m + 4;            // row pitch in LDS: a multiple of 4 that is not a multiple of 128
+    uint8_t *tile = tr_lds, *act = tr_lds + 256 * tp;
+    const uint64_t row0 = (uint64_t)blockIdx.x * 256;
+    for (uint32_t s = threadIdx.x; s < m; s += 256) act[s] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_sub; i += 256) {
+        const uint32_t s = sub_list[i];
+        act[s] = gate_active ? gate_active[s] : (uint8_t)1;
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t s = wave; s < m; s += 4) {  // lane l: rows 4 l .. 4 l + 3 of subspace s (pitch and row0 are multiples of 256)
+        uint32_t v = 0;
+        if (act[s]) {
+            v = *reinterpret_cast<const uint32_t *>(ct + (size_t)s * pitch + row0 + 4 * lane);
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint64_t r = row0 + 4 * lane + i;
+                if (r < n) v |= (uint32_t)codes[r * m + s] << (8 * i);
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) tile[(4 * lane + i) * tp + s] = (uint8_t)(v >> (8 * i));
+    }
+    __syncthreads();
+    const uint32_t rows_here = (uint32_t)min((uint64_t)256, n - row0), qpr = m / 4;  // dwords per row
+    uint32_t *out = reinterpret_cast<uint32_t *>(codes + row0 * m);
+    for (uint32_t idx = threadIdx.x; idx < rows_here * qpr; idx += 256) {
+        const uint32_t r = idx / qpr, q = idx - r * qpr;
+        out[idx] = *reinterpret_cast<const uint32_t *>(tile + r * tp + 4 * q);
+    }
+}
+
 template <int SD, int NT32, int G = 1, int PVW = 0, bool ACC = false>
 int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stream, uint32_t groups_rt = 0) {
     const uint32_t groups = (G > 0) ? (uint32_t)G : groups_rt;  // G == 0: run-time group count (k > 256)
@@ -915,8 +963,13 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
                        cb.m, cb.prepA32, cb.cn32, NT32 * groups * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
                        a.wl_seg, n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen,
                        reinterpret_cast<uint4 *>(a.part), groups, cb.sd, ACC ? a.acc_sums : nullptr, ACC ? a.acc_counts : nullptr,
-                       a.gate_active, a.gate_halt);
+                       a.gate_active, a.gate_halt, (G == 1) ? a.codes_t : nullptr, a.codes_t_pitch);
     VQ_LAUNCH_CHECK("k_assign_screen_bf16_x32");
+    if (G == 1 && a.codes_t) {
+        hipLaunchKernelGGL(k_codes_transpose, dim3((uint32_t)((a.n + 255) / 256)), dim3(256), (size_t)256 * (cb.m + 4) + cb.m, stream,
+                           a.codes_t, a.codes_t_pitch, a.codes, a.n, cb.m, a.sub_list, a.n_sub, a.gate_active, a.gate_halt);
+        VQ_LAUNCH_CHECK("k_codes_transpose");
+    }
     if (G != 1) {
         uint64_t mblocks = (a.n + 255) / 256;
         if (mblocks > (uint64_t)num_cus() * 8) mblocks = (uint64_t)num_cus() * 8;

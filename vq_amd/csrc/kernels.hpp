@@ -76,6 +76,11 @@ struct AssignArgs {
     const uint32_t *sub_list = nullptr;  // device [n_sub] subspace ids to process
     uint32_t n_sub = 0;
     uint8_t *codes = nullptr;  // [n][m]
+    // optional scratch [m][codes_t_pitch] (pitch = n rounded up to 256): the single-pass bf16 screen writes a subspace's
+    // codes contiguously there and a transposition forms [n][m] (byte stores m apart cost 15 x the code bytes in
+    // write traffic at m = 96); nullptr = the screen writes [n][m] itself
+    uint8_t *codes_t = nullptr;
+    uint64_t codes_t_pitch = 0;
     // per-subspace work lists of rows needing the exact re-check (screen -> exact)
     uint32_t *wl_rows = nullptr;   // [m][wl_stride]
     uint32_t *wl_count = nullptr;  // [m]

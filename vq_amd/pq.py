@@ -251,7 +251,7 @@ class ProductQuantizer:
             raise DimensionMismatch(self._m, codes.shape[1] if codes.ndim == 2 else codes.size)
         if not 1 <= topk <= min(codes.shape[0], 1024):
             raise InvalidParameter("topk", f"must be between 1 and min(n, 1024), got {topk}")
-        if self._distance.name() == "cosine":
+        if self._distance.metric in (_lib.COSINE, _lib.COSINE_UNCLAMPED):
             raise InvalidParameter("distance", "cosine distance is not a sum over subspaces: no ADC form")
         if codes.size and int(codes.max()) >= self._k:  # the scan indexes its LDS tables by code
             raise InvalidParameter("codes", f"a code is outside [0, {self._k})")

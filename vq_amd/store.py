@@ -27,6 +27,8 @@ from .distance import Distance
 
 MAGIC = b"VQPQIDX1"
 _HEADER = struct.Struct("<8sIIIIQ")
+# metric ids of include/vqhip.h in id order (4 = the simd build's cosine without the epsilon rule and the clamp)
+_METRIC_NAMES = ["squared_euclidean", "euclidean", "manhattan", "cosine", "cosine_unclamped"]
 
 
 def _code_dtype(k: int):
@@ -112,7 +114,7 @@ class PQIndex:
             magic, metric, dim, m, k, n = _HEADER.unpack(head)
             if magic != MAGIC:
                 raise ValueError("not a VQPQIDX1 file")
-            if m == 0 or k == 0 or k > 65536 or dim == 0 or dim % m != 0 or metric > 3:
+            if m == 0 or k == 0 or k > 65536 or dim == 0 or dim % m != 0 or metric >= len(_METRIC_NAMES):
                 raise ValueError("corrupt index header")
             sd = dim // m
             cb = np.frombuffer(f.read(m * k * sd * 4), dtype="<f4")
@@ -131,9 +133,8 @@ class PQIndex:
         for r0 in range(0, n, 1 << 22):
             if codes[r0:r0 + (1 << 22)].size and int(codes[r0:r0 + (1 << 22)].max()) >= k:
                 raise ValueError(f"corrupt index: a code is outside [0, {k})")
-        names = ["squared_euclidean", "euclidean", "manhattan", "cosine"]
         self = cls.__new__(cls)
         self.codebooks = cb.reshape(m, k, sd).astype(np.float32)
         self.codes = codes
-        self.distance = Distance(names[metric])
+        self.distance = Distance(_METRIC_NAMES[metric])
         return self
