@@ -146,8 +146,8 @@ def test_c4_every_leaf(oracle):
 def test_c4_zero_mean_rows_build_and_every_leaf(oracle):
     """BASELINE configs[3]'s shape on ZERO-MEAN rows (N(0,1)): the column sums of the mean passes are random walks that
     change binade all the time -- the hard case of the build's exact emulation (no sampled guesses for
-    such columns, ~45 % of the mean-pass tiles re-added) and, with cosines of either sign, of the cosine descent's
-    clamp rules.  The whole tree and every leaf against the oracle."""
+    such columns, 10-29 % of the mean passes' 64-row segments re-added) and, with cosines of either sign, of the cosine
+    descent's clamp rules.  The whole tree and every leaf against the oracle."""
     from vq_amd import Distance, TSVQ
 
     from vq_amd.tsvq import build_tree

@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(64, 2) void k_fs_fold(const float *__restrict__ X, 
 // identity): no summary is loaded twice.  The next batch of 256 summaries is requested before the current one is
 // scanned, and so are the addends of the first kFsAhead segments the fold kernel predicted to fail (it parked them
 // contiguously): a re-addition costs its 64 additions, not a memory round trip.
-constexpr int kFsSpl = 4;     // segments per lane and batch
+constexpr int kFsSpl = 8;     // segments per lane and batch
 constexpr int kFsAhead = 8;   // parked segments whose addends travel together (two such groups: one complete, one in flight)
 
 __device__ __forceinline__ void fs_scan_incl(FsT &v, uint32_t lane) {
