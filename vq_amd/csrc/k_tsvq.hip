@@ -1340,10 +1340,6 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
     const float mu = (MODE == 1) ? na.centroid[(size_t)node * d + c] : 0.0f;
     float s = (MODE == 0) ? 0.0f : -0.0f;
     uint32_t fallbacks = 0;
-    // dbg only: where the time of this chain goes (s_memtime ticks): batch set-up, scan + apply, walking a lane's segments,
-    // waiting for a re-added segment's addends, its 64 additions
-    const uint64_t tk0 = dbg ? __builtin_readcyclecounter() : 0;
-    uint32_t tk_setup = 0, tk_scan = 0, tk_step = 0, tk_wait = 0, tk_add = 0, n_batches = 0, n_two = 0;
     // UNCONDITIONAL loads (index clamped): a load under `if (t < nseg)` is followed by the merge with the other branch's
     // value, i.e. by s_waitcnt vmcnt(0) right behind the load -- every batch then cost four serial memory round trips
     // (~3 us).  What lies past the node's end is marked unusable when the registers are consumed.
@@ -1360,8 +1356,6 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
     load4(2 * kBatch, nx2);
     for (uint32_t t0 = 0; t0 < nseg; t0 += kBatch) {
         const uint32_t cnt = min(kBatch, nseg - t0), nl = (cnt + kFsSpl - 1) / kFsSpl;  // segments / lanes of this batch
-        const uint64_t tkb = dbg ? __builtin_readcyclecounter() : 0;
-        ++n_batches;
         FsS m[kFsSpl];
 #pragma unroll
         for (int j = 0; j < kFsSpl; ++j) {
@@ -1472,7 +1466,6 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                         s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se1 << 23) | (m2a & 0x7FFFFFu));
                     } else {
                         ++fallbacks;
-                        const uint64_t tkw = dbg ? __builtin_readcyclecounter() : 0;
                         if (dbg && lane == 0) {
                             const int why = (se1 == 0u || se1 == 255u) ? 6 : (gef & 1) ? 3 : ((int)se1 - 127 != fs_ef_e(gef)) ? 4 : 5;
                             atomicAdd(dbg + why, 1u);
@@ -1501,11 +1494,6 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                         // the additions that use them: a v_readlane next to its v_add pays the VALU-writes-SGPR hazard on
                         // every addition (29 cycles each, measured); with the reads a group ahead the chain runs at the
                         // add's own latency (~10 cycles) and needs neither LDS staging nor its round trip.
-                        uint64_t tka = 0;
-                        if (dbg) {
-                            tka = __builtin_readcyclecounter();
-                            tk_wait += (uint32_t)(tka - tkw);
-                        }
                         float tq[16], tn[16];
 #pragma unroll
                         for (int k = 0; k < 16; ++k) tq[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), k));
@@ -1520,14 +1508,11 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
 #pragma unroll
                             for (int k = 0; k < 16; ++k) tq[k] = tn[k];
                         }
-                        if (dbg) tk_add += (uint32_t)(__builtin_readcyclecounter() - tka);
                     }
                 }
             }
         };
         const uint64_t past = nl < 64 ? (~0ull << nl) : 0ull;  // lanes behind the batch's last
-        const bool dense = false;
-        if (dbg) tk_setup += (uint32_t)(__builtin_readcyclecounter() - tkb);
         if (!two) {
             // One stream (no exact tie anywhere in the batch: every batch of continuous data): the deltas simply add, so ONE
             // scan serves the whole batch -- behind a lane that did not hold, the S entering lane l is the S the walk
@@ -1547,12 +1532,11 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
             uint32_t start = 0;   // first lane of the batch not yet applied
             int32_t base_d = 0;   // inclusive delta of lane start - 1
             for (;;) {
-                const uint64_t tks = dbg ? __builtin_readcyclecounter() : 0;
                 const uint32_t sb = __float_as_uint(s), se = (sb >> 23) & 0xFFu;
                 const bool s_normal = (se != 0u) && (se != 255u);
                 const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
                 const int32_t S = (sb >> 31) ? -mag : mag;
-                const bool ok = !dense && s_normal && lane_ok && ((int)se - 127 == lane_e) && fs_inside(S + before - base_d, mine.lo0, mine.hi0);
+                const bool ok = s_normal && lane_ok && ((int)se - 127 == lane_e) && fs_inside(S + before - base_d, mine.lo0, mine.hi0);
                 const uint64_t below = start ? ((~0ull) >> (64 - start)) : 0ull;
                 const uint64_t bad_mask = (__ballot(!ok) | past) & ~below;
                 const uint32_t good = bad_mask ? (uint32_t)__builtin_ctzll(bad_mask) : 64u;  // lanes start .. good-1 hold (uniform)
@@ -1561,11 +1545,8 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                     const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
                     s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2a & 0x7FFFFFu));
                 }
-                const uint64_t tkt = dbg ? __builtin_readcyclecounter() : 0;
-                if (dbg) tk_scan += (uint32_t)(tkt - tks);
                 if (good >= nl) break;
                 step_lane(good);
-                if (dbg) tk_step += (uint32_t)(__builtin_readcyclecounter() - tkt);  // (includes the re-additions' wait and additions)
                 base_d = __builtin_amdgcn_readlane(incl, (int)good);
                 start = good + 1;
                 if (start >= nl) break;
@@ -1579,23 +1560,18 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                 const bool s_normal = (se != 0u) && (se != 255u);
                 const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
                 const int32_t S = (sb >> 31) ? -mag : mag;
-                const uint64_t tks = dbg ? __builtin_readcyclecounter() : 0;
-                int32_t incl_d = 0;
-                bool ok = false;
-                if (!dense) {  // uniform
-                    const bool in = lane >= start;
-                    FsT v;
-                    v.d0 = in ? mine.d0 : 0, v.d1 = in ? mine.d1 : 0, v.lo0 = in ? mine.lo0 : 0, v.lo1 = in ? mine.lo1 : 0;
-                    v.hi0 = in ? mine.hi0 : 0, v.hi1 = in ? mine.hi1 : 0;
-                    fs_scan_incl(v, lane);
-                    incl_d = (S & 1) ? v.d1 : v.d0;  // delta from position `start`, for the actual parity of S
-                    int32_t before = __shfl_up(incl_d, 1);
-                    if (lane == 0) before = 0;
-                    const int32_t Sin = S + before;
-                    const bool podd = (Sin & 1) != 0;
-                    ok = s_normal && (lane < nl) && !lane_bad && ((int)se - 127 == lane_e);
-                    ok = ok && fs_inside(Sin, podd ? mine.lo1 : mine.lo0, podd ? mine.hi1 : mine.hi0);
-                }
+                const bool in = lane >= start;
+                FsT v;
+                v.d0 = in ? mine.d0 : 0, v.d1 = in ? mine.d1 : 0, v.lo0 = in ? mine.lo0 : 0, v.lo1 = in ? mine.lo1 : 0;
+                v.hi0 = in ? mine.hi0 : 0, v.hi1 = in ? mine.hi1 : 0;
+                fs_scan_incl(v, lane);
+                const int32_t incl_d = (S & 1) ? v.d1 : v.d0;  // delta from position `start`, for the actual parity of S
+                int32_t before = __shfl_up(incl_d, 1);
+                if (lane == 0) before = 0;
+                const int32_t Sin = S + before;
+                const bool podd = (Sin & 1) != 0;
+                bool ok = s_normal && (lane < nl) && !lane_bad && ((int)se - 127 == lane_e);
+                ok = ok && fs_inside(Sin, podd ? mine.lo1 : mine.lo0, podd ? mine.hi1 : mine.hi0);
                 const uint64_t below = start ? ((~0ull) >> (64 - start)) : 0ull;
                 const uint64_t bad_mask = (__ballot(!ok) | past) & ~below;
                 const uint32_t good = bad_mask ? (uint32_t)__builtin_ctzll(bad_mask) : 64u;
@@ -1604,11 +1580,8 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                     const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
                     s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2a & 0x7FFFFFu));
                 }
-                const uint64_t tkt = dbg ? __builtin_readcyclecounter() : 0;
-                if (dbg) tk_scan += (uint32_t)(tkt - tks), ++n_two;
                 if (good >= nl) break;
                 step_lane(good);
-                if (dbg) tk_step += (uint32_t)(__builtin_readcyclecounter() - tkt);
                 start = good + 1;
                 if (start >= nl) break;
             }
@@ -1622,10 +1595,6 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
             atomicAdd(dbg + 0, 1u);
             atomicAdd(dbg + 1, fallbacks);
             atomicMax(dbg + 2, fallbacks);
-            if (blockIdx.x == 0 && blockIdx.y == 0) {  // the time split of ONE chain: the first node's first column
-                dbg[8] = (uint32_t)(__builtin_readcyclecounter() - tk0);
-                dbg[9] = n_batches | (n_two << 16), dbg[10] = tk_setup, dbg[11] = tk_scan, dbg[12] = fallbacks, dbg[13] = tk_step, dbg[14] = tk_wait, dbg[15] = tk_add;
-            }
         }
     }
 }
@@ -2219,10 +2188,6 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
                 fprintf(stderr, "[vqhip]   level %u %s: %u chains, %u segments re-added (most in one chain %u): unusable summary %u, "
                                 "other binade than guessed %u, prefix leaves the binade %u, sum not normal %u; %u gathered (not parked)\n",
                         q / 2, (q & 1) ? "variance" : "mean", c8[0], c8[1], c8[2], c8[3], c8[4], c8[5], c8[6], c8[7]);
-            if (c8[0])  // one chain of the pass (first node, first column), ticks of s_memtime (100 MHz on gfx950)
-                fprintf(stderr, "[vqhip]     chain (node 0, column 0): %.1f us = %u batches (%u scans with ties): set-up %.1f us, scan + apply %.1f us, %u re-additions: walking lanes %.1f us "
-                                "of which fetching a parked segment's addends %.1f us and the 64 additions %.1f us  [s_memtime ticks / 2400]\n",
-                        c8[8] / 2400.0, c8[9] & 0xFFFFu, c8[9] >> 16, c8[10] / 2400.0, c8[11] / 2400.0, c8[12], c8[13] / 2400.0, c8[14] / 2400.0, c8[15] / 2400.0);
         }
     }
     // nodes -> host, then BFS -> pre-order (the oracle's numbering)
