@@ -348,7 +348,10 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
         g_prof.engines.push_back(engine);
     }
     if (screened) {
-        VQ_HIP(hipMemsetAsync(ws.wl_count.p, 0, (size_t)cs.m * 4, stream));
+        // the single-pass bf16 screen fills wave-private list SEGMENTS (wl_seg); only the other screens append to the
+        // per-subspace counters, which must start at zero
+        const bool segmented = engine == VQHIP_ENGINE_MFMA_BF16 && cs.x32_groups == 1 && x32_padded_sd(cs.sd) <= 64;
+        if (!segmented) VQ_HIP(hipMemsetAsync(ws.wl_count.p, 0, (size_t)cs.m * 4, stream));
         if (e0) VQ_HIP(hipEventRecord(e0, stream));
         if (engine == VQHIP_ENGINE_MFMA_BF16) VQ_TRY(launch_assign_screen_bf16(v, a, stream));
         else VQ_TRY(launch_assign_screen(v, a, stream));
@@ -361,11 +364,9 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
             fused->chunks = a.acc_chunks + fused->n_patch;
         }
         if (e2) VQ_HIP(hipEventRecord(e2, stream));
+        // the re-check counts stay on the device: vqhip_last_assign_stats fetches them when somebody asks (a copy queued
+        // behind every pass was one of five stream operations of a 10k-row encode)
         ws.last_n_seg = a.n_seg;
-        if (a.n_seg > 0)
-            VQ_HIP(hipMemcpyAsync(ws.seg_host, ws.wl_seg.p, (size_t)cs.m * a.n_seg * 8, hipMemcpyDeviceToHost, stream));
-        else
-            VQ_HIP(hipMemcpyAsync(ws.stats_host, ws.wl_count.p, (size_t)cs.m * 4, hipMemcpyDeviceToHost, stream));
         ws.stats_pending = true;
     } else {
         if (e0) VQ_HIP(hipEventRecord(e0, stream));
@@ -754,6 +755,10 @@ int vqhip_last_assign_stats(uint64_t *rechecked, int *engine) {
         if (ws && ws->stats_pending) {
             hipStream_t s;
             VQ_TRY(current_stream(&s));
+            if (ws->last_n_seg > 0)
+                VQ_HIP(hipMemcpyAsync(ws->seg_host, ws->wl_seg.p, (size_t)ws->stats_m * ws->last_n_seg * 8, hipMemcpyDeviceToHost, s));
+            else
+                VQ_HIP(hipMemcpyAsync(ws->stats_host, ws->wl_count.p, (size_t)ws->stats_m * 4, hipMemcpyDeviceToHost, s));
             VQ_HIP(hipStreamSynchronize(s));
             uint64_t tot = 0;
             if (ws->last_n_seg > 0) {
