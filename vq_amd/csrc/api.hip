@@ -1063,7 +1063,7 @@ static int kmeans_accumulate_enqueue(vqhip_kmeans *km, hipStream_t s, bool gated
         VQ_TRY(launch_reduce_partials_pos(km->cs.m, km->cs.k, km->cs.sd, km->partial_sums.as<float>(),
                                           km->partial_counts.as<uint32_t>(), fused.chunks, (uint32_t)subs.size(),
                                           km->ws.sub_pos.as<int32_t>(), km->slab.as<double>(), s, fused.gate_active,
-                                          fused.gate_halt));
+                                          fused.gate_halt, gated ? km->changed.as<uint32_t>() : nullptr));
     } else if (km->exact_update || km->sums_by_chains) {
         size_t need = exact_sums_workspace_bytes(km->cs.m, km->cs.k, ds->n);
         VQ_TRY(km->xs_ws.ensure(need));
@@ -1096,13 +1096,19 @@ int vqhip_kmeans_partials(vqhip_kmeans *km, void **dev_slab, uint64_t *n_doubles
     return VQHIP_OK;
 }
 
-// queue mean / convergence test + the read-back of counts and flags (capturable)
+// queue mean / convergence test + the read-back of counts and flags (capturable); gated (device-driven run): the same
+// kernel also ends the iteration (retire converged subspaces, count it, halt on an empty cluster)
 static int kmeans_finalize_enqueue(vqhip_kmeans *km, hipStream_t s, bool gated = false, bool read_back = true) {
-    const uint8_t *act = (km->all_active && !gated) ? nullptr : km->active_dev.as<uint8_t>();
     const uint32_t m = km->cs.m, k = km->cs.k;
-    VQ_TRY(launch_finalize(m, k, km->cs.sd, km->slab.as<double>(), act, km->cs.cb.as<float>(),
-                           km->counts.as<uint32_t>(), km->changed.as<uint32_t>(), km->exact_update, s,
-                           gated ? km->run_state.as<uint32_t>() : nullptr));
+    if (gated) {
+        uint32_t *rs = km->run_state.as<uint32_t>();  // [0] halt, [1..m] iterations, [m+1] finished-workgroup counter
+        VQ_TRY(launch_finalize_run(m, k, km->cs.sd, km->slab.as<double>(), km->active_dev.as<uint8_t>(), km->cs.cb.as<float>(),
+                                   km->counts.as<uint32_t>(), km->changed.as<uint32_t>(), rs, rs + 1, rs + 1 + m, s));
+    } else {
+        const uint8_t *act = km->all_active ? nullptr : km->active_dev.as<uint8_t>();
+        VQ_TRY(launch_finalize(m, k, km->cs.sd, km->slab.as<double>(), act, km->cs.cb.as<float>(),
+                               km->counts.as<uint32_t>(), km->changed.as<uint32_t>(), km->exact_update, s));
+    }
     km->cs.prepared = false;
     km->accumulated = false;
     if (read_back) {
@@ -1292,16 +1298,13 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
         }
         return VQHIP_OK;
     }
-    VQ_TRY(km->run_state.ensure((size_t)(m + 1) * 4));
-    VQ_HIP(hipMemsetAsync(km->run_state.p, 0, (size_t)(m + 1) * 4, s));
-    uint32_t *halt = km->run_state.as<uint32_t>(), *iters = halt + 1;
+    VQ_TRY(km->run_state.ensure((size_t)(m + 2) * 4));
+    VQ_HIP(hipMemsetAsync(km->run_state.p, 0, (size_t)(m + 2) * 4, s));
     for (uint32_t it = 0; it < max_iters; ++it) {
         VQ_TRY(kmeans_accumulate_enqueue(km, s, true));
         // row-sharded: the one exchange of the iteration (a paused run re-sums a slab nobody reads: all ranks pause alike)
         VQ_TRY(comm_allreduce_f64(comm, km->slab.as<double>(), (size_t)m * k * (km->cs.sd + 1), s));
-        VQ_TRY(kmeans_finalize_enqueue(km, s, true, false));
-        VQ_TRY(launch_run_update(m, k, km->counts.as<uint32_t>(), km->changed.as<uint32_t>(), km->active_dev.as<uint8_t>(), iters,
-                                 halt, s));
+        VQ_TRY(kmeans_finalize_enqueue(km, s, true, false));  // + the iteration's decisions (k_finalize<true>)
     }
     std::vector<uint32_t> st(m + 1);
     std::vector<uint8_t> act(m);

@@ -424,9 +424,14 @@ __global__ __launch_bounds__(256) void k_reduce_partials(
 __global__ __launch_bounds__(256) void k_reduce_partials_pos(
     const float *__restrict__ partial_sums, const uint32_t *__restrict__ partial_counts,
     uint32_t n_chunks, uint32_t n_sub, const int32_t *__restrict__ sub_pos, uint32_t m, uint32_t k, uint32_t sd,
-    double *__restrict__ slab, const uint8_t *__restrict__ gate_active, const uint32_t *__restrict__ gate_halt) {
+    double *__restrict__ slab, const uint8_t *__restrict__ gate_active, const uint32_t *__restrict__ gate_halt,
+    uint32_t *__restrict__ clear_changed) {
     __shared__ double part[kRedGroups][32];
     if (gate_halt && *gate_halt) return;  // paused run: the slab keeps the pausing iteration's sums
+    // device-driven run: the `changed` flags of the iteration are cleared here (k_finalize sets them; a paused run keeps
+    // those of the iteration that paused it) -- a kernel of its own for m words was one launch in ten at small sizes
+    if (clear_changed && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < m; i += 256) clear_changed[i] = 0u;
     const uint32_t total = m * k * (sd + 1);
     const uint32_t el = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const uint32_t e = blockIdx.x * 32 + el;
@@ -480,32 +485,62 @@ __global__ __launch_bounds__(256) void k_reduce_partials_pos(
     }
 }
 
-// one lane per centroid component
+// one lane per centroid component.  RUN (device-driven run, vqhip_kmeans_run): the workgroup that finishes last also ends
+// the iteration (src/core/vector.rs:440-457 without the host; it used to be a kernel of its own, k_run_update): an active
+// subspace with an empty cluster pauses the run (the caller reseeds: the draw is the host's); otherwise subspaces
+// whose centroids did not move retire, the others count one more iteration.
+template <bool RUN>
 __global__ __launch_bounds__(256) void k_finalize(uint32_t m, uint32_t k, uint32_t sd,
                                                   const double *__restrict__ slab,
-                                                  const uint8_t *__restrict__ active,
+                                                  uint8_t *__restrict__ active,
                                                   float *__restrict__ centroids,
                                                   uint32_t *__restrict__ counts,
                                                   uint32_t *__restrict__ changed, int exact_div,
-                                                  const uint32_t *__restrict__ gate_halt) {
+                                                  uint32_t *__restrict__ gate_halt, uint32_t *__restrict__ iters,
+                                                  uint32_t *__restrict__ done_blocks) {
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= m * k * sd) return;
-    if (gate_halt && *gate_halt) return;  // paused run: centroids, counts and flags keep the pausing iteration's values
-    const uint32_t sj = e / sd, t = e - sj * sd, s = sj / k;
-    const bool act = !active || active[s];
-    const double *row = slab + (size_t)sj * (sd + 1);
-    const double cnt = row[sd];
-    if (t == 0 && counts) counts[sj] = act ? (uint32_t)cnt : 0u;
-    if (!act || !(cnt > 0.0)) return;
-    const float EPSILON = 1e-6f;  // vector.rs:439
-    float nv;
-    if (exact_div) nv = (float)row[t] / (float)cnt;  // row[t] holds an exact f32 value; vector.rs:373,382
-    else nv = (float)(row[t] / cnt);
-    const float diff = nv - centroids[e];
-    // every writer stores the same value: no atomic needed (34816 contended atomicOr on m words
-    // cost 370 us)
-    if (!(fabsf(diff) < EPSILON)) changed[s] = 1u;  // vector.rs:232-240, 444-446
-    centroids[e] = nv;
+    const bool halted = gate_halt && *gate_halt;  // paused run: centroids, counts and flags keep the pausing iteration's values
+    if (e < m * k * sd && !halted) {
+        const uint32_t sj = e / sd, t = e - sj * sd, s = sj / k;
+        const bool act = !active || active[s];
+        const double *row = slab + (size_t)sj * (sd + 1);
+        const double cnt = row[sd];
+        if (t == 0 && counts) counts[sj] = act ? (uint32_t)cnt : 0u;
+        if (act && cnt > 0.0) {
+            const float EPSILON = 1e-6f;  // vector.rs:439
+            float nv;
+            if (exact_div) nv = (float)row[t] / (float)cnt;  // row[t] holds an exact f32 value; vector.rs:373,382
+            else nv = (float)(row[t] / cnt);
+            const float diff = nv - centroids[e];
+            // every writer stores the same value: no atomic needed (34816 contended atomicOr on m words
+            // cost 370 us)
+            if (!(fabsf(diff) < EPSILON)) changed[s] = 1u;  // vector.rs:232-240, 444-446
+            centroids[e] = nv;
+        }
+    }
+    if (!RUN) return;
+    __shared__ int is_last, any_empty;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();  // this workgroup's counts / flags / centroids before its ticket
+        is_last = atomicAdd(done_blocks, 1u) == gridDim.x - 1 ? 1 : 0;
+        any_empty = 0;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();  // the other workgroups' writes
+    if (threadIdx.x == 0) *done_blocks = 0u;  // ready for the next launch
+    if (halted) return;
+    for (uint32_t q = threadIdx.x; q < m * k; q += 256)
+        if (active[q / k] && __builtin_nontemporal_load(&counts[q]) == 0u) any_empty = 1;
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < m; s += 256) {
+        if (!active[s]) continue;
+        iters[s] += 1u;
+        if (!any_empty && !__builtin_nontemporal_load(&changed[s])) active[s] = 0;  // converged (vector.rs:455-457); on a pause the host decides
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && any_empty) *gate_halt = 1u;
 }
 
 __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ X, uint32_t d,
@@ -531,46 +566,6 @@ __global__ __launch_bounds__(256) void k_gather_rows_owned(const float *__restri
     const uint64_t r = rows[sj];
     const bool mine = r >= row_offset && r - row_offset < n_local;
     out_bits[e] = mine ? __float_as_uint(X[(r - row_offset) * d + (size_t)s * sd + t]) : 0u;
-}
-
-__global__ void k_clear_gated(uint32_t *__restrict__ words, uint32_t n, const uint32_t *__restrict__ gate_halt) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && !*gate_halt) words[i] = 0u;
-}
-
-// End of one iteration of a device-driven run (src/core/vector.rs:440-457 without the host): an active subspace with an
-// empty cluster pauses the run (the caller reseeds: the draw is the host's); otherwise subspaces whose centroids did
-// not move retire, the others count one more iteration.  One workgroup.
-__global__ __launch_bounds__(1024) void k_run_update(uint32_t m, uint32_t k, const uint32_t *__restrict__ counts,
-                                                     const uint32_t *__restrict__ changed, uint8_t *__restrict__ active,
-                                                     uint32_t *__restrict__ iters, uint32_t *__restrict__ halt) {
-    __shared__ int any_empty;
-    if (*halt) return;
-    if (threadIdx.x == 0) any_empty = 0;
-    __syncthreads();
-    // four counts per thread and round, all requested before any is looked at (the kernel is a chain of memory
-    // latencies: 16 us with 256 threads and one load per round at C2's 2048 counts)
-    for (uint32_t e0 = threadIdx.x; e0 < m * k; e0 += 4 * 1024) {
-        uint32_t c[4];
-        uint8_t a[4];
-#pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-            const uint32_t e = e0 + u * 1024;
-            c[u] = (e < m * k) ? counts[e] : 1u;
-            a[u] = (e < m * k) ? active[e / k] : (uint8_t)0;
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < 4; ++u)
-            if (a[u] && c[u] == 0u) any_empty = 1;
-    }
-    __syncthreads();
-    for (uint32_t s = threadIdx.x; s < m; s += 1024) {
-        if (!active[s]) continue;
-        iters[s] += 1u;
-        if (!any_empty && !changed[s]) active[s] = 0;  // converged (vector.rs:455-457); on a pause the host decides
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && any_empty) *halt = 1u;
 }
 
 }  // namespace
@@ -753,35 +748,35 @@ int launch_reduce_partials(const UpdatePlan &p, const float *partial_sums,
     return VQHIP_OK;
 }
 
-int launch_run_update(uint32_t m, uint32_t k, const uint32_t *counts, const uint32_t *changed, uint8_t *active,
-                      uint32_t *iters, uint32_t *halt, hipStream_t stream) {
-    hipLaunchKernelGGL(k_run_update, dim3(1), dim3(1024), 0, stream, m, k, counts, changed, active, iters, halt);
-    VQ_LAUNCH_CHECK("k_run_update");
-    return VQHIP_OK;
-}
-
 int launch_reduce_partials_pos(uint32_t m, uint32_t k, uint32_t sd, const float *partial_sums, const uint32_t *partial_counts,
                                uint32_t n_chunks, uint32_t n_sub, const int32_t *sub_pos, double *slab, hipStream_t stream,
-                               const uint8_t *gate_active, const uint32_t *gate_halt) {
+                               const uint8_t *gate_active, const uint32_t *gate_halt, uint32_t *clear_changed) {
     const uint32_t total = m * k * (sd + 1);
     hipLaunchKernelGGL(k_reduce_partials_pos, dim3((total + 31) / 32), dim3(256), 0, stream, partial_sums, partial_counts,
-                       n_chunks, n_sub, sub_pos, m, k, sd, slab, gate_active, gate_halt);
+                       n_chunks, n_sub, sub_pos, m, k, sd, slab, gate_active, gate_halt, clear_changed);
     VQ_LAUNCH_CHECK("k_reduce_partials_pos");
     return VQHIP_OK;
 }
 
 int launch_finalize(uint32_t m, uint32_t k, uint32_t sd, const double *slab, const uint8_t *active,
                     float *centroids, uint32_t *counts, uint32_t *changed, int exact_div,
-                    hipStream_t stream, const uint32_t *gate_halt) {
-    if (gate_halt) {  // a paused run keeps the flags of the iteration that paused it
-        hipLaunchKernelGGL(k_clear_gated, dim3((m + 255) / 256), dim3(256), 0, stream, changed, m, gate_halt);
-        VQ_LAUNCH_CHECK("k_clear_gated");
-    } else {
-        VQ_HIP(hipMemsetAsync(changed, 0, (size_t)m * sizeof(uint32_t), stream));
-    }
-    hipLaunchKernelGGL(k_finalize, dim3((m * k * sd + 255) / 256), dim3(256), 0, stream, m, k, sd, slab,
-                       active, centroids, counts, changed, exact_div, gate_halt);
+                    hipStream_t stream) {
+    VQ_HIP(hipMemsetAsync(changed, 0, (size_t)m * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(k_finalize<false>, dim3((m * k * sd + 255) / 256), dim3(256), 0, stream, m, k, sd, slab,
+                       const_cast<uint8_t *>(active), centroids, counts, changed, exact_div, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                       (uint32_t *)nullptr);
     VQ_LAUNCH_CHECK("k_finalize");
+    return VQHIP_OK;
+}
+
+// finalize + the end of one iteration of a device-driven run (`changed` was cleared by the gated k_reduce_partials_pos;
+// run_state = {halt flag, iterations executed [m]}; done_blocks: a zeroed counter the kernel leaves zeroed)
+int launch_finalize_run(uint32_t m, uint32_t k, uint32_t sd, const double *slab, uint8_t *active, float *centroids,
+                        uint32_t *counts, uint32_t *changed, uint32_t *halt, uint32_t *iters, uint32_t *done_blocks,
+                        hipStream_t stream) {
+    hipLaunchKernelGGL(k_finalize<true>, dim3((m * k * sd + 255) / 256), dim3(256), 0, stream, m, k, sd, slab, active, centroids,
+                       counts, changed, 0, halt, iters, done_blocks);
+    VQ_LAUNCH_CHECK("k_finalize<run>");
     return VQHIP_OK;
 }
 

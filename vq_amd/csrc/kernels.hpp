@@ -144,10 +144,8 @@ int launch_accumulate_listed(uint32_t m, uint32_t k, uint32_t sd, const float *X
 // fixed-order f64 combination of the fused path's slabs [chunk][position in the active list][k][sd]
 int launch_reduce_partials_pos(uint32_t m, uint32_t k, uint32_t sd, const float *partial_sums, const uint32_t *partial_counts,
                                uint32_t n_chunks, uint32_t n_sub, const int32_t *sub_pos, double *slab, hipStream_t stream,
-                               const uint8_t *gate_active = nullptr, const uint32_t *gate_halt = nullptr);
-// end of one device-driven Lloyd iteration (vqhip_kmeans_run): pause on an empty cluster, retire converged subspaces
-int launch_run_update(uint32_t m, uint32_t k, const uint32_t *counts, const uint32_t *changed, uint8_t *active,
-                      uint32_t *iters, uint32_t *halt, hipStream_t stream);
+                               const uint8_t *gate_active = nullptr, const uint32_t *gate_halt = nullptr,
+                               uint32_t *clear_changed = nullptr);  // device-driven run: also clears the iteration's `changed` flags [m]
 // fixed-order f64 combination of the partial slabs -> slab [m][k][sd+1] (last = count)
 int launch_reduce_partials(const UpdatePlan &p, const float *partial_sums,
                            const uint32_t *partial_counts, const uint8_t *active, double *slab,
@@ -160,7 +158,12 @@ size_t exact_sums_workspace_bytes(uint32_t m, uint32_t k, uint64_t n);
 // means + 1e-6 convergence test; exact_div: slab sums are f32-exact values -> f32 divide
 int launch_finalize(uint32_t m, uint32_t k, uint32_t sd, const double *slab, const uint8_t *active,
                     float *centroids, uint32_t *counts, uint32_t *changed, int exact_div,
-                    hipStream_t stream, const uint32_t *gate_halt = nullptr);
+                    hipStream_t stream);
+// the same + the end of one iteration of a device-driven run (vqhip_kmeans_run): retire converged subspaces, count the
+// iteration, raise *halt on an empty cluster; `changed` must have been cleared by the gated launch_reduce_partials_pos
+int launch_finalize_run(uint32_t m, uint32_t k, uint32_t sd, const double *slab, uint8_t *active, float *centroids,
+                        uint32_t *counts, uint32_t *changed, uint32_t *halt, uint32_t *iters, uint32_t *done_blocks,
+                        hipStream_t stream);
 // centroids[s][j] = X[rows[s*k+j]][s*sd ..]
 int launch_gather_rows(const float *X, uint32_t d, uint32_t m, uint32_t k, uint32_t sd,
                        const uint64_t *rows, float *centroids, hipStream_t stream);
