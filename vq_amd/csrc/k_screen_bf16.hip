@@ -227,8 +227,8 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     uint32_t *__restrict__ acc_counts, const uint8_t *__restrict__ gate_active, const uint32_t *__restrict__ gate_halt,
     uint8_t *__restrict__ codes_t, uint64_t codes_t_pitch) {
     // device-side gates of vqhip_kmeans_run (iterations queued ahead of the host): a paused run or a subspace that
-    // has converged meanwhile does nothing (the work-list segments stay zeroed: the re-check finds them empty)
-    if (gate_halt && *gate_halt) return;
+    // has converged meanwhile does nothing but publish an EMPTY work-list segment (the re-check then finds nothing)
+    const bool halted = gate_halt && *gate_halt;
     static_assert(!ACC || (G == 1 && PVW == 0 && SD % 8 == 0), "fused update: single-pass kernels, lane halves of whole 16-byte parts");
     // G > 0: compile-time group count (k <= 256); G == 0: k > 256, the count comes in groups_rt
     const uint32_t groups = (G > 0) ? (uint32_t)G : groups_rt;
@@ -244,9 +244,21 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     if (gw >= n_chunks * n_virt) return;
     const uint32_t vv = gw % n_virt;
     const uint32_t s = sub_list[vv / groups];
-    if (gate_active && !gate_active[s]) return;
     const uint32_t grp = vv % groups;
     const uint32_t chunk = gw / n_virt;
+    // every (listed subspace, chunk) has exactly one owner wave, and every owner writes its segment header -- also the
+    // ones that do nothing: no memset of the headers in front of the launch
+    auto empty_segment = [&]() {
+        if (G == 1 && lane == 0) {
+            uint32_t *sg = wl_seg + ((size_t)s * n_seg + chunk) * 2;
+            sg[0] = 0u;
+            sg[1] = 0u;
+        }
+    };
+    if (halted || (gate_active && !gate_active[s])) {
+        empty_segment();
+        return;
+    }
     const uint64_t n_steps = (n + 31) / 32;
     const uint64_t steps_per_chunk = (n_steps + n_chunks - 1) / n_chunks;
     const uint64_t st0 = (uint64_t)chunk * steps_per_chunk;
@@ -344,6 +356,7 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     };
     if (st0 >= st1) {
         write_partial();  // an empty chunk still owns a (zero) slab
+        empty_segment();
         return;
     }
     // wave-private work-list segment: slots [seg_first, seg_first + rows of the chunk) of the
@@ -941,7 +954,9 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
     if (G == 1) {
         if (!a.wl_seg || n_chunks > a.wl_seg_cap)
             return fail(VQHIP_ERR_FAILURE, "segmented work list missing or too small (%u > %u)", n_chunks, a.wl_seg_cap);
-        VQ_HIP(hipMemsetAsync(a.wl_seg, 0, (size_t)cb.m * n_chunks * 8, stream));
+        // the kernel writes the header of every (listed subspace, chunk); the headers of subspaces that are not listed
+        // (retired ones of a host-driven fit) are only read by the statistics: zeroed when there are any
+        if (a.n_sub < cb.m) VQ_HIP(hipMemsetAsync(a.wl_seg, 0, (size_t)cb.m * n_chunks * 8, stream));
         a.n_seg = n_chunks;
     } else {
         if (!a.part) return fail(VQHIP_ERR_FAILURE, "grouped screen without a partial-result buffer");
