@@ -54,3 +54,16 @@ def test_two_ranks_sharing_the_gpu_weak_and_strong():
     assert weak["scaling"] == "weak" and weak["config"]["rows_global"] == 200000
     assert weak["kmeans_counts_sum_per_subspace"] == [200000, 200000]
     assert weak["value"] > 0 and weak["kmeans_valid"]
+
+
+def test_two_ranks_strong_and_c5_blocks():
+    """what an N > 1 line carries beside the headline: the same job strong-scaled and BASELINE configs[4]'s per-GPU share
+    (12.5M x 128 rows per rank, m = 16) -- here two ranks on the one GPU, the all-reduce over gloo"""
+    line = _bench(["--gpus", "2", "--collective", "gloo", "--rows", "100000", "--steps", "2", "--warmup", "1", "--kmeans-iters", "3",
+                   "--no-cpu-baseline"], env={"VQ_BENCH_SHARE_GPU": "1"}, timeout=1200)
+    s, c5 = line["strong_C2"], line["weak_C5"]
+    assert s["scaling"] == "strong" and s["rows_global"] == 100000 and s["rows_this_rank"] == 50000
+    assert s["kmeans_counts_sum_per_subspace"] == [100000, 100000] and s["kmeans_valid"]
+    assert c5["rows_global"] == 25_000_000 and c5["m"] == 16 and c5["kmeans_counts_sum_per_subspace"] == [25_000_000] * 2
+    assert c5["kmeans_valid"] and c5["encode_vectors_per_s"] > 1e8
+    assert "configs" not in line  # the C1 / C3 / C4 block belongs to the one-GPU line
