@@ -1104,76 +1104,101 @@ __global__ __launch_bounds__(64, 2) void k_fs_fold(const float *__restrict__ X, 
                 *reinterpret_cast<float4 *>(&p_s1[g][4 * q]) = make_float4(ps[0], ps[1], ps[2], ps[3]);
                 *reinterpret_cast<float4 *>(&p_s2[g][4 * q]) = make_float4(sq[0], sq[1], sq[2], sq[3]);
             }
+            // The four columns of a lane are independent: everything below is written column-innermost so that the four
+            // dependent chains (cross-lane sums, the running delta and its min / max) interleave in one basic block --
+            // a lone pair of waves per SIMD hides nothing else (column after column, with the tie test in between,
+            // the block ran at ~10 cycles per instruction).
             float scale[4];
             int32_t gbad[4], gbits[4];
+            {
+                // segment sums: lanes 8 apart (row_ror:8 of a 16-lane row), then the two rows of a segment
+                // (v_permlane16_swap), then the block's other segment (v_permlane32_swap): no LDS round trips
+                float t[4], other[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t = ps[j];
-                t += __shfl_xor(t, 8);
-                t += __shfl_xor(t, 16);                         // the sum of this lane's segment
-                const float other = __shfl_xor(t, 32);          // ... and of the block's other segment
-                const float t0 = (g >= 4) ? other : t;          // segment 0's sum on every lane
-                const float guess = pref[j] + run[j] + (g >= 4 ? t0 : 0.0f);
-                run[j] += t0 + ((g >= 4) ? t : other);          // the same value on every lane that holds the column
-                const uint32_t gb = __float_as_uint(guess), ex = (gb >> 23) & 0xFFu;
-                const int e = (int)ex - 127;
-                // scale = 2^(23-e): needs a normal guess and a representable power of two
-                const bool bad = (ex == 0u) || (ex == 255u) || (23 - e > 126) || (23 - e < -126);
-                scale[j] = bad ? 1.0f : __uint_as_float((uint32_t)(23 - e + 127) << 23);
-                gbad[j] = bad ? 1 : 0, gbits[j] = (int32_t)gb;
+                for (int j = 0; j < 4; ++j)
+                    t[j] = ps[j] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ps[j]), 0x128, 0xF, 0xF, false));  // row_ror:8
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(t[j]), __float_as_uint(t[j]), false, false);
+                    t[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);  // rows (0,1) and (2,3) of the wave: the sum of this lane's segment
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[j]), __float_as_uint(t[j]), false, false);
+                    other[j] = (g >= 4) ? __uint_as_float(sw[0]) : __uint_as_float(sw[1]);  // ... of the block's other segment
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t0 = (g >= 4) ? other[j] : t[j];          // segment 0's sum on every lane
+                    const float guess = pref[j] + run[j] + (g >= 4 ? t0 : 0.0f);
+                    run[j] += t0 + ((g >= 4) ? t[j] : other[j]);          // the same value on every lane that holds the column
+                    const uint32_t gb = __float_as_uint(guess), ex = (gb >> 23) & 0xFFu;
+                    const int e = (int)ex - 127;
+                    // scale = 2^(23-e): needs a normal guess and a representable power of two
+                    const bool bad = (ex == 0u) || (ex == 255u) || (23 - e > 126) || (23 - e < -126);
+                    scale[j] = bad ? 1.0f : __uint_as_float((uint32_t)(23 - e + 127) << 23);
+                    gbad[j] = bad ? 1 : 0, gbits[j] = (int32_t)gb;
+                }
             }
             // ---- fold: 16 rows x 4 columns per lane -----------------------------------------------------------
-            int32_t od0[4], od1[4], olo0[4], olo1[4], ohi0[4], ohi1[4], obad[4];
+            // Fast fold, ONE stream: with q = x / ulp(s) and S = s / ulp(s) an integer, fl(s + x) / ulp = S + rne(q)
+            // whenever q is not exactly half-way between two integers -- whatever the parity of S (the test is exact:
+            // q - rne(q) = +-1/2); a run that does hold a tie is folded again by the two-stream code.
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // Fast fold, ONE stream: with q = x / ulp(s) and S = s / ulp(s) an integer, fl(s + x) / ulp = S + rne(q)
-                // whenever q is not exactly half-way between two integers -- whatever the parity of S (the test is
-                // exact: q - rne(q) = +-1/2); a run that does hold a tie is folded again by the two-stream code.
-                int32_t d1 = 0, lo1 = 0, hi1 = 0;
-                float tmax = 0.0f;
-                uint32_t imax = 0u;
+            for (int jp = 0; jp < 4; jp += 2) {  // two columns at a time, their chains interleaved; results to LDS at once
+                int32_t d1[2] = {0, 0}, lo1[2] = {0, 0}, hi1[2] = {0, 0};
+                float tmax[2] = {0.f, 0.f};
+                uint32_t imax[2] = {0u, 0u};
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float qq = w[i][j] * scale[j];   // exact (power of two) unless it overflows: caught by imax
-                    const float r = __builtin_rintf(qq);   // v_rndne_f32
-                    tmax = fmaxf(tmax, fabsf(qq - r));     // qq - r is exact; a NaN is caught by imax
-                    imax = max(imax, __float_as_uint(qq) & 0x7FFFFFFFu);
-                    d1 += (int32_t)r;
-                    lo1 = min(lo1, d1);
-                    hi1 = max(hi1, d1);
-                }
-                obad[j] = gbad[j] | (imax >= 0x4B800000u ? 1 : 0);  // |q| >= 2^24, inf or NaN: cannot stay in the binade
-                od0[j] = od1[j] = d1, olo0[j] = olo1[j] = lo1, ohi0[j] = ohi1[j] = hi1;
-                if (!obad[j] && tmax == 0.5f) {
-                    // two streams (even / odd incoming S), exact tie handling.  q = a + f, a = floor(q), 0 <= f < 1,
-                    // classified EXACTLY from 2q (exact: |q| < 2^24): with i2 = floor(2q), a = i2 >> 1 and f is above /
-                    // at / below one half as (i2 odd, 2q not an integer) / (i2 odd, 2q an integer) / (i2 even).
-                    const float scale2 = scale[j] + scale[j];
-                    int32_t dA = 0, dB = 0, loA = 0, loB = 0, hiA = 0, hiB = 0;  // A: even incoming S, B: odd
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float qq = w[i][j] * scale2;
-                        const float fl = floorf(qq);
-                        const int32_t i2 = (int32_t)fl, sticky = qq != fl ? 1 : 0;
-                        const int32_t ai = i2 >> 1, half = i2 & 1;
-                        const int32_t up = half & sticky, tie = half & (sticky ^ 1);
-                        const int32_t bA = dA + ai, bB = dB + ai;
-                        dA = bA + (up | (tie & bA));        // tie: round to the even S
-                        dB = bB + (up | (tie & (1 + bB)));
-                        loA = min(loA, dA), hiA = max(hiA, dA);
-                        loB = min(loB, dB), hiB = max(hiB, dB);
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const float qq = w[i][jp + jj] * scale[jp + jj];  // exact (power of two) unless it overflows: caught by imax
+                        const float r = __builtin_rintf(qq);              // v_rndne_f32
+                        tmax[jj] = fmaxf(tmax[jj], fabsf(qq - r));        // qq - r is exact; a NaN is caught by imax
+                        imax[jj] = max(imax[jj], __float_as_uint(qq) & 0x7FFFFFFFu);
+                        d1[jj] += (int32_t)r;
+                        lo1[jj] = min(lo1[jj], d1[jj]);
+                        hi1[jj] = max(hi1[jj], d1[jj]);
                     }
-                    od0[j] = dA, od1[j] = dB, olo0[j] = loA, olo1[j] = loB, ohi0[j] = hiA, ohi1[j] = hiB;
                 }
+                int32_t od0[2], od1[2], olo0[2], olo1[2], ohi0[2], ohi1[2], obad[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = jp + jj;
+                    obad[jj] = gbad[j] | (imax[jj] >= 0x4B800000u ? 1 : 0);  // |q| >= 2^24, inf or NaN: cannot stay in the binade
+                    od0[jj] = od1[jj] = d1[jj], olo0[jj] = olo1[jj] = lo1[jj], ohi0[jj] = ohi1[jj] = hi1[jj];
+                    if (!obad[jj] && tmax[jj] == 0.5f) {
+                        // two streams (even / odd incoming S), exact tie handling.  q = a + f, a = floor(q), 0 <= f < 1,
+                        // classified EXACTLY from 2q (exact: |q| < 2^24): with i2 = floor(2q), a = i2 >> 1 and f is above
+                        // / at / below one half as (i2 odd, 2q not an integer) / (i2 odd, 2q an integer) / (i2 even).
+                        const float scale2 = scale[j] + scale[j];
+                        int32_t dA = 0, dB = 0, loA = 0, loB = 0, hiA = 0, hiB = 0;  // A: even incoming S, B: odd
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float qq = w[i][j] * scale2;
+                            const float fl = floorf(qq);
+                            const int32_t i2 = (int32_t)fl, sticky = qq != fl ? 1 : 0;
+                            const int32_t ai = i2 >> 1, half = i2 & 1;
+                            const int32_t up = half & sticky, tie = half & (sticky ^ 1);
+                            const int32_t bA = dA + ai, bB = dB + ai;
+                            dA = bA + (up | (tie & bA));        // tie: round to the even S
+                            dB = bB + (up | (tie & (1 + bB)));
+                            loA = min(loA, dA), hiA = max(hiA, dA);
+                            loB = min(loB, dB), hiB = max(hiB, dB);
+                        }
+                        od0[jj] = dA, od1[jj] = dB, olo0[jj] = loA, olo1[jj] = loB, ohi0[jj] = hiA, ohi1[jj] = hiB;
+                    }
+                }
+                *reinterpret_cast<int2 *>(&p_d0[g][4 * q + jp]) = make_int2(od0[0], od0[1]);
+                *reinterpret_cast<int2 *>(&p_d1[g][4 * q + jp]) = make_int2(od1[0], od1[1]);
+                *reinterpret_cast<int2 *>(&p_lo0[g][4 * q + jp]) = make_int2(olo0[0], olo0[1]);
+                *reinterpret_cast<int2 *>(&p_lo1[g][4 * q + jp]) = make_int2(olo1[0], olo1[1]);
+                *reinterpret_cast<int2 *>(&p_hi0[g][4 * q + jp]) = make_int2(ohi0[0], ohi0[1]);
+                *reinterpret_cast<int2 *>(&p_hi1[g][4 * q + jp]) = make_int2(ohi1[0], ohi1[1]);
+                *reinterpret_cast<int2 *>(&p_bad[g][4 * q + jp]) = make_int2(obad[0], obad[1]);
+                *reinterpret_cast<int2 *>(&p_gb[g][4 * q + jp]) = make_int2(gbits[jp], gbits[jp + 1]);
             }
-            *reinterpret_cast<int4 *>(&p_d0[g][4 * q]) = make_int4(od0[0], od0[1], od0[2], od0[3]);
-            *reinterpret_cast<int4 *>(&p_d1[g][4 * q]) = make_int4(od1[0], od1[1], od1[2], od1[3]);
-            *reinterpret_cast<int4 *>(&p_lo0[g][4 * q]) = make_int4(olo0[0], olo0[1], olo0[2], olo0[3]);
-            *reinterpret_cast<int4 *>(&p_lo1[g][4 * q]) = make_int4(olo1[0], olo1[1], olo1[2], olo1[3]);
-            *reinterpret_cast<int4 *>(&p_hi0[g][4 * q]) = make_int4(ohi0[0], ohi0[1], ohi0[2], ohi0[3]);
-            *reinterpret_cast<int4 *>(&p_hi1[g][4 * q]) = make_int4(ohi1[0], ohi1[1], ohi1[2], ohi1[3]);
-            *reinterpret_cast<int4 *>(&p_bad[g][4 * q]) = make_int4(obad[0], obad[1], obad[2], obad[3]);
-            *reinterpret_cast<int4 *>(&p_gb[g][4 * q]) = make_int4(gbits[0], gbits[1], gbits[2], gbits[3]);
             fs_wave_lds_sync();
             // ---- compose the segment's four runs in row order; predict; write ---------------------------------
             const uint32_t c = cur.c0 + cl;
