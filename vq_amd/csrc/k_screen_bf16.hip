@@ -34,6 +34,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWavesPerBlock * 64;
+constexpr uint64_t kPipeMinSteps = 8;  // shortest row chunk (in 32-row steps) given to the pipelined X32 screen
 
 // term pairs, big to small: (A part, X part), parts numbered 0..2
 __host__ __device__ constexpr int pair_a(int p) { return p == 0 ? 0 : p == 1 ? 1 : p == 2 ? 0 : p == 3 ? 2 : p == 4 ? 1 : 0; }
@@ -697,6 +698,369 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     }
 }
 
+// ---- variant X32P: the X32 kernel software-pipelined across steps -------------------------------------------
+// A lone wave issues in order: in the X32 kernel the operand split of a step (~100 VALU instructions) and its tail
+// (~70) run with the matrix pipe idle, and the 12 MFMAs of a step's first two tiles issue back to back with nothing
+// to hide behind (28 idle cycles each); the counters show the wave issuing VALU work 56 % of its time.  Here the
+// accumulator ring simply runs on across steps -- phase i of step st reduces tile i, issues the MFMA chain of tile
+// i + 2 (tiles 8 and 9 are tiles 0 and 1 of step st + 1) and starts the |c|^2 reads of tile i + 3 -- and the rest of
+// the work rides in the gaps between those MFMAs, one piece per gap:
+//     the operand split of step st + 1 (its rows were loaded a step ago; the load of step st + 2 is issued as soon
+//     as they are consumed) and the tail of step st - 1 (merge of the chains and lane halves, margin test, code,
+//     work list), all within phases 0..5 -- the operands must be complete when phase 6 issues tile 0 of step st + 1.
+// Two operand sets and two sets of chains alternate (the loop body is unrolled twice).  The arithmetic, the index
+// tags and the order in which values enter a chain are those of the X32 kernel: codes, work lists and statistics
+// are the same bits.  One extra (drain) iteration runs the last tail; launch_one_x32 picks this variant for chunks
+// of at least kPipeMinSteps steps, 8 tiles (k in 225..256), sub_dim 8 or 16, one centroid group.
+template <int SD, int NT32>
+__global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_assign_screen_bf16_x32p(
+    const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m, const uint32_t *__restrict__ prepA32,
+    const float *__restrict__ prepCn, uint32_t cn_stride, const float *__restrict__ meta,
+    const uint32_t *__restrict__ sub_list, uint32_t n_sub, uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows,
+    uint32_t *__restrict__ wl_seg, uint32_t n_seg, uint64_t wl_stride, int cosine, uint32_t k_real,
+    const float *__restrict__ cen, const uint8_t *__restrict__ gate_active, const uint32_t *__restrict__ gate_halt,
+    uint8_t *__restrict__ codes_t, uint64_t codes_t_pitch) {
+    static_assert(NT32 == 8 && (SD == 8 || SD == 16), "pipelined screen: 8 tiles, sub_dim 8 or 16");
+    constexpr int DPH = SD / 2;
+    constexpr int NMF = (6 * DPH + 7) / 8;
+    static_assert(6 * DPH == 8 * NMF, "every MFMA carries one term pair (sub_dim 16) or two (sub_dim 8), no padding slots");
+    const bool halted = gate_halt && *gate_halt;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t h = lane >> 5, p = lane & 31;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    const uint32_t n_chunks = total_waves / n_sub;
+    if (gw >= n_chunks * n_sub) return;
+    const uint32_t vv = gw % n_sub;
+    const uint32_t s = sub_list[vv];
+    const uint32_t chunk = gw / n_sub;
+    uint32_t *const seg_hdr = wl_seg + ((size_t)s * n_seg + chunk) * 2;
+    // rows and steps in 32 bits (the work list holds 32-bit rows; launch_one_x32 sends n >= 2^32 - 64 to the X32 kernel)
+    const uint32_t n32 = (uint32_t)n;
+    const uint32_t n_steps = (n32 + 31) / 32;
+    const uint32_t steps_per_chunk = (n_steps + n_chunks - 1) / n_chunks;
+    const uint32_t st0 = chunk * steps_per_chunk;
+    uint32_t st1 = st0 + steps_per_chunk;
+    if (st1 > n_steps) st1 = n_steps;
+    if (halted || (gate_active && !gate_active[s]) || st0 >= st1) {
+        if (lane == 0) seg_hdr[0] = 0u, seg_hdr[1] = 0u;
+        return;
+    }
+    const uint32_t nst = st1 - st0;
+    const uint32_t seg_first = st0 * 32;
+    uint32_t seg_count = 0;
+
+    __shared__ __attribute__((aligned(16))) float lds_cn[kWavesPerBlock][NT32 * 32];
+    bf16x8 a[NT32][NMF];
+    {
+        const uint32_t *base = prepA32 + (size_t)s * NT32 * NMF * 4 * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NT32; ++i)
+#pragma unroll
+            for (int f = 0; f < NMF; ++f) {
+                u32x4 v;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v[w] = base[((i * NMF + f) * 4 + w) * 64];
+                a[i][f] = __builtin_bit_cast(bf16x8, v);
+            }
+        const float *pc = prepCn + (size_t)s * cn_stride;
+        for (uint32_t e = lane; e < NT32 * 32; e += 64) {
+            float v = (e < cn_stride) ? pc[e] : 3.0e38f;
+            if (cosine) v = (e < k_real) ? 0.0f : 3.0e38f;
+            lds_cn[wave][e] = (v < 3.0e38f) ? v : 3.0e38f;
+        }
+    }
+    const f32x4 *cnp = reinterpret_cast<const f32x4 *>(&lds_cn[wave][4 * h]);
+    float pinf = __builtin_inff(), ninf = -__builtin_inff();
+    uint32_t idx_mask = 0xFFFFFFC0u;
+    asm volatile("" : "+s"(idx_mask));
+    asm volatile("" : "+s"(pinf), "+s"(ninf));
+    float cmax, tcoef;
+    float mu[DPH];
+    if (cosine) {
+        cmax = 0.0f;
+        tcoef = meta[s * 4 + 3];
+        if (tcoef <= 3.0e38f) tcoef = (6.0f * SD + 2.5f * kBf16AssumedUlps * NMF + 200.0f) * 5.9604644775390625e-08f;
+#pragma unroll
+        for (int q = 0; q < DPH; ++q) mu[q] = 0.0f;
+    } else {
+        const float *cs = cen + (size_t)s * (SD + 4);
+        cmax = cs[SD];
+        tcoef = cs[SD + 1];
+#pragma unroll
+        for (int q = 0; q < DPH; ++q) mu[q] = cs[DPH * h + q];
+    }
+    const char *const x_base = reinterpret_cast<const char *>(X + (size_t)s * SD + (size_t)DPH * h);
+    const uint32_t x_pitch = d * 4;
+    // codes: [row][m] bytes, or the [m][pitch] scratch of the transposing caller -- one address form for both
+    uint8_t *const code_base = codes_t ? codes_t + (size_t)s * codes_t_pitch : codes + s;
+    const uint32_t code_stride = codes_t ? 1u : m;
+    // rows in flight, TWO steps deep (1024 waves x 2 KB per step in flight is ~2 MB, what 1.1 TB/s needs at ~2 us of
+    // latency; one step deep the wave waited 19 % of its time): at the top of step st, xn_[par ^ 1] holds step st + 1
+    // (about to be consumed, then reloaded with st + 3) and xn_[par] step st + 2
+    float xn_[2][DPH];
+    auto load_x = [&](uint32_t row, int buf) {
+        row = row < n32 ? row : n32 - 1;
+        const float *ptr = reinterpret_cast<const float *>(x_base + (uint64_t)row * x_pitch);
+#pragma unroll
+        for (int q = 0; q < DPH; q += 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(ptr + q);
+            xn_[buf][q + 0] = t.x;
+            xn_[buf][q + 1] = t.y;
+            xn_[buf][q + 2] = t.z;
+            xn_[buf][q + 3] = t.w;
+        }
+    };
+    auto init_acc = [&](f32x16 &acc, int i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 c4 = cnp[(32 * i + 8 * q) / 4];
+            acc[4 * q + 0] = c4[0];
+            acc[4 * q + 1] = c4[1];
+            acc[4 * q + 2] = c4[2];
+            acc[4 * q + 3] = c4[3];
+        }
+    };
+    // One wave per SIMD (sub_dim 16) has VGPRs to spare: the |c|^2 image of the first kCnV tiles (16 values per lane and
+    // tile) stays in registers and enters as the C operand of the tile's first MFMA -- no LDS re-read of the
+    // accumulator's initial value for them (4 ds_read_b128 and a wait per tile; every instruction of a lone wave costs
+    // an issue slot of ~5 cycles, profiles/ubench/valu_issue.hip).  (C and D of an MFMA share their register class, so
+    // the 64 spare AGPRs cannot hold the other tiles' images.)  Two waves per SIMD (sub_dim 8): LDS for all tiles.
+    constexpr int kCnV = x32_two_waves(SD, NT32) ? 0 : 6;
+    f32x16 cnr[kCnV > 0 ? kCnV : 1];
+#pragma unroll
+    for (int i = 0; i < kCnV; ++i) init_acc(cnr[i], i);
+    auto mfma = [&](f32x16 &accv, int ti, int f, const bf16x8 &bv) {
+        if (f == 0 && ti < kCnV) {  // D = A B + |c|^2 (register image), the chain then runs in place
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(accv) : "a"(a[ti][f]), "v"(bv), "v"(cnr[ti]));
+            return;
+        }
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv) : "a"(a[ti][f]), "v"(bv));
+    };
+
+    bf16x8 b[2][NMF];
+    float q1[2][4], q2[2][4], snap[2][4];
+    float xc[DPH];
+    uint32_t xp[3][DPH];
+    float xsT = 0.0f, xsM = 0.0f, xsN = 0.0f;  // |x - mu|^2 (this lane half) of steps st - 1, st, st + 1
+    f32x16 acc[4];
+
+    // operand split of one step in 1 + DPH / 4 + NMF pieces (four dimensions to a split piece: two independent packed
+    // chains, no wait states between a v_pk_add_f32 and its consumer); piece 0 consumes the loaded rows (buffer nb) and issues the
+    // load that refills the buffer
+    constexpr int kSplitPieces = 1 + DPH / 4 + NMF;
+    auto split_piece = [&](int k, int nb, uint32_t next_step) {
+        if (k == 0) {
+#pragma unroll
+            for (int q = 0; q < DPH; ++q) {
+                xc[q] = xn_[nb][q] - mu[q];
+                asm volatile("" ::"v"(xc[q]));  // consumed HERE (see reduce_hg), the registers are free for the next load
+            }
+            xsN = 0.0f;
+            load_x(next_step * 32 + p, nb);
+        } else if (k <= DPH / 4) {
+#pragma unroll
+            for (int q = 4 * (k - 1); q < 4 * k; ++q) {
+                uint32_t parts[3];
+                split3(xc[q], parts);
+                xp[0][q] = parts[0];
+                xp[1][q] = parts[1];
+                xp[2][q] = parts[2];
+                xsN = fmaf(xc[q], xc[q], xsN);
+            }
+        } else {
+            const int f = k - 1 - DPH / 4;
+            u32x4 v;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                uint32_t hw[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int flat = 8 * f + 2 * w + hh, pair = flat / DPH, dd = flat % DPH;
+                    hw[hh] = xp[pair_x(pair)][dd];
+                }
+                v[w] = (hw[0] >> 16) | (hw[1] & 0xFFFF0000u);
+            }
+            b[nb][f] = __builtin_bit_cast(bf16x8, v);
+            asm volatile("" ::"v"(b[nb][f]));
+        }
+    };
+    // two chains' share (r = 2 (hg & 1), + 1) of values 8 (hg >> 1) .. + 7 of a finished tile: see reduce8 above.  The
+    // chain's second-minimum takes both pairs of a tile in one v_min3 (hg >= 2), as the compiler does for reduce8; the
+    // results are pinned to their gap (an empty asm that reads them): without a use here the compiler sinks the whole
+    // reduction below the tail's branches.
+    float ta[4];
+    auto min3 = [](float x, float y, float z) { return __builtin_fminf(__builtin_fminf(x, y), z); };  // v_min3_f32
+    auto reduce_hg = [&](const f32x16 &fin, int ifin, int hg, int par) {
+        const int g8 = hg >> 1;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * (hg & 1) + rr;
+            const uint32_t ca = (uint32_t)((16 * ifin + 8 * g8 + r) & 63), cb = (uint32_t)((16 * ifin + 8 * g8 + 4 + r) & 63);
+            const float pa = __uint_as_float((__float_as_uint(fin[8 * g8 + r]) & idx_mask) | ca);
+            const float pb = __uint_as_float((__float_as_uint(fin[8 * g8 + 4 + r]) & idx_mask) | cb);
+            const float t = __builtin_amdgcn_fmed3f(q1[par][r], pa, pb);
+            q1[par][r] = min3(q1[par][r], pa, pb);
+            if (g8 == 0) {
+                ta[r] = t;
+                asm volatile("" ::"v"(q1[par][r]), "v"(ta[r]));
+            } else {
+                q2[par][r] = min3(q2[par][r], ta[r], t);
+                asm volatile("" ::"v"(q1[par][r]), "v"(q2[par][r]));
+            }
+        }
+    };
+    // merges two chains' (min, second min); the winner's snapshot travels along (its 7-bit value index is read off once,
+    // at the end: low 6 bits of the minimum + 64 if it moved after the snapshot)
+    auto merge2 = [&](float a1, float a2, float as, float b1, float b2, float bs, float &o1, float &o2, float &os) {
+        const float hi = __builtin_amdgcn_fmed3f(a1, b1, pinf);
+        const float lo2 = __builtin_amdgcn_fmed3f(a2, b2, ninf);
+        o2 = __builtin_amdgcn_fmed3f(hi, lo2, ninf);
+        const bool tb = b1 < a1;
+        o1 = tb ? b1 : a1;
+        os = tb ? bs : as;
+    };
+    // tail of a finished step in 4 pieces (the X32 kernel's tail, same order of operations)
+    float t_m1 = 0.0f, t_m2 = 0.0f, t_xs = 0.0f;
+    uint32_t t_j = 0;
+    bool t_proven = false;
+    auto tail_piece = [&](int k, int tp, uint32_t tst, bool in_loop) {
+        if (k == 0) {
+            float u1, u2, us, w1, w2, ws, ms;
+            merge2(q1[tp][0], q2[tp][0], snap[tp][0], q1[tp][1], q2[tp][1], snap[tp][1], u1, u2, us);
+            merge2(q1[tp][2], q2[tp][2], snap[tp][2], q1[tp][3], q2[tp][3], snap[tp][3], w1, w2, ws);
+            merge2(u1, u2, us, w1, w2, ws, t_m1, t_m2, ms);
+            const uint32_t vidx = (__float_as_uint(t_m1) & 63u) + ((t_m1 < ms) ? 64u : 0u);
+            t_j = ((vidx >> 4) << 5) + (vidx & 3u) + (((vidx >> 2) & 3u) << 3) + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q1[tp][r] = pinf, q2[tp][r] = pinf;  // the chains of step tst + 2 start here
+        } else if (k == 1) {
+            const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t_m1), __float_as_uint(t_m1), false, false);
+            const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t_m2), __float_as_uint(t_m2), false, false);
+            const auto rj = __builtin_amdgcn_permlane32_swap(t_j, t_j, false, false);
+            const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(xsT), __float_as_uint(xsT), false, false);
+            const float a1 = __uint_as_float(r1[0]), b1 = __uint_as_float(r1[1]);
+            const float a2 = __uint_as_float(r2[0]), b2 = __uint_as_float(r2[1]);
+            t_xs = __uint_as_float(rx[0]) + __uint_as_float(rx[1]);
+            const float hi = __builtin_amdgcn_fmed3f(a1, b1, pinf);
+            const float lo2 = __builtin_amdgcn_fmed3f(a2, b2, ninf);
+            t_m2 = __builtin_amdgcn_fmed3f(lo2, hi, ninf);
+            const bool take = (b1 < a1) || (b1 == a1 && rj[1] < rj[0]);
+            t_j = take ? rj[1] : rj[0];
+            t_m1 = take ? b1 : a1;
+        } else if (k == 2) {
+            const float xnorm = __builtin_sqrtf(t_xs) * 1.000001f;
+            const float xn = xnorm + cmax;
+            const float bnd = cosine ? xnorm : xn * xn;
+            const float T = tcoef * bnd + 1e-35f * xn + 1e-37f;
+            const float gap = t_m2 - t_m1;
+            bool proven = (gap > T) && (fabsf(t_m1) <= 3.0e38f) && (T <= 3.0e38f);
+            if (cosine) proven = proven && (t_m1 < -T) && (xnorm > 4e-10f);
+            t_proven = proven;
+        } else {
+            // In the loop the only tail without a step behind it is the first one (tst = st0 - 1, chains still +inf): it is
+            // aimed at the rows of step st0, which the real tail of st0 overwrites a step later; rows past n repeat row
+            // n - 1 (they were loaded from it) and both lane halves hold the same verdict -- so the code is stored
+            // by every lane, without a branch.  The tail after the loop may belong to a dummy step: it asks.
+            const bool valid = in_loop ? (tst != st0 - 1) : (tst < st1);
+            const uint32_t row = (in_loop && !valid ? st0 : tst) * 32 + p;
+            const uint32_t rowc = row < n32 ? row : n32 - 1;
+            if (in_loop || valid) code_base[(uint64_t)rowc * code_stride] = (uint8_t)t_j;
+            const bool writer = (h == 0) && (row < n32) && valid;
+            const bool recheck = writer && !t_proven;
+            const unsigned long long mask = __ballot(recheck);
+            if (mask != 0ull) {
+                if (recheck) {
+                    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                    wl_rows[(size_t)s * wl_stride + seg_first + seg_count + rank] = (uint32_t)row;
+                }
+                seg_count += (uint32_t)__popcll(mask);
+            }
+        }
+    };
+
+    // ---- prologue: operands of step st0, its first two MFMA chains, the rows of st0 + 1 on their way ----
+    load_x(st0 * 32 + p, 0);
+    load_x((st0 + 1) * 32 + p, 1);
+#pragma unroll
+    for (int k = 0; k < kSplitPieces; ++k) split_piece(k, 0, st0 + 2);  // buffer 0: step st0 now, st0 + 2 next
+    xsM = xsN;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q1[0][r] = q2[0][r] = snap[0][r] = q1[1][r] = q2[1][r] = snap[1][r] = pinf;
+    if (0 >= kCnV) init_acc(acc[0], 0);
+    if (1 >= kCnV) init_acc(acc[1], 1);
+    if (2 >= kCnV) init_acc(acc[2], 2);
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int f = 0; f < NMF; ++f) mfma(acc[0], 0, f, b[0][f]);
+#pragma unroll
+    for (int f = 0; f < NMF; ++f) mfma(acc[1], 1, f, b[0][f]);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // always an even number of steps: a step at or past st1 is a dummy (rows clamped, nothing written), so the loop body
+    // has no exit in the middle; the tail of the very last step follows the loop
+    for (uint32_t it0 = 0; it0 < nst; it0 += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const uint32_t st = st0 + it0 + par;
+#pragma unroll
+            for (int i = 0; i < NT32; ++i) {
+                if ((i + 3) % NT32 >= kCnV) init_acc(acc[(i + 3) & 3], (i + 3) % NT32);
+                if (i == 4) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) snap[par][r] = q1[par][r];
+                }
+#pragma unroll
+                for (int f = 0; f < NMF; ++f) {
+                    if (i + 2 < NT32) mfma(acc[(i + 2) & 3], i + 2, f, b[par][f]);
+                    else mfma(acc[(i + 2) & 3], i + 2 - NT32, f, b[par ^ 1][f]);
+                    // the gap's share of the phase: 4 reduce half-groups (9 VALU instructions each) and the fillers.
+                    // Order of the fillers: the rows of step st + 1 are consumed (and the load of st + 2 issued) FIRST,
+                    // the tail's stores follow -- the wait in front of the next consumption covers every earlier
+                    // memory operation, so the stores get most of a step to retire before it.
+                    if constexpr (NMF == 6) {
+                        if (f == 0) reduce_hg(acc[i & 3], i, 0, par);
+                        if (f == 1) reduce_hg(acc[i & 3], i, 1, par);
+                        if (f == 3) reduce_hg(acc[i & 3], i, 2, par);
+                        if (f == 4) reduce_hg(acc[i & 3], i, 3, par);
+                        if (f == 2 || f == 5) {
+                            const int slot = 2 * i + (f == 5);  // 0..15
+                            if (slot == 0) split_piece(0, par ^ 1, st + 3);
+                            else if (slot <= 4) tail_piece(slot - 1, par ^ 1, st - 1, true);
+                            else if (slot <= 10) split_piece(slot - 4, par ^ 1, st + 3);      // 2 splits, packs 0..3
+                            else if (slot == 11) split_piece(7, par ^ 1, st + 3), split_piece(8, par ^ 1, st + 3);
+                        }
+                    } else {  // NMF == 3: one filler gap per phase
+                        if (f == 0) reduce_hg(acc[i & 3], i, 0, par), reduce_hg(acc[i & 3], i, 1, par);
+                        if (f == 1) reduce_hg(acc[i & 3], i, 2, par), reduce_hg(acc[i & 3], i, 3, par);
+                        if (f == 2) {
+                            if (i == 0) {
+                                split_piece(0, par ^ 1, st + 3);
+                                tail_piece(0, par ^ 1, st - 1, true), tail_piece(1, par ^ 1, st - 1, true);
+                            } else if (i == 1) {
+                                tail_piece(2, par ^ 1, st - 1, true), tail_piece(3, par ^ 1, st - 1, true);
+                                split_piece(1, par ^ 1, st + 3);
+                            } else if (i < kSplitPieces) {
+                                split_piece(i, par ^ 1, st + 3);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            xsT = xsM;
+            xsM = xsN;
+        }
+    }
+    {
+        const uint32_t last = st0 + ((nst + 1) & ~1u) - 1;  // parity 1
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tail_piece(k, 1, last, false);
+    }
+    if (lane == 0) seg_hdr[0] = seg_first, seg_hdr[1] = seg_count;
+}
+
 // merges the G group verdicts of every (row, subspace), applies the margin test of the single-pass
 // kernel and either writes the code or appends the row to the subspace's re-check list
 template <int G>
@@ -976,11 +1340,28 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
             attr_set.done();
         }
     }
-    hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32, G, PVW, ACC>), dim3(blocks), dim3(kBlock), dyn_lds, stream, a.X, a.n, a.d,
-                       cb.m, cb.prepA32, cb.cn32, NT32 * groups * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
-                       a.wl_seg, n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen,
-                       reinterpret_cast<uint4 *>(a.part), groups, cb.sd, ACC ? a.acc_sums : nullptr, ACC ? a.acc_counts : nullptr,
-                       a.gate_active, a.gate_halt, (G == 1) ? a.codes_t : nullptr, a.codes_t_pitch);
+    bool piped = false;
+    if constexpr (G == 1 && PVW == 0 && !ACC && NT32 == 8 && (SD == 8 || SD == 16)) {
+        // chunks of at least kPipeMinSteps steps: the software-pipelined variant (same results; one drain iteration)
+        static const bool pipe_on = [] {
+            const char *e = std::getenv("VQHIP_SCREEN_PIPE");
+            return !(e && e[0] == '0');
+        }();
+        const uint64_t steps_per_chunk = (n_steps + n_chunks - 1) / n_chunks;
+        if (pipe_on && steps_per_chunk >= kPipeMinSteps && a.n < 0xFFFFFFC0ull) {
+            piped = true;
+            hipLaunchKernelGGL((k_assign_screen_bf16_x32p<SD, NT32>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d, cb.m,
+                               cb.prepA32, cb.cn32, NT32 * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows, a.wl_seg,
+                               n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen, a.gate_active,
+                               a.gate_halt, a.codes_t, a.codes_t_pitch);
+        }
+    }
+    if (!piped)
+        hipLaunchKernelGGL((k_assign_screen_bf16_x32<SD, NT32, G, PVW, ACC>), dim3(blocks), dim3(kBlock), dyn_lds, stream, a.X, a.n, a.d,
+                           cb.m, cb.prepA32, cb.cn32, NT32 * groups * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows,
+                           a.wl_seg, n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen,
+                           reinterpret_cast<uint4 *>(a.part), groups, cb.sd, ACC ? a.acc_sums : nullptr, ACC ? a.acc_counts : nullptr,
+                           a.gate_active, a.gate_halt, (G == 1) ? a.codes_t : nullptr, a.codes_t_pitch);
     VQ_LAUNCH_CHECK("k_assign_screen_bf16_x32");
     if (G == 1 && a.codes_t) {
         hipLaunchKernelGGL(k_codes_transpose, dim3((uint32_t)((a.n + 255) / 256)), dim3(256), (size_t)256 * (cb.m + 4) + cb.m, stream,
