@@ -712,14 +712,14 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
 // tags and the order in which values enter a chain are those of the X32 kernel: codes, work lists and statistics
 // are the same bits.  One extra (drain) iteration runs the last tail; launch_one_x32 picks this variant for chunks
 // of at least kPipeMinSteps steps, 8 tiles (k in 225..256), sub_dim 8 or 16, one centroid group.
-template <int SD, int NT32>
+template <int SD, int NT32, bool ACC = false>
 __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_assign_screen_bf16_x32p(
     const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m, const uint32_t *__restrict__ prepA32,
     const float *__restrict__ prepCn, uint32_t cn_stride, const float *__restrict__ meta,
     const uint32_t *__restrict__ sub_list, uint32_t n_sub, uint8_t *__restrict__ codes, uint32_t *__restrict__ wl_rows,
     uint32_t *__restrict__ wl_seg, uint32_t n_seg, uint64_t wl_stride, int cosine, uint32_t k_real,
     const float *__restrict__ cen, const uint8_t *__restrict__ gate_active, const uint32_t *__restrict__ gate_halt,
-    uint8_t *__restrict__ codes_t, uint64_t codes_t_pitch) {
+    uint8_t *__restrict__ codes_t, uint64_t codes_t_pitch, float *__restrict__ acc_sums, uint32_t *__restrict__ acc_counts) {
     static_assert(NT32 == 8 && (SD == 8 || SD == 16), "pipelined screen: 8 tiles, sub_dim 8 or 16");
     constexpr int DPH = SD / 2;
     constexpr int NMF = (6 * DPH + 7) / 8;
@@ -743,7 +743,43 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     const uint32_t st0 = chunk * steps_per_chunk;
     uint32_t st1 = st0 + steps_per_chunk;
     if (st1 > n_steps) st1 = n_steps;
-    if (halted || (gate_active && !gate_active[s]) || st0 >= st1) {
+    if (halted || (gate_active && !gate_active[s])) {
+        if (lane == 0) seg_hdr[0] = 0u, seg_hdr[1] = 0u;
+        return;
+    }
+    // fused update (ACC, see the X32 kernel): this wave's [NT32*32][SD] sums (R copies) + counts in LDS, one partial slab
+    extern __shared__ __attribute__((aligned(16))) float acc_lds[];
+    constexpr uint32_t R = x32_acc_copies(SD, NT32);
+    constexpr uint32_t kCopy = NT32 * 32 * SD;
+    float *sums = nullptr;
+    uint32_t *cnts = nullptr;
+    if constexpr (ACC) {
+        constexpr uint32_t kPerWave = NT32 * 32 * (R * SD + 1);
+        sums = acc_lds + (size_t)wave * kPerWave;
+        cnts = reinterpret_cast<uint32_t *>(sums + R * kCopy);
+        for (uint32_t e = lane; e < R * kCopy / 4; e += 64) reinterpret_cast<float4 *>(sums)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t e = lane; e < NT32 * 32; e += 64) cnts[e] = 0u;
+    }
+    auto write_partial = [&]() {
+        if constexpr (ACC) {
+            float4 *ps = reinterpret_cast<float4 *>(acc_sums + ((size_t)chunk * n_sub + vv) * k_real * SD);
+            for (uint32_t e = lane; e < k_real * SD / 4; e += 64) {
+                float4 t = reinterpret_cast<const float4 *>(sums)[e];
+                if constexpr (R == 2) {
+                    const float4 u = reinterpret_cast<const float4 *>(sums + kCopy)[e];
+                    t.x = t.x + u.x;
+                    t.y = t.y + u.y;
+                    t.z = t.z + u.z;
+                    t.w = t.w + u.w;
+                }
+                ps[e] = t;
+            }
+            uint32_t *pc = acc_counts + ((size_t)chunk * n_sub + vv) * k_real;
+            for (uint32_t e = lane; e < k_real; e += 64) pc[e] = cnts[e];
+        }
+    };
+    if (st0 >= st1) {
+        write_partial();  // an empty chunk still owns a (zero) slab
         if (lane == 0) seg_hdr[0] = 0u, seg_hdr[1] = 0u;
         return;
     }
@@ -827,7 +863,7 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     // accumulator's initial value for them (4 ds_read_b128 and a wait per tile; every instruction of a lone wave costs
     // an issue slot of ~5 cycles, profiles/ubench/valu_issue.hip).  (C and D of an MFMA share their register class, so
     // the 64 spare AGPRs cannot hold the other tiles' images.)  Two waves per SIMD (sub_dim 8): LDS for all tiles.
-    constexpr int kCnV = x32_two_waves(SD, NT32) ? 0 : 6;
+    constexpr int kCnV = x32_two_waves(SD, NT32) ? 0 : (ACC ? 4 : 6);
     f32x16 cnr[kCnV > 0 ? kCnV : 1];
 #pragma unroll
     for (int i = 0; i < kCnV; ++i) init_acc(cnr[i], i);
@@ -921,10 +957,89 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
         o1 = tb ? b1 : a1;
         os = tb ? bs : as;
     };
-    // tail of a finished step in 4 pieces (the X32 kernel's tail, same order of operations)
     float t_m1 = 0.0f, t_m2 = 0.0f, t_xs = 0.0f;
     uint32_t t_j = 0;
     bool t_proven = false;
+    // Fused update of the rows a tail has just proven, spread over the step the tail runs in: the row's own values are
+    // RE-READ (they were consumed two steps ago; an L2 hit, issued in gap 0), the ticket (count before + returning add
+    // on the cluster's counter) is taken at the end of the tail, the accumulator rows are read in phase 6 and written
+    // back in phase 7 -- each LDS round trip hides behind the gaps in between.
+    bool pend_mine = false;
+    uint32_t pend_j = 0, pend_before = 0, pend_seq = 0, pend_rank = 0xFFFFFFFFu;
+    float pend_x[ACC ? DPH : 1];
+    float4 pend_t[ACC ? DPH / 4 : 1];
+    float4 *pend_slot = nullptr;
+    auto acc_reload = [&](uint32_t tst) {  // the rows of step tst, as loaded (the screen worked on x - mu)
+        if constexpr (ACC) {
+            uint32_t row = tst * 32 + p;
+            row = row < n32 ? row : n32 - 1;
+            const float *ptr = reinterpret_cast<const float *>(x_base + (uint64_t)row * x_pitch);
+#pragma unroll
+            for (int q = 0; q < DPH; q += 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(ptr + q);
+                pend_x[q + 0] = t.x;
+                pend_x[q + 1] = t.y;
+                pend_x[q + 2] = t.z;
+                pend_x[q + 3] = t.w;
+            }
+        }
+    };
+    auto acc_ticket = [&](bool mine) {
+        if constexpr (ACC) {
+            pend_mine = mine;  // both lane halves of the row agree
+            pend_j = t_j;
+            if (pend_mine && h == 0) {
+                pend_before = cnts[pend_j];              // every lane reads before any lane adds (one wave, in order)
+                pend_seq = atomicAdd(&cnts[pend_j], 1u);  // ds_add_rtn_u32: the rows of one cluster get before, before + 1, ...
+            }
+        }
+    };
+    auto acc_issue = [&]() {
+        if constexpr (ACC) {
+            uint32_t rank = (pend_mine && h == 0) ? pend_seq - pend_before : 0xFFFFFFFFu;
+            rank = __builtin_amdgcn_permlane32_swap(rank, rank, false, false)[0];  // the row's other half takes the same turn
+            pend_rank = rank;
+            const uint32_t copy = (R == 2 && rank == 1u) ? kCopy : 0u;
+            pend_slot = reinterpret_cast<float4 *>(sums + copy + (size_t)(pend_mine ? pend_j : 0u) * SD + DPH * h);
+            if (rank < R) {
+#pragma unroll
+                for (int q = 0; q < DPH / 4; ++q) pend_t[q] = pend_slot[q];
+            }
+        }
+    };
+    auto acc_commit = [&]() {
+        if constexpr (ACC) {
+            if (pend_rank < R) {
+#pragma unroll
+                for (int q = 0; q < DPH / 4; ++q) {
+                    float4 t = pend_t[q];
+                    t.x = t.x + pend_x[4 * q + 0];
+                    t.y = t.y + pend_x[4 * q + 1];
+                    t.z = t.z + pend_x[4 * q + 2];
+                    t.w = t.w + pend_x[4 * q + 3];
+                    pend_slot[q] = t;
+                }
+            }
+            for (uint32_t r = R;; ++r) {  // three or more rows of one cluster in a step take turns
+                if (!__any(pend_rank != 0xFFFFFFFFu && pend_rank >= r)) break;
+                if (pend_rank == r) {
+#pragma unroll
+                    for (int q = 0; q < DPH / 4; ++q) {
+                        float4 t = pend_slot[q];
+                        t.x = t.x + pend_x[4 * q + 0];
+                        t.y = t.y + pend_x[4 * q + 1];
+                        t.z = t.z + pend_x[4 * q + 2];
+                        t.w = t.w + pend_x[4 * q + 3];
+                        pend_slot[q] = t;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            pend_mine = false;
+            pend_rank = 0xFFFFFFFFu;
+        }
+    };
+    // tail of a finished step in 4 pieces (the X32 kernel's tail, same order of operations)
     auto tail_piece = [&](int k, int tp, uint32_t tst, bool in_loop) {
         if (k == 0) {
             float u1, u2, us, w1, w2, ws, ms;
@@ -977,6 +1092,7 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
                 }
                 seg_count += (uint32_t)__popcll(mask);
             }
+            acc_ticket(t_proven && valid && (row < n32));
         }
     };
 
@@ -1026,16 +1142,19 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
                         if (f == 4) reduce_hg(acc[i & 3], i, 3, par);
                         if (f == 2 || f == 5) {
                             const int slot = 2 * i + (f == 5);  // 0..15
-                            if (slot == 0) split_piece(0, par ^ 1, st + 3);
+                            if (slot == 0) acc_reload(st - 1), split_piece(0, par ^ 1, st + 3);
                             else if (slot <= 4) tail_piece(slot - 1, par ^ 1, st - 1, true);
                             else if (slot <= 10) split_piece(slot - 4, par ^ 1, st + 3);      // 2 splits, packs 0..3
                             else if (slot == 11) split_piece(7, par ^ 1, st + 3), split_piece(8, par ^ 1, st + 3);
+                            else if (slot == 12) acc_issue();
+                            else if (slot == 14) acc_commit();
                         }
                     } else {  // NMF == 3: one filler gap per phase
                         if (f == 0) reduce_hg(acc[i & 3], i, 0, par), reduce_hg(acc[i & 3], i, 1, par);
                         if (f == 1) reduce_hg(acc[i & 3], i, 2, par), reduce_hg(acc[i & 3], i, 3, par);
                         if (f == 2) {
                             if (i == 0) {
+                                acc_reload(st - 1);
                                 split_piece(0, par ^ 1, st + 3);
                                 tail_piece(0, par ^ 1, st - 1, true), tail_piece(1, par ^ 1, st - 1, true);
                             } else if (i == 1) {
@@ -1043,6 +1162,10 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
                                 split_piece(1, par ^ 1, st + 3);
                             } else if (i < kSplitPieces) {
                                 split_piece(i, par ^ 1, st + 3);
+                            } else if (i == 6) {
+                                acc_issue();
+                            } else if (i == 7) {
+                                acc_commit();
                             }
                         }
                     }
@@ -1055,8 +1178,12 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     }
     {
         const uint32_t last = st0 + ((nst + 1) & ~1u) - 1;  // parity 1
+        acc_reload(last);
 #pragma unroll
         for (int k = 0; k < 4; ++k) tail_piece(k, 1, last, false);
+        acc_issue();
+        acc_commit();
+        write_partial();
     }
     if (lane == 0) seg_hdr[0] = seg_first, seg_hdr[1] = seg_count;
 }
@@ -1341,7 +1468,8 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
         }
     }
     bool piped = false;
-    if constexpr (G == 1 && PVW == 0 && !ACC && NT32 == 8 && (SD == 8 || SD == 16)) {
+    // (fused update at sub_dim 8: two waves per SIMD leave the pipelined variant short of registers -- X32 kernel)
+    if constexpr (G == 1 && PVW == 0 && NT32 == 8 && (SD == 16 || (SD == 8 && !ACC))) {
         // chunks of at least kPipeMinSteps steps: the software-pipelined variant (same results; one drain iteration)
         static const bool pipe_on = [] {
             const char *e = std::getenv("VQHIP_SCREEN_PIPE");
@@ -1350,10 +1478,18 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
         const uint64_t steps_per_chunk = (n_steps + n_chunks - 1) / n_chunks;
         if (pipe_on && steps_per_chunk >= kPipeMinSteps && a.n < 0xFFFFFFC0ull) {
             piped = true;
-            hipLaunchKernelGGL((k_assign_screen_bf16_x32p<SD, NT32>), dim3(blocks), dim3(kBlock), 0, stream, a.X, a.n, a.d, cb.m,
-                               cb.prepA32, cb.cn32, NT32 * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows, a.wl_seg,
+            if constexpr (ACC) {
+                static PerDeviceOnce attr_set_p;
+                if (attr_set_p.needed()) {
+                    VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign_screen_bf16_x32p<SD, NT32, ACC>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+                    attr_set_p.done();
+                }
+            }
+            hipLaunchKernelGGL((k_assign_screen_bf16_x32p<SD, NT32, ACC>), dim3(blocks), dim3(kBlock), dyn_lds, stream, a.X, a.n, a.d,
+                               cb.m, cb.prepA32, cb.cn32, NT32 * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows, a.wl_seg,
                                n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen, a.gate_active,
-                               a.gate_halt, a.codes_t, a.codes_t_pitch);
+                               a.gate_halt, a.codes_t, a.codes_t_pitch, ACC ? a.acc_sums : nullptr, ACC ? a.acc_counts : nullptr);
         }
     }
     if (!piped)
