@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 # BASELINE.md section 3 / SURVEY.md section 8(d)
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 N_PER_GPU, DIM, M, K = 1_000_000, 128, 8, 256
 DATA_SEED, TRAIN_ITERS = 66, 4
@@ -547,7 +548,11 @@ def measure(args, ranks, wl_name, scaling, *, torch, _lib, engine, ncomm, collec
     kern_ms = ranks.reduce(primary_ms / max(calls, 1), "max")
     step_ms = dt / steps * 1e3
     sd = dim // m_
-    kernel_name = {2: f"k_assign_screen<{sd},16>", 3: f"k_assign_screen_bf16_x32<{sd},8,1,0,false>"}.get(used_engine, "k_assign_exact")
+    # the software-pipelined variant serves 8 tiles (k in 225..256) at sub_dim 8 / 16 when a wave's row chunk has >= 8 steps
+    piped = (sd in (8, 16) and 224 < k_ <= 256 and os.environ.get("VQHIP_SCREEN_PIPE", "1")[:1] != "0" and n >= 64 * 1024)
+    kernel_name = {2: f"k_assign_screen<{sd},16>",
+                   3: (f"k_assign_screen_bf16_x32p<{sd},8,false>" if piped else f"k_assign_screen_bf16_x32<{sd},8,1,0,false>")
+                   }.get(used_engine, "k_assign_exact")
     out.update({
         "encode_vectors_per_s": n_global * steps / dt, "encode_ms_per_step": step_ms,
         "encode_engine": {1: "exact", 2: "fp32_mfma_screen+exact_recheck", 3: "bf16x3_mfma_screen+exact_recheck"}.get(used_engine, str(used_engine)),
@@ -555,6 +560,8 @@ def measure(args, ranks, wl_name, scaling, *, torch, _lib, engine, ncomm, collec
         "encode_roofline": mfma_roofline(flop_row * n, kern_ms, kernel=kernel_name, extra={
             "step_frac": flop_row * n / (step_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "recheck_avg_launch_ms": recheck_ms / max(calls, 1), "flop_per_launch": flop_row * n,
+            # the contraction itself runs on the bf16 pipe: 6 bf16 products per algorithmic fp32 product
+            "frac_of_bf16_dense_peak": 6.0 * flop_row * n / (kern_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS if kern_ms > 0 else 0.0,
             "algorithmic_bytes_per_launch": (4.0 * dim + m_) * n}),
         "codes_checksum_rank0": int(codes.to(torch.int64).sum().item()),
     })
@@ -738,7 +745,8 @@ def worker(args) -> int:
         roof.update({
             "note": "achieved = algorithmic 2*k*D flop per row / device time of the screen kernel (HIP events on the "
                     "launch stream, max over ranks); with the bf16-split engine the contraction runs as 6 bf16 products per fp32 "
-                    "product on the bf16 matrix pipe and the kernel is VALU-bound (epilogue), see DESIGN.md 4.1; "
+                    "product on the bf16 matrix pipe (frac_of_bf16_dense_peak; frac is against the fp32-MFMA figure the north star names and "
+                    "may exceed 1) and the kernel is instruction-issue-bound (epilogue), see DESIGN.md 4.1; "
                     "step_frac = the same work over the whole driver-timed step (screen + exact re-check)",
             "traffic": traffic, "traffic_source": traffic_src})
         line = {

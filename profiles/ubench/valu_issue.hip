@@ -20,7 +20,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define REP16(x) REP4(REP4(x))
 
 template <int T>
-__global__ __launch_bounds__(256) void k(unsigned long long* out, float* sink, int iters) {
+__global__ __launch_bounds__(512) void k(unsigned long long* out, float* sink, int iters) {
     extern __shared__ float pad[];
     float v0 = threadIdx.x, v1 = 1.f, v2 = 2.f, v3 = 3.f, v4 = 4.f, v5 = 5.f, v6 = 6.f, v7 = 7.f, v8 = 8.f, v9 = 9.f, v10 = 10.f, v11 = 11.f;
     float q10 = 1e30f, q11 = 1e30f, q12 = 1e30f, q13 = 1e30f, q20 = 1e30f, q21 = 1e30f, q22 = 1e30f, q23 = 1e30f;
@@ -82,6 +82,25 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, float* sink, i
                                : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3) : "v"(v4), "v"(v5), "v"(v6));)
         } else if constexpr (T == 10) {  // MFMA alone, one chain
             REP16(asm volatile(MF : [acc] "+v"(acc) : [am] "v"(am), [bm] "v"(bm));)
+        } else if constexpr (T == 12) {  // min3, 16 rotating destinations, sources rotate too
+            REP4(asm volatile("v_min3_f32 v0, v16, v17, v18\n v_min3_f32 v1, v17, v18, v19\n v_min3_f32 v2, v18, v19, v20\n v_min3_f32 v3, v19, v20, v21\n"
+                              "v_min3_f32 v4, v20, v21, v22\n v_min3_f32 v5, v21, v22, v23\n v_min3_f32 v6, v22, v23, v24\n v_min3_f32 v7, v23, v24, v25\n"
+                              "v_min3_f32 v8, v24, v25, v26\n v_min3_f32 v9, v25, v26, v27\n v_min3_f32 v10, v26, v27, v28\n v_min3_f32 v11, v27, v28, v29\n"
+                              "v_min3_f32 v12, v28, v29, v30\n v_min3_f32 v13, v29, v30, v31\n v_min3_f32 v14, v30, v31, v16\n v_min3_f32 v15, v31, v16, v17"
+                              ::: "v0","v1","v2","v3","v4","v5","v6","v7","v8","v9","v10","v11","v12","v13","v14","v15");)
+        } else if constexpr (T == 13) {  // alternate VOP3 (min3) and VOP2 e32 (min), 4 dests
+            REP16(asm volatile("v_min3_f32 %0, %4, %5, %6\n v_min_f32 %1, %4, %5\n v_min3_f32 %2, %4, %5, %6\n v_min_f32 %3, %4, %5"
+                               : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3) : "v"(v4), "v"(v5), "v"(v6));)
+        } else if constexpr (T == 14) {  // s_nop 0 only
+            REP16(asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");)
+        } else if constexpr (T == 15) {  // salu only
+            REP16(asm volatile("s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1" ::: "s20", "s21", "s22", "s23");)
+        } else if constexpr (T == 16) {  // min3 with 2 waves per SIMD (launched with 512 threads)
+            REP16(asm volatile("v_min3_f32 %0, %4, %5, %6\n v_min3_f32 %1, %4, %5, %6\n v_min3_f32 %2, %4, %5, %6\n v_min3_f32 %3, %4, %5, %6"
+                               : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3) : "v"(v4), "v"(v5), "v"(v6));)
+        } else if constexpr (T == 17) {  // ds_read_b128 from a fixed address, no wait in the loop
+            REP16(asm volatile("ds_read_b128 v[16:19], %0\n ds_read_b128 v[20:23], %0\n ds_read_b128 v[24:27], %0\n ds_read_b128 v[28:31], %0" :: "v"(0) : "v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31");)
+            asm volatile("s_waitcnt lgkmcnt(0)");
         } else if constexpr (T == 11) {  // v_min_f32 (VOP2) independent
             REP16(asm volatile("v_min_f32 %0, %4, %5\n v_min_f32 %1, %4, %5\n v_min_f32 %2, %4, %5\n v_min_f32 %3, %4, %5"
                                : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3) : "v"(v4), "v"(v5));)
@@ -90,30 +109,30 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, float* sink, i
     const unsigned long long c1 = clock64();
     float s = v0 + v1 + v2 + v3 + q10 + q11 + q12 + q13 + q20 + q21 + q22 + q23 + acc[0] + acc[5];
     if (s == 1234.5f) sink[0] = s + v7 + v8 + v9 + v10 + v11 + pad[0];
-    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = c1 - c0;
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 256) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = c1 - c0;
 }
 
 template <int T>
-void run(const char* name, int instr_per_iter, int mfma_per_iter) {
+void run(const char* name, int instr_per_iter, int mfma_per_iter, int threads = 256) {
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int grid = p.multiProcessorCount, iters = 2000;
     unsigned long long* out;
     float* sink;
-    hipMalloc(&out, grid * 4 * 8);
+    hipMalloc(&out, grid * 8 * 8);
     hipMalloc(&sink, 4);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    k<T><<<grid, 256, 100 * 1024>>>(out, sink, 10);
+    k<T><<<grid, threads, 100 * 1024>>>(out, sink, 10);
     hipEventRecord(e0);
-    k<T><<<grid, 256, 100 * 1024>>>(out, sink, iters);
+    k<T><<<grid, threads, 100 * 1024>>>(out, sink, iters);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> h(grid * 4);
+    std::vector<unsigned long long> h(grid * 4);  // first 4 waves of each block
     hipMemcpy(h.data(), out, grid * 4 * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     const double med = (double)h[h.size() / 2];
@@ -124,6 +143,7 @@ void run(const char* name, int instr_per_iter, int mfma_per_iter) {
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     run<0>("T0 min3 independent", 64, 0);
     run<1>("T1 min3 dependent chain", 64, 0);
     run<2>("T2 epilogue, compiler order", 80, 0);
@@ -136,5 +156,11 @@ int main() {
     run<9>("T9 med3 independent", 64, 0);
     run<10>("T10 mfma chain alone (per mfma)", 16, 16);
     run<11>("T11 v_min_f32 independent", 64, 0);
+    run<12>("T12 min3, 16 dests, rotating sources", 64, 0);
+    run<13>("T13 alternate min3 / min e32", 64, 0);
+    run<14>("T14 s_nop 0", 64, 0);
+    run<15>("T15 s_add_u32", 64, 0);
+    run<16>("T16 min3 independent, TWO waves per SIMD", 64, 0, 512);
+    run<17>("T17 ds_read_b128 (+1 wait per 64)", 64, 0);
     return 0;
 }
