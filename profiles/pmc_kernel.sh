@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmck_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --no-cpu-baseline --no-configs --steps 20 --warmup 2 $*"
+BENCH="python3 $REPO/bench.py --no-cpu-baseline --no-configs ${*:---steps 20 --warmup 2}"
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
@@ -19,13 +19,14 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_W
   rocprofv3 --pmc $grp --output-format csv -d "$OUT/g$i" -o pmc -- $BENCH > "$OUT/g$i.json" 2> "$OUT/g$i.err" || echo "group $i failed" >> "$OUT/errors.txt"
 done
 python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections, json
+import csv, glob, sys, collections, json, re
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
-        if "screen_bf16" not in k: continue
+        m = re.search(r"(k_[A-Za-z_0-9]+)(<[^>]*>)?", r["Kernel_Name"])
+        if not m or "screen_bf16" not in m.group(1): continue
+        k = m.group(1) + (m.group(2) or "").replace(" ", "")
         a = acc[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 res = {}
 for k, cs in acc.items():

@@ -834,8 +834,10 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     const uint32_t code_stride = codes_t ? 1u : m;
     // rows in flight, TWO steps deep (1024 waves x 2 KB per step in flight is ~2 MB, what 1.1 TB/s needs at ~2 us of
     // latency; one step deep the wave waited 19 % of its time): at the top of step st, xn_[par ^ 1] holds step st + 1
-    // (about to be consumed, then reloaded with st + 3) and xn_[par] step st + 2
-    float xn_[2][DPH];
+    // (about to be consumed, then reloaded with st + 1 + kDeep) and xn_[par] step st + 2
+    // (two waves per SIMD: one step deep -- the partner wave covers the latency and the registers are short)
+    constexpr int kDeep = x32_two_waves(SD, NT32) ? 1 : 2;
+    float xn_[kDeep][DPH];
     auto load_x = [&](uint32_t row, int buf) {
         row = row < n32 ? row : n32 - 1;
         const float *ptr = reinterpret_cast<const float *>(x_base + (uint64_t)row * x_pitch);
@@ -872,7 +874,10 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(accv) : "a"(a[ti][f]), "v"(bv), "v"(cnr[ti]));
             return;
         }
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv) : "a"(a[ti][f]), "v"(bv));
+        // two waves per SIMD: a kernel that names AGPRs gets the register file split 128 : 128, and this one needs ~165
+        // VGPRs next to the 96 of the A image -- all of it in VGPRs (256) instead of spilling through v_accvgpr moves
+        if constexpr (x32_two_waves(SD, NT32)) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv) : "v"(a[ti][f]), "v"(bv));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv) : "a"(a[ti][f]), "v"(bv));
     };
 
     bf16x8 b[2][NMF];
@@ -890,11 +895,11 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
         if (k == 0) {
 #pragma unroll
             for (int q = 0; q < DPH; ++q) {
-                xc[q] = xn_[nb][q] - mu[q];
+                xc[q] = xn_[nb % kDeep][q] - mu[q];
                 asm volatile("" ::"v"(xc[q]));  // consumed HERE (see reduce_hg), the registers are free for the next load
             }
             xsN = 0.0f;
-            load_x(next_step * 32 + p, nb);
+            load_x(next_step * 32 + p, nb % kDeep);
         } else if (k <= DPH / 4) {
 #pragma unroll
             for (int q = 4 * (k - 1); q < 4 * k; ++q) {
@@ -1098,9 +1103,9 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
 
     // ---- prologue: operands of step st0, its first two MFMA chains, the rows of st0 + 1 on their way ----
     load_x(st0 * 32 + p, 0);
-    load_x((st0 + 1) * 32 + p, 1);
+    if (kDeep == 2) load_x((st0 + 1) * 32 + p, 1);
 #pragma unroll
-    for (int k = 0; k < kSplitPieces; ++k) split_piece(k, 0, st0 + 2);  // buffer 0: step st0 now, st0 + 2 next
+    for (int k = 0; k < kSplitPieces; ++k) split_piece(k, 0, st0 + kDeep);  // buffer 0: step st0 now, st0 + kDeep next
     xsM = xsN;
 #pragma unroll
     for (int r = 0; r < 4; ++r) q1[0][r] = q2[0][r] = snap[0][r] = q1[1][r] = q2[1][r] = snap[1][r] = pinf;
@@ -1142,10 +1147,10 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
                         if (f == 4) reduce_hg(acc[i & 3], i, 3, par);
                         if (f == 2 || f == 5) {
                             const int slot = 2 * i + (f == 5);  // 0..15
-                            if (slot == 0) acc_reload(st - 1), split_piece(0, par ^ 1, st + 3);
+                            if (slot == 0) acc_reload(st - 1), split_piece(0, par ^ 1, st + 1 + kDeep);
                             else if (slot <= 4) tail_piece(slot - 1, par ^ 1, st - 1, true);
-                            else if (slot <= 10) split_piece(slot - 4, par ^ 1, st + 3);      // 2 splits, packs 0..3
-                            else if (slot == 11) split_piece(7, par ^ 1, st + 3), split_piece(8, par ^ 1, st + 3);
+                            else if (slot <= 10) split_piece(slot - 4, par ^ 1, st + 1 + kDeep);      // 2 splits, packs 0..3
+                            else if (slot == 11) split_piece(7, par ^ 1, st + 1 + kDeep), split_piece(8, par ^ 1, st + 1 + kDeep);
                             else if (slot == 12) acc_issue();
                             else if (slot == 14) acc_commit();
                         }
@@ -1155,13 +1160,13 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
                         if (f == 2) {
                             if (i == 0) {
                                 acc_reload(st - 1);
-                                split_piece(0, par ^ 1, st + 3);
+                                split_piece(0, par ^ 1, st + 1 + kDeep);
                                 tail_piece(0, par ^ 1, st - 1, true), tail_piece(1, par ^ 1, st - 1, true);
                             } else if (i == 1) {
                                 tail_piece(2, par ^ 1, st - 1, true), tail_piece(3, par ^ 1, st - 1, true);
-                                split_piece(1, par ^ 1, st + 3);
+                                split_piece(1, par ^ 1, st + 1 + kDeep);
                             } else if (i < kSplitPieces) {
-                                split_piece(i, par ^ 1, st + 3);
+                                split_piece(i, par ^ 1, st + 1 + kDeep);
                             } else if (i == 6) {
                                 acc_issue();
                             } else if (i == 7) {
@@ -1468,8 +1473,7 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
         }
     }
     bool piped = false;
-    // (fused update at sub_dim 8: two waves per SIMD leave the pipelined variant short of registers -- X32 kernel)
-    if constexpr (G == 1 && PVW == 0 && NT32 == 8 && (SD == 16 || (SD == 8 && !ACC))) {
+    if constexpr (G == 1 && PVW == 0 && NT32 == 8 && (SD == 16 || SD == 8)) {
         // chunks of at least kPipeMinSteps steps: the software-pipelined variant (same results; one drain iteration)
         static const bool pipe_on = [] {
             const char *e = std::getenv("VQHIP_SCREEN_PIPE");
