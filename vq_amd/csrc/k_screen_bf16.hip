@@ -1005,15 +1005,23 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
             rank = __builtin_amdgcn_permlane32_swap(rank, rank, false, false)[0];  // the row's other half takes the same turn
             pend_rank = rank;
             const uint32_t copy = (R == 2 && rank == 1u) ? kCopy : 0u;
-            pend_slot = reinterpret_cast<float4 *>(sums + copy + (size_t)(pend_mine ? pend_j : 0u) * SD + DPH * h);
-            if (rank < R) {
+            pend_slot = reinterpret_cast<float4 *>(__builtin_assume_aligned(sums + copy + (size_t)(pend_mine ? pend_j : 0u) * SD + DPH * h, 16));
+            // read by every lane (a lane without a turn reads a valid record and drops it).  The reads are spelled as
+            // ds_read_b128: the compiler cannot see the 16-byte alignment of the loop-invariant base and emitted
+            // b96 + b32 pieces (twice the LDS instructions, 2.5x the bank-conflict cycles); acc_commit waits for them.
+            const uint32_t la = (uint32_t)(uintptr_t)pend_slot;
 #pragma unroll
-                for (int q = 0; q < DPH / 4; ++q) pend_t[q] = pend_slot[q];
+            for (int q = 0; q < DPH / 4; ++q) {
+                f32x4 v;
+                if (q == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(la));
+                else asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(v) : "v"(la));
+                pend_t[q] = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
     };
     auto acc_commit = [&]() {
         if constexpr (ACC) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // acc_issue's reads
             if (pend_rank < R) {
 #pragma unroll
                 for (int q = 0; q < DPH / 4; ++q) {
