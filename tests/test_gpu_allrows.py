@@ -222,6 +222,48 @@ def test_c2_clustered_rows_codes_and_lloyd_step(oracle):
     ds.close()
 
 
+def test_c2_normal_rows_codes_and_lloyd_step(oracle):
+    """Zero-mean rows (N(0,1), what real embeddings look like; the other all-rows PQ checks are Uniform[0,1) or a clustered
+    mixture): every assignment / count / centroid of a Lloyd step and every code of an encode pass, squared L2 and cosine
+    (cosine on zero-mean rows is the case where the best cosine of many rows is barely positive)."""
+    import torch
+
+    n, d, m, k = 1_000_000, 128, 8, 256
+    sd = d // m
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4242)
+    Xd = torch.randn((n, d), device="cuda", generator=g, dtype=torch.float32)
+    ds = _lib.Dataset.from_device(Xd.data_ptr(), n, d)
+    X = Xd.cpu().numpy()
+    km = _lib.KMeans(ds, m, k)
+    init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64)
+    km.init_from_rows(init)
+    for _ in range(2):
+        km.step()
+    c_in = km.get_centroids()
+    counts, changed = km.step()
+    assert _lib.last_assign_stats()[1] == _lib.ENGINE_MFMA_BF16
+    assign = km.get_assignments()
+    c_out = km.get_centroids()
+    km.close()
+    for s in range(m):
+        c1, a_ref, n_ref, ch_ref = oracle.lloyd_step(X[:, s * sd:(s + 1) * sd], c_in[s], threads=0)
+        assert int((assign[:, s].astype(np.uint32) != a_ref).sum()) == 0
+        np.testing.assert_array_equal(counts[s], n_ref)
+        assert bool(changed[s]) == ch_ref
+        err = np.max(np.abs(c_out[s] - c1) / np.maximum(1.0, np.abs(c1)))
+        assert err <= 1e-5, f"subspace {s}: centroid deviation {err:g}"
+    codes = torch.empty((n, m), dtype=torch.uint8, device="cuda")
+    for lib_metric, o_metric in ((_lib.SQUARED_EUCLIDEAN, O.SQUARED_EUCLIDEAN), (_lib.COSINE, O.COSINE)):
+        enc = _lib.PQEncoder(c_out, lib_metric)
+        enc.encode_device(Xd.data_ptr(), n, codes.data_ptr(), None)
+        _lib.synchronize()
+        want, _ = oracle.pq_encode(o_metric, X, c_out, want_f16=False, threads=0)
+        assert int((codes.cpu().numpy().astype(np.uint32) != want).sum()) == 0, lib_metric
+        enc.close()
+    ds.close()
+
+
 def test_c2_kmeans_run_10_iterations(oracle):
     """vqhip_kmeans_run (iterations queued back to back, decisions on the device) at C2 for 10 iterations from the
     bench's strided initial rows, against the oracle's Lloyd loop from the same rows (vector.rs:415-458): iteration
