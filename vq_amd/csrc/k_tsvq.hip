@@ -37,8 +37,8 @@ namespace vqhip {
 namespace {
 
 constexpr uint32_t kInactive = 0xFFFFFFFFu;
-constexpr uint32_t kCsBlock = 20;  // rows the consumer of the column-sum kernel stages per register block (5 x ds_read_b128)
-constexpr uint32_t kCsAhead = 6;   // tiles a loader wave keeps in flight in registers
+constexpr uint32_t kCsBlock = 12;  // rows the consumer of the column-sum kernel stages per register block (5 x ds_read_b128)
+constexpr uint32_t kCsAhead = 3;   // tiles a loader wave keeps in flight in registers
 
 // geometry of the plain column-sum kernel for DGT columns per workgroup (one consumer lane per column):
 // a loader wave covers 64 / DGT groups of 4 consecutive rows per step
@@ -102,7 +102,7 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
 //   * rows past the node's end are staged as +0.0: after the first real row the running sum is never -0.0 (MODE 0
 //     starts from +0.0; MODE 1 adds squares), so adding +0.0 changes no bit and every tile is whole.
 template <int MODE, uint32_t DGT>
-__global__ __launch_bounds__(1024) void k_seg_colsum(const float *__restrict__ X, uint32_t d,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_seg_colsum(const float *__restrict__ X, uint32_t d,
                                                      const uint32_t *__restrict__ perm,
                                                      const uint32_t *__restrict__ lvl_node,
                                                      const LevelInfo *__restrict__ lv, NodeArrays na) {
