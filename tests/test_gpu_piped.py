@@ -1,0 +1,85 @@
+"""The software-pipelined screen (k_assign_screen_bf16_x32p: 8 tiles, sub_dim 8 / 16, row chunks of >= 8 steps) on the
+cases the other suites only meet at 1M rows: row counts that are no multiple of 32 (a partial last step, clamped
+loads), chunks of odd and even step counts (the dummy step), NaN / inf rows, rows next to ties, all three screened
+metrics, codes through the transposing path (m >= 16) -- bit for bit against the oracle."""
+import numpy as np
+import pytest
+
+import oracle as O
+from vq_amd import _lib
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def _codebook(rng, m, k, sd, ties=True):
+    cb = rng.standard_normal((m, k, sd)).astype(F)
+    if ties:
+        for s in range(m):
+            for j in range(0, k - 1, 8):  # every eighth centroid has a twin 1 ulp away in one coordinate
+                cb[s, j + 1] = cb[s, j]
+                t = (j // 8) % sd
+                cb[s, j + 1, t] = np.nextafter(cb[s, j, t], F(9.0))
+    return cb
+
+
+def _rows(rng, n, cb):
+    m, k, sd = cb.shape
+    X = rng.standard_normal((n, m * sd)).astype(F)
+    near = rng.integers(0, n, n // 50)  # rows on top of a centroid (the twins make them undecidable for the screen)
+    for i in near:
+        for s in range(m):
+            X[i, s * sd:(s + 1) * sd] = cb[s, rng.integers(0, k)] + (1e-4 * rng.standard_normal(sd)).astype(F)
+    X[5, 3] = np.nan
+    X[n - 1, :] = np.inf          # the last row of a partial step
+    X[n - 2, 7] = -np.inf
+    X[n // 2, :] = 0.0            # |x| = 0: cosine's EPSILON rule
+    X[n // 3, :] = np.nan
+    return X
+
+
+@pytest.mark.parametrize("shape", [(40_007, 8, 256, 16), (33_000, 8, 250, 16), (70_003, 16, 256, 8), (70_001, 4, 225, 16)])
+@pytest.mark.parametrize("metric", [O.SQUARED_EUCLIDEAN, O.EUCLIDEAN, O.COSINE])
+def test_piped_encode_ragged_rows_bit_exact(oracle, shape, metric):
+    n, m, k, sd = shape
+    rng = np.random.default_rng(n + metric)
+    cb = _codebook(rng, m, k, sd)
+    X = _rows(rng, n, cb)
+    enc = _lib.PQEncoder(cb, metric)
+    codes, f16 = enc.encode(X)
+    rechecked, engine = _lib.last_assign_stats()
+    assert engine == _lib.ENGINE_MFMA_BF16 and rechecked > 0
+    want_c, want_f = oracle.pq_encode(metric, X, cb, threads=0)
+    np.testing.assert_array_equal(codes.astype(np.uint32), want_c)
+    same = (f16.view(np.uint16) == want_f) | (np.isnan(f16) & np.isnan(want_f.view(np.float16)))
+    assert same.all()
+    enc.close()
+
+
+@pytest.mark.parametrize("shape", [(40_007, 8, 256, 16), (70_003, 16, 256, 8)])
+def test_piped_lloyd_step_ragged_rows(oracle, shape):
+    """The fused update of the pipelined kernel on a ragged row count with special rows: assignments and counts exact,
+    centroids within the summation tolerance."""
+    n, m, k, sd = shape
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, m * sd)).astype(F)
+    X[n - 1, :] = 1e4   # a far row in the partial last step
+    ds = _lib.Dataset.from_host(X)
+    km = _lib.KMeans(ds, m, k)
+    init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64)
+    km.init_from_rows(init)
+    km.step()
+    c_in = km.get_centroids()
+    counts, changed = km.step()
+    assert _lib.last_assign_stats()[1] == _lib.ENGINE_MFMA_BF16
+    assign = km.get_assignments()
+    c_out = km.get_centroids()
+    for s in range(m):
+        c1, a_ref, n_ref, ch_ref = oracle.lloyd_step(X[:, s * sd:(s + 1) * sd], c_in[s], threads=0)
+        assert int((assign[:, s].astype(np.uint32) != a_ref).sum()) == 0
+        np.testing.assert_array_equal(counts[s], n_ref)
+        assert bool(changed[s]) == ch_ref
+        err = np.max(np.abs(c_out[s] - c1) / np.maximum(1.0, np.abs(c1)))
+        assert err <= 1e-5, f"subspace {s}: centroid deviation {err:g}"
+    km.close()
+    ds.close()
