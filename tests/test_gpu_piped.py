@@ -83,3 +83,47 @@ def test_piped_lloyd_step_ragged_rows(oracle, shape):
         assert err <= 1e-5, f"subspace {s}: centroid deviation {err:g}"
     km.close()
     ds.close()
+
+
+def _fuzz_cases():
+    import os
+
+    scale = int(os.environ.get("VQ_FUZZ_SCALE", "1"))
+    return list(range(12 * scale))
+
+
+@pytest.mark.parametrize("seed", _fuzz_cases())
+def test_piped_fuzz(oracle, seed):
+    """Randomised shapes inside the pipelined kernel's range (k in 225..256, sub_dim 8 / 16, row chunks of >= 8 steps):
+    row count, m, k, metric and data family drawn per seed; encode codes and f16 against the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    sd = int(rng.choice([8, 16]))
+    m = int(rng.choice([4, 8, 16])) if sd == 16 else int(rng.choice([8, 16, 32]))
+    k = int(rng.integers(225, 257))
+    waves = 1024 * (2 if sd == 8 else 1)                 # one wave per SIMD, two at sub_dim 8
+    n_min = 32 * 8 * max(1, waves // m) + 1              # >= 8 steps per row chunk
+    n = int(rng.integers(n_min, n_min + 30_000))
+    metric = int(rng.choice([O.SQUARED_EUCLIDEAN, O.EUCLIDEAN, O.COSINE]))
+    kind = rng.choice(["uniform", "normal", "lattice", "clustered", "offset"])
+    d = m * sd
+    if kind == "uniform":
+        X = rng.random((n, d), dtype=F)
+    elif kind == "normal":
+        X = rng.standard_normal((n, d)).astype(F)
+    elif kind == "lattice":
+        X = rng.integers(0, 3, (n, d)).astype(F)
+    elif kind == "clustered":
+        centers = rng.standard_normal((40, d)).astype(F) * 3
+        X = (centers[rng.integers(0, 40, n)] + 0.05 * rng.standard_normal((n, d))).astype(F)
+    else:
+        X = (rng.random((n, d), dtype=F) + F(1000.0)).astype(F)
+    cb = X[rng.choice(n, k, replace=False)].reshape(k, m, sd).transpose(1, 0, 2).copy()  # centroids = rows: exact hits and ties
+    cb += (1e-3 * rng.standard_normal(cb.shape)).astype(F) * (rng.random(cb.shape) < 0.5)
+    enc = _lib.PQEncoder(cb, metric)
+    codes, f16 = enc.encode(X)
+    assert _lib.last_assign_stats()[1] == _lib.ENGINE_MFMA_BF16
+    want_c, want_f = oracle.pq_encode(metric, X, cb, threads=0)
+    np.testing.assert_array_equal(codes.astype(np.uint32), want_c)
+    same = (f16.view(np.uint16) == want_f) | (np.isnan(f16) & np.isnan(want_f.view(np.float16)))
+    assert same.all()
+    enc.close()
