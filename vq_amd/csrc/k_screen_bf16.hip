@@ -972,7 +972,7 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     bool pend_mine = false;
     uint32_t pend_j = 0, pend_before = 0, pend_seq = 0, pend_rank = 0xFFFFFFFFu;
     float pend_x[ACC ? DPH : 1];
-    float4 pend_t[ACC ? DPH / 4 : 1];
+    f32x4 pend_t[ACC ? DPH / 4 : 1];
     float4 *pend_slot = nullptr;
     auto acc_reload = [&](uint32_t tst) {  // the rows of step tst, as loaded (the screen worked on x - mu)
         if constexpr (ACC) {
@@ -1006,31 +1006,24 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
             pend_rank = rank;
             const uint32_t copy = (R == 2 && rank == 1u) ? kCopy : 0u;
             pend_slot = reinterpret_cast<float4 *>(__builtin_assume_aligned(sums + copy + (size_t)(pend_mine ? pend_j : 0u) * SD + DPH * h, 16));
-            // read by every lane (a lane without a turn reads a valid record and drops it).  The reads are spelled as
-            // ds_read_b128: the compiler cannot see the 16-byte alignment of the loop-invariant base and emitted
-            // b96 + b32 pieces (twice the LDS instructions, 2.5x the bank-conflict cycles); acc_commit waits for them.
-            const uint32_t la = (uint32_t)(uintptr_t)pend_slot;
+            // read by every lane (a lane without a turn reads a valid record and drops it), as ext_vector loads: the
+            // float4 STRUCT loads came out of the compiler as ds_read_b96 + ds_read2_b32 + ds_read_b32 pieces (twice the LDS
+            // instructions, 2.5x the bank-conflict cycles)
 #pragma unroll
-            for (int q = 0; q < DPH / 4; ++q) {
-                f32x4 v;
-                if (q == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(la));
-                else asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(v) : "v"(la));
-                pend_t[q] = make_float4(v[0], v[1], v[2], v[3]);
-            }
+            for (int q = 0; q < DPH / 4; ++q) pend_t[q] = reinterpret_cast<const f32x4 *>(pend_slot)[q];
         }
     };
     auto acc_commit = [&]() {
         if constexpr (ACC) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // acc_issue's reads
             if (pend_rank < R) {
 #pragma unroll
                 for (int q = 0; q < DPH / 4; ++q) {
-                    float4 t = pend_t[q];
-                    t.x = t.x + pend_x[4 * q + 0];
-                    t.y = t.y + pend_x[4 * q + 1];
-                    t.z = t.z + pend_x[4 * q + 2];
-                    t.w = t.w + pend_x[4 * q + 3];
-                    pend_slot[q] = t;
+                    f32x4 t = pend_t[q];
+                    t[0] = t[0] + pend_x[4 * q + 0];
+                    t[1] = t[1] + pend_x[4 * q + 1];
+                    t[2] = t[2] + pend_x[4 * q + 2];
+                    t[3] = t[3] + pend_x[4 * q + 3];
+                    reinterpret_cast<f32x4 *>(pend_slot)[q] = t;
                 }
             }
             for (uint32_t r = R;; ++r) {  // three or more rows of one cluster in a step take turns
