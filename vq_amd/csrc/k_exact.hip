@@ -845,7 +845,7 @@ int dispatch_exact(const CodebookView &cb, const AssignArgs &a, bool wl, dim3 gr
             // register-resident sub-codebook; enough (segment, part) units for ~2 waves per SIMD.  The grouped
             // sub_dim-32 screen and the fp32 screen leave one list per subspace: n_seg = 1, many parts.
             const uint32_t kpl = cb.k <= 64 ? 1u : cb.k <= 128 ? 2u : 4u;
-            const uint32_t target = (uint32_t)num_cus() * 8;
+            const uint32_t target = (uint32_t)num_cus() * 16;
             const uint32_t nseg = seg ? a.n_seg : 1u;
             uint32_t parts = target / std::max(1u, nseg * a.n_sub);
             parts = std::max(parts, 1u);
