@@ -403,7 +403,7 @@ struct vqhip_kmeans {
     AssignWorkspace ws;
     UpdatePlan plan;
     DevBuf codes, partial_sums, partial_counts, slab, counts, changed, active_dev, rows_tmp, xs_ws, gather_ws;
-    DevBuf run_state;  // vqhip_kmeans_run: [0] halt flag, [1 .. m] iterations executed per subspace
+    DevBuf run_state;  // vqhip_kmeans_run: [0] halt flag, [1 .. m] iterations executed per subspace, [m+1], [m+2] k_finalize's own
     std::vector<uint8_t> active;
     bool all_active = true;
     int engine = VQHIP_ENGINE_AUTO;
@@ -1101,7 +1101,7 @@ int vqhip_kmeans_partials(vqhip_kmeans *km, void **dev_slab, uint64_t *n_doubles
 static int kmeans_finalize_enqueue(vqhip_kmeans *km, hipStream_t s, bool gated = false, bool read_back = true) {
     const uint32_t m = km->cs.m, k = km->cs.k;
     if (gated) {
-        uint32_t *rs = km->run_state.as<uint32_t>();  // [0] halt, [1..m] iterations, [m+1] finished-workgroup counter
+        uint32_t *rs = km->run_state.as<uint32_t>();  // [0] halt, [1..m] iterations, [m+1] finished-workgroup counter, [m+2] empty-cluster flag of the iteration
         VQ_TRY(launch_finalize_run(m, k, km->cs.sd, km->slab.as<double>(), km->active_dev.as<uint8_t>(), km->cs.cb.as<float>(),
                                    km->counts.as<uint32_t>(), km->changed.as<uint32_t>(), rs, rs + 1, rs + 1 + m, s));
     } else {
@@ -1298,8 +1298,8 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
         }
         return VQHIP_OK;
     }
-    VQ_TRY(km->run_state.ensure((size_t)(m + 2) * 4));
-    VQ_HIP(hipMemsetAsync(km->run_state.p, 0, (size_t)(m + 2) * 4, s));
+    VQ_TRY(km->run_state.ensure((size_t)(m + 3) * 4));
+    VQ_HIP(hipMemsetAsync(km->run_state.p, 0, (size_t)(m + 3) * 4, s));
     for (uint32_t it = 0; it < max_iters; ++it) {
         VQ_TRY(kmeans_accumulate_enqueue(km, s, true));
         // row-sharded: the one exchange of the iteration (a paused run re-sums a slab nobody reads: all ranks pause alike)
