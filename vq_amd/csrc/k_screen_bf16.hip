@@ -699,19 +699,21 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
 }
 
 // ---- variant X32P: the X32 kernel software-pipelined across steps -------------------------------------------
-// A lone wave issues in order: in the X32 kernel the operand split of a step (~100 VALU instructions) and its tail
-// (~70) run with the matrix pipe idle, and the 12 MFMAs of a step's first two tiles issue back to back with nothing
-// to hide behind (28 idle cycles each); the counters show the wave issuing VALU work 56 % of its time.  Here the
-// accumulator ring simply runs on across steps -- phase i of step st reduces tile i, issues the MFMA chain of tile
-// i + 2 (tiles 8 and 9 are tiles 0 and 1 of step st + 1) and starts the |c|^2 reads of tile i + 3 -- and the rest of
-// the work rides in the gaps between those MFMAs, one piece per gap:
-//     the operand split of step st + 1 (its rows were loaded a step ago; the load of step st + 2 is issued as soon
+// A lone wave pays an issue slot of ~5 cycles for EVERY instruction, VALU or not (profiles/ubench/valu_issue.hip), so
+// this kernel's time is its instruction count -- and in the X32 kernel the 12 MFMAs of a step's first two tiles issue
+// back to back with nothing between them, the operand split (~100 instructions) and the tail (~70) run with the matrix
+// pipe idle.  Here the accumulator ring simply runs on across steps -- phase i of step st reduces tile i, issues the
+// MFMA chain of tile i + 2 (tiles 8 and 9 are tiles 0 and 1 of step st + 1) and starts the |c|^2 reads of tile i + 3
+// (the tiles whose image is not kept in VGPRs) -- and the rest of the work rides in the gaps between those MFMAs, one
+// piece per gap:
+//     the operand split of step st + 1 (its rows were loaded two steps ago; the load of step st + 3 is issued as soon
 //     as they are consumed) and the tail of step st - 1 (merge of the chains and lane halves, margin test, code,
 //     work list), all within phases 0..5 -- the operands must be complete when phase 6 issues tile 0 of step st + 1.
-// Two operand sets and two sets of chains alternate (the loop body is unrolled twice).  The arithmetic, the index
-// tags and the order in which values enter a chain are those of the X32 kernel: codes, work lists and statistics
-// are the same bits.  One extra (drain) iteration runs the last tail; launch_one_x32 picks this variant for chunks
-// of at least kPipeMinSteps steps, 8 tiles (k in 225..256), sub_dim 8 or 16, one centroid group.
+// Two operand sets and two sets of chains alternate (the loop body is unrolled twice; a chunk of an odd number of
+// steps runs one dummy step whose rows are clamped and whose tail writes nothing).  The arithmetic, the index tags and
+// the order in which values enter a chain are those of the X32 kernel: codes, work lists and statistics are the same
+// bits.  launch_one_x32 picks this variant for chunks of at least kPipeMinSteps steps, 8 tiles (k in 225..256),
+// sub_dim 8 or 16, one centroid group.
 template <int SD, int NT32, bool ACC = false>
 __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_assign_screen_bf16_x32p(
     const float *__restrict__ X, uint64_t n, uint32_t d, uint32_t m, const uint32_t *__restrict__ prepA32,
@@ -1489,7 +1491,7 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
     }
     bool piped = false;
     if constexpr (G == 1 && PVW == 0 && NT32 == 8 && (SD == 16 || SD == 8)) {
-        // chunks of at least kPipeMinSteps steps: the software-pipelined variant (same results; one drain iteration)
+        // chunks of at least kPipeMinSteps steps: the software-pipelined variant (same results)
         static const bool pipe_on = [] {
             const char *e = std::getenv("VQHIP_SCREEN_PIPE");
             return !(e && e[0] == '0');
