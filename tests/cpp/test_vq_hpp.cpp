@@ -3,12 +3,15 @@
 //   test_vq_hpp validate            -- error variants and messages (no device needed)
 //   test_vq_hpp run <in> <out>      -- fit + quantize on the GPU, results to <out> for the
 //                                      Python mirror to compare (tests/test_cpp_host.py)
+//   test_vq_hpp threads <in> <out>  -- ONE ProductQuantizer and ONE TSVQ shared by eight std::threads through their
+//                                      const quantize(): the types are Send + Sync upstream (src/pq.rs:39-45)
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <fstream>
 #include <iostream>
+#include <thread>
 
 #include "vq.hpp"
 
@@ -156,14 +159,65 @@ static int run(const char *in_path, const char *out_path) {
     return failures ? 1 : 0;
 }
 
+// same <in> as run(); <out>: codebooks, node count, tree, then what the threads' quantize() calls returned, row by row
+static int threads(const char *in_path, const char *out_path) {
+    std::ifstream in(in_path, std::ios::binary);
+    std::uint64_t h[7];
+    in.read(reinterpret_cast<char *>(h), sizeof(h));
+    const std::size_t n = h[0], dim = h[1], m = h[2], k = h[3], iters = h[4], depth = h[6];
+    std::vector<float> X(n * dim);
+    in.read(reinterpret_cast<char *>(X.data()), X.size() * 4);
+    if (!in) return 2;
+    const vq::ProductQuantizer pq(X.data(), n, dim, m, k, iters, Distance::Euclidean, h[5]);
+    const vq::TSVQ tree(X.data(), n, dim, depth, Distance::SquaredEuclidean);
+    std::vector<vq::f16> got_pq(n * dim), got_tree(n * dim);
+    constexpr std::size_t kThreads = 8;
+    std::vector<std::thread> pool;
+    std::vector<std::string> errors(kThreads);
+    for (std::size_t t = 0; t < kThreads; ++t)
+        pool.emplace_back([&, t] {
+            try {
+                for (std::size_t i = t; i < n; i += kThreads) {  // interleaved: neighbours in time are different rows
+                    const auto a = pq.quantize(X.data() + i * dim, dim);
+                    std::copy(a.begin(), a.end(), got_pq.begin() + (std::ptrdiff_t)(i * dim));
+                    const auto b = tree.quantize(X.data() + i * dim, dim);
+                    std::copy(b.begin(), b.end(), got_tree.begin() + (std::ptrdiff_t)(i * dim));
+                }
+            } catch (const std::exception &e) {
+                errors[t] = e.what();
+            }
+        });
+    for (auto &th : pool) th.join();
+    for (const auto &e : errors) {
+        if (!e.empty()) std::printf("thread error: %s\n", e.c_str());
+        EXPECT(e.empty());
+    }
+    // the batch forms on this thread agree with what the threads saw
+    const auto all = pq.quantize_batch(X.data(), n);
+    EXPECT(std::equal(all.begin(), all.end(), got_pq.begin()));
+    std::ofstream out(out_path, std::ios::binary);
+    auto put = [&](const void *p, std::size_t bytes) { out.write(reinterpret_cast<const char *>(p), bytes); };
+    put(pq.codebooks().data(), pq.codebooks().size() * 4);
+    const std::uint64_t nodes = tree.num_nodes();
+    put(&nodes, 8);
+    put(tree.centroids().data(), tree.centroids().size() * 4);
+    put(tree.left().data(), nodes * 4);
+    put(tree.right().data(), nodes * 4);
+    put(got_pq.data(), got_pq.size() * 2);
+    put(got_tree.data(), got_tree.size() * 2);
+    std::printf(failures ? "THREADS_FAILED\n" : "THREADS_OK\n");
+    return failures ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
     try {
         if (argc >= 2 && std::string(argv[1]) == "validate") return validate();
         if (argc >= 4 && std::string(argv[1]) == "run") return run(argv[2], argv[3]);
+        if (argc >= 4 && std::string(argv[1]) == "threads") return threads(argv[2], argv[3]);
     } catch (const std::exception &e) {
         std::printf("EXCEPTION %s\n", e.what());
         return 3;
     }
-    std::printf("usage: test_vq_hpp validate | run <in> <out>\n");
+    std::printf("usage: test_vq_hpp validate | run <in> <out> | threads <in> <out>\n");
     return 64;
 }

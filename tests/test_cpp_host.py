@@ -19,7 +19,7 @@ def exe(tmp_path_factory):
     _lib.build_if_missing() if hasattr(_lib, "build_if_missing") else None
     out = tmp_path_factory.mktemp("cpp") / "test_vq_hpp"
     libdir = os.path.join(ROOT, "vq_amd")
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+    cmd = ["g++", "-std=c++17", "-O1", "-pthread", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
            os.path.join(ROOT, "tests", "cpp", "test_vq_hpp.cpp"), "-o", str(out), "-L", libdir, "-lvqhip",
            f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -73,3 +73,37 @@ def test_cpp_host_equals_python_mirror(exe, tmp_path):
     np.testing.assert_array_equal(take(np.int32, n), t.leaf_ids(X))
     np.testing.assert_array_equal(take(np.uint16, dim), t.quantize(X[1]).view(np.uint16))
     assert off == len(raw)
+
+
+@pytest.mark.gpu
+def test_cpp_const_quantize_from_eight_std_threads(exe, tmp_path, oracle):
+    """`const` methods of vq::ProductQuantizer / vq::TSVQ from eight std::threads on ONE object each (the crate's types are
+    Send + Sync, src/pq.rs:39-45, src/tsvq.rs:186-191): every per-vector result equals the oracle's for the codebooks /
+    tree the program trained"""
+    import oracle as O
+
+    n, dim, m, k, iters, seed, depth = 4000, 32, 4, 16, 4, 5, 5
+    X = np.random.default_rng(8).random((n, dim), dtype=F)
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<7Q", n, dim, m, k, iters, seed, depth))
+        f.write(X.tobytes())
+    r = subprocess.run([exe, "threads", str(inp), str(outp)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "THREADS_OK" in r.stdout, r.stdout + r.stderr
+    raw = open(outp, "rb").read()
+    off = 0
+
+    def take(dtype, count):
+        nonlocal off
+        a = np.frombuffer(raw, dtype=dtype, count=count, offset=off)
+        off += a.nbytes
+        return a
+
+    cb = take(F, m * k * (dim // m)).reshape(m, k, dim // m)
+    nodes = int(take(np.uint64, 1)[0])
+    tree = dict(centroids=take(F, nodes * dim).reshape(nodes, dim), left=take(np.int32, nodes), right=take(np.int32, nodes))
+    got_pq = take(np.uint16, n * dim).reshape(n, dim)
+    got_tree = take(np.uint16, n * dim).reshape(n, dim)
+    assert off == len(raw)
+    np.testing.assert_array_equal(got_pq, oracle.pq_encode(O.EUCLIDEAN, X, cb)[1])
+    np.testing.assert_array_equal(got_tree, oracle.tsvq_encode(O.SQUARED_EUCLIDEAN, X, tree)[1])

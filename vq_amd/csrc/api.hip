@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -181,6 +182,7 @@ struct AssignWorkspace {
     static constexpr uint32_t kSegCap = 4096;  // wave-private work-list segments per subspace
     uint32_t *seg_host = nullptr;               // pinned [m][kSegCap][2]
     uint32_t last_n_seg = 0;
+    bool last_segmented = false;  // the last screened pass filled list segments (wl_seg), not the per-subspace counters
     uint64_t wl_stride = 0;
     uint32_t wl_m = 0;
     std::vector<uint32_t> sub_host;
@@ -320,7 +322,7 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
     // forms [n][m] (k_screen_bf16.hip): at m = 96 the byte stores m apart were 1.46 GB of write traffic for 96 MB of codes
     static const char *ct_env = getenv("VQHIP_CODES_TRANSPOSE");  // =0: never, =1: whenever the shape allows (A/B)
     const bool ct_shape = engine == VQHIP_ENGINE_MFMA_BF16 && cs.x32_groups == 1 && x32_padded_sd(cs.sd) <= 64 && cs.k <= 256 &&
-                          cs.m % 4 == 0 && (size_t)256 * (cs.m + 4) + cs.m <= 60 * 1024 && (reinterpret_cast<uintptr_t>(codes) & 3) == 0;
+                          cs.m % 4 == 0 && (size_t)256 * codes_transpose_pitch(cs.m) + cs.m <= 60 * 1024 && (reinterpret_cast<uintptr_t>(codes) & 3) == 0;
     if (ct_shape && !(ct_env && ct_env[0] == '0') && (cs.m >= 16 || (ct_env && ct_env[0] == '1'))) {
         const uint64_t pitch = (n + 255) / 256 * 256;
         VQ_TRY(ws.codes_t.ensure((size_t)cs.m * pitch));
@@ -367,6 +369,7 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
         // the re-check counts stay on the device: vqhip_last_assign_stats fetches them when somebody asks (a copy queued
         // behind every pass was one of five stream operations of a 10k-row encode)
         ws.last_n_seg = a.n_seg;
+        ws.last_segmented = segmented;
         ws.stats_pending = true;
     } else {
         if (e0) VQ_HIP(hipEventRecord(e0, stream));
@@ -382,7 +385,105 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
     return VQHIP_OK;
 }
 
-static thread_local AssignWorkspace *g_last_ws = nullptr;
+// ----------------------------------------------------------- handles under threads ----
+// The reference's quantizers are plain data (src/pq.rs:39-45, src/tsvq.rs:186-191): `Send + Sync`, and
+// `quantize(&self)` may run on many threads at once.  Here a handle owns device workspaces and work is queued on the
+// CALLING thread's stream, so two things are needed for the same guarantee:
+//   * one recursive mutex per handle around every entry point that touches the handle's state (entry points call each
+//     other: vqhip_pq_encode -> _device, vqhip_kmeans_run -> _step -> _set_active);
+//   * stream order across threads: a call that returns with work still queued leaves a tail (its stream); the next
+//     call on ANOTHER stream first waits for that tail through an event.  The event is recorded when the other
+//     stream shows up if the tail is one of the library's own per-thread streams (never destroyed); for a caller's
+//     stream (vqhip_set_stream) it is recorded when the call leaves, because the caller may destroy that stream later.
+struct HandleSync {
+    std::recursive_mutex mu;
+    hipEvent_t ev = nullptr;
+    hipStream_t tail = nullptr;  // stream holding queued work of this handle (nullptr: the last call synchronised)
+    bool tail_lazy = false;      // the event for `tail` has not been recorded yet (library-owned stream)
+    int depth = 0;
+    ~HandleSync() {
+        if (ev) (void)hipEventDestroy(ev);
+    }
+    int event() {
+        if (!ev) VQ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        return VQHIP_OK;
+    }
+    // order stream s behind whatever this handle still has queued elsewhere
+    int order(hipStream_t s) {
+        if (tail && tail != s) {
+            VQ_TRY(event());
+            if (tail_lazy) VQ_HIP(hipEventRecord(ev, tail));
+            VQ_HIP(hipStreamWaitEvent(s, ev, 0));
+            tail = nullptr;
+        }
+        return VQHIP_OK;
+    }
+    void leave(hipStream_t s, bool synced) {
+        if (synced || !s) {
+            if (synced) tail = nullptr;
+            return;
+        }
+        tail = s;
+        tail_lazy = true;
+        if (tls().user_stream_set && tls().user_stream == s) {
+            if (event() == VQHIP_OK && hipEventRecord(ev, s) == hipSuccess) tail_lazy = false;
+        }
+    }
+};
+
+// RAII for one entry point: lock, order the calling thread's stream behind the handle's tail, and on the way out
+// note whether the call left work queued (the default) or synchronised its stream (`synced()`).
+class Entry {
+   public:
+    explicit Entry(HandleSync &h) : h_(&h) {
+        h_->mu.lock();
+        ++h_->depth;
+    }
+    ~Entry() { release(); }
+    Entry(const Entry &) = delete;
+    Entry &operator=(const Entry &) = delete;
+    int stream(hipStream_t *out) {
+        VQ_TRY(current_stream(&s_));
+        VQ_TRY(h_->order(s_));
+        *out = s_;
+        return VQHIP_OK;
+    }
+    void synced() { synced_ = true; }
+    // give the handle back before the call ends (the rest of the call touches nothing the handle owns mutably)
+    void release() {
+        if (!h_) return;
+        if (--h_->depth == 0) h_->leave(s_, synced_);
+        h_->mu.unlock();
+        h_ = nullptr;
+    }
+
+   private:
+    HandleSync *h_;
+    hipStream_t s_ = nullptr;
+    bool synced_ = false;
+};
+
+// vqhip_last_assign_stats names "the most recent pass of this thread" by workspace; the workspace may belong to a
+// handle another thread destroys, so the thread-local note is an id looked up in a registry of live workspaces.
+struct WsEntry {
+    AssignWorkspace *ws;
+    HandleSync *sync;
+};
+static std::mutex g_ws_mu;
+static std::map<uint64_t, WsEntry> g_ws_live;
+static std::atomic<uint64_t> g_ws_next{1};
+static thread_local uint64_t g_last_ws = 0;  // registry id, 0 = none
+
+static uint64_t ws_register(AssignWorkspace *ws, HandleSync *sync) {
+    const uint64_t id = g_ws_next.fetch_add(1);
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    g_ws_live[id] = WsEntry{ws, sync};
+    return id;
+}
+static void ws_unregister(uint64_t id) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    g_ws_live.erase(id);
+}
 
 
 }  // namespace vqhip
@@ -398,11 +499,14 @@ struct vqhip_dataset {
 };
 
 struct vqhip_kmeans {
+    HandleSync sync;
+    uint64_t ws_id = 0;
     const vqhip_dataset *ds = nullptr;
     CodebookState cs;
     AssignWorkspace ws;
     UpdatePlan plan;
     DevBuf codes, partial_sums, partial_counts, slab, counts, changed, active_dev, rows_tmp, xs_ws, gather_ws;
+    DevBuf agree;      // two words the ranks of a sharded run all-reduce before anything is queued
     DevBuf run_state;  // vqhip_kmeans_run: [0] halt flag, [1 .. m] iterations executed per subspace, [m+1], [m+2] k_finalize's own
     std::vector<uint8_t> active;
     bool all_active = true;
@@ -422,7 +526,9 @@ struct vqhip_kmeans {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         graph_exec = nullptr;
     }
+    vqhip_kmeans() { ws_id = ws_register(&ws, &sync); }
     ~vqhip_kmeans() {
+        ws_unregister(ws_id);
         drop_graph();
         if (counts_host) (void)hipHostFree(counts_host);
         if (changed_host) (void)hipHostFree(changed_host);
@@ -430,6 +536,7 @@ struct vqhip_kmeans {
 };
 
 struct vqhip_comm {
+    std::recursive_mutex mu;  // an ncclComm_t takes one enqueueing thread at a time
     Comm *c = nullptr;
 };
 
@@ -454,6 +561,51 @@ struct PinnedStage {
 };
 constexpr uint64_t kSmallRows = 8;  // calls with at most this many host rows take the one-kernel path
 
+// The per-vector path stages through a buffer that belongs to the CALL, not to the handle: `quantize(&self)` from many
+// threads on one quantizer then overlaps on the device (each thread its own stream and staging) instead of queueing on
+// the handle's lock.  Buffers are pooled per device and never returned to the runtime (64 KB each, as many as there
+// were concurrent calls); the pool itself is leaked on purpose -- static destructors run after the HIP runtime's.
+struct StagePool {
+    std::mutex mu;
+    std::vector<std::pair<int, PinnedStage *>> idle;
+};
+static StagePool &stage_pool() {
+    static StagePool *p = new StagePool();
+    return *p;
+}
+class StageLease {
+   public:
+    StageLease() = default;
+    StageLease(const StageLease &) = delete;
+    StageLease &operator=(const StageLease &) = delete;
+    ~StageLease() {
+        if (!st_) return;
+        std::lock_guard<std::mutex> lk(stage_pool().mu);
+        stage_pool().idle.emplace_back(dev_, st_);
+    }
+    int acquire(size_t need) {
+        VQ_HIP(hipGetDevice(&dev_));
+        {
+            StagePool &p = stage_pool();
+            std::lock_guard<std::mutex> lk(p.mu);
+            for (size_t i = 0; i < p.idle.size(); ++i)
+                if (p.idle[i].first == dev_) {
+                    st_ = p.idle[i].second;
+                    p.idle.erase(p.idle.begin() + (long)i);
+                    break;
+                }
+        }
+        if (!st_) st_ = new PinnedStage();
+        return st_->ensure(need);
+    }
+    char *host() const { return static_cast<char *>(st_->host); }
+    char *dev() const { return static_cast<char *>(st_->dev); }
+
+   private:
+    PinnedStage *st_ = nullptr;
+    int dev_ = 0;
+};
+
 // wait for a ~10-40 us kernel by polling: hipStreamSynchronize parks the thread after a short spin and
 // then costs ~100 us to wake up (measured 134 us per TSVQ quantize call against a 14 us kernel)
 static int spin_wait(hipStream_t s) {
@@ -467,20 +619,23 @@ static int spin_wait(hipStream_t s) {
 }
 
 struct vqhip_pq_encoder {
+    HandleSync sync;
+    uint64_t ws_id = 0;
+    vqhip_pq_encoder() { ws_id = ws_register(&ws, &sync); }
+    ~vqhip_pq_encoder() { ws_unregister(ws_id); }
     CodebookState cs;
     AssignWorkspace ws;
     int metric = VQHIP_EUCLIDEAN;
     int engine = VQHIP_ENGINE_AUTO;
     DevBuf xbuf, codes, f16buf, f32buf, adc_q, adc_lut, adc_dist, adc_idx, adc_out, adc_codes, adc_state, adc_cand;
-    PinnedStage stage;
     std::vector<uint32_t> all_subs;
 };
 
 struct vqhip_tsvq {
+    HandleSync sync;
     uint32_t n_nodes = 0, d = 0;
     int metric = VQHIP_EUCLIDEAN;
     DevBuf centroids, cnorm, left, right, xbuf, leafbuf, f16buf, table16;
-    PinnedStage stage;
     // screened descent (k_tsvq_screen.hip); use_screen = false -> exact walk only
     bool use_screen = false, last_screened = false;
     TsvqScreen scr;
@@ -747,29 +902,42 @@ int vqhip_synchronize(void) {
 }
 
 int vqhip_last_assign_stats(uint64_t *rechecked, int *engine) {
+    VQ_API_BEGIN
     ThreadState &st = tls();
     if (engine) *engine = st.last_engine;
     if (rechecked) {
         *rechecked = 0;
-        AssignWorkspace *ws = g_last_ws;
-        if (ws && ws->stats_pending) {
+        if (!g_last_ws) return VQHIP_OK;
+        // the registry lock is held for the whole query: the workspace cannot be destroyed under it (its handle's
+        // destructor unregisters first); lock order registry -> handle, and no entry point takes them the other way
+        std::lock_guard<std::mutex> reg(g_ws_mu);
+        auto it = g_ws_live.find(g_last_ws);
+        if (it == g_ws_live.end()) return VQHIP_OK;  // the handle is gone
+        AssignWorkspace *ws = it->second.ws;
+        Entry in(*it->second.sync);
+        if (ws->stats_pending) {
+            // the copy is ordered behind the pass whatever stream that ran on (Entry::stream waits for the handle's
+            // tail); a handle that several threads use reports its most recent pass, whoever queued it
             hipStream_t s;
-            VQ_TRY(current_stream(&s));
-            if (ws->last_n_seg > 0)
-                VQ_HIP(hipMemcpyAsync(ws->seg_host, ws->wl_seg.p, (size_t)ws->stats_m * ws->last_n_seg * 8, hipMemcpyDeviceToHost, s));
-            else
-                VQ_HIP(hipMemcpyAsync(ws->stats_host, ws->wl_count.p, (size_t)ws->stats_m * 4, hipMemcpyDeviceToHost, s));
-            VQ_HIP(hipStreamSynchronize(s));
+            VQ_TRY(in.stream(&s));
             uint64_t tot = 0;
-            if (ws->last_n_seg > 0) {
-                for (size_t i = 0; i < (size_t)ws->stats_m * ws->last_n_seg; ++i) tot += ws->seg_host[2 * i + 1];
+            if (ws->last_segmented) {
+                if (ws->last_n_seg > 0) {
+                    VQ_HIP(hipMemcpyAsync(ws->seg_host, ws->wl_seg.p, (size_t)ws->stats_m * ws->last_n_seg * 8, hipMemcpyDeviceToHost, s));
+                    VQ_HIP(hipStreamSynchronize(s));
+                    for (size_t i = 0; i < (size_t)ws->stats_m * ws->last_n_seg; ++i) tot += ws->seg_host[2 * i + 1];
+                }
             } else {
+                VQ_HIP(hipMemcpyAsync(ws->stats_host, ws->wl_count.p, (size_t)ws->stats_m * 4, hipMemcpyDeviceToHost, s));
+                VQ_HIP(hipStreamSynchronize(s));
                 for (uint32_t i = 0; i < ws->stats_m; ++i) tot += ws->stats_host[i];
             }
+            in.synced();
             *rechecked = tot;
         }
     }
     return VQHIP_OK;
+    VQ_API_END
 }
 
 int vqhip_set_profiling(int on) {
@@ -867,6 +1035,8 @@ int vqhip_dataset_synthetic(uint64_t n, uint32_t d, uint64_t seed, uint64_t row_
     vqhip_dataset *ds = new vqhip_dataset();
     int rc = ds->own.alloc((size_t)n * d * 4);
     if (rc == VQHIP_OK) rc = launch_synth_uniform(ds->own.as<float>(), n, d, seed, row_offset, s);
+    // a data set is immutable and shared freely between threads / streams: it is complete when the handle exists
+    if (rc == VQHIP_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(VQHIP_ERR_RUNTIME, "generating the synthetic rows failed");
     if (rc != VQHIP_OK) {
         delete ds;
         return rc;
@@ -945,6 +1115,7 @@ int vqhip_kmeans_create(const vqhip_dataset *ds, uint32_t m, uint32_t k, vqhip_k
     VQ_TRY(km->changed.alloc((size_t)m * 4));
     VQ_TRY(km->active_dev.alloc(m));
     VQ_TRY(km->rows_tmp.alloc((size_t)m * k * 8));
+    VQ_TRY(km->agree.alloc(16));
     VQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&km->counts_host), (size_t)m * k * 4));
     VQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&km->changed_host), (size_t)m * 4));
     km->active.assign(m, 1);
@@ -960,17 +1131,18 @@ int vqhip_kmeans_create(const vqhip_dataset *ds, uint32_t m, uint32_t k, vqhip_k
 }
 
 int vqhip_kmeans_destroy(vqhip_kmeans *km) {
-    if (km && g_last_ws == &km->ws) g_last_ws = nullptr;
-    delete km;
+    delete km;  // (unregisters its workspace: a later vqhip_last_assign_stats of any thread finds it gone)
     return VQHIP_OK;
 }
 
 int vqhip_kmeans_set_centroids(vqhip_kmeans *km, const float *centroids) {
     if (!km || !centroids) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    Entry in(km->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     VQ_HIP(hipMemcpyAsync(km->cs.cb.p, centroids, (size_t)km->cs.m * km->cs.k * km->cs.sd * 4, hipMemcpyHostToDevice, s));
     VQ_HIP(hipStreamSynchronize(s));
+    in.synced();
     km->cs.prepared = false;
     return VQHIP_OK;
 }
@@ -981,27 +1153,32 @@ int vqhip_kmeans_init_from_rows(vqhip_kmeans *km, const uint64_t *init_rows) {
     for (size_t i = 0; i < cnt; ++i)
         if (init_rows[i] >= km->ds->n)
             return fail(VQHIP_ERR_INVALID_INPUT, "init row %llu out of range", (unsigned long long)init_rows[i]);
+    Entry in(km->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     VQ_HIP(hipMemcpyAsync(km->rows_tmp.p, init_rows, cnt * 8, hipMemcpyHostToDevice, s));
     VQ_TRY(launch_gather_rows(km->ds->X, km->ds->d, km->cs.m, km->cs.k, km->cs.sd, km->rows_tmp.as<uint64_t>(),
                               km->cs.cb.as<float>(), s));
     VQ_HIP(hipStreamSynchronize(s));
+    in.synced();
     km->cs.prepared = false;
     return VQHIP_OK;
 }
 
 int vqhip_kmeans_get_centroids(vqhip_kmeans *km, float *centroids) {
     if (!km || !centroids) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    Entry in(km->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     VQ_HIP(hipMemcpyAsync(centroids, km->cs.cb.p, (size_t)km->cs.m * km->cs.k * km->cs.sd * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipStreamSynchronize(s));
+    in.synced();
     return VQHIP_OK;
 }
 
 int vqhip_kmeans_set_active(vqhip_kmeans *km, const uint8_t *active) {
     if (!km || !active) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    Entry in(km->sync);
     bool all = true;
     for (uint32_t s = 0; s < km->cs.m; ++s) {
         km->active[s] = active[s] ? 1 : 0;
@@ -1009,14 +1186,16 @@ int vqhip_kmeans_set_active(vqhip_kmeans *km, const uint8_t *active) {
     }
     km->all_active = all;
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     VQ_HIP(hipMemcpyAsync(km->active_dev.p, km->active.data(), km->cs.m, hipMemcpyHostToDevice, s));
     VQ_HIP(hipStreamSynchronize(s));
+    in.synced();
     return VQHIP_OK;
 }
 
 int vqhip_kmeans_get_active(const vqhip_kmeans *km, uint8_t *active) {
     if (!km || !active) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    std::lock_guard<std::recursive_mutex> lk(const_cast<vqhip_kmeans *>(km)->sync.mu);
     for (uint32_t s = 0; s < km->cs.m; ++s) active[s] = km->active[s] ? 1 : 0;
     return VQHIP_OK;
 }
@@ -1024,6 +1203,7 @@ int vqhip_kmeans_get_active(const vqhip_kmeans *km, uint8_t *active) {
 int vqhip_kmeans_set_engine(vqhip_kmeans *km, int engine) {
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     if (engine < VQHIP_ENGINE_AUTO || engine > VQHIP_ENGINE_MFMA_BF16) return fail(VQHIP_ERR_INVALID_INPUT, "unknown engine %d", engine);
+    std::lock_guard<std::recursive_mutex> lk(km->sync.mu);
     km->engine = engine;
     return VQHIP_OK;
 }
@@ -1032,6 +1212,7 @@ uint32_t vqhip_code_bytes(uint32_t k) { return code_bytes(k); }
 
 int vqhip_kmeans_set_exact_update(vqhip_kmeans *km, int exact_update) {
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    std::lock_guard<std::recursive_mutex> lk(km->sync.mu);
     km->exact_update = exact_update ? 1 : 0;
     return VQHIP_OK;
 }
@@ -1043,7 +1224,7 @@ static int kmeans_accumulate_enqueue(vqhip_kmeans *km, hipStream_t s, bool gated
     for (uint32_t i = 0; i < km->cs.m; ++i)
         if (km->active[i]) subs.push_back(i);
     const vqhip_dataset *ds = km->ds;
-    g_last_ws = &km->ws;
+    g_last_ws = km->ws_id;
     // assignment: always squared L2 (src/core/vector.rs:352-363); with the update fused in where the shape allows
     FusedAcc fused;
     if (km->fused_slabs && !km->exact_update && !km->sums_by_chains) {
@@ -1083,14 +1264,16 @@ int vqhip_kmeans_accumulate(vqhip_kmeans *km) {
     VQ_API_BEGIN
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     VQ_TRY(require_gfx950());
+    Entry in(km->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     return kmeans_accumulate_enqueue(km, s);
     VQ_API_END
 }
 
 int vqhip_kmeans_partials(vqhip_kmeans *km, void **dev_slab, uint64_t *n_doubles) {
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    std::lock_guard<std::recursive_mutex> lk(km->sync.mu);
     if (dev_slab) *dev_slab = km->slab.p;
     if (n_doubles) *n_doubles = (uint64_t)km->cs.m * km->cs.k * (km->cs.sd + 1);
     return VQHIP_OK;
@@ -1127,11 +1310,13 @@ static void kmeans_finalize_collect(vqhip_kmeans *km, uint32_t *counts, uint8_t 
 int vqhip_kmeans_finalize(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
     VQ_API_BEGIN
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    Entry in(km->sync);
     if (!km->accumulated) return fail(VQHIP_ERR_INVALID_INPUT, "finalize without a preceding accumulate");
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     VQ_TRY(kmeans_finalize_enqueue(km, s));
     VQ_TRY(spin_wait(s));  // a parked thread wakes ~100 us late; an iteration is 0.1-10 ms
+    in.synced();
     kmeans_finalize_collect(km, counts, changed);
     return VQHIP_OK;
     VQ_API_END
@@ -1153,12 +1338,14 @@ int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
     VQ_API_BEGIN
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     VQ_TRY(require_gfx950());
+    Entry in(km->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     if (!kmeans_graph_eligible(km)) {
         VQ_TRY(kmeans_accumulate_enqueue(km, s));
         VQ_TRY(kmeans_finalize_enqueue(km, s));
         VQ_TRY(spin_wait(s));
+        in.synced();
         kmeans_finalize_collect(km, counts, changed);
         return VQHIP_OK;
     }
@@ -1200,11 +1387,12 @@ int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
         VQ_TRY(spin_wait(s));
         km->warm_key = key;
     }
+    in.synced();  // every branch above ended in spin_wait
     // host-side state the enqueue functions leave behind (a replay does not run them)
     km->cs.prepared = false;
     km->accumulated = false;
     km->ws.stats_pending = (km->ws.last_engine == VQHIP_ENGINE_MFMA || km->ws.last_engine == VQHIP_ENGINE_MFMA_BF16);
-    g_last_ws = &km->ws;
+    g_last_ws = km->ws_id;
     tls().last_engine = km->ws.last_engine;
     kmeans_finalize_collect(km, counts, changed);
     return VQHIP_OK;
@@ -1221,11 +1409,12 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     int world = 1;
     comm_info(comm, &world, nullptr);
+    Entry in(km->sync);
+    // (arguments every rank passes alike -- the host program's contract -- may end the call before the agreement below;
+    // anything that depends on THIS rank's device, environment or memory may not: a rank that left early would leave
+    // its peers blocked in the collective)
     if (world > 1 && km->exact_update)
         return fail(VQHIP_ERR_UNSUPPORTED, "exact_update sums rows in one sequential chain: single GPU only");
-    VQ_TRY(require_gfx950());
-    hipStream_t s;
-    VQ_TRY(current_stream(&s));
     const uint32_t m = km->cs.m, k = km->cs.k;
     if (iters_done) memset(iters_done, 0, (size_t)m * 4);
     if (paused) *paused = 0;
@@ -1235,30 +1424,41 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
         if (changed) memset(changed, 0, m);
         return VQHIP_OK;
     }
+    hipStream_t s = nullptr;
     int engine = 0;
-    VQ_TRY(pick_engine(km->engine, km->cs, VQHIP_SQUARED_EUCLIDEAN, &engine));
+    int local_rc = require_gfx950();
+    if (local_rc == VQHIP_OK) local_rc = in.stream(&s);
+    if (local_rc == VQHIP_OK) local_rc = pick_engine(km->engine, km->cs, VQHIP_SQUARED_EUCLIDEAN, &engine);
     static const char *host_loop_env = getenv("VQHIP_RUN_ON_HOST");  // =1: decisions on the host (A/B)
     uint32_t n_active = 0;
     for (uint32_t i = 0; i < m; ++i) n_active += km->active[i] ? 1u : 0u;
     // the device-driven loop needs the fused update: exactly run_assign's predicate (engine, one centroid group, a slab
     // per (chunk, active subspace) beyond the list-driven ones), evaluated BEFORE anything is queued -- otherwise the
     // host-driven loop below serves the shape
-    bool device_loop = km->fused_slabs && !km->exact_update && !km->sums_by_chains && engine == VQHIP_ENGINE_MFMA_BF16 &&
-                       km->cs.x32_groups == 1 && screen_bf16_fused_update_supported(km->cs.sd, k) &&
+    bool device_loop = local_rc == VQHIP_OK && km->fused_slabs && !km->exact_update && !km->sums_by_chains &&
+                       engine == VQHIP_ENGINE_MFMA_BF16 && km->cs.x32_groups == 1 && screen_bf16_fused_update_supported(km->cs.sd, k) &&
                        km->fused_slabs / n_active > FusedAcc().n_patch && km->ds->n != 0 && km->ds->n < (1ull << 32) &&
                        !g_prof.on && !(host_loop_env && host_loop_env[0] == '1');
     if (world > 1) {
         // every rank must queue the same number of all-reduces: the decision depends on per-rank state (environment,
-        // profiling hooks, the local row count), so the ranks agree on it -- device loop only if ALL of them can
-        VQ_TRY(km->gather_ws.ensure(4));
-        const uint32_t mine = device_loop ? 1u : 0u;
-        uint32_t all = 0;
-        VQ_HIP(hipMemcpyAsync(km->gather_ws.p, &mine, 4, hipMemcpyHostToDevice, s));
-        VQ_TRY(comm_allreduce_u32(comm, km->gather_ws.as<uint32_t>(), 1, s));
-        VQ_HIP(hipMemcpyAsync(&all, km->gather_ws.p, 4, hipMemcpyDeviceToHost, s));
+        // profiling hooks, the local row count), so the ranks agree on it -- device loop only if ALL of them can -- and
+        // in the same collective on whether every rank got this far: {ranks that are ready, ranks that can loop on
+        // the device}.  `agree` was allocated with the handle, so a rank short of memory still takes part.
+        const std::string my_error = local_rc == VQHIP_OK ? std::string() : tls().last_error;
+        if (!s) VQ_TRY(current_stream(&s));  // (no stream at all: nothing can be queued, the peers time out in RCCL)
+        const uint32_t mine[2] = {local_rc == VQHIP_OK ? 1u : 0u, device_loop ? 1u : 0u};
+        uint32_t all[2] = {0, 0};
+        VQ_HIP(hipMemcpyAsync(km->agree.p, mine, 8, hipMemcpyHostToDevice, s));
+        VQ_TRY(comm_allreduce_u32(comm, km->agree.as<uint32_t>(), 2, s));
+        VQ_HIP(hipMemcpyAsync(all, km->agree.p, 8, hipMemcpyDeviceToHost, s));
         VQ_HIP(hipStreamSynchronize(s));
-        device_loop = all == (uint32_t)world;
+        if (local_rc != VQHIP_OK) return fail(local_rc, "%s", my_error.c_str());
+        if (all[0] != (uint32_t)world)
+            return fail(VQHIP_ERR_FAILURE, "%u of %d ranks could not start the run (their own error text says why)",
+                        (uint32_t)world - all[0], world);
+        device_loop = all[1] == (uint32_t)world;
     }
+    VQ_TRY(local_rc);
     if (!device_loop) {
         std::vector<uint32_t> cnt((size_t)m * k);
         std::vector<uint8_t> chg(m);
@@ -1296,6 +1496,7 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
                 }
             if (flip) VQ_TRY(vqhip_kmeans_set_active(km, act.data()));
         }
+        in.synced();  // every step ended in a wait
         return VQHIP_OK;
     }
     VQ_TRY(km->run_state.ensure((size_t)(m + 3) * 4));
@@ -1313,6 +1514,7 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
     VQ_HIP(hipMemcpyAsync(st.data(), km->run_state.p, (size_t)(m + 1) * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipMemcpyAsync(act.data(), km->active_dev.p, m, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipStreamSynchronize(s));
+    in.synced();
     kmeans_finalize_collect(km, counts, changed);  // flags of the last executed iteration, for the subspaces active in it
     if (iters_done) memcpy(iters_done, st.data() + 1, (size_t)m * 4);
     if (paused) *paused = st[0] ? 1 : 0;
@@ -1323,7 +1525,7 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
     }
     km->all_active = all;
     km->ws.stats_pending = true;
-    g_last_ws = &km->ws;
+    g_last_ws = km->ws_id;
     tls().last_engine = km->ws.last_engine;
     return VQHIP_OK;
     VQ_API_END
@@ -1336,17 +1538,23 @@ int vqhip_kmeans_run(vqhip_kmeans *km, uint32_t max_iters, uint32_t *iters_done,
 
 int vqhip_kmeans_run_sharded(vqhip_kmeans *km, vqhip_comm *comm, uint32_t max_iters, uint32_t *iters_done, uint32_t *counts,
                              uint8_t *changed, int *paused) {
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    std::lock_guard<std::recursive_mutex> lk_km(km->sync.mu);  // lock order: k-means handle, then communicator
+    std::unique_lock<std::recursive_mutex> lk_comm;
+    if (comm) lk_comm = std::unique_lock<std::recursive_mutex>(comm->mu);
     return kmeans_run_impl(km, comm ? comm->c : nullptr, max_iters, iters_done, counts, changed, paused);
 }
 
 int vqhip_kmeans_patch_centroid(vqhip_kmeans *km, uint32_t s, uint32_t j, const float *sub_row) {
     if (!km || !sub_row) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     if (s >= km->cs.m || j >= km->cs.k) return fail(VQHIP_ERR_INVALID_INPUT, "centroid (%u,%u) out of range", s, j);
+    Entry in(km->sync);
     hipStream_t st;
-    VQ_TRY(current_stream(&st));
+    VQ_TRY(in.stream(&st));
     float *dst = km->cs.cb.as<float>() + ((size_t)s * km->cs.k + j) * km->cs.sd;
     VQ_HIP(hipMemcpyAsync(dst, sub_row, (size_t)km->cs.sd * 4, hipMemcpyHostToDevice, st));
     VQ_HIP(hipStreamSynchronize(st));
+    in.synced();
     km->cs.prepared = false;
     return VQHIP_OK;
 }
@@ -1355,8 +1563,9 @@ int vqhip_kmeans_patch_from_row(vqhip_kmeans *km, uint32_t s, uint32_t j, uint64
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     if (s >= km->cs.m || j >= km->cs.k) return fail(VQHIP_ERR_INVALID_INPUT, "centroid (%u,%u) out of range", s, j);
     if (row >= km->ds->n) return fail(VQHIP_ERR_INVALID_INPUT, "row %llu out of range", (unsigned long long)row);
+    Entry in(km->sync);
     hipStream_t st;
-    VQ_TRY(current_stream(&st));
+    VQ_TRY(in.stream(&st));
     float *dst = km->cs.cb.as<float>() + ((size_t)s * km->cs.k + j) * km->cs.sd;
     const float *src = km->ds->X + row * km->ds->d + (size_t)s * km->cs.sd;
     VQ_HIP(hipMemcpyAsync(dst, src, (size_t)km->cs.sd * 4, hipMemcpyDeviceToDevice, st));
@@ -1366,10 +1575,12 @@ int vqhip_kmeans_patch_from_row(vqhip_kmeans *km, uint32_t s, uint32_t j, uint64
 
 int vqhip_kmeans_get_assignments(vqhip_kmeans *km, uint8_t *codes) {
     if (!km || !codes) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    Entry in(km->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     VQ_HIP(hipMemcpyAsync(codes, km->codes.p, (size_t)km->ds->n * km->cs.m * code_bytes(km->cs.k), hipMemcpyDeviceToHost, s));
     VQ_HIP(hipStreamSynchronize(s));
+    in.synced();
     return VQHIP_OK;
 }
 
@@ -1421,13 +1632,16 @@ int vqhip_comm_destroy(vqhip_comm *comm) {
 int vqhip_kmeans_allreduce(vqhip_kmeans *km, vqhip_comm *comm) {
     VQ_API_BEGIN
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    Entry in(km->sync);
+    std::unique_lock<std::recursive_mutex> lk_comm;
+    if (comm) lk_comm = std::unique_lock<std::recursive_mutex>(comm->mu);
     if (!km->accumulated) return fail(VQHIP_ERR_INVALID_INPUT, "allreduce without a preceding accumulate");
     int world = 1;
     comm_info(comm ? comm->c : nullptr, &world, nullptr);
     if (world > 1 && km->exact_update)
         return fail(VQHIP_ERR_UNSUPPORTED, "exact_update sums rows in one sequential chain: single GPU only");
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     return comm_allreduce_f64(comm ? comm->c : nullptr, km->slab.as<double>(),
                               (size_t)km->cs.m * km->cs.k * (km->cs.sd + 1), s);
     VQ_API_END
@@ -1437,12 +1651,16 @@ int vqhip_kmeans_step_sharded(vqhip_kmeans *km, vqhip_comm *comm, uint32_t *coun
     VQ_API_BEGIN
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     VQ_TRY(require_gfx950());
+    Entry in(km->sync);
+    std::unique_lock<std::recursive_mutex> lk_comm;
+    if (comm) lk_comm = std::unique_lock<std::recursive_mutex>(comm->mu);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     VQ_TRY(kmeans_accumulate_enqueue(km, s));
     VQ_TRY(vqhip_kmeans_allreduce(km, comm));
     VQ_TRY(kmeans_finalize_enqueue(km, s));
     VQ_TRY(spin_wait(s));
+    in.synced();
     kmeans_finalize_collect(km, counts, changed);
     return VQHIP_OK;
     VQ_API_END
@@ -1461,11 +1679,13 @@ int vqhip_kmeans_gather_owned_rows(vqhip_kmeans *km, const uint64_t *global_rows
     VQ_API_BEGIN
     if (!km || !global_rows || !bits_out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     VQ_TRY(require_gfx950());
+    Entry in(km->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     VQ_TRY(gather_owned_enqueue(km, global_rows, row_offset, s));
     VQ_HIP(hipMemcpyAsync(bits_out, km->gather_ws.p, (size_t)km->cs.m * km->cs.k * km->cs.sd * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipStreamSynchronize(s));
+    in.synced();
     return VQHIP_OK;
     VQ_API_END
 }
@@ -1474,13 +1694,17 @@ int vqhip_kmeans_init_from_global_rows(vqhip_kmeans *km, vqhip_comm *comm, const
     VQ_API_BEGIN
     if (!km || !global_rows) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     VQ_TRY(require_gfx950());
+    Entry in(km->sync);
+    std::unique_lock<std::recursive_mutex> lk_comm;
+    if (comm) lk_comm = std::unique_lock<std::recursive_mutex>(comm->mu);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     const size_t words = (size_t)km->cs.m * km->cs.k * km->cs.sd;
     VQ_TRY(gather_owned_enqueue(km, global_rows, row_offset, s));
     VQ_TRY(comm_allreduce_u32(comm ? comm->c : nullptr, km->gather_ws.as<uint32_t>(), words, s));
     VQ_HIP(hipMemcpyAsync(km->cs.cb.p, km->gather_ws.p, words * 4, hipMemcpyDeviceToDevice, s));
     VQ_HIP(hipStreamSynchronize(s));
+    in.synced();
     km->cs.prepared = false;
     return VQHIP_OK;
     VQ_API_END
@@ -1492,8 +1716,11 @@ int vqhip_kmeans_patch_from_global_row(vqhip_kmeans *km, vqhip_comm *comm, uint3
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     if (sub >= km->cs.m || j >= km->cs.k) return fail(VQHIP_ERR_INVALID_INPUT, "centroid (%u,%u) out of range", sub, j);
     VQ_TRY(require_gfx950());
+    Entry in(km->sync);
+    std::unique_lock<std::recursive_mutex> lk_comm;
+    if (comm) lk_comm = std::unique_lock<std::recursive_mutex>(comm->mu);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     const uint32_t sd = km->cs.sd;
     VQ_TRY(km->gather_ws.ensure((size_t)km->cs.m * km->cs.k * sd * 4));
     VQ_HIP(hipMemcpyAsync(km->rows_tmp.p, &global_row, 8, hipMemcpyHostToDevice, s));
@@ -1504,6 +1731,7 @@ int vqhip_kmeans_patch_from_global_row(vqhip_kmeans *km, vqhip_comm *comm, uint3
     VQ_HIP(hipMemcpyAsync(km->cs.cb.as<float>() + ((size_t)sub * km->cs.k + j) * sd, km->gather_ws.p, (size_t)sd * 4,
                           hipMemcpyDeviceToDevice, s));
     VQ_HIP(hipStreamSynchronize(s));  // &global_row is a stack address
+    in.synced();
     km->cs.prepared = false;
     return VQHIP_OK;
     VQ_API_END
@@ -1535,7 +1763,6 @@ int vqhip_pq_encoder_create(const float *codebooks, uint32_t m, uint32_t k, uint
 }
 
 int vqhip_pq_encoder_destroy(vqhip_pq_encoder *enc) {
-    if (enc && g_last_ws == &enc->ws) g_last_ws = nullptr;
     delete enc;
     return VQHIP_OK;
 }
@@ -1543,6 +1770,7 @@ int vqhip_pq_encoder_destroy(vqhip_pq_encoder *enc) {
 int vqhip_pq_encoder_set_engine(vqhip_pq_encoder *enc, int engine) {
     if (!enc) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     if (engine < VQHIP_ENGINE_AUTO || engine > VQHIP_ENGINE_MFMA_BF16) return fail(VQHIP_ERR_INVALID_INPUT, "unknown engine %d", engine);
+    std::lock_guard<std::recursive_mutex> lk(enc->sync.mu);
     enc->engine = engine;
     return VQHIP_OK;
 }
@@ -1553,14 +1781,15 @@ int vqhip_pq_encode_device(vqhip_pq_encoder *enc, const void *dev_rows, uint64_t
     if (n == 0) return VQHIP_OK;
     if (!dev_rows) return fail(VQHIP_ERR_NULL_PTR, "dev_rows is NULL");
     VQ_TRY(require_gfx950());
+    Entry in(enc->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     uint8_t *codes = reinterpret_cast<uint8_t *>(dev_codes);
     if (!codes) {  // f16-only output still needs the codes internally
         VQ_TRY(enc->codes.ensure((size_t)n * enc->cs.m * code_bytes(enc->cs.k)));
         codes = enc->codes.as<uint8_t>();
     }
-    g_last_ws = &enc->ws;
+    g_last_ws = enc->ws_id;
     VQ_TRY(run_assign(enc->cs, enc->ws, reinterpret_cast<const float *>(dev_rows), n, enc->cs.m * enc->cs.sd,
                       enc->metric, enc->all_subs, codes, enc->engine, s));
     if (dev_f16_out) VQ_TRY(launch_gather_f16(enc->cs.view(), codes, n, reinterpret_cast<uint16_t *>(dev_f16_out), s));
@@ -1574,20 +1803,37 @@ int vqhip_pq_encode(vqhip_pq_encoder *enc, const float *rows, uint64_t n, uint8_
     if (n == 0) return VQHIP_OK;
     if (!rows) return fail(VQHIP_ERR_NULL_PTR, "rows is NULL");
     VQ_TRY(require_gfx950());
+    Entry in(enc->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
     const uint32_t m = enc->cs.m, d = enc->cs.m * enc->cs.sd;
     const size_t cw = code_bytes(enc->cs.k);  // bytes per code: 1 (k <= 256) or 2
     static const char *no_small = getenv("VQHIP_NO_SMALL_PATH");
-    if (n <= kSmallRows && !(no_small && no_small[0] == '1')) {
-        // per-vector calls (Quantizer::quantize): one kernel over mapped pinned memory, exact arithmetic
+    const bool small = n <= kSmallRows && !(no_small && no_small[0] == '1');
+    // (the per-vector path needs no order behind the handle's queued batch work: it shares nothing mutable with it)
+    if (small && enc->cs.prepared && enc->cs.prepared_base) VQ_TRY(current_stream(&s));
+    else VQ_TRY(in.stream(&s));
+    if (small) {
+        // per-vector calls (Quantizer::quantize): one kernel over mapped pinned memory, exact arithmetic.  The kernel
+        // reads only what an encoder never changes after its first use (codebooks, centroid norms), and the staging
+        // belongs to the call: the handle is given back before the launch, so calls from many threads on one encoder
+        // (`quantize(&self)` on a Sync type, src/pq.rs:39-45) run side by side on their threads' streams.
         const size_t in_b = (size_t)n * d * 4, code_b = ((size_t)n * m * cw + 15) & ~(size_t)15, f16_b = (size_t)n * d * 2;
-        VQ_TRY(enc->stage.ensure(in_b + code_b + f16_b));
-        VQ_TRY(enc->cs.prepare(s));  // centroid norms (cosine)
-        char *hb = static_cast<char *>(enc->stage.host), *db = static_cast<char *>(enc->stage.dev);
+        if (!(enc->cs.prepared && enc->cs.prepared_base)) {
+            VQ_TRY(enc->cs.prepare(s));  // centroid norms (cosine)
+            VQ_HIP(hipStreamSynchronize(s));  // once per encoder: other threads' streams read the images from now on
+            in.synced();
+        }
+        const int metric = enc->metric;
+        const uint32_t k = enc->cs.k, sd = enc->cs.sd;
+        const float *cb = enc->cs.cb.as<float>(), *cnsqrt = enc->cs.cnsqrt.as<float>();
+        enc->ws.stats_pending = false;
+        enc->ws.last_engine = VQHIP_ENGINE_EXACT;
+        in.release();
+        StageLease stage;
+        VQ_TRY(stage.acquire(in_b + code_b + f16_b));
+        char *hb = stage.host(), *db = stage.dev();
         memcpy(hb, rows, in_b);
-        VQ_TRY(launch_pq_encode_small(reinterpret_cast<const float *>(db), (uint32_t)n, d, m, enc->cs.k, enc->cs.sd,
-                                      enc->metric, enc->cs.cb.as<float>(), enc->cs.cnsqrt.as<float>(),
+        VQ_TRY(launch_pq_encode_small(reinterpret_cast<const float *>(db), (uint32_t)n, d, m, k, sd, metric, cb, cnsqrt,
                                       reinterpret_cast<uint8_t *>(db + in_b),
                                       f16_out ? reinterpret_cast<uint16_t *>(db + in_b + code_b) : nullptr, s));
         VQ_TRY(spin_wait(s));
@@ -1596,8 +1842,7 @@ int vqhip_pq_encode(vqhip_pq_encoder *enc, const float *rows, uint64_t n, uint8_
         ThreadState &st = tls();
         st.last_engine = VQHIP_ENGINE_EXACT;
         st.last_rechecked = 0;
-        enc->ws.stats_pending = false;
-        enc->ws.last_engine = VQHIP_ENGINE_EXACT;
+        g_last_ws = 0;
         return VQHIP_OK;
     }
     // bounded staging: at most ~1 GiB of rows per pass
@@ -1614,6 +1859,7 @@ int vqhip_pq_encode(vqhip_pq_encoder *enc, const float *rows, uint64_t n, uint8_
         if (f16_out) VQ_HIP(hipMemcpyAsync(f16_out + r0 * d, enc->f16buf.p, (size_t)nr * d * 2, hipMemcpyDeviceToHost, s));
         VQ_HIP(hipStreamSynchronize(s));
     }
+    in.synced();
     return VQHIP_OK;
     VQ_API_END
 }
@@ -1626,8 +1872,9 @@ int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uin
     if (nq == 0) return VQHIP_OK;
     if (n == 0 || n >= (1ull << 32)) return fail(VQHIP_ERR_INVALID_INPUT, "n must be in [1, 2^32)");
     VQ_TRY(require_gfx950());
+    Entry in(enc->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     const uint32_t m = enc->cs.m, k = enc->cs.k, sd = enc->cs.sd, dim = m * sd;
     VQ_TRY(enc->adc_q.ensure((size_t)nq * dim * 4));
     VQ_TRY(enc->adc_lut.ensure((size_t)adc_query_batch() * m * k * 4));
@@ -1644,6 +1891,7 @@ int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uin
     VQ_HIP(hipMemcpyAsync(idx_out, enc->adc_idx.p, (size_t)nq * topk * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipMemcpyAsync(dist_out, enc->adc_out.p, (size_t)nq * topk * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipStreamSynchronize(s));
+    in.synced();
     return VQHIP_OK;
     VQ_API_END
 }
@@ -1652,8 +1900,9 @@ int vqhip_pq_adc_search(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n,
                         uint32_t topk, uint32_t *idx_out, float *dist_out) {
     VQ_API_BEGIN
     if (!enc || !codes) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    Entry in(enc->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     const size_t code_b = (size_t)n * enc->cs.m * code_bytes(enc->cs.k);
     VQ_TRY(enc->adc_codes.ensure(code_b));
     VQ_HIP(hipMemcpyAsync(enc->adc_codes.p, codes, code_b, hipMemcpyHostToDevice, s));
@@ -1685,8 +1934,9 @@ int vqhip_pq_decode(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n, flo
     if (n == 0) return VQHIP_OK;
     if (!codes || !out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     VQ_TRY(require_gfx950());
+    Entry in(enc->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     const uint32_t m = enc->cs.m, d = enc->cs.m * enc->cs.sd;
     const size_t cw = code_bytes(enc->cs.k);
     for (uint64_t i = 0; i < n * m; ++i) {
@@ -1704,6 +1954,7 @@ int vqhip_pq_decode(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n, flo
     VQ_TRY(launch_decode_f32(enc->cs.view(), enc->codes.as<uint8_t>(), n, enc->f32buf.as<float>(), s));
     VQ_HIP(hipMemcpyAsync(out, enc->f32buf.p, (size_t)n * d * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipStreamSynchronize(s));
+    in.synced();
     return VQHIP_OK;
     VQ_API_END
 }
@@ -1803,8 +2054,9 @@ int vqhip_tsvq_encode_device(vqhip_tsvq *t, const void *dev_rows, uint64_t n, vo
     if (n == 0) return VQHIP_OK;
     if (!dev_rows) return fail(VQHIP_ERR_NULL_PTR, "dev_rows is NULL");
     VQ_TRY(require_gfx950());
+    Entry in(t->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
+    VQ_TRY(in.stream(&s));
     int32_t *leaf = reinterpret_cast<int32_t *>(dev_leaf);
     if (!leaf) {
         VQ_TRY(t->leafbuf.ensure((size_t)n * 4));
@@ -1841,14 +2093,16 @@ int vqhip_tsvq_encode_device(vqhip_tsvq *t, const void *dev_rows, uint64_t n, vo
 int vqhip_tsvq_last_stats(vqhip_tsvq *t, int *screened, uint64_t *undecided) {
     VQ_API_BEGIN
     if (!t || !screened || !undecided) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    Entry in(t->sync);
     *screened = t->last_screened ? 1 : 0;
     *undecided = 0;
     if (t->last_screened) {
         hipStream_t s;
-        VQ_TRY(current_stream(&s));
+        VQ_TRY(in.stream(&s));
         uint32_t c = 0;
         VQ_HIP(hipMemcpyAsync(&c, t->scr_count.p, 4, hipMemcpyDeviceToHost, s));
         VQ_HIP(hipStreamSynchronize(s));
+        in.synced();
         *undecided = c;
     }
     return VQHIP_OK;
@@ -1861,14 +2115,22 @@ int vqhip_tsvq_encode(vqhip_tsvq *t, const float *rows, uint64_t n, int32_t *lea
     if (n == 0) return VQHIP_OK;
     if (!rows) return fail(VQHIP_ERR_NULL_PTR, "rows is NULL");
     VQ_TRY(require_gfx950());
+    Entry in(t->sync);
     hipStream_t s;
-    VQ_TRY(current_stream(&s));
     const uint32_t d = t->d;
     static const char *no_small = getenv("VQHIP_NO_SMALL_PATH");
-    if (n <= kSmallRows && tsvq_small_supported(d) && !(no_small && no_small[0] == '1')) {
+    const bool small = n <= kSmallRows && tsvq_small_supported(d) && !(no_small && no_small[0] == '1');
+    if (small) VQ_TRY(current_stream(&s));  // nothing mutable shared with the handle's queued batch work: no order needed
+    else VQ_TRY(in.stream(&s));
+    if (small) {
+        // per-vector calls: the kernel reads the tree only (fixed at creation, complete before the handle existed) and
+        // stages through a buffer of its own, so the handle is given back before the launch (see vqhip_pq_encode)
         const size_t in_b = (size_t)n * d * 4, leaf_b = ((size_t)n * 4 + 15) & ~(size_t)15, f16_b = (size_t)n * d * 2;
-        VQ_TRY(t->stage.ensure(in_b + leaf_b + f16_b));
-        char *hb = static_cast<char *>(t->stage.host), *db = static_cast<char *>(t->stage.dev);
+        t->last_screened = false;
+        in.release();
+        StageLease stage;
+        VQ_TRY(stage.acquire(in_b + leaf_b + f16_b));
+        char *hb = stage.host(), *db = stage.dev();
         memcpy(hb, rows, in_b);
         VQ_TRY(launch_tsvq_encode_small(reinterpret_cast<const float *>(db), (uint32_t)n, d, t->metric,
                                         t->centroids.as<float>(), t->cnorm.as<float>(), t->left.as<int32_t>(),
@@ -1877,7 +2139,6 @@ int vqhip_tsvq_encode(vqhip_tsvq *t, const float *rows, uint64_t n, int32_t *lea
         VQ_TRY(spin_wait(s));
         if (leaf) memcpy(leaf, hb + in_b, (size_t)n * 4);
         if (f16_out) memcpy(f16_out, hb + in_b + leaf_b, f16_b);
-        t->last_screened = false;
         return VQHIP_OK;
     }
     uint64_t chunk = std::max<uint64_t>(1, (1ull << 30) / ((uint64_t)d * 4));
@@ -1894,6 +2155,7 @@ int vqhip_tsvq_encode(vqhip_tsvq *t, const float *rows, uint64_t n, int32_t *lea
         if (f16_out) VQ_HIP(hipMemcpyAsync(f16_out + r0 * d, t->f16buf.p, (size_t)nr * d * 2, hipMemcpyDeviceToHost, s));
         VQ_HIP(hipStreamSynchronize(s));
     }
+    in.synced();
     return VQHIP_OK;
     VQ_API_END
 }

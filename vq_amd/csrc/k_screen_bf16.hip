@@ -1399,9 +1399,9 @@ __global__ __launch_bounds__(256) void k_codes_transpose(const uint8_t *__restri
                                                          uint64_t n, uint32_t m, const uint32_t *__restrict__ sub_list,
                                                          uint32_t n_sub, const uint8_t *__restrict__ gate_active,
                                                          const uint32_t *__restrict__ gate_halt) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t tr_lds[];  // [256][m + 4] codes, then [m] activity flags
+    extern __shared__ __attribute__((aligned(16))) uint8_t tr_lds[];  // [256][pitch] codes, then [m] activity flags
     if (gate_halt && *gate_halt) return;  // a paused run: the screen wrote nothing
-    const uint32_t tp = m + 4;            // row pitch in LDS: a multiple of 4 that is not a multiple of 128
+    const uint32_t tp = codes_transpose_pitch(m);  // row pitch in LDS: a multiple of 4 that is not a multiple of 128
     uint8_t *tile = tr_lds, *act = tr_lds + 256 * tp;
     const uint64_t row0 = (uint64_t)blockIdx.x * 256;
     for (uint32_t s = threadIdx.x; s < m; s += 256) act[s] = 0;
@@ -1521,7 +1521,7 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
                            a.gate_active, a.gate_halt, (G == 1) ? a.codes_t : nullptr, a.codes_t_pitch);
     VQ_LAUNCH_CHECK("k_assign_screen_bf16_x32");
     if (G == 1 && a.codes_t) {
-        hipLaunchKernelGGL(k_codes_transpose, dim3((uint32_t)((a.n + 255) / 256)), dim3(256), (size_t)256 * (cb.m + 4) + cb.m, stream,
+        hipLaunchKernelGGL(k_codes_transpose, dim3((uint32_t)((a.n + 255) / 256)), dim3(256), (size_t)256 * codes_transpose_pitch(cb.m) + cb.m, stream,
                            a.codes_t, a.codes_t_pitch, a.codes, a.n, cb.m, a.sub_list, a.n_sub, a.gate_active, a.gate_halt);
         VQ_LAUNCH_CHECK("k_codes_transpose");
     }

@@ -523,9 +523,12 @@ __global__ __launch_bounds__(256) void k_finalize(uint32_t m, uint32_t k, uint32
     }
     if (!RUN) return;
     __shared__ int is_last, any_empty;
+    // every wave drains ITS OWN stores (changed[s], done_blocks[1], counts, centroids) to agent scope before the barrier:
+    // a fence by thread 0 alone waits for thread 0's wave only, and s_barrier does not wait for the other waves'
+    // outstanding stores -- the last workgroup could have read a stale flag
+    __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();  // this workgroup's counts / flags / centroids before its ticket
         is_last = atomicAdd(done_blocks, 1u) == gridDim.x - 1 ? 1 : 0;
         any_empty = 0;
     }

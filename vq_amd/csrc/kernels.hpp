@@ -68,6 +68,10 @@ int launch_prepare_codebook(const CodebookView &v, float *prepA, float *prepCn, 
                             float *cnsqrt, hipStream_t stream);
 
 // ---- assignment -------------------------------------------------------------------
+// LDS row pitch of k_codes_transpose's [256][pitch] tile: a multiple of 4 above m that is never a multiple of 128
+// bytes (m = 124: m + 4 would put every row's byte s into one bank, a 32-way conflict on the scatter)
+__host__ __device__ constexpr uint32_t codes_transpose_pitch(uint32_t m) { return m + 4 + (((m + 4) % 128 == 0) ? 4u : 0u); }
+
 struct AssignArgs {
     const float *X = nullptr;  // [n][d]
     uint64_t n = 0;
