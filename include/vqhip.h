@@ -25,9 +25,20 @@
  * StdRng (src/core/vector.rs:412-413, 448-452).  Those draws stay on the host side of this
  * ABI: the caller passes row ids in (vqhip_kmeans_init_from_rows, *_patch_from_row).
  *
- * Threading: handles are single-owner (one thread at a time per handle); distinct handles
- * may be used from distinct threads.  Work is enqueued on the calling thread's current
- * stream (vqhip_set_stream) of the current HIP device.
+ * Threading: every handle may be used from any number of threads at once -- the reference's
+ * quantizers are plain data, `Send + Sync`, and `quantize(&self)` runs on thread pools
+ * (src/pq.rs:39-45, 167-199; src/tsvq.rs:186-191, 239-255).  Each handle carries a lock that an
+ * entry point holds while it touches the handle's state; a call that returns with work still
+ * queued (the *_device forms, vqhip_kmeans_accumulate, _patch_from_row) is followed, on whatever
+ * stream the next call on that handle arrives, by a wait for that work (an event; no host wait).
+ * Per-vector calls (vqhip_pq_encode / vqhip_tsvq_encode with n <= 8) stage through buffers owned by
+ * the CALL and give the handle back before they launch, so calls from many threads on one
+ * quantizer overlap on the device.  A vqhip_dataset is immutable and complete when it is handed
+ * out: share it freely.  What stays with the caller: a handle must outlive the calls on it
+ * (destroy is not a synchronisation point), and caller-owned device buffers passed to *_device
+ * forms are ordered by the caller.  Work is enqueued on the calling thread's current stream
+ * (vqhip_set_stream; default: a per-thread stream the library creates) of the current HIP device.
+ * vqhip_last_error / vqhip_last_assign_stats / vqhip_set_profiling are per calling thread.
  */
 #ifndef VQHIP_H
 #define VQHIP_H

@@ -35,6 +35,9 @@ class OracleError(RuntimeError):
 def build(native: bool = False) -> str:
     """(Re)build the shared library with the committed Makefile; returns its path."""
     name = "libvq_oracle_native.so" if native else "libvq_oracle.so"
+    override = os.environ.get("VQ_ORACLE_LIB")  # tools/run_asan.sh: the sanitizer build of the same source
+    if override and not native:
+        return override
     path = os.path.join(_HERE, name)
     src = [os.path.join(_HERE, f) for f in ("vq_oracle.c", "vq_oracle.h", "Makefile")]
     stale = (not os.path.exists(path)) or any(
