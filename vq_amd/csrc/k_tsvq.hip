@@ -451,9 +451,9 @@ __global__ __launch_bounds__(256) void k_flags_scan(const float *__restrict__ va
     }
     if (threadIdx.x == 255) block_sums[blockIdx.x] = sh[255];
 }
-__global__ __launch_bounds__(1024) void k_scan_sums(uint32_t *__restrict__ block_sums, uint32_t nb) {
+// (body shared with the fused per-level planner k_plan_fused: one workgroup of 1024 threads, `sh` its 4 KB of LDS)
+__device__ inline void scan_sums_body(uint32_t *__restrict__ block_sums, uint32_t nb, uint32_t *sh) {
     // single workgroup; nb <= a few thousand: serial chunks of 1024
-    __shared__ uint32_t sh[1024];
     uint32_t carry = 0;
     for (uint32_t c0 = 0; c0 < nb; c0 += 1024) {
         const uint32_t i = c0 + threadIdx.x;
@@ -1732,12 +1732,11 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *sh, uint32_t *t
 }
 
 // start of a level: the split list (+ remap level-local -> split-local), the fast / slow lists and the tile table
-__global__ __launch_bounds__(1024) void k_plan_level(LevelInfo *__restrict__ lv, int can_split, int can_fast, uint32_t fs_min_rows, NodeArrays na,
-                                                     uint32_t *__restrict__ lvl_split, uint32_t *__restrict__ remap,
-                                                     uint32_t *__restrict__ fast_nodes, uint32_t *__restrict__ slow_nodes,
-                                                     uint32_t *__restrict__ tile_base, uint32_t *__restrict__ n_tiles_of,
-                                                     FsTile *__restrict__ tiles) {
-    __shared__ uint32_t sh[1024];
+__device__ inline void plan_level_body(LevelInfo *__restrict__ lv, int can_split, int can_fast, uint32_t fs_min_rows, NodeArrays na,
+                                       uint32_t *__restrict__ lvl_split, uint32_t *__restrict__ remap,
+                                       uint32_t *__restrict__ fast_nodes, uint32_t *__restrict__ slow_nodes,
+                                       uint32_t *__restrict__ tile_base, uint32_t *__restrict__ n_tiles_of,
+                                       FsTile *__restrict__ tiles, uint32_t *sh) {
     const uint32_t first = lv->first, count = lv->count;
     uint32_t n_split = 0, n_fast = 0, n_tiles = 0;
     for (uint32_t b = 0; b < count; b += 1024) {
@@ -1792,14 +1791,21 @@ __global__ __launch_bounds__(1024) void k_plan_level(LevelInfo *__restrict__ lv,
         lv->n_tiles = n_tiles;
     }
 }
+__global__ __launch_bounds__(1024) void k_plan_level(LevelInfo *__restrict__ lv, int can_split, int can_fast, uint32_t fs_min_rows, NodeArrays na,
+                                                     uint32_t *__restrict__ lvl_split, uint32_t *__restrict__ remap,
+                                                     uint32_t *__restrict__ fast_nodes, uint32_t *__restrict__ slow_nodes,
+                                                     uint32_t *__restrict__ tile_base, uint32_t *__restrict__ n_tiles_of,
+                                                     FsTile *__restrict__ tiles) {
+    __shared__ uint32_t sh[1024];
+    plan_level_body(lv, can_split, can_fast, fs_min_rows, na, lvl_split, remap, fast_nodes, slow_nodes, tile_base, n_tiles_of, tiles, sh);
+}
 
 // end of a level: children of the split nodes from nleft / nv (src/tsvq.rs:88-108), numbered in order
-__global__ __launch_bounds__(1024) void k_plan_children(LevelInfo *__restrict__ lv, LevelInfo *__restrict__ lv_next,
-                                                        const uint32_t *__restrict__ lvl_split, NodeArrays na,
-                                                        int32_t *__restrict__ node_left, int32_t *__restrict__ node_right,
-                                                        uint32_t dcap, const uint32_t *__restrict__ Pb,
-                                                        const uint32_t *__restrict__ bsums, const uint32_t *__restrict__ flags) {
-    __shared__ uint32_t sh[1024];
+__device__ inline void plan_children_body(LevelInfo *__restrict__ lv, LevelInfo *__restrict__ lv_next,
+                                          const uint32_t *__restrict__ lvl_split, NodeArrays na,
+                                          int32_t *__restrict__ node_left, int32_t *__restrict__ node_right,
+                                          uint32_t dcap, const uint32_t *__restrict__ Pb,
+                                          const uint32_t *__restrict__ bsums, const uint32_t *__restrict__ flags, uint32_t *sh) {
     const uint32_t n_split = lv->n_split, next_first = lv->first + lv->count;
     uint32_t made = 0, err = 0;
     for (uint32_t b = 0; b < n_split; b += 1024) {
@@ -1850,16 +1856,39 @@ __global__ __launch_bounds__(1024) void k_plan_children(LevelInfo *__restrict__ 
         if (next_first + made > dcap) lv->error = 2;
     }
 }
+// The three single-workgroup steps between two levels in ONE launch (each kernel boundary of the build costs ~5 us, and a
+// level had 24 of them): the scan of the partition's block totals and the children of level L's split nodes
+// (src/tsvq.rs:88-108), then -- the children's segment lengths now known -- the plan of level L + 1.  k_scatter runs
+// behind it (it needs nleft / child_local / the scanned totals, not the plan).
+__global__ __launch_bounds__(1024) void k_plan_fused(LevelInfo *__restrict__ lv, LevelInfo *__restrict__ lv_next,
+                                                     uint32_t *__restrict__ lvl_split, NodeArrays na,
+                                                     int32_t *__restrict__ node_left, int32_t *__restrict__ node_right,
+                                                     uint32_t dcap, const uint32_t *__restrict__ Pb, uint32_t *__restrict__ bsums,
+                                                     uint32_t nb, const uint32_t *__restrict__ flags, int next_can_split,
+                                                     int can_fast, uint32_t fs_min_rows, uint32_t *__restrict__ lvl_split_next,
+                                                     uint32_t *__restrict__ remap_next, uint32_t *__restrict__ fast_nodes,
+                                                     uint32_t *__restrict__ slow_nodes, uint32_t *__restrict__ tile_base,
+                                                     uint32_t *__restrict__ n_tiles_of, FsTile *__restrict__ tiles) {
+    __shared__ uint32_t sh[1024];
+    scan_sums_body(bsums, nb, sh);
+    __threadfence();
+    __syncthreads();
+    plan_children_body(lv, lv_next, lvl_split, na, node_left, node_right, dcap, Pb, bsums, flags, sh);
+    __threadfence();
+    __syncthreads();
+    plan_level_body(lv_next, next_can_split, can_fast, fs_min_rows, na, lvl_split_next, remap_next, fast_nodes, slow_nodes, tile_base,
+                    n_tiles_of, tiles, sh);
+}
 
 // ---- host driver of the build ------------------------------------------------------------
 // Device scratch of a build, kept per host thread between builds (their hipMalloc calls were 2-3 ms of a
 // 13 ms build); dropped when it exceeds 1 GiB or the device changes.
 struct TsvqBuildWs {
     int device = -1;
-    DevBuf b_perm[2], b_nodeof[2], b_vals, b_flags, b_scan, b_bsums, b_hist, b_lvl, b_remap;
+    DevBuf b_perm[2], b_nodeof[2], b_vals, b_flags, b_scan, b_bsums, b_hist, b_lvl, b_remap, b_lvl2, b_remap2;
     DevBuf b_seg_start, b_seg_len, b_split, b_nv, b_nleft, b_median, b_selp, b_selr, b_child, b_cent, b_var, b_left, b_right;
     DevBuf b_fs_tiles, b_fs_nodes, b_fs_base, b_fs_nt, b_fs_sum, b_fs_pref, b_fs_summ2, b_fs_summ, b_lvl_slow, b_fs_fb, b_fs_side, b_fs_mom, b_lv;
-    DevBuf *all[37] = {&b_perm[0], &b_perm[1], &b_nodeof[0], &b_nodeof[1], &b_vals, &b_flags, &b_scan, &b_bsums, &b_hist,
+    DevBuf *all[39] = {&b_lvl2, &b_remap2, &b_perm[0], &b_perm[1], &b_nodeof[0], &b_nodeof[1], &b_vals, &b_flags, &b_scan, &b_bsums, &b_hist,
                        &b_lvl, &b_remap, &b_seg_start, &b_seg_len, &b_split, &b_nv, &b_nleft, &b_median, &b_selp, &b_selr,
                        &b_child, &b_cent, &b_var, &b_left, &b_right, &b_fs_tiles, &b_fs_nodes, &b_fs_base, &b_fs_nt, &b_fs_sum, &b_fs_pref, &b_fs_summ2,
                        &b_fs_summ, &b_lvl_slow, &b_fs_fb, &b_fs_side, &b_fs_mom, &b_lv};
@@ -1955,6 +1984,8 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     VQ_TRY(ws.b_bsums.ensure((size_t)nblk * 4));
     VQ_TRY(ws.b_lvl.ensure((size_t)wmax * 4));
     VQ_TRY(ws.b_remap.ensure((size_t)wmax * 4));
+    VQ_TRY(ws.b_lvl2.ensure((size_t)wmax * 4));
+    VQ_TRY(ws.b_remap2.ensure((size_t)wmax * 4));
     VQ_TRY(ws.b_lvl_slow.ensure((size_t)wmax * 4));
     VQ_TRY(ws.b_hist.ensure((size_t)wmax * 2 * 256 * 4));
     VQ_TRY(ws.b_seg_start.ensure((size_t)dcap * 4));
@@ -2032,6 +2063,9 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     VQ_HIP(hipMemsetAsync(ws.b_left.p, 0xFF, (size_t)dcap * 4, stream));
     VQ_HIP(hipMemsetAsync(ws.b_right.p, 0xFF, (size_t)dcap * 4, stream));
     VQ_HIP(hipMemsetAsync(ws.b_fs_fb.p, 0, 8 + 64 * 2 * 64, stream));
+    // the radix-select histograms start at zero and every round's k_select_pick leaves the bins it read at zero again:
+    // one clear per build (it used to be one per level)
+    VQ_HIP(hipMemsetAsync(ws.b_hist.p, 0, (size_t)wmax * 2 * 256 * 4, stream));
     if (adaptive_sampling && n >= fs_min_rows) {
         hipLaunchKernelGGL(k_fs_policy, dim3(n_cblk), dim3(1024), 0, stream, X, n, d, ws.b_fs_fb.as<uint32_t>() + 2 + 64 * 2 * 16);
         VQ_LAUNCH_CHECK("k_fs_policy");
@@ -2049,7 +2083,9 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     marks.mark("setup");
     int cur = 0;
     const uint32_t ncb = (d + kFsCols - 1) / kFsCols;
-    uint32_t *lvl_split = ws.b_lvl.as<uint32_t>(), *remap = ws.b_remap.as<uint32_t>(), *slow_nodes = ws.b_lvl_slow.as<uint32_t>();
+    uint32_t *const lvl_split_buf[2] = {ws.b_lvl.as<uint32_t>(), ws.b_lvl2.as<uint32_t>()};  // by level parity: k_plan_fused writes
+    uint32_t *const remap_buf[2] = {ws.b_remap.as<uint32_t>(), ws.b_remap2.as<uint32_t>()};   // level L + 1's while k_scatter still reads level L's
+    uint32_t *slow_nodes = ws.b_lvl_slow.as<uint32_t>();
     const FsTile *tl = ws.b_fs_tiles.as<FsTile>();
     double *ts = ws.b_fs_sum.as<double>();
     float *tp = ws.b_fs_pref.as<float>();
@@ -2063,10 +2099,10 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     // sequential-order column sums of the level's nodes: long nodes through the tile-parallel exact emulation (k_fs_*),
     // the rest through the plain chain kernel.  Grids are upper bounds; the kernels read the level's counts.
     static const bool fs_debug = getenv("VQHIP_TSVQ_DEBUG") != nullptr;
-    auto colsum = [&](int mode, const LevelInfo *lvp, uint32_t ub_nodes, const uint32_t *perm) -> int {
+    auto colsum = [&](int mode, const LevelInfo *lvp, uint32_t ub_nodes, const uint32_t *perm, bool with_fast) -> int {
         const uint32_t lvl_idx = (uint32_t)(lvp - lv);
         uint32_t *dbg = (fs_debug && lvl_idx < 64) ? fbk + 2 + (lvl_idx * 2 + (uint32_t)mode) * 16 : nullptr;
-        const uint32_t ub_fast = have_fast ? std::min(ub_nodes, fast_max) : 0u;
+        const uint32_t ub_fast = (have_fast && with_fast) ? std::min(ub_nodes, fast_max) : 0u;
         // few nodes: 16 columns per workgroup (more chains in flight); many: 32 (fewer, fuller workgroups)
         const uint32_t g16 = (d + 15) / 16, g32 = (d + 31) / 32;
         static const char *narrow_env = getenv("VQHIP_TSVQ_NARROW_WGS");
@@ -2111,9 +2147,22 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     };
 
     uint32_t levels_run = 0;
+    // Long nodes only get shorter down the tree (a child has fewer rows than its parent), so once a level has none the
+    // seven k_fs_* launches per level can stop -- each empty launch is ~5 us, 130 us of a depth-8 build of 1M rows.  Which
+    // level that is the host learns from ONE small read-back (a synchronisation: ~20 us of idle device) at the first
+    // level where evenly split nodes would be too short, repeated only while long nodes are still found.
+    bool fast_possible = have_fast;
+    uint32_t ask_from = 0;
+    while (ask_from < 31 && (uint64_t)(n >> ask_from) >= fs_min_rows) ++ask_from;
+    static const char *noask_env = getenv("VQHIP_TSVQ_NO_LEVEL_ASK");  // =1: always launch both halves (A/B)
+    hipLaunchKernelGGL(k_plan_level, dim3(1), dim3(1024), 0, stream, &lv[0], max_depth > 0 ? 1 : 0, can_fast ? 1 : 0, fs_min_rows, na, lvl_split_buf[0],
+                       remap_buf[0], ws.b_fs_nodes.as<uint32_t>(), slow_nodes, ws.b_fs_base.as<uint32_t>(), ws.b_fs_nt.as<uint32_t>(),
+                       ws.b_fs_tiles.as<FsTile>());
+    VQ_LAUNCH_CHECK("k_plan_level");
     for (uint32_t L = 0; L < n_levels; ++L) {
         uint32_t ub_nodes = level_width(L);
-        if (ub_nodes > 1024) {
+        const bool ask = fast_possible && L >= ask_from && !(noask_env && noask_env[0] == '1');
+        if (ub_nodes > 1024 || ask) {
             // wide levels: read the level's node count (one small copy + synchronisation) instead of launching the
             // per-node grids over 2^L mostly absent nodes; also ends the loop when the tree has stopped growing
             LevelInfo h;
@@ -2121,29 +2170,23 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             VQ_HIP(hipStreamSynchronize(stream));
             marks.mark("level-sync");
             if (h.count == 0) break;
-            ub_nodes = h.count;
+            ub_nodes = std::min(ub_nodes, h.count);
+            if (h.n_fast == 0) fast_possible = false;
         }
         ++levels_run;
         const LevelInfo *lvp = &lv[L];
-        const bool can_split = L + 1 < n_levels || L < max_depth;  // depth left at this level (src/tsvq.rs:38)
-        const bool splits = L < max_depth;
-        (void)can_split;
+        const bool splits = L < max_depth;  // depth left at this level (src/tsvq.rs:38)
+        uint32_t *lvl_split = lvl_split_buf[L & 1], *remap = remap_buf[L & 1];
         uint32_t *perm = ws.b_perm[cur].as<uint32_t>(), *node_of = ws.b_nodeof[cur].as<uint32_t>();
-        hipLaunchKernelGGL(k_plan_level, dim3(1), dim3(1024), 0, stream, &lv[L], splits ? 1 : 0, can_fast ? 1 : 0, fs_min_rows, na, lvl_split, remap,
-                           ws.b_fs_nodes.as<uint32_t>(), slow_nodes, ws.b_fs_base.as<uint32_t>(), ws.b_fs_nt.as<uint32_t>(),
-                           ws.b_fs_tiles.as<FsTile>());
-        VQ_LAUNCH_CHECK("k_plan_level");
         // means of every node of the level (tsvq.rs:36)
-        VQ_TRY(colsum(0, lvp, ub_nodes, perm));
+        VQ_TRY(colsum(0, lvp, ub_nodes, perm, fast_possible));
         if (!splits) break;
         // variances + split dimension (tsvq.rs:46-66)
-        VQ_TRY(colsum(1, lvp, ub_nodes, perm));
+        VQ_TRY(colsum(1, lvp, ub_nodes, perm, fast_possible));
         hipLaunchKernelGGL(k_pick_split, dim3((ub_nodes + 3) / 4), dim3(256), 0, stream, lvl_split, lvp, d, na);
         VQ_LAUNCH_CHECK("k_pick_split");
-        // median (tsvq.rs:68-81)
         // median (tsvq.rs:68-81): 4-round radix select of the two middle order statistics; the first round gathers the
         // split dimension's values
-        VQ_HIP(hipMemsetAsync(ws.b_hist.p, 0, (size_t)ub_nodes * 2 * 256 * 4, stream));
         {
             const uint32_t hblocks = std::min<uint32_t>((n + 2047) / 2048, (uint32_t)num_cus() * 4);
             const uint32_t hchunk = (n + hblocks - 1) / hblocks;
@@ -2162,15 +2205,16 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
                 VQ_LAUNCH_CHECK("k_select_*");
             }
         }
-        // partition (tsvq.rs:84-85): flags + in-block scan, block totals, children (tsvq.rs:88-108), stable scatter
+        // partition (tsvq.rs:84-85): flags + in-block scan; block totals, children (tsvq.rs:88-108) and the NEXT level's
+        // plan in one launch; stable scatter
         hipLaunchKernelGGL(k_flags_scan, dim3(nblk), dim3(256), 0, stream, ws.b_vals.as<float>(), n, node_of, remap, lvl_split, na,
                            ws.b_flags.as<uint32_t>(), ws.b_scan.as<uint32_t>(), ws.b_bsums.as<uint32_t>());
         VQ_LAUNCH_CHECK("k_flags_scan");
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, stream, ws.b_bsums.as<uint32_t>(), nblk);
-        VQ_LAUNCH_CHECK("k_scan_sums");
-        hipLaunchKernelGGL(k_plan_children, dim3(1), dim3(1024), 0, stream, &lv[L], &lv[L + 1], lvl_split, na, node_left, node_right, dcap,
-                           ws.b_scan.as<uint32_t>(), ws.b_bsums.as<uint32_t>(), ws.b_flags.as<uint32_t>());
-        VQ_LAUNCH_CHECK("k_plan_children");
+        hipLaunchKernelGGL(k_plan_fused, dim3(1), dim3(1024), 0, stream, &lv[L], &lv[L + 1], lvl_split, na, node_left, node_right, dcap,
+                           ws.b_scan.as<uint32_t>(), ws.b_bsums.as<uint32_t>(), nblk, ws.b_flags.as<uint32_t>(), (L + 1 < max_depth) ? 1 : 0,
+                           can_fast ? 1 : 0, fs_min_rows, lvl_split_buf[(L + 1) & 1], remap_buf[(L + 1) & 1], ws.b_fs_nodes.as<uint32_t>(),
+                           slow_nodes, ws.b_fs_base.as<uint32_t>(), ws.b_fs_nt.as<uint32_t>(), ws.b_fs_tiles.as<FsTile>());
+        VQ_LAUNCH_CHECK("k_plan_fused");
         hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, n, perm, node_of, remap, lvl_split, na,
                            ws.b_scan.as<uint32_t>(), ws.b_bsums.as<uint32_t>(), ws.b_flags.as<uint32_t>(), ws.b_perm[cur ^ 1].as<uint32_t>(),
                            ws.b_nodeof[cur ^ 1].as<uint32_t>());
