@@ -34,6 +34,10 @@ sys.path.insert(0, ROOT)
 # BASELINE.md section 3 / SURVEY.md section 8(d)
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md)
+# The bf16x3-split engine forms every fp32 product from SIX bf16 products on the bf16 matrix pipe: the roofline of the
+# kernel that does the work is that pipe's dense rate / 6, in fp32-equivalent (algorithmic) flop
+PEAK_BF16X3_EQUIV_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+CYCLES_PER_ISSUE_LONE_WAVE = 5.3  # profiles/ubench/valu_issue.hip: one wave per SIMD issues an instruction of any kind every 4.4-5.4 cycles
 PEAK_HBM_GBS = 8000.0
 N_PER_GPU, DIM, M, K = 1_000_000, 128, 8, 256
 DATA_SEED, TRAIN_ITERS = 66, 4
@@ -124,12 +128,43 @@ def strided_init(n_global, m, k):
     return np.array([[(j * (n_global // k) + s) % n_global for j in range(k)] for s in range(m)], np.int64)
 
 
-def mfma_roofline(flop, ms, kernel=None, extra=None):
+def pmc_issue_model(kernel_name):
+    """Instruction-issue share of `kernel_name`'s run time from the committed PMC summary: a lone wave per SIMD issues one
+    instruction every ~5.3 cycles whatever its kind, so (instructions per SIMD) x 5.3 cycles against the kernel's own
+    cycle count (GRBM_GUI_ACTIVE, summed over the 8 XCDs) says how much of the kernel is issue slots.  SQ_INSTS_VALU
+    counts the MFMAs too.  Returns a dict or None."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(path)).get(kernel_name.replace(" ", ""))
+            if d and "SQ_INSTS_VALU" in d and "GRBM_GUI_ACTIVE" in d:
+                insts = d["SQ_INSTS_VALU"]["avg_per_launch"] + d.get("SQ_INSTS_SALU", {}).get("avg_per_launch", 0.0)
+                cycles = d["GRBM_GUI_ACTIVE"]["avg_per_launch"] / 8.0
+                return {"instructions_per_launch": insts, "mfma_per_launch": d.get("SQ_INSTS_MFMA", {}).get("avg_per_launch"),
+                        "simds": 1024, "cycles_per_issue": CYCLES_PER_ISSUE_LONE_WAVE, "kernel_cycles": cycles,
+                        "frac_of_kernel": insts / 1024.0 * CYCLES_PER_ISSUE_LONE_WAVE / cycles, "source": os.path.relpath(path, ROOT)}
+        except Exception:
+            continue
+    return None
+
+
+def mfma_roofline(flop, ms, kernel=None, extra=None, engine=3):
+    """`frac` is achieved / the peak of the pipe that does the work, <= 1 by construction: the fp32-equivalent rate of
+    the bf16 matrix pipe for the bf16x3-split engine (engine 3), the fp32 MFMA rate otherwise.  The north star's 40 %
+    target reads against the fp32-MFMA figure: `frac_vs_fp32_mfma_peak` (it can pass 1 for engine 3)."""
     ach = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    r = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-         "frac": ach / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": ms}
+    peak = PEAK_BF16X3_EQUIV_TFLOPS if engine == 3 else PEAK_F32_MFMA_TFLOPS
+    r = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+         "peak_is": ("fp32-equivalent rate of the bf16 matrix pipe: 2500 TFLOP/s dense bf16 / 6 bf16 products per fp32 product (bf16x3 split)"
+                     if engine == 3 else "dense fp32 MFMA"),
+         "frac_vs_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": ms}
     if kernel:
         r["kernel"] = kernel
+        im = pmc_issue_model(kernel)
+        if im:  # the binding resource of the screen: instruction issue of one wave per SIMD
+            im["issue_bound_ms"] = im["frac_of_kernel"] * ms
+            r["issue_bound"] = im
     if extra:
         r.update(extra)
     return r
@@ -142,6 +177,81 @@ def hbm_roofline(nbytes, ms, extra=None):
     if extra:
         r.update(extra)
     return r
+
+
+def eval_shape(_lib, engine):
+    """The reference's own evaluation shape through the HOST API, wall clock: what `make eval ALG=pq` prints upstream
+    (src/bin/eval_pq.rs:42-70 with src/bin/common.rs:9-15: 1M x 384 Uniform[0,1) rows, m = 16, k = 256, 10 iterations,
+    Euclidean, seed 66) -- ProductQuantizer(X_host, ...) with the rows in host memory, then every row quantized to f16
+    in host memory.  Beside it the CPU port (oracle) on a stated subsample, training threaded like the reference (rayon
+    over rows in the assignment), encode on one thread like eval_pq.rs."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O  # cpu leg of this block only
+    from vq_amd import Distance, ProductQuantizer
+
+    n, dim, m, k, iters, seed = 1_000_000, 384, 16, 256, 10, 66
+    X = _lib.synth_uniform_host(n, dim, seed, 0)
+    ProductQuantizer(X[:20000], m, k, 2, Distance.euclidean(), seed, engine=engine)  # code objects, pinned pools
+    t0 = time.perf_counter()
+    pq = ProductQuantizer(X, m, k, iters, Distance.euclidean(), seed, engine=engine)
+    train_ms = (time.perf_counter() - t0) * 1e3
+    pq.quantize_batch(X[:50000])
+    t0 = time.perf_counter()
+    q = pq.quantize_batch(X)
+    quant_ms = (time.perf_counter() - t0) * 1e3
+    sub = slice(0, 100_000)
+    mse = float(np.mean((q[sub].astype(np.float32) - X[sub]) ** 2))
+    t0 = time.perf_counter()
+    codes = pq.encode(X)
+    codes_ms = (time.perf_counter() - t0) * 1e3
+    del q, codes
+    # the device part alone, for the PCIe-inclusive bound: rows already resident
+    ds = _lib.Dataset.from_host(X)
+    from vq_amd.pq import fit_codebooks
+    _lib.synchronize()
+    t0 = time.perf_counter()
+    fit_codebooks(ds, m, k, iters, seed, engine=engine)
+    fit_ms = (time.perf_counter() - t0) * 1e3
+    ds.close()
+    pcie_gbs = 53.0  # measured host -> device rate of this pool's boxes (DESIGN.md 5)
+    bound_ms = n * dim * 4 / (pcie_gbs * 1e9) * 1e3 + fit_ms
+    # CPU port on a subsample (bounded: ~10-20 s)
+    orc = O.get()
+    ns = 50_000
+    Xs = X[:ns]
+    rng = np.random.default_rng(seed)
+    init = np.stack([rng.choice(ns, k, replace=False) for _ in range(m)]).astype(np.uint64)
+    reseed = rng.integers(0, ns, (m, 64)).astype(np.uint64)
+    nt = orc.max_threads()
+    t0 = time.perf_counter()
+    cb_cpu, _ = orc.pq_fit(Xs, m, k, iters, init, reseed, threads=nt)
+    cpu_train_s = time.perf_counter() - t0
+    ne = 20_000
+    t0 = time.perf_counter()
+    orc.pq_encode(O.EUCLIDEAN, X[:ne], cb_cpu, want_f16=True, threads=1)
+    cpu_enc_s = time.perf_counter() - t0
+    del X
+    return {
+        "workload": "src/bin/eval_pq.rs + common.rs:9-15: PQ m=16 k=256 Euclidean, 10 iterations, seed 66, 1M x 384 Uniform[0,1) rows in HOST memory "
+                    "(the package's own SplitMix64 draws: other codebooks than the crate's seed 66, same work)",
+        "rows": n, "dim": dim, "m": m, "k": k, "iters": iters,
+        "train_ms": train_ms, "train_iters_done": [int(x) for x in np.asarray(pq.fit_stats.get("iters", []))][:4],
+        "train_device_fit_ms": fit_ms, "train_bound_ms": bound_ms, "train_over_bound": train_ms / bound_ms,
+        "quantize_batch_ms": quant_ms, "quantize_vectors_per_s": n / (quant_ms * 1e-3),
+        "quantize_host_bytes_per_vector": dim * 4 + dim * 2, "quantize_pcie_gbs": n * (dim * 6) / (quant_ms * 1e-3) / 1e9,
+        "encode_codes_ms": codes_ms, "encode_codes_vectors_per_s": n / (codes_ms * 1e-3),
+        "reconstruction_mse_first_100k_rows": mse,
+        "note": "wall clock around the host API calls, rows in pageable host memory; train_bound_ms = rows over PCIe at 53 GB/s + the fit "
+                "alone on resident rows",
+        "cpu_port": {"kind": "port", "train_rows": ns, "train_s": cpu_train_s, "train_threads": nt,
+                     "train_s_extrapolated_to_1M_rows": cpu_train_s * n / ns,
+                     "encode_rows": ne, "encode_s": cpu_enc_s, "encode_threads": 1,
+                     "encode_s_extrapolated_to_1M_rows": cpu_enc_s * n / ne,
+                     "note": "oracle restatement on the first rows of the same matrix; training assigns over all host threads like rayon "
+                             "(src/core/vector.rs:417-423), encode is one vector at a time on one thread like eval_pq.rs:54-57; linear in rows"},
+    }
 
 
 def other_configs(_lib, torch, engine):
@@ -183,6 +293,7 @@ def other_configs(_lib, torch, engine):
         km_ms = km_dt * 1e3 / km_iters
         km_active = float(it.sum()) / km_iters  # subspaces that executed, averaged over the timed iterations
         km_valid = bool(not paused and int(it.min()) == int(it.max()) == iters)
+        km_engine = _lib.last_assign_stats()[1]
         km.close()
         enc = _lib.PQEncoder(cb, metric)
         enc.set_engine(engine)
@@ -206,13 +317,13 @@ def other_configs(_lib, torch, engine):
             "encode_vectors_per_s": n / (step_ms * 1e-3), "encode_ms_per_step": step_ms,
             "encode_engine": {1: "exact", 2: "fp32_mfma_screen", 3: "bf16x3_mfma_screen"}.get(used, str(used)),
             "recheck_fraction": rechecked / float(n * m),
-            "encode_roofline": mfma_roofline(flop, primary_ms / max(calls, 1), extra={
-                "step_frac": flop / (step_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "encode_roofline": mfma_roofline(flop, primary_ms / max(calls, 1), engine=used, extra={
+                "step_frac": flop / (step_ms * 1e-3) / 1e12 / (PEAK_BF16X3_EQUIV_TFLOPS if used == 3 else PEAK_F32_MFMA_TFLOPS),
                 "recheck_avg_launch_ms": recheck_ms / max(calls, 1), "flop_per_launch": flop}),
             "kmeans_ms_per_iter": km_ms, "kmeans_iter_per_s": 1e3 / km_ms,
             "kmeans_iters_timed": [int(it.min()), int(it.max())], "kmeans_active_subspaces": km_active,
             "kmeans_paused": bool(paused), "kmeans_valid": km_valid,
-            "kmeans_roofline": mfma_roofline(flop * km_active / m, km_ms, extra={
+            "kmeans_roofline": mfma_roofline(flop * km_active / m, km_ms, engine=km_engine, extra={
                 "flop_per_iter": flop * km_active / m,
                 "note": "whole Lloyd iteration (assign + fused update + reduce + finalize), decisions on the device; flop scaled by "
                         "the subspaces that executed"}),
@@ -222,6 +333,8 @@ def other_configs(_lib, torch, engine):
 
     pq_case("C1", 10_000, 64, 4, 16, _lib.EUCLIDEAN, "BASELINE.json configs[0]: PQ m=4 k=16 Euclidean, 10k x 64 (launch-latency bound on a GPU)")
     pq_case("C3", 1_000_000, 768, 96, 256, _lib.COSINE, "BASELINE.json configs[2]: PQ m=96 k=256 cosine, 1M x 768 (training is squared L2, src/core/vector.rs:352-363)")
+
+    out["eval_shape"] = eval_shape(_lib, engine)
 
     # C4: TSVQ depth 8 on 1M x 128
     n, d, depth = 1_000_000, 128, 8
@@ -505,6 +618,7 @@ def measure(args, ranks, wl_name, scaling, *, torch, _lib, engine, ncomm, collec
         shard.close()
         _lib.set_stream(torch.cuda.current_stream().cuda_stream)
     km_dt = ranks.reduce(km_dt, "max")
+    km_engine = _lib.last_assign_stats()[1]  # the engine of the training passes (3 = bf16x3-split MFMA screen)
     km_iters = max(1, int(it.max()))
     # a run that paused on an empty cluster or retired subspaces did less than m subspaces x iterations of work:
     # the per-iteration flop is scaled by the subspaces that really executed
@@ -519,7 +633,7 @@ def measure(args, ranks, wl_name, scaling, *, torch, _lib, engine, ncomm, collec
         "kmeans_counts_sum_per_subspace": [int(counts[0].sum()), int(counts[-1].sum())] if counts is not None else None,
         "kmeans_allreduce_ms": ar_ms,
         "codebooks_abs_sum": float(np.abs(codebooks.astype(np.float64)).sum()),  # same on every rank; ~equal for any sharding
-        "kmeans_roofline": mfma_roofline(flop_row * n * active_avg / m_, km_ms, extra={
+        "kmeans_roofline": mfma_roofline(flop_row * n * active_avg / m_, km_ms, engine=km_engine, extra={
             "flop_per_iter_per_gpu": flop_row * n * active_avg / m_,
             "note": "per GPU: 2*N*k*D flop of one Lloyd iteration (assign + fused update + all-reduce + finalize) x the fraction "
                     "of subspaces that executed / its wall time; X is read once per iteration (4*N*D bytes, SURVEY.md 8(d))"}),
@@ -557,11 +671,10 @@ def measure(args, ranks, wl_name, scaling, *, torch, _lib, engine, ncomm, collec
         "encode_vectors_per_s": n_global * steps / dt, "encode_ms_per_step": step_ms,
         "encode_engine": {1: "exact", 2: "fp32_mfma_screen+exact_recheck", 3: "bf16x3_mfma_screen+exact_recheck"}.get(used_engine, str(used_engine)),
         "recheck_fraction": rechecked / float(max(1, n * m_)),
-        "encode_roofline": mfma_roofline(flop_row * n, kern_ms, kernel=kernel_name, extra={
-            "step_frac": flop_row * n / (step_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        "encode_engine_id": int(used_engine),
+        "encode_roofline": mfma_roofline(flop_row * n, kern_ms, kernel=kernel_name, engine=used_engine, extra={
+            "step_frac": flop_row * n / (step_ms * 1e-3) / 1e12 / (PEAK_BF16X3_EQUIV_TFLOPS if used_engine == 3 else PEAK_F32_MFMA_TFLOPS),
             "recheck_avg_launch_ms": recheck_ms / max(calls, 1), "flop_per_launch": flop_row * n,
-            # the contraction itself runs on the bf16 pipe: 6 bf16 products per algorithmic fp32 product
-            "frac_of_bf16_dense_peak": 6.0 * flop_row * n / (kern_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS if kern_ms > 0 else 0.0,
             "algorithmic_bytes_per_launch": (4.0 * dim + m_) * n}),
         "codes_checksum_rank0": int(codes.to(torch.int64).sum().item()),
     })
@@ -707,6 +820,49 @@ def worker(args) -> int:
             kmc.close()
             dsc.close()
             del Xc
+            # (c) N(0,1) rows (zero-mean, like real embeddings): one encode + one k-means figure with the re-check share
+            Xn = torch.randn((n, dim), device="cuda", generator=g).contiguous()
+            torch.cuda.synchronize()
+            dsn = _lib.Dataset.from_device(Xn.data_ptr(), n, dim)
+            kmn = _lib.KMeans(dsn, m_, k_)
+            kmn.set_engine(engine)
+            init_n = strided_init(n, m_, k_).astype(np.uint64)
+            kmn.init_from_rows(init_n)
+            kmn.run(TRAIN_ITERS)
+            cbn = kmn.get_centroids()
+            kmn.init_from_rows(init_n)
+            kmn.set_active(np.ones(m_, np.uint8))
+            kmn.run(10)
+            kmn.init_from_rows(init_n)
+            kmn.set_active(np.ones(m_, np.uint8))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            itn, _, _, pausedn = kmn.run(10)
+            torch.cuda.synchronize()
+            kmn_ms = (time.perf_counter() - t0) * 1e3 / max(1, int(np.asarray(itn).max()))
+            encn = _lib.PQEncoder(cbn, _lib.SQUARED_EUCLIDEAN)
+            encn.set_engine(engine)
+            for _ in range(2):
+                encn.encode_device(Xn.data_ptr(), n, codes.data_ptr(), None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                encn.encode_device(Xn.data_ptr(), n, codes.data_ptr(), None)
+            torch.cuda.synchronize()
+            enc_n_ms = (time.perf_counter() - t0) * 1e3 / 5
+            rn, en = _lib.last_assign_stats()
+            flop_n = 2.0 * k_ * dim * n
+            extras["normal_data"] = {
+                "rows": "N(0,1), same shape", "encode_vectors_per_s": n / (enc_n_ms * 1e-3), "encode_ms_per_step": enc_n_ms,
+                "recheck_fraction": rn / float(n * m_),
+                "encode_roofline": mfma_roofline(flop_n, enc_n_ms, engine=en, extra={"note": "whole step (screen + re-check), wall time"}),
+                "kmeans_ms_per_iter": kmn_ms, "kmeans_paused": bool(pausedn), "kmeans_iters_timed": [int(np.asarray(itn).min()), int(np.asarray(itn).max())],
+                "kmeans_roofline": mfma_roofline(flop_n * float(np.asarray(itn).sum()) / max(1, int(np.asarray(itn).max())) / m_, kmn_ms, engine=en),
+            }
+            encn.close()
+            kmn.close()
+            dsn.close()
+            del Xn
         enc.close()
         ds.close()
         del codes, keep
@@ -744,10 +900,12 @@ def worker(args) -> int:
         roof = dict(o["encode_roofline"])
         roof.update({
             "note": "achieved = algorithmic 2*k*D flop per row / device time of the screen kernel (HIP events on the "
-                    "launch stream, max over ranks); with the bf16-split engine the contraction runs as 6 bf16 products per fp32 "
-                    "product on the bf16 matrix pipe (frac_of_bf16_dense_peak; frac is against the fp32-MFMA figure the north star names and "
-                    "may exceed 1) and the kernel is instruction-issue-bound (epilogue), see DESIGN.md 4.1; "
-                    "step_frac = the same work over the whole driver-timed step (screen + exact re-check)",
+                    "launch stream, max over ranks); frac = achieved / peak of the pipe that does the work (peak_is): with the "
+                    "bf16x3-split engine every fp32 product is six bf16 products on the bf16 matrix pipe, so the roofline is "
+                    "2500 / 6 TFLOP/s of algorithmic fp32 work; frac_vs_fp32_mfma_peak reads the same rate against the 157.3 TFLOP/s "
+                    "the north star names (its 40 % target) and can pass 1.  The kernel is instruction-issue-bound (issue_bound: "
+                    "one wave per SIMD, ~5.3 cycles per instruction, DESIGN.md 4.1); step_frac = the same work over the whole "
+                    "driver-timed step (screen + exact re-check)",
             "traffic": traffic, "traffic_source": traffic_src})
         line = {
             "metric": "pq_encode_vectors_per_s",
@@ -760,7 +918,7 @@ def worker(args) -> int:
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": ("f32 (bf16x3-split MFMA screen, exact f32 re-check)" if o.get("encode_engine_id") == 3 else "f32"),
             "data": "synthetic",
             "config": {
                 "workload": f"PQ m={m_} k={k_} L2 encode on {o['rows_global']}x{dim} f32 rows in all, {n} on this GPU, device-resident "
