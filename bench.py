@@ -201,6 +201,9 @@ def eval_shape(_lib, engine):
     t0 = time.perf_counter()
     q = pq.quantize_batch(X)
     quant_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    pq.quantize_batch(X, out=q)
+    quant_reuse_ms = (time.perf_counter() - t0) * 1e3
     sub = slice(0, 100_000)
     mse = float(np.mean((q[sub].astype(np.float32) - X[sub]) ** 2))
     t0 = time.perf_counter()
@@ -240,6 +243,8 @@ def eval_shape(_lib, engine):
         "train_ms": train_ms, "train_iters_done": [int(x) for x in np.asarray(pq.fit_stats.get("iters", []))][:4],
         "train_device_fit_ms": fit_ms, "train_bound_ms": bound_ms, "train_over_bound": train_ms / bound_ms,
         "quantize_batch_ms": quant_ms, "quantize_vectors_per_s": n / (quant_ms * 1e-3),
+        "quantize_batch_out_reused_ms": quant_reuse_ms, "quantize_out_reused_vectors_per_s": n / (quant_reuse_ms * 1e-3),
+        "quantize_bound_ms": n * dim * 4 / 55e9 * 1e3,
         "quantize_host_bytes_per_vector": dim * 4 + dim * 2, "quantize_pcie_gbs": n * (dim * 6) / (quant_ms * 1e-3) / 1e9,
         "encode_codes_ms": codes_ms, "encode_codes_vectors_per_s": n / (codes_ms * 1e-3),
         "reconstruction_mse_first_100k_rows": mse,
@@ -792,7 +797,21 @@ def worker(args) -> int:
                 enc.encode(Xh, want_codes=True, want_f16=False)
             extras["encode_host_in_host_out_vectors_per_s"] = nh * 3 / (time.perf_counter() - t0)
             extras["encode_host_rows"] = nh
-            del Xh
+            # the reference-shaped call: rows in host memory, the f16 reconstruction back in host memory (768 B over PCIe
+            # per vector at D = 128: 512 in + 256 out, both directions at once on two lanes below the ABI); into the
+            # caller's own array (out=, pages that exist) and into a fresh array per call (its first touch included)
+            out16 = np.empty((nh, dim), np.float16)
+            enc.encode(Xh, want_codes=False, want_f16=True, out_f16=out16)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                enc.encode(Xh, want_codes=False, want_f16=True, out_f16=out16)
+            extras["encode_host_in_f16_out_vectors_per_s"] = nh * 3 / (time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                enc.encode(Xh, want_codes=False, want_f16=True)
+            extras["encode_host_in_f16_out_fresh_array_vectors_per_s"] = nh * 2 / (time.perf_counter() - t0)
+            extras["encode_host_pcie_bound_vectors_per_s"] = 55e9 / (4.0 * dim)  # rows in at ~55 GB/s, results out concurrently
+            del Xh, out16
             # (b) clustered data once (mixture of K Gaussians around the trained centroids' scale):
             # uniform data is the worst case for near-ties, this is the friendly one
             g = torch.Generator(device="cuda").manual_seed(DATA_SEED)

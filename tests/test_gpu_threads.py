@@ -196,3 +196,35 @@ def test_stats_after_the_handle_died_on_another_thread():
     th.start()
     th.join()
     assert _lib.last_assign_stats() == (0, _lib.ENGINE_MFMA_BF16)
+
+
+def test_large_host_batches_go_through_transfer_lanes(oracle):
+    """host batches of 48 MB and more are cut into chunks that four host threads of the LIBRARY carry end to end (pinned
+    staging, H2D, kernels, D2H) through one encoder handle: same bits as the one-stream path and as the oracle; the
+    data-set upload takes the same lanes"""
+    import vq_amd as pyvq
+
+    rng = np.random.default_rng(17)
+    m, k, sd = 8, 256, 16
+    n = 230_000  # 118 MB of rows: several chunks per lane, a ragged last one
+    cb = _codebooks(rng, m, k, sd)
+    X = rng.random((n, m * sd), dtype=F)
+    want_c, want_f = oracle.pq_encode(O.EUCLIDEAN, X, cb, threads=8)
+    enc = _lib.PQEncoder(cb, _lib.EUCLIDEAN)
+    codes, f16 = enc.encode(X)
+    assert np.array_equal(codes.astype(np.uint32), want_c) and np.array_equal(f16.view(np.uint16), want_f)
+    rechecked, engine = _lib.last_assign_stats()
+    assert engine == _lib.ENGINE_MFMA_BF16
+    only_f16 = enc.encode(X, want_codes=False)[1]
+    assert np.array_equal(only_f16.view(np.uint16), want_f)
+    only_codes = enc.encode(X, want_f16=False)[0]
+    assert np.array_equal(only_codes.astype(np.uint32), want_c)
+    ds = _lib.Dataset.from_host(X)
+    assert np.array_equal(ds.read(), X)
+    tree = oracle.tsvq_build(X[:20000, :32].copy(), 6)
+    t = pyvq.TSVQ.from_tree(tree["centroids"], tree["left"], tree["right"], pyvq.Distance.euclidean())
+    Y = rng.random((400_000, 32), dtype=F)  # 51 MB
+    want_l, want_t = oracle.tsvq_encode(O.EUCLIDEAN, Y, tree, threads=8)
+    assert np.array_equal(t.leaf_ids(Y), want_l)
+    assert np.array_equal(t.quantize_batch(Y).view(np.uint16), want_t)
+    ds.close()

@@ -10,6 +10,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "kernels.hpp"
@@ -561,6 +562,109 @@ struct PinnedStage {
 };
 constexpr uint64_t kSmallRows = 8;  // calls with at most this many host rows take the one-kernel path
 
+// ------------------------------------------------- host <-> device streaming for large batches ----
+// What this pool's boxes deliver (profiles/ubench/pcie_duplex.hip, tools/host_xfer.py): a copy between device memory
+// and host pages that have been touched runs at 55-57 GB/s each way whether the pages are pinned or not, both ways at
+// once if TWO host threads issue them (a pageable copy occupies its thread); staging through pinned buffers with host
+// memcpys (29 GB/s per thread) only loses (measured: 4 lanes of pinned staging 6.1e7 vectors/s against 7.1e7 for the
+// plain copies in turn, rows in / f16 out at 1M x 128).  So a large host batch whose results are a sizeable share of
+// its input goes through two LANES: two host threads, each with its own stream and device buffers, take alternate
+// chunks end to end -- H2D straight from the caller's rows, the kernels (the handle orders the lanes' launches on the
+// device: HandleSync), D2H straight into the caller's buffers -- so one lane's results travel while the other lane's rows do.
+struct XferLane {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    DevBuf dev_in, dev_out, dev_out2;
+    int ensure() {
+        if (!stream) VQ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return VQHIP_OK;
+    }
+};
+constexpr int kXferLanesMax = 8;
+static int xfer_lanes() {  // host threads per large transfer (VQHIP_XFER_LANES, 1..8; A/B)
+    static const int v = [] {
+        const char *e = getenv("VQHIP_XFER_LANES");
+        const int x = e ? atoi(e) : 2;
+        return x < 1 ? 1 : (x > kXferLanesMax ? kXferLanesMax : x);
+    }();
+    return v;
+}
+static size_t xfer_chunk_bytes() {  // bytes of input per chunk (VQHIP_XFER_CHUNK_MB; A/B)
+    static const size_t v = [] {
+        const char *e = getenv("VQHIP_XFER_CHUNK_MB");
+        const int x = e ? atoi(e) : 32;
+        return (size_t)(x < 1 ? 1 : (x > 1024 ? 1024 : x)) << 20;
+    }();
+    return v;
+}
+constexpr size_t kXferMinBytes = (size_t)96 << 20;  // smaller batches keep the one-stream path (two host threads to start)
+// lanes pay when the results are at least a quarter of the rows in bytes (f16 reconstructions); codes alone are 1-6 %
+static bool xfer_lanes_pay(size_t in_b, size_t out_b) {
+    static const char *no_lanes = getenv("VQHIP_NO_XFER_LANES");  // =1: one stream, copies and kernels in turn (A/B)
+    return in_b >= kXferMinBytes && 4 * out_b >= in_b && !(no_lanes && no_lanes[0] == '1');
+}
+struct XferPool {  // leaked on purpose, like StagePool
+    std::mutex mu;
+    std::vector<XferLane *> idle;
+};
+static XferPool &xfer_pool() {
+    static XferPool *p = new XferPool();
+    return *p;
+}
+// fn(lane index, lane, lanes) on that many host threads (each bound to the caller's device); the first failure's status
+// and text come back on the calling thread
+template <class Fn>
+static int run_lanes(Fn fn) {
+    int dev = 0;
+    VQ_HIP(hipGetDevice(&dev));
+    const int n_lanes = xfer_lanes();
+    XferLane *lanes[kXferLanesMax] = {};
+    {
+        XferPool &p = xfer_pool();
+        std::lock_guard<std::mutex> lk(p.mu);
+        int got = 0;
+        for (size_t i = 0; i < p.idle.size() && got < n_lanes;)
+            if (p.idle[i]->device == dev) {
+                lanes[got++] = p.idle[i];
+                p.idle.erase(p.idle.begin() + (long)i);
+            } else {
+                ++i;
+            }
+        for (; got < n_lanes; ++got) {
+            lanes[got] = new XferLane();
+            lanes[got]->device = dev;
+        }
+    }
+    int rcs[kXferLanesMax];
+    std::string errs[kXferLanesMax];
+    std::thread th[kXferLanesMax];
+    for (int t = 0; t < n_lanes; ++t)
+        th[t] = std::thread([&, t] {
+            rcs[t] = VQHIP_OK;
+            if (hipSetDevice(dev) != hipSuccess) {
+                rcs[t] = VQHIP_ERR_RUNTIME;
+                errs[t] = "hipSetDevice failed on a transfer lane";
+                return;
+            }
+            rcs[t] = lanes[t]->ensure();
+            if (rcs[t] == VQHIP_OK) {
+                ThreadState &st = tls();
+                st.user_stream = lanes[t]->stream, st.user_stream_set = true;  // this thread's launches go to the lane's stream
+                rcs[t] = fn(t, *lanes[t], n_lanes);
+            }
+            if (rcs[t] != VQHIP_OK) errs[t] = tls().last_error;
+        });
+    for (int t = 0; t < n_lanes; ++t) th[t].join();
+    {
+        XferPool &p = xfer_pool();
+        std::lock_guard<std::mutex> lk(p.mu);
+        for (int t = 0; t < n_lanes; ++t) p.idle.push_back(lanes[t]);
+    }
+    for (int t = 0; t < n_lanes; ++t)
+        if (rcs[t] != VQHIP_OK) return fail(rcs[t], "%s", errs[t].c_str());
+    return VQHIP_OK;
+}
+
 // The per-vector path stages through a buffer that belongs to the CALL, not to the handle: `quantize(&self)` from many
 // threads on one quantizer then overlaps on the device (each thread its own stream and staging) instead of queueing on
 // the handle's lock.  Buffers are pooled per device and never returned to the runtime (64 KB each, as many as there
@@ -992,6 +1096,8 @@ int vqhip_dataset_from_host(const float *rows, uint64_t n, uint32_t d, vqhip_dat
         delete ds;
         return rc;
     }
+    // ONE copy straight from the caller's pages: 54.7 GB/s here (tools/host_xfer.py), 0.96 of what pinned memory gives;
+    // staging through pinned buffers on several host threads was measured slower (45.9 GB/s: the host memcpys)
     hipError_t e = hipMemcpyAsync(ds->own.p, rows, (size_t)n * d * 4, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
@@ -1845,6 +1951,41 @@ int vqhip_pq_encode(vqhip_pq_encoder *enc, const float *rows, uint64_t n, uint8_
         g_last_ws = 0;
         return VQHIP_OK;
     }
+    if (xfer_lanes_pay((size_t)n * d * 4, (codes ? (size_t)n * m * cw : 0) + (f16_out ? (size_t)n * d * 2 : 0))) {
+        // large host batch with the f16 reconstruction coming back: alternate chunks on two lanes (see XferLane), so the
+        // results of one chunk travel while the rows of the next do.  The lanes call vqhip_pq_encode_device themselves,
+        // from their own threads: this call gives the handle back first (its lock is per thread; whatever it still has
+        // queued stays its tail) and the handle orders the lanes' launches.
+        in.release();
+        const size_t row_b = (size_t)d * 4;
+        const uint64_t per = std::max<uint64_t>(1, xfer_chunk_bytes() / row_b), chunks = (n + per - 1) / per;
+        std::mutex h2d_turn;  // one lane's rows on the bus at a time: the lanes stay out of phase (both copying in, then both out, overlaps nothing: 13.3 against 10.6 ms)
+        const int rc_lanes = run_lanes([&](int t, XferLane &ln, int n_lanes) -> int {
+            VQ_TRY(ln.dev_in.ensure((size_t)per * row_b));
+            VQ_TRY(ln.dev_out.ensure((size_t)per * m * cw));
+            if (f16_out) VQ_TRY(ln.dev_out2.ensure((size_t)per * d * 2));
+            for (uint64_t c = (uint64_t)t; c < chunks; c += (uint64_t)n_lanes) {
+                const uint64_t r0 = c * per, nr = std::min(per, n - r0);
+                {
+                    std::lock_guard<std::mutex> turn(h2d_turn);
+                    VQ_HIP(hipMemcpyAsync(ln.dev_in.p, rows + r0 * d, (size_t)nr * row_b, hipMemcpyHostToDevice, ln.stream));
+                    VQ_HIP(hipStreamSynchronize(ln.stream));
+                }
+                VQ_TRY(vqhip_pq_encode_device(enc, ln.dev_in.p, nr, ln.dev_out.p, f16_out ? ln.dev_out2.p : nullptr));
+                if (codes) VQ_HIP(hipMemcpyAsync(codes + r0 * m * cw, ln.dev_out.p, (size_t)nr * m * cw, hipMemcpyDeviceToHost, ln.stream));
+                if (f16_out) VQ_HIP(hipMemcpyAsync(f16_out + r0 * d, ln.dev_out2.p, (size_t)nr * d * 2, hipMemcpyDeviceToHost, ln.stream));
+                VQ_HIP(hipStreamSynchronize(ln.stream));
+            }
+            return VQHIP_OK;
+        });
+        // "the most recent pass of this thread" for vqhip_last_assign_stats: the lanes' passes were this call's
+        g_last_ws = enc->ws_id;
+        {
+            std::lock_guard<std::recursive_mutex> lk(enc->sync.mu);
+            tls().last_engine = enc->ws.last_engine;
+        }
+        return rc_lanes;
+    }
     // bounded staging: at most ~1 GiB of rows per pass
     uint64_t chunk = std::max<uint64_t>(1, (1ull << 30) / ((uint64_t)d * 4));
     if (chunk > n) chunk = n;
@@ -2140,6 +2281,30 @@ int vqhip_tsvq_encode(vqhip_tsvq *t, const float *rows, uint64_t n, int32_t *lea
         if (leaf) memcpy(leaf, hb + in_b, (size_t)n * 4);
         if (f16_out) memcpy(f16_out, hb + in_b + leaf_b, f16_b);
         return VQHIP_OK;
+    }
+    if (xfer_lanes_pay((size_t)n * d * 4, (leaf ? (size_t)n * 4 : 0) + (f16_out ? (size_t)n * d * 2 : 0))) {  // two lanes, as vqhip_pq_encode
+        in.release();
+        const size_t row_b = (size_t)d * 4;
+        const uint64_t per = std::max<uint64_t>(1, xfer_chunk_bytes() / row_b), chunks = (n + per - 1) / per;
+        std::mutex h2d_turn;
+        return run_lanes([&](int tl, XferLane &ln, int n_lanes) -> int {
+            VQ_TRY(ln.dev_in.ensure((size_t)per * row_b));
+            VQ_TRY(ln.dev_out.ensure((size_t)per * 4));
+            if (f16_out) VQ_TRY(ln.dev_out2.ensure((size_t)per * d * 2));
+            for (uint64_t c = (uint64_t)tl; c < chunks; c += (uint64_t)n_lanes) {
+                const uint64_t r0 = c * per, nr = std::min(per, n - r0);
+                {
+                    std::lock_guard<std::mutex> turn(h2d_turn);
+                    VQ_HIP(hipMemcpyAsync(ln.dev_in.p, rows + r0 * d, (size_t)nr * row_b, hipMemcpyHostToDevice, ln.stream));
+                    VQ_HIP(hipStreamSynchronize(ln.stream));
+                }
+                VQ_TRY(vqhip_tsvq_encode_device(t, ln.dev_in.p, nr, ln.dev_out.p, f16_out ? ln.dev_out2.p : nullptr));
+                if (leaf) VQ_HIP(hipMemcpyAsync(leaf + r0, ln.dev_out.p, (size_t)nr * 4, hipMemcpyDeviceToHost, ln.stream));
+                if (f16_out) VQ_HIP(hipMemcpyAsync(f16_out + r0 * d, ln.dev_out2.p, (size_t)nr * d * 2, hipMemcpyDeviceToHost, ln.stream));
+                VQ_HIP(hipStreamSynchronize(ln.stream));
+            }
+            return VQHIP_OK;
+        });
     }
     uint64_t chunk = std::max<uint64_t>(1, (1ull << 30) / ((uint64_t)d * 4));
     if (chunk > n) chunk = n;
