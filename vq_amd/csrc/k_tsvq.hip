@@ -452,23 +452,44 @@ __global__ __launch_bounds__(256) void k_flags_scan(const float *__restrict__ va
     if (threadIdx.x == 255) block_sums[blockIdx.x] = sh[255];
 }
 // (body shared with the fused per-level planner k_plan_fused: one workgroup of 1024 threads, `sh` its 4 KB of LDS)
+// exclusive scan of one value per thread over the workgroup (1024 threads); returns the total.  Wave scans through
+// ds_bpermute plus one scan of the 16 wave totals: three barriers (the 10-step LDS scan it replaces had thirty, and the
+// planner runs five such scans per level: 23 us per level for what is a few hundred additions)
+__device__ inline uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)v, off);
+        if ((int)lane >= off) v += u;
+    }
+    return v;
+}
+__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *sh, uint32_t *total) {
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t incl = wave_incl_scan_u32(v, lane);
+    if (lane == 63u) sh[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t w = lane < 16u ? sh[lane] : 0u;
+        const uint32_t wi = wave_incl_scan_u32(w, lane);
+        if (lane < 16u) sh[32 + lane] = wi - w;  // exclusive offset of wave `lane`
+        if (lane == 15u) sh[48] = wi;
+    }
+    __syncthreads();
+    const uint32_t base = sh[32 + wave];
+    *total = sh[48];
+    __syncthreads();  // sh is free again for the caller's next scan
+    return base + incl - v;
+}
+
 __device__ inline void scan_sums_body(uint32_t *__restrict__ block_sums, uint32_t nb, uint32_t *sh) {
     // single workgroup; nb <= a few thousand: serial chunks of 1024
     uint32_t carry = 0;
     for (uint32_t c0 = 0; c0 < nb; c0 += 1024) {
         const uint32_t i = c0 + threadIdx.x;
         const uint32_t v = (i < nb) ? block_sums[i] : 0u;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            uint32_t t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0u;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < nb) block_sums[i] = carry + sh[threadIdx.x] - v;
-        const uint32_t tot = sh[1023];
-        __syncthreads();
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, sh, &tot);
+        if (i < nb) block_sums[i] = carry + ex;
         carry += tot;
     }
 }
@@ -901,19 +922,22 @@ __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ 
 // column), and sum over the tile of (x - mu)^2 = S2 - 2 mu S1 + rows mu^2, in f64 (the f32 block sums behind S1 / S2 make
 // it good to ~1e-7 (1 + mu^2 / sigma^2) relative: ample for a binade guess unless the offset dwarfs the spread, where
 // it merely costs re-additions).
+constexpr uint32_t kFsPrefCols = 8, kFsPrefChunks = 1024 / kFsPrefCols;
 template <bool VAR>
 __global__ __launch_bounds__(1024) void k_fs_prefix(uint32_t d, const uint32_t *__restrict__ fast_nodes, const uint32_t *__restrict__ tile_base,
                                                     const uint32_t *__restrict__ n_tiles_of, NodeArrays na, const double *__restrict__ tile_sum,
                                                     const double2 *__restrict__ tile_mom,
                                                     float *__restrict__ tile_pref, const LevelInfo *__restrict__ lv,
                                                     uint32_t *__restrict__ side_count) {
-    __shared__ double part[32][kFsCols + 1];
+    // 8 columns x 128 chunks of tiles per workgroup (it was 32 x 32: at the root that is d / 32 = 4 workgroups walking
+    // 61 tiles per thread twice -- 45 us of memory round trips on an otherwise idle chip)
+    __shared__ double part[kFsPrefChunks][kFsPrefCols + 1];
     // the side buffer's slot counter of this pass (k_fs_fold hands slots out; the previous pass's chain is done)
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *side_count = 0u;
     if (blockIdx.x >= lv->n_fast) return;
-    const uint32_t c = blockIdx.y * kFsCols + (threadIdx.x & 31), lt = threadIdx.x >> 5;
+    const uint32_t cl = threadIdx.x % kFsPrefCols, c = blockIdx.y * kFsPrefCols + cl, lt = threadIdx.x / kFsPrefCols;
     const uint32_t base = tile_base[blockIdx.x], nt = n_tiles_of[blockIdx.x];
-    const uint32_t chunk = (nt + 31) / 32, t0 = lt * chunk, t1 = min(nt, t0 + chunk);
+    const uint32_t chunk = (nt + kFsPrefChunks - 1) / kFsPrefChunks, t0 = min(nt, lt * chunk), t1 = min(nt, t0 + chunk);
     const bool col_ok = c < d;
     const uint32_t node = fast_nodes[blockIdx.x], len = na.seg_len[node];
     const double mu = (VAR && col_ok) ? (double)na.centroid[(size_t)node * d + c] : 0.0;
@@ -933,11 +957,11 @@ __global__ __launch_bounds__(1024) void k_fs_prefix(uint32_t d, const uint32_t *
 #pragma unroll
             for (uint32_t u = 0; u < 8; ++u) local += v[u];
         }
-    part[lt][threadIdx.x & 31] = local;
+    part[lt][cl] = local;
     __syncthreads();
     if (!col_ok) return;
     double run = 0.0;
-    for (uint32_t q = 0; q < lt; ++q) run += part[q][threadIdx.x & 31];
+    for (uint32_t q = 0; q < lt; ++q) run += part[q][cl];
     for (uint32_t t = t0; t < t1; t += 8) {
         double v[8];
 #pragma unroll
@@ -1714,23 +1738,6 @@ int launch_tsvq_gather_table(const uint16_t *table, uint32_t d, const int32_t *l
 // tile table looks like -- one stream synchronisation and ~15 small uploads per level (1.4 of 8.6 ms at 1M x 128,
 // depth 8).  Two single-workgroup kernels do it on the device instead; the host only launches, over upper bounds.
 
-// exclusive scan of one value per thread over the workgroup (1024 threads); returns the total
-__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *sh, uint32_t *total) {
-    const uint32_t t = threadIdx.x;
-    sh[t] = v;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        const uint32_t add = (t >= off) ? sh[t - off] : 0u;
-        __syncthreads();
-        sh[t] += add;
-        __syncthreads();
-    }
-    const uint32_t incl = sh[t];
-    *total = sh[1023];
-    __syncthreads();
-    return incl - v;
-}
-
 // start of a level: the split list (+ remap level-local -> split-local), the fast / slow lists and the tile table
 __device__ inline void plan_level_body(LevelInfo *__restrict__ lv, int can_split, int can_fast, uint32_t fs_min_rows, NodeArrays na,
                                        uint32_t *__restrict__ lvl_split, uint32_t *__restrict__ remap,
@@ -1768,14 +1775,21 @@ __device__ inline void plan_level_body(LevelInfo *__restrict__ lv, int can_split
     }
     __threadfence();
     __syncthreads();
-    // tile table: tile T belongs to the fast node f with tile_base[f] <= T < tile_base[f] + nt[f]
+    // tile table: tile T belongs to the fast node f with tile_base[f] <= T < tile_base[f] + nt[f].  The search runs on a
+    // copy of tile_base in LDS when it fits (the usual case: a handful of long nodes): five dependent global loads per tile
+    // were half of this kernel's 20 us
+    const bool in_lds = n_fast <= 1024u;
+    if (in_lds) {
+        if (threadIdx.x < n_fast) sh[threadIdx.x] = tile_base[threadIdx.x];
+        __syncthreads();
+    }
     for (uint32_t T = threadIdx.x; T < n_tiles; T += 1024) {
         uint32_t lo = 0, hi = n_fast;  // last f with tile_base[f] <= T
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (tile_base[mid] <= T) lo = mid; else hi = mid;
+            if ((in_lds ? sh[mid] : tile_base[mid]) <= T) lo = mid; else hi = mid;
         }
-        const uint32_t node = fast_nodes[lo], t = T - tile_base[lo];
+        const uint32_t node = fast_nodes[lo], t = T - (in_lds ? sh[lo] : tile_base[lo]);
         const uint32_t len = na.seg_len[node];
         FsTile tl;
         tl.node = node;
@@ -1843,14 +1857,9 @@ __device__ inline void plan_children_body(LevelInfo *__restrict__ lv, LevelInfo 
         }
         made += tot;
     }
-    sh[threadIdx.x] = err;
-    __syncthreads();
-    for (uint32_t off = 512; off > 0; off >>= 1) {
-        if (threadIdx.x < off) sh[threadIdx.x] |= sh[threadIdx.x + off];
-        __syncthreads();
-    }
+    const int any_err = __syncthreads_or((int)err);
     if (threadIdx.x == 0) {
-        if (sh[0]) lv->error = 1;
+        if (any_err) lv->error = 1;
         lv_next->first = next_first;
         lv_next->count = (next_first + made <= dcap) ? made : 0u;  // cannot happen (dcap bounds the tree); no overrun if it did
         if (next_first + made > dcap) lv->error = 2;
@@ -2120,7 +2129,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         const uint32_t ub_tiles = std::min(tiles_max, n / kFsTile + ub_fast);
         // k_fs_fold: persistent single-wave workgroups, two per SIMD (the kernel's register budget)
         const dim3 tgrid(ub_tiles * ncb), xgrid(std::min<uint32_t>(ub_tiles * ncb, (uint32_t)num_cus() * 8));
-        const dim3 pgrid(ub_fast, ncb), cgrid(ub_fast, d);
+        const dim3 pgrid(ub_fast, (d + kFsPrefCols - 1) / kFsPrefCols), cgrid(ub_fast, d);
         if (mode == 0) {
             // the binade guesses: f64 sums of every 8th group of rows of each tile where k_fs_policy allows (|mean| >= sigma),
             // of every row elsewhere; prefix over the node's tiles
