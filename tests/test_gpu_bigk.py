@@ -71,7 +71,8 @@ def test_encode_bit_exact(oracle, shape, kind, metric, engine):
     codes, f16 = enc.encode(X)
     assert codes.dtype == np.uint16 and codes.shape == (n, m)
     rechecked, used = _lib.last_assign_stats()
-    screened = engine == _lib.ENGINE_AUTO and metric != O.MANHATTAN and _x32_groups(d // m, k) > 0
+    # AUTO: the screen where the shape has one -- unless the whole pass is so little work that the one-launch exact scan wins
+    screened = (engine == _lib.ENGINE_AUTO and metric != O.MANHATTAN and _x32_groups(d // m, k) > 0 and n * m * k * (d // m) > 32e6)
     if _lib.selftest()[2]:
         assert used == (_lib.ENGINE_MFMA_BF16 if screened else _lib.ENGINE_EXACT)
     if used == _lib.ENGINE_MFMA_BF16 and kind == "uniform" and metric != O.COSINE:

@@ -237,7 +237,8 @@ def test_encode_cosine_screen_bit_exact(oracle, shape, kind):
     if kind in ("uniform", "normal"):
         assert rechecked < 0.2 * n * m     # the screen decides most rows
     _check_encode(oracle, X, cb, O.COSINE, _lib.ENGINE_AUTO)
-    assert _check_encode.last_stats[1] == _lib.ENGINE_MFMA_BF16
+    # AUTO: the screen, unless the whole pass is so little work (n m k sub_dim <= 32M) that the one-launch exact scan wins
+    assert _check_encode.last_stats[1] == (_lib.ENGINE_EXACT if n * m * k * (d // m) <= 32e6 else _lib.ENGINE_MFMA_BF16)
 
 
 def test_encode_cosine_screen_adversarial(oracle):
@@ -350,7 +351,8 @@ def test_encode_adversarial_near_ties(oracle):
             j = rng.integers(0, k)
             X[i, s * sd:(s + 1) * sd] = cb[s, j] + (1e-3 * rng.standard_normal(sd)).astype(F)
     for metric in (O.SQUARED_EUCLIDEAN, O.EUCLIDEAN):
-        _check_encode(oracle, X, cb, metric, _lib.ENGINE_AUTO)
+        _check_encode(oracle, X, cb, metric, _lib.ENGINE_AUTO)  # (this little work: the exact scan, one launch)
+        _check_encode(oracle, X, cb, metric, _lib.ENGINE_MFMA_BF16)
     rechecked, engine = _check_encode.last_stats
     assert engine in (_lib.ENGINE_MFMA, _lib.ENGINE_MFMA_BF16) and rechecked > 0
 

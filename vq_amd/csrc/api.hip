@@ -295,6 +295,12 @@ static int run_assign(CodebookState &cs, AssignWorkspace &ws, const float *X, ui
     if (engine == VQHIP_ENGINE_MFMA_BF16 && engine_req == VQHIP_ENGINE_AUTO && cs.k > 256 &&
         (size_t)cs.m * cs.x32_groups * n * 16 > ((size_t)4 << 30))
         engine = VQHIP_ENGINE_EXACT;
+    // small work (C1's encode: 10k rows x 4 subspaces x 16 centroids x 16 dimensions): the exact scan is one launch of a
+    // few microseconds, the screen is two (+ its codebook images) -- launch latency is all there is at that size
+    static const char *small_exact_env = getenv("VQHIP_SMALL_EXACT");  // =0: never (A/B)
+    if (engine_req == VQHIP_ENGINE_AUTO && engine != VQHIP_ENGINE_EXACT && !(fused && fused->sums) &&
+        (double)n * cs.m * cs.k * cs.sd <= 32.0e6 && !(small_exact_env && small_exact_env[0] == '0'))
+        engine = VQHIP_ENGINE_EXACT;
     const bool x32_only = engine == VQHIP_ENGINE_MFMA_BF16 && cs.x32_groups == 1 && x32_padded_sd(cs.sd) <= 64 &&
                           (metric == VQHIP_SQUARED_EUCLIDEAN || metric == VQHIP_EUCLIDEAN) && cs.metric != VQHIP_COSINE;
     VQ_TRY(cs.prepare(stream, !x32_only));
@@ -508,6 +514,7 @@ struct vqhip_kmeans {
     UpdatePlan plan;
     DevBuf codes, partial_sums, partial_counts, slab, counts, changed, active_dev, rows_tmp, xs_ws, gather_ws;
     DevBuf agree;      // two words the ranks of a sharded run all-reduce before anything is queued
+    DevBuf sm_psum, sm_pcnt, sm_tick;  // k_lloyd_small.hip: partials per 64-row range, the two flag sets of a device-driven run
     DevBuf run_state;  // vqhip_kmeans_run: [0] halt flag, [1 .. m] iterations executed per subspace, [m+1], [m+2] k_finalize's own
     std::vector<uint8_t> active;
     bool all_active = true;
@@ -1323,6 +1330,51 @@ int vqhip_kmeans_set_exact_update(vqhip_kmeans *km, int exact_update) {
     return VQHIP_OK;
 }
 
+// A small problem's iteration is TWO launches (k_lloyd_small.hip) wherever the whole loop body runs on this device: the
+// single-GPU vqhip_kmeans_step / vqhip_kmeans_run; the split accumulate / all-reduce / finalize forms run the same
+// kernels up to the f64 slab and k_finalize behind it, with the same bits.  Against the general path (VQHIP_SMALL_LLOYD=0)
+// codes, counts and flags are equal bit for bit; the means differ in the last bits (other row ranges behind the f64
+// combination), both inside the tolerance DESIGN.md 2 states.
+static bool kmeans_small_eligible(const vqhip_kmeans *km) {
+    static const char *env = getenv("VQHIP_SMALL_LLOYD");  // =0: never (A/B)
+    if (env && env[0] == '0') return false;
+    return km->engine == VQHIP_ENGINE_AUTO && !km->exact_update && !km->sums_by_chains && !g_prof.on &&
+           lloyd_small_supported(km->ds->n, km->cs.m, km->cs.k, km->cs.sd);
+}
+static int kmeans_small_workspace(vqhip_kmeans *km, hipStream_t s) {
+    const uint32_t m = km->cs.m, k = km->cs.k, sd = km->cs.sd;
+    if (!km->sm_tick.p) {
+        size_t cnt_b = 0, tick_b = 0;
+        const size_t sum_b = lloyd_small_workspace(km->ds->n, m, k, sd, &cnt_b, &tick_b);
+        VQ_TRY(km->sm_psum.alloc(sum_b));
+        VQ_TRY(km->sm_pcnt.alloc(cnt_b));
+        VQ_TRY(km->sm_tick.alloc(tick_b));
+        VQ_HIP(hipMemsetAsync(km->sm_tick.p, 0, tick_b, s));
+    }
+    return VQHIP_OK;
+}
+static void kmeans_small_note(vqhip_kmeans *km) {  // host-side state behind a small-path launch
+    km->ws.stats_pending = false;
+    km->ws.last_engine = VQHIP_ENGINE_EXACT;
+    ThreadState &st = tls();
+    st.last_engine = VQHIP_ENGINE_EXACT;
+    st.last_rechecked = 0;
+    g_last_ws = km->ws_id;
+}
+// run: iteration `it` of a device-driven run (its flags behind sm_tick, the iterations executed in run_state[1 .. m])
+static int kmeans_small_enqueue(vqhip_kmeans *km, hipStream_t s, bool run, uint32_t it = 0) {
+    const uint32_t m = km->cs.m, k = km->cs.k, sd = km->cs.sd;
+    VQ_TRY(kmeans_small_workspace(km, s));
+    const uint8_t *act = run ? km->active_dev.as<uint8_t>() : (km->all_active ? nullptr : km->active_dev.as<uint8_t>());
+    VQ_TRY(launch_lloyd_small(km->ds->X, km->ds->n, km->ds->d, m, k, sd, km->cs.cb.as<float>(), km->codes.as<uint8_t>(),
+                              km->sm_psum.as<float>(), km->sm_pcnt.as<uint32_t>(), km->counts.as<uint32_t>(), km->changed.as<uint32_t>(),
+                              act, run ? km->sm_tick.as<uint32_t>() : nullptr, run ? km->run_state.as<uint32_t>() + 1 : nullptr, it, s));
+    km->cs.prepared = false;
+    km->accumulated = false;
+    kmeans_small_note(km);
+    return VQHIP_OK;
+}
+
 // queue assign + update of one Lloyd iteration on `s` (no host synchronisation: capturable); gated: inside a
 // device-driven run (vqhip_kmeans_run) every kernel that changes state checks the run's device flags
 static int kmeans_accumulate_enqueue(vqhip_kmeans *km, hipStream_t s, bool gated = false) {
@@ -1331,6 +1383,16 @@ static int kmeans_accumulate_enqueue(vqhip_kmeans *km, hipStream_t s, bool gated
         if (km->active[i]) subs.push_back(i);
     const vqhip_dataset *ds = km->ds;
     g_last_ws = km->ws_id;
+    if (kmeans_small_eligible(km)) {  // small problem: assignment + this rank's f64 slab in one launch (k_lloyd_small.hip)
+        VQ_TRY(kmeans_small_workspace(km, s));
+        const uint8_t *act = gated ? km->active_dev.as<uint8_t>() : (km->all_active ? nullptr : km->active_dev.as<uint8_t>());
+        VQ_TRY(launch_lloyd_small_slab(ds->X, ds->n, ds->d, km->cs.m, km->cs.k, km->cs.sd, km->cs.cb.as<float>(), km->codes.as<uint8_t>(),
+                                       km->sm_psum.as<float>(), km->sm_pcnt.as<uint32_t>(), act,
+                                       gated ? km->run_state.as<uint32_t>() : nullptr, km->changed.as<uint32_t>(), km->slab.as<double>(), s));
+        kmeans_small_note(km);
+        km->accumulated = true;
+        return VQHIP_OK;
+    }
     // assignment: always squared L2 (src/core/vector.rs:352-363); with the update fused in where the shape allows
     FusedAcc fused;
     if (km->fused_slabs && !km->exact_update && !km->sums_by_chains) {
@@ -1447,6 +1509,16 @@ int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
     Entry in(km->sync);
     hipStream_t s;
     VQ_TRY(in.stream(&s));
+    if (kmeans_small_eligible(km)) {
+        const uint32_t m = km->cs.m, k = km->cs.k;
+        VQ_TRY(kmeans_small_enqueue(km, s, false));
+        VQ_HIP(hipMemcpyAsync(km->counts_host, km->counts.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, s));
+        VQ_HIP(hipMemcpyAsync(km->changed_host, km->changed.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+        VQ_TRY(spin_wait(s));
+        in.synced();
+        kmeans_finalize_collect(km, counts, changed);
+        return VQHIP_OK;
+    }
     if (!kmeans_graph_eligible(km)) {
         VQ_TRY(kmeans_accumulate_enqueue(km, s));
         VQ_TRY(kmeans_finalize_enqueue(km, s));
@@ -1545,6 +1617,7 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
                        engine == VQHIP_ENGINE_MFMA_BF16 && km->cs.x32_groups == 1 && screen_bf16_fused_update_supported(km->cs.sd, k) &&
                        km->fused_slabs / n_active > FusedAcc().n_patch && km->ds->n != 0 && km->ds->n < (1ull << 32) &&
                        !g_prof.on && !(host_loop_env && host_loop_env[0] == '1');
+    if (local_rc == VQHIP_OK && kmeans_small_eligible(km) && !(host_loop_env && host_loop_env[0] == '1')) device_loop = true;
     if (world > 1) {
         // every rank must queue the same number of all-reduces: the decision depends on per-rank state (environment,
         // profiling hooks, the local row count), so the ranks agree on it -- device loop only if ALL of them can -- and
@@ -1565,6 +1638,10 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
         device_loop = all[1] == (uint32_t)world;
     }
     VQ_TRY(local_rc);
+    // small problems: one launch per iteration on a single GPU (small_loop); row-sharded, the slab form of the same kernel
+    // + all-reduce + k_finalize<true>, still without the host
+    const bool small_ok = local_rc == VQHIP_OK && kmeans_small_eligible(km) && !(host_loop_env && host_loop_env[0] == '1');
+    const bool small_loop = world == 1 && small_ok;
     if (!device_loop) {
         std::vector<uint32_t> cnt((size_t)m * k);
         std::vector<uint8_t> chg(m);
@@ -1607,7 +1684,15 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
     }
     VQ_TRY(km->run_state.ensure((size_t)(m + 3) * 4));
     VQ_HIP(hipMemsetAsync(km->run_state.p, 0, (size_t)(m + 3) * 4, s));
+    if (small_loop) {  // the small form keeps the loop's decisions in two flag sets (k_lloyd_small.hip)
+        VQ_TRY(kmeans_small_workspace(km, s));
+        VQ_HIP(hipMemsetAsync(km->sm_tick.p, 0, (size_t)6 * m * 4, s));
+    }
     for (uint32_t it = 0; it < max_iters; ++it) {
+        if (small_loop) {  // two launches per iteration, the loop's decisions read from the previous iteration's flags
+            VQ_TRY(kmeans_small_enqueue(km, s, true, it));
+            continue;
+        }
         VQ_TRY(kmeans_accumulate_enqueue(km, s, true));
         // row-sharded: the one exchange of the iteration (a paused run re-sums a slab nobody reads: all ranks pause alike)
         VQ_TRY(comm_allreduce_f64(comm, km->slab.as<double>(), (size_t)m * k * (km->cs.sd + 1), s));
@@ -1619,7 +1704,20 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
     VQ_HIP(hipMemcpyAsync(km->changed_host, km->changed.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipMemcpyAsync(st.data(), km->run_state.p, (size_t)(m + 1) * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipMemcpyAsync(act.data(), km->active_dev.p, m, hipMemcpyDeviceToHost, s));
+    std::vector<uint32_t> sm_flags;
+    if (small_loop) {
+        sm_flags.resize((size_t)6 * m);
+        VQ_HIP(hipMemcpyAsync(sm_flags.data(), km->sm_tick.p, (size_t)6 * m * 4, hipMemcpyDeviceToHost, s));
+    }
     VQ_HIP(hipStreamSynchronize(s));
+    if (small_loop) {  // the loop's decisions from the flags the last executed iteration left (the kernels never write the set itself)
+        bool pause = false;
+        std::vector<uint8_t> start(act);  // active_dev still holds the set the run started from
+        lloyd_small_run_result(m, start.data(), sm_flags.data(), st.data() + 1, &pause, act.data(), km->changed_host);
+        st[0] = pause ? 1u : 0u;
+        VQ_HIP(hipMemcpyAsync(km->active_dev.p, act.data(), m, hipMemcpyHostToDevice, s));
+        VQ_HIP(hipStreamSynchronize(s));
+    }
     in.synced();
     kmeans_finalize_collect(km, counts, changed);  // flags of the last executed iteration, for the subspaces active in it
     if (iters_done) memcpy(iters_done, st.data() + 1, (size_t)m * 4);
@@ -1630,7 +1728,7 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
         all = all && km->active[i];
     }
     km->all_active = all;
-    km->ws.stats_pending = true;
+    km->ws.stats_pending = !small_loop;
     g_last_ws = km->ws_id;
     tls().last_engine = km->ws.last_engine;
     return VQHIP_OK;

@@ -195,6 +195,17 @@ int tsvq_build_device(const float *X, uint64_t n, uint32_t d, uint32_t max_depth
 int launch_pq_encode_small(const float *rows_dev, uint32_t n, uint32_t d, uint32_t m, uint32_t k, uint32_t sd, int metric,
                            const float *cb, const float *cnsqrt, uint8_t *codes_dev, uint16_t *f16_dev,
                            hipStream_t stream);
+// one Lloyd iteration of a small problem in two launches (k_lloyd_small.hip)
+bool lloyd_small_supported(uint64_t n, uint32_t m, uint32_t k, uint32_t sd);
+size_t lloyd_small_workspace(uint64_t n, uint32_t m, uint32_t k, uint32_t sd, size_t *cnt_bytes, size_t *flag_bytes);
+int launch_lloyd_small(const float *X, uint64_t n, uint32_t d, uint32_t m, uint32_t k, uint32_t sd, float *cb, uint8_t *codes,
+                       float *psum, uint32_t *pcnt, uint32_t *counts, uint32_t *changed, const uint8_t *active, uint32_t *run_flags,
+                       uint32_t *run_iters, uint32_t it, hipStream_t stream);
+void lloyd_small_run_result(uint32_t m, const uint8_t *start_active, const uint32_t *flags, const uint32_t *iters, bool *paused,
+                            uint8_t *active_out, uint32_t *changed_out);
+int launch_lloyd_small_slab(const float *X, uint64_t n, uint32_t d, uint32_t m, uint32_t k, uint32_t sd, const float *cb, uint8_t *codes,
+                            float *psum, uint32_t *pcnt, const uint8_t *active, const uint32_t *gate_halt, uint32_t *changed, double *slab,
+                            hipStream_t stream);
 bool tsvq_small_supported(uint32_t d);
 int launch_tsvq_encode_small(const float *rows_dev, uint32_t n, uint32_t d, int metric, const float *centroids,
                              const float *cnorm, const int32_t *left, const int32_t *right, int32_t *leaf_dev,
