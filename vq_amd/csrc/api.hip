@@ -903,6 +903,7 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     t->scr.mu = t->scr_mu.as<float>();
     t->scr.wl_count = t->scr_count.as<uint32_t>();
     t->scr.n_int = n_lds;  // slots resident in LDS; w / info / slot_node hold all of the tree's slots
+    t->scr.n_slots = n_int;
     t->scr.n_nodes = n_nodes;
     // a non-finite tree sends every row to the exact continuation (T = NaN never passes)
     t->scr.R = finite ? (float)(std::sqrt(r2max) * 1.000001) : std::numeric_limits<float>::quiet_NaN();

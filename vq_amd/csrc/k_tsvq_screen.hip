@@ -66,7 +66,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //     left   iff  S_l (1 + m) <= S_r,      right  iff  S_r (1 + m) < S_l,      m = 2.01 (d + D/32 + 6) u
 // and anything else -- or a sum that is not finite and below 1e37 -- is undecided.
 constexpr int kScrL2 = 0, kScrCos = 1, kScrMan = 2;
-template <int D, int LPR, int WAVES, int MODE>
+// DEEP: the tree has more two-child nodes than LDS holds and the deeper ones are read from L2.  Its own instantiation:
+// a global load anywhere in the descent loop makes the loop wait on vmcnt(0) at every level -- the counter the NEXT
+// tile's rows (requested before the descent, to travel during it) are counted on, so every tile waited out a full HBM
+// round trip before its first level.  Without the path (the usual case: depth <= 8 at d = 128) the rows travel while the
+// descent runs.
+template <int D, int LPR, int WAVES, int MODE, bool DEEP>
 __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
     const float *__restrict__ X, uint64_t n, uint32_t d_real, const float *__restrict__ w_g,
     const int4 *__restrict__ info_g, const float *__restrict__ mu_g, uint32_t n_int, int32_t start_slot, float R,
@@ -99,6 +104,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
                 const uint32_t e = e0 + i * T + threadIdx.x;
                 v[i] = reinterpret_cast<const float4 *>(w_g)[e < total ? e : 0];
             }
+            // (pinned: left alone, the compiler sinks each load into the conditional LDS store below and waits for it there:
+            // one memory round trip per 16 KB of the 130 KB image, ~16 us in front of every workgroup's first row)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t e = e0 + i * T + threadIdx.x;
@@ -176,10 +185,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
         if (tile + tile_stride < n_tiles) load_tile(tile + tile_stride, xn);  // in flight during the descent
         for (;;) {
             const int32_t a = cur > 0 ? cur : 0;
-            const bool deep = a >= (int32_t)n_int;
+            const bool deep = DEEP && a >= (int32_t)n_int;
             int4 inf;
             float P[NV];
-            const bool any_deep = __any(deep);
+            const bool any_deep = DEEP && __any(deep);
             if (!any_deep || !deep) inf = lds_info[a];
             else inf = info_g[a];
 #pragma unroll
@@ -649,15 +658,21 @@ int launch_screen(const float *X, uint64_t n, uint32_t d_real, const TsvqScreen 
     const size_t lds_bytes = tsvq_screen_lds_bytes(s.n_int, MODE == kScrL2 ? 1 : 2, D);
     static PerDeviceOnce attr_set;
     if (attr_set.needed()) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR, WAVES, MODE>),
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR, WAVES, MODE, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR, WAVES, MODE, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set.done();
     }
     const uint64_t n_tiles = (n + RPW - 1) / RPW;
     uint64_t grid = (n_tiles + WAVES - 1) / WAVES;
     if (grid > (uint64_t)num_cus()) grid = (uint64_t)num_cus();
-    hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES, MODE>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X,
-                       n, d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count, table16, f16_out);
+    if (s.n_slots > s.n_int)
+        hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES, MODE, true>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X, n,
+                           d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count, table16, f16_out);
+    else
+        hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES, MODE, false>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X, n,
+                           d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count, table16, f16_out);
     VQ_LAUNCH_CHECK("k_tsvq_screen_descend");
     return VQHIP_OK;
 }

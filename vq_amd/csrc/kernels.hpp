@@ -228,7 +228,8 @@ struct TsvqScreen {
     const int32_t *node_slot = nullptr;  // [n_nodes] slot of a two-child node, -1 otherwise (the continuation's re-screen)
     int32_t start_slot = 0;       // slot the root resolves to
     const float *mu = nullptr;    // [d]         root centroid
-    uint32_t n_int = 0, n_nodes = 0;
+    uint32_t n_int = 0, n_nodes = 0;  // n_int: slots resident in LDS (the levels nearest the root)
+    uint32_t n_slots = 0;         // all two-child nodes of the tree (>= n_int; more: the deeper ones are read from L2)
     float R = 0.0f;               // >= max_node |c - mu|
     float coef_a = 0.0f, coef_b = 0.0f;
     uint2 *wl = nullptr;          // [n] undecided (row, node)
