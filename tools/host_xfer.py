@@ -5,6 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from vq_amd import _lib
 _lib.load(); _lib.set_device(0)
+if os.environ.get("WITH_TORCH_STREAM") == "1":  # as bench.py runs it: torch initialised, the library on a torch stream
+    import torch
+    _ts = torch.cuda.Stream()
+    _lib.set_stream(_ts.cuda_stream)
 n, d, m, k = 1_000_000, 128, 8, 256
 X = _lib.synth_uniform_host(n, d, 66, 0)
 cb = np.random.default_rng(1).random((m, k, d // m), dtype=np.float32)

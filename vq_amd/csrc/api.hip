@@ -575,8 +575,8 @@ constexpr uint64_t kSmallRows = 8;  // calls with at most this many host rows ta
 // once if TWO host threads issue them (a pageable copy occupies its thread); staging through pinned buffers with host
 // memcpys (29 GB/s per thread) only loses (measured: 4 lanes of pinned staging 6.1e7 vectors/s against 7.1e7 for the
 // plain copies in turn, rows in / f16 out at 1M x 128).  So a large host batch whose results are a sizeable share of
-// its input goes through two LANES: two host threads, each with its own stream and device buffers, take alternate
-// chunks end to end -- H2D straight from the caller's rows, the kernels (the handle orders the lanes' launches on the
+// its input goes through LANES: a few host threads (three), each with its own stream and device buffers, take every
+// n-th chunk end to end -- H2D straight from the caller's rows, the kernels (the handle orders the lanes' launches on the
 // device: HandleSync), D2H straight into the caller's buffers -- so one lane's results travel while the other lane's rows do.
 struct XferLane {
     int device = -1;
@@ -591,7 +591,7 @@ constexpr int kXferLanesMax = 8;
 static int xfer_lanes() {  // host threads per large transfer (VQHIP_XFER_LANES, 1..8; A/B)
     static const int v = [] {
         const char *e = getenv("VQHIP_XFER_LANES");
-        const int x = e ? atoi(e) : 2;
+        const int x = e ? atoi(e) : 3;  // (two suffice when they stay out of phase, 9.7 ms at 1M x 128 rows in / f16 out, but now and then a call falls back to 14 ms; three: 10.2-10.5 ms every time)
         return x < 1 ? 1 : (x > kXferLanesMax ? kXferLanesMax : x);
     }();
     return v;

@@ -252,10 +252,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
         }
         if (j == 0 && cur < 0 && cur > kFlagBase / 2 && row < n) leaf_out[row] = -1 - cur;
         if (f16_out && cur < 0 && cur > kFlagBase / 2 && row < n) {
+            // the leaf's f16 row: this lane's pieces j, j + LPR, ... all requested before the first is stored (a load next to
+            // its store waits for the table AND for the store in front of it: both sit on vmcnt)
             const uint32_t pieces = d_real / 8;
             const uint4 *src = table16 + (size_t)(-1 - cur) * pieces;
             uint4 *dst = f16_out + row * pieces;
-            for (uint32_t q = j; q < pieces; q += LPR) dst[q] = src[q];
+            constexpr int NP = (D / 8 + LPR - 1) / LPR;
+            uint4 tmp[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) tmp[i] = src[min(j + (uint32_t)i * LPR, pieces - 1u)];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(tmp[i].x), "+v"(tmp[i].y), "+v"(tmp[i].z), "+v"(tmp[i].w));
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                if (j + (uint32_t)i * LPR < pieces) dst[j + (uint32_t)i * LPR] = tmp[i];
         }
         const bool push = (j == 0) && (cur <= kFlagBase / 2);
         const uint64_t mask = __ballot(push);
