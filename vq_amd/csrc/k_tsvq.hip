@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstddef>
 #include <utility>
 #include <vector>
 
@@ -520,12 +521,22 @@ __global__ __launch_bounds__(256) void k_scatter(uint32_t n, const uint32_t *__r
     node_of2[pos] = na.child_local[2 * node + (f ? 0 : 1)];
 }
 
-__global__ __launch_bounds__(256) void k_iota(uint32_t *__restrict__ perm, uint32_t *__restrict__ node_of, uint32_t n) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
-        perm[i] = i;
-        node_of[i] = 0;
-    }
+// The whole initial state of a build in ONE launch (it was k_iota + five memsets + three 4-byte uploads from the host's
+// stack and the synchronisation they needed: ~70 us in front of the first useful kernel): identity permutation, every row in
+// node 0; no children anywhere; the level table {first 0, count 1} then zeros; the root's segment; diagnostics and
+// radix-select histograms at zero.  Grid-stride over the largest of the ranges.
+__global__ __launch_bounds__(256) void k_build_init(uint32_t *__restrict__ perm, uint32_t *__restrict__ node_of, uint32_t n,
+                                                    int32_t *__restrict__ left, int32_t *__restrict__ right, uint32_t dcap,
+                                                    uint32_t *__restrict__ lv_words, uint32_t n_lv_words, uint32_t *__restrict__ seg_start,
+                                                    uint32_t *__restrict__ seg_len, uint32_t *__restrict__ fb, uint32_t n_fb,
+                                                    uint32_t *__restrict__ hist, uint32_t n_hist) {
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) perm[i] = i, node_of[i] = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < dcap; i += stride) left[i] = -1, right[i] = -1;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_lv_words; i += stride) lv_words[i] = (i == 1u) ? 1u : 0u;  // LevelInfo[0] = {first 0, count 1, ...}
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_fb; i += stride) fb[i] = 0u;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_hist; i += stride) hist[i] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) seg_start[0] = 0u, seg_len[0] = n;
 }
 
 // ---- encode ------------------------------------------------------------------------------
@@ -2064,31 +2075,18 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     const bool have_fast = can_fast && n >= fs_min_rows;
 
     marks.mark("allocated");
-    // initial state: identity permutation, every row in node 0 (the root), no children anywhere
-    hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, stream, ws.b_perm[0].as<uint32_t>(),
-                       ws.b_nodeof[0].as<uint32_t>(), n);
-    VQ_LAUNCH_CHECK("k_iota");
-    VQ_HIP(hipMemsetAsync(ws.b_lv.p, 0, (size_t)(n_levels + 1) * sizeof(LevelInfo), stream));
-    VQ_HIP(hipMemsetAsync(ws.b_left.p, 0xFF, (size_t)dcap * 4, stream));
-    VQ_HIP(hipMemsetAsync(ws.b_right.p, 0xFF, (size_t)dcap * 4, stream));
-    VQ_HIP(hipMemsetAsync(ws.b_fs_fb.p, 0, 8 + 64 * 2 * 64, stream));
-    // the radix-select histograms start at zero and every round's k_select_pick leaves the bins it read at zero again:
-    // one clear per build (it used to be one per level)
-    VQ_HIP(hipMemsetAsync(ws.b_hist.p, 0, (size_t)wmax * 2 * 256 * 4, stream));
+    // initial state (k_build_init), then the sampling policy; nothing comes from the host, so nothing waits for it here
+    static_assert(sizeof(LevelInfo) == 32 && offsetof(LevelInfo, count) == 4, "k_build_init writes LevelInfo[0].count as word 1");
+    hipLaunchKernelGGL(k_build_init, dim3(std::min<uint32_t>((n + 255) / 256, (uint32_t)num_cus() * 16)), dim3(256), 0, stream,
+                       ws.b_perm[0].as<uint32_t>(), ws.b_nodeof[0].as<uint32_t>(), n, ws.b_left.as<int32_t>(), ws.b_right.as<int32_t>(), dcap,
+                       ws.b_lv.as<uint32_t>(), (uint32_t)((n_levels + 1) * sizeof(LevelInfo) / 4), na.seg_start, na.seg_len,
+                       ws.b_fs_fb.as<uint32_t>(), (uint32_t)((8 + 64 * 2 * 64) / 4), ws.b_hist.as<uint32_t>(), wmax * 2 * 256);
+    VQ_LAUNCH_CHECK("k_build_init");
     if (adaptive_sampling && n >= fs_min_rows) {
         hipLaunchKernelGGL(k_fs_policy, dim3(n_cblk), dim3(1024), 0, stream, X, n, d, ws.b_fs_fb.as<uint32_t>() + 2 + 64 * 2 * 16);
         VQ_LAUNCH_CHECK("k_fs_policy");
     }
     marks.mark("queued");
-    {
-        const uint32_t root[2] = {0u, n};  // seg_start[0], seg_len[0]; lv[0] = {first 0, count 1}
-        const uint32_t one = 1u;
-        VQ_HIP(hipMemcpyAsync(na.seg_start, &root[0], 4, hipMemcpyHostToDevice, stream));
-        VQ_HIP(hipMemcpyAsync(na.seg_len, &root[1], 4, hipMemcpyHostToDevice, stream));
-        VQ_HIP(hipMemcpyAsync(&lv[0].count, &one, 4, hipMemcpyHostToDevice, stream));
-        marks.mark("uploaded");
-        VQ_HIP(hipStreamSynchronize(stream));  // stack sources; also the only synchronisation before the final download
-    }
     marks.mark("setup");
     int cur = 0;
     const uint32_t ncb = (d + kFsCols - 1) / kFsCols;
