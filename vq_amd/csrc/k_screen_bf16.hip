@@ -829,6 +829,9 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
 #pragma unroll
         for (int q = 0; q < DPH; ++q) mu[q] = cs[DPH * h + q];
     }
+    f32x4 mu4[DPH / 4];
+#pragma unroll
+    for (int q = 0; q < DPH; ++q) mu4[q / 4][q % 4] = mu[q];
     const char *const x_base = reinterpret_cast<const char *>(X + (size_t)s * SD + (size_t)DPH * h);
     const uint32_t x_pitch = d * 4;
     // codes: [row][m] bytes, or the [m][pitch] scratch of the transposing caller -- one address form for both
@@ -839,18 +842,16 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     // (about to be consumed, then reloaded with st + 1 + kDeep) and xn_[par] step st + 2
     // (two waves per SIMD: one step deep -- the partner wave covers the latency and the registers are short)
     constexpr int kDeep = x32_two_waves(SD, NT32) ? 1 : 2;
-    float xn_[kDeep][DPH];
+    // kept as the 16-byte vectors the loads return and consumed as such (x - mu on whole vectors): handed on as scalars,
+    // the packed subtraction paired lanes 0 / 3 and 1 / 2 of a vector and the register copies that pairing needs were
+    // placed right behind the LOAD -- with its wait: the sub_dim-8 kernel waited for every row load a quarter of a step
+    // (or less) after issuing it
+    f32x4 xn_[kDeep][DPH / 4];
     auto load_x = [&](uint32_t row, int buf) {
         row = row < n32 ? row : n32 - 1;
         const float *ptr = reinterpret_cast<const float *>(x_base + (uint64_t)row * x_pitch);
 #pragma unroll
-        for (int q = 0; q < DPH; q += 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(ptr + q);
-            xn_[buf][q + 0] = t.x;
-            xn_[buf][q + 1] = t.y;
-            xn_[buf][q + 2] = t.z;
-            xn_[buf][q + 3] = t.w;
-        }
+        for (int q = 0; q < DPH / 4; ++q) xn_[buf][q] = *reinterpret_cast<const f32x4 *>(ptr + 4 * q);
     };
     auto init_acc = [&](f32x16 &acc, int i) {
 #pragma unroll
@@ -883,7 +884,7 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     };
 
     bf16x8 b[2][NMF];
-    float q1[2][4], q2[2][4], snap[2][4];
+    float q1[2][2], q2[2][2];  // [step parity][chain]: the two smallest tagged values so far (see reduce_hg)
     float xc[DPH];
     uint32_t xp[3][DPH];
     float xsT = 0.0f, xsM = 0.0f, xsN = 0.0f;  // |x - mu|^2 (this lane half) of steps st - 1, st, st + 1
@@ -893,15 +894,32 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     // chains, no wait states between a v_pk_add_f32 and its consumer); piece 0 consumes the loaded rows (buffer nb) and issues the
     // load that refills the buffer
     constexpr int kSplitPieces = 1 + DPH / 4 + NMF;
-    auto split_piece = [&](int k, int nb, uint32_t next_step) {
+    // (anchor: the loads of the peeled first trip are consumed by the loop, and left alone the compiler sinks them out
+    // of the trip to the loop's door -- the operations in flight at the loop's first wait are then again not the steady
+    // state's.  A use the compiler cannot rule out, in a block of the trip itself, keeps them where they are written;
+    // launch_one_x32 never sends n = 2^32 - 1 here, the branch is never taken and its wait never paid.)
+    auto split_piece = [&](int k, int nb, uint32_t next_step, bool anchor = false) {
         if (k == 0) {
 #pragma unroll
-            for (int q = 0; q < DPH; ++q) {
-                xc[q] = xn_[nb % kDeep][q] - mu[q];
-                asm volatile("" ::"v"(xc[q]));  // consumed HERE (see reduce_hg), the registers are free for the next load
+            for (int q = 0; q < DPH / 4; ++q) {
+                if constexpr (x32_two_waves(SD, NT32) && !ACC) {
+                    f32x4 dv = xn_[nb % kDeep][q] - mu4[q];
+                    asm volatile("" : "+v"(dv));  // consumed HERE (see reduce_hg), the registers are free for the next load
+                    xc[4 * q + 0] = dv[0], xc[4 * q + 1] = dv[1], xc[4 * q + 2] = dv[2], xc[4 * q + 3] = dv[3];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xc[4 * q + e] = xn_[nb % kDeep][q][e] - mu[4 * q + e];
+                        asm volatile("" ::"v"(xc[4 * q + e]));
+                    }
+                }
             }
             xsN = 0.0f;
             load_x(next_step * 32 + p, nb % kDeep);
+            if (anchor && n32 == 0xFFFFFFFFu) {
+#pragma unroll
+                for (int q = 0; q < DPH / 4; ++q) asm volatile("" ::"v"(xn_[nb % kDeep][q]));
+            }
         } else if (k <= DPH / 4) {
 #pragma unroll
             for (int q = 4 * (k - 1); q < 4 * k; ++q) {
@@ -929,40 +947,36 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
             asm volatile("" ::"v"(b[nb][f]));
         }
     };
-    // two chains' share (r = 2 (hg & 1), + 1) of values 8 (hg >> 1) .. + 7 of a finished tile: see reduce8 above.  The
-    // chain's second-minimum takes both pairs of a tile in one v_min3 (hg >= 2), as the compiler does for reduce8; the
-    // results are pinned to their gap (an empty asm that reads them): without a use here the compiler sinks the whole
-    // reduction below the tail's branches.
-    float ta[4];
+    // Values 8 (hg >> 1) + 2 (hg & 1) + {0, 1, 4, 5} of a finished tile enter the lane's TWO chains, two values per chain
+    // (reduce8 above has the three-instruction update).  Element e of tile i goes to chain e & 1 under the 6-bit tag
+    // [5:3] = i, [2:1] = e >> 2, [0] = bit 1 of e: a chain sees its 64 values of a step under 64 different tags, so the
+    // winner's index is read off its low bits and its chain -- the X32 kernel's four chains re-use their tags after
+    // four tiles and carry a snapshot through three merges to tell the halves apart (~23 instructions of every step's
+    // tail).  The tags sit in bits the margin already gives away, and (minimum, second minimum) of a multiset do not
+    // depend on the order of arrival: the codes are the same; a row whose gap is within 64 ulps of T may change sides
+    // of the test (it is then settled by the exact re-check, or was).  The chain's second minimum takes both pairs of
+    // a half-tile in one v_min3 (odd hg); the results are pinned to their gap (an empty asm that reads them): without a
+    // use here the compiler sinks the whole reduction below the tail's branches.
+    float ta[2];
     auto min3 = [](float x, float y, float z) { return __builtin_fminf(__builtin_fminf(x, y), z); };  // v_min3_f32
     auto reduce_hg = [&](const f32x16 &fin, int ifin, int hg, int par) {
         const int g8 = hg >> 1;
+        const uint32_t ca = (uint32_t)(8 * ifin + 4 * g8 + (hg & 1)), cb = ca + 2u;
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int r = 2 * (hg & 1) + rr;
-            const uint32_t ca = (uint32_t)((16 * ifin + 8 * g8 + r) & 63), cb = (uint32_t)((16 * ifin + 8 * g8 + 4 + r) & 63);
+        for (int c = 0; c < 2; ++c) {
+            const int r = 2 * (hg & 1) + c;
             const float pa = __uint_as_float((__float_as_uint(fin[8 * g8 + r]) & idx_mask) | ca);
             const float pb = __uint_as_float((__float_as_uint(fin[8 * g8 + 4 + r]) & idx_mask) | cb);
-            const float t = __builtin_amdgcn_fmed3f(q1[par][r], pa, pb);
-            q1[par][r] = min3(q1[par][r], pa, pb);
-            if (g8 == 0) {
-                ta[r] = t;
-                asm volatile("" ::"v"(q1[par][r]), "v"(ta[r]));
+            const float t = __builtin_amdgcn_fmed3f(q1[par][c], pa, pb);
+            q1[par][c] = min3(q1[par][c], pa, pb);
+            if ((hg & 1) == 0) {
+                ta[c] = t;
+                asm volatile("" ::"v"(q1[par][c]), "v"(ta[c]));
             } else {
-                q2[par][r] = min3(q2[par][r], ta[r], t);
-                asm volatile("" ::"v"(q1[par][r]), "v"(q2[par][r]));
+                q2[par][c] = min3(q2[par][c], ta[c], t);
+                asm volatile("" ::"v"(q1[par][c]), "v"(q2[par][c]));
             }
         }
-    };
-    // merges two chains' (min, second min); the winner's snapshot travels along (its 7-bit value index is read off once,
-    // at the end: low 6 bits of the minimum + 64 if it moved after the snapshot)
-    auto merge2 = [&](float a1, float a2, float as, float b1, float b2, float bs, float &o1, float &o2, float &os) {
-        const float hi = __builtin_amdgcn_fmed3f(a1, b1, pinf);
-        const float lo2 = __builtin_amdgcn_fmed3f(a2, b2, ninf);
-        o2 = __builtin_amdgcn_fmed3f(hi, lo2, ninf);
-        const bool tb = b1 < a1;
-        o1 = tb ? b1 : a1;
-        os = tb ? bs : as;
     };
     float t_m1 = 0.0f, t_m2 = 0.0f, t_xs = 0.0f;
     uint32_t t_j = 0;
@@ -1048,16 +1062,20 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
         }
     };
     // tail of a finished step in 4 pieces (the X32 kernel's tail, same order of operations)
-    auto tail_piece = [&](int k, int tp, uint32_t tst, bool in_loop) {
+    auto tail_piece = [&](int k, int tp, uint32_t tst, bool in_loop, bool no_step = false) {
         if (k == 0) {
-            float u1, u2, us, w1, w2, ws, ms;
-            merge2(q1[tp][0], q2[tp][0], snap[tp][0], q1[tp][1], q2[tp][1], snap[tp][1], u1, u2, us);
-            merge2(q1[tp][2], q2[tp][2], snap[tp][2], q1[tp][3], q2[tp][3], snap[tp][3], w1, w2, ws);
-            merge2(u1, u2, us, w1, w2, ws, t_m1, t_m2, ms);
-            const uint32_t vidx = (__float_as_uint(t_m1) & 63u) + ((t_m1 < ms) ? 64u : 0u);
-            t_j = ((vidx >> 4) << 5) + (vidx & 3u) + (((vidx >> 2) & 3u) << 3) + 4 * h;
+            // the lane's two chains -> (minimum, second minimum, centroid): element e = 4 tag[2:1] + 2 tag[0] + chain of
+            // tile tag[5:3] is centroid 32 tile + 8 (e >> 2) + 4 h + (e & 3)
+            const float a1 = q1[tp][0], a2 = q2[tp][0], b1 = q1[tp][1], b2 = q2[tp][1];
+            const float hi = __builtin_amdgcn_fmed3f(a1, b1, pinf);
+            const float lo2 = __builtin_amdgcn_fmed3f(a2, b2, ninf);
+            t_m2 = __builtin_amdgcn_fmed3f(hi, lo2, ninf);
+            const bool tb = b1 < a1;
+            t_m1 = tb ? b1 : a1;
+            const uint32_t tag = __float_as_uint(t_m1) & 63u;
+            t_j = ((tag & 62u) << 2) + ((tag & 1u) << 1) + (tb ? 1u : 0u) + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) q1[tp][r] = pinf, q2[tp][r] = pinf;  // the chains of step tst + 2 start here
+            for (int c = 0; c < 2; ++c) q1[tp][c] = pinf, q2[tp][c] = pinf;  // the chains of step tst + 2 start here
         } else if (k == 1) {
             const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t_m1), __float_as_uint(t_m1), false, false);
             const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t_m2), __float_as_uint(t_m2), false, false);
@@ -1082,11 +1100,11 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
             if (cosine) proven = proven && (t_m1 < -T) && (xnorm > 4e-10f);
             t_proven = proven;
         } else {
-            // In the loop the only tail without a step behind it is the first one (tst = st0 - 1, chains still +inf): it is
+            // In the loop the only tail without a step behind it is the first one (no_step: tst = st0 - 1, chains still +inf): it is
             // aimed at the rows of step st0, which the real tail of st0 overwrites a step later; rows past n repeat row
             // n - 1 (they were loaded from it) and both lane halves hold the same verdict -- so the code is stored
             // by every lane, without a branch.  The tail after the loop may belong to a dummy step: it asks.
-            const bool valid = in_loop ? (tst != st0 - 1) : (tst < st1);
+            const bool valid = in_loop ? !no_step : (tst < st1);
             const uint32_t row = (in_loop && !valid ? st0 : tst) * 32 + p;
             const uint32_t rowc = row < n32 ? row : n32 - 1;
             if (in_loop || valid) code_base[(uint64_t)rowc * code_stride] = (uint8_t)t_j;
@@ -1104,6 +1122,56 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
         }
     };
 
+    // ACC = false: TWO steps share the part of the tail behind the lane's own merge.  Piece 0 of step S - 1 (run inside
+    // step S, the first of a loop trip) parks the lane's (minimum, second minimum, centroid, |x|^2 half) in held_*;
+    // a step later piece 0 of step S leaves its own in t_*, and ONE v_permlane32_swap per quantity hands lanes 0..31
+    // both halves of row p of step S - 1 and lanes 32..63 both halves of row p of step S (the one-step form swaps a
+    // register with itself and both halves of the wave then do the same work).  Merge, margin test, code store and
+    // work-list append run once for the two steps: 64 rows in 64 lanes, the same values in the same order of rows.
+    // The first trip has no step S - 1: its lanes 0..31 are no writers.
+    float held_m1 = 0.0f, held_m2 = 0.0f, held_xs = 0.0f;
+    uint32_t held_j = 0;
+    auto tail_hold = [&]() { held_m1 = t_m1, held_m2 = t_m2, held_j = t_j, held_xs = xsT; };
+    auto tail_pair_piece = [&](int k, uint32_t S, bool first) {
+        if (k == 1) {
+            const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(held_m1), __float_as_uint(t_m1), false, false);
+            const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(held_m2), __float_as_uint(t_m2), false, false);
+            const auto rj = __builtin_amdgcn_permlane32_swap(held_j, t_j, false, false);
+            const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(held_xs), __float_as_uint(xsT), false, false);
+            const float a1 = __uint_as_float(r1[0]), b1 = __uint_as_float(r1[1]);
+            const float a2 = __uint_as_float(r2[0]), b2 = __uint_as_float(r2[1]);
+            t_xs = __uint_as_float(rx[0]) + __uint_as_float(rx[1]);
+            const float hi = __builtin_amdgcn_fmed3f(a1, b1, pinf);
+            const float lo2 = __builtin_amdgcn_fmed3f(a2, b2, ninf);
+            t_m2 = __builtin_amdgcn_fmed3f(lo2, hi, ninf);
+            const bool take = (b1 < a1) || (b1 == a1 && rj[1] < rj[0]);
+            t_j = take ? rj[1] : rj[0];
+            t_m1 = take ? b1 : a1;
+        } else {  // k == 3 (piece 2, the margin test, is tail_piece's)
+            const bool valid = (h != 0) || !first;
+            const uint32_t row = (S - 1 + h) * 32 + p;
+            // The store is unconditional in every trip (a predicated one is an operation the compiler cannot count on
+            // when it sizes the vmcnt wait in front of the row loads).  First trip: lanes 0..31 have no row of their own
+            // and repeat the store of their partner lane, same address, same byte.
+            uint32_t srow = row, sj = t_j;
+            if (first) {
+                sj = __builtin_amdgcn_permlane32_swap(t_j, t_j, false, false)[1];
+                srow = S * 32 + p;
+            }
+            const uint32_t rowc = srow < n32 ? srow : n32 - 1;
+            code_base[(uint64_t)rowc * code_stride] = (uint8_t)sj;
+            const bool recheck = valid && (row < n32) && !t_proven;
+            const unsigned long long mask = __ballot(recheck);
+            if (mask != 0ull) {
+                if (recheck) {
+                    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                    wl_rows[(size_t)s * wl_stride + seg_first + seg_count + rank] = (uint32_t)row;
+                }
+                seg_count += (uint32_t)__popcll(mask);
+            }
+        }
+    };
+
     // ---- prologue: operands of step st0, its first two MFMA chains, the rows of st0 + 1 on their way ----
     load_x(st0 * 32 + p, 0);
     if (kDeep == 2) load_x((st0 + 1) * 32 + p, 1);
@@ -1111,7 +1179,7 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     for (int k = 0; k < kSplitPieces; ++k) split_piece(k, 0, st0 + kDeep);  // buffer 0: step st0 now, st0 + kDeep next
     xsM = xsN;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) q1[0][r] = q2[0][r] = snap[0][r] = q1[1][r] = q2[1][r] = snap[1][r] = pinf;
+    for (int c = 0; c < 2; ++c) q1[0][c] = q2[0][c] = q1[1][c] = q2[1][c] = pinf;
     if (0 >= kCnV) init_acc(acc[0], 0);
     if (1 >= kCnV) init_acc(acc[1], 1);
     if (2 >= kCnV) init_acc(acc[2], 2);
@@ -1123,18 +1191,24 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     __builtin_amdgcn_sched_barrier(0);
 
     // always an even number of steps: a step at or past st1 is a dummy (rows clamped, nothing written), so the loop body
-    // has no exit in the middle; the tail of the very last step follows the loop
-    for (uint32_t it0 = 0; it0 < nst; it0 += 2) {
+    // has no exit in the middle; the tail of the very last step follows the loop.
+    // The first trip is peeled (the outer two-trip loop is unrolled), for the compiler's wait counts: vmcnt is ONE in-order
+    // counter of loads and stores, and the count in front of a consumed row load is the smallest number of younger
+    // operations over all paths to that point.  Entered from the prologue, only the other buffer's two loads are
+    // younger, so both waits of the loop came out as vmcnt(2) -- which in the steady state also waits for the loads
+    // issued ONE step ago (a tail's store follows them): the rows were in fact prefetched one step deep, not two.  With
+    // the first trip outside, every path into the loop carries the steady state's operations.  (`first` is a constant
+    // in both copies.)
+#pragma clang loop unroll(full)
+    for (int peel = 0; peel < 2; ++peel) {
+      const bool first = peel == 0;
+      for (uint32_t it0 = first ? 0u : 2u; it0 < (first ? 1u : nst); it0 += 2) {
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
             const uint32_t st = st0 + it0 + par;
 #pragma unroll
             for (int i = 0; i < NT32; ++i) {
                 if ((i + 3) % NT32 >= kCnV) init_acc(acc[(i + 3) & 3], (i + 3) % NT32);
-                if (i == 4) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) snap[par][r] = q1[par][r];
-                }
 #pragma unroll
                 for (int f = 0; f < NMF; ++f) {
                     if (i + 2 < NT32) mfma(acc[(i + 2) & 3], i + 2, f, b[par][f]);
@@ -1150,8 +1224,18 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
                         if (f == 4) reduce_hg(acc[i & 3], i, 3, par);
                         if (f == 2 || f == 5) {
                             const int slot = 2 * i + (f == 5);  // 0..15
-                            if (slot == 0) acc_reload(st - 1), split_piece(0, par ^ 1, st + 1 + kDeep);
-                            else if (slot <= 4) tail_piece(slot - 1, par ^ 1, st - 1, true);
+                            if (slot == 0) acc_reload(st - 1), split_piece(0, par ^ 1, st + 1 + kDeep, first);
+                            else if (slot <= 4) {
+                                if constexpr (ACC) {
+                                    tail_piece(slot - 1, par ^ 1, st - 1, true, first && par == 0);
+                                } else if (par == 0) {  // step st - 1: the lane's own merge, parked for the partner step
+                                    if (slot == 1) tail_piece(0, 1, st - 1, true), tail_hold();
+                                } else {                // steps st - 2 and st - 1 together
+                                    if (slot == 1) tail_piece(0, 0, st - 1, true);
+                                    else if (slot == 3) tail_piece(2, 0, st - 1, true);
+                                    else tail_pair_piece(slot - 1, st - 1, first);
+                                }
+                            }
                             else if (slot <= 10) split_piece(slot - 4, par ^ 1, st + 1 + kDeep);      // 2 splits, packs 0..3
                             else if (slot == 11) split_piece(7, par ^ 1, st + 1 + kDeep), split_piece(8, par ^ 1, st + 1 + kDeep);
                             else if (slot == 12) acc_issue();
@@ -1163,10 +1247,14 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
                         if (f == 2) {
                             if (i == 0) {
                                 acc_reload(st - 1);
-                                split_piece(0, par ^ 1, st + 1 + kDeep);
-                                tail_piece(0, par ^ 1, st - 1, true), tail_piece(1, par ^ 1, st - 1, true);
+                                split_piece(0, par ^ 1, st + 1 + kDeep, first);
+                                tail_piece(0, par ^ 1, st - 1, true);
+                                if constexpr (ACC) tail_piece(1, par ^ 1, st - 1, true, first && par == 0);
+                                else if (par == 0) tail_hold();
+                                else tail_pair_piece(1, st - 1, first);
                             } else if (i == 1) {
-                                tail_piece(2, par ^ 1, st - 1, true), tail_piece(3, par ^ 1, st - 1, true);
+                                if constexpr (ACC) tail_piece(2, par ^ 1, st - 1, true), tail_piece(3, par ^ 1, st - 1, true, first && par == 0);
+                                else if (par == 1) tail_piece(2, 0, st - 1, true), tail_pair_piece(3, st - 1, first);
                                 split_piece(1, par ^ 1, st + 1 + kDeep);
                             } else if (i < kSplitPieces) {
                                 split_piece(i, par ^ 1, st + 1 + kDeep);
@@ -1183,6 +1271,7 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
             xsT = xsM;
             xsM = xsN;
         }
+      }
     }
     {
         const uint32_t last = st0 + ((nst + 1) & ~1u) - 1;  // parity 1
