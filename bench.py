@@ -115,7 +115,8 @@ def pmc_traffic(kernel_name):
             summ = json.load(open(path))
             d = summ.get(kernel_name.replace(" ", "")) or summ.get(base)  # the exact instantiation when the summary has it
             if d and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-                kib = 2.0 * d["FETCH_SIZE"]["avg_per_launch"] + d["WRITE_SIZE"]["avg_per_launch"]
+                per = lambda c: d[c].get("avg_largest", d[c]["avg_per_launch"])  # the launches of the bench line's size (summarize.py)
+                kib = 2.0 * per("FETCH_SIZE") + per("WRITE_SIZE")
                 return kib * 1024.0, os.path.relpath(path, ROOT)
         except Exception:
             continue
@@ -139,9 +140,10 @@ def pmc_issue_model(kernel_name):
         try:
             d = json.load(open(path)).get(kernel_name.replace(" ", ""))
             if d and "SQ_INSTS_VALU" in d and "GRBM_GUI_ACTIVE" in d:
-                insts = d["SQ_INSTS_VALU"]["avg_per_launch"] + d.get("SQ_INSTS_SALU", {}).get("avg_per_launch", 0.0)
-                cycles = d["GRBM_GUI_ACTIVE"]["avg_per_launch"] / 8.0
-                return {"instructions_per_launch": insts, "mfma_per_launch": d.get("SQ_INSTS_MFMA", {}).get("avg_per_launch"),
+                per = lambda c: d[c].get("avg_largest", d[c]["avg_per_launch"]) if c in d else 0.0
+                insts = per("SQ_INSTS_VALU") + per("SQ_INSTS_SALU")
+                cycles = per("GRBM_GUI_ACTIVE") / 8.0
+                return {"instructions_per_launch": insts, "mfma_per_launch": per("SQ_INSTS_MFMA") or None,
                         "simds": 1024, "cycles_per_issue": CYCLES_PER_ISSUE_LONE_WAVE, "kernel_cycles": cycles,
                         "frac_of_kernel": insts / 1024.0 * CYCLES_PER_ISSUE_LONE_WAVE / cycles, "source": os.path.relpath(path, ROOT)}
         except Exception:

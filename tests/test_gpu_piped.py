@@ -85,6 +85,30 @@ def test_piped_lloyd_step_ragged_rows(oracle, shape):
     ds.close()
 
 
+@pytest.mark.parametrize("tail_steps", [1, 2, 3, 4, 9])
+@pytest.mark.parametrize("sd,m", [(16, 8), (8, 16)])
+def test_piped_last_chunk_lengths(oracle, sd, m, tail_steps):
+    """The last row chunk of a launch may be any number of steps long (the others are >= 8).  The two-step tail of the
+    encode form pairs step S - 1 with step S: a chunk of one step has no partner for its only step (it is the dummy's
+    partner after the loop), one of two or three steps ends on a real / a dummy second step -- codes bit for bit, and a
+    partial last step on top."""
+    waves = 1024 * (2 if sd == 8 else 1)
+    chunks = waves // m
+    per = 10                                            # steps per chunk (>= 8: the pipelined kernel)
+    n_steps = (chunks - 1) * per + tail_steps           # the last chunk gets tail_steps steps
+    n = n_steps * 32 - 13                               # ... the last one partial
+    assert (n_steps + chunks - 1) // chunks == per
+    rng = np.random.default_rng(100 * sd + tail_steps)
+    cb = _codebook(rng, m, 256, sd)
+    X = _rows(rng, n, cb)
+    enc = _lib.PQEncoder(cb, O.SQUARED_EUCLIDEAN)
+    codes, _ = enc.encode(X, want_f16=False)
+    assert _lib.last_assign_stats()[1] == _lib.ENGINE_MFMA_BF16
+    want_c, _ = oracle.pq_encode(O.SQUARED_EUCLIDEAN, X, cb, threads=0)
+    np.testing.assert_array_equal(codes.astype(np.uint32), want_c)
+    enc.close()
+
+
 def _fuzz_cases():
     import os
 

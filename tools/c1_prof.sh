@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o t -- python3 $GRAFT_REPO_ROOT/tools/c1_trace.py > /tmp/o.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o t -- python3 $GRAFT_REPO_ROOT/tools/c1_trace.py > /tmp/o.txt 2>&1
 cat /tmp/o.txt | tail -3
 f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'

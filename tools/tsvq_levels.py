@@ -7,7 +7,7 @@ for r in tr:
     if m:
         ks.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), m.group(0)))
 ks.sort()
-idx = max(i for i, k in enumerate(ks) if k[2].startswith('k_iota'))
+idx = max(i for i, k in enumerate(ks) if k[2].startswith(('k_build_init', 'k_iota')))
 sel = ks[idx:]
 t0 = sel[0][0]
 args = sys.argv[2:]
