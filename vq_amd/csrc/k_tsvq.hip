@@ -985,6 +985,8 @@ __global__ __launch_bounds__(1024) void k_fs_prefix(uint32_t d, const uint32_t *
     }
 }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 // LDS exchange inside ONE wave (k_fs_fold and k_fs_chain run one-wave workgroups): the LDS serves a wave's instructions
 // in order, so all that is needed is that the compiler keeps the order and waits for the LDS counter.  __syncthreads()
 // would also wait for every global load in flight (s_waitcnt vmcnt(0)) -- the rows of the next block, the next batches
@@ -1371,6 +1373,23 @@ __device__ __forceinline__ void fs_scan_incl(FsT &v, uint32_t lane) {
 #undef VQ_FS_DPP
 }
 
+// the same over every group of eight lanes (three in-row steps; lane j of a group composes lanes 0 .. j of it)
+__device__ __forceinline__ void fs_scan_incl8(FsT &v, uint32_t jl) {
+#define VQ_FS_DPP(X, CTRL) __builtin_amdgcn_update_dpp(0, X, CTRL, 0xF, 0xF, true)
+#define VQ_FS_STEP(CTRL, COND)                                                                         \
+    {                                                                                                  \
+        FsT p;                                                                                         \
+        p.d0 = VQ_FS_DPP(v.d0, CTRL), p.lo0 = VQ_FS_DPP(v.lo0, CTRL), p.hi0 = VQ_FS_DPP(v.hi0, CTRL);  \
+        p.d1 = VQ_FS_DPP(v.d1, CTRL), p.lo1 = VQ_FS_DPP(v.lo1, CTRL), p.hi1 = VQ_FS_DPP(v.hi1, CTRL);  \
+        if (COND) v = fs_compose(p, v);                                                                \
+    }
+    VQ_FS_STEP(0x111, jl >= 1u)  // row_shr:1
+    VQ_FS_STEP(0x112, jl >= 2u)  // row_shr:2
+    VQ_FS_STEP(0x114, jl >= 4u)  // row_shr:4
+#undef VQ_FS_STEP
+#undef VQ_FS_DPP
+}
+
 // does a run with prefixes lo .. hi (relative to S) stay strictly inside the binade of S = +-[2^23, 2^24)?  Strictly on
 // the zero side: a sum that rounds to exactly +-2^23 on this grid may have had a smaller magnitude, which the finer
 // grid below represents differently (it may also be exact -- then the segment is merely re-added)
@@ -1391,6 +1410,10 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
     // dbg: 8 counters of this (level, pass): chains, re-added segments, most in one chain, and the first reason the
     // re-added segment failed: unusable summary / other binade than guessed / prefix leaves the binade / sum not normal
     __shared__ int plist[64 * kFsSpl];                            // side slots of the batch's parked segments, in order
+    __shared__ __attribute__((aligned(16))) FsS lsum[64 * kFsSpl];  // the batch's summaries [lane][j], staged at its first failing lane
+    __shared__ __attribute__((aligned(16))) FsS lsum2[64 * kFsSpl];  // ... and their odd streams (batches with an exact tie)
+    __shared__ __attribute__((aligned(16))) float ladd[64];         // the addends of a gathered (not parked) segment being re-added
+    __shared__ __attribute__((aligned(16))) float lpark[kFsAhead * 64];  // group A: the addends of kFsAhead parked segments
     if (blockIdx.x >= lv->n_fast) return;
     const uint32_t node = fast_nodes[blockIdx.x], c = blockIdx.y, lane = threadIdx.x;
     const uint32_t a = na.seg_start[node], len = na.seg_len[node];
@@ -1400,6 +1423,10 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
     const float mu = (MODE == 1) ? na.centroid[(size_t)node * d + c] : 0.0f;
     float s = (MODE == 0) ? 0.0f : -0.0f;
     uint32_t fallbacks = 0;
+    // dbg: core cycles (s_memtime) of the whole chain, inside the failing lanes' walks, inside the re-additions, in the
+    // wave-wide scan passes of two-stream batches (one stream: the fetch of the staged summaries); failing lanes
+    unsigned long long cyc_all = dbg ? clock64() : 0ull, cyc_walk = 0ull, cyc_readd = 0ull, cyc_lds = 0ull;
+    uint32_t n_walks = 0;
     // UNCONDITIONAL loads (index clamped): a load under `if (t < nseg)` is followed by the merge with the other branch's
     // value, i.e. by s_waitcnt vmcnt(0) right behind the load -- every batch then cost four serial memory round trips
     // (~3 us).  What lies past the node's end is marked unusable when the registers are consumed.
@@ -1468,8 +1495,8 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
         // addends of the parked segments, kFsAhead at a time: group A is complete (plain registers: reading it waits for
         // nothing), group B in flight behind it; when the walk passes A's last rank B becomes A and the next group is
         // requested.  The batch starts with its first group in B.
-        float pa[kFsAhead], pb[kFsAhead];
-        int32_t pa_base = -kFsAhead;  // rank held by pa[0]
+        float pb[kFsAhead];
+        int32_t pa_base = -kFsAhead;  // rank of group A's first segment (lpark[0 .. 63])
         auto request_b = [&](uint32_t base) {
 #pragma unroll
             for (int k = 0; k < kFsAhead; ++k) {
@@ -1477,8 +1504,6 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                 if (base + (uint32_t)k < ptotal) pb[k] = side[(size_t)plist[base + (uint32_t)k] * kFsSeg + lane];
             }
         };
-#pragma unroll
-        for (int k = 0; k < kFsAhead; ++k) pa[k] = 0.0f;
         request_b(0);
         // ---- this lane's run: its segments composed, usable iff all are and share a binade ----
         FsT mine;
@@ -1499,77 +1524,184 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                 mine.d1 = mine.d0, mine.lo1 = mine.lo0, mine.hi1 = mine.hi0;
             }
         }
-        // ---- lane `good` does not hold as a whole: its segments one by one, applied or re-added ----
-        auto step_lane = [&](uint32_t good) {
+        // the 64 rows of segment `seg` re-added in the reference's order (uniform: every lane carries the same s)
+        // The 64 additions in row order, the addends in LDS: sixteen BROADCAST reads (every lane reads the same 16 bytes:
+        // four addends per ds_read_b128, no bank conflicts), all in flight ahead of the additions that use them -- the
+        // chain is 64 dependent v_add_f32 on VGPR operands at the add's own ~4 cycles.  (Round 3 handed the addends from
+        // lane to SGPR with 64 v_readlane, sixteen ahead: 32 SGPRs of a kernel that spills 45 already, and ~1300 cycles
+        // per segment measured in place -- 20 per addition.)
+        auto add64 = [&](const float *lds64) {
+            const f32x4_t *l4 = reinterpret_cast<const f32x4_t *>(lds64);
+            f32x4_t rq[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) rq[g] = l4[g];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                s = s + rq[g][0];
+                s = s + rq[g][1];
+                s = s + rq[g][2];
+                s = s + rq[g][3];
+            }
+        };
+        // the 64 rows of segment `seg` re-added in the reference's order (uniform: every lane carries the same s).  Parked
+        // segments: the group of kFsAhead that has arrived sits in LDS (written when it became group A: the fold parked
+        // +0.0 for rows past the node's end), the re-addition reads its 256 bytes from there; the two sources of addends
+        // do NOT join before the additions (joined, the gathered path's wait for its load -- vmcnt(0): everything in
+        // flight, the group just requested included, a full memory round trip at every eighth parked segment -- was paid
+        // by the parked path too; picking one of eight registers by a run-time rank went through scratch memory).
+        auto readd = [&](uint32_t seg, int32_t gef, int32_t rank) {
+            ++fallbacks;
+            const unsigned long long c_in = dbg ? clock64() : 0ull;
+            const int slot = fs_ef_slot(gef);
+            if (slot >= 0) {  // parked by k_fs_fold: contiguous, requested a group ahead
+                while (rank >= pa_base + kFsAhead) {  // uniform: group B has arrived and becomes A, the next one is requested
+                    fs_wave_lds_sync();  // the reads of the old group A are done
+#pragma unroll
+                    for (int k = 0; k < kFsAhead; ++k) lpark[k * 64 + (int)lane] = pb[k];
+                    pa_base += kFsAhead;
+                    request_b((uint32_t)(pa_base + kFsAhead));
+                    fs_wave_lds_sync();
+                }
+                add64(lpark + (rank - pa_base) * 64);
+            } else {
+                const uint32_t r0 = seg * kFsSeg, rows_here = min(kFsSeg, len - r0);
+                const float vv = (lane < rows_here) ? fs_value<MODE>(X[(size_t)perm[a + r0 + lane] * d + c], mu) : 0.0f;  // (+0.0 past the end)
+                if (dbg && lane == 0) atomicAdd(dbg + 7, 1u);
+                fs_wave_lds_sync();
+                ladd[lane] = vv;
+                fs_wave_lds_sync();
+                add64(ladd);
+            }
+            if (dbg) {
+                asm volatile("" ::"v"(s));
+                cyc_readd += clock64() - c_in;
+            }
+        };
+        // One stream: the failing lane's eight segments are SCANNED, not walked.  Walking them one by one (four
+        // v_readlane and ~25 dependent scalar-ish instructions per segment, whether it holds or not) was ~1100 of the
+        // ~2000 cycles a failing lane costs -- and on zero-mean columns 10-28 % of the segments fail, one wave per column
+        // paying for each in series.  The batch's summaries go to LDS once (at its first failing lane), lanes 0..7 fetch
+        // the failing lane's eight (one ds_read_b128), a three-step prefix gives every segment its incoming S, one ballot
+        // finds the first that does not hold: the segments in front of it are applied in one step, it is re-added, the
+        // ballot is repeated behind it.
+        bool staged = false;
+        auto walk_lane = [&](uint32_t good) {
+            const unsigned long long w_in = dbg ? clock64() : 0ull;
+            ++n_walks;
+            if (!staged) {  // uniform
+                fs_wave_lds_sync();  // the previous batch's reads of lsum are done
+#pragma unroll
+                for (int j = 0; j < kFsSpl; ++j) lsum[lane * kFsSpl + (uint32_t)j] = m[j];
+                fs_wave_lds_sync();
+                staged = true;
+            }
             const uint32_t pb_g = (uint32_t)__builtin_amdgcn_readlane((int)pbefore, (int)good),
                            pk_g = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)good);
-#pragma unroll
-            for (int j = 0; j < kFsSpl; ++j) {
-                const uint32_t seg = t0 + kFsSpl * good + (uint32_t)j;
-                if (seg < nseg) {  // uniform
-                    const int32_t gd0 = __builtin_amdgcn_readlane(m[j].d, (int)good), glo0 = __builtin_amdgcn_readlane(m[j].lo, (int)good),
-                                  ghi0 = __builtin_amdgcn_readlane(m[j].hi, (int)good), gef = __builtin_amdgcn_readlane(m[j].ef, (int)good);
-                    int32_t gd1 = gd0, glo1 = glo0, ghi1 = ghi0;
-                    if (two) {
-                        gd1 = __builtin_amdgcn_readlane(m2[j].d, (int)good), glo1 = __builtin_amdgcn_readlane(m2[j].lo, (int)good);
-                        ghi1 = __builtin_amdgcn_readlane(m2[j].hi, (int)good);
-                    }
-                    const uint32_t sb1 = __float_as_uint(s), se1 = (sb1 >> 23) & 0xFFu;
-                    const int32_t mag1 = (int32_t)((sb1 & 0x7FFFFFu) | 0x800000u);
-                    const int32_t S1 = (sb1 >> 31) ? -mag1 : mag1;
-                    const bool odd1 = (S1 & 1) != 0;
-                    const bool holds = (se1 != 0u) && (se1 != 255u) && !(gef & 1) && ((int)se1 - 127 == fs_ef_e(gef)) &&
-                                       fs_inside(S1, odd1 ? glo1 : glo0, odd1 ? ghi1 : ghi0);
-                    if (holds) {
-                        const int32_t S2 = S1 + (odd1 ? gd1 : gd0);
-                        const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
-                        s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se1 << 23) | (m2a & 0x7FFFFFu));
-                    } else {
-                        ++fallbacks;
-                        if (dbg && lane == 0) {
-                            const int why = (se1 == 0u || se1 == 255u) ? 6 : (gef & 1) ? 3 : ((int)se1 - 127 != fs_ef_e(gef)) ? 4 : 5;
-                            atomicAdd(dbg + why, 1u);
-                        }
-                        const uint32_t r0 = seg * kFsSeg, rows_here = min(kFsSeg, len - r0);
-                        const int slot = fs_ef_slot(gef);
-                        float vv;
-                        if (slot >= 0) {  // parked by k_fs_fold: contiguous, requested a group ahead
-                            const int32_t rank = (int32_t)(pb_g + (uint32_t)__builtin_popcount(pk_g & ((1u << j) - 1u)));
-                            while (rank >= pa_base + kFsAhead) {  // uniform
-#pragma unroll
-                                for (int k = 0; k < kFsAhead; ++k) pa[k] = pb[k];
-                                pa_base += kFsAhead;
-                                request_b((uint32_t)(pa_base + kFsAhead));
-                            }
-                            const int32_t at = rank - pa_base;
-                            vv = pa[0];
-#pragma unroll
-                            for (int k = 1; k < kFsAhead; ++k) vv = (at == k) ? pa[k] : vv;
-                        } else {
-                            vv = (lane < rows_here) ? fs_value<MODE>(X[(size_t)perm[a + r0 + lane] * d + c], mu) : 0.0f;
-                            if (dbg && lane == 0) atomicAdd(dbg + 7, 1u);
-                        }
-                        if (lane >= rows_here) vv = 0.0f;  // rows past the node's end: +0.0 (the sum is never -0.0 once a real row is in)
-                        // The 64 additions in row order, the addends handed from lane to SGPR sixteen at a time AHEAD of
-                        // the additions that use them: a v_readlane next to its v_add pays the VALU-writes-SGPR hazard on
-                        // every addition (29 cycles each, measured); with the reads a group ahead the chain runs at the
-                        // add's own latency (~10 cycles) and needs neither LDS staging nor its round trip.
-                        float tq[16], tn[16];
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) tq[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), k));
-#pragma unroll
-                        for (int grp = 0; grp < 4; ++grp) {
-                            if (grp < 3) {
-#pragma unroll
-                                for (int k = 0; k < 16; ++k) tn[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), 16 * (grp + 1) + k));
-                            }
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) s = s + tq[k];
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) tq[k] = tn[k];
-                        }
-                    }
+            const uint32_t jl = lane & 7u;
+            FsS g = lsum[good * kFsSpl + jl];  // every group of eight lanes holds a copy; lanes 0..7 decide
+            if (dbg) {
+                asm volatile("" : "+v"(g.d), "+v"(g.lo), "+v"(g.hi), "+v"(g.ef));
+                cyc_lds += clock64() - w_in;
+            }
+            const uint32_t seg_first = t0 + kFsSpl * good;
+            const uint32_t nvalid = min((uint32_t)kFsSpl, nseg - seg_first);  // this lane's segments inside the node (>= 1)
+            int32_t incl8 = g.d;
+#define VQ_FS_ADD8(CTRL, K) { const int32_t t = __builtin_amdgcn_update_dpp(0, incl8, CTRL, 0xF, 0xF, true); if (jl >= K) incl8 += t; }
+            VQ_FS_ADD8(0x111, 1u)
+            VQ_FS_ADD8(0x112, 2u)
+            VQ_FS_ADD8(0x114, 4u)
+#undef VQ_FS_ADD8
+            const int32_t before8 = incl8 - g.d;
+            const bool usable = !(g.ef & 1);
+            const int g_e = fs_ef_e(g.ef);
+            const uint32_t beyond = ~0u << nvalid;  // (nvalid <= 8)
+            uint32_t start2 = 0;
+            int32_t base2 = 0;
+            for (;;) {
+                const uint32_t sb1 = __float_as_uint(s), se1 = (sb1 >> 23) & 0xFFu;
+                const int32_t mag1 = (int32_t)((sb1 & 0x7FFFFFu) | 0x800000u);
+                const int32_t S1 = (sb1 >> 31) ? -mag1 : mag1;
+                const bool ok = (se1 != 0u) && (se1 != 255u) && usable && ((int)se1 - 127 == g_e) && fs_inside(S1 + before8 - base2, g.lo, g.hi);
+                const uint32_t bad8 = (uint32_t)__ballot(!ok) & 0xFFu;
+                const uint32_t js = (uint32_t)__builtin_ctz((bad8 | beyond) & (~0u << start2));  // first that does not hold, or nvalid
+                if (js > start2) {
+                    const int32_t S2 = S1 + __builtin_amdgcn_readlane(incl8, (int)js - 1) - base2;
+                    const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
+                    s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se1 << 23) | (m2a & 0x7FFFFFu));
                 }
+                if (js >= nvalid) break;
+                const int32_t gef = __builtin_amdgcn_readlane(g.ef, (int)js);
+                if (dbg && lane == 0) {
+                    const uint32_t sb2 = __float_as_uint(s), se2 = (sb2 >> 23) & 0xFFu;  // the S the failing segment meets
+                    const int why = (se2 == 0u || se2 == 255u) ? 6 : (gef & 1) ? 3 : ((int)se2 - 127 != fs_ef_e(gef)) ? 4 : 5;
+                    atomicAdd(dbg + why, 1u);
+                }
+                readd(seg_first + js, gef, (int32_t)(pb_g + (uint32_t)__builtin_popcount(pk_g & ((1u << js) - 1u))));
+                base2 = __builtin_amdgcn_readlane(incl8, (int)js);
+                start2 = js + 1;
+                if (start2 >= nvalid) break;
+            }
+            if (dbg) {
+                asm volatile("" ::"v"(s));
+                cyc_walk += clock64() - w_in;
+            }
+        };
+        // Two streams (an exact tie somewhere in the batch -- every batch of zero-mean data, whose sums stay small against
+        // their addends): the same, with the segments' parity transducers composed over the eight lanes; the scan is
+        // repeated behind every segment that does not hold, the segments already consumed scanning as the identity --
+        // the wave's own loop at the scale of one lane.  (Round 3 walked the eight segments one by one through
+        // v_readlane and SGPRs: 580 cycles per segment visited, holding or not, 4600 of the 9500 a failing lane cost.)
+        auto walk_lane2 = [&](uint32_t good) {
+            if (!staged) {  // uniform
+                fs_wave_lds_sync();
+#pragma unroll
+                for (int j = 0; j < kFsSpl; ++j) lsum[lane * kFsSpl + (uint32_t)j] = m[j], lsum2[lane * kFsSpl + (uint32_t)j] = m2[j];
+                fs_wave_lds_sync();
+                staged = true;
+            }
+            const uint32_t pb_g = (uint32_t)__builtin_amdgcn_readlane((int)pbefore, (int)good),
+                           pk_g = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)good);
+            const uint32_t jl = lane & 7u;
+            const FsS g = lsum[good * kFsSpl + jl], g2 = lsum2[good * kFsSpl + jl];
+            const uint32_t seg_first = t0 + kFsSpl * good;
+            const uint32_t nvalid = min((uint32_t)kFsSpl, nseg - seg_first);
+            const bool usable = !(g.ef & 1);
+            const int g_e = fs_ef_e(g.ef);
+            const uint32_t beyond = ~0u << nvalid;
+            uint32_t start2 = 0;
+            for (;;) {
+                const uint32_t sb1 = __float_as_uint(s), se1 = (sb1 >> 23) & 0xFFu;
+                const int32_t mag1 = (int32_t)((sb1 & 0x7FFFFFu) | 0x800000u);
+                const int32_t S1 = (sb1 >> 31) ? -mag1 : mag1;
+                const bool in = jl >= start2;
+                FsT v;
+                v.d0 = in ? g.d : 0, v.lo0 = in ? g.lo : 0, v.hi0 = in ? g.hi : 0;
+                v.d1 = in ? g2.d : 0, v.lo1 = in ? g2.lo : 0, v.hi1 = in ? g2.hi : 0;
+                fs_scan_incl8(v, jl);
+                const int32_t incl_d = (S1 & 1) ? v.d1 : v.d0;  // delta from segment start2 through this one, for the actual parity of S
+                int32_t before8 = __builtin_amdgcn_update_dpp(0, incl_d, 0x111, 0xF, 0xF, true);  // row_shr:1
+                if (jl == 0u) before8 = 0;
+                const int32_t Sin = S1 + before8;
+                const bool podd = (Sin & 1) != 0;
+                const bool ok = (se1 != 0u) && (se1 != 255u) && usable && ((int)se1 - 127 == g_e) &&
+                                fs_inside(Sin, podd ? g2.lo : g.lo, podd ? g2.hi : g.hi);
+                const uint32_t bad8 = (uint32_t)__ballot(!ok) & 0xFFu;
+                const uint32_t js = (uint32_t)__builtin_ctz((bad8 | beyond) & (~0u << start2));
+                if (js > start2) {
+                    const int32_t S2 = S1 + __builtin_amdgcn_readlane(incl_d, (int)js - 1);
+                    const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
+                    s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se1 << 23) | (m2a & 0x7FFFFFu));
+                }
+                if (js >= nvalid) break;
+                const int32_t gef = __builtin_amdgcn_readlane(g.ef, (int)js);
+                if (dbg && lane == 0) {
+                    const uint32_t sb2 = __float_as_uint(s), se2 = (sb2 >> 23) & 0xFFu;
+                    const int why = (se2 == 0u || se2 == 255u) ? 6 : (gef & 1) ? 3 : ((int)se2 - 127 != fs_ef_e(gef)) ? 4 : 5;
+                    atomicAdd(dbg + why, 1u);
+                }
+                readd(seg_first + js, gef, (int32_t)(pb_g + (uint32_t)__builtin_popcount(pk_g & ((1u << js) - 1u))));
+                start2 = js + 1;
+                if (start2 >= nvalid) break;
             }
         };
         const uint64_t past = nl < 64 ? (~0ull << nl) : 0ull;  // lanes behind the batch's last
@@ -1606,7 +1738,7 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                     s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2a & 0x7FFFFFu));
                 }
                 if (good >= nl) break;
-                step_lane(good);
+                walk_lane(good);
                 base_d = __builtin_amdgcn_readlane(incl, (int)good);
                 start = good + 1;
                 if (start >= nl) break;
@@ -1621,6 +1753,7 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                 const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
                 const int32_t S = (sb >> 31) ? -mag : mag;
                 const bool in = lane >= start;
+                const unsigned long long sc_in = dbg ? clock64() : 0ull;
                 FsT v;
                 v.d0 = in ? mine.d0 : 0, v.d1 = in ? mine.d1 : 0, v.lo0 = in ? mine.lo0 : 0, v.lo1 = in ? mine.lo1 : 0;
                 v.hi0 = in ? mine.hi0 : 0, v.hi1 = in ? mine.hi1 : 0;
@@ -1640,8 +1773,18 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                     const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
                     s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2a & 0x7FFFFFu));
                 }
+                if (dbg) {
+                    asm volatile("" ::"v"(s));
+                    cyc_lds += clock64() - sc_in;  // (two streams: scan + test + apply)
+                }
                 if (good >= nl) break;
-                step_lane(good);
+                const unsigned long long w_in = dbg ? clock64() : 0ull;
+                ++n_walks;
+                walk_lane2(good);
+                if (dbg) {
+                    asm volatile("" ::"v"(s));
+                    cyc_walk += clock64() - w_in;
+                }
                 start = good + 1;
                 if (start >= nl) break;
             }
@@ -1655,6 +1798,12 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
             atomicAdd(dbg + 0, 1u);
             atomicAdd(dbg + 1, fallbacks);
             atomicMax(dbg + 2, fallbacks);
+            atomicAdd(dbg + 8, (uint32_t)((clock64() - cyc_all) >> 6));
+            atomicAdd(dbg + 9, (uint32_t)(cyc_walk >> 6));
+            atomicAdd(dbg + 10, (uint32_t)(cyc_readd >> 6));
+            atomicAdd(dbg + 11, (uint32_t)(cyc_lds >> 6));
+            atomicAdd(dbg + 12, n_walks);
+            atomicMax(dbg + 13, (uint32_t)((clock64() - cyc_all) >> 6));
         }
     }
 }
@@ -2264,6 +2413,11 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
                 fprintf(stderr, "[vqhip]   level %u %s: %u chains, %u segments re-added (most in one chain %u): unusable summary %u, "
                                 "other binade than guessed %u, prefix leaves the binade %u, sum not normal %u; %u gathered (not parked)\n",
                         q / 2, (q & 1) ? "variance" : "mean", c8[0], c8[1], c8[2], c8[3], c8[4], c8[5], c8[6], c8[7]);
+            if (c8[0] && c8[12])
+                fprintf(stderr, "[vqhip]     core cycles per chain (average; longest %.0f k): %.0f k, of which in %u failing lanes %.0f k "
+                                "(%.0f per lane; wave-wide scan pass / summary fetch %.0f; re-additions %.0f per segment)\n",
+                        c8[13] * 64.0 / 1e3, c8[8] * 64.0 / c8[0] / 1e3, c8[12] / c8[0], c8[9] * 64.0 / c8[0] / 1e3, c8[9] * 64.0 / c8[12],
+                        c8[11] * 64.0 / c8[12], c8[10] * 64.0 / (c8[1] ? c8[1] : 1));
         }
     }
     // nodes -> host, then BFS -> pre-order (the oracle's numbering)
