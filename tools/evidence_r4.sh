@@ -1,5 +1,5 @@
 set -u
-O=gpurun_out/prof_r4b; mkdir -p $O
+O=gpurun_out/prof_r4c; mkdir -p $O
 timeout 300 python -m pytest tests/test_gpu_piped.py -x -q 2>&1 | tail -2
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json | head -c 300; echo
 timeout 400 python bench.py --config C5 --no-configs --no-cpu-baseline > $O/bench_c5.json 2>/dev/null; python3 -c "
