@@ -1352,43 +1352,42 @@ __global__ __launch_bounds__(64, 2) void k_fs_fold(const float *__restrict__ X, 
 constexpr int kFsSpl = 8;     // segments per lane and batch
 constexpr int kFsAhead = 8;   // parked segments whose addends travel together (two such groups: one complete, one in flight)
 
-__device__ __forceinline__ void fs_scan_incl(FsT &v, uint32_t lane) {
-    // in-row steps by DPP row_shr (lane i <- lane i - off of its 16-lane row), then the totals of rows 0 / 2 into
-    // rows 1 / 3 (row_bcast:15) and of lane 31 into rows 2 and 3 (row_bcast:31): six steps, no LDS round trips
-#define VQ_FS_DPP(X, CTRL) __builtin_amdgcn_update_dpp(0, X, CTRL, 0xF, 0xF, true)
-#define VQ_FS_STEP(CTRL, COND)                                                                         \
-    {                                                                                                  \
-        FsT p;                                                                                         \
-        p.d0 = VQ_FS_DPP(v.d0, CTRL), p.lo0 = VQ_FS_DPP(v.lo0, CTRL), p.hi0 = VQ_FS_DPP(v.hi0, CTRL);  \
-        p.d1 = VQ_FS_DPP(v.d1, CTRL), p.lo1 = VQ_FS_DPP(v.lo1, CTRL), p.hi1 = VQ_FS_DPP(v.hi1, CTRL);  \
-        if (COND) v = fs_compose(p, v);                                                                \
-    }
-    VQ_FS_STEP(0x111, (lane & 15u) >= 1u)   // row_shr:1
-    VQ_FS_STEP(0x112, (lane & 15u) >= 2u)   // row_shr:2
-    VQ_FS_STEP(0x114, (lane & 15u) >= 4u)   // row_shr:4
-    VQ_FS_STEP(0x118, (lane & 15u) >= 8u)   // row_shr:8
-    VQ_FS_STEP(0x142, (lane & 16u) != 0u)   // row_bcast:15 -> rows 1 and 3
-    VQ_FS_STEP(0x143, lane >= 32u)          // row_bcast:31 -> rows 2 and 3
-#undef VQ_FS_STEP
-#undef VQ_FS_DPP
+// The chain's scans only place the runs: what they need of a composition is where it leaves S (d0 / d1 by the parity
+// of the S entering) -- whether a run holds is tested against its OWN prefix bounds.  Two fields instead of six: 2 DPP
+// moves and ~6 instructions per step instead of 6 and ~14.
+struct FsD {
+    int32_t d0, d1;
+};
+__device__ __forceinline__ FsD fs_compose_d(const FsD &f, const FsD &g) {
+    FsD h;
+    h.d0 = f.d0 + ((f.d0 & 1) ? g.d1 : g.d0);
+    h.d1 = f.d1 + (((1 + f.d1) & 1) ? g.d1 : g.d0);
+    return h;
 }
-
-// the same over every group of eight lanes (three in-row steps; lane j of a group composes lanes 0 .. j of it)
-__device__ __forceinline__ void fs_scan_incl8(FsT &v, uint32_t jl) {
 #define VQ_FS_DPP(X, CTRL) __builtin_amdgcn_update_dpp(0, X, CTRL, 0xF, 0xF, true)
-#define VQ_FS_STEP(CTRL, COND)                                                                         \
-    {                                                                                                  \
-        FsT p;                                                                                         \
-        p.d0 = VQ_FS_DPP(v.d0, CTRL), p.lo0 = VQ_FS_DPP(v.lo0, CTRL), p.hi0 = VQ_FS_DPP(v.hi0, CTRL);  \
-        p.d1 = VQ_FS_DPP(v.d1, CTRL), p.lo1 = VQ_FS_DPP(v.lo1, CTRL), p.hi1 = VQ_FS_DPP(v.hi1, CTRL);  \
-        if (COND) v = fs_compose(p, v);                                                                \
+#define VQ_FS_STEP_D(CTRL, COND)                                   \
+    {                                                              \
+        FsD p;                                                     \
+        p.d0 = VQ_FS_DPP(v.d0, CTRL), p.d1 = VQ_FS_DPP(v.d1, CTRL); \
+        if (COND) v = fs_compose_d(p, v);                          \
     }
-    VQ_FS_STEP(0x111, jl >= 1u)  // row_shr:1
-    VQ_FS_STEP(0x112, jl >= 2u)  // row_shr:2
-    VQ_FS_STEP(0x114, jl >= 4u)  // row_shr:4
-#undef VQ_FS_STEP
-#undef VQ_FS_DPP
+// in-row steps by DPP row_shr (lane i <- lane i - off of its 16-lane row), then the totals of rows 0 / 2 into rows 1 / 3
+// (row_bcast:15) and of lane 31 into rows 2 and 3 (row_bcast:31): six steps, no LDS round trips
+__device__ __forceinline__ void fs_scan_incl_d(FsD &v, uint32_t lane) {
+    VQ_FS_STEP_D(0x111, (lane & 15u) >= 1u)
+    VQ_FS_STEP_D(0x112, (lane & 15u) >= 2u)
+    VQ_FS_STEP_D(0x114, (lane & 15u) >= 4u)
+    VQ_FS_STEP_D(0x118, (lane & 15u) >= 8u)
+    VQ_FS_STEP_D(0x142, (lane & 16u) != 0u)
+    VQ_FS_STEP_D(0x143, lane >= 32u)
 }
+__device__ __forceinline__ void fs_scan_incl8_d(FsD &v, uint32_t jl) {  // every group of eight lanes
+    VQ_FS_STEP_D(0x111, jl >= 1u)
+    VQ_FS_STEP_D(0x112, jl >= 2u)
+    VQ_FS_STEP_D(0x114, jl >= 4u)
+}
+#undef VQ_FS_STEP_D
+#undef VQ_FS_DPP
 
 // does a run with prefixes lo .. hi (relative to S) stay strictly inside the binade of S = +-[2^23, 2^24)?  Strictly on
 // the zero side: a sum that rounds to exactly +-2^23 on this grid may have had a smaller magnitude, which the finer
@@ -1427,6 +1426,8 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
     // wave-wide scan passes of two-stream batches (one stream: the fetch of the staged summaries); failing lanes
     unsigned long long cyc_all = dbg ? clock64() : 0ull, cyc_walk = 0ull, cyc_readd = 0ull, cyc_lds = 0ull;
     uint32_t n_walks = 0;
+    unsigned long long cy_fetch = 0ull, cy_scan = 0ull, cy_apply = 0ull, cy_pre = 0ull, cy_add = 0ull;  // dbg, chain (0, 0): parts of a failing lane's walk
+    uint32_t n_iter = 0;
     // UNCONDITIONAL loads (index clamped): a load under `if (t < nseg)` is followed by the merge with the other branch's
     // value, i.e. by s_waitcnt vmcnt(0) right behind the load -- every batch then cost four serial memory round trips
     // (~3 us).  What lies past the node's end is marked unusable when the registers are consumed.
@@ -1484,6 +1485,7 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
 #undef VQ_FS_ADD
         }
         const uint32_t pbefore = pincl - pc, ptotal = (uint32_t)__builtin_amdgcn_readlane((int)pincl, 63);
+        if (dbg && lane == 0) atomicAdd(dbg + 14, ptotal);
         if (ptotal) {  // uniform
             fs_wave_lds_sync();  // the previous batch's reads of plist are done
             uint32_t r = pbefore;
@@ -1562,7 +1564,13 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                     request_b((uint32_t)(pa_base + kFsAhead));
                     fs_wave_lds_sync();
                 }
+                const unsigned long long q3 = dbg ? clock64() : 0ull;
+                if (dbg) cy_pre += q3 - c_in;
                 add64(lpark + (rank - pa_base) * 64);
+                if (dbg) {
+                    asm volatile("" ::"v"(s));
+                    cy_add += clock64() - q3;
+                }
             } else {
                 const uint32_t r0 = seg * kFsSeg, rows_here = min(kFsSeg, len - r0);
                 const float vv = (lane < rows_here) ? fs_value<MODE>(X[(size_t)perm[a + r0 + lane] * d + c], mu) : 0.0f;  // (+0.0 past the end)
@@ -1662,7 +1670,12 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
             const uint32_t pb_g = (uint32_t)__builtin_amdgcn_readlane((int)pbefore, (int)good),
                            pk_g = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)good);
             const uint32_t jl = lane & 7u;
-            const FsS g = lsum[good * kFsSpl + jl], g2 = lsum2[good * kFsSpl + jl];
+            const unsigned long long q0 = dbg ? clock64() : 0ull;
+            FsS g = lsum[good * kFsSpl + jl], g2 = lsum2[good * kFsSpl + jl];
+            if (dbg) {
+                asm volatile("" : "+v"(g.d), "+v"(g2.d));
+                cy_fetch += clock64() - q0;
+            }
             const uint32_t seg_first = t0 + kFsSpl * good;
             const uint32_t nvalid = min((uint32_t)kFsSpl, nseg - seg_first);
             const bool usable = !(g.ef & 1);
@@ -1670,14 +1683,15 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
             const uint32_t beyond = ~0u << nvalid;
             uint32_t start2 = 0;
             for (;;) {
+                const unsigned long long q1 = dbg ? clock64() : 0ull;
+                ++n_iter;
                 const uint32_t sb1 = __float_as_uint(s), se1 = (sb1 >> 23) & 0xFFu;
                 const int32_t mag1 = (int32_t)((sb1 & 0x7FFFFFu) | 0x800000u);
                 const int32_t S1 = (sb1 >> 31) ? -mag1 : mag1;
                 const bool in = jl >= start2;
-                FsT v;
-                v.d0 = in ? g.d : 0, v.lo0 = in ? g.lo : 0, v.hi0 = in ? g.hi : 0;
-                v.d1 = in ? g2.d : 0, v.lo1 = in ? g2.lo : 0, v.hi1 = in ? g2.hi : 0;
-                fs_scan_incl8(v, jl);
+                FsD v;
+                v.d0 = in ? g.d : 0, v.d1 = in ? g2.d : 0;
+                fs_scan_incl8_d(v, jl);
                 const int32_t incl_d = (S1 & 1) ? v.d1 : v.d0;  // delta from segment start2 through this one, for the actual parity of S
                 int32_t before8 = __builtin_amdgcn_update_dpp(0, incl_d, 0x111, 0xF, 0xF, true);  // row_shr:1
                 if (jl == 0u) before8 = 0;
@@ -1686,11 +1700,20 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                 const bool ok = (se1 != 0u) && (se1 != 255u) && usable && ((int)se1 - 127 == g_e) &&
                                 fs_inside(Sin, podd ? g2.lo : g.lo, podd ? g2.hi : g.hi);
                 const uint32_t bad8 = (uint32_t)__ballot(!ok) & 0xFFu;
-                const uint32_t js = (uint32_t)__builtin_ctz((bad8 | beyond) & (~0u << start2));
+                uint32_t js = (uint32_t)__builtin_ctz((bad8 | beyond) & (~0u << start2));
+                const unsigned long long q2 = dbg ? clock64() : 0ull;
+                if (dbg) {
+                    asm volatile("" : "+s"(js));
+                    cy_scan += q2 - q1;
+                }
                 if (js > start2) {
                     const int32_t S2 = S1 + __builtin_amdgcn_readlane(incl_d, (int)js - 1);
                     const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
                     s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se1 << 23) | (m2a & 0x7FFFFFu));
+                }
+                if (dbg) {
+                    asm volatile("" ::"v"(s));
+                    cy_apply += clock64() - q2;
                 }
                 if (js >= nvalid) break;
                 const int32_t gef = __builtin_amdgcn_readlane(g.ef, (int)js);
@@ -1754,10 +1777,9 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                 const int32_t S = (sb >> 31) ? -mag : mag;
                 const bool in = lane >= start;
                 const unsigned long long sc_in = dbg ? clock64() : 0ull;
-                FsT v;
-                v.d0 = in ? mine.d0 : 0, v.d1 = in ? mine.d1 : 0, v.lo0 = in ? mine.lo0 : 0, v.lo1 = in ? mine.lo1 : 0;
-                v.hi0 = in ? mine.hi0 : 0, v.hi1 = in ? mine.hi1 : 0;
-                fs_scan_incl(v, lane);
+                FsD v;
+                v.d0 = in ? mine.d0 : 0, v.d1 = in ? mine.d1 : 0;
+                fs_scan_incl_d(v, lane);
                 const int32_t incl_d = (S & 1) ? v.d1 : v.d0;  // delta from position `start`, for the actual parity of S
                 int32_t before = __shfl_up(incl_d, 1);
                 if (lane == 0) before = 0;
@@ -1804,6 +1826,11 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
             atomicAdd(dbg + 11, (uint32_t)(cyc_lds >> 6));
             atomicAdd(dbg + 12, n_walks);
             atomicMax(dbg + 13, (uint32_t)((clock64() - cyc_all) >> 6));
+            if (blockIdx.x == 0 && blockIdx.y == 0 && n_walks)
+                printf("[vqhip-dev] chain(0,0) mode %d: %u failing lanes, %u scan passes, %u re-added; cycles per failing lane: fetch %.0f; per scan pass: "
+                       "scan+test %.0f, apply %.0f; per re-added segment: before the additions %.0f, additions %.0f; all %.0f k\n",
+                       MODE, n_walks, n_iter, fallbacks, (double)cy_fetch / n_walks, (double)cy_scan / n_iter, (double)cy_apply / n_iter,
+                       (double)cy_pre / (fallbacks ? fallbacks : 1), (double)cy_add / (fallbacks ? fallbacks : 1), (double)(clock64() - cyc_all) / 1e3);
         }
     }
 }
@@ -2415,9 +2442,9 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
                         q / 2, (q & 1) ? "variance" : "mean", c8[0], c8[1], c8[2], c8[3], c8[4], c8[5], c8[6], c8[7]);
             if (c8[0] && c8[12])
                 fprintf(stderr, "[vqhip]     core cycles per chain (average; longest %.0f k): %.0f k, of which in %u failing lanes %.0f k "
-                                "(%.0f per lane; wave-wide scan pass / summary fetch %.0f; re-additions %.0f per segment)\n",
+                                "(%.0f per lane; wave-wide scan pass / summary fetch %.0f; re-additions %.0f per segment); %u segments parked\n",
                         c8[13] * 64.0 / 1e3, c8[8] * 64.0 / c8[0] / 1e3, c8[12] / c8[0], c8[9] * 64.0 / c8[0] / 1e3, c8[9] * 64.0 / c8[12],
-                        c8[11] * 64.0 / c8[12], c8[10] * 64.0 / (c8[1] ? c8[1] : 1));
+                        c8[11] * 64.0 / c8[12], c8[10] * 64.0 / (c8[1] ? c8[1] : 1), c8[14]);
         }
     }
     // nodes -> host, then BFS -> pre-order (the oracle's numbering)
