@@ -49,6 +49,30 @@ def test_build_bit_identical(oracle, kind, shape):
     _assert_same_tree(got, oracle.tsvq_build(X, depth))
 
 
+@pytest.mark.parametrize("kind", ["normal", "normal_scales", "lattice0", "uniform0"])
+@pytest.mark.parametrize("shape", [(70_001, 40, 4), (150_003, 36, 5), (33_000, 128, 2)])
+def test_build_zero_mean_long_nodes_bit_identical(oracle, kind, shape):
+    """Zero-mean columns on nodes long enough for the exact parallel column sums (>= 16384 rows): the running sum is a
+    random walk that keeps re-crossing binade edges and meets exact ties in practically every segment, so the chain runs
+    its two-stream path, scans failing lanes over eight lanes and re-adds parked segments from LDS -- on row counts that
+    are no multiple of 64, column counts that are no multiple of 32, values over twelve binades, a centred lattice (exact
+    sums, ties everywhere) and centred uniform rows.  Structure and every centroid bit against the oracle."""
+    n, d, depth = shape
+    rng = np.random.default_rng(n + d)
+    if kind == "normal":
+        X = rng.standard_normal((n, d)).astype(F)
+    elif kind == "normal_scales":
+        X = (rng.standard_normal((n, d)) * 10.0 ** rng.uniform(-3, 3, (n, 1))).astype(F)
+    elif kind == "lattice0":
+        X = rng.integers(-2, 3, (n, d)).astype(F)
+    else:
+        X = (rng.random((n, d), dtype=F) - F(0.5)).astype(F)
+    ds = _lib.Dataset.from_host(X)
+    got = build_tree(ds, depth)
+    ds.close()
+    _assert_same_tree(got, oracle.tsvq_build(X, depth))
+
+
 def test_build_partial_nan_and_identical_rows(oracle):
     X = _data(22, 500, 8, "normal")
     X[17, 3] = np.nan
