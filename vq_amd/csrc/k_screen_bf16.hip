@@ -710,9 +710,10 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
 //     as they are consumed) and the tail of step st - 1 (merge of the chains and lane halves, margin test, code,
 //     work list), all within phases 0..5 -- the operands must be complete when phase 6 issues tile 0 of step st + 1.
 // Two operand sets and two sets of chains alternate (the loop body is unrolled twice; a chunk of an odd number of
-// steps runs one dummy step whose rows are clamped and whose tail writes nothing).  The arithmetic, the index tags and
-// the order in which values enter a chain are those of the X32 kernel: codes, work lists and statistics are the same
-// bits.  launch_one_x32 picks this variant for chunks of at least kPipeMinSteps steps, 8 tiles (k in 225..256),
+// steps runs one dummy step whose rows are clamped and whose tail writes nothing).  The arithmetic is the X32 kernel's
+// and the codes are the same bits; since round 4 a lane runs two chains under other tags (reduce_hg) and the encode form
+// shares one tail between two steps (tail_pair_piece), so a row whose gap sits within the tags' 64 ulps of the margin may
+// land on the other side of the test -- in the re-check list or out of it.  launch_one_x32 picks this variant for chunks of at least kPipeMinSteps steps, 8 tiles (k in 225..256),
 // sub_dim 8 or 16, one centroid group.
 template <int SD, int NT32, bool ACC = false>
 __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_assign_screen_bf16_x32p(
