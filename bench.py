@@ -41,7 +41,7 @@ CYCLES_PER_ISSUE_LONE_WAVE = 5.3  # profiles/ubench/valu_issue.hip: one wave per
 PEAK_HBM_GBS = 8000.0
 N_PER_GPU, DIM, M, K = 1_000_000, 128, 8, 256
 DATA_SEED, TRAIN_ITERS = 66, 4
-PREWARM_STEPS = 40  # untimed encode passes in front of the warmup (GPU clocks back up after the host-side gap)
+PREWARM_STEPS = 200  # untimed encode passes in front of the warmup (GPU clocks back up after the host-side gap)
 WORKLOADS = {  # BASELINE.json configs[1] and configs[4] (per-GPU share of the 100M x 128 job on 8 GPUs)
     "C2": dict(rows=1_000_000, dim=128, m=8, k=256, label="BASELINE.json configs[1]"),
     "C5": dict(rows=12_500_000, dim=128, m=16, k=256, label="BASELINE.json configs[4], one GPU's rows of 100M x 128 on 8 GPUs"),
@@ -657,7 +657,7 @@ def measure(args, ranks, wl_name, scaling, *, torch, _lib, engine, ncomm, collec
     codes = torch.empty((n, m_), dtype=torch.uint8, device="cuda")
     xptr = ds.device_ptr
     # the host work between the k-means block and here leaves the GPU idle and its clocks down; the first ~30 passes after
-    # that run up to 10 % slow (0.44, 0.44, 0.41, 0.39 ms per pass in groups of ten: tools/ab_screen.py).  PREWARM_STEPS
+    # that run up to 10 % slow (0.44, 0.44, 0.41, 0.39 ms per pass in groups of ten, 0.365 after ~300: tools/ab_screen.py).  PREWARM_STEPS
     # untimed passes bring the clocks back before the W warmup steps the contract asks for; reported in the line.
     for _ in range(PREWARM_STEPS):
         enc.encode_device(xptr, n, codes.data_ptr(), None)
