@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "FETCH_SIZE" "WRITE_SIZE" "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d "$OUT/g$i" -o pmc -- python3 "$SCRIPT" "$@" > "$OUT/g$i.out" 2> "$OUT/g$i.err" || echo "group $i ($grp) failed" >> "$OUT/errors.txt"
+  timeout 900 rocprofv3 --pmc $grp --output-format csv -d "$OUT/g$i" -o pmc -- python3 "$SCRIPT" "$@" > "$OUT/g$i.out" 2> "$OUT/g$i.err" || echo "group $i ($grp) failed" >> "$OUT/errors.txt"
 done
 python3 - "$OUT" "$FILTER" <<'PY'
 import csv,glob,re,collections,sys,json

@@ -10,7 +10,7 @@ BENCH="python3 $REPO/bench.py --steps 4 --warmup 1 --kmeans-iters 1 --no-cpu-bas
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d "$OUT/g$i" -o pmc -- $BENCH > "$OUT/g$i.json" 2> "$OUT/g$i.err" || echo "group $i failed" >> "$OUT/errors.txt"
+  timeout 900 rocprofv3 --pmc $grp --output-format csv -d "$OUT/g$i" -o pmc -- $BENCH > "$OUT/g$i.json" 2> "$OUT/g$i.err" || echo "group $i failed" >> "$OUT/errors.txt"
 done
 python3 - "$OUT" <<'PY'
 import csv,glob,re,collections,sys

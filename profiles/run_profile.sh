@@ -15,6 +15,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ
   name=$(echo $grp | tr ' ' '+' | cut -c1-40)
   timeout 900 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_$name" -o pmc -- $BENCH > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" || echo "pmc group '$grp' failed" >> "$OUT/errors.txt"
 done
-rocprofv3 -L > "$OUT/counters_list.txt" 2>&1 || true
+timeout 120 rocprofv3 -L > "$OUT/counters_list.txt" 2>&1 || true
 find "$OUT" -name "*.csv" | head -50 > "$OUT/files.txt"
 du -sh "$OUT" >> "$OUT/files.txt"

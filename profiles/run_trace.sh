@@ -7,6 +7,6 @@ OUT=$REPO/gpurun_out/trace_$TAG
 mkdir -p "$OUT"
 SCRIPT=$REPO/$1; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o t -- python3 "$SCRIPT" "$@" > "$OUT/stdout.txt" 2> "$OUT/stderr.txt"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o t -- python3 "$SCRIPT" "$@" > "$OUT/stdout.txt" 2> "$OUT/stderr.txt"
 f=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 head -25 "$f" | cut -c1-200
