@@ -893,7 +893,8 @@ static int tsvq_prepare_screen(vqhip_tsvq *t, const float *centroids, const int3
     VQ_TRY(t->scr_info.alloc(info.size() * 4));
     VQ_TRY(t->scr_mu.alloc((size_t)dp * 4));
     VQ_HIP(hipMemsetAsync(t->scr_mu.p, 0, (size_t)dp * 4, s));
-    VQ_TRY(t->scr_count.alloc(4));
+    VQ_TRY(t->scr_count.alloc(8));  // two counters used in turn (TsvqScreen::turn)
+    VQ_HIP(hipMemsetAsync(t->scr_count.p, 0, 8, s));
     VQ_HIP(hipMemcpyAsync(t->scr_w.p, w.data(), w.size() * 4, hipMemcpyHostToDevice, s));
     VQ_HIP(hipMemcpyAsync(t->scr_info.p, info.data(), info.size() * 4, hipMemcpyHostToDevice, s));
     if (!cosine && !manhattan) VQ_HIP(hipMemcpyAsync(t->scr_mu.p, mu, (size_t)d * 4, hipMemcpyHostToDevice, s));  // else y = x
@@ -2340,7 +2341,7 @@ int vqhip_tsvq_last_stats(vqhip_tsvq *t, int *screened, uint64_t *undecided) {
         hipStream_t s;
         VQ_TRY(in.stream(&s));
         uint32_t c = 0;
-        VQ_HIP(hipMemcpyAsync(&c, t->scr_count.p, 4, hipMemcpyDeviceToHost, s));
+        VQ_HIP(hipMemcpyAsync(&c, t->scr_count.as<uint32_t>() + (t->scr.turn ^ 1u), 4, hipMemcpyDeviceToHost, s));  // the last call's counter
         VQ_HIP(hipStreamSynchronize(s));
         in.synced();
         *undecided = c;

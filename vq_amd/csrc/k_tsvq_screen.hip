@@ -324,7 +324,9 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
                                                        int32_t *__restrict__ leaf_out, const uint4 *__restrict__ table16,
                                                        uint4 *__restrict__ f16_out, const float *__restrict__ w_g,
                                                        const int4 *__restrict__ info_g, const int32_t *__restrict__ node_slot,
-                                                       const float *__restrict__ mu_g, float R, float coef_a, float coef_b) {
+                                                       const float *__restrict__ mu_g, float R, float coef_a, float coef_b,
+                                                       uint32_t *__restrict__ clear_next) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *clear_next = 0u;  // the next call's counter (nobody reads or appends to it in this call)
     // d_real <= D: rows and centroids are d_real floats long; the pieces behind it count as zeros (a zero term
     // leaves a running sum that already holds a real term unchanged, so the reference's bits are kept)
     // w_g / info_g / node_slot: below the
@@ -591,7 +593,8 @@ __global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restri
                                                            const uint2 *__restrict__ wl,
                                                            const uint32_t *__restrict__ wl_count,
                                                            int32_t *__restrict__ leaf_out, const uint4 *__restrict__ table16,
-                                                           uint4 *__restrict__ f16_out) {
+                                                           uint4 *__restrict__ f16_out, uint32_t *__restrict__ clear_next) {
+    if (clear_next && blockIdx.x == 0 && threadIdx.x == 0) *clear_next = 0u;
     const uint32_t count = *wl_count;
     const bool cosine = mode == kScrCos, manh = mode == kScrMan;
     for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < count; e += gridDim.x * 256) {
@@ -651,18 +654,18 @@ __global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restri
 template <int D, int MODE>
 static int launch_continue(const float *X, const float *centroids, const float *cnorm, const int32_t *left,
                            const int32_t *right, int euclid, const TsvqScreen &s, int32_t *leaf, hipStream_t stream,
-                           uint32_t d_real, const uint4 *table16, uint4 *f16_out) {
+                           uint32_t d_real, const uint4 *table16, uint4 *f16_out, uint32_t *count, uint32_t *clear_next) {
     const bool rescreen = s.node_slot != nullptr;
     hipLaunchKernelGGL((k_tsvq_continue<D, MODE>), dim3(1024), dim3(256), 0, stream, X, centroids, cnorm, left, right, euclid,
-                       s.slot_node, s.wl, s.wl_count, d_real, leaf, table16, f16_out, rescreen ? s.w : nullptr,
-                       rescreen ? s.info : nullptr, rescreen ? s.node_slot : nullptr, s.mu, s.R, s.coef_a, s.coef_b);
+                       s.slot_node, s.wl, count, d_real, leaf, table16, f16_out, rescreen ? s.w : nullptr,
+                       rescreen ? s.info : nullptr, rescreen ? s.node_slot : nullptr, s.mu, s.R, s.coef_a, s.coef_b, clear_next);
     VQ_LAUNCH_CHECK("k_tsvq_continue");
     return VQHIP_OK;
 }
 
 template <int D, int LPR, int MODE>
 int launch_screen(const float *X, uint64_t n, uint32_t d_real, const TsvqScreen &s, hipStream_t stream, int32_t *leaf,
-                  const uint4 *table16, uint4 *f16_out) {
+                  const uint4 *table16, uint4 *f16_out, uint32_t *count) {
     constexpr int RPW = 64 / LPR;
     constexpr int WAVES = (D >= 512) ? 4 : (D >= 256) ? 8 : kWaves;  // 512 / 256 / 128 VGPRs per lane
     const size_t lds_bytes = tsvq_screen_lds_bytes(s.n_int, MODE == kScrL2 ? 1 : 2, D);
@@ -679,10 +682,10 @@ int launch_screen(const float *X, uint64_t n, uint32_t d_real, const TsvqScreen 
     if (grid > (uint64_t)num_cus()) grid = (uint64_t)num_cus();
     if (s.n_slots > s.n_int)
         hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES, MODE, true>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X, n,
-                           d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count, table16, f16_out);
+                           d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, count, table16, f16_out);
     else
         hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES, MODE, false>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X, n,
-                           d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, s.wl_count, table16, f16_out);
+                           d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, count, table16, f16_out);
     VQ_LAUNCH_CHECK("k_tsvq_screen_descend");
     return VQHIP_OK;
 }
@@ -721,14 +724,16 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
     if (f16_out && (!table16 || d % 8 != 0 || (reinterpret_cast<uintptr_t>(f16_out_h) & 15) != 0))
         return fail(VQHIP_ERR_INVALID_INPUT, "fused f16 output needs d %% 8 == 0 and a 16-byte aligned buffer");
     if (n > 0xFFFFFFFFull) return fail(VQHIP_ERR_UNSUPPORTED, "screened TSVQ descent takes < 2^32 rows per call");
-    VQ_HIP(hipMemsetAsync(s.wl_count, 0, 4, stream));
+    // this call's counter (zero: cleared by the previous call's continuation kernel, or at creation) and the next call's
+    uint32_t *const count = s.wl_count + s.turn, *const clear_next = s.wl_count + (s.turn ^ 1u);
+    s.turn ^= 1u;
     const int euclid = metric == VQHIP_EUCLIDEAN ? 1 : 0;
     const int mode = metric == VQHIP_COSINE ? kScrCos : metric == VQHIP_MANHATTAN ? kScrMan : kScrL2;
     const uint32_t dp = tsvq_screen_width(d);  // instantiated width serving d (d itself, or the next one up: zero padding)
 #define VQ_TSVQ_DM(DV, MV)                                                                         \
-    VQ_TRY((launch_screen<DV, 8, MV>(X, n, d, s, stream, leaf, table16, f16_out)));                \
+    VQ_TRY((launch_screen<DV, 8, MV>(X, n, d, s, stream, leaf, table16, f16_out, count)));         \
     if (DV >= 64 || d == DV)                                                                       \
-        VQ_TRY((launch_continue<DV, MV>(X, centroids, cnorm, left, right, euclid, s, leaf, stream, d, table16, f16_out)));
+        VQ_TRY((launch_continue<DV, MV>(X, centroids, cnorm, left, right, euclid, s, leaf, stream, d, table16, f16_out, count, clear_next)));
 #define VQ_TSVQ_D(DV)                                                                              \
     case DV:                                                                                       \
         if (mode == kScrCos) {                                                                     \
@@ -748,7 +753,7 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
 #undef VQ_TSVQ_DM
     if (d != dp && dp < 64) {  // d < 32 (8-byte pieces in k_tsvq_continue): the run-time-length kernel
         hipLaunchKernelGGL(k_tsvq_continue_any, dim3(256), dim3(256), 0, stream, X, d, centroids, cnorm, left, right, euclid,
-                           mode, s.slot_node, s.wl, s.wl_count, leaf, table16, f16_out);
+                           mode, s.slot_node, s.wl, count, leaf, table16, f16_out, clear_next);
         VQ_LAUNCH_CHECK("k_tsvq_continue_any");
     }
     return VQHIP_OK;

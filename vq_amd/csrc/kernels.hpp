@@ -233,7 +233,10 @@ struct TsvqScreen {
     float R = 0.0f;               // >= max_node |c - mu|
     float coef_a = 0.0f, coef_b = 0.0f;
     uint2 *wl = nullptr;          // [n] undecided (row, node)
+    // two counters used in turn: a call appends under wl_count[turn] and its continuation kernel, which is the last to
+    // read it, clears the OTHER one for the next call -- the memset in front of every call was one launch in four
     uint32_t *wl_count = nullptr;
+    mutable uint32_t turn = 0;    // counter of the next call (flipped by launch_tsvq_screen_encode, under the handle's lock)
 };
 size_t tsvq_screen_lds_bytes(uint32_t n_int, uint32_t nv, uint32_t d);
 uint32_t tsvq_screen_width(uint32_t d);  // instantiated width serving d (zero padding for other multiples of 4), 0 = none
