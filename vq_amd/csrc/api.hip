@@ -525,6 +525,10 @@ struct vqhip_kmeans {
     bool accumulated = false;
     uint32_t *counts_host = nullptr;   // pinned [m*k]
     uint32_t *changed_host = nullptr;  // pinned [m]
+    // pinned, vqhip_kmeans_run's read-back: {paused, iterations [m]} | small-problem flag sets [6 m] | active set [m bytes].
+    // (Read into vectors on the stack, every one of those copies was a staged pageable copy with a wait of its own: 85 us per
+    // call, whatever the number of iterations -- a third of a ten-iteration run at 10k rows.)
+    uint32_t *run_host = nullptr;
     // launch-bound regime (small n): one Lloyd step = ~14 stream operations, replayed as a hipGraph
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t graph_stream = nullptr;
@@ -540,6 +544,7 @@ struct vqhip_kmeans {
         drop_graph();
         if (counts_host) (void)hipHostFree(counts_host);
         if (changed_host) (void)hipHostFree(changed_host);
+        if (run_host) (void)hipHostFree(run_host);
     }
 };
 
@@ -1233,6 +1238,7 @@ int vqhip_kmeans_create(const vqhip_dataset *ds, uint32_t m, uint32_t k, vqhip_k
     VQ_TRY(km->agree.alloc(16));
     VQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&km->counts_host), (size_t)m * k * 4));
     VQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&km->changed_host), (size_t)m * 4));
+    VQ_HIP(hipHostMalloc(reinterpret_cast<void **>(&km->run_host), (size_t)(m + 1 + 6 * m) * 4 + ((size_t)m + 3) / 4 * 4));
     km->active.assign(m, 1);
     hipStream_t s;
     VQ_TRY(current_stream(&s));
@@ -1700,29 +1706,28 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
         VQ_TRY(comm_allreduce_f64(comm, km->slab.as<double>(), (size_t)m * k * (km->cs.sd + 1), s));
         VQ_TRY(kmeans_finalize_enqueue(km, s, true, false));  // + the iteration's decisions (k_finalize<true>)
     }
-    std::vector<uint32_t> st(m + 1);
-    std::vector<uint8_t> act(m);
+    // everything the host reads goes to pinned memory, queued back to back, ONE wait
+    uint32_t *const st = km->run_host, *const sm_flags = st + (m + 1);
+    uint8_t *const act = reinterpret_cast<uint8_t *>(sm_flags + (size_t)6 * m);
     VQ_HIP(hipMemcpyAsync(km->counts_host, km->counts.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipMemcpyAsync(km->changed_host, km->changed.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-    VQ_HIP(hipMemcpyAsync(st.data(), km->run_state.p, (size_t)(m + 1) * 4, hipMemcpyDeviceToHost, s));
-    VQ_HIP(hipMemcpyAsync(act.data(), km->active_dev.p, m, hipMemcpyDeviceToHost, s));
-    std::vector<uint32_t> sm_flags;
-    if (small_loop) {
-        sm_flags.resize((size_t)6 * m);
-        VQ_HIP(hipMemcpyAsync(sm_flags.data(), km->sm_tick.p, (size_t)6 * m * 4, hipMemcpyDeviceToHost, s));
-    }
+    VQ_HIP(hipMemcpyAsync(st, km->run_state.p, (size_t)(m + 1) * 4, hipMemcpyDeviceToHost, s));
+    VQ_HIP(hipMemcpyAsync(act, km->active_dev.p, m, hipMemcpyDeviceToHost, s));
+    if (small_loop) VQ_HIP(hipMemcpyAsync(sm_flags, km->sm_tick.p, (size_t)6 * m * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipStreamSynchronize(s));
     if (small_loop) {  // the loop's decisions from the flags the last executed iteration left (the kernels never write the set itself)
         bool pause = false;
-        std::vector<uint8_t> start(act);  // active_dev still holds the set the run started from
-        lloyd_small_run_result(m, start.data(), sm_flags.data(), st.data() + 1, &pause, act.data(), km->changed_host);
+        std::vector<uint8_t> start(act, act + m);  // active_dev still holds the set the run started from
+        lloyd_small_run_result(m, start.data(), sm_flags, st + 1, &pause, act, km->changed_host);
         st[0] = pause ? 1u : 0u;
-        VQ_HIP(hipMemcpyAsync(km->active_dev.p, act.data(), m, hipMemcpyHostToDevice, s));
-        VQ_HIP(hipStreamSynchronize(s));
+        // the set as the run left it goes back behind everything queued so far; pinned source, nothing else writes it before
+        // the next run's own read-back has been waited for: no wait here (the handle's stream tail stays set)
+        VQ_HIP(hipMemcpyAsync(km->active_dev.p, act, m, hipMemcpyHostToDevice, s));
+    } else {
+        in.synced();
     }
-    in.synced();
     kmeans_finalize_collect(km, counts, changed);  // flags of the last executed iteration, for the subspaces active in it
-    if (iters_done) memcpy(iters_done, st.data() + 1, (size_t)m * 4);
+    if (iters_done) memcpy(iters_done, st + 1, (size_t)m * 4);
     if (paused) *paused = st[0] ? 1 : 0;
     bool all = true;
     for (uint32_t i = 0; i < m; ++i) {
