@@ -570,7 +570,9 @@ def measure(args, ranks, wl_name, scaling, *, torch, _lib, engine, ncomm, collec
         km.init_from_global_rows(ncomm, init, offset)
         km.run(TRAIN_ITERS, ncomm)
         codebooks = km.get_centroids()
-        for _ in range(3):  # untimed: the first ~30 iterations of a process run 10 % slow (clocks ramping up from idle)
+        # untimed: the first ~100 ms of work after an idle spell run up to 10 % slow (clocks ramping up); the same count on
+        # every rank (each run carries its all-reduces)
+        for _ in range(25 if n * dim <= 4e8 else 6):
             km.run(10, ncomm)
 
         def restart():
