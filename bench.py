@@ -663,6 +663,17 @@ def measure(args, ranks, wl_name, scaling, *, torch, _lib, engine, ncomm, collec
     # the host work between the k-means block and here leaves the GPU idle and its clocks down; the first ~30 passes after
     # that run up to 10 % slow (0.44, 0.44, 0.41, 0.39 ms per pass in groups of ten, 0.365 after ~300: tools/ab_screen.py).  PREWARM_STEPS
     # untimed passes bring the clocks back before the W warmup steps the contract asks for; reported in the line.
+    # first the same W + K passes with NO prewarm (`cold_ms_per_step`: what a caller sees right after host-side work)
+    for _ in range(warmup):
+        enc.encode_device(xptr, n, codes.data_ptr(), None)
+    sync()
+    ranks.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        enc.encode_device(xptr, n, codes.data_ptr(), None)
+    sync()
+    ranks.barrier()
+    cold_ms = ranks.reduce(time.perf_counter() - t0, "max") / steps * 1e3
     for _ in range(PREWARM_STEPS):
         enc.encode_device(xptr, n, codes.data_ptr(), None)
     for _ in range(warmup):
@@ -690,6 +701,7 @@ def measure(args, ranks, wl_name, scaling, *, torch, _lib, engine, ncomm, collec
                    }.get(used_engine, "k_assign_exact")
     out.update({
         "encode_vectors_per_s": n_global * steps / dt, "encode_ms_per_step": step_ms, "prewarm_steps": PREWARM_STEPS,
+        "cold_ms_per_step": cold_ms,
         "encode_engine": {1: "exact", 2: "fp32_mfma_screen+exact_recheck", 3: "bf16x3_mfma_screen+exact_recheck"}.get(used_engine, str(used_engine)),
         "recheck_fraction": rechecked / float(max(1, n * m_)),
         "encode_engine_id": int(used_engine),
@@ -941,7 +953,10 @@ def worker(args) -> int:
                     "the north star names (its 40 % target) and can pass 1.  What binds the kernel: issue_bound (every "
                     "instruction at the lone wave's ~5.3 cycles) and DESIGN.md 4.1 (VALU + MFMA issue 64 %, stalls behind the matrix pipe 19 %); step_frac = the same work over the whole "
                     "driver-timed step (screen + exact re-check)",
-            "traffic": traffic, "traffic_source": traffic_src})
+            "traffic": traffic, "traffic_source": traffic_src,
+            "kmeans_frac": (o.get("kmeans_roofline") or {}).get("frac"),
+            "kmeans_achieved": (o.get("kmeans_roofline") or {}).get("achieved"),
+            "kmeans_ms_per_iter": o.get("kmeans_ms_per_iter")})
         line = {
             "metric": "pq_encode_vectors_per_s",
             "value": o["encode_vectors_per_s"],
@@ -962,6 +977,12 @@ def worker(args) -> int:
                 "rows_per_gpu": n, "rows_global": o["rows_global"], "dim": dim, "m": m_, "k": k_, "sub_dim": dim // m_,
                 "engine": o["encode_engine"], "recheck_fraction": o["recheck_fraction"],
                 "codebooks": f"{TRAIN_ITERS} Lloyd iterations from strided init rows",
+                # the k-means half of BASELINE's metric and the untimed-pass disclosure, in a dict the driver keeps
+                "kmeans_iter_per_s": o.get("kmeans_iter_per_s"), "kmeans_ms_per_iter": o.get("kmeans_ms_per_iter"),
+                "kmeans_valid": o.get("kmeans_valid"), "kmeans_roofline_frac": (o.get("kmeans_roofline") or {}).get("frac"),
+                "kmeans_roofline_frac_vs_fp32_mfma_peak": (o.get("kmeans_roofline") or {}).get("frac_vs_fp32_mfma_peak"),
+                "prewarm_steps": o.get("prewarm_steps"), "cold_ms_per_step": o.get("cold_ms_per_step"),
+                "cold_vectors_per_s": (o["rows_global"] / (o["cold_ms_per_step"] * 1e-3) if o.get("cold_ms_per_step") else None),
             },
             "roofline": roof,
             "kmeans_rows_global": o["rows_global"],

@@ -13,7 +13,10 @@
 // from the documented SplitMix64 sampler also used by the Python mirror (vq_amd/rng.py) -- rand's
 // StdRng stream is not reproducible outside Rust -- or from the caller (`init_rows`).
 //
-// Header-only, C++17; link with -lvqhip.  Not thread-safe per object (one stream per thread).
+// Header-only, C++17; link with -lvqhip.  Thread-safe per object like the reference's plain-data types (`Send + Sync`,
+// src/pq.rs:39-45): the `const` methods (`quantize`, `dequantize`, the getters) may be called on one object from any
+// number of threads at once -- every libvqhip handle carries its own lock and hands its stream's tail over between
+// threads (include/vqhip.h "Threads"; held by tests/cpp/test_vq_hpp.cpp's std::thread case).
 #ifndef VQ_HPP
 #define VQ_HPP
 

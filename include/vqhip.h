@@ -135,6 +135,10 @@ int vqhip_last_assign_stats(uint64_t *rechecked, int *engine);
  * the engine) and of the exact re-check stage, and clears the record. */
 int vqhip_set_profiling(int on);
 int vqhip_profile_collect(uint32_t *n_calls, double *primary_ms, double *recheck_ms);
+/* process-wide count of host-batch calls (vqhip_pq_encode / vqhip_tsvq_encode / vqhip_dataset_from_host on host
+ * pointers) that went through the library's transfer lanes (several host threads, each with its own stream: uploads,
+ * kernels and downloads of different chunks overlap) rather than the one-stream path -- diagnostics and tests */
+int vqhip_xfer_lane_calls(uint64_t *calls);
 /* device-to-device copy on the current stream (plumbing for callers that all-reduce the
  * k-means slab in their own buffers) */
 int vqhip_memcpy_device(void *dst, const void *src, uint64_t bytes);

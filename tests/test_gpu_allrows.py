@@ -338,3 +338,55 @@ def test_c1_at_its_ten_thousand_rows(oracle):
         want_c, want_f = oracle.pq_encode(O.EUCLIDEAN, X, pq.codebooks, threads=0)
         np.testing.assert_array_equal(codes.astype(np.uint32), want_c)
         np.testing.assert_array_equal(f16.view(np.uint16), want_f)
+
+
+def _lloyd_step_all_rows_vs_oracle(oracle, n, d, m, k, chunk, run_iters=0):
+    """One generic full-size Lloyd iteration (after a warm-up step off the initial rows) with every assignment, count and
+    `changed` flag equal to the oracle's (vector.rs:417-447) and centroids within |d| <= 1e-5 max(1,|c|); with
+    `run_iters`, additionally vqhip_kmeans_run for that many iterations whose LAST iteration is checked the same way
+    from the run's own centroids going into it.  The rows come to the host one subspace block at a time."""
+    sd = d // m
+    ds = _lib.Dataset.synthetic(n, d, seed=66)
+    km = _lib.KMeans(ds, m, k)
+    init = np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64)
+    km.init_from_rows(init)
+    km.step()
+    stages = []
+    c_in = km.get_centroids()
+    counts, changed = km.step()
+    assert _lib.last_assign_stats()[1] == _lib.ENGINE_MFMA_BF16
+    stages.append((c_in, counts.copy(), np.array(changed).copy(), km.get_assignments(), km.get_centroids()))
+    if run_iters:
+        it, _, _, paused = km.run(run_iters - 1)
+        assert not paused and it.tolist() == [run_iters - 1] * m
+        c_in = km.get_centroids()
+        it, counts, changed, paused = km.run(1)
+        assert not paused and it.tolist() == [1] * m
+        stages.append((c_in, counts.copy(), np.array(changed).copy(), km.get_assignments(), km.get_centroids()))
+    km.close()
+    X = np.empty((n, d), np.float32)
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        X[r0:r1] = ds.read(r0, r1 - r0)
+    ds.close()
+    for s in range(m):
+        xs = np.ascontiguousarray(X[:, s * sd:(s + 1) * sd])
+        for c_in, counts, changed, assign, c_out in stages:
+            c1, a_ref, n_ref, ch_ref = oracle.lloyd_step(xs, c_in[s], threads=0)
+            assert int((assign[:, s].astype(np.uint32) != a_ref).sum()) == 0, s
+            np.testing.assert_array_equal(counts[s], n_ref)
+            assert bool(changed[s]) == ch_ref
+            err = np.max(np.abs(c_out[s] - c1) / np.maximum(1.0, np.abs(c1)))
+            assert err <= 1e-5, f"subspace {s}: centroid deviation {err:g}"
+
+
+def test_c3_lloyd_step_all_rows(oracle):
+    """BASELINE configs[2]'s training half at its full 1M x 768, m = 96 (sub_dim 8: the two-waves-per-SIMD fused-update
+    screen with the subspace-major code scratch; VERDICT r4 "What's weak 2"): a generic step, then vqhip_kmeans_run for
+    3 iterations with the last one checked -- 96M assignments each."""
+    _lloyd_step_all_rows_vs_oracle(oracle, 1_000_000, 768, 96, 256, 250_000, run_iters=3)
+
+
+def test_c5_shard_lloyd_step_all_rows(oracle):
+    """BASELINE configs[4]'s training half on the rows one of the 8 GPUs holds: 12.5M x 128, m = 16 (200M assignments)."""
+    _lloyd_step_all_rows_vs_oracle(oracle, 12_500_000, 128, 16, 256, 2_500_000)

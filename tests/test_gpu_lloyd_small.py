@@ -155,6 +155,24 @@ for name, (n, d, m, k) in {"c1": (10000, 64, 4, 16), "odd": (1000, 21, 3, 7)}.it
     out[name + "_run_cb"] = km.get_centroids()
     out[name + "_engine"] = np.array(_lib.last_assign_stats()[1])
     km.close(); ds.close()
+# an early-converging run (0/1 lattice rows: every sum is exact in f32, both paths walk the same trajectory): iterations
+# stay queued behind the retirement of the last subspace, and the counts / changed flags handed back are those of the
+# last EXECUTED iteration in both forms (include/vqhip.h; ADVICE r4: the small path zeroed them)
+n, d, m, k = 4000, 16, 4, 4
+X = np.random.default_rng(5).integers(0, 2, (n, d)).astype(np.float32)
+rng = np.random.default_rng(6)
+init = np.stack([rng.choice(n, k, replace=False) for _ in range(m)]).astype(np.uint64)
+ds = _lib.Dataset.from_host(X)
+km = _lib.KMeans(ds, m, k)
+km.init_from_rows(init)
+itr, counts, changed, paused = km.run(40)
+out["lattice_run_iters"] = itr
+out["lattice_run_counts"] = counts
+out["lattice_run_changed"] = changed
+out["lattice_run_paused"] = np.array(paused)
+out["lattice_run_active"] = km.get_active()
+out["lattice_run_cb"] = km.get_centroids()
+km.close(); ds.close()
 np.savez(sys.argv[1], **out)
 print("WORKER_OK")
 '''
@@ -171,6 +189,10 @@ def test_against_the_general_path(tmp_path):
         return np.load(out)
 
     small, general = run(1), run(0)
+    if not bool(small["lattice_run_paused"]):  # converged before the 40 queued iterations ran out: the case under test
+        assert int(small["lattice_run_iters"].max()) < 40
+        last = small["lattice_run_iters"] == small["lattice_run_iters"].max()
+        assert (small["lattice_run_counts"][last].sum(axis=1) == 4000).all()  # the last executed iteration's counts survive
     assert int(small["c1_engine"]) == _lib.ENGINE_EXACT and int(general["c1_engine"]) == _lib.ENGINE_MFMA_BF16
     for key in small.files:
         if key.endswith("_engine"):

@@ -199,9 +199,11 @@ def test_stats_after_the_handle_died_on_another_thread():
 
 
 def test_large_host_batches_go_through_transfer_lanes(oracle):
-    """host batches of 48 MB and more are cut into chunks that four host threads of the LIBRARY carry end to end (pinned
-    staging, H2D, kernels, D2H) through one encoder handle: same bits as the one-stream path and as the oracle; the
-    data-set upload takes the same lanes"""
+    """host batches of 96 MB and more whose results are at least a quarter of the rows in bytes (f16 reconstructions) are
+    cut into 32 MB chunks that three host threads of the LIBRARY carry end to end (H2D straight from the caller's rows,
+    kernels, D2H straight into the caller's buffers), each on its own stream through the one encoder / tree handle:
+    same bits as the oracle.  `xfer_lane_calls` proves which path a call took (PQ f16 and TSVQ f16: lanes; codes or
+    leaf ids alone: the one-stream path)."""
     import vq_amd as pyvq
 
     rng = np.random.default_rng(17)
@@ -211,20 +213,27 @@ def test_large_host_batches_go_through_transfer_lanes(oracle):
     X = rng.random((n, m * sd), dtype=F)
     want_c, want_f = oracle.pq_encode(O.EUCLIDEAN, X, cb, threads=8)
     enc = _lib.PQEncoder(cb, _lib.EUCLIDEAN)
+    lanes0 = _lib.xfer_lane_calls()
     codes, f16 = enc.encode(X)
+    assert _lib.xfer_lane_calls() == lanes0 + 1
     assert np.array_equal(codes.astype(np.uint32), want_c) and np.array_equal(f16.view(np.uint16), want_f)
     rechecked, engine = _lib.last_assign_stats()
     assert engine == _lib.ENGINE_MFMA_BF16
     only_f16 = enc.encode(X, want_codes=False)[1]
     assert np.array_equal(only_f16.view(np.uint16), want_f)
+    lanes1 = _lib.xfer_lane_calls()
     only_codes = enc.encode(X, want_f16=False)[0]
+    assert _lib.xfer_lane_calls() == lanes1  # codes alone are 1.6 % of the rows: one stream
     assert np.array_equal(only_codes.astype(np.uint32), want_c)
     ds = _lib.Dataset.from_host(X)
     assert np.array_equal(ds.read(), X)
     tree = oracle.tsvq_build(X[:20000, :32].copy(), 6)
     t = pyvq.TSVQ.from_tree(tree["centroids"], tree["left"], tree["right"], pyvq.Distance.euclidean())
-    Y = rng.random((400_000, 32), dtype=F)  # 51 MB
-    want_l, want_t = oracle.tsvq_encode(O.EUCLIDEAN, Y, tree, threads=8)
+    Y = rng.random((900_000, 32), dtype=F)  # 115 MB: vqhip_tsvq_encode's run_lanes branch (three streams share the
+    want_l, want_t = oracle.tsvq_encode(O.EUCLIDEAN, Y, tree, threads=8)  # undecided list and its turn counters)
     assert np.array_equal(t.leaf_ids(Y), want_l)
+    lanes2 = _lib.xfer_lane_calls()
     assert np.array_equal(t.quantize_batch(Y).view(np.uint16), want_t)
+    assert _lib.xfer_lane_calls() == lanes2 + 1
+    assert np.array_equal(t.quantize_batch(Y).view(np.uint16), want_t)  # and again over the recycled lanes
     ds.close()

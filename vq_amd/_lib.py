@@ -41,6 +41,7 @@ SIGNATURES = {
     "vqhip_set_stream": (C.c_int, [_vp]),
     "vqhip_synchronize": (C.c_int, []),
     "vqhip_last_assign_stats": (C.c_int, [_u64p, C.POINTER(C.c_int)]),
+    "vqhip_xfer_lane_calls": (C.c_int, [C.POINTER(C.c_uint64)]),
     "vqhip_set_profiling": (C.c_int, [C.c_int]),
     "vqhip_profile_collect": (C.c_int, [_u32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vqhip_memcpy_device": (C.c_int, [_vp, _vp, C.c_uint64]),
@@ -525,6 +526,13 @@ def device_count() -> int:
 
 def backend() -> str:
     return load().vqhip_backend().decode()
+
+
+def xfer_lane_calls() -> int:
+    """host-batch calls of this process that went through the library's transfer lanes"""
+    v = C.c_uint64(0)
+    check(load().vqhip_xfer_lane_calls(C.byref(v)))
+    return int(v.value)
 
 
 def set_profiling(on: bool):

@@ -8,6 +8,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -475,8 +476,10 @@ class Entry {
 struct WsEntry {
     AssignWorkspace *ws;
     HandleSync *sync;
+    int pins = 0;  // vqhip_last_assign_stats queries in flight: the handle's destructor waits for them
 };
 static std::mutex g_ws_mu;
+static std::condition_variable g_ws_cv;
 static std::map<uint64_t, WsEntry> g_ws_live;
 static std::atomic<uint64_t> g_ws_next{1};
 static thread_local uint64_t g_last_ws = 0;  // registry id, 0 = none
@@ -484,13 +487,40 @@ static thread_local uint64_t g_last_ws = 0;  // registry id, 0 = none
 static uint64_t ws_register(AssignWorkspace *ws, HandleSync *sync) {
     const uint64_t id = g_ws_next.fetch_add(1);
     std::lock_guard<std::mutex> lk(g_ws_mu);
-    g_ws_live[id] = WsEntry{ws, sync};
+    g_ws_live[id] = WsEntry{ws, sync, 0};
     return id;
 }
 static void ws_unregister(uint64_t id) {
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    g_ws_live.erase(id);
+    std::unique_lock<std::mutex> lk(g_ws_mu);
+    auto it = g_ws_live.find(id);
+    if (it == g_ws_live.end()) return;
+    g_ws_cv.wait(lk, [&] { return it->second.pins == 0; });  // only THIS handle's destructor waits for a query on it
+    g_ws_live.erase(it);
 }
+// a live workspace pinned for one query: the registry lock is held only to look it up and to let it go, so a query that
+// blocks behind a long call on its handle stalls no other handle's constructor / destructor
+struct WsPin {
+    uint64_t id = 0;
+    AssignWorkspace *ws = nullptr;
+    HandleSync *sync = nullptr;
+    explicit WsPin(uint64_t want) {
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        auto it = g_ws_live.find(want);
+        if (it == g_ws_live.end()) return;
+        ++it->second.pins;
+        id = want;
+        ws = it->second.ws;
+        sync = it->second.sync;
+    }
+    ~WsPin() {
+        if (!id) return;
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        auto it = g_ws_live.find(id);
+        if (it != g_ws_live.end() && --it->second.pins == 0) g_ws_cv.notify_all();
+    }
+    WsPin(const WsPin &) = delete;
+    WsPin &operator=(const WsPin &) = delete;
+};
 
 
 }  // namespace vqhip
@@ -625,10 +655,12 @@ static XferPool &xfer_pool() {
 }
 // fn(lane index, lane, lanes) on that many host threads (each bound to the caller's device); the first failure's status
 // and text come back on the calling thread
+static std::atomic<uint64_t> g_xfer_lane_calls{0};
 template <class Fn>
 static int run_lanes(Fn fn) {
     int dev = 0;
     VQ_HIP(hipGetDevice(&dev));
+    g_xfer_lane_calls.fetch_add(1);
     const int n_lanes = xfer_lanes();
     XferLane *lanes[kXferLanesMax] = {};
     {
@@ -745,6 +777,9 @@ struct vqhip_pq_encoder {
     int engine = VQHIP_ENGINE_AUTO;
     DevBuf xbuf, codes, f16buf, f32buf, adc_q, adc_lut, adc_dist, adc_idx, adc_out, adc_codes, adc_state, adc_cand;
     std::vector<uint32_t> all_subs;
+    // the per-vector path's images (codebooks, cosine norms) are complete on the DEVICE -- set only after a host wait behind
+    // their prepare kernels; `cs.prepared` alone says they were ENQUEUED, possibly on another thread's stream
+    bool small_ready = false;
 };
 
 struct vqhip_tsvq {
@@ -1026,13 +1061,11 @@ int vqhip_last_assign_stats(uint64_t *rechecked, int *engine) {
     if (rechecked) {
         *rechecked = 0;
         if (!g_last_ws) return VQHIP_OK;
-        // the registry lock is held for the whole query: the workspace cannot be destroyed under it (its handle's
-        // destructor unregisters first); lock order registry -> handle, and no entry point takes them the other way
-        std::lock_guard<std::mutex> reg(g_ws_mu);
-        auto it = g_ws_live.find(g_last_ws);
-        if (it == g_ws_live.end()) return VQHIP_OK;  // the handle is gone
-        AssignWorkspace *ws = it->second.ws;
-        Entry in(*it->second.sync);
+        // the workspace is pinned for the query: its handle's destructor unregisters first and waits for the pin
+        WsPin pin(g_last_ws);
+        if (!pin.ws) return VQHIP_OK;  // the handle is gone
+        AssignWorkspace *ws = pin.ws;
+        Entry in(*pin.sync);
         if (ws->stats_pending) {
             // the copy is ordered behind the pass whatever stream that ran on (Entry::stream waits for the handle's
             // tail); a handle that several threads use reports its most recent pass, whoever queued it
@@ -1056,6 +1089,12 @@ int vqhip_last_assign_stats(uint64_t *rechecked, int *engine) {
     }
     return VQHIP_OK;
     VQ_API_END
+}
+
+int vqhip_xfer_lane_calls(uint64_t *calls) {
+    if (!calls) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    *calls = g_xfer_lane_calls.load();
+    return VQHIP_OK;
 }
 
 int vqhip_set_profiling(int on) {
@@ -2020,8 +2059,9 @@ int vqhip_pq_encode(vqhip_pq_encoder *enc, const float *rows, uint64_t n, uint8_
     const size_t cw = code_bytes(enc->cs.k);  // bytes per code: 1 (k <= 256) or 2
     static const char *no_small = getenv("VQHIP_NO_SMALL_PATH");
     const bool small = n <= kSmallRows && !(no_small && no_small[0] == '1');
-    // (the per-vector path needs no order behind the handle's queued batch work: it shares nothing mutable with it)
-    if (small && enc->cs.prepared && enc->cs.prepared_base) VQ_TRY(current_stream(&s));
+    // (the per-vector path needs no order behind the handle's queued batch work once its images are known to be complete:
+    // it shares nothing mutable with it)
+    if (small && enc->small_ready) VQ_TRY(current_stream(&s));
     else VQ_TRY(in.stream(&s));
     if (small) {
         // per-vector calls (Quantizer::quantize): one kernel over mapped pinned memory, exact arithmetic.  The kernel
@@ -2029,10 +2069,14 @@ int vqhip_pq_encode(vqhip_pq_encoder *enc, const float *rows, uint64_t n, uint8_
         // belongs to the call: the handle is given back before the launch, so calls from many threads on one encoder
         // (`quantize(&self)` on a Sync type, src/pq.rs:39-45) run side by side on their threads' streams.
         const size_t in_b = (size_t)n * d * 4, code_b = ((size_t)n * m * cw + 15) & ~(size_t)15, f16_b = (size_t)n * d * 2;
-        if (!(enc->cs.prepared && enc->cs.prepared_base)) {
-            VQ_TRY(enc->cs.prepare(s));  // centroid norms (cosine)
-            VQ_HIP(hipStreamSynchronize(s));  // once per encoder: other threads' streams read the images from now on
+        if (!enc->small_ready) {
+            // once per encoder: s is ordered behind the handle's tail here (in.stream), so the wait also covers a prepare
+            // another thread's asynchronous batch call enqueued on ITS stream; other threads' streams read the images
+            // without any order from now on
+            if (!(enc->cs.prepared && enc->cs.prepared_base)) VQ_TRY(enc->cs.prepare(s));  // centroid norms (cosine)
+            VQ_HIP(hipStreamSynchronize(s));
             in.synced();
+            enc->small_ready = true;
         }
         const int metric = enc->metric;
         const uint32_t k = enc->cs.k, sd = enc->cs.sd;

@@ -210,7 +210,15 @@ __global__ __launch_bounds__(kSmThreads) void k_sm_reduce(uint32_t m, uint32_t k
     const uint32_t e = min(e_raw, ksd - 1u), j = e / sd, t = e - j * sd;  // (clamped: every lane's loads are valid and unconditional)
     if (MODE == 2 && gate_halt && blockIdx.x == 0 && tid == 0) changed[s] = 0u;  // a device-driven sharded run: k_finalize<true> only sets the flag
     if (!act) {  // a subspace that does not execute: counts read 0, nothing moved (include/vqhip.h)
-        if (MODE != 2 && live && g == 0 && t == 0) counts[(size_t)s * k + j] = 0u;
+        // ... of the last EXECUTED iteration: an iteration queued behind the retirement of every subspace executes
+        // nothing and must leave the counts of the subspaces that ran the last executed one alone
+        bool any_runs = true;
+        if (MODE == 1 && it > 0) {
+            const SmFlags prev = sm_flags(flags, m, (it - 1) & 1u);
+            any_runs = false;
+            for (uint32_t q = 0; q < m; ++q) any_runs = any_runs || (active[q] != 0 && prev.ran[q] && prev.moved[q]);
+        }
+        if (MODE != 2 && any_runs && live && g == 0 && t == 0) counts[(size_t)s * k + j] = 0u;
         return;
     }
     const uint32_t per = (n_chunks + kSmLanes - 1) / kSmLanes;  // <= 32

@@ -727,6 +727,9 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
     // this call's counter (zero: cleared by the previous call's continuation kernel, or at creation) and the next call's
     uint32_t *const count = s.wl_count + s.turn, *const clear_next = s.wl_count + (s.turn ^ 1u);
     s.turn ^= 1u;
+    // a launch that fails below leaves the continuation -- the kernel that clears the next call's counter -- out: both
+    // counters are then cleared on the stream, so that the next call does not append behind a stale count
+    const int rc = [&]() -> int {
     const int euclid = metric == VQHIP_EUCLIDEAN ? 1 : 0;
     const int mode = metric == VQHIP_COSINE ? kScrCos : metric == VQHIP_MANHATTAN ? kScrMan : kScrL2;
     const uint32_t dp = tsvq_screen_width(d);  // instantiated width serving d (d itself, or the next one up: zero padding)
@@ -757,6 +760,12 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
         VQ_LAUNCH_CHECK("k_tsvq_continue_any");
     }
     return VQHIP_OK;
+    }();
+    if (rc != VQHIP_OK) {
+        (void)hipMemsetAsync(s.wl_count, 0, 2 * sizeof(uint32_t), stream);
+        s.turn = 0;
+    }
+    return rc;
 }
 
 }  // namespace vqhip
