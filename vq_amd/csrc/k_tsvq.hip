@@ -25,6 +25,7 @@
 #include <hip/hip_fp16.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstddef>
 #include <utility>
@@ -62,7 +63,7 @@ struct LevelInfo {
     uint32_t n_fast, n_slow;  // nodes by column-sum path (tile-parallel emulation / plain chain)
     uint32_t n_tiles;         // tiles of the fast nodes
     uint32_t error;           // != 0: a split dimension whose values are all NaN (the reference panics, src/tsvq.rs:77-78)
-    uint32_t pad;
+    uint32_t pad;             // batches of 64 tiles over the fast nodes (k_fs_prep's grid bound)
 };
 
 struct NodeArrays {
@@ -991,6 +992,11 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // in order, so all that is needed is that the compiler keeps the order and waits for the LDS counter.  __syncthreads()
 // would also wait for every global load in flight (s_waitcnt vmcnt(0)) -- the rows of the next block, the next batches
 // of summaries, the parked addends: exactly the loads these kernels issue early to hide their latency.
+// a value the compiler must keep in a vector register (it cannot prove it uniform any more)
+__device__ __forceinline__ uint32_t fs_vgpr(uint32_t x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 __device__ __forceinline__ void fs_wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
@@ -1014,7 +1020,9 @@ __device__ __forceinline__ int32_t fs_ef(int bad, int two, int e, int slot) {
     return (bad ? 1 : 0) | (two ? 2 : 0) | (((e + 128) & 0xFF) << 2) | ((slot + 1) << 10);
 }
 __device__ __forceinline__ int fs_ef_e(int32_t ef) { return ((ef >> 2) & 0xFF) - 128; }
-__device__ __forceinline__ int fs_ef_slot(int32_t ef) { return (int)((uint32_t)ef >> 10) - 1; }
+__device__ __forceinline__ int fs_ef_slot(int32_t ef) { return (int)(((uint32_t)ef >> 10) & 0x1FFFFFu) - 1; }
+// (bit 31: the sign of the guess -- with the binade, the raw-bit range the segment's incoming sums lie in; k_fs_prep)
+__device__ __forceinline__ int32_t fs_ef_key(int32_t ef) { return ((ef >> 2) & 0xFF) | (int32_t)(((uint32_t)ef >> 31) << 8); }
 
 struct FsT {  // parity transducer of a run of rows: stream 0 for an even incoming S, stream 1 for an odd one
     int32_t d0, d1, lo0, lo1, hi0, hi1;
@@ -1052,7 +1060,8 @@ __global__ __launch_bounds__(64, 2) void k_fs_fold(const float *__restrict__ X, 
                                                    const float *__restrict__ tile_pref, FsS *__restrict__ summ,
                                                    FsS *__restrict__ summ_odd, float *__restrict__ side, uint32_t side_cap,
                                                    uint32_t *__restrict__ side_count, double2 *__restrict__ tile_mom,
-                                                   float park_rel_arg, const uint32_t *__restrict__ policy) {
+                                                   float park_rel_arg, const uint32_t *__restrict__ policy,
+                                                   uint4 *__restrict__ side_meta, uint32_t pass_tag) {
     __shared__ __attribute__((aligned(16))) int32_t p_d0[8][kFsCols], p_d1[8][kFsCols], p_lo0[8][kFsCols], p_lo1[8][kFsCols],
         p_hi0[8][kFsCols], p_hi1[8][kFsCols], p_bad[8][kFsCols], p_gb[8][kFsCols];
     __shared__ __attribute__((aligned(16))) float p_s1[8][kFsCols], p_s2[8][kFsCols];
@@ -1298,9 +1307,13 @@ __global__ __launch_bounds__(64, 2) void k_fs_fold(const float *__restrict__ X, 
                 if (seg_live && c < d) {
                     const bool two = f.d0 != f.d1 || f.lo0 != f.lo1 || f.hi0 != f.hi1;
                     const size_t at = ((size_t)cur.tile_id * kFsSegsPerTile + 2 * cur.b + sg) * d + c;
+                    // for k_fs_prep's tables: the guess the segment was folded under, this pass's tag (tells its slots from what
+                    // an earlier pass left in the unused rest of a chunk), where its summary is, and whether the guess is a sampled one
+                    if (slot >= 0 && side_meta)
+                        side_meta[slot] = make_uint4(gb, pass_tag, (uint32_t)at, (policy && policy[cur.c0 / kFsCols] && park_rel_arg > 0.0f) ? 1u : 0u);
                     FsS o;
                     o.d = f.d0, o.lo = f.lo0, o.hi = f.hi0;
-                    o.ef = fs_ef(anybad, two, (int)((gb >> 23) & 0xFFu) - 127, slot);
+                    o.ef = fs_ef(anybad, two, (int)((gb >> 23) & 0xFFu) - 127, slot) | (int32_t)(gb & 0x80000000u);
                     summ[at] = o;
                     if (two) {
                         FsS o2;
@@ -1404,8 +1417,11 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
                                                  const uint32_t *__restrict__ tile_base, NodeArrays na,
                                                  const FsS *__restrict__ summ, const FsS *__restrict__ summ_odd,
                                                  const float *__restrict__ side, uint32_t *__restrict__ n_fallback,
-                                                 const LevelInfo *__restrict__ lv, uint32_t *__restrict__ dbg_arg) {
+                                                 const LevelInfo *__restrict__ lv, uint32_t *__restrict__ dbg_arg,
+                                                 const uint32_t *__restrict__ only_sampled) {
     uint32_t *const dbg = DBG ? dbg_arg : nullptr;  // folds every `if (dbg)` below away when !DBG
+    // (round 5: the mean pass's columns with an exact guess -- zero-mean columns -- go through k_fs_prep / k_fs_chain3)
+    if (only_sampled && only_sampled[blockIdx.y / kFsCols] == 0u) return;
     // dbg: 8 counters of this (level, pass): chains, re-added segments, most in one chain, and the first reason the
     // re-added segment failed: unusable summary / other binade than guessed / prefix leaves the binade / sum not normal
     __shared__ int plist[64 * kFsSpl];                            // side slots of the batch's parked segments, in order
@@ -1835,6 +1851,597 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
     }
 }
 
+// ---- round 5: re-additions looked up, not executed --------------------------------------------------------------------
+// On zero-mean columns the running sum is a random walk that keeps crossing binade edges near zero: 10-30 % of the
+// 64-row segments are parked (their guess comes close to an edge), half of those really leave the binade their summary
+// was folded under, and k_fs_chain above pays ~2000 cycles in series for each (64 dependent additions, an eight-lane scan
+// pass, a wave-wide rescan) on the ONE wave a column has.  Two kernels take that work off the column's wave:
+//
+// k_fs_prep, TABLES.  For a parked segment let F be the map "incoming f32 sum -> sum after the segment's 64 additions".
+// Write an incoming sum of the guessed binade by its raw bits r = c0 + 32 m + i (c0 = the guess's bits rounded down to a
+// multiple of 32: same sign and exponent).  Half a wave per parked segment, chip-wide: lane i really adds the 64 addends
+// to the input c0 + i (T[i]: exact by construction), and
+//     F(c0 + 32 m + i) = T[i] +- m * 32 ulp_in        for every m in [mlo, mhi]      (-: negative sums)
+// because fl(y + g) = fl(y) + g whenever g is an even multiple of the grid y is rounded on: true for g = 32 ulp_in at
+// every step if (1) the partial sums of the shifted input have the same (sign, exponent) as those of c0 at every step
+// -- fl(s + x) is monotone in s, so it is enough that the two END points c0 + 32 mlo and c0 + 32 mhi + 31 do: lanes
+// 0..15 / 16..31 run those chains for 16 geometrically spaced mlo / mhi, next to a reference chain from c0 (for m < 0 the
+// chains from c0 .. c0 + 31 themselves must be on the reference's itinerary too) -- and (2) no partial sum is more than
+// four binades above the input (else m = 0 only).  tools/fs_table_sim.py checks the claim by brute force; the trees stay
+// bit-identical to the oracle's (tests/test_gpu_tsvq.py, test_gpu_allrows.py).  No table for a segment whose summary
+// holds for every sum within 2^11 ulps of the guess, nor under a sampled guess (off by far more than any window).
+//
+// k_fs_prep, ITEMS.  A batch of 512 segment summaries of one column becomes a list of items, one wave per (batch,
+// column): the segments between two terminators composed into ONE run (a segmented scan over the lanes) and written as
+// the raw-bit range of incoming sums it holds for plus the raw-bit delta it applies, per parity of the sum -- sign,
+// exponent, "stays inside the binade" and the parity streams are all in those two compares.
+//
+// k_fs_chain3 is then one pass over a column's items: test + apply a run (ten instructions); a parked segment first
+// tries its own summary, then its table (one dependent LDS read: T[r & 31] +- m 2^(e-18)), then -- a sum outside
+// [mlo, mhi] or in another binade than guessed: a few per cent, the guess is an f64 prefix and the f32 chain has
+// drifted from it by its own rounding errors -- the 64 additions from the parked addends, as before.
+// end points of the validity test, in periods of 32 ulps, on either side of the table's 32 candidates
+__constant__ int32_t kFsTabM[16] = {1, 2, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 256, 512, 2048};
+constexpr int32_t kFsTabSlack = 1 << 11;  // a summary that holds this far around the guess needs no table
+constexpr uint32_t kFsTabN = 32;          // candidates per table: two tables per wave (half a wave each), period 32 ulps
+
+__device__ __forceinline__ void fs_tables_wave(uint32_t lane, uint32_t wave, uint32_t n_waves, const float *__restrict__ side,
+                                               const uint4 *__restrict__ side_meta, uint32_t pass_tag,
+                                               const uint32_t *__restrict__ side_count, uint32_t side_cap,
+                                               const FsS *__restrict__ summ, const FsS *__restrict__ summ_odd,
+                                               float *__restrict__ tab, int4 *__restrict__ tmeta) {
+    const uint32_t n_slots = min(*side_count, side_cap), half = lane >> 5, hl = lane & 31u;
+    for (uint32_t pair = wave; 2u * pair < n_slots; pair += n_waves) {
+        const uint32_t slot = min(2u * pair + half, n_slots - 1u);  // (an odd count: the last pair's second half repeats the first's slot)
+        const bool dup = 2u * pair + half >= n_slots;
+        const uint4 sm = side_meta[slot];
+        const uint32_t gb = sm.x, ex = (gb >> 23) & 0xFFu;
+        // tmeta = {c0, mlo, mhi, bits of +-2^(e-18)}; mlo > mhi: no table.  None for: the unused rest of a wave's chunk of
+        // slots (another pass's tag), a sampled guess, no normal guess (a node's first segment: the sum starts at 0) or
+        // 2^(e-18) not normal, a summary that holds well around the guess
+        bool none = sm.y != pass_tag || sm.w != 0u || ex < 24u || ex > 240u;
+        if (!none) {
+            const FsS g = summ[sm.z];
+            if (!(g.ef & 1)) {
+                FsS g2 = g;
+                if ((g.ef & 3) == 2) g2 = summ_odd[sm.z];
+                const int32_t lo = min(g.lo, g2.lo), hi = max(g.hi, g2.hi), mo = (int32_t)(gb & 0x7FFFFFu);
+                none = (gb >> 31) ? (mo - hi - kFsTabSlack > 0 && mo - lo + kFsTabSlack <= 0x7FFFFF)
+                                  : (mo + lo - kFsTabSlack > 0 && mo + hi + kFsTabSlack <= 0x7FFFFF);
+            }
+        }
+        if (__ballot(!none) == 0ull) {  // uniform: neither half has a table to build
+            if (hl == 0 && !dup && sm.y == pass_tag) tmeta[slot] = make_int4(0, 1, 0, 0);
+            continue;
+        }
+        // Lane roles inside the half: both rows of sixteen lanes are complete tests of their own -- lanes 0..7 of a row run the
+        // LOWER end points of eight window sizes, lanes 8..15 the UPPER end points of the same eight, and the reference
+        // they are compared with is the row's first lane's own chain (c0 / c0 + 16: inside every window), handed along by DPP
+        // row_newbcast: no third chain, five instructions per addend.
+        const uint32_t c0 = gb & ~(kFsTabN - 1u);
+        const uint32_t row = hl >> 4, pos = hl & 15u, kk = 8u * row + (pos & 7u);
+        const int32_t M = kFsTabM[kk];
+        const uint32_t rB = (pos < 8u) ? c0 - kFsTabN * (uint32_t)M : c0 + kFsTabN * (uint32_t)M + (kFsTabN - 1u);
+        const bool inB = ((rB ^ c0) >> 23) == 0u;  // the end point has the guess's sign and exponent
+        float sA = __uint_as_float(c0 + hl), sB = __uint_as_float(inB ? rB : c0);
+#ifdef VQ_FS_TAB_NODPP
+        float sR = __uint_as_float(c0 + 16u * row);
+#endif
+        uint32_t mism = 0u;
+        float amax = 0.0f;
+        // (the two halves add different segments: the addends are vector loads -- sixteen 16-byte loads, all in flight
+        // before the first addition; the other waves of the SIMD cover the one round trip)
+        const f32x4_t *ad = reinterpret_cast<const f32x4_t *>(side + (size_t)slot * kFsSeg);
+        f32x4_t av[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) av[u] = ad[u];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                sA = sA + av[u][w];
+                sB = sB + av[u][w];
+#ifdef VQ_FS_TAB_NODPP
+                sR = sR + av[u][w];
+                const uint32_t bR = __float_as_uint(sR);
+#else
+                const uint32_t bR = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(sA), 0x150, 0xF, 0xF, true);  // row_newbcast:0
+#endif
+                mism |= __float_as_uint(sB) ^ bR;
+                amax = fmaxf(amax, fabsf(__uint_as_float(bR)));  // (an inf stays an inf; a NaN can only follow one)
+            }
+        }
+        const bool sameB = inB && (mism & 0xFF800000u) == 0u;
+        const uint32_t bal = (uint32_t)(__ballot(sameB) >> (32u * half));
+        const uint32_t m_lo = (bal & 0xFFu) | (((bal >> 16) & 0xFFu) << 8), m_hi = ((bal >> 8) & 0xFFu) | ((bal >> 24) << 8);
+        int32_t mlo = m_lo ? -kFsTabM[31 - __builtin_clz(m_lo)] : 0, mhi = m_hi ? kFsTabM[31 - __builtin_clz(m_hi)] : 0;
+        // The candidates c0 .. c0 + 31 themselves must share one itinerary -- T[i] stands in for inputs on either side, and
+        // the second row's reference is c0 + 16, not c0 -- which the smallest upper window (c0 + 63 against c0) proves;
+        // without it only m = 0 is left
+        if (!(m_hi & 1u)) mlo = mhi = 0;
+        // 32 ulp_in must be an even multiple of the coarsest grid met: no partial sum more than four binades above the input
+        const bool high = (int)((__float_as_uint(amax) >> 23) & 0xFFu) - (int)ex > 4;
+        if ((uint32_t)(__ballot(high) >> (32u * half)) != 0u) mlo = mhi = 0;
+        if (none) mlo = 1, mhi = 0;
+        if (!dup && sm.y == pass_tag) {
+            if (!none) tab[(size_t)slot * kFsTabN + hl] = sA;
+            if (hl == 0) tmeta[slot] = make_int4((int32_t)c0, mlo, mhi, (int32_t)((gb & 0x80000000u) | ((ex - 18u) << 23)));
+        }
+    }
+}
+
+// A run of consecutive segments as ONE parity transducer, with the (sign, binade) key its summaries were folded under
+// (kFsEAny: no segment yet; kFsEMixed: summaries of different keys -- such a run never passes its test).
+constexpr int32_t kFsEAny = -100000, kFsEMixed = -200000;
+struct FsR {
+    FsT t;
+    int32_t e;
+};
+__device__ __forceinline__ FsR fs_run_none() {
+    FsR r;
+    r.t.d0 = r.t.d1 = r.t.lo0 = r.t.lo1 = r.t.hi0 = r.t.hi1 = 0;
+    r.e = kFsEAny;
+    return r;
+}
+__device__ __forceinline__ FsR fs_run_compose(const FsR &f, const FsR &g) {  // f first, then g
+    FsR h;
+    h.t = fs_compose(f.t, g.t);
+    h.e = (f.e == kFsEAny) ? g.e : ((g.e == kFsEAny || g.e == f.e) ? f.e : kFsEMixed);
+    return h;
+}
+
+constexpr uint32_t kFsBatch = 64 * kFsSpl;         // segments per batch: one lane's eight are one 512-row tile
+constexpr uint32_t kFsItemCap = 2 * kFsBatch + 1;  // items of a batch: at most two per segment, plus the end
+// An item is a run and what ends it, 32 bytes: {rmin0, rmax0, dm0, rmin1}, {rmax1, dm1, info, 0}.  With r the raw bits
+// of the running sum and p = r & 1 (the parity of S: the same as that of |S|), the run holds iff rmin_p <= r <= rmax_p
+// (unsigned: one range per sign and binade) and leaves the sum at r + dm_p.  info = type | tseg << 3 | slot << 12:
+//   0 end of the batch           3 parked segment whose own summary is the run: tried first, then its table
+//   1 parked segment: its table  4 nothing (closes the run in front of a type-3 item)
+//   2 segment without a usable summary: its rows are gathered and added
+// tseg = the segment the terminator stands for, inside the batch (types 0: the batch's segment count).
+enum : uint32_t { kFsItEnd = 0, kFsItTable = 1, kFsItGather = 2, kFsItSeg = 3, kFsItNop = 4 };
+__device__ __forceinline__ int32_t fs_item_info(uint32_t type, uint32_t tseg, uint32_t slot) { return (int32_t)(type | (tseg << 3) | (slot << 12)); }
+struct FsItem {
+    int4 a, b;
+};
+__device__ __forceinline__ FsItem fs_item(const FsR &r, int32_t info) {
+    FsItem it;
+    uint32_t mn0 = 0u, mx0 = 0xFFFFFFFFu, mn1 = 0u, mx1 = 0xFFFFFFFFu;  // no segment: every sum passes, nothing moves
+    int32_t dm0 = 0, dm1 = 0;
+    if (r.e != kFsEAny) {
+        const bool neg = (r.e >> 8) & 1;
+        const uint32_t base = (neg ? 0x80000000u : 0u) | ((uint32_t)((r.e & 0xFF) - 1) << 23);
+        const int32_t lim = 0x7FFFFF;
+        const bool sane = r.e != kFsEMixed && r.t.lo0 >= -lim && r.t.lo1 >= -lim && r.t.hi0 <= lim && r.t.hi1 <= lim;
+        // mantissa offsets o = |S| - 2^23 the run holds for (fs_inside): S + lo > 2^23, S + hi <= 2^24 - 1, mirrored for S < 0
+        mn0 = base + (uint32_t)(neg ? r.t.hi0 + 1 : 1 - r.t.lo0), mx0 = base + (uint32_t)(neg ? lim + r.t.lo0 : lim - r.t.hi0);
+        mn1 = base + (uint32_t)(neg ? r.t.hi1 + 1 : 1 - r.t.lo1), mx1 = base + (uint32_t)(neg ? lim + r.t.lo1 : lim - r.t.hi1);
+        dm0 = neg ? -r.t.d0 : r.t.d0, dm1 = neg ? -r.t.d1 : r.t.d1;
+        if (!sane) mn0 = mn1 = 1u, mx0 = mx1 = 0u;
+    }
+    it.a = make_int4((int32_t)mn0, (int32_t)mx0, dm0, (int32_t)mn1);
+    it.b = make_int4((int32_t)mx1, dm1, info, 0);
+    return it;
+}
+
+__device__ __forceinline__ void fs_items_wave(uint32_t lane, uint32_t c, uint32_t d, uint32_t G, uint32_t fidx, uint32_t b,
+                                              const uint32_t *__restrict__ fast_nodes, const uint32_t *__restrict__ tile_base,
+                                              const NodeArrays &na, const FsS *__restrict__ summ, const FsS *__restrict__ summ_odd,
+                                              int4 *__restrict__ items, uint32_t *__restrict__ ihdr, bool seg_first) {
+    const uint32_t node = fast_nodes[fidx], len = na.seg_len[node];
+    const uint32_t nseg = (len + kFsSeg - 1) / kFsSeg, t0 = b * kFsBatch;
+    const size_t seg0 = (size_t)tile_base[fidx] * kFsSegsPerTile;
+    const FsS *sp = summ + seg0 * d + c, *sp2 = summ_odd + seg0 * d + c;
+    const uint32_t cnt = min(kFsBatch, nseg - t0);
+    FsS m[kFsSpl], m2[kFsSpl];
+#pragma unroll
+    for (int j = 0; j < kFsSpl; ++j) m[j] = sp[(size_t)min(t0 + kFsSpl * lane + (uint32_t)j, nseg - 1u) * d];  // unconditional, clamped
+    bool two_l = false;
+#pragma unroll
+    for (int j = 0; j < kFsSpl; ++j) {
+        if (kFsSpl * lane + (uint32_t)j >= cnt) m[j].d = m[j].lo = m[j].hi = 0, m[j].ef = -1;  // past the node's end: ef = -1 marks it
+        m2[j] = m[j];
+        two_l = two_l || (m[j].ef != -1 && (m[j].ef & 3) == 2);
+    }
+    if (__ballot(two_l) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < kFsSpl; ++j)
+            if (m[j].ef != -1 && (m[j].ef & 3) == 2) {
+                const FsS o = sp2[(size_t)(t0 + kFsSpl * lane + (uint32_t)j) * d];
+                m2[j].d = o.d, m2[j].lo = o.lo, m2[j].hi = o.hi;
+            }
+    }
+    // terminators: parked segments (bit j of pk; of pu if their own summary is usable and worth trying first: under a
+    // sampled guess and in the variance pass most parked segments do hold -- the guess is the rough part -- while the
+    // mean pass of a zero-mean column, with its exact guess, parks what really leaves its binade: 96 % fail) and segments
+    // without a usable summary (gathered)
+    uint32_t pk = 0, pu = 0, tm = 0;
+#pragma unroll
+    for (int j = 0; j < kFsSpl; ++j) {
+        const bool live = m[j].ef != -1;
+        const bool parked = live && fs_ef_slot(m[j].ef) >= 0, bad = live && (m[j].ef & 1);
+        pk |= parked ? (1u << j) : 0u;
+        pu |= (parked && !bad && seg_first) ? (1u << j) : 0u;
+        tm |= (parked || bad) ? (1u << j) : 0u;
+    }
+    auto seg_run = [&](int j) {
+        FsR r;
+        r.t.d0 = m[j].d, r.t.lo0 = m[j].lo, r.t.hi0 = m[j].hi, r.t.d1 = m2[j].d, r.t.lo1 = m2[j].lo, r.t.hi1 = m2[j].hi;
+        r.e = fs_ef_key(m[j].ef);
+        return r;
+    };
+    FsR agg = fs_run_none();  // the segments behind the lane's last terminator (all of them if it has none)
+#pragma unroll
+    for (int j = 0; j < kFsSpl; ++j) {
+        const FsR nx = fs_run_compose(agg, seg_run(j));
+        const bool is_t = (tm >> j) & 1u, live = m[j].ef != -1;
+        agg = is_t ? fs_run_none() : (live ? nx : agg);
+    }
+    FsR v = agg;
+    int vf = tm != 0u ? 1 : 0;
+    {
+#define VQ_FS_DPP(XX, CTRL) __builtin_amdgcn_update_dpp(0, XX, CTRL, 0xF, 0xF, true)
+#define VQ_FS_SEG(CTRL, COND)                                                                                            \
+    {                                                                                                                    \
+        FsR p;                                                                                                           \
+        p.t.d0 = VQ_FS_DPP(v.t.d0, CTRL), p.t.d1 = VQ_FS_DPP(v.t.d1, CTRL), p.t.lo0 = VQ_FS_DPP(v.t.lo0, CTRL);          \
+        p.t.lo1 = VQ_FS_DPP(v.t.lo1, CTRL), p.t.hi0 = VQ_FS_DPP(v.t.hi0, CTRL), p.t.hi1 = VQ_FS_DPP(v.t.hi1, CTRL);      \
+        p.e = VQ_FS_DPP(v.e, CTRL);                                                                                      \
+        const int pf = VQ_FS_DPP(vf, CTRL);                                                                              \
+        const FsR cv = fs_run_compose(p, v);                                                                             \
+        const bool take = (COND) && !vf;                                                                                 \
+        v = take ? cv : v, vf = take ? pf : vf;                                                                          \
+    }
+        VQ_FS_SEG(0x111, (lane & 15u) >= 1u)
+        VQ_FS_SEG(0x112, (lane & 15u) >= 2u)
+        VQ_FS_SEG(0x114, (lane & 15u) >= 4u)
+        VQ_FS_SEG(0x118, (lane & 15u) >= 8u)
+        VQ_FS_SEG(0x142, (lane & 16u) != 0u)
+        VQ_FS_SEG(0x143, lane >= 32u)
+#undef VQ_FS_SEG
+#undef VQ_FS_DPP
+    }
+    FsR open;  // the run open when this lane starts: the inclusive value of the lane in front
+    open.t.d0 = __shfl_up(v.t.d0, 1), open.t.d1 = __shfl_up(v.t.d1, 1), open.t.lo0 = __shfl_up(v.t.lo0, 1);
+    open.t.lo1 = __shfl_up(v.t.lo1, 1), open.t.hi0 = __shfl_up(v.t.hi0, 1), open.t.hi1 = __shfl_up(v.t.hi1, 1);
+    open.e = __shfl_up(v.e, 1);
+    if (lane == 0) open = fs_run_none();
+    // items of this lane: one per terminator, two where a usable parked segment follows a run that is not empty
+    uint32_t mine_cnt = 0;
+    {
+        bool empty = open.e == kFsEAny;
+#pragma unroll
+        for (int j = 0; j < kFsSpl; ++j) {
+            const bool is_t = (tm >> j) & 1u, live = m[j].ef != -1;
+            mine_cnt += is_t ? (((pu >> j) & 1u) && !empty ? 2u : 1u) : 0u;
+            empty = is_t ? true : (live ? false : empty);
+        }
+    }
+    uint32_t incl = mine_cnt;
+    {
+#define VQ_FS_ADD(CTRL, COND) { const int32_t t = __builtin_amdgcn_update_dpp(0, (int32_t)incl, CTRL, 0xF, 0xF, true); if (COND) incl += (uint32_t)t; }
+        VQ_FS_ADD(0x111, (lane & 15u) >= 1u)
+        VQ_FS_ADD(0x112, (lane & 15u) >= 2u)
+        VQ_FS_ADD(0x114, (lane & 15u) >= 4u)
+        VQ_FS_ADD(0x118, (lane & 15u) >= 8u)
+        VQ_FS_ADD(0x142, (lane & 16u) != 0u)
+        VQ_FS_ADD(0x143, lane >= 32u)
+#undef VQ_FS_ADD
+    }
+    const uint32_t n_items = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) + 1u;
+    int4 *const out = items + ((size_t)G * d + c) * kFsItemCap * 2;
+    uint32_t at = incl - mine_cnt;
+    auto put = [&](const FsR &r, int32_t info) {
+        const FsItem it = fs_item(r, info);
+        out[2 * at] = it.a, out[2 * at + 1] = it.b;
+        ++at;
+    };
+    FsR r = open;
+#pragma unroll
+    for (int j = 0; j < kFsSpl; ++j) {
+        const bool is_t = (tm >> j) & 1u, live = m[j].ef != -1;
+        const uint32_t tseg = kFsSpl * lane + (uint32_t)j;
+        if (is_t) {
+            const bool parked = (pk >> j) & 1u;
+            const uint32_t slot = parked ? (uint32_t)fs_ef_slot(m[j].ef) : 0u;
+            if ((pu >> j) & 1u) {
+                if (r.e != kFsEAny) put(r, fs_item_info(kFsItNop, tseg, 0u));
+                put(seg_run(j), fs_item_info(kFsItSeg, tseg, slot));
+            } else {
+                put(r, fs_item_info(parked ? kFsItTable : kFsItGather, tseg, slot));
+            }
+        }
+        const FsR nx = fs_run_compose(r, seg_run(j));
+        r = is_t ? fs_run_none() : (live ? nx : r);
+    }
+    if (lane == 63u) {
+        put(r, fs_item_info(kFsItEnd, cnt, 0u));
+        ihdr[(size_t)G * d + c] = n_items;
+    }
+}
+
+// tables and items in ONE launch (both only need the fold's output): workgroups [0, n_tab_blocks) run the tables' body,
+// the others take one batch x four adjacent columns each (their summaries share 64-byte sectors)
+__global__ __launch_bounds__(256) void k_fs_prep(const float *__restrict__ side, const uint4 *__restrict__ side_meta, uint32_t pass_tag,
+                                                 const uint32_t *__restrict__ side_count, uint32_t side_cap, float *__restrict__ tab,
+                                                 int4 *__restrict__ tmeta, uint32_t n_tab_blocks, uint32_t d,
+                                                 const uint32_t *__restrict__ fast_nodes, const uint32_t *__restrict__ tile_base,
+                                                 const uint2 *__restrict__ batch_tab, NodeArrays na, const FsS *__restrict__ summ,
+                                                 const FsS *__restrict__ summ_odd, int4 *__restrict__ items, uint32_t *__restrict__ ihdr,
+                                                 const LevelInfo *__restrict__ lv, const uint32_t *__restrict__ policy, int seg_first_default) {
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    if (blockIdx.x < n_tab_blocks) {
+        fs_tables_wave(lane, blockIdx.x * 4u + w, n_tab_blocks * 4u, side, side_meta, pass_tag, side_count, side_cap, summ, summ_odd, tab, tmeta);
+        return;
+    }
+    const uint32_t cq = (d + 3) / 4, q = blockIdx.x - n_tab_blocks, G = q / cq, c = (q - G * cq) * 4u + w;
+    if (G >= lv->pad || c >= d) return;  // (pad = the level's batches; launched over an upper bound)
+    const uint2 bt = batch_tab[G];
+    const bool seg_first = policy ? policy[c / kFsCols] != 0u : seg_first_default != 0;  // (policy: 1 = sampled guess allowed for the column block)
+    if (seg_first) return;  // columns under a sampled guess keep k_fs_chain
+    fs_items_wave(lane, c, d, G, bt.x, bt.y, fast_nodes, tile_base, na, summ, summ_odd, items, ihdr, seg_first);
+}
+
+// The exact chain, third form: one wave per (node, column), ONE pass over the column's items.  Items travel 64 at a time
+// (a chunk): the chunk after the one being walked sits in LDS already, the one after that is in flight in registers;
+// ALL tables of a chunk's parked segments (at most 64: 16 KB) are requested a chunk ahead and sit in LDS while the chunk
+// is walked, their validity records (tmeta) next to the items.  The loop over a chunk's items has ONE branch per item:
+// the common outcomes -- the run holds, and the item ends in nothing or in a table whose window holds the sum -- are
+// computed without a test between them (the table's entry is read speculatively), everything else (a run that does not
+// hold: walked segment by segment from the summaries in memory, or -- a parked segment's own summary -- followed by its
+// table; a sum outside the table's window: the 64 additions from the parked addends; a segment without a summary: its
+// rows gathered) leaves the loop for one item.  Every lane carries the same sum: all branches are uniform.
+template <int MODE, bool DBG>
+__global__ __launch_bounds__(64) void k_fs_chain3(const float *__restrict__ X, uint32_t d, const uint32_t *__restrict__ perm,
+                                                  const uint32_t *__restrict__ fast_nodes, const uint32_t *__restrict__ tile_base,
+                                                  const uint32_t *__restrict__ batch_base, NodeArrays na,
+                                                  const FsS *__restrict__ summ, const FsS *__restrict__ summ_odd,
+                                                  const float *__restrict__ side, const float *__restrict__ tab,
+                                                  const int4 *__restrict__ tmeta, const int4 *__restrict__ items,
+                                                  const uint32_t *__restrict__ ihdr, uint32_t *__restrict__ n_fallback,
+                                                  const LevelInfo *__restrict__ lv, uint32_t *__restrict__ dbg_arg,
+                                                  const uint32_t *__restrict__ skip_sampled) {
+    uint32_t *const dbg = DBG ? dbg_arg : nullptr;
+    __shared__ __attribute__((aligned(16))) int4 litA[2][64], litB[2][64], litM[2][64];  // the chunk being walked / the next one; tmeta of their parked items
+    __shared__ int plist[64];                                               // side slots of the next chunk's parked items, in order
+    __shared__ __attribute__((aligned(16))) float ltab[64 * kFsTabN];       // the tables of the chunk being walked
+    __shared__ __attribute__((aligned(16))) float ladd[64];                 // addends of a segment being re-added
+    __shared__ __attribute__((aligned(16))) FsS lwk[64], lwk2[64];          // summaries of a run being walked
+    __shared__ uint32_t lhdr[1024];                                        // items per batch
+    if (blockIdx.x >= lv->n_fast) return;
+    if (skip_sampled && skip_sampled[blockIdx.y / kFsCols] != 0u) return;  // columns under a sampled guess keep k_fs_chain
+    const uint32_t fidx = blockIdx.x, node = fast_nodes[fidx], c = blockIdx.y, lane = threadIdx.x;
+    const uint32_t a = na.seg_start[node], len = na.seg_len[node];
+    const uint32_t nseg = (len + kFsSeg - 1) / kFsSeg, nbat = (nseg + kFsBatch - 1) / kFsBatch, G0 = batch_base[fidx];
+    const size_t seg0 = (size_t)tile_base[fidx] * kFsSegsPerTile;
+    const FsS *sp = summ + seg0 * d + c, *sp2 = summ_odd + seg0 * d + c;
+    const float mu = (MODE == 1) ? na.centroid[(size_t)node * d + c] : 0.0f;
+    float s = (MODE == 0) ? 0.0f : -0.0f;
+    uint32_t n_readd = 0, n_hit = 0, n_miss = 0, n_slow = 0, n_parked = 0, n_own = 0, n_out = 0;
+    unsigned long long cy_all = DBG ? clock64() : 0ull, cy_out = 0ull, cy_miss = 0ull, cy_stage = 0ull;  // VQHIP_TSVQ_DEBUG
+    plist[lane] = 0;  // (clamped table requests read entries nobody wrote: slot 0 is a valid address)
+    auto add64 = [&](const float *lds64) {  // 64 additions in row order, the addends by broadcast LDS reads
+        const f32x4_t *l4 = reinterpret_cast<const f32x4_t *>(lds64);
+        f32x4_t rq[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) rq[g] = l4[g];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            s = s + rq[g][0];
+            s = s + rq[g][1];
+            s = s + rq[g][2];
+            s = s + rq[g][3];
+        }
+    };
+    auto readd_from = [&](float vv) {
+        fs_wave_lds_sync();
+        ladd[lane] = vv;
+        fs_wave_lds_sync();
+        add64(ladd);
+        ++n_readd;
+    };
+    auto gather_add = [&](uint32_t seg) {  // the 64 rows of a segment through `perm`, added in row order
+        const uint32_t r0 = seg * kFsSeg, rows_here = min(kFsSeg, len - r0);
+        readd_from((lane < rows_here) ? fs_value<MODE>(X[(size_t)perm[a + r0 + lane] * d + c], mu) : 0.0f);  // (+0.0 past the end)
+    };
+    // a run that did not hold: its segments [from, to) of the column one by one -- 64 summaries at a time through LDS
+    auto walk = [&](uint32_t from, uint32_t to) {
+        ++n_slow;
+        for (uint32_t q0 = from; q0 < to; q0 += 64u) {
+            const uint32_t q = min(q0 + lane, to - 1u);
+            const FsS g = sp[(size_t)q * d];
+            FsS g2 = g;
+            if ((g.ef & 3) == 2) g2 = sp2[(size_t)q * d];
+            fs_wave_lds_sync();
+            lwk[lane] = g, lwk2[lane] = g2;
+            fs_wave_lds_sync();
+            const uint32_t nq = min(64u, to - q0);
+            for (uint32_t k = 0; k < nq; ++k) {
+                const FsS h = lwk[k], h2 = lwk2[k];
+                const uint32_t sb2 = __float_as_uint(s), se2 = (sb2 >> 23) & 0xFFu;
+                const int32_t mg2 = (int32_t)((sb2 & 0x7FFFFFu) | 0x800000u);
+                const int32_t Sq = (sb2 >> 31) ? -mg2 : mg2;
+                const bool oq = (Sq & 1) != 0;
+                const bool okq = (se2 != 0u) && (se2 != 255u) && !(h.ef & 1) && ((int)se2 - 127 == fs_ef_e(h.ef)) &&
+                                 fs_inside(Sq, oq ? h2.lo : h.lo, oq ? h2.hi : h.hi);
+                if (__builtin_amdgcn_readfirstlane(okq ? 1 : 0)) {
+                    const int32_t S2 = Sq + (oq ? h2.d : h.d);
+                    const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
+                    s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se2 << 23) | (m2a & 0x7FFFFFu));
+                } else {
+                    gather_add(q0 + k);
+                }
+            }
+        }
+    };
+    // items per batch: the first 1024 batches' counts sit in LDS (one pass at the start: a count read when the cursor gets
+    // there would be a memory round trip per batch); longer columns read the rest from memory
+    constexpr uint32_t kHdrLds = 1024;
+    for (uint32_t b = lane; b < min(nbat, kHdrLds); b += 64) lhdr[b] = ihdr[(size_t)(G0 + b) * d + c];
+    fs_wave_lds_sync();
+    auto hdr = [&](uint32_t b) -> uint32_t {
+        const uint32_t bb = min(b, nbat - 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)(bb < kHdrLds ? lhdr[bb] : ihdr[(size_t)(G0 + bb) * d + c]));
+    };
+    // the chunks of the column in order: (batch, chunk inside the batch); a cursor names the next chunk to REQUEST
+    uint32_t q_b = 0, q_k = 0, q_n = hdr(0);
+    int4 rA, rB;              // the chunk in flight
+    uint32_t rn = 0, rt = 0;  // its items (0: past the column's end), its batch's first segment
+    auto request = [&]() {
+        const bool live = q_b < nbat;
+        const uint32_t bb = live ? q_b : nbat - 1u;
+        rn = live ? min(64u, q_n - q_k * 64u) : 0u;
+        rt = bb * kFsBatch;
+        const uint32_t i = min(q_k * 64u + lane, kFsItemCap - 1u);
+        const int4 *src = items + (((size_t)(G0 + bb) * d + c) * kFsItemCap + i) * 2;
+        rA = src[0], rB = src[1];
+        if (live) {
+            if ((q_k + 1u) * 64u < q_n) ++q_k;
+            else ++q_b, q_k = 0u, q_n = hdr(q_b);
+        }
+    };
+    // stage the chunk in flight: registers -> LDS buffer bf (each parked item gets the byte offset of its table in `ltab`),
+    // its parked items listed, ALL their tables (pf: a chunk ahead of their use) and their validity records requested
+    float pf[32];
+    int4 rM = make_int4(0, 1, 0, 0);
+    auto stage = [&](int bf) -> uint32_t {
+        const uint32_t type = (uint32_t)rB.z & 7u;
+        const bool parked = lane < rn && (type == kFsItTable || type == kFsItSeg);
+        const uint64_t pmask = __ballot(parked);
+        const uint32_t prank = (uint32_t)__builtin_popcountll(pmask & ((1ull << lane) - 1ull));
+        const uint32_t slot = parked ? ((uint32_t)rB.z >> 12) : 0u;
+        litA[bf][lane] = rA, litB[bf][lane] = make_int4(rB.x, rB.y, rB.z, (int32_t)(parked ? prank * kFsTabN * 4u : 0u));
+        fs_wave_lds_sync();  // (the previous chunk's table requests have read plist)
+        if (parked) plist[prank] = (int)slot;
+        rM = tmeta[slot];
+        fs_wave_lds_sync();
+        const uint32_t ptotal = (uint32_t)__builtin_popcountll(pmask);
+        const uint32_t last = max(ptotal, 1u) - 1u;
+#pragma unroll
+        for (int g8 = 0; g8 < 4; ++g8)
+            if ((uint32_t)(16 * g8) < ptotal) {  // uniform; a load fetches two tables (half a wave each)
+#pragma unroll
+                for (int k = 8 * g8; k < 8 * g8 + 8; ++k)
+                    pf[k] = tab[(size_t)plist[min(2u * (uint32_t)k + (lane >> 5), last)] * kFsTabN + (lane & 31u)];
+            }
+        return ptotal;
+    };
+    request();
+    uint32_t ptot_next = stage(0);      // chunk 0 -> buffer 0
+    uint32_t cn = rn, ct0 = rt;         // the chunk being walked: items, first segment of its batch
+    request();                          // chunk 1 in flight
+    int buf = 0;
+    uint32_t pos = 0;                   // next segment of the batch not yet consumed when the chunk starts
+    while (cn != 0u) {                  // uniform
+        const unsigned long long q_st = DBG ? clock64() : 0ull;
+        // this chunk: its validity records and tables (requested a chunk ago) into LDS; the NEXT chunk: out of its registers
+        // into the other buffer, its tables requested; the chunk after it requested
+        litM[buf][lane] = rM;
+        const uint32_t ptot_cur = ptot_next;
+        fs_wave_lds_sync();  // the reads of ltab and of the other buffer (the chunk walked before this one) are done
+#pragma unroll
+        for (int g8 = 0; g8 < 4; ++g8)
+            if ((uint32_t)(16 * g8) < ptot_cur) {  // uniform
+#pragma unroll
+                for (int k = 8 * g8; k < 8 * g8 + 8; ++k) ltab[k * 64 + (int)lane] = pf[k];  // tables 2k and 2k + 1
+            }
+        if (DBG) n_parked += ptot_cur;
+        const uint32_t nn = rn, nt0 = rt;
+        ptot_next = stage(buf ^ 1);
+        request();
+        if (DBG) cy_stage += clock64() - q_st;
+        // (the item index goes through fs_vgpr: an LDS read at a uniform address is moved to SGPRs -- eleven v_readfirstlane --
+        // right behind the read, i.e. the wave waits for the item it has just asked for; as vector registers the next
+        // item's fields are waited for when they are used, an item later)
+        int4 A = litA[buf][fs_vgpr(0u)], B = litB[buf][fs_vgpr(0u)], M = litM[buf][fs_vgpr(0u)];
+        for (uint32_t i = 0; i < cn; ++i) {
+            const uint32_t inx = fs_vgpr(min(i + 1u, 63u));
+            const int4 nA = litA[buf][inx], nB = litB[buf][inx], nM = litM[buf][inx];  // (do not depend on s: in flight behind this item)
+            const uint32_t sb = __float_as_uint(s);
+            const bool odd = (sb & 1u) != 0u;
+            const uint32_t rmin = (uint32_t)(odd ? A.w : A.x), rmax = (uint32_t)(odd ? B.x : A.y);
+            const bool ok = sb >= rmin && sb <= rmax;
+            const uint32_t s1 = sb + (uint32_t)(odd ? B.y : A.z);
+            const uint32_t type = (uint32_t)B.z & 7u;
+            const int32_t mm = (int32_t)(s1 - (uint32_t)M.x) >> 5;  // (another sign or binade: far outside any window)
+            const bool hit = mm >= M.y && mm <= M.z;
+            const float tv = ltab[((uint32_t)B.w >> 2) + (s1 & 31u)];
+            const bool is_tab = type == kFsItTable;
+            const bool fast = ok && (is_tab ? hit : type != kFsItGather);
+            if (__builtin_amdgcn_readfirstlane(fast ? 1 : 0)) {
+                s = is_tab ? tv + (float)mm * __int_as_float(M.w) : __uint_as_float(s1);
+                if (DBG) n_hit += is_tab ? 1u : 0u, n_own += type == kFsItSeg ? 1u : 0u;
+            } else {
+                const unsigned long long q_o = DBG ? clock64() : 0ull;
+                ++n_out;
+                const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane(B.z), ty = info & 7u, tseg = (info >> 3) & 511u;
+                // where the run starts: behind what the item in front consumed
+                uint32_t from = pos;
+                if (i > 0u) {
+                    const uint32_t pi = (uint32_t)__builtin_amdgcn_readfirstlane(litB[buf][i - 1u].z), pt = pi & 7u, ps = (pi >> 3) & 511u;
+                    from = pt == kFsItEnd ? 0u : (pt == kFsItNop ? ps : ps + 1u);
+                }
+                bool need_table = ty == kFsItTable;
+                if (__builtin_amdgcn_readfirstlane(ok ? 1 : 0)) s = __uint_as_float(s1);
+                else if (ty == kFsItSeg) need_table = true;
+                else walk(ct0 + from, ct0 + (ty == kFsItEnd ? info >> 3 : tseg));
+                if (need_table) {
+                    const uint32_t sb3 = __float_as_uint(s);
+                    const int32_t m3 = (int32_t)(sb3 - (uint32_t)M.x) >> 5;
+                    const bool hit3 = m3 >= M.y && m3 <= M.z;
+                    if (__builtin_amdgcn_readfirstlane(hit3 ? 1 : 0)) {
+                        const float tv3 = ltab[((uint32_t)B.w >> 2) + (sb3 & 31u)];
+                        s = tv3 + (float)m3 * __int_as_float(M.w);
+                        if (DBG) ++n_hit;
+                    } else {
+                        const unsigned long long q_ms = DBG ? clock64() : 0ull;
+                        readd_from(side[(size_t)(info >> 12) * kFsSeg + lane]);
+                        if (DBG) {
+                            asm volatile("" ::"v"(s));
+                            cy_miss += clock64() - q_ms;
+                        }
+                        ++n_miss;
+                    }
+                } else if (ty == kFsItGather) {
+                    gather_add(ct0 + tseg);
+                }
+                if (DBG) {
+                    asm volatile("" ::"v"(s));
+                    cy_out += clock64() - q_o;
+                }
+            }
+            A = nA, B = nB, M = nM;
+        }
+        {  // what this chunk's last item consumed: where a run that continues in the next chunk starts
+            const uint32_t li = (uint32_t)__builtin_amdgcn_readfirstlane(litB[buf][cn - 1u].z), lt = li & 7u, ls = (li >> 3) & 511u;
+            pos = lt == kFsItEnd ? 0u : (lt == kFsItNop ? ls : ls + 1u);
+        }
+        buf ^= 1;
+        cn = nn, ct0 = nt0;
+    }
+    if (lane == 0) {
+        if (MODE == 0) na.centroid[(size_t)node * d + c] = s / (float)len;  // T::from_usize(n)
+        else na.var[(size_t)node * d + c] = s;
+        if (n_fallback && n_readd) atomicAdd(n_fallback, n_readd);
+        if (dbg) {  // VQHIP_TSVQ_DEBUG: chains, re-added segments (most in one chain), table hits / misses, runs walked, core cycles
+            atomicAdd(dbg + 0, 1u);
+            atomicAdd(dbg + 1, n_readd);
+            atomicMax(dbg + 2, n_readd);
+            atomicAdd(dbg + 3, n_hit);
+            atomicAdd(dbg + 4, n_miss);
+            atomicAdd(dbg + 5, n_slow);
+            atomicAdd(dbg + 6, n_own);
+            atomicAdd(dbg + 7, n_out);
+            atomicAdd(dbg + 14, n_parked);
+            atomicAdd(dbg + 8, (uint32_t)((clock64() - cy_all) >> 6));
+            atomicAdd(dbg + 9, (uint32_t)(cy_out >> 6));
+            atomicAdd(dbg + 10, (uint32_t)(cy_miss >> 6));
+            atomicAdd(dbg + 11, (uint32_t)(cy_stage >> 6));
+            atomicMax(dbg + 13, (uint32_t)((clock64() - cy_all) >> 6));
+        }
+    }
+}
+
 // debug aid (VQHIP_TSVQ_CHECK=1): per (node, column) walk the segments one by one, compare the summary-applied
 // sum with the row-by-row sum and report the first disagreement
 template <int MODE>
@@ -1930,9 +2537,10 @@ __device__ inline void plan_level_body(LevelInfo *__restrict__ lv, int can_split
                                        uint32_t *__restrict__ lvl_split, uint32_t *__restrict__ remap,
                                        uint32_t *__restrict__ fast_nodes, uint32_t *__restrict__ slow_nodes,
                                        uint32_t *__restrict__ tile_base, uint32_t *__restrict__ n_tiles_of,
-                                       FsTile *__restrict__ tiles, uint32_t *sh) {
+                                       FsTile *__restrict__ tiles, uint32_t *__restrict__ batch_base, uint2 *__restrict__ batch_tab,
+                                       uint32_t *sh) {
     const uint32_t first = lv->first, count = lv->count;
-    uint32_t n_split = 0, n_fast = 0, n_tiles = 0;
+    uint32_t n_split = 0, n_fast = 0, n_tiles = 0, n_bat = 0;
     for (uint32_t b = 0; b < count; b += 1024) {
         const uint32_t li = b + threadIdx.x;
         const bool in = li < count;
@@ -1945,6 +2553,10 @@ __device__ inline void plan_level_body(LevelInfo *__restrict__ lv, int can_split
         const uint32_t ps = block_excl_scan(is_split, sh, &tot_s);
         const uint32_t pf = block_excl_scan(is_fast, sh, &tot_f);
         const uint32_t pt = block_excl_scan(nt, sh, &tot_t);
+        // batches of 64 tiles (k_fs_prep / k_fs_chain3: the items of a column are kept per batch)
+        uint32_t tot_b;
+        const uint32_t pbt = block_excl_scan((nt + 63u) / 64u, sh, &tot_b);
+        if (in && is_fast && batch_base) batch_base[n_fast + pf] = n_bat + pbt;
         if (in) {
             remap[li] = is_split ? n_split + ps : kInactive;
             if (is_split) lvl_split[n_split + ps] = node;
@@ -1959,6 +2571,7 @@ __device__ inline void plan_level_body(LevelInfo *__restrict__ lv, int can_split
         n_split += tot_s;
         n_fast += tot_f;
         n_tiles += tot_t;
+        n_bat += tot_b;
     }
     __threadfence();
     __syncthreads();
@@ -1985,7 +2598,24 @@ __device__ inline void plan_level_body(LevelInfo *__restrict__ lv, int can_split
         tl.rows = min(kFsTile, len - t * kFsTile);
         tiles[T] = tl;
     }
+    if (batch_tab) {  // batch B = batch B - batch_base[f] of the fast node f with batch_base[f] <= B (same search)
+        const bool b_lds = n_fast <= 1024u;
+        __syncthreads();
+        if (b_lds) {
+            if (threadIdx.x < n_fast) sh[threadIdx.x] = batch_base[threadIdx.x];
+            __syncthreads();
+        }
+        for (uint32_t B = threadIdx.x; B < n_bat; B += 1024) {
+            uint32_t lo = 0, hi = n_fast;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((b_lds ? sh[mid] : batch_base[mid]) <= B) lo = mid; else hi = mid;
+            }
+            batch_tab[B] = make_uint2(lo, B - (b_lds ? sh[lo] : batch_base[lo]));
+        }
+    }
     if (threadIdx.x == 0) {
+        lv->pad = n_bat;
         lv->n_split = n_split;
         lv->n_fast = n_fast;
         lv->n_slow = count - n_fast;
@@ -1996,9 +2626,9 @@ __global__ __launch_bounds__(1024) void k_plan_level(LevelInfo *__restrict__ lv,
                                                      uint32_t *__restrict__ lvl_split, uint32_t *__restrict__ remap,
                                                      uint32_t *__restrict__ fast_nodes, uint32_t *__restrict__ slow_nodes,
                                                      uint32_t *__restrict__ tile_base, uint32_t *__restrict__ n_tiles_of,
-                                                     FsTile *__restrict__ tiles) {
+                                                     FsTile *__restrict__ tiles, uint32_t *__restrict__ batch_base, uint2 *__restrict__ batch_tab) {
     __shared__ uint32_t sh[1024];
-    plan_level_body(lv, can_split, can_fast, fs_min_rows, na, lvl_split, remap, fast_nodes, slow_nodes, tile_base, n_tiles_of, tiles, sh);
+    plan_level_body(lv, can_split, can_fast, fs_min_rows, na, lvl_split, remap, fast_nodes, slow_nodes, tile_base, n_tiles_of, tiles, batch_base, batch_tab, sh);
 }
 
 // end of a level: children of the split nodes from nleft / nv (src/tsvq.rs:88-108), numbered in order
@@ -2064,7 +2694,8 @@ __global__ __launch_bounds__(1024) void k_plan_fused(LevelInfo *__restrict__ lv,
                                                      int can_fast, uint32_t fs_min_rows, uint32_t *__restrict__ lvl_split_next,
                                                      uint32_t *__restrict__ remap_next, uint32_t *__restrict__ fast_nodes,
                                                      uint32_t *__restrict__ slow_nodes, uint32_t *__restrict__ tile_base,
-                                                     uint32_t *__restrict__ n_tiles_of, FsTile *__restrict__ tiles) {
+                                                     uint32_t *__restrict__ n_tiles_of, FsTile *__restrict__ tiles,
+                                                     uint32_t *__restrict__ batch_base, uint2 *__restrict__ batch_tab) {
     __shared__ uint32_t sh[1024];
     scan_sums_body(bsums, nb, sh);
     __threadfence();
@@ -2073,7 +2704,7 @@ __global__ __launch_bounds__(1024) void k_plan_fused(LevelInfo *__restrict__ lv,
     __threadfence();
     __syncthreads();
     plan_level_body(lv_next, next_can_split, can_fast, fs_min_rows, na, lvl_split_next, remap_next, fast_nodes, slow_nodes, tile_base,
-                    n_tiles_of, tiles, sh);
+                    n_tiles_of, tiles, batch_base, batch_tab, sh);
 }
 
 // ---- host driver of the build ------------------------------------------------------------
@@ -2084,7 +2715,9 @@ struct TsvqBuildWs {
     DevBuf b_perm[2], b_nodeof[2], b_vals, b_flags, b_scan, b_bsums, b_hist, b_lvl, b_remap, b_lvl2, b_remap2;
     DevBuf b_seg_start, b_seg_len, b_split, b_nv, b_nleft, b_median, b_selp, b_selr, b_child, b_cent, b_var, b_left, b_right;
     DevBuf b_fs_tiles, b_fs_nodes, b_fs_base, b_fs_nt, b_fs_sum, b_fs_pref, b_fs_summ2, b_fs_summ, b_lvl_slow, b_fs_fb, b_fs_side, b_fs_mom, b_lv;
-    DevBuf *all[39] = {&b_lvl2, &b_remap2, &b_perm[0], &b_perm[1], &b_nodeof[0], &b_nodeof[1], &b_vals, &b_flags, &b_scan, &b_bsums, &b_hist,
+    DevBuf b_fs_smeta, b_fs_tab, b_fs_tmeta;  // k_fs_prep: guess + pass tag per parked slot, the tables, their validity
+    DevBuf b_fs_bbase, b_fs_btab, b_fs_items, b_fs_ihdr;  // batches per fast node, batch table, the items per (batch, column)
+    DevBuf *all[46] = {&b_fs_bbase, &b_fs_btab, &b_fs_items, &b_fs_ihdr, &b_fs_smeta, &b_fs_tab, &b_fs_tmeta, &b_lvl2, &b_remap2, &b_perm[0], &b_perm[1], &b_nodeof[0], &b_nodeof[1], &b_vals, &b_flags, &b_scan, &b_bsums, &b_hist,
                        &b_lvl, &b_remap, &b_seg_start, &b_seg_len, &b_split, &b_nv, &b_nleft, &b_median, &b_selp, &b_selr,
                        &b_child, &b_cent, &b_var, &b_left, &b_right, &b_fs_tiles, &b_fs_nodes, &b_fs_base, &b_fs_nt, &b_fs_sum, &b_fs_pref, &b_fs_summ2,
                        &b_fs_summ, &b_lvl_slow, &b_fs_fb, &b_fs_side, &b_fs_mom, &b_lv};
@@ -2229,6 +2862,10 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     // parked segments per pass (256 bytes each; beyond the cap the re-addition gathers its rows, two dependent loads): half
     // of all segments (zero-mean columns park up to a third at the deeper levels), 256 MB at most
     const uint32_t side_cap = (nopark && nopark[0] == '1') ? 0u : (uint32_t)std::min<uint64_t>(seg_slots * d / 2 + 1, 1ull << 20);
+    // VQHIP_TSVQ_CHAIN=1: round 4's chain (re-additions executed on the column's wave) instead of the table form (A/B)
+    static const char *chain_env = getenv("VQHIP_TSVQ_CHAIN");
+    const bool use_tables = side_cap > 0 && !(chain_env && chain_env[0] == '1');
+    const uint32_t batches_max = tiles_max / 64 + fast_max + 1;
     if (can_fast) {
         VQ_TRY(ws.b_fs_tiles.ensure((size_t)tiles_max * sizeof(FsTile)));
         VQ_TRY(ws.b_fs_nodes.ensure((size_t)fast_max * 4));
@@ -2241,6 +2878,15 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             VQ_TRY(ws.b_fs_summ.ensure(seg_slots * d * sizeof(FsS)));
             VQ_TRY(ws.b_fs_summ2.ensure(seg_slots * d * sizeof(FsS)));
             VQ_TRY(ws.b_fs_side.ensure(std::max<size_t>((size_t)side_cap * kFsSeg * 4, 16)));
+            if (use_tables) {
+                VQ_TRY(ws.b_fs_tab.ensure(std::max<size_t>((size_t)side_cap * kFsTabN * 4, 16)));
+                VQ_TRY(ws.b_fs_smeta.ensure(std::max<size_t>((size_t)side_cap * sizeof(uint4), 16)));
+                VQ_TRY(ws.b_fs_tmeta.ensure(std::max<size_t>((size_t)side_cap * sizeof(int4), 16)));
+                VQ_TRY(ws.b_fs_bbase.ensure((size_t)fast_max * 4));
+                VQ_TRY(ws.b_fs_btab.ensure((size_t)batches_max * sizeof(uint2)));
+                VQ_TRY(ws.b_fs_items.ensure((size_t)batches_max * d * kFsItemCap * 2 * sizeof(int4)));
+                VQ_TRY(ws.b_fs_ihdr.ensure((size_t)batches_max * d * 4));
+            }
         }
     } else {
         VQ_TRY(ws.b_fs_tiles.ensure(16));
@@ -2276,6 +2922,16 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     FsS *sm = ws.b_fs_summ.as<FsS>(), *sm2 = ws.b_fs_summ2.as<FsS>();
     const uint32_t *fn = ws.b_fs_nodes.as<uint32_t>(), *fb = ws.b_fs_base.as<uint32_t>(), *fc = ws.b_fs_nt.as<uint32_t>();
     float *side = ws.b_fs_side.as<float>();
+    float *tabs = ws.b_fs_tab.as<float>();
+    uint4 *smeta = use_tables ? ws.b_fs_smeta.as<uint4>() : nullptr;
+    int4 *tmeta = ws.b_fs_tmeta.as<int4>();
+    const bool have_prep = use_tables && can_fast && n >= fs_min_rows;
+    uint32_t *bbase = have_prep ? ws.b_fs_bbase.as<uint32_t>() : nullptr;
+    uint2 *btab = have_prep ? ws.b_fs_btab.as<uint2>() : nullptr;
+    int4 *items = ws.b_fs_items.as<int4>();
+    uint32_t *ihdr = ws.b_fs_ihdr.as<uint32_t>();
+    // tags of this build's passes: never a value an earlier pass (of this or an earlier build over the same scratch) used
+    static std::atomic<uint32_t> g_pass_tag{1};
     uint32_t *fbk = ws.b_fs_fb.as<uint32_t>();
     const uint32_t *policy = adaptive_sampling ? fbk + 2 + 64 * 2 * 16 : nullptr;
 
@@ -2304,21 +2960,43 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         // k_fs_fold: persistent single-wave workgroups, two per SIMD (the kernel's register budget)
         const dim3 tgrid(ub_tiles * ncb), xgrid(std::min<uint32_t>(ub_tiles * ncb, (uint32_t)num_cus() * 8));
         const dim3 pgrid(ub_fast, (d + kFsPrefCols - 1) / kFsPrefCols), cgrid(ub_fast, d);
+        uint32_t tag = g_pass_tag.fetch_add(1);
+        if (tag == 0) tag = g_pass_tag.fetch_add(1);
+        // k_fs_prep: the tables (four waves per workgroup striding over the parked slots: the count is the device's) and
+        // the items (one workgroup per batch x four columns, over an upper bound of the level's batches)
+        const uint32_t n_tab_blocks = std::min<uint32_t>((side_cap + 3) / 4, (uint32_t)num_cus() * 4);
+        const uint32_t ub_batches = std::min(batches_max, ub_tiles / 64 + ub_fast);
+        const dim3 bgrid(n_tab_blocks + ub_batches * ((d + 3) / 4));
+        // Mean pass: columns with an exact guess (k_fs_policy: zero-mean columns, where 10-30 % of the segments leave their
+        // binade) through the tables + items + one-pass chain of round 5; columns under a sampled guess (most parked segments
+        // hold there, and the guess is off by far more than a table's window) and the variance pass (monotone sums: a
+        // handful of crossings per column) keep round 4's chain.
+        const bool new_any = use_tables && mode == 0 && (policy != nullptr || fs_sample == 1);
+        const bool old_any = !(use_tables && mode == 0 && fs_sample == 1 && policy == nullptr);
+        const uint32_t *only_sampled = (new_any && old_any) ? policy : nullptr;
         if (mode == 0) {
             // the binade guesses: f64 sums of every 8th group of rows of each tile where k_fs_policy allows (|mean| >= sigma),
             // of every row elsewhere; prefix over the node's tiles
             hipLaunchKernelGGL(k_fs_tile_sums<0>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts, fs_sample, policy, lvp);
             hipLaunchKernelGGL(k_fs_prefix<false>, pgrid, dim3(1024), 0, stream, d, fn, fb, fc, na, ts, mom, tp, lvp, fbk + 1);
-            hipLaunchKernelGGL(k_fs_fold<0>, xgrid, dim3(64), 0, stream, X, d, perm, tl, lvp, na, tp, sm, sm2, side, side_cap, fbk + 1, mom, park_rel, policy);
-            if (dbg) hipLaunchKernelGGL((k_fs_chain<0, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg);
-            else hipLaunchKernelGGL((k_fs_chain<0, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg);
+            hipLaunchKernelGGL(k_fs_fold<0>, xgrid, dim3(64), 0, stream, X, d, perm, tl, lvp, na, tp, sm, sm2, side, side_cap, fbk + 1, mom, park_rel, policy, new_any ? smeta : (uint4 *)nullptr, tag);
+            if (new_any) {
+                hipLaunchKernelGGL(k_fs_prep, bgrid, dim3(256), 0, stream, side, smeta, tag, fbk + 1, side_cap, tabs, tmeta, n_tab_blocks, d, fn, fb, btab, na, sm, sm2, items, ihdr, lvp, policy, 0);
+                if (dbg) hipLaunchKernelGGL((k_fs_chain3<0, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, bbase, na, sm, sm2, side, tabs, tmeta, items, ihdr, fbk, lvp, dbg, policy);
+                else hipLaunchKernelGGL((k_fs_chain3<0, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, bbase, na, sm, sm2, side, tabs, tmeta, items, ihdr, fbk, lvp, dbg, policy);
+            }
+            if (old_any) {
+                // (VQHIP_TSVQ_DEBUG counts one form per pass: the new one where both run)
+                if (dbg && !new_any) hipLaunchKernelGGL((k_fs_chain<0, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, only_sampled);
+                else hipLaunchKernelGGL((k_fs_chain<0, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, (uint32_t *)nullptr, only_sampled);
+            }
         } else {
             // the guess comes from the sums the mean pass of the same level left behind (same tile table: every node
             // long enough for the emulation has more than one row, so it is a split node whenever the level splits)
             hipLaunchKernelGGL(k_fs_prefix<true>, pgrid, dim3(1024), 0, stream, d, fn, fb, fc, na, ts, mom, tp, lvp, fbk + 1);
-            hipLaunchKernelGGL(k_fs_fold<1>, xgrid, dim3(64), 0, stream, X, d, perm, tl, lvp, na, tp, sm, sm2, side, side_cap, fbk + 1, (double2 *)nullptr, 0.0f, (const uint32_t *)nullptr);
-            if (dbg) hipLaunchKernelGGL((k_fs_chain<1, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg);
-            else hipLaunchKernelGGL((k_fs_chain<1, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg);
+            hipLaunchKernelGGL(k_fs_fold<1>, xgrid, dim3(64), 0, stream, X, d, perm, tl, lvp, na, tp, sm, sm2, side, side_cap, fbk + 1, (double2 *)nullptr, 0.0f, (const uint32_t *)nullptr, (uint4 *)nullptr, 0u);
+            if (dbg) hipLaunchKernelGGL((k_fs_chain<1, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
+            else hipLaunchKernelGGL((k_fs_chain<1, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
         }
         VQ_LAUNCH_CHECK("k_fs_*");
         if (getenv("VQHIP_TSVQ_CHECK")) {
@@ -2340,7 +3018,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     static const char *noask_env = getenv("VQHIP_TSVQ_NO_LEVEL_ASK");  // =1: always launch both halves (A/B)
     hipLaunchKernelGGL(k_plan_level, dim3(1), dim3(1024), 0, stream, &lv[0], max_depth > 0 ? 1 : 0, can_fast ? 1 : 0, fs_min_rows, na, lvl_split_buf[0],
                        remap_buf[0], ws.b_fs_nodes.as<uint32_t>(), slow_nodes, ws.b_fs_base.as<uint32_t>(), ws.b_fs_nt.as<uint32_t>(),
-                       ws.b_fs_tiles.as<FsTile>());
+                       ws.b_fs_tiles.as<FsTile>(), bbase, btab);
     VQ_LAUNCH_CHECK("k_plan_level");
     for (uint32_t L = 0; L < n_levels; ++L) {
         uint32_t ub_nodes = level_width(L);
@@ -2396,7 +3074,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         hipLaunchKernelGGL(k_plan_fused, dim3(1), dim3(1024), 0, stream, &lv[L], &lv[L + 1], lvl_split, na, node_left, node_right, dcap,
                            ws.b_scan.as<uint32_t>(), ws.b_bsums.as<uint32_t>(), nblk, ws.b_flags.as<uint32_t>(), (L + 1 < max_depth) ? 1 : 0,
                            can_fast ? 1 : 0, fs_min_rows, lvl_split_buf[(L + 1) & 1], remap_buf[(L + 1) & 1], ws.b_fs_nodes.as<uint32_t>(),
-                           slow_nodes, ws.b_fs_base.as<uint32_t>(), ws.b_fs_nt.as<uint32_t>(), ws.b_fs_tiles.as<FsTile>());
+                           slow_nodes, ws.b_fs_base.as<uint32_t>(), ws.b_fs_nt.as<uint32_t>(), ws.b_fs_tiles.as<FsTile>(), bbase, btab);
         VQ_LAUNCH_CHECK("k_plan_fused");
         hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, n, perm, node_of, remap, lvl_split, na,
                            ws.b_scan.as<uint32_t>(), ws.b_bsums.as<uint32_t>(), ws.b_flags.as<uint32_t>(), ws.b_perm[cur ^ 1].as<uint32_t>(),
@@ -2436,6 +3114,17 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         }
         for (uint32_t q = 0; q < 128; ++q) {
             const uint32_t *c8 = fbn + 2 + q * 16;
+            if (c8[0] && use_tables && !(q & 1) && c8[7] + c8[3] + c8[14] != 0 && c8[12] == 0) {
+                fprintf(stderr, "[vqhip]   level %u %s: %u chains, %u segments parked: %u held by their own summary, %u looked up in their tables, %u outside the "
+                                "table's window or without one (%.2f %% of the parked: re-added from the parked addends); %u segments re-added in all (most in one chain %u), "
+                                "%u runs walked segment by segment\n",
+                        q / 2, (q & 1) ? "variance" : "mean", c8[0], c8[14], c8[6], c8[3], c8[4], 100.0 * c8[4] / (c8[14] ? c8[14] : 1), c8[1], c8[2], c8[5]);
+                fprintf(stderr, "[vqhip]     core cycles per chain (average; longest %.0f k): %.0f k, of which %u items off the fast path %.0f k (table misses "
+                                "%.0f k, %.0f each), staging chunks %.0f k\n",
+                        c8[13] * 64.0 / 1e3, c8[8] * 64.0 / c8[0] / 1e3, c8[7] / c8[0], c8[9] * 64.0 / c8[0] / 1e3, c8[10] * 64.0 / c8[0] / 1e3,
+                        c8[10] * 64.0 / (c8[4] ? c8[4] : 1), c8[11] * 64.0 / c8[0] / 1e3);
+                continue;
+            }
             if (c8[0])
                 fprintf(stderr, "[vqhip]   level %u %s: %u chains, %u segments re-added (most in one chain %u): unusable summary %u, "
                                 "other binade than guessed %u, prefix leaves the binade %u, sum not normal %u; %u gathered (not parked)\n",
