@@ -11,6 +11,8 @@ import os
 
 import numpy as np
 
+from . import _arena
+
 from .errors import FfiError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -419,18 +421,19 @@ class PQEncoder(Handle):
         return idx, dist
 
     def encode(self, rows, want_codes=True, want_f16=True, out_codes=None, out_f16=None):
-        """codes (n, m) and / or the f16 reconstruction (n, dim).  out_codes / out_f16: C-contiguous arrays of the right
-        shape and dtype to fill instead of fresh ones (a fresh 256 MB array costs its first touch: ~25 ms of page faults
-        under the copy from the device, against 10 ms for the whole call into pages that exist)"""
+        """codes (n, m) and / or the f16 reconstruction (n, dim): fresh arrays per call, like the reference's binding
+        (pyvq/src/pq.rs:96-107) -- large ones in recycled buffers (vq_amd/_arena.py: the first touch of a new 256 MB array
+        was 25 ms of page faults under the copy from the device, against 10 ms for the whole call into pages that exist).
+        out_codes / out_f16: C-contiguous arrays of the right shape and dtype to fill instead."""
         rows = f32c(rows).reshape(-1, self.m * self.sd)
         n = rows.shape[0]
         codes = f16 = None
         if want_codes or out_codes is not None:
-            codes = out_codes if out_codes is not None else np.empty((n, self.m), code_dtype(self.k))
+            codes = out_codes if out_codes is not None else _arena.fresh((n, self.m), code_dtype(self.k))
             if codes.shape != (n, self.m) or codes.dtype != code_dtype(self.k) or not codes.flags.c_contiguous:
                 raise FfiError(f"out_codes must be a C-contiguous {np.dtype(code_dtype(self.k)).name} array of shape ({n}, {self.m})", ERR_INVALID_INPUT)
         if want_f16 or out_f16 is not None:
-            f16 = out_f16 if out_f16 is not None else np.empty((n, self.m * self.sd), np.float16)
+            f16 = out_f16 if out_f16 is not None else _arena.fresh((n, self.m * self.sd), np.float16)
             if f16.shape != (n, self.m * self.sd) or f16.dtype.itemsize != 2 or not f16.flags.c_contiguous:
                 raise FfiError(f"out_f16 must be a C-contiguous float16 array of shape ({n}, {self.m * self.sd})", ERR_INVALID_INPUT)
         check(load().vqhip_pq_encode(self.raw, ptr(rows, _f32p), n, ptr(codes, _u8p),

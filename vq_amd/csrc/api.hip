@@ -2,6 +2,7 @@
 // the reference file:line each entry replaces).  Host-side orchestration only; the kernels
 // are in k_*.hip.  No CPU compute fallback exists anywhere in this file.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>

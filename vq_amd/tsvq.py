@@ -11,7 +11,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib
+from . import _arena, _lib
 from .distance import Distance
 from .errors import DimensionMismatch
 from .pq import _as_training_matrix
@@ -108,8 +108,8 @@ class TSVQ:
         if X.shape[1] != self._dim:
             raise DimensionMismatch(self._dim, X.shape[1])
         n = X.shape[0]
-        leaf = np.empty(n, np.int32) if want_leaf else None
-        f16 = np.empty((n, self._dim), np.uint16) if want_f16 else None
+        leaf = _arena.fresh((n,), np.int32) if want_leaf else None  # (large results: recycled buffers, vq_amd/_arena.py)
+        f16 = _arena.fresh((n, self._dim), np.uint16) if want_f16 else None
         if n:
             _lib.check(_lib.load().vqhip_tsvq_encode(self._enc.raw, _lib.ptr(X, _lib._f32p), n,
                                                      _lib.ptr(leaf, _lib._i32p), _lib.ptr(f16, _lib._u16p)))
