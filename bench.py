@@ -188,8 +188,8 @@ PEAK_VALU_TOPS = 78.6  # the VALU roofline for Manhattan (no con
 def valu_roofline(ops, ms, extra=None):
     ach = ops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     r = {"bound": "valu", "achieved": ach, "peak": PEAK_VALU_TOPS, "unit": "Tops/s", "frac": ach / PEAK_VALU_TOPS,
-         "peak_is": "SURVEY.md 8(d): 157.3 TFLOP/s of fp32 VALU work counts an FMA as two; one op per lane-slot = 78.6 Tops/s; a Manhattan "
-                    "term is counted as 3 ops (sub, abs, add): ops = 3*N*k*D",
+         "peak_is": "SURVEY.md 8(d): 157.3 TFLOP/s of fp32 VALU work counts an FMA as two: 78.6 T f32 ops/s; a Manhattan term executes "
+                    "as 2 ops (sub, add with |.| as operand modifier): ops = 2*N*k*D",
          "avg_launch_ms": ms, "ops_per_launch": ops}
     if extra:
         r.update(extra)
@@ -405,9 +405,13 @@ def other_configs(_lib, torch, engine):
         rechecked, used = _lib.last_assign_stats()
         kern_ms = primary_ms / max(calls, 1)
         if used == 1:  # exact VALU engine: 3 ops per (row, centroid, dimension)
-            ops = 3.0 * n * k * d
+            # SURVEY.md 8(d) counts a term as sub + abs + add = 3 ops against 78.6 Tops/s; |x| is an operand modifier on this
+            # ISA (v_add_f32 acc, acc, |diff|), so a term is TWO instructions and the 3-op count passes the peak (1.09):
+            # `frac` counts the two that execute, the 3-op figure is kept beside it
+            ops = 2.0 * n * k * d
             roof = valu_roofline(ops, kern_ms, {
                 "kernel": "k_assign_exact", "step_frac": ops / (step_ms * 1e-3) / 1e12 / PEAK_VALU_TOPS,
+                "frac_counting_3_ops_per_term": 1.5 * ops / (kern_ms * 1e-3) / 1e12 / PEAK_VALU_TOPS,
                 "note": "the kernel keeps the reference's sequential f32 sum per (row, centroid): one lane per (row, subspace)"})
         else:
             flop = 2.0 * k * d * n
