@@ -253,6 +253,19 @@ int vqhip_comm_create(const uint8_t *id, int world, int rank, vqhip_comm **out);
 int vqhip_comm_adopt(void *nccl_comm, vqhip_comm **out);
 int vqhip_comm_info(const vqhip_comm *comm, int *world, int *rank);
 int vqhip_comm_destroy(vqhip_comm *comm);
+/* The ranks of ONE process (a host thread per GPU) need no communicator library: an in-process group exchanges the slab
+ * directly -- every rank publishes its slab on its own device, every rank's stream then adds all published slabs IN RANK
+ * ORDER through peer access (xGMI): stream-ordered like ncclAllReduce, the same bits on every rank and run to run.
+ *   comm_group_create : the shared state of `world` ranks (<= 16)
+ *   comm_create_local : rank `rank` of the group, on the calling thread's current device; collective over the group's
+ *                       ranks, each called from its own thread.  Two ranks may name the same device.
+ *   comm_kind         : 0 identity (one rank), 1 RCCL, 2 in-process exchange
+ * Destroy the ranks' communicators (streams drained) before the group. */
+typedef struct vqhip_comm_group vqhip_comm_group;
+int vqhip_comm_group_create(int world, vqhip_comm_group **out);
+int vqhip_comm_create_local(vqhip_comm_group *group, int rank, vqhip_comm **out);
+int vqhip_comm_group_destroy(vqhip_comm_group *group);
+int vqhip_comm_kind(const vqhip_comm *comm, int *kind);
 /* in-place all-reduce of the slab between _accumulate and _finalize (NULL comm: no-op) */
 int vqhip_kmeans_allreduce(vqhip_kmeans *km, vqhip_comm *comm);
 /* = accumulate + allreduce + finalize: vqhip_kmeans_step for a sharded data set; counts are global */
@@ -273,6 +286,51 @@ int vqhip_kmeans_patch_from_global_row(vqhip_kmeans *km, vqhip_comm *comm, uint3
  * rows among global_rows [m][k], zero words for rows of other ranks; ONE gather launch + ONE copy */
 int vqhip_kmeans_gather_owned_rows(vqhip_kmeans *km, const uint64_t *global_rows, uint64_t row_offset,
                                    uint32_t *bits_out);
+
+/* ---- one call, one process, several GPUs ------------------------------------------------------
+ * `ProductQuantizer::new` is ONE call in ONE process (src/pq.rs:83-141).  These handles put the ranks of the
+ * row-sharded fit above INSIDE the library: a worker thread per entry of `devices` (its device current, its own
+ * stream), each holding a contiguous block of the rows (the first n % n_devices blocks one row longer), a vqhip_kmeans
+ * on it and a communicator -- the in-process exchange by default, RCCL with VQHIP_MULTI_COMM=rccl -- and every call
+ * below runs the per-rank entry point of the same name on all workers at once (init_from_rows / patch_from_row take
+ * GLOBAL row ids; run = vqhip_kmeans_run_sharded).  Same results contract as the sharded fit; with one device the
+ * bits of the single-device handles.  `devices` may name a device more than once (in-process exchange only).
+ * The Rust shim's `ProductQuantizer::new` keeps its signature and passes the visible devices. */
+typedef struct vqhip_mdataset vqhip_mdataset;
+typedef struct vqhip_mkmeans vqhip_mkmeans;
+typedef struct vqhip_mpq_encoder vqhip_mpq_encoder;
+int vqhip_mdataset_from_host(const float *rows, uint64_t n, uint32_t d, const int *devices, int n_devices,
+                             vqhip_mdataset **out);
+int vqhip_mdataset_synthetic(uint64_t n, uint32_t d, uint64_t seed, const int *devices, int n_devices,
+                             vqhip_mdataset **out);
+/* rows_per_device [n_devices] out (optional) */
+int vqhip_mdataset_info(const vqhip_mdataset *ds, uint64_t *n, uint32_t *d, int *n_devices, uint64_t *rows_per_device);
+int vqhip_mdataset_destroy(vqhip_mdataset *ds);
+/* the data set must outlive the k-means handle */
+int vqhip_mkmeans_create(vqhip_mdataset *ds, uint32_t m, uint32_t k, vqhip_mkmeans **out);
+int vqhip_mkmeans_destroy(vqhip_mkmeans *km);
+/* world = n_devices; comm_kind as vqhip_comm_kind */
+int vqhip_mkmeans_info(vqhip_mkmeans *km, int *world, int *comm_kind);
+int vqhip_mkmeans_set_engine(vqhip_mkmeans *km, int engine);
+int vqhip_mkmeans_init_from_rows(vqhip_mkmeans *km, const uint64_t *init_rows);
+int vqhip_mkmeans_set_centroids(vqhip_mkmeans *km, const float *centroids);
+int vqhip_mkmeans_get_centroids(vqhip_mkmeans *km, float *centroids);
+int vqhip_mkmeans_set_active(vqhip_mkmeans *km, const uint8_t *active);
+int vqhip_mkmeans_get_active(vqhip_mkmeans *km, uint8_t *active);
+int vqhip_mkmeans_run(vqhip_mkmeans *km, uint32_t max_iters, uint32_t *iters_done, uint32_t *counts, uint8_t *changed,
+                      int *paused);
+int vqhip_mkmeans_patch_from_row(vqhip_mkmeans *km, uint32_t s, uint32_t j, uint64_t row);
+/* vqhip_pq_encode with the host rows split in row blocks over the devices (no collective) */
+int vqhip_mpq_encoder_create(const float *codebooks, uint32_t m, uint32_t k, uint32_t sub_dim, int metric,
+                             const int *devices, int n_devices, vqhip_mpq_encoder **out);
+int vqhip_mpq_encoder_set_engine(vqhip_mpq_encoder *enc, int engine);
+int vqhip_mpq_encode(vqhip_mpq_encoder *enc, const float *rows, uint64_t n, uint8_t *codes, uint16_t *f16_out);
+/* the RESIDENT rows of a sharded data set (same device list) through the encoder, `repeat` passes per device; codes_host
+ * [n][m] (optional) receives the last pass's codes */
+int vqhip_mpq_encode_dataset(vqhip_mpq_encoder *enc, vqhip_mdataset *ds, uint32_t repeat, uint8_t *codes_host);
+int vqhip_mpq_encoder_destroy(vqhip_mpq_encoder *enc);
+/* the contiguous row block of `rank` among `world` ranks: the first n % world blocks are one row longer */
+int vqhip_shard_rows(uint64_t n, int world, int rank, uint64_t *offset, uint64_t *count);
 
 /* empty-cluster reseed (vector.rs:448-452): the caller draws the row */
 int vqhip_kmeans_patch_centroid(vqhip_kmeans *km, uint32_t s, uint32_t j, const float *sub_row);

@@ -123,3 +123,19 @@ def test_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "vq_oracle" not in text and "import oracle" not in text, f
+
+
+def test_shard_rows_matches_the_python_drivers():
+    """the row blocks of the one-process multi-GPU handles (vqhip_shard_rows) are those of vq_amd/sharded.py"""
+    from vq_amd import _lib
+    from vq_amd.sharded import shard_rows
+
+    for n in (1, 7, 8, 1000, 1_000_003, 100_000_000):
+        for world in (1, 2, 3, 4, 8, 16):
+            covered = 0
+            for rank in range(world):
+                got = _lib.shard_rows(n, world, rank)
+                assert got == tuple(shard_rows(n, world, rank)), (n, world, rank)
+                assert got[0] == covered
+                covered += got[1]
+            assert covered == n

@@ -105,6 +105,31 @@ SIGNATURES = {
     "vqhip_mfma_bf16_model_failures": (C.c_int, [C.c_uint64, C.c_uint64, _u64p, C.c_uint32, _u64p]),
     "vqhip_mfma_bf16_model_case": (C.c_int, [C.c_uint64, C.c_uint64, _u16p, _u16p, _f32p]),
     "vqhip_tsvq_last_stats": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "vqhip_comm_group_create": (C.c_int, [C.c_int, _vpp]),
+    "vqhip_comm_create_local": (C.c_int, [_vp, C.c_int, _vpp]),
+    "vqhip_comm_group_destroy": (C.c_int, [_vp]),
+    "vqhip_comm_kind": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "vqhip_mdataset_from_host": (C.c_int, [_f32p, C.c_uint64, C.c_uint32, _i32p, C.c_int, _vpp]),
+    "vqhip_mdataset_synthetic": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint64, _i32p, C.c_int, _vpp]),
+    "vqhip_mdataset_info": (C.c_int, [_vp, _u64p, _u32p, C.POINTER(C.c_int), _u64p]),
+    "vqhip_mdataset_destroy": (C.c_int, [_vp]),
+    "vqhip_mkmeans_create": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vpp]),
+    "vqhip_mkmeans_destroy": (C.c_int, [_vp]),
+    "vqhip_mkmeans_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vqhip_mkmeans_set_engine": (C.c_int, [_vp, C.c_int]),
+    "vqhip_mkmeans_init_from_rows": (C.c_int, [_vp, _u64p]),
+    "vqhip_mkmeans_set_centroids": (C.c_int, [_vp, _f32p]),
+    "vqhip_mkmeans_get_centroids": (C.c_int, [_vp, _f32p]),
+    "vqhip_mkmeans_set_active": (C.c_int, [_vp, _u8p]),
+    "vqhip_mkmeans_get_active": (C.c_int, [_vp, _u8p]),
+    "vqhip_mkmeans_run": (C.c_int, [_vp, C.c_uint32, _u32p, _u32p, _u8p, C.POINTER(C.c_int)]),
+    "vqhip_mkmeans_patch_from_row": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "vqhip_mpq_encoder_create": (C.c_int, [_f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _i32p, C.c_int, _vpp]),
+    "vqhip_mpq_encoder_set_engine": (C.c_int, [_vp, C.c_int]),
+    "vqhip_mpq_encode": (C.c_int, [_vp, _f32p, C.c_uint64, _u8p, _u16p]),
+    "vqhip_mpq_encoder_destroy": (C.c_int, [_vp]),
+    "vqhip_mpq_encode_dataset": (C.c_int, [_vp, _vp, C.c_uint32, _u8p]),
+    "vqhip_shard_rows": (C.c_int, [C.c_uint64, C.c_int, C.c_int, _u64p, _u64p]),
 }
 
 _lib = None
@@ -380,6 +405,151 @@ class NativeComm(Handle):
         w, r = C.c_int(0), C.c_int(0)
         check(load().vqhip_comm_info(self.raw, C.byref(w), C.byref(r)))
         return int(w.value), int(r.value)
+
+
+def _devices(devices) -> np.ndarray:
+    """device slots of a one-process multi-GPU handle: None -> every visible device; an int -> that many, 0..n-1"""
+    if devices is None:
+        devices = range(max(1, device_count()))
+    elif isinstance(devices, (int, np.integer)):
+        devices = range(int(devices))
+    dv = np.ascontiguousarray(list(devices), dtype=np.int32)
+    if dv.size == 0:
+        raise FfiError("devices is empty", ERR_INVALID_INPUT)
+    return dv
+
+
+class MDataset(Handle):
+    """vqhip_mdataset: the rows in contiguous blocks over several devices of THIS process (a worker thread per device
+    slot inside the library); `devices` may name a device more than once"""
+    _destroy = "vqhip_mdataset_destroy"
+
+    def __init__(self, raw, n: int, d: int, devices: np.ndarray):
+        super().__init__(raw)
+        self.n, self.d, self.devices = int(n), int(d), devices
+
+    @classmethod
+    def from_host(cls, rows: np.ndarray, devices=None) -> "MDataset":
+        rows = f32c(rows)
+        assert rows.ndim == 2
+        dv = _devices(devices)
+        raw = C.c_void_p()
+        check(load().vqhip_mdataset_from_host(ptr(rows, _f32p), rows.shape[0], rows.shape[1], ptr(dv, _i32p), dv.size, C.byref(raw)))
+        return cls(raw, rows.shape[0], rows.shape[1], dv)
+
+    @classmethod
+    def synthetic(cls, n: int, d: int, seed: int, devices=None) -> "MDataset":
+        dv = _devices(devices)
+        raw = C.c_void_p()
+        check(load().vqhip_mdataset_synthetic(n, d, seed, ptr(dv, _i32p), dv.size, C.byref(raw)))
+        return cls(raw, n, d, dv)
+
+    def rows_per_device(self) -> np.ndarray:
+        out = np.zeros(self.devices.size, np.uint64)
+        check(load().vqhip_mdataset_info(self.raw, None, None, None, ptr(out, _u64p)))
+        return out
+
+
+class MKMeans(Handle):
+    """vqhip_mkmeans: the sharded fit with its ranks inside the library -- KMeans's methods (what pq.fit_codebooks uses),
+    row ids GLOBAL"""
+    _destroy = "vqhip_mkmeans_destroy"
+
+    def __init__(self, ds: MDataset, m: int, k: int):
+        raw = C.c_void_p()
+        check(load().vqhip_mkmeans_create(ds.raw, m, k, C.byref(raw)))
+        super().__init__(raw)
+        self.ds, self.m, self.k, self.sd = ds, m, k, ds.d // m
+
+    def info(self) -> tuple[int, int]:
+        """(ranks, communicator kind: 0 identity, 1 RCCL, 2 in-process exchange)"""
+        w, kd = C.c_int(0), C.c_int(0)
+        check(load().vqhip_mkmeans_info(self.raw, C.byref(w), C.byref(kd)))
+        return int(w.value), int(kd.value)
+
+    def set_engine(self, engine: int):
+        check(load().vqhip_mkmeans_set_engine(self.raw, engine))
+
+    def set_exact_update(self, on: bool):
+        if on and self.ds.devices.size > 1:
+            raise FfiError("exact_update sums rows in one sequential chain: single GPU only", ERR_UNSUPPORTED)
+
+    def set_centroids(self, c):
+        c = f32c(c).reshape(self.m, self.k, self.sd)
+        check(load().vqhip_mkmeans_set_centroids(self.raw, ptr(c, _f32p)))
+
+    def init_from_rows(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64).reshape(self.m, self.k)
+        check(load().vqhip_mkmeans_init_from_rows(self.raw, ptr(rows, _u64p)))
+
+    def get_centroids(self) -> np.ndarray:
+        out = np.empty((self.m, self.k, self.sd), np.float32)
+        check(load().vqhip_mkmeans_get_centroids(self.raw, ptr(out, _f32p)))
+        return out
+
+    def set_active(self, active):
+        a = np.ascontiguousarray(active, dtype=np.uint8).reshape(self.m)
+        check(load().vqhip_mkmeans_set_active(self.raw, ptr(a, _u8p)))
+
+    def get_active(self) -> np.ndarray:
+        a = np.zeros(self.m, np.uint8)
+        check(load().vqhip_mkmeans_get_active(self.raw, ptr(a, _u8p)))
+        return a.astype(bool)
+
+    def run(self, max_iters: int):
+        iters = np.zeros(self.m, np.uint32)
+        counts = np.zeros((self.m, self.k), np.uint32)
+        changed = np.zeros(self.m, np.uint8)
+        paused = C.c_int(0)
+        check(load().vqhip_mkmeans_run(self.raw, int(max_iters), ptr(iters, _u32p), ptr(counts, _u32p), ptr(changed, _u8p), C.byref(paused)))
+        return iters, counts, changed.astype(bool), bool(paused.value)
+
+    def patch_from_row(self, s: int, j: int, row: int):
+        check(load().vqhip_mkmeans_patch_from_row(self.raw, s, j, row))
+
+
+class MPQEncoder(Handle):
+    """vqhip_mpq_encoder: PQEncoder.encode with the host rows split in row blocks over several devices of this process"""
+    _destroy = "vqhip_mpq_encoder_destroy"
+
+    def __init__(self, codebooks, metric: int, devices=None):
+        cb = f32c(codebooks)
+        assert cb.ndim == 3
+        self.m, self.k, self.sd = cb.shape
+        self.devices = _devices(devices)
+        raw = C.c_void_p()
+        check(load().vqhip_mpq_encoder_create(ptr(cb, _f32p), self.m, self.k, self.sd, metric, ptr(self.devices, _i32p),
+                                              self.devices.size, C.byref(raw)))
+        super().__init__(raw)
+
+    def set_engine(self, engine: int):
+        check(load().vqhip_mpq_encoder_set_engine(self.raw, engine))
+
+    def encode(self, rows, want_codes=True, want_f16=True, out_codes=None, out_f16=None):
+        rows = f32c(rows).reshape(-1, self.m * self.sd)
+        n = rows.shape[0]
+        codes = f16 = None
+        if want_codes or out_codes is not None:
+            codes = out_codes if out_codes is not None else _arena.fresh((n, self.m), code_dtype(self.k))
+        if want_f16 or out_f16 is not None:
+            f16 = out_f16 if out_f16 is not None else _arena.fresh((n, self.m * self.sd), np.float16)
+        check(load().vqhip_mpq_encode(self.raw, ptr(rows, _f32p), n, ptr(codes, _u8p),
+                                      None if f16 is None else f16.ctypes.data_as(_u16p)))
+        return codes, (None if f16 is None else f16.view(np.float16))
+
+
+    def encode_dataset(self, ds: MDataset, repeat: int = 1, want_codes: bool = False):
+        """`repeat` passes over the RESIDENT rows of a sharded data set on their devices; the last pass's codes if asked"""
+        codes = np.empty((ds.n, self.m), code_dtype(self.k)) if want_codes else None
+        check(load().vqhip_mpq_encode_dataset(self.raw, ds.raw, int(repeat), ptr(codes, _u8p)))
+        return codes
+
+
+def shard_rows(n: int, world: int, rank: int) -> tuple[int, int]:
+    """(offset, count) of `rank`'s row block as the library's one-process handles cut it"""
+    off, cnt = C.c_uint64(0), C.c_uint64(0)
+    check(load().vqhip_shard_rows(n, world, rank, C.byref(off), C.byref(cnt)))
+    return int(off.value), int(cnt.value)
 
 
 class PQEncoder(Handle):

@@ -1880,6 +1880,48 @@ int vqhip_comm_destroy(vqhip_comm *comm) {
     return VQHIP_OK;
 }
 
+struct vqhip_comm_group {
+    LocalGroup *g = nullptr;
+};
+
+int vqhip_comm_group_create(int world, vqhip_comm_group **out) {
+    VQ_API_BEGIN
+    if (!out) return fail(VQHIP_ERR_NULL_PTR, "out is NULL");
+    *out = nullptr;
+    std::unique_ptr<vqhip_comm_group> h(new vqhip_comm_group());
+    VQ_TRY(local_group_create(world, &h->g));
+    *out = h.release();
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_comm_create_local(vqhip_comm_group *group, int rank, vqhip_comm **out) {
+    VQ_API_BEGIN
+    if (!out) return fail(VQHIP_ERR_NULL_PTR, "out is NULL");
+    *out = nullptr;
+    if (!group) return fail(VQHIP_ERR_NULL_PTR, "group is NULL");
+    VQ_TRY(require_gfx950());
+    std::unique_ptr<vqhip_comm> h(new vqhip_comm());
+    VQ_TRY(comm_create_local(group->g, rank, &h->c));
+    *out = h.release();
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_comm_group_destroy(vqhip_comm_group *group) {
+    if (group) {
+        local_group_destroy(group->g);
+        delete group;
+    }
+    return VQHIP_OK;
+}
+
+int vqhip_comm_kind(const vqhip_comm *comm, int *kind) {
+    if (!kind) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    *kind = comm_kind(comm ? comm->c : nullptr);
+    return VQHIP_OK;
+}
+
 int vqhip_kmeans_allreduce(vqhip_kmeans *km, vqhip_comm *comm) {
     VQ_API_BEGIN
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");

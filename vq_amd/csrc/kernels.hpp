@@ -185,6 +185,12 @@ void comm_info(const Comm *c, int *world, int *rank);
 int comm_destroy(Comm *c);
 int comm_allreduce_f64(Comm *c, double *buf, size_t count, hipStream_t stream);
 int comm_allreduce_u32(Comm *c, uint32_t *buf, size_t count, hipStream_t stream);
+// the ranks of one process (a host thread per GPU): a direct fixed-order exchange through peer access (comm.hip)
+struct LocalGroup;
+int local_group_create(int world, LocalGroup **out);
+void local_group_destroy(LocalGroup *g);
+int comm_create_local(LocalGroup *g, int rank, Comm **out);  // collective over the group's ranks, each on its own thread
+int comm_kind(const Comm *c);                                // 0 identity, 1 RCCL, 2 in-process exchange
 
 // ---- TSVQ -----------------------------------------------------------------------------
 // build on a device-resident matrix; outputs are HOST arrays in pre-order (see vqhip.h)

@@ -42,7 +42,7 @@ def _as_training_matrix(training_data) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(rows, dtype=np.float32).reshape(len(rows), dim))
 
 
-def fit_codebooks(ds: "_lib.Dataset", m: int, k: int, max_iters: int, seed: int = 42, *,
+def fit_codebooks(ds: "_lib.Dataset | _lib.MDataset", m: int, k: int, max_iters: int, seed: int = 42, *,
                   init_rows=None, reseed_rows=None, engine: int = _lib.ENGINE_AUTO,
                   exact_update: bool = False, stats: dict | None = None) -> np.ndarray:
     """Lloyd / LBG for all m subspaces of a resident dataset: the control flow of
@@ -72,7 +72,9 @@ def fit_codebooks(ds: "_lib.Dataset", m: int, k: int, max_iters: int, seed: int 
         init = np.ascontiguousarray(init_rows, dtype=np.uint64).reshape(m, k)
     reseed_iters = None if reseed_rows is None else [iter(list(r)) for r in reseed_rows]
 
-    km = _lib.KMeans(ds, m, k)
+    # rows resident on one device, or in blocks over several devices of this process (the ranks of the sharded fit run as
+    # worker threads inside the library: same methods, row ids global)
+    km = _lib.MKMeans(ds, m, k) if isinstance(ds, _lib.MDataset) else _lib.KMeans(ds, m, k)
     try:
         km.set_engine(engine)
         km.set_exact_update(exact_update)
@@ -126,7 +128,11 @@ class ProductQuantizer:
 
     def __init__(self, training_data, num_subspaces: int, num_centroids: int, max_iters: int = 10,
                  distance: Distance | None = None, seed: int = 42, *, init_rows=None,
-                 reseed_rows=None, engine: int = _lib.ENGINE_AUTO, exact_update: bool = False):
+                 reseed_rows=None, engine: int = _lib.ENGINE_AUTO, exact_update: bool = False, devices=None):
+        """devices (not in pyvq): the GPUs the training batch is partitioned over -- None: every visible device; an int n:
+        devices 0..n-1; a sequence of device ids.  One call, one process: with more than one device the rows are
+        sharded over worker threads inside the library and each Lloyd iteration all-reduces the per-cluster sums
+        (include/vqhip.h, "one call, one process, several GPUs"); batch encodes split their rows the same way."""
         X = _as_training_matrix(training_data)
         n, dim = X.shape
         m, k = int(num_subspaces), int(num_centroids)
@@ -143,15 +149,26 @@ class ProductQuantizer:
         self._distance = distance if distance is not None else Distance.euclidean()
         self._m, self._k, self._dim, self._sub_dim = m, k, dim, dim // m
         self.fit_stats: dict = {}
-        ds = _lib.Dataset.from_host(X)
+        dv = _lib._devices(devices)
+        if devices is None:  # every visible device, as far as the batch gives each of them work (4M elements)
+            dv = dv[:max(1, min(dv.size, (n * dim) >> 22))]
+        if dv.size > n:
+            dv = dv[:n]  # (every device needs a row)
+        multi = dv.size > 1
+        ds = _lib.MDataset.from_host(X, dv) if multi else _lib.Dataset.from_host(X)
         try:
             self._codebooks = fit_codebooks(ds, m, k, int(max_iters), int(seed), init_rows=init_rows,
                                             reseed_rows=reseed_rows, engine=engine,
                                             exact_update=exact_update, stats=self.fit_stats)
         finally:
             ds.close()
+        self.fit_stats["devices"] = [int(x) for x in dv]
         self._enc = _lib.PQEncoder(self._codebooks, self._distance.metric)
         self._enc.set_engine(engine)
+        self._menc = None
+        if multi:  # batch encodes: row blocks over the same devices
+            self._menc = _lib.MPQEncoder(self._codebooks, self._distance.metric, dv)
+            self._menc.set_engine(engine)
 
     @classmethod
     def from_codebooks(cls, codebooks, distance: Distance | None = None,
@@ -168,7 +185,12 @@ class ProductQuantizer:
         self.fit_stats = {}
         self._enc = _lib.PQEncoder(cb, self._distance.metric)
         self._enc.set_engine(engine)
+        self._menc = None
         return self
+
+    def _batch_encoder(self, n: int):
+        # (small batches are not worth the workers' hand-over)
+        return self._menc if (self._menc is not None and n >= 65536) else self._enc
 
     # -- reference surface ----------------------------------------------------------------
     def quantize(self, vector) -> np.ndarray:
@@ -228,7 +250,7 @@ class ProductQuantizer:
         X = self._check_batch(X)
         if X.shape[0] == 0:
             return np.empty((0, self._dim), np.float16) if out is None else out
-        return self._enc.encode(X, want_codes=False, want_f16=True, out_f16=out)[1]
+        return self._batch_encoder(X.shape[0]).encode(X, want_codes=False, want_f16=True, out_f16=out)[1]
 
     def encode(self, X) -> np.ndarray:
         """(n, dim) float32 -> (n, m) codes: ``best_idx`` per subspace (src/pq.rs:183-191); uint8 while
@@ -236,7 +258,7 @@ class ProductQuantizer:
         X = self._check_batch(X)
         if X.shape[0] == 0:
             return np.empty((0, self._m), _lib.code_dtype(self._k))
-        return self._enc.encode(X, want_codes=True, want_f16=False)[0]
+        return self._batch_encoder(X.shape[0]).encode(X, want_codes=True, want_f16=False)[0]
 
     def search(self, codes, queries, topk: int = 10):
         """Asymmetric-distance search: the `topk` rows of `codes` (n, m) (uint8, uint16 above 256 centroids)
