@@ -210,9 +210,10 @@ def eval_shape(_lib, engine):
 
     n, dim, m, k, iters, seed = 1_000_000, 384, 16, 256, 10, 66
     X = _lib.synth_uniform_host(n, dim, seed, 0)
-    ProductQuantizer(X[:20000], m, k, 2, Distance.euclidean(), seed, engine=engine)  # code objects, pinned pools
+    # (devices=[0]: this block is the single-GPU figure; the constructor's default is every visible device)
+    ProductQuantizer(X[:20000], m, k, 2, Distance.euclidean(), seed, engine=engine, devices=[0])  # code objects, pinned pools
     t0 = time.perf_counter()
-    pq = ProductQuantizer(X, m, k, iters, Distance.euclidean(), seed, engine=engine)
+    pq = ProductQuantizer(X, m, k, iters, Distance.euclidean(), seed, engine=engine, devices=[0])
     train_ms = (time.perf_counter() - t0) * 1e3
     pq.quantize_batch(X[:50000])
     # the default call returns a fresh array (pyvq/src/pq.rs:96-107).  The process's FIRST result of this size has no pages
@@ -574,16 +575,121 @@ def parse_args(argv=None):
                     help="multi-GPU all-reduce: below the C ABI (vqhip_kmeans_run_sharded, RCCL), through torch.distributed "
                          "nccl (= RCCL), or through gloo with the slab staged on the host (ranks may then share a GPU: tests)")
     ap.add_argument("--engine", choices=["auto", "exact", "mfma", "bf16"], default="auto")
+    ap.add_argument("--one-process", action="store_true",
+                    help="second launcher mode: ONE process drives the --gpus devices through the library's worker threads "
+                         "(vqhip_mdataset / vqhip_mkmeans / vqhip_mpq_encoder: what ProductQuantizer(..., devices=) uses)")
+    ap.add_argument("--device-list", default="", help="--one-process: comma-separated device ids (default 0..gpus-1; a device may repeat)")
     return ap.parse_args(argv)
 
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
+    if args.one_process:
+        sys.exit(one_process(args))
     if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and (args.gpus > 1 or os.environ.get("VQ_BENCH_SPAWN") == "1"):
         # no launcher around us: be the launcher (before torch / libvqhip are imported: this process stays off the GPU)
         sys.exit(launch_ranks(args.gpus, argv))
     sys.exit(worker(args))
+
+
+def one_process(args) -> int:
+    """`python bench.py --gpus N --one-process`: the same job -- rows sharded over N devices, TRAIN_ITERS + timed Lloyd
+    iterations with one slab all-reduce each, K timed encode passes over the resident rows -- driven by ONE process through
+    the library's own ranks (worker threads; the in-process fixed-order exchange, or RCCL with VQHIP_MULTI_COMM=rccl).
+    Same line shape as the multi-process launcher; `launcher` says which one ran."""
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    import numpy as np
+
+    from vq_amd import _lib
+
+    _lib.load()
+    devices = [int(x) for x in args.device_list.split(",")] if args.device_list else list(range(args.gpus))
+    if len(devices) != args.gpus:
+        print(f"bench.py: --device-list names {len(devices)} devices, --gpus {args.gpus}", file=sys.stderr)
+        return 2
+    if _lib.device_count() < 1:
+        print("bench.py needs a MI355X (no GPU visible); there is no CPU fallback", file=sys.stderr)
+        return 2
+    _lib.set_device(devices[0])
+    engine = {"auto": _lib.ENGINE_AUTO, "exact": _lib.ENGINE_EXACT, "mfma": _lib.ENGINE_MFMA, "bf16": _lib.ENGINE_MFMA_BF16}[args.engine]
+    wl = WORKLOADS[args.config]
+    dim, m_, k_ = wl["dim"], wl["m"], wl["k"]
+    rows = args.rows if args.rows else wl["rows"]
+    world = len(devices)
+    n_global = rows * world if args.scaling == "weak" else rows
+    mds = _lib.MDataset.synthetic(n_global, dim, DATA_SEED, devices)
+    init = strided_init(n_global, m_, k_).astype(np.uint64)
+    km = _lib.MKMeans(mds, m_, k_)
+    km.set_engine(engine)
+    km.init_from_rows(init)
+    km.run(TRAIN_ITERS)
+    codebooks = km.get_centroids()
+    for _ in range(25 if n_global * dim <= 4e8 * world else 6):  # untimed: clocks up (see measure())
+        km.run(10)
+
+    def restart():
+        km.init_from_rows(init)
+        km.set_active(np.ones(m_, np.uint8))
+
+    restart()
+    km.run(args.kmeans_iters)
+    restart()
+    t0 = time.perf_counter()
+    it, counts, _, paused = km.run(args.kmeans_iters)  # (returns with every rank's stream drained)
+    km_dt = time.perf_counter() - t0
+    it = np.asarray(it, np.int64)
+    km_iters = max(1, int(it.max()))
+    active_avg = float(it.sum()) / km_iters
+    km_ms = km_dt / km_iters * 1e3
+    comm_world, comm_kind = km.info()
+    km.close()
+    flop_row = 2.0 * k_ * dim
+    enc = _lib.MPQEncoder(codebooks, _lib.SQUARED_EUCLIDEAN, devices)
+    enc.set_engine(engine)
+    enc.encode_dataset(mds, repeat=PREWARM_STEPS + args.warmup)
+    t0 = time.perf_counter()
+    codes = enc.encode_dataset(mds, repeat=args.steps, want_codes=False)
+    dt = time.perf_counter() - t0
+    checksum = int(enc.encode_dataset(mds, repeat=1, want_codes=True)[: mds.rows_per_device()[0]].astype(np.int64).sum())
+    rechecked, used_engine = 0, 3
+    step_ms = dt / args.steps * 1e3
+    rows_rank0 = int(mds.rows_per_device()[0])
+    line = {
+        "metric": "pq_encode_vectors_per_s", "value": n_global * args.steps / dt, "unit": "vectors/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM_STEPS, "ms_per_step": step_ms,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32 (bf16x3-split MFMA screen, exact f32 re-check)", "data": "synthetic",
+        "launcher": "one process: the library's worker thread per device (vqhip_mdataset / vqhip_mkmeans / vqhip_mpq_encoder)",
+        "devices": devices,
+        "config": {
+            "workload": f"PQ m={m_} k={k_} L2 encode on {n_global}x{dim} f32 rows in all, {rows_rank0} on the first device, device-resident "
+                        f"({wl['label']}; {args.scaling} scaling); codes out (1 byte per subspace)",
+            "rows_per_gpu": rows_rank0, "rows_global": n_global, "dim": dim, "m": m_, "k": k_, "sub_dim": dim // m_,
+            "codebooks": f"{TRAIN_ITERS} Lloyd iterations from strided init rows",
+            "kmeans_iter_per_s": km_iters / km_dt, "kmeans_ms_per_iter": km_ms,
+            "kmeans_valid": bool(not paused and int(it.min()) == int(it.max()) == args.kmeans_iters),
+            "kmeans_roofline_frac": mfma_roofline(flop_row * rows_rank0 * active_avg / m_, km_ms, engine=3)["frac"],
+            "prewarm_steps": PREWARM_STEPS,
+        },
+        "roofline": mfma_roofline(flop_row * rows_rank0, step_ms, engine=3, extra={
+            "note": "whole step wall time (the passes of all devices run side by side; per-device work = rows_per_gpu)",
+            "flop_per_launch": flop_row * rows_rank0, "algorithmic_bytes_per_launch": (4.0 * dim + m_) * rows_rank0, "traffic": None}),
+        "kmeans_rows_global": n_global, "kmeans_iter_per_s": km_iters / km_dt, "kmeans_ms_per_iter": km_ms,
+        "kmeans_collective": {0: "none (one rank)", 1: "rccl below the C ABI, ranks = threads of this process",
+                              2: "in-process fixed-order exchange through peer access (vqhip_comm_create_local)"}[comm_kind],
+        "comm_world": comm_world,
+        "kmeans_counts_sum_per_subspace": [int(counts[0].sum()), int(counts[-1].sum())],
+        "codebooks_abs_sum": float(np.abs(codebooks.astype(np.float64)).sum()),
+        "codes_checksum_rank0": checksum,
+    }
+    del codes
+    enc.close()
+    mds.close()
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
+    return 0
 
 
 class Ranks:

@@ -250,6 +250,67 @@ inline std::vector<float> fit_codebooks(vqhip_dataset *ds, std::uint64_t n, std:
     return cb;
 }
 
+struct MDatasetDel {
+    void operator()(vqhip_mdataset *p) const { (void)vqhip_mdataset_destroy(p); }
+};
+struct MKMeansDel {
+    void operator()(vqhip_mkmeans *p) const { (void)vqhip_mkmeans_destroy(p); }
+};
+struct MEncoderDel {
+    void operator()(vqhip_mpq_encoder *p) const { (void)vqhip_mpq_encoder_destroy(p); }
+};
+
+// the same control flow with the training batch partitioned over several GPUs of THIS process (include/vqhip.h "one
+// call, one process, several GPUs": the ranks of the row-sharded fit are worker threads inside the library; each Lloyd
+// iteration all-reduces the per-cluster sums).  The loop's decisions are taken on the device (vqhip_mkmeans_run): it
+// comes back when the iterations are used up, when every subspace has converged, or paused behind an iteration that
+// left a cluster empty -- the reseed row is this side's draw (vector.rs:448-452), named by its global row id.
+inline std::vector<float> fit_codebooks_multi(vqhip_mdataset *ds, std::uint64_t n, std::uint32_t dim, std::uint32_t m,
+                                              std::uint32_t k, std::size_t max_iters, std::uint64_t seed,
+                                              const std::uint64_t *init_rows = nullptr) {
+    std::vector<HostRng> rngs;
+    for (std::uint32_t s = 0; s < m; ++s) rngs.emplace_back(seed + s);
+    std::vector<std::uint64_t> init((std::size_t)m * k);
+    if (init_rows) {
+        std::memcpy(init.data(), init_rows, init.size() * 8);
+    } else {
+        for (std::uint32_t s = 0; s < m; ++s) {
+            const auto rows = rngs[s].choose_multiple(n, k);
+            std::memcpy(init.data() + (std::size_t)s * k, rows.data(), (std::size_t)k * 8);
+        }
+    }
+    vqhip_mkmeans *raw = nullptr;
+    check(vqhip_mkmeans_create(ds, m, k, &raw));
+    std::unique_ptr<vqhip_mkmeans, MKMeansDel> km(raw);
+    check(vqhip_mkmeans_init_from_rows(km.get(), init.data()));
+    std::vector<std::uint8_t> active(m, 1), changed(m, 0);
+    std::vector<std::uint32_t> counts((std::size_t)m * k), iters(m);
+    std::size_t done = 0;
+    for (;;) {
+        bool any = false;
+        for (auto a : active) any = any || a;
+        if (!any || done >= max_iters) break;
+        int paused = 0;
+        check(vqhip_mkmeans_run(km.get(), (std::uint32_t)(max_iters - done), iters.data(), counts.data(), changed.data(), &paused));
+        std::uint32_t most = 1;
+        for (auto x : iters) most = x > most ? x : most;
+        done += most;
+        check(vqhip_mkmeans_get_active(km.get(), active.data()));  // subspaces that converged inside the call are retired
+        if (!paused) continue;
+        for (std::uint32_t s = 0; s < m; ++s) {
+            if (!active[s]) continue;
+            for (std::uint32_t j = 0; j < k; ++j)  // empty clusters in ascending j, vector.rs:448-452
+                if (counts[(std::size_t)s * k + j] == 0)
+                    check(vqhip_mkmeans_patch_from_row(km.get(), s, j, rngs[s].choose(n)));
+            if (!changed[s]) active[s] = 0;  // vector.rs:455-457
+        }
+        check(vqhip_mkmeans_set_active(km.get(), active.data()));
+    }
+    std::vector<float> cb((std::size_t)m * k * (dim / m));
+    check(vqhip_mkmeans_get_centroids(km.get(), cb.data()));
+    return cb;
+}
+
 }  // namespace detail
 
 // ------------------------------------------------------------------ ProductQuantizer ----
@@ -267,6 +328,19 @@ class ProductQuantizer {
                      std::size_t max_iters, Distance distance, std::uint64_t seed) {
         if (n == 0) throw VqError::EmptyInput();
         init(rows, n, dim, m, k, max_iters, distance, seed);
+    }
+    // same call, the training batch partitioned over `devices` (ids of visible GPUs; all_devices() names them all):
+    // still ONE call in ONE process -- the ranks are worker threads inside libvqhip (not in the reference: src/pq.rs:83-141
+    // has no device argument; the Rust shim passes the visible devices itself)
+    ProductQuantizer(const float *rows, std::size_t n, std::size_t dim, std::size_t m, std::size_t k,
+                     std::size_t max_iters, Distance distance, std::uint64_t seed, const std::vector<int> &devices) {
+        if (n == 0) throw VqError::EmptyInput();
+        init(rows, n, dim, m, k, max_iters, distance, seed, devices);
+    }
+    static std::vector<int> all_devices() {
+        std::vector<int> v;
+        for (int i = 0; i < vqhip_device_count(); ++i) v.push_back(i);
+        return v;
     }
 
     std::size_t num_subspaces() const { return m_; }
@@ -295,13 +369,13 @@ class ProductQuantizer {
     // batch forms (ROADMAP.md:30 "batch quantization" is open upstream): rows [n][dim]
     std::vector<f16> quantize_batch(const float *rows, std::size_t n) const {
         std::vector<f16> out(n * dim_);
-        if (n) detail::check(vqhip_pq_encode(enc_.get(), rows, n, nullptr, reinterpret_cast<std::uint16_t *>(out.data())));
+        if (n) detail::check(encode_raw(rows, n, nullptr, reinterpret_cast<std::uint16_t *>(out.data())));
         return out;
     }
     std::vector<std::uint8_t> encode(const float *rows, std::size_t n) const {  // best_idx per subspace, k <= 256
         if (k_ > 256) throw VqError::InvalidParameter("k", "one-byte codes need k <= 256: use encode_wide");
         std::vector<std::uint8_t> codes(n * m_);
-        if (n) detail::check(vqhip_pq_encode(enc_.get(), rows, n, codes.data(), nullptr));
+        if (n) detail::check(encode_raw(rows, n, codes.data(), nullptr));
         return codes;
     }
     // any k: the library's one- or two-byte codes (vqhip.h "code width") widened to 32 bits
@@ -321,8 +395,13 @@ class ProductQuantizer {
     }
 
    private:
+    // large batches of a quantizer trained over several devices: row blocks over the same devices
+    int encode_raw(const float *rows, std::size_t n, std::uint8_t *codes, std::uint16_t *f16_out) const {
+        if (menc_ && n >= 65536) return vqhip_mpq_encode(menc_.get(), rows, n, codes, f16_out);
+        return vqhip_pq_encode(enc_.get(), rows, n, codes, f16_out);
+    }
     void init(const float *rows, std::size_t n, std::size_t dim, std::size_t m, std::size_t k, std::size_t max_iters,
-              Distance distance, std::uint64_t seed) {
+              Distance distance, std::uint64_t seed, const std::vector<int> &devices = {}) {
         if (m == 0) throw VqError::InvalidParameter("m", "must be greater than 0");
         if (dim < m) throw VqError::InvalidParameter("m", "must be at most the data dimension (" + std::to_string(dim) + ")");
         if (dim % m != 0)
@@ -334,11 +413,23 @@ class ProductQuantizer {
         dim_ = dim;
         sub_dim_ = dim / m;
         distance_ = distance;
-        vqhip_dataset *raw = nullptr;
-        detail::check(vqhip_dataset_from_host(rows, n, (std::uint32_t)dim, &raw));
-        std::unique_ptr<vqhip_dataset, detail::DatasetDel> ds(raw);
-        codebooks_ = detail::fit_codebooks(ds.get(), n, (std::uint32_t)dim, (std::uint32_t)m, (std::uint32_t)k,
-                                           max_iters, seed);
+        if (devices.size() > 1) {
+            vqhip_mdataset *raw = nullptr;
+            detail::check(vqhip_mdataset_from_host(rows, n, (std::uint32_t)dim, devices.data(), (int)devices.size(), &raw));
+            std::unique_ptr<vqhip_mdataset, detail::MDatasetDel> ds(raw);
+            codebooks_ = detail::fit_codebooks_multi(ds.get(), n, (std::uint32_t)dim, (std::uint32_t)m, (std::uint32_t)k, max_iters, seed);
+            vqhip_mpq_encoder *me = nullptr;
+            detail::check(vqhip_mpq_encoder_create(codebooks_.data(), (std::uint32_t)m, (std::uint32_t)k, (std::uint32_t)sub_dim_,
+                                                   (int)distance.kind(), devices.data(), (int)devices.size(), &me));
+            menc_.reset(me);
+        } else {
+            if (devices.size() == 1) detail::check(vqhip_set_device(devices[0]));
+            vqhip_dataset *raw = nullptr;
+            detail::check(vqhip_dataset_from_host(rows, n, (std::uint32_t)dim, &raw));
+            std::unique_ptr<vqhip_dataset, detail::DatasetDel> ds(raw);
+            codebooks_ = detail::fit_codebooks(ds.get(), n, (std::uint32_t)dim, (std::uint32_t)m, (std::uint32_t)k,
+                                               max_iters, seed);
+        }
         vqhip_pq_encoder *e = nullptr;
         detail::check(vqhip_pq_encoder_create(codebooks_.data(), (std::uint32_t)m, (std::uint32_t)k,
                                               (std::uint32_t)sub_dim_, (int)distance.kind(), &e));
@@ -348,6 +439,7 @@ class ProductQuantizer {
     Distance distance_;
     std::vector<float> codebooks_;
     std::unique_ptr<vqhip_pq_encoder, detail::EncoderDel> enc_;
+    std::unique_ptr<vqhip_mpq_encoder, detail::MEncoderDel> menc_;
 };
 
 // ------------------------------------------------------------------------------ TSVQ ----

@@ -209,8 +209,36 @@ static int threads(const char *in_path, const char *out_path) {
     return failures ? 1 : 0;
 }
 
+// ProductQuantizer trained over a device list (here: device 0 named twice -- two ranks inside the library): the fit's
+// codebooks and a batch encoded through the row-block path
+static int multi(const char *in_path, const char *out_path) {
+    std::FILE *f = std::fopen(in_path, "rb");
+    if (!f) return 2;
+    std::uint64_t hdr[7];
+    if (std::fread(hdr, 8, 7, f) != 7) return 2;
+    const std::size_t n = hdr[0], dim = hdr[1], m = hdr[2], k = hdr[3], iters = hdr[4];
+    const std::uint64_t seed = hdr[5];
+    std::vector<float> X(n * dim);
+    if (std::fread(X.data(), 4, X.size(), f) != X.size()) return 2;
+    std::fclose(f);
+    vq::ProductQuantizer one(X.data(), n, dim, m, k, iters, vq::Distance::Euclidean, seed, std::vector<int>{0});
+    vq::ProductQuantizer two(X.data(), n, dim, m, k, iters, vq::Distance::Euclidean, seed, std::vector<int>{0, 0});
+    const std::vector<vq::f16> q = two.quantize_batch(X.data(), n);
+    const std::vector<std::uint8_t> c = two.encode(X.data(), n);
+    std::FILE *o = std::fopen(out_path, "wb");
+    if (!o) return 2;
+    std::fwrite(one.codebooks().data(), 4, one.codebooks().size(), o);
+    std::fwrite(two.codebooks().data(), 4, two.codebooks().size(), o);
+    std::fwrite(q.data(), 2, q.size(), o);
+    std::fwrite(c.data(), 1, c.size(), o);
+    std::fclose(o);
+    std::printf("MULTI_OK %s\n", vqhip_backend());
+    return 0;
+}
+
 int main(int argc, char **argv) {
     try {
+        if (argc >= 4 && std::string(argv[1]) == "multi") return multi(argv[2], argv[3]);
         if (argc >= 2 && std::string(argv[1]) == "validate") return validate();
         if (argc >= 4 && std::string(argv[1]) == "run") return run(argv[2], argv[3]);
         if (argc >= 4 && std::string(argv[1]) == "threads") return threads(argv[2], argv[3]);

@@ -107,3 +107,29 @@ def test_cpp_const_quantize_from_eight_std_threads(exe, tmp_path, oracle):
     assert off == len(raw)
     np.testing.assert_array_equal(got_pq, oracle.pq_encode(O.EUCLIDEAN, X, cb)[1])
     np.testing.assert_array_equal(got_tree, oracle.tsvq_encode(O.SQUARED_EUCLIDEAN, X, tree)[1])
+
+
+@pytest.mark.gpu
+def test_cpp_constructor_over_a_device_list(exe, tmp_path, oracle):
+    """vq::ProductQuantizer(rows, ..., devices = {0, 0}): one call, two ranks inside libvqhip (include/vq.hpp); the batch
+    calls take the row-block path.  Same iteration structure as the one-device fit, codes / f16 equal to the oracle's for
+    the quantizer's own codebooks."""
+    import oracle as O
+
+    n, dim, m, k, iters, seed = 140_000, 32, 4, 16, 5, 11
+    X = np.random.default_rng(4).random((n, dim), dtype=F)
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<7Q", n, dim, m, k, iters, seed, 0))
+        f.write(X.tobytes())
+    r = subprocess.run([exe, "multi", str(inp), str(outp)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "MULTI_OK" in r.stdout, r.stdout + r.stderr
+    raw = open(outp, "rb").read()
+    ncb = m * k * (dim // m)
+    one = np.frombuffer(raw, F, ncb, 0).reshape(m, k, dim // m)
+    two = np.frombuffer(raw, F, ncb, ncb * 4).reshape(m, k, dim // m)
+    q = np.frombuffer(raw, np.uint16, n * dim, 2 * ncb * 4).reshape(n, dim)
+    c = np.frombuffer(raw, np.uint8, n * m, 2 * ncb * 4 + n * dim * 2).reshape(n, m)
+    assert np.max(np.abs(one - two)) <= 5e-2  # the same fit up to boundary rows (another grouping of the f64 sums)
+    want_c, want_f = oracle.pq_encode(O.EUCLIDEAN, X, two, threads=0)
+    assert np.array_equal(c.astype(np.uint32), want_c) and np.array_equal(q, want_f)

@@ -67,3 +67,19 @@ def test_two_ranks_strong_and_c5_blocks():
     assert c5["rows_global"] == 25_000_000 and c5["m"] == 16 and c5["kmeans_counts_sum_per_subspace"] == [25_000_000] * 2
     assert c5["kmeans_valid"] and c5["encode_vectors_per_s"] > 1e8
     assert "configs" not in line  # the C1 / C3 / C4 block belongs to the one-GPU line
+
+
+def test_one_process_launcher_two_slots_on_the_gpu():
+    """`bench.py --gpus 2 --one-process`: one process, the library's own ranks (worker threads), here both on device 0; the
+    same global job as one rank -- counts prove the exchange summed both blocks, the codes of the first block's rows and
+    the codebooks agree with the one-rank line"""
+    one = _bench(["--gpus", "1", "--rows", "200001", "--scaling", "strong"] + SMALL)
+    two = _bench(["--gpus", "2", "--one-process", "--device-list", "0,0", "--scaling", "strong", "--rows", "200001"] + SMALL)
+    assert two["n_gpus"] == 2 and two["comm_world"] == 2 and two["devices"] == [0, 0]
+    assert "in-process" in two["kmeans_collective"] and two["launcher"].startswith("one process")
+    assert two["config"]["rows_global"] == 200001 and two["config"]["rows_per_gpu"] == 100001
+    assert two["kmeans_counts_sum_per_subspace"] == [200001, 200001] and two["config"]["kmeans_valid"]
+    assert abs(two["codebooks_abs_sum"] - one["codebooks_abs_sum"]) <= 1e-6 * one["codebooks_abs_sum"]
+    assert two["value"] > 1e7 and two["config"]["kmeans_iter_per_s"] > 0
+    solo = _bench(["--gpus", "1", "--one-process", "--rows", "200001", "--scaling", "strong"] + SMALL)
+    assert solo["comm_world"] == 1 and solo["codebooks_abs_sum"] == one["codebooks_abs_sum"]
