@@ -2024,33 +2024,12 @@ __device__ __forceinline__ FsItem fs_item(const FsR &r, int32_t info) {
     return it;
 }
 
-__device__ __forceinline__ void fs_items_wave(uint32_t lane, uint32_t c, uint32_t d, uint32_t G, uint32_t fidx, uint32_t b,
-                                              const uint32_t *__restrict__ fast_nodes, const uint32_t *__restrict__ tile_base,
-                                              const NodeArrays &na, const FsS *__restrict__ summ, const FsS *__restrict__ summ_odd,
-                                              int4 *__restrict__ items, uint32_t *__restrict__ ihdr, bool seg_first) {
-    const uint32_t node = fast_nodes[fidx], len = na.seg_len[node];
-    const uint32_t nseg = (len + kFsSeg - 1) / kFsSeg, t0 = b * kFsBatch;
-    const size_t seg0 = (size_t)tile_base[fidx] * kFsSegsPerTile;
-    const FsS *sp = summ + seg0 * d + c, *sp2 = summ_odd + seg0 * d + c;
-    const uint32_t cnt = min(kFsBatch, nseg - t0);
-    FsS m[kFsSpl], m2[kFsSpl];
+// m / m2: the lane's eight summaries (even / odd stream) of segments 8 lane .. 8 lane + 7 of the batch; cnt: the batch's segments
+__device__ __forceinline__ void fs_items_wave(uint32_t lane, uint32_t c, uint32_t d, uint32_t G, uint32_t cnt, FsS (&m)[kFsSpl],
+                                              FsS (&m2)[kFsSpl], int4 *__restrict__ items, uint32_t *__restrict__ ihdr, bool seg_first) {
 #pragma unroll
-    for (int j = 0; j < kFsSpl; ++j) m[j] = sp[(size_t)min(t0 + kFsSpl * lane + (uint32_t)j, nseg - 1u) * d];  // unconditional, clamped
-    bool two_l = false;
-#pragma unroll
-    for (int j = 0; j < kFsSpl; ++j) {
-        if (kFsSpl * lane + (uint32_t)j >= cnt) m[j].d = m[j].lo = m[j].hi = 0, m[j].ef = -1;  // past the node's end: ef = -1 marks it
-        m2[j] = m[j];
-        two_l = two_l || (m[j].ef != -1 && (m[j].ef & 3) == 2);
-    }
-    if (__ballot(two_l) != 0ull) {
-#pragma unroll
-        for (int j = 0; j < kFsSpl; ++j)
-            if (m[j].ef != -1 && (m[j].ef & 3) == 2) {
-                const FsS o = sp2[(size_t)(t0 + kFsSpl * lane + (uint32_t)j) * d];
-                m2[j].d = o.d, m2[j].lo = o.lo, m2[j].hi = o.hi;
-            }
-    }
+    for (int j = 0; j < kFsSpl; ++j)
+        if (kFsSpl * lane + (uint32_t)j >= cnt) m[j].d = m[j].lo = m[j].hi = 0, m[j].ef = -1, m2[j] = m[j];  // past the node's end: ef = -1 marks it
     // terminators: parked segments (bit j of pk; of pu if their own summary is usable and worth trying first: under a
     // sampled guess and in the variance pass most parked segments do hold -- the guess is the rough part -- while the
     // mean pass of a zero-mean column, with its exact guess, parks what really leaves its binade: 96 % fail) and segments
@@ -2174,12 +2153,53 @@ __global__ __launch_bounds__(256) void k_fs_prep(const float *__restrict__ side,
         fs_tables_wave(lane, blockIdx.x * 4u + w, n_tab_blocks * 4u, side, side_meta, pass_tag, side_count, side_cap, summ, summ_odd, tab, tmeta);
         return;
     }
-    const uint32_t cq = (d + 3) / 4, q = blockIdx.x - n_tab_blocks, G = q / cq, c = (q - G * cq) * 4u + w;
-    if (G >= lv->pad || c >= d) return;  // (pad = the level's batches; launched over an upper bound)
+    // ---- items: one batch x four adjacent columns per workgroup.  The summaries are [segment][column]: the 512 x 4 block is
+    // fetched by all four waves together (four threads per segment: one 64-byte sector each) and handed to the waves
+    // through LDS, column by column -- a wave reading its own column took 16 bytes out of every sector it touched.
+    __shared__ __attribute__((aligned(16))) FsS lsm[4][kFsBatch];  // [column][j * 64 + lane]: segment 8 lane + j
+    const uint32_t cq = (d + 3) / 4, q = blockIdx.x - n_tab_blocks, G = q / cq, c0 = (q - G * cq) * 4u, c = c0 + w;
+    if (G >= lv->pad) return;  // (pad = the level's batches; launched over an upper bound)
+    const bool seg_first = policy ? policy[c0 / kFsCols] != 0u : seg_first_default != 0;  // (policy: 1 = sampled guess allowed for the column block)
+    if (seg_first) return;  // columns under a sampled guess keep k_fs_chain (uniform over the workgroup: four columns of one block of 32)
     const uint2 bt = batch_tab[G];
-    const bool seg_first = policy ? policy[c / kFsCols] != 0u : seg_first_default != 0;  // (policy: 1 = sampled guess allowed for the column block)
-    if (seg_first) return;  // columns under a sampled guess keep k_fs_chain
-    fs_items_wave(lane, c, d, G, bt.x, bt.y, fast_nodes, tile_base, na, summ, summ_odd, items, ihdr, seg_first);
+    const uint32_t node = fast_nodes[bt.x], len = na.seg_len[node];
+    const uint32_t nseg = (len + kFsSeg - 1) / kFsSeg, t0 = bt.y * kFsBatch, cnt = min(kFsBatch, nseg - t0);
+    const size_t seg0 = (size_t)tile_base[bt.x] * kFsSegsPerTile;
+    const uint32_t col = threadIdx.x & 3u, sg0 = threadIdx.x >> 2;  // this thread's column of the four, its segment in a group of 64
+    const bool col_ok = c0 + col < d;
+    const FsS *gp = summ + seg0 * d + (col_ok ? c0 + col : c0), *gp2 = summ_odd + seg0 * d + (col_ok ? c0 + col : c0);
+    FsS e[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = gp[(size_t)min(t0 + (uint32_t)r * 64u + sg0, nseg - 1u) * d];  // unconditional, clamped
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t sgi = (uint32_t)r * 64u + sg0;
+        lsm[col][(sgi & 7u) * 64u + (sgi >> 3)] = e[r];
+    }
+    __syncthreads();
+    FsS m[kFsSpl], m2[kFsSpl];
+#pragma unroll
+    for (int j = 0; j < kFsSpl; ++j) m[j] = lsm[w][(uint32_t)j * 64u + lane];
+    __syncthreads();
+    // the odd streams of the runs with an exact tie, else a copy of the even ones
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t sgi = (uint32_t)r * 64u + sg0;
+        if (sgi < cnt && (e[r].ef & 3) == 2) {
+            const FsS o = gp2[(size_t)(t0 + sgi) * d];
+            e[r].d = o.d, e[r].lo = o.lo, e[r].hi = o.hi;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t sgi = (uint32_t)r * 64u + sg0;
+        lsm[col][(sgi & 7u) * 64u + (sgi >> 3)] = e[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kFsSpl; ++j) m2[j] = lsm[w][(uint32_t)j * 64u + lane];
+    if (c >= d) return;
+    fs_items_wave(lane, c, d, G, cnt, m, m2, items, ihdr, seg_first);
 }
 
 // The exact chain, third form: one wave per (node, column), ONE pass over the column's items.  Items travel 64 at a time
