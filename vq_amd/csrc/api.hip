@@ -534,6 +534,7 @@ struct vqhip_dataset {
     const float *X = nullptr;
     uint64_t n = 0;
     uint32_t d = 0;
+    mutable TsvqPolicyCache tsvq_policy;  // (library-owned rows only: a borrowed buffer may change between builds)
 };
 
 struct vqhip_kmeans {
@@ -2321,7 +2322,7 @@ int vqhip_tsvq_build(const vqhip_dataset *ds, uint32_t max_depth, uint32_t cap, 
     VQ_TRY(require_gfx950());
     hipStream_t s;
     VQ_TRY(current_stream(&s));
-    return tsvq_build_device(ds->X, ds->n, ds->d, max_depth, cap, centroids, left, right, n_nodes, s);
+    return tsvq_build_device(ds->X, ds->n, ds->d, max_depth, cap, centroids, left, right, n_nodes, s, ds->own.p ? &ds->tsvq_policy : nullptr);
     VQ_API_END
 }
 

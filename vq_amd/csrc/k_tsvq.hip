@@ -2222,7 +2222,12 @@ __global__ __launch_bounds__(64) void k_fs_chain3(const float *__restrict__ X, u
                                                   const LevelInfo *__restrict__ lv, uint32_t *__restrict__ dbg_arg,
                                                   const uint32_t *__restrict__ skip_sampled) {
     uint32_t *const dbg = DBG ? dbg_arg : nullptr;
-    __shared__ __attribute__((aligned(16))) int4 litA[2][64], litB[2][64], litM[2][64];  // the chunk being walked / the next one; tmeta of their parked items
+    // the chunk being walked / the next one: per item {run fields a, b; m = its table's validity record, or a record that
+    // always / never holds for an item without a table: the loop tests nothing else}, one 48-byte record (one address)
+    struct __attribute__((aligned(16))) LItem {
+        int4 a, b, m;
+    };
+    __shared__ LItem lit[2][64];
     __shared__ int plist[64];                                               // side slots of the next chunk's parked items, in order
     __shared__ __attribute__((aligned(16))) float ltab[64 * kFsTabN];       // the tables of the chunk being walked
     __shared__ __attribute__((aligned(16))) float ladd[64];                 // addends of a segment being re-added
@@ -2324,13 +2329,16 @@ __global__ __launch_bounds__(64) void k_fs_chain3(const float *__restrict__ X, u
     // its parked items listed, ALL their tables (pf: a chunk ahead of their use) and their validity records requested
     float pf[32];
     int4 rM = make_int4(0, 1, 0, 0);
+    uint32_t stype = 0, ctype = 0;  // the type of this lane's item in the chunk just staged / being walked
     auto stage = [&](int bf) -> uint32_t {
         const uint32_t type = (uint32_t)rB.z & 7u;
         const bool parked = lane < rn && (type == kFsItTable || type == kFsItSeg);
         const uint64_t pmask = __ballot(parked);
         const uint32_t prank = (uint32_t)__builtin_popcountll(pmask & ((1ull << lane) - 1ull));
         const uint32_t slot = parked ? ((uint32_t)rB.z >> 12) : 0u;
-        litA[bf][lane] = rA, litB[bf][lane] = make_int4(rB.x, rB.y, rB.z, (int32_t)(parked ? prank * kFsTabN * 4u : 0u));
+        // (b.w: the byte offset of the item's table in `ltab`, sign bit set for an item that ends in a table)
+        lit[bf][lane].a = rA, lit[bf][lane].b = make_int4(rB.x, rB.y, rB.z, (int32_t)(parked ? (prank * kFsTabN * 4u) | (type == kFsItTable ? 0x80000000u : 0u) : 0u));
+        stype = type;
         fs_wave_lds_sync();  // (the previous chunk's table requests have read plist)
         if (parked) plist[prank] = (int)slot;
         rM = tmeta[slot];
@@ -2348,6 +2356,7 @@ __global__ __launch_bounds__(64) void k_fs_chain3(const float *__restrict__ X, u
     };
     request();
     uint32_t ptot_next = stage(0);      // chunk 0 -> buffer 0
+    ctype = stype;
     uint32_t cn = rn, ct0 = rt;         // the chunk being walked: items, first segment of its batch
     request();                          // chunk 1 in flight
     int buf = 0;
@@ -2356,7 +2365,12 @@ __global__ __launch_bounds__(64) void k_fs_chain3(const float *__restrict__ X, u
         const unsigned long long q_st = DBG ? clock64() : 0ull;
         // this chunk: its validity records and tables (requested a chunk ago) into LDS; the NEXT chunk: out of its registers
         // into the other buffer, its tables requested; the chunk after it requested
-        litM[buf][lane] = rM;
+        // (an item that ends in nothing passes the table test whatever the sum, a gathered one never does; a parked segment
+        // whose own summary is tried first -- not on the columns this kernel serves -- takes the slow path for its table)
+        {
+            const bool tb = ctype == kFsItTable, always = ctype == kFsItEnd || ctype == kFsItNop;
+            lit[buf][lane].m = make_int4(rM.x, tb ? rM.y : (always ? INT32_MIN : 1), tb ? rM.z : (always ? INT32_MAX : 0), rM.w);
+        }
         const uint32_t ptot_cur = ptot_next;
         fs_wave_lds_sync();  // the reads of ltab and of the other buffer (the chunk walked before this one) are done
 #pragma unroll
@@ -2368,37 +2382,39 @@ __global__ __launch_bounds__(64) void k_fs_chain3(const float *__restrict__ X, u
         if (DBG) n_parked += ptot_cur;
         const uint32_t nn = rn, nt0 = rt;
         ptot_next = stage(buf ^ 1);
+        const uint32_t ntype = stype;
         request();
         if (DBG) cy_stage += clock64() - q_st;
         // (the item index goes through fs_vgpr: an LDS read at a uniform address is moved to SGPRs -- eleven v_readfirstlane --
         // right behind the read, i.e. the wave waits for the item it has just asked for; as vector registers the next
         // item's fields are waited for when they are used, an item later)
-        int4 A = litA[buf][fs_vgpr(0u)], B = litB[buf][fs_vgpr(0u)], M = litM[buf][fs_vgpr(0u)];
+        int4 A = lit[buf][fs_vgpr(0u)].a, B = lit[buf][fs_vgpr(0u)].b, M = lit[buf][fs_vgpr(0u)].m;
         for (uint32_t i = 0; i < cn; ++i) {
             const uint32_t inx = fs_vgpr(min(i + 1u, 63u));
-            const int4 nA = litA[buf][inx], nB = litB[buf][inx], nM = litM[buf][inx];  // (do not depend on s: in flight behind this item)
+            const int4 nA = lit[buf][inx].a, nB = lit[buf][inx].b, nM = lit[buf][inx].m;  // (do not depend on s: in flight behind this item)
             const uint32_t sb = __float_as_uint(s);
             const bool odd = (sb & 1u) != 0u;
             const uint32_t rmin = (uint32_t)(odd ? A.w : A.x), rmax = (uint32_t)(odd ? B.x : A.y);
-            const bool ok = sb >= rmin && sb <= rmax;
             const uint32_t s1 = sb + (uint32_t)(odd ? B.y : A.z);
-            const uint32_t type = (uint32_t)B.z & 7u;
             const int32_t mm = (int32_t)(s1 - (uint32_t)M.x) >> 5;  // (another sign or binade: far outside any window)
-            const bool hit = mm >= M.y && mm <= M.z;
-            const float tv = ltab[((uint32_t)B.w >> 2) + (s1 & 31u)];
-            const bool is_tab = type == kFsItTable;
-            const bool fast = ok && (is_tab ? hit : type != kFsItGather);
+            const float tv = ltab[(((uint32_t)B.w & 0x7FFFFFFFu) >> 2) + (s1 & 31u)];
+            const bool is_tab = B.w < 0;
+            const bool fast = sb >= rmin && sb <= rmax && mm >= M.y && mm <= M.z;
             if (__builtin_amdgcn_readfirstlane(fast ? 1 : 0)) {
                 s = is_tab ? tv + (float)mm * __int_as_float(M.w) : __uint_as_float(s1);
-                if (DBG) n_hit += is_tab ? 1u : 0u, n_own += type == kFsItSeg ? 1u : 0u;
+                if (DBG) n_hit += is_tab ? 1u : 0u;
             } else {
                 const unsigned long long q_o = DBG ? clock64() : 0ull;
                 ++n_out;
                 const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane(B.z), ty = info & 7u, tseg = (info >> 3) & 511u;
+                const bool ok = sb >= rmin && sb <= rmax;
+                // (M is the item's table record only for type 1: a parked segment whose own summary comes first -- no such item
+                // on the columns this kernel serves -- is re-added when that summary does not hold)
+                const int32_t Mt_y = (ty == kFsItTable) ? M.y : 1, Mt_z = (ty == kFsItTable) ? M.z : 0;
                 // where the run starts: behind what the item in front consumed
                 uint32_t from = pos;
                 if (i > 0u) {
-                    const uint32_t pi = (uint32_t)__builtin_amdgcn_readfirstlane(litB[buf][i - 1u].z), pt = pi & 7u, ps = (pi >> 3) & 511u;
+                    const uint32_t pi = (uint32_t)__builtin_amdgcn_readfirstlane(lit[buf][i - 1u].b.z), pt = pi & 7u, ps = (pi >> 3) & 511u;
                     from = pt == kFsItEnd ? 0u : (pt == kFsItNop ? ps : ps + 1u);
                 }
                 bool need_table = ty == kFsItTable;
@@ -2408,9 +2424,9 @@ __global__ __launch_bounds__(64) void k_fs_chain3(const float *__restrict__ X, u
                 if (need_table) {
                     const uint32_t sb3 = __float_as_uint(s);
                     const int32_t m3 = (int32_t)(sb3 - (uint32_t)M.x) >> 5;
-                    const bool hit3 = m3 >= M.y && m3 <= M.z;
+                    const bool hit3 = m3 >= Mt_y && m3 <= Mt_z;
                     if (__builtin_amdgcn_readfirstlane(hit3 ? 1 : 0)) {
-                        const float tv3 = ltab[((uint32_t)B.w >> 2) + (sb3 & 31u)];
+                        const float tv3 = ltab[(((uint32_t)B.w & 0x7FFFFFFFu) >> 2) + (sb3 & 31u)];
                         s = tv3 + (float)m3 * __int_as_float(M.w);
                         if (DBG) ++n_hit;
                     } else {
@@ -2433,11 +2449,11 @@ __global__ __launch_bounds__(64) void k_fs_chain3(const float *__restrict__ X, u
             A = nA, B = nB, M = nM;
         }
         {  // what this chunk's last item consumed: where a run that continues in the next chunk starts
-            const uint32_t li = (uint32_t)__builtin_amdgcn_readfirstlane(litB[buf][cn - 1u].z), lt = li & 7u, ls = (li >> 3) & 511u;
+            const uint32_t li = (uint32_t)__builtin_amdgcn_readfirstlane(lit[buf][cn - 1u].b.z), lt = li & 7u, ls = (li >> 3) & 511u;
             pos = lt == kFsItEnd ? 0u : (lt == kFsItNop ? ls : ls + 1u);
         }
         buf ^= 1;
-        cn = nn, ct0 = nt0;
+        cn = nn, ct0 = nt0, ctype = ntype;
     }
     if (lane == 0) {
         if (MODE == 0) na.centroid[(size_t)node * d + c] = s / (float)len;  // T::from_usize(n)
@@ -2772,7 +2788,7 @@ struct TsvqBuildWs {
 
 int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_depth, uint32_t cap,
                       float *centroids_out, int32_t *left_out, int32_t *right_out, int32_t *n_nodes_out,
-                      hipStream_t stream) {
+                      hipStream_t stream, TsvqPolicyCache *policy_cache) {
     if (n64 >= (1ull << 31)) return fail(VQHIP_ERR_UNSUPPORTED, "TSVQ build supports < 2^31 rows per device");
     const uint32_t n = (uint32_t)n64;
     const uint64_t need_cap = (max_depth < 31) ? std::min<uint64_t>((1ull << (max_depth + 1)) - 1, 2ull * n - 1) : 2ull * n - 1;
@@ -2924,9 +2940,26 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
                        ws.b_lv.as<uint32_t>(), (uint32_t)((n_levels + 1) * sizeof(LevelInfo) / 4), na.seg_start, na.seg_len,
                        ws.b_fs_fb.as<uint32_t>(), (uint32_t)((8 + 64 * 2 * 64) / 4), ws.b_hist.as<uint32_t>(), wmax * 2 * 256);
     VQ_LAUNCH_CHECK("k_build_init");
+    // the sampling policy: from the data set's cache if an earlier build left it there, else the kernel (into the cache's
+    // buffer when there is one)
+    uint32_t *policy_buf = ws.b_fs_fb.as<uint32_t>() + 2 + 64 * 2 * 16;
+    bool policy_cached = false, any_sampled = true, any_exact = true;
     if (adaptive_sampling && n >= fs_min_rows) {
-        hipLaunchKernelGGL(k_fs_policy, dim3(n_cblk), dim3(1024), 0, stream, X, n, d, ws.b_fs_fb.as<uint32_t>() + 2 + 64 * 2 * 16);
-        VQ_LAUNCH_CHECK("k_fs_policy");
+        if (policy_cache) {
+            std::lock_guard<std::mutex> lk(policy_cache->mu);
+            if (policy_cache->valid && policy_cache->n_cblk == n_cblk) {
+                policy_cached = true;
+                any_sampled = any_exact = false;
+                for (uint32_t v : policy_cache->host) (v ? any_sampled : any_exact) = true;
+            } else {
+                VQ_TRY(policy_cache->dev.ensure((size_t)n_cblk * 4));
+            }
+            policy_buf = policy_cache->dev.as<uint32_t>();
+        }
+        if (!policy_cached) {
+            hipLaunchKernelGGL(k_fs_policy, dim3(n_cblk), dim3(1024), 0, stream, X, n, d, policy_buf);
+            VQ_LAUNCH_CHECK("k_fs_policy");
+        }
     }
     marks.mark("queued");
     marks.mark("setup");
@@ -2953,7 +2986,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     // tags of this build's passes: never a value an earlier pass (of this or an earlier build over the same scratch) used
     static std::atomic<uint32_t> g_pass_tag{1};
     uint32_t *fbk = ws.b_fs_fb.as<uint32_t>();
-    const uint32_t *policy = adaptive_sampling ? fbk + 2 + 64 * 2 * 16 : nullptr;
+    const uint32_t *policy = adaptive_sampling ? policy_buf : nullptr;
 
     // sequential-order column sums of the level's nodes: long nodes through the tile-parallel exact emulation (k_fs_*),
     // the rest through the plain chain kernel.  Grids are upper bounds; the kernels read the level's counts.
@@ -2991,8 +3024,9 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         // binade) through the tables + items + one-pass chain of round 5; columns under a sampled guess (most parked segments
         // hold there, and the guess is off by far more than a table's window) and the variance pass (monotone sums: a
         // handful of crossings per column) keep round 4's chain.
-        const bool new_any = use_tables && mode == 0 && (policy != nullptr || fs_sample == 1);
-        const bool old_any = !(use_tables && mode == 0 && fs_sample == 1 && policy == nullptr);
+        // (a cached policy tells the host which of the two has columns at all: no empty launches)
+        const bool new_any = use_tables && mode == 0 && (policy != nullptr ? any_exact : fs_sample == 1);
+        const bool old_any = !(use_tables && mode == 0) || (policy != nullptr ? any_sampled : fs_sample > 1);
         const uint32_t *only_sampled = (new_any && old_any) ? policy : nullptr;
         if (mode == 0) {
             // the binade guesses: f64 sums of every 8th group of rows of each tile where k_fs_policy allows (|mean| >= sigma),
@@ -3186,6 +3220,14 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         right_out[q] = hr[id] >= 0 ? newid[hr[id]] : -1;
     }
     *n_nodes_out = (int32_t)order.size();
+    if (policy_cache && !policy_cached && adaptive_sampling && n >= fs_min_rows) {  // (the stream is idle: the nodes have been downloaded)
+        std::vector<uint32_t> h(n_cblk);
+        VQ_HIP(hipMemcpy(h.data(), policy_buf, (size_t)n_cblk * 4, hipMemcpyDeviceToHost));
+        std::lock_guard<std::mutex> lk(policy_cache->mu);
+        policy_cache->host = h;
+        policy_cache->n_cblk = n_cblk;
+        policy_cache->valid = true;
+    }
     return VQHIP_OK;
 }
 

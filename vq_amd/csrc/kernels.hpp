@@ -2,6 +2,9 @@
 // Every wrapper enqueues on `stream` and returns a vqhip status.
 #pragma once
 
+#include <mutex>
+#include <vector>
+
 #include "common.hpp"
 
 namespace vqhip {
@@ -194,9 +197,19 @@ int comm_kind(const Comm *c);                                // 0 identity, 1 RC
 
 // ---- TSVQ -----------------------------------------------------------------------------
 // build on a device-resident matrix; outputs are HOST arrays in pre-order (see vqhip.h)
+// what k_fs_policy found out about a data set's columns (which blocks of 32 may take a sampled binade guess): a property
+// of the rows, kept with a library-owned (immutable) data set from its first build on -- later builds skip the kernel
+// and the host knows which of the two mean-pass chains have columns to work on
+struct TsvqPolicyCache {
+    std::mutex mu;
+    bool valid = false;
+    uint32_t n_cblk = 0;
+    DevBuf dev;
+    std::vector<uint32_t> host;
+};
 int tsvq_build_device(const float *X, uint64_t n, uint32_t d, uint32_t max_depth, uint32_t cap,
                       float *centroids_out, int32_t *left_out, int32_t *right_out, int32_t *n_nodes_out,
-                      hipStream_t stream);
+                      hipStream_t stream, TsvqPolicyCache *policy_cache = nullptr);
 // latency path for a handful of rows (k_small.hip): rows / outputs are device-visible pinned host pointers
 int launch_pq_encode_small(const float *rows_dev, uint32_t n, uint32_t d, uint32_t m, uint32_t k, uint32_t sd, int metric,
                            const float *cb, const float *cnsqrt, uint8_t *codes_dev, uint16_t *f16_dev,
