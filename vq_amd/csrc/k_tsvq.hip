@@ -28,6 +28,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstddef>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -275,23 +276,27 @@ __global__ __launch_bounds__(256) void k_pick_split(const uint32_t *__restrict__
 // histograms are privatised in LDS (8 slots keyed by the level-local node index, claimed with
 // a CAS) and flushed once; the rare slot collision falls back to a global atomic.  Unprivatised,
 // the root level is 1M atomics on 512 words (0.64 ms per round).
-constexpr uint32_t kHistSlots = 8;
+constexpr uint32_t kHistSlots = 8;    // 8-bit rounds (four of them): eight privatised node histograms per workgroup
+constexpr uint32_t kHistSlots11 = 2;  // 11-bit rounds (three: 11 + 11 + 10 bits): two (2 x 2 x 2048 words = 32 KB of LDS)
 // GATHER: the first round (shift 24).  The values are not there yet: vals[i] = X[perm[i]][split_dim(node of i)] is formed
 // here (and written for the later rounds, the median test and the partition), NaNs are taken off nv[node] (k_pick_split
 // set it to the segment length); no prefix has been chosen yet, so every key counts for both ranks.
-template <bool GATHER>
+// BITS: 8 (rounds at shift 24 / 16 / 8 / 0) or 11 (shift 21 / 10 / 0, the last one 10 bits wide: its top bins stay empty)
+template <bool GATHER, int BITS>
 __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ X, uint32_t d, const uint32_t *__restrict__ perm,
                                                      float *__restrict__ vals, uint32_t n, uint32_t chunk,
                                                      const uint32_t *__restrict__ node_of,
                                                      const uint32_t *__restrict__ remap,
                                                      const uint32_t *__restrict__ lvl_node, NodeArrays na,
-                                                     uint32_t shift, uint32_t *__restrict__ hist) {
-    __shared__ uint32_t tags[kHistSlots];
-    __shared__ uint32_t lh[kHistSlots][2][256];
-    for (uint32_t e = threadIdx.x; e < kHistSlots * 512; e += 256) (&lh[0][0][0])[e] = 0u;
-    if (threadIdx.x < kHistSlots) tags[threadIdx.x] = kInactive;
+                                                     uint32_t shift, uint32_t *__restrict__ hist, uint32_t width) {
+    // width: key bits of THIS round (<= BITS: the histograms keep 2^BITS bins, a narrower round leaves the top ones empty)
+    constexpr uint32_t kBins = 1u << BITS, kSlots = BITS == 8 ? kHistSlots : kHistSlots11;
+    __shared__ uint32_t tags[kSlots];
+    __shared__ uint32_t lh[kSlots][2][kBins];
+    for (uint32_t e = threadIdx.x; e < kSlots * 2 * kBins; e += 256) (&lh[0][0][0])[e] = 0u;
+    if (threadIdx.x < kSlots) tags[threadIdx.x] = kInactive;
     __syncthreads();
-    const uint32_t hi_mask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+    const uint32_t hi_mask = (shift + width >= 32) ? 0u : (0xFFFFFFFFu << (shift + width)), bin_mask = (1u << width) - 1u;
     const uint32_t i0 = blockIdx.x * chunk;
     const uint32_t i1 = min(n, i0 + chunk);
     for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256) {
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ X
         }
         if (x != x) continue;
         const uint32_t key = order_key(x);
-        const uint32_t slot = li & (kHistSlots - 1);
+        const uint32_t slot = li & (kSlots - 1);
         uint32_t owner = tags[slot];
         if (owner == kInactive) {
             const uint32_t old = atomicCAS(&tags[slot], kInactive, li);
@@ -318,33 +323,37 @@ __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ X
 #pragma unroll
         for (uint32_t sel = 0; sel < 2u; ++sel)
             if (GATHER || (key & hi_mask) == na.sel_prefix[2 * node + sel]) {
-                const uint32_t bin = (key >> shift) & 255u;
+                const uint32_t bin = (key >> shift) & bin_mask;
                 if (owner == li) atomicAdd(&lh[slot][sel][bin], 1u);
-                else atomicAdd(&hist[((size_t)li * 2 + sel) * 256 + bin], 1u);
+                else atomicAdd(&hist[((size_t)li * 2 + sel) * kBins + bin], 1u);
             }
     }
     __syncthreads();
-    for (uint32_t e = threadIdx.x; e < kHistSlots * 512; e += 256) {
-        const uint32_t slot = e >> 9, rest = e & 511;
+    for (uint32_t e = threadIdx.x; e < kSlots * 2 * kBins; e += 256) {
+        const uint32_t slot = e / (2 * kBins), rest = e % (2 * kBins);
         const uint32_t c = (&lh[0][0][0])[e];
         const uint32_t li = tags[slot];
-        if (c != 0 && li != kInactive) atomicAdd(&hist[(size_t)li * 512 + rest], c);
+        if (c != 0 && li != kInactive) atomicAdd(&hist[(size_t)li * 2 * kBins + rest], c);
     }
 }
 
 // one wave per (node, which of the two ranks): lane l owns bins 4l..4l+3, a wave prefix scan finds
 // the bin holding the rank (the serial walk over 256 dependent loads cost 25 us per launch)
 // FIRST (shift 24): the ranks of the two order statistics the median needs come from nv (tsvq.rs:77-81).
-template <bool FIRST>
+template <bool FIRST, int BITS>
 __global__ __launch_bounds__(64) void k_select_pick(const uint32_t *__restrict__ lvl_node, const LevelInfo *__restrict__ lv,
                                                     NodeArrays na, uint32_t shift, uint32_t *__restrict__ hist) {
+    constexpr uint32_t kBins = 1u << BITS, kPer = kBins / 64, kV = kPer / 4;  // bins per lane (4 or 32), as 16-byte vectors
     const uint32_t idx = blockIdx.x, lane = threadIdx.x;
     if (idx >= lv->n_split * 2) return;
     const uint32_t li = idx >> 1, sel = idx & 1;
     const uint32_t node = lvl_node[li];
-    uint4 *h4 = reinterpret_cast<uint4 *>(hist + ((size_t)li * 2 + sel) * 256);
-    const uint4 c = h4[lane];
-    h4[lane] = make_uint4(0u, 0u, 0u, 0u);  // ready for the next round
+    uint4 *h4 = reinterpret_cast<uint4 *>(hist + ((size_t)li * 2 + sel) * kBins) + (size_t)lane * kV;
+    uint4 c[kV];
+#pragma unroll
+    for (uint32_t v = 0; v < kV; ++v) c[v] = h4[v];
+#pragma unroll
+    for (uint32_t v = 0; v < kV; ++v) h4[v] = make_uint4(0u, 0u, 0u, 0u);  // ready for the next round
     uint32_t rank;
     if (FIRST) {
         const uint32_t nv = na.nv[node], h = nv / 2;
@@ -352,7 +361,9 @@ __global__ __launch_bounds__(64) void k_select_pick(const uint32_t *__restrict__
     } else {
         rank = na.sel_rank[2 * node + sel];
     }
-    const uint32_t mine = c.x + c.y + c.z + c.w;
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t v = 0; v < kV; ++v) mine += c[v].x + c[v].y + c[v].z + c[v].w;
     uint32_t incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -360,32 +371,31 @@ __global__ __launch_bounds__(64) void k_select_pick(const uint32_t *__restrict__
         if ((int)lane >= off) incl += up;
     }
     const uint32_t excl = incl - mine;
-    // first bin b with rank < cumulative(b); the serial rule stops at bin 255 if none does
+    // first bin b with rank < cumulative(b); the serial rule stops at the last bin if none does
     const bool here = (rank >= excl) && (rank < incl);
     const uint64_t m = __ballot(here);
-    uint32_t b = 255, new_rank;
+    uint32_t b = kBins - 1, new_rank;
     if (na.nv[node] == 0) {
         b = 0;
         new_rank = rank;
     } else if (m) {
         const int src = __builtin_ctzll(m);
-        uint32_t r = rank - excl, bb = 4 * lane;
-        if (r >= c.x) {
-            r -= c.x;
-            ++bb;
-            if (r >= c.y) {
-                r -= c.y;
-                ++bb;
-                if (r >= c.z) {
-                    r -= c.z;
-                    ++bb;
-                }
+        uint32_t r = rank - excl, bb = kPer * lane;
+        bool found = false;
+#pragma unroll
+        for (uint32_t v = 0; v < kV; ++v) {
+            const uint32_t w4[4] = {c[v].x, c[v].y, c[v].z, c[v].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool last = (v == kV - 1) && (q == 3);
+                if (!found && (r < w4[q] || last)) found = true;
+                else if (!found) r -= w4[q], ++bb;
             }
         }
         b = (uint32_t)__shfl((int)bb, src);
         new_rank = (uint32_t)__shfl((int)r, src);
-    } else {  // rank beyond every bin: walk ends at bin 255 with the counts of bins 0..254 removed
-        const uint32_t total = (uint32_t)__shfl((int)incl, 63), last = (uint32_t)__shfl((int)c.w, 63);
+    } else {  // rank beyond every bin: the walk ends at the last bin with the counts of the bins in front removed
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63), last = (uint32_t)__shfl((int)c[kV - 1].w, 63);
         new_rank = rank - (total - last);
     }
     if (lane == 0) {
@@ -1991,7 +2001,8 @@ __device__ __forceinline__ FsR fs_run_compose(const FsR &f, const FsR &g) {  // 
 }
 
 constexpr uint32_t kFsBatch = 64 * kFsSpl;         // segments per batch: one lane's eight are one 512-row tile
-constexpr uint32_t kFsItemCap = 2 * kFsBatch + 1;  // items of a batch: at most two per segment, plus the end
+constexpr uint32_t kFsItemCap = kFsBatch + 1;      // items of a batch: at most one per segment, plus the end (the two-item form of
+                                                   // a parked segment -- types 3 and 4 -- is not emitted: its columns keep k_fs_chain)
 // An item is a run and what ends it, 32 bytes: {rmin0, rmax0, dm0, rmin1}, {rmax1, dm1, info, 0}.  With r the raw bits
 // of the running sum and p = r & 1 (the parity of S: the same as that of |S|), the run holds iff rmin_p <= r <= rmax_p
 // (unsigned: one range per sign and binade) and leaves the sum at r + dm_p.  info = type | tseg << 3 | slot << 12:
@@ -2040,7 +2051,7 @@ __device__ __forceinline__ void fs_items_wave(uint32_t lane, uint32_t c, uint32_
         const bool live = m[j].ef != -1;
         const bool parked = live && fs_ef_slot(m[j].ef) >= 0, bad = live && (m[j].ef & 1);
         pk |= parked ? (1u << j) : 0u;
-        pu |= (parked && !bad && seg_first) ? (1u << j) : 0u;
+        pu |= (parked && !bad && seg_first && kFsItemCap > 2 * kFsBatch) ? (1u << j) : 0u;  // (two items per segment need the room)
         tm |= (parked || bad) ? (1u << j) : 0u;
     }
     auto seg_run = [&](int j) {
@@ -2745,7 +2756,8 @@ __global__ __launch_bounds__(1024) void k_plan_fused(LevelInfo *__restrict__ lv,
 
 // ---- host driver of the build ------------------------------------------------------------
 // Device scratch of a build, kept per host thread between builds (their hipMalloc calls were 2-3 ms of a
-// 13 ms build); dropped when it exceeds 1 GiB or the device changes.
+// 13 ms build); dropped when it exceeds 6 GiB (of 288: a 1M x 384 build holds 1.3 GiB, and re-allocating it was 3.4 of
+// that build's 10 ms) or the device changes.
 struct TsvqBuildWs {
     int device = -1;
     DevBuf b_perm[2], b_nodeof[2], b_vals, b_flags, b_scan, b_bsums, b_hist, b_lvl, b_remap, b_lvl2, b_remap2;
@@ -2825,7 +2837,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     struct WsTrim {  // keep the scratch for the next build unless it is large
         TsvqBuildWs &w;
         ~WsTrim() {
-            if (w.total() > (1ull << 30)) w.release();
+            if (w.total() > (6ull << 30)) w.release();
         }
     } ws_trim{ws};
     // widest level: min(2^level, n) nodes
@@ -2852,7 +2864,12 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     VQ_TRY(ws.b_lvl2.ensure((size_t)wmax * 4));
     VQ_TRY(ws.b_remap2.ensure((size_t)wmax * 4));
     VQ_TRY(ws.b_lvl_slow.ensure((size_t)wmax * 4));
-    VQ_TRY(ws.b_hist.ensure((size_t)wmax * 2 * 256 * 4));
+    // median: three radix rounds of 11 / 11 / 10 bits (2048 bins per node and rank) while the widest level's histograms
+    // stay small, else four rounds of 8 bits
+    static const char *radix_env = getenv("VQHIP_TSVQ_RADIX8");  // =1: four 8-bit rounds (A/B)
+    const bool radix11 = wmax <= 4096 && !(radix_env && radix_env[0] == '1');
+    const uint32_t hist_bins = radix11 ? 2048u : 256u;
+    VQ_TRY(ws.b_hist.ensure((size_t)wmax * 2 * hist_bins * 4));
     VQ_TRY(ws.b_seg_start.ensure((size_t)dcap * 4));
     VQ_TRY(ws.b_seg_len.ensure((size_t)dcap * 4));
     VQ_TRY(ws.b_split.ensure((size_t)dcap * 4));
@@ -2938,7 +2955,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     hipLaunchKernelGGL(k_build_init, dim3(std::min<uint32_t>((n + 255) / 256, (uint32_t)num_cus() * 16)), dim3(256), 0, stream,
                        ws.b_perm[0].as<uint32_t>(), ws.b_nodeof[0].as<uint32_t>(), n, ws.b_left.as<int32_t>(), ws.b_right.as<int32_t>(), dcap,
                        ws.b_lv.as<uint32_t>(), (uint32_t)((n_levels + 1) * sizeof(LevelInfo) / 4), na.seg_start, na.seg_len,
-                       ws.b_fs_fb.as<uint32_t>(), (uint32_t)((8 + 64 * 2 * 64) / 4), ws.b_hist.as<uint32_t>(), wmax * 2 * 256);
+                       ws.b_fs_fb.as<uint32_t>(), (uint32_t)((8 + 64 * 2 * 64) / 4), ws.b_hist.as<uint32_t>(), wmax * 2 * hist_bins);
     VQ_LAUNCH_CHECK("k_build_init");
     // the sampling policy: from the data set's cache if an earlier build left it there, else the kernel (into the cache's
     // buffer when there is one)
@@ -3100,25 +3117,32 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         VQ_TRY(colsum(1, lvp, ub_nodes, perm, fast_possible));
         hipLaunchKernelGGL(k_pick_split, dim3((ub_nodes + 3) / 4), dim3(256), 0, stream, lvl_split, lvp, d, na);
         VQ_LAUNCH_CHECK("k_pick_split");
-        // median (tsvq.rs:68-81): 4-round radix select of the two middle order statistics; the first round gathers the
+        // median (tsvq.rs:68-81): radix select (three rounds of 11 / 11 / 10 bits) of the two middle order statistics; the first round gathers the
         // split dimension's values
         {
             const uint32_t hblocks = std::min<uint32_t>((n + 2047) / 2048, (uint32_t)num_cus() * 4);
             const uint32_t hchunk = (n + hblocks - 1) / hblocks;
-            for (int shift = 24; shift >= 0; shift -= 8) {
-                if (shift == 24) {
-                    hipLaunchKernelGGL(k_select_hist<true>, dim3(hblocks), dim3(256), 0, stream, X, d, perm, ws.b_vals.as<float>(), n, hchunk,
-                                       node_of, remap, lvl_split, na, (uint32_t)shift, ws.b_hist.as<uint32_t>());
-                    hipLaunchKernelGGL(k_select_pick<true>, dim3(ub_nodes * 2), dim3(64), 0, stream, lvl_split, lvp, na, (uint32_t)shift,
-                                       ws.b_hist.as<uint32_t>());
-                } else {
-                    hipLaunchKernelGGL(k_select_hist<false>, dim3(hblocks), dim3(256), 0, stream, X, d, perm, ws.b_vals.as<float>(), n, hchunk,
-                                       node_of, remap, lvl_split, na, (uint32_t)shift, ws.b_hist.as<uint32_t>());
-                    hipLaunchKernelGGL(k_select_pick<false>, dim3(ub_nodes * 2), dim3(64), 0, stream, lvl_split, lvp, na, (uint32_t)shift,
-                                       ws.b_hist.as<uint32_t>());
-                }
-                VQ_LAUNCH_CHECK("k_select_*");
+            auto round = [&](auto first_c, auto bits_c, uint32_t shift, uint32_t width) {
+                constexpr bool kFirst = decltype(first_c)::value;
+                constexpr int kBits = decltype(bits_c)::value;
+                hipLaunchKernelGGL((k_select_hist<kFirst, kBits>), dim3(hblocks), dim3(256), 0, stream, X, d, perm, ws.b_vals.as<float>(), n, hchunk,
+                                   node_of, remap, lvl_split, na, shift, ws.b_hist.as<uint32_t>(), width);
+                hipLaunchKernelGGL((k_select_pick<kFirst, kBits>), dim3(ub_nodes * 2), dim3(64), 0, stream, lvl_split, lvp, na, shift,
+                                   ws.b_hist.as<uint32_t>());
+            };
+            using T = std::true_type;
+            using F = std::false_type;
+            if (radix11) {
+                round(T{}, std::integral_constant<int, 11>{}, 21u, 11u);
+                round(F{}, std::integral_constant<int, 11>{}, 10u, 11u);
+                round(F{}, std::integral_constant<int, 11>{}, 0u, 10u);  // (the low 10 bits: bins 1024.. stay empty)
+            } else {
+                round(T{}, std::integral_constant<int, 8>{}, 24u, 8u);
+                round(F{}, std::integral_constant<int, 8>{}, 16u, 8u);
+                round(F{}, std::integral_constant<int, 8>{}, 8u, 8u);
+                round(F{}, std::integral_constant<int, 8>{}, 0u, 8u);
             }
+            VQ_LAUNCH_CHECK("k_select_*");
         }
         // partition (tsvq.rs:84-85): flags + in-block scan; block totals, children (tsvq.rs:88-108) and the NEXT level's
         // plan in one launch; stable scatter
