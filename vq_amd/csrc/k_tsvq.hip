@@ -1002,6 +1002,12 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // in order, so all that is needed is that the compiler keeps the order and waits for the LDS counter.  __syncthreads()
 // would also wait for every global load in flight (s_waitcnt vmcnt(0)) -- the rows of the next block, the next batches
 // of summaries, the parked addends: exactly the loads these kernels issue early to hide their latency.
+// a * b + c on 24-bit signed factors in ONE full-rate instruction (v_mad_i32_i24)
+__device__ __forceinline__ int32_t fs_mad24(int32_t a, int32_t b, int32_t c) {
+    int32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 // a value the compiler must keep in a vector register (it cannot prove it uniform any more)
 __device__ __forceinline__ uint32_t fs_vgpr(uint32_t x) {
     asm volatile("" : "+v"(x));
@@ -2347,8 +2353,22 @@ __global__ __launch_bounds__(64) void k_fs_chain3(const float *__restrict__ X, u
         const uint64_t pmask = __ballot(parked);
         const uint32_t prank = (uint32_t)__builtin_popcountll(pmask & ((1ull << lane) - 1ull));
         const uint32_t slot = parked ? ((uint32_t)rB.z >> 12) : 0u;
-        // (b.w: the byte offset of the item's table in `ltab`, sign bit set for an item that ends in a table)
-        lit[bf][lane].a = rA, lit[bf][lane].b = make_int4(rB.x, rB.y, rB.z, (int32_t)(parked ? (prank * kFsTabN * 4u) | (type == kFsItTable ? 0x80000000u : 0u) : 0u));
+        // The record as the loop wants it: every per-parity field as "even value + (r & 1) * difference" (one v_mad_i32_i24
+        // behind the parity bit instead of compare + select), ranges as (start, span) for ONE unsigned compare:
+        //   a = {rmin0, span0, r + dm0 's dm0, rmin1 - rmin0},  b = {span1 - span0, dm1 - dm0, info, table offset | table flag}
+        // A run whose differences do not fit 24 bits is made one that never holds (rmin0 = 1, span0 = 0 means r == 1 only: a
+        // subnormal sum no run holds for anyway; then differences 0): it is walked.
+        {
+            uint32_t rmin0 = (uint32_t)rA.x, span0 = (uint32_t)rA.y - (uint32_t)rA.x, rmin1 = (uint32_t)rA.w, span1 = (uint32_t)rB.x - (uint32_t)rA.w;
+            if ((uint32_t)rA.y < (uint32_t)rA.x) rmin0 = 1u, span0 = 0u;  // an empty range (first > last)
+            if ((uint32_t)rB.x < (uint32_t)rA.w) rmin1 = 1u, span1 = 0u;
+            int32_t dm0 = rA.z, dr = (int32_t)(rmin1 - rmin0), ds = (int32_t)(span1 - span0), dd = rB.y - rA.z;
+            const int32_t lim24 = (1 << 23) - 1;
+            if (dr < -lim24 || dr > lim24 || ds < -lim24 || ds > lim24 || dd < -lim24 || dd > lim24) rmin0 = 1u, span0 = 0u, dr = ds = dd = 0;
+            lit[bf][lane].a = make_int4((int32_t)rmin0, (int32_t)span0, dm0, dr);
+            // (b.w: the byte offset of the item's table in `ltab`, sign bit set for an item that ends in a table)
+            lit[bf][lane].b = make_int4(ds, dd, rB.z, (int32_t)(parked ? (prank * kFsTabN * 4u) | (type == kFsItTable ? 0x80000000u : 0u) : 0u));
+        }
         stype = type;
         fs_wave_lds_sync();  // (the previous chunk's table requests have read plist)
         if (parked) plist[prank] = (int)slot;
@@ -2378,9 +2398,11 @@ __global__ __launch_bounds__(64) void k_fs_chain3(const float *__restrict__ X, u
         // into the other buffer, its tables requested; the chunk after it requested
         // (an item that ends in nothing passes the table test whatever the sum, a gathered one never does; a parked segment
         // whose own summary is tried first -- not on the columns this kernel serves -- takes the slow path for its table)
+        // m = {c0 + 32 mlo, mlo, mhi - mlo, +-2^(e-18)}: with mml = (r' - m.x) >> 5 the window test is 0 <= mml <= m.z (another sign
+        // or binade: mml far outside); m.z = -1 (no table, or not this kernel's to use) never passes.
         {
-            const bool tb = ctype == kFsItTable, always = ctype == kFsItEnd || ctype == kFsItNop;
-            lit[buf][lane].m = make_int4(rM.x, tb ? rM.y : (always ? INT32_MIN : 1), tb ? rM.z : (always ? INT32_MAX : 0), rM.w);
+            const bool tb = ctype == kFsItTable, valid = tb && rM.y <= rM.z;
+            lit[buf][lane].m = make_int4((int32_t)((uint32_t)rM.x + 32u * (uint32_t)rM.y), rM.y, valid ? rM.z - rM.y : -1, rM.w);
         }
         const uint32_t ptot_cur = ptot_next;
         fs_wave_lds_sync();  // the reads of ltab and of the other buffer (the chunk walked before this one) are done
@@ -2403,42 +2425,47 @@ __global__ __launch_bounds__(64) void k_fs_chain3(const float *__restrict__ X, u
         for (uint32_t i = 0; i < cn; ++i) {
             const uint32_t inx = fs_vgpr(min(i + 1u, 63u));
             const int4 nA = lit[buf][inx].a, nB = lit[buf][inx].b, nM = lit[buf][inx].m;  // (do not depend on s: in flight behind this item)
+            // The dependent chain from the sum to the next sum, kept short: parity bit -> one multiply-add per per-parity
+            // field -> r' = r + dm -> table address -> LDS -> one addition.  The tests (run range: one unsigned compare;
+            // table window: 0 <= mml <= span) hang off it and meet in ONE ballot: the only branch of an item.
             const uint32_t sb = __float_as_uint(s);
-            const bool odd = (sb & 1u) != 0u;
-            const uint32_t rmin = (uint32_t)(odd ? A.w : A.x), rmax = (uint32_t)(odd ? B.x : A.y);
-            const uint32_t s1 = sb + (uint32_t)(odd ? B.y : A.z);
-            const int32_t mm = (int32_t)(s1 - (uint32_t)M.x) >> 5;  // (another sign or binade: far outside any window)
-            const float tv = ltab[(((uint32_t)B.w & 0x7FFFFFFFu) >> 2) + (s1 & 31u)];
+            const int32_t odd = (int32_t)(sb & 1u);
+            const uint32_t rmin = (uint32_t)fs_mad24(odd, A.w, A.x), span = (uint32_t)fs_mad24(odd, B.x, A.y);
+            const uint32_t s1 = (uint32_t)fs_mad24(odd, B.y, (int32_t)(sb + (uint32_t)A.z));
             const bool is_tab = B.w < 0;
-            const bool fast = sb >= rmin && sb <= rmax && mm >= M.y && mm <= M.z;
-            if (__builtin_amdgcn_readfirstlane(fast ? 1 : 0)) {
-                s = is_tab ? tv + (float)mm * __int_as_float(M.w) : __uint_as_float(s1);
+            const int32_t mml = (int32_t)(s1 - (uint32_t)M.x) >> 5;
+            const float tv = ltab[(((uint32_t)B.w & 0x7FFFFFFFu) >> 2) + (s1 & 31u)];
+            // an item that ends in a table needs its window; one that ends in nothing (the batch's end) needs nothing more;
+            // anything else (a gathered segment, forms this kernel does not serve) leaves the loop: its b.z type is not 0
+            const bool tail_ok = is_tab ? (mml >= 0 && mml <= M.z) : (((uint32_t)B.z & 7u) == kFsItEnd);
+            const bool fast = (sb - rmin) <= span && tail_ok;
+            if (__ballot(fast) != 0ull) {  // (every lane holds the same sum: any == all)
+                s = is_tab ? tv + (float)(mml + M.y) * __int_as_float(M.w) : __uint_as_float(s1);
                 if (DBG) n_hit += is_tab ? 1u : 0u;
             } else {
                 const unsigned long long q_o = DBG ? clock64() : 0ull;
                 ++n_out;
                 const uint32_t info = (uint32_t)__builtin_amdgcn_readfirstlane(B.z), ty = info & 7u, tseg = (info >> 3) & 511u;
-                const bool ok = sb >= rmin && sb <= rmax;
-                // (M is the item's table record only for type 1: a parked segment whose own summary comes first -- no such item
-                // on the columns this kernel serves -- is re-added when that summary does not hold)
-                const int32_t Mt_y = (ty == kFsItTable) ? M.y : 1, Mt_z = (ty == kFsItTable) ? M.z : 0;
+                const bool ok = (sb - rmin) <= span;
                 // where the run starts: behind what the item in front consumed
                 uint32_t from = pos;
                 if (i > 0u) {
                     const uint32_t pi = (uint32_t)__builtin_amdgcn_readfirstlane(lit[buf][i - 1u].b.z), pt = pi & 7u, ps = (pi >> 3) & 511u;
                     from = pt == kFsItEnd ? 0u : (pt == kFsItNop ? ps : ps + 1u);
                 }
-                bool need_table = ty == kFsItTable;
-                if (__builtin_amdgcn_readfirstlane(ok ? 1 : 0)) s = __uint_as_float(s1);
+                // (a parked segment whose own summary comes first -- no such item on the columns this kernel serves -- is re-added
+                // when that summary does not hold: m is its table record only for type 1)
+                bool need_table = ty == kFsItTable, table_ok = ty == kFsItTable;
+                if (__ballot(ok) != 0ull) s = __uint_as_float(s1);
                 else if (ty == kFsItSeg) need_table = true;
                 else walk(ct0 + from, ct0 + (ty == kFsItEnd ? info >> 3 : tseg));
                 if (need_table) {
                     const uint32_t sb3 = __float_as_uint(s);
                     const int32_t m3 = (int32_t)(sb3 - (uint32_t)M.x) >> 5;
-                    const bool hit3 = m3 >= Mt_y && m3 <= Mt_z;
-                    if (__builtin_amdgcn_readfirstlane(hit3 ? 1 : 0)) {
+                    const bool hit3 = table_ok && m3 >= 0 && m3 <= M.z;
+                    if (__ballot(hit3) != 0ull) {
                         const float tv3 = ltab[(((uint32_t)B.w & 0x7FFFFFFFu) >> 2) + (sb3 & 31u)];
-                        s = tv3 + (float)m3 * __int_as_float(M.w);
+                        s = tv3 + (float)(m3 + M.y) * __int_as_float(M.w);
                         if (DBG) ++n_hit;
                     } else {
                         const unsigned long long q_ms = DBG ? clock64() : 0ull;
