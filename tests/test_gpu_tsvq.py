@@ -73,6 +73,47 @@ def test_build_zero_mean_long_nodes_bit_identical(oracle, kind, shape):
     _assert_same_tree(got, oracle.tsvq_build(X, depth))
 
 
+@pytest.mark.parametrize("shape", [(150_003, 96, 4), (90_001, 160, 3)])
+def test_build_mixed_columns_both_chain_forms_and_the_policy_cache(oracle, shape):
+    """Column blocks of both kinds in one data set -- zero-mean blocks (exact guess: tables + items + the one-pass chain,
+    round 5) next to blocks with |mean| >= sigma (sampled guess: round 4's chain) -- so that both forms run in the same
+    mean pass, each on its own columns; a last block mixes both kinds of column (one zero-mean column makes the block an
+    exact one).  Built three times on ONE library-owned data set: the second and third builds take the sampling policy
+    from the data set's cache (no k_fs_policy, only the forms that have columns are launched) and must give the first
+    one's bits; a borrowed device buffer (no cache) gives them too."""
+    import torch
+
+    n, d, depth = shape
+    rng = np.random.default_rng(n + d)
+    X = np.empty((n, d), F)
+    for c0 in range(0, d, 32):
+        blk = (c0 // 32) % 3
+        w = min(32, d - c0)
+        if blk == 0:
+            X[:, c0:c0 + w] = rng.standard_normal((n, w)).astype(F)
+        elif blk == 1:
+            X[:, c0:c0 + w] = rng.random((n, w), dtype=F) + F(0.25)
+        else:
+            X[:, c0:c0 + w] = rng.random((n, w), dtype=F) * F(3.0)
+            X[:, c0] = rng.standard_normal(n).astype(F)
+    want = oracle.tsvq_build(X, depth)
+    ds = _lib.Dataset.from_host(X)
+    first = build_tree(ds, depth)
+    _assert_same_tree(first, want)
+    for _ in range(2):
+        again = build_tree(ds, depth)
+        for a, b in zip(first, again):
+            assert a.tobytes() == b.tobytes()
+    ds.close()
+    Xd = torch.from_numpy(X).cuda()
+    borrowed = _lib.Dataset.from_device(Xd.data_ptr(), n, d, keepalive=Xd)
+    _assert_same_tree(build_tree(borrowed, depth), want)
+    Xd.mul_(-1.0)  # the caller changes the rows behind a borrowed handle: nothing about them is kept between builds
+    torch.cuda.synchronize()
+    _assert_same_tree(build_tree(borrowed, depth), oracle.tsvq_build(-X, depth))
+    borrowed.close()
+
+
 def test_build_partial_nan_and_identical_rows(oracle):
     X = _data(22, 500, 8, "normal")
     X[17, 3] = np.nan
