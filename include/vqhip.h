@@ -312,6 +312,8 @@ int vqhip_mkmeans_destroy(vqhip_mkmeans *km);
 /* world = n_devices; comm_kind as vqhip_comm_kind */
 int vqhip_mkmeans_info(vqhip_mkmeans *km, int *world, int *comm_kind);
 int vqhip_mkmeans_set_engine(vqhip_mkmeans *km, int engine);
+/* vqhip_kmeans_set_exact_update; VQHIP_ERR_UNSUPPORTED with more than one device slot */
+int vqhip_mkmeans_set_exact_update(vqhip_mkmeans *km, int exact_update);
 int vqhip_mkmeans_init_from_rows(vqhip_mkmeans *km, const uint64_t *init_rows);
 int vqhip_mkmeans_set_centroids(vqhip_mkmeans *km, const float *centroids);
 int vqhip_mkmeans_get_centroids(vqhip_mkmeans *km, float *centroids);

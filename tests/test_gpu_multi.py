@@ -33,7 +33,16 @@ def test_one_slot_is_the_single_device_fit_bit_for_bit():
     km = _lib.MKMeans(mds, m, k)
     assert km.info() == (1, 0)  # one rank: the identity communicator
     km.close()
+    # the reference's summation order through the one-slot handles: the single-device bits
+    exact = fit_codebooks(mds, m, k, 3, init_rows=init, exact_update=True)
     mds.close()
+    ds = _lib.Dataset.from_host(X)
+    np.testing.assert_array_equal(exact, fit_codebooks(ds, m, k, 3, init_rows=init, exact_update=True))
+    ds.close()
+    two = _lib.MDataset.from_host(X, [0, 0])
+    with pytest.raises(FfiError):
+        fit_codebooks(two, m, k, 3, init_rows=init, exact_update=True)
+    two.close()
     np.testing.assert_array_equal(got, want)
     enc, menc = _lib.PQEncoder(want, _lib.EUCLIDEAN), _lib.MPQEncoder(want, _lib.EUCLIDEAN, [0])
     c0, f0 = enc.encode(X)

@@ -117,6 +117,7 @@ SIGNATURES = {
     "vqhip_mkmeans_destroy": (C.c_int, [_vp]),
     "vqhip_mkmeans_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vqhip_mkmeans_set_engine": (C.c_int, [_vp, C.c_int]),
+    "vqhip_mkmeans_set_exact_update": (C.c_int, [_vp, C.c_int]),
     "vqhip_mkmeans_init_from_rows": (C.c_int, [_vp, _u64p]),
     "vqhip_mkmeans_set_centroids": (C.c_int, [_vp, _f32p]),
     "vqhip_mkmeans_get_centroids": (C.c_int, [_vp, _f32p]),
@@ -471,8 +472,7 @@ class MKMeans(Handle):
         check(load().vqhip_mkmeans_set_engine(self.raw, engine))
 
     def set_exact_update(self, on: bool):
-        if on and self.ds.devices.size > 1:
-            raise FfiError("exact_update sums rows in one sequential chain: single GPU only", ERR_UNSUPPORTED)
+        check(load().vqhip_mkmeans_set_exact_update(self.raw, 1 if on else 0))
 
     def set_centroids(self, c):
         c = f32c(c).reshape(self.m, self.k, self.sd)

@@ -284,6 +284,13 @@ int vqhip_mkmeans_info(vqhip_mkmeans *km, int *world, int *comm_kind) {
     })
 
 int vqhip_mkmeans_set_engine(vqhip_mkmeans *km, int engine) { VQ_M_ALL(km, vqhip_kmeans_set_engine(h, engine)); }
+// (the reference's summation order is one sequential chain over all rows: one device slot only)
+int vqhip_mkmeans_set_exact_update(vqhip_mkmeans *km, int exact_update) {
+    if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    if (exact_update && km->mds->team->world() > 1)
+        return fail(VQHIP_ERR_UNSUPPORTED, "exact_update sums rows in one sequential chain: single GPU only");
+    VQ_M_ALL(km, vqhip_kmeans_set_exact_update(h, exact_update));
+}
 int vqhip_mkmeans_set_centroids(vqhip_mkmeans *km, const float *centroids) { VQ_M_ALL(km, vqhip_kmeans_set_centroids(h, centroids)); }
 int vqhip_mkmeans_set_active(vqhip_mkmeans *km, const uint8_t *active) { VQ_M_ALL(km, vqhip_kmeans_set_active(h, active)); }
 int vqhip_mkmeans_init_from_rows(vqhip_mkmeans *km, const uint64_t *init_rows) {
