@@ -74,6 +74,7 @@ struct NodeArrays {
     uint32_t *child_local;            // [cap][2] level-local index of children in the NEXT level
     float *centroid;                  // [cap][d]
     float *var;                       // [cap][d]
+    uint32_t fs_seg_stride;           // k_fs_*: segment summaries are [column][segment slot], this many slots per column
 };
 
 // order-preserving map f32 -> u32 (total order: -NaN < -inf < ... < -0 < +0 < ... < +inf < +NaN)
@@ -1082,6 +1083,9 @@ __global__ __launch_bounds__(64, 2) void k_fs_fold(const float *__restrict__ X, 
         p_hi0[8][kFsCols], p_hi1[8][kFsCols], p_bad[8][kFsCols], p_gb[8][kFsCols];
     __shared__ __attribute__((aligned(16))) float p_s1[8][kFsCols], p_s2[8][kFsCols];
     __shared__ int pslot[2][kFsCols];
+    // the tile's summaries [segment of the tile][column] (rows padded to 33 x 16 bytes: the write-out reads eight rows at
+    // once), written out per column when the tile is done: 128 contiguous bytes each (summaries are [column][segment])
+    __shared__ __attribute__((aligned(16))) FsS t_sum[kFsSegsPerTile][kFsCols + 1];
     const uint32_t ncb = (d + kFsCols - 1) / kFsCols;  // the last column block may be short (d % 4 == 0)
     const uint32_t n_tasks = lv->n_tiles * ncb;
     const uint32_t lane = threadIdx.x, q = lane & 7u, g = lane >> 3;  // load / fold role
@@ -1322,7 +1326,7 @@ __global__ __launch_bounds__(64, 2) void k_fs_fold(const float *__restrict__ X, 
                 }
                 if (seg_live && c < d) {
                     const bool two = f.d0 != f.d1 || f.lo0 != f.lo1 || f.hi0 != f.hi1;
-                    const size_t at = ((size_t)cur.tile_id * kFsSegsPerTile + 2 * cur.b + sg) * d + c;
+                    const size_t at = (size_t)c * na.fs_seg_stride + (size_t)cur.tile_id * kFsSegsPerTile + 2 * cur.b + sg;
                     // for k_fs_prep's tables: the guess the segment was folded under, this pass's tag (tells its slots from what
                     // an earlier pass left in the unused rest of a chunk), where its summary is, and whether the guess is a sampled one
                     if (slot >= 0 && side_meta)
@@ -1330,7 +1334,7 @@ __global__ __launch_bounds__(64, 2) void k_fs_fold(const float *__restrict__ X, 
                     FsS o;
                     o.d = f.d0, o.lo = f.lo0, o.hi = f.hi0;
                     o.ef = fs_ef(anybad, two, (int)((gb >> 23) & 0xFFu) - 127, slot) | (int32_t)(gb & 0x80000000u);
-                    summ[at] = o;
+                    t_sum[2 * cur.b + sg][cl] = o;
                     if (two) {
                         FsS o2;
                         o2.d = f.d1, o2.lo = f.lo1, o2.hi = f.hi1, o2.ef = 0;
@@ -1357,6 +1361,17 @@ __global__ __launch_bounds__(64, 2) void k_fs_fold(const float *__restrict__ X, 
                     for (int i4 = 0; i4 < 4; ++i4) dst[i4] = make_float4(w[4 * i4][j], w[4 * i4 + 1][j], w[4 * i4 + 2][j], w[4 * i4 + 3][j]);
                 }
             }
+        }
+        if (cur.b == kFsBlksPerTile - 1) {  // the tile's last block: its summaries out, eight lanes per column (one whole line)
+            fs_wave_lds_sync();
+            const uint32_t piece = lane & 7u;
+#pragma unroll
+            for (uint32_t i = 0; i < kFsCols / 8; ++i) {
+                const uint32_t col = 8u * i + (lane >> 3);
+                if (cur.c0 + col < d)  // (slots past the node's last segment receive what an earlier tile left: nobody reads them)
+                    summ[(size_t)(cur.c0 + col) * na.fs_seg_stride + (size_t)cur.tile_id * kFsSegsPerTile + piece] = t_sum[piece][col];
+            }
+            fs_wave_lds_sync();  // (the next tile's first block writes t_sum again)
         }
         if (MODE == 0 && tile_mom && (cur.b == kFsBlksPerTile - 1)) {  // the tile's last block: its sums out, reset
             if (sg == 0 && cur.c0 + cl < d) tile_mom[(size_t)cur.tile_id * d + cur.c0 + cl] = make_double2(mom1, mom2);
@@ -1450,7 +1465,7 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
     const uint32_t a = na.seg_start[node], len = na.seg_len[node];
     const uint32_t nseg = (len + kFsSeg - 1) / kFsSeg;
     const size_t seg0 = (size_t)tile_base[blockIdx.x] * kFsSegsPerTile;
-    const FsS *sp = summ + seg0 * d + c, *sp2 = summ_odd + seg0 * d + c;
+    const FsS *sp = summ + (size_t)c * na.fs_seg_stride + seg0, *sp2 = summ_odd + (size_t)c * na.fs_seg_stride + seg0;
     const float mu = (MODE == 1) ? na.centroid[(size_t)node * d + c] : 0.0f;
     float s = (MODE == 0) ? 0.0f : -0.0f;
     uint32_t fallbacks = 0;
@@ -1465,7 +1480,7 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
     // (~3 us).  What lies past the node's end is marked unusable when the registers are consumed.
     auto load4 = [&](uint32_t tstart, FsS (&m)[kFsSpl]) {
 #pragma unroll
-        for (int j = 0; j < kFsSpl; ++j) m[j] = sp[(size_t)min(tstart + kFsSpl * lane + (uint32_t)j, nseg - 1u) * d];
+        for (int j = 0; j < kFsSpl; ++j) m[j] = sp[min(tstart + kFsSpl * lane + (uint32_t)j, nseg - 1u)];
     };
     // summaries of the next batches in flight behind the one being scanned (a batch's scan is shorter than a memory round
     // trip): a set is consumed two iterations after its loads were issued
@@ -1496,7 +1511,7 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
 #pragma unroll
             for (int j = 0; j < kFsSpl; ++j)
                 if ((m[j].ef & 3) == 2) {
-                    const FsS o = sp2[(size_t)(t0 + kFsSpl * lane + (uint32_t)j) * d];
+                    const FsS o = sp2[t0 + kFsSpl * lane + (uint32_t)j];
                     m2[j].d = o.d, m2[j].lo = o.lo, m2[j].hi = o.hi;
                 }
         }
@@ -2170,52 +2185,30 @@ __global__ __launch_bounds__(256) void k_fs_prep(const float *__restrict__ side,
         fs_tables_wave(lane, blockIdx.x * 4u + w, n_tab_blocks * 4u, side, side_meta, pass_tag, side_count, side_cap, summ, summ_odd, tab, tmeta);
         return;
     }
-    // ---- items: one batch x four adjacent columns per workgroup.  The summaries are [segment][column]: the 512 x 4 block is
-    // fetched by all four waves together (four threads per segment: one 64-byte sector each) and handed to the waves
-    // through LDS, column by column -- a wave reading its own column took 16 bytes out of every sector it touched.
-    __shared__ __attribute__((aligned(16))) FsS lsm[4][kFsBatch];  // [column][j * 64 + lane]: segment 8 lane + j
+    // ---- items: one batch x four adjacent columns per workgroup, a wave per column.  The summaries are [column][segment]:
+    // a lane's eight are one 128-byte line
     const uint32_t cq = (d + 3) / 4, q = blockIdx.x - n_tab_blocks, G = q / cq, c0 = (q - G * cq) * 4u, c = c0 + w;
     if (G >= lv->pad) return;  // (pad = the level's batches; launched over an upper bound)
     const bool seg_first = policy ? policy[c0 / kFsCols] != 0u : seg_first_default != 0;  // (policy: 1 = sampled guess allowed for the column block)
     if (seg_first) return;  // columns under a sampled guess keep k_fs_chain (uniform over the workgroup: four columns of one block of 32)
+    if (c >= d) return;
     const uint2 bt = batch_tab[G];
     const uint32_t node = fast_nodes[bt.x], len = na.seg_len[node];
     const uint32_t nseg = (len + kFsSeg - 1) / kFsSeg, t0 = bt.y * kFsBatch, cnt = min(kFsBatch, nseg - t0);
     const size_t seg0 = (size_t)tile_base[bt.x] * kFsSegsPerTile;
-    const uint32_t col = threadIdx.x & 3u, sg0 = threadIdx.x >> 2;  // this thread's column of the four, its segment in a group of 64
-    const bool col_ok = c0 + col < d;
-    const FsS *gp = summ + seg0 * d + (col_ok ? c0 + col : c0), *gp2 = summ_odd + seg0 * d + (col_ok ? c0 + col : c0);
-    FsS e[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) e[r] = gp[(size_t)min(t0 + (uint32_t)r * 64u + sg0, nseg - 1u) * d];  // unconditional, clamped
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const uint32_t sgi = (uint32_t)r * 64u + sg0;
-        lsm[col][(sgi & 7u) * 64u + (sgi >> 3)] = e[r];
-    }
-    __syncthreads();
+    const FsS *gp = summ + (size_t)c * na.fs_seg_stride + seg0, *gp2 = summ_odd + (size_t)c * na.fs_seg_stride + seg0;
     FsS m[kFsSpl], m2[kFsSpl];
 #pragma unroll
-    for (int j = 0; j < kFsSpl; ++j) m[j] = lsm[w][(uint32_t)j * 64u + lane];
-    __syncthreads();
+    for (int j = 0; j < kFsSpl; ++j) m[j] = gp[min(t0 + kFsSpl * lane + (uint32_t)j, nseg - 1u)];  // unconditional, clamped
     // the odd streams of the runs with an exact tie, else a copy of the even ones
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const uint32_t sgi = (uint32_t)r * 64u + sg0;
-        if (sgi < cnt && (e[r].ef & 3) == 2) {
-            const FsS o = gp2[(size_t)(t0 + sgi) * d];
-            e[r].d = o.d, e[r].lo = o.lo, e[r].hi = o.hi;
+    for (int j = 0; j < kFsSpl; ++j) {
+        m2[j] = m[j];
+        if (kFsSpl * lane + (uint32_t)j < cnt && (m[j].ef & 3) == 2) {
+            const FsS o = gp2[t0 + kFsSpl * lane + (uint32_t)j];
+            m2[j].d = o.d, m2[j].lo = o.lo, m2[j].hi = o.hi;
         }
     }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const uint32_t sgi = (uint32_t)r * 64u + sg0;
-        lsm[col][(sgi & 7u) * 64u + (sgi >> 3)] = e[r];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kFsSpl; ++j) m2[j] = lsm[w][(uint32_t)j * 64u + lane];
-    if (c >= d) return;
     fs_items_wave(lane, c, d, G, cnt, m, m2, items, ihdr, seg_first);
 }
 
@@ -2256,7 +2249,7 @@ __global__ __launch_bounds__(64) void k_fs_chain3(const float *__restrict__ X, u
     const uint32_t a = na.seg_start[node], len = na.seg_len[node];
     const uint32_t nseg = (len + kFsSeg - 1) / kFsSeg, nbat = (nseg + kFsBatch - 1) / kFsBatch, G0 = batch_base[fidx];
     const size_t seg0 = (size_t)tile_base[fidx] * kFsSegsPerTile;
-    const FsS *sp = summ + seg0 * d + c, *sp2 = summ_odd + seg0 * d + c;
+    const FsS *sp = summ + (size_t)c * na.fs_seg_stride + seg0, *sp2 = summ_odd + (size_t)c * na.fs_seg_stride + seg0;
     const float mu = (MODE == 1) ? na.centroid[(size_t)node * d + c] : 0.0f;
     float s = (MODE == 0) ? 0.0f : -0.0f;
     uint32_t n_readd = 0, n_hit = 0, n_miss = 0, n_slow = 0, n_parked = 0, n_own = 0, n_out = 0;
@@ -2291,9 +2284,9 @@ __global__ __launch_bounds__(64) void k_fs_chain3(const float *__restrict__ X, u
         ++n_slow;
         for (uint32_t q0 = from; q0 < to; q0 += 64u) {
             const uint32_t q = min(q0 + lane, to - 1u);
-            const FsS g = sp[(size_t)q * d];
+            const FsS g = sp[q];
             FsS g2 = g;
-            if ((g.ef & 3) == 2) g2 = sp2[(size_t)q * d];
+            if ((g.ef & 3) == 2) g2 = sp2[q];
             fs_wave_lds_sync();
             lwk[lane] = g, lwk2[lane] = g2;
             fs_wave_lds_sync();
@@ -2533,9 +2526,9 @@ __global__ __launch_bounds__(64) void k_fs_check(const float *__restrict__ X, ui
     const float mu = (MODE == 1) ? na.centroid[(size_t)node * d + c] : 0.0f;
     float s = (MODE == 0) ? 0.0f : -0.0f;
     for (uint32_t t = 0; t < nseg; ++t) {
-        const FsS sm = summ[(seg0 + t) * d + c];
+        const FsS sm = summ[(size_t)c * na.fs_seg_stride + seg0 + t];
         FsS so = sm;
-        if ((sm.ef & 3) == 2) so = summ_odd[(seg0 + t) * d + c];
+        if ((sm.ef & 3) == 2) so = summ_odd[(size_t)c * na.fs_seg_stride + seg0 + t];
         float seq = s;
         const uint32_t r0 = t * kFsSeg, r1 = min(len, r0 + kFsSeg);
         for (uint32_t r = r0; r < r1; ++r) seq = seq + fs_value<MODE>(X[(size_t)perm[a + r] * d + c], mu);
@@ -2924,6 +2917,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     na.child_local = ws.b_child.as<uint32_t>();
     na.centroid = ws.b_cent.as<float>();
     na.var = ws.b_var.as<float>();
+    na.fs_seg_stride = 0;
     int32_t *node_left = ws.b_left.as<int32_t>(), *node_right = ws.b_right.as<int32_t>();
     LevelInfo *lv = ws.b_lv.as<LevelInfo>();
 
@@ -2939,6 +2933,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     const float park_rel = fs_sample > 1 ? 3.0f * 0.6f * sqrtf((float)fs_sample / (float)kFsTile) : 0.0f;  // k_fs_fold: parking margin
     // segment summaries [segment slot][column]: eight slots per tile, a node's segments contiguous
     const size_t seg_slots = (size_t)tiles_max * kFsSegsPerTile;
+    na.fs_seg_stride = (uint32_t)seg_slots;  // (a multiple of 8: a tile's eight summaries of a column are one aligned 128-byte line)
     // parked segments per pass (256 bytes each; beyond the cap the re-addition gathers its rows, two dependent loads): half
     // of all segments (zero-mean columns park up to a third at the deeper levels), 256 MB at most
     const uint32_t side_cap = (nopark && nopark[0] == '1') ? 0u : (uint32_t)std::min<uint64_t>(seg_slots * d / 2 + 1, 1ull << 20);
