@@ -1882,6 +1882,481 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
     }
 }
 
+// ---- the chain with its operands in LDS ahead of time (round 5) -------------------------------------------------------
+// k_fs_chain above keeps the next batches of summaries in registers and fetches parked addends eight segments at a time
+// on demand.  Measured (VQHIP_TSVQ_DEBUG, C4): a batch of 512 summaries that holds costs ~6000 cycles where its
+// instructions are ~2000 -- the register sets are rotated by moves, a move waits for the newest load, so the look-ahead
+// is one batch deep and every batch pays what is left of a memory round trip; and the first re-addition of a batch waits
+// 600 .. 25000 cycles for its addends (the groups of eight are requested one after the other).  Here nothing the walk
+// reads comes from memory: summaries and parked addends are written into LDS rings by LDS-DMA loads
+// (global_load_lds_dwordx4: no destination registers, so the look-ahead is as deep as the ring) issued a fixed number of
+// iterations ahead, and the only waits are s_waitcnt vmcnt(N) with N = the number of DMA instructions issued SINCE the
+// ones needed -- exact, because every iteration issues the same count (8 for a batch of summaries + P4 for its parked
+// segments, padded with loads of a dummy line).  The loads are written in inline assembly: the compiler neither knows
+// nor tracks them (its own waits for ordinary loads can only become more conservative, never wrong: loads return in
+// order) -- profiles/ubench/lds_dma.hip checks placement and the counting rule on the device.
+//   DEEP = 0: parked addends one batch ahead, summaries two (three + two ring slots, 33 KB: four waves per CU);
+//   DEEP = 1: two / four batches ahead (five + three slots, 60 KB: two waves per CU -- levels with few, long chains).
+// Everything else -- lane runs of eight segments, wave scan, the eight-lane scan of a failing lane, 64 dependent
+// additions per re-added segment -- is k_fs_chain's; every sum is still the reference's bit pattern.
+__device__ __forceinline__ void fs_dma16(const void *gp, uint32_t lds_byte_addr) {  // lane l: 16 bytes from gp to lds_byte_addr + 16 l
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lds_byte_addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void fs_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int MODE, bool DBG, int DEEP>
+__global__ __launch_bounds__(128) void k_fs_chain4(const float *__restrict__ X, uint32_t d, const uint32_t *__restrict__ perm,
+                                                   const uint32_t *__restrict__ fast_nodes, const uint32_t *__restrict__ tile_base,
+                                                   NodeArrays na, const FsS *__restrict__ summ, const FsS *__restrict__ summ_odd,
+                                                   const float *__restrict__ side, uint32_t *__restrict__ n_fallback,
+                                                   const LevelInfo *__restrict__ lv, uint32_t *__restrict__ dbg_arg,
+                                                   const uint32_t *__restrict__ only_sampled) {
+    uint32_t *const dbg = DBG ? dbg_arg : nullptr;
+    if (only_sampled && only_sampled[blockIdx.y / kFsCols] == 0u) return;
+    constexpr uint32_t kBatch = 64 * kFsSpl;
+    constexpr int A = DEEP ? 2 : 1, B = DEEP ? 4 : 2;  // batches ahead: parked addends, summaries
+    constexpr int NS = B + 1, NP = A + 1;              // ring slots
+    constexpr int P4 = DEEP ? 6 : 4;                   // parked DMA instructions per batch, four segments each
+    constexpr uint32_t PCAP = 4 * P4;                  // parked segments of a batch fetched ahead (the rest: on demand)
+    __shared__ __attribute__((aligned(16))) FsS sring[NS][kBatch];       // [slot][j * 64 + lane]: segment 8 lane + j of the batch
+    __shared__ __attribute__((aligned(16))) float pring[NP][PCAP * 64];  // [slot][rank among the batch's parked][row]
+    __shared__ int plist[NP][kBatch];                                   // side slots of the batch's parked segments, in order
+    __shared__ uint2 pinfo[NP][64];                                     // per lane: parked segments in front of the lane's, its own (bit j)
+    __shared__ __attribute__((aligned(16))) float ladd[64];             // addends of a segment fetched on demand
+    __shared__ uint32_t sync_ready, sync_done;                          // batches the loader has made ready / the walker is done with
+    if (blockIdx.x >= lv->n_fast) return;
+    const uint32_t node = fast_nodes[blockIdx.x], c = blockIdx.y, lane = threadIdx.x & 63u;
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: the walker, 1: the loader
+    const uint32_t a = na.seg_start[node], len = na.seg_len[node];
+    const uint32_t nseg = (len + kFsSeg - 1) / kFsSeg, nb = (nseg + kBatch - 1) / kBatch;
+    const size_t seg0 = (size_t)tile_base[blockIdx.x] * kFsSegsPerTile;
+    const FsS *sp = summ + (size_t)c * na.fs_seg_stride + seg0, *sp2 = summ_odd + (size_t)c * na.fs_seg_stride + seg0;
+    if (threadIdx.x == 0) sync_ready = 0u, sync_done = 0u;
+    __syncthreads();
+    // the flags: plain LDS words, ordered against the LDS data around them by LDS-only fences (a release / acquire over all
+    // address spaces would also wait for the loader's DMA queue -- the very thing that must stay in flight)
+    auto flag_wait = [&](uint32_t *flag, uint32_t want) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+    auto flag_set = [&](uint32_t *flag, uint32_t v) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    const uint32_t pring_addr = (uint32_t)(uintptr_t)&pring[0][0];
+    if (role == 1u) {
+        // ================= the loader: DMA queue, parked lists ==========================================================
+        const uint32_t sring_addr = (uint32_t)(uintptr_t)&sring[0][0];
+        // eight DMA instructions: the summaries of batch b (clamped at the node's last segment: a batch past the end re-reads it)
+        auto issue_summ = [&](uint32_t b) {
+            const uint32_t base = sring_addr + (b % (uint32_t)NS) * (uint32_t)(kBatch * sizeof(FsS));
+            if ((b + 1u) * kBatch <= nseg) {  // uniform: a whole batch, one address
+                const FsS *p0 = sp + (b * kBatch + kFsSpl * lane);
+#pragma unroll
+                for (int j = 0; j < kFsSpl; ++j) fs_dma16(p0 + j, base + (uint32_t)j * 1024u);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kFsSpl; ++j)
+                    fs_dma16(sp + min(b * kBatch + kFsSpl * lane + (uint32_t)j, nseg - 1u), base + (uint32_t)j * 1024u);
+            }
+        };
+        // batch b's summaries are in their slot: its parked segments listed in order, the addends of the first PCAP requested
+        // with EXACTLY P4 DMA instructions (sixteen lanes per segment; ranks past the batch's count read a line of summaries)
+        auto issue_parked = [&](uint32_t b) {
+            const uint32_t ss = b % (uint32_t)NS, ps = b % (uint32_t)NP;
+            uint32_t efv[kFsSpl];
+#pragma unroll
+            for (int j = 0; j < kFsSpl; ++j) efv[j] = fs_vgpr((uint32_t)sring[ss][(uint32_t)j * 64u + lane].ef);  // (all eight reads in flight)
+            const uint32_t left = nseg - min(nseg, b * kBatch + kFsSpl * lane);  // this lane's segments inside the node, if < 8
+            uint32_t pk = 0;
+#pragma unroll
+            for (int j = 0; j < kFsSpl; ++j) pk |= ((efv[j] >> 10) & 0x1FFFFFu) != 0u && (uint32_t)j < left ? (1u << j) : 0u;
+            const uint32_t pc = (uint32_t)__builtin_popcount(pk);
+            uint32_t pincl = pc;
+#define VQ_FS_ADD(CTRL, COND) { const int32_t t = __builtin_amdgcn_update_dpp(0, (int32_t)pincl, CTRL, 0xF, 0xF, true); if (COND) pincl += (uint32_t)t; }
+            VQ_FS_ADD(0x111, (lane & 15u) >= 1u)
+            VQ_FS_ADD(0x112, (lane & 15u) >= 2u)
+            VQ_FS_ADD(0x114, (lane & 15u) >= 4u)
+            VQ_FS_ADD(0x118, (lane & 15u) >= 8u)
+            VQ_FS_ADD(0x142, (lane & 16u) != 0u)
+            VQ_FS_ADD(0x143, lane >= 32u)
+#undef VQ_FS_ADD
+            const uint32_t pbefore = pincl - pc, ptotal = (uint32_t)__builtin_amdgcn_readlane((int)pincl, 63);
+            pinfo[ps][lane] = make_uint2(pbefore, pk);
+            const uint32_t pdst = pring_addr + ps * (PCAP * 256u);
+            const char *const dummy = reinterpret_cast<const char *>(sp) + 16u * (lane & 15u);
+            if (ptotal == 0u) {  // uniform: most batches -- the count of DMA instructions stays what the waits assume
+#pragma unroll
+                for (int i = 0; i < P4; ++i) fs_dma16(dummy, pdst + (uint32_t)i * 1024u);
+                return;
+            }
+            uint32_t r = pbefore;
+#pragma unroll
+            for (int j = 0; j < kFsSpl; ++j)
+                if (pk & (1u << j)) plist[ps][r++] = (int)((efv[j] >> 10) & 0x1FFFFFu) - 1;
+            fs_wave_lds_sync();
+            const uint32_t have = min(ptotal, PCAP);
+            uint32_t slot[P4];
+#pragma unroll
+            for (int i = 0; i < P4; ++i) slot[i] = fs_vgpr((uint32_t)plist[ps][min(4u * (uint32_t)i + (lane >> 4), PCAP - 1u)]);
+#pragma unroll
+            for (int i = 0; i < P4; ++i) {
+                const uint32_t rank = 4u * (uint32_t)i + (lane >> 4);
+                const char *src = reinterpret_cast<const char *>(side + (size_t)slot[i] * kFsSeg) + 16u * (lane & 15u);
+                fs_dma16((rank < have) ? src : dummy, pdst + (uint32_t)i * 1024u);
+            }
+        };
+#pragma unroll
+        for (int b = 0; b < B; ++b) issue_summ((uint32_t)b);
+        fs_wait_vm<0>();
+        fs_wave_lds_sync();
+#pragma unroll
+        for (int b = 0; b < A; ++b) issue_parked((uint32_t)b);
+        bool prev_issued = false;  // the queue starts empty for the counted wait (DEEP: drained here)
+        if (DEEP) fs_wait_vm<0>();
+        unsigned long long l_all = dbg ? clock64() : 0ull, l_vm = 0ull, l_done = 0ull;  // VQHIP_TSVQ_DEBUG
+        for (uint32_t t = 0; t < nb; ++t) {
+            const unsigned long long q0 = dbg ? clock64() : 0ull;
+            // batch t is complete once its parked addends and (for the list built next) the summaries of batch t + A have
+            // landed: everything issued before the previous iteration (DEEP) / before this one
+            if (DEEP && prev_issued) fs_wait_vm<P4 + 8>();
+            else fs_wait_vm<0>();
+            if (dbg) l_vm += clock64() - q0;
+            flag_set(&sync_ready, t + 1u);
+            if (t + (uint32_t)A >= nb) {  // nothing left to request (what is in flight is waited for above, batch by batch)
+                prev_issued = false;
+                continue;
+            }
+            const unsigned long long q1 = dbg ? clock64() : 0ull;
+            if (t > 0u) flag_wait(&sync_done, t);  // the slots written next are batch t - 1's
+            if (dbg) l_done += clock64() - q1;
+            issue_parked(t + (uint32_t)A);
+            issue_summ(t + (uint32_t)B);
+            prev_issued = true;
+        }
+        fs_wait_vm<0>();  // (nothing may land in LDS after the wave has gone)
+        if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
+            printf("[vqhip-dev] chain4(0,0) mode %d loader: %u batches, %.0f k cycles: waiting for DMA %.0f k, for the walker %.0f k\n", MODE, nb,
+                   (double)(clock64() - l_all) / 1e3, (double)l_vm / 1e3, (double)l_done / 1e3);
+        return;
+    }
+
+    // ===================== the walker: k_fs_chain's batch loop over operands that are already in LDS ====================
+    const float mu = (MODE == 1) ? na.centroid[(size_t)node * d + c] : 0.0f;
+    float s = (MODE == 0) ? 0.0f : -0.0f;
+    uint32_t fallbacks = 0, n_walks = 0;
+    const unsigned long long cyc_all = dbg ? clock64() : 0ull;
+    unsigned long long w_ready = 0ull, w_walk = 0ull;  // VQHIP_TSVQ_DEBUG: waiting for the loader, inside failing lanes
+    auto add64 = [&](const float *lds64) {  // 64 additions in row order, the addends by broadcast LDS reads (k_fs_chain)
+        const f32x4_t *l4 = reinterpret_cast<const f32x4_t *>(lds64);
+        f32x4_t rq[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) rq[g] = l4[g];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            s = s + rq[g][0];
+            s = s + rq[g][1];
+            s = s + rq[g][2];
+            s = s + rq[g][3];
+        }
+    };
+    for (uint32_t t = 0; t < nb; ++t) {
+        const uint32_t t0 = t * kBatch, cnt = min(kBatch, nseg - t0), nl = (cnt + kFsSpl - 1) / kFsSpl;
+        const unsigned long long w0 = dbg ? clock64() : 0ull;
+        flag_wait(&sync_ready, t + 1u);
+        if (dbg) w_ready += clock64() - w0;
+        const uint32_t ss = t % (uint32_t)NS, ps = t % (uint32_t)NP;
+        FsS m[kFsSpl];
+#pragma unroll
+        for (int j = 0; j < kFsSpl; ++j) m[j] = sring[ss][(uint32_t)j * 64u + lane];
+        const uint2 pi = pinfo[ps][lane];
+        if (cnt < kBatch) {  // uniform: the node's last batch -- what lies past its end is unusable
+#pragma unroll
+            for (int j = 0; j < kFsSpl; ++j)
+                if (kFsSpl * lane + (uint32_t)j >= cnt) m[j].d = m[j].lo = m[j].hi = 0, m[j].ef = 1;
+        }
+        const uint32_t pbefore = pi.x, pk = pi.y;
+        if (dbg && lane == 63) atomicAdd(dbg + 14, pbefore + (uint32_t)__builtin_popcount(pk));
+        // flags of the lane's run: any summary unusable, binades differ, any odd stream (bit 1; with bit 0 set the run is
+        // unusable anyway and the two-stream path is merely taken for nothing)
+        uint32_t ef_or = (uint32_t)m[0].ef, ef_x = 0u;
+#pragma unroll
+        for (int j = 1; j < kFsSpl; ++j) ef_or |= (uint32_t)m[j].ef, ef_x |= (uint32_t)(m[j].ef ^ m[0].ef);
+        const int lane_bad = (int)((ef_or & 1u) | ((ef_x & 0x3FCu) ? 1u : 0u));
+        const int lane_e = fs_ef_e(m[0].ef);
+        const bool two = __ballot((ef_or & 2u) != 0u) != 0ull;
+        // ---- this lane's run: its segments composed ----
+        FsT mine;
+        mine.d0 = m[0].d, mine.lo0 = m[0].lo, mine.hi0 = m[0].hi;
+#pragma unroll
+        for (int j = 1; j < kFsSpl; ++j) {
+            mine.lo0 = min(mine.lo0, mine.d0 + m[j].lo);
+            mine.hi0 = max(mine.hi0, mine.d0 + m[j].hi);
+            mine.d0 = mine.d0 + m[j].d;
+        }
+        mine.d1 = mine.d0, mine.lo1 = mine.lo0, mine.hi1 = mine.hi0;
+        FsS m2[kFsSpl];  // the odd streams (only set and read when `two`)
+        if (two) {  // uniform (the first batch of most chains: small sums cut few bits of an addend): the odd streams by
+                    // ordinary loads, the run composed again as a parity transducer
+            // (all eight loads unconditional and in flight together: a load under `if` is waited for on the spot -- eight
+            // memory round trips in a row; what a segment without a tie reads there is never used)
+            FsS o[kFsSpl];
+            const FsS *const p2 = sp2 + min(t0 + kFsSpl * lane, nseg - 1u);
+#pragma unroll
+            for (int j = 0; j < kFsSpl; ++j) o[j] = p2[min((uint32_t)j, nseg - 1u - min(t0 + kFsSpl * lane, nseg - 1u))];
+#pragma unroll
+            for (int j = 0; j < kFsSpl; ++j) {
+                o[j].d = (int32_t)fs_vgpr((uint32_t)o[j].d);
+                const bool tie = (m[j].ef & 3) == 2;
+                m2[j] = m[j];
+                m2[j].d = tie ? o[j].d : m[j].d, m2[j].lo = tie ? o[j].lo : m[j].lo, m2[j].hi = tie ? o[j].hi : m[j].hi;
+            }
+            mine.d0 = m[0].d, mine.lo0 = m[0].lo, mine.hi0 = m[0].hi, mine.d1 = m2[0].d, mine.lo1 = m2[0].lo, mine.hi1 = m2[0].hi;
+#pragma unroll
+            for (int j = 1; j < kFsSpl; ++j) {
+                FsT gj;
+                gj.d0 = m[j].d, gj.lo0 = m[j].lo, gj.hi0 = m[j].hi, gj.d1 = m2[j].d, gj.lo1 = m2[j].lo, gj.hi1 = m2[j].hi;
+                mine = fs_compose(mine, gj);
+            }
+        }
+        // the 64 rows of segment `seg` re-added in the reference's order (uniform: every lane carries the same s)
+        uint32_t pr_base = 0;  // rank of the parked segment at the front of this batch's ring slot
+        auto readd = [&](uint32_t seg, int32_t gef, uint32_t rank) {
+            ++fallbacks;
+            const int slot = fs_ef_slot(gef);
+            if (slot >= 0) {  // parked: its addends are in the ring, or the ring is moved on to it
+                if (rank >= pr_base + PCAP) {
+                    // Behind what was fetched ahead: the walk only moves forward, so the slot is refilled with the PCAP parked
+                    // segments from this one on (failures come in runs: under a sampled guess the segments between the
+                    // guessed and the true crossing were all folded under the wrong binade) -- one round trip per run,
+                    // not per segment.  The walker has nothing else in flight: vmcnt(0) is this request.
+                    const uint32_t ptotal = (uint32_t)__builtin_amdgcn_readlane((int)(pbefore + (uint32_t)__builtin_popcount(pk)), 63);
+                    fs_wave_lds_sync();
+#pragma unroll
+                    for (int i = 0; i < P4; ++i) {
+                        const int sl = plist[ps][min(rank + 4u * (uint32_t)i + (lane >> 4), ptotal - 1u)];
+                        fs_dma16(reinterpret_cast<const char *>(side + (size_t)sl * kFsSeg) + 16u * (lane & 15u),
+                                 pring_addr + ps * (PCAP * 256u) + (uint32_t)i * 1024u);
+                    }
+                    fs_wait_vm<0>();
+                    fs_wave_lds_sync();
+                    pr_base = rank;
+                    if (dbg && lane == 0) atomicAdd(dbg + 7, 1u);
+                }
+                add64(&pring[ps][(rank - pr_base) * 64u]);
+            } else {
+                float vv;
+                {
+                    const uint32_t r0 = seg * kFsSeg, rows_here = min(kFsSeg, len - r0);
+                    vv = (lane < rows_here) ? fs_value<MODE>(X[(size_t)perm[a + r0 + lane] * d + c], mu) : 0.0f;  // (+0.0 past the end)
+                    if (dbg && lane == 0) atomicAdd(dbg + 7, 1u);
+                }
+                fs_wave_lds_sync();
+                ladd[lane] = vv;
+                fs_wave_lds_sync();
+                add64(ladd);
+            }
+        };
+        // a failing lane's eight segments, scanned over eight lanes (k_fs_chain's walk_lane; the summaries come from the ring)
+        auto walk_lane = [&](uint32_t good) {
+            const uint32_t pb_g = (uint32_t)__builtin_amdgcn_readlane((int)pbefore, (int)good),
+                           pk_g = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)good);
+            const uint32_t jl = lane & 7u;
+            FsS g = sring[ss][jl * 64u + good];  // every group of eight lanes holds a copy; lanes 0..7 decide
+            const uint32_t seg_first = t0 + kFsSpl * good;
+            const uint32_t nvalid = min((uint32_t)kFsSpl, nseg - seg_first);  // this lane's segments inside the node (>= 1)
+            if (jl >= nvalid) g.d = g.lo = g.hi = 0, g.ef = 1;
+            int32_t incl8 = g.d;
+#define VQ_FS_ADD8(CTRL, K) { const int32_t t = __builtin_amdgcn_update_dpp(0, incl8, CTRL, 0xF, 0xF, true); if (jl >= K) incl8 += t; }
+            VQ_FS_ADD8(0x111, 1u)
+            VQ_FS_ADD8(0x112, 2u)
+            VQ_FS_ADD8(0x114, 4u)
+#undef VQ_FS_ADD8
+            const int32_t before8 = incl8 - g.d;
+            const bool usable = !(g.ef & 1);
+            const int g_e = fs_ef_e(g.ef);
+            const uint32_t beyond = ~0u << nvalid;  // (nvalid <= 8)
+            uint32_t start2 = 0;
+            int32_t base2 = 0;
+            for (;;) {
+                const uint32_t sb1 = __float_as_uint(s), se1 = (sb1 >> 23) & 0xFFu;
+                const int32_t mag1 = (int32_t)((sb1 & 0x7FFFFFu) | 0x800000u);
+                const int32_t S1 = (sb1 >> 31) ? -mag1 : mag1;
+                const bool ok = (se1 != 0u) && (se1 != 255u) && usable && ((int)se1 - 127 == g_e) && fs_inside(S1 + before8 - base2, g.lo, g.hi);
+                const uint32_t bad8 = (uint32_t)__ballot(!ok) & 0xFFu;
+                const uint32_t js = (uint32_t)__builtin_ctz((bad8 | beyond) & (~0u << start2));  // first that does not hold, or nvalid
+                if (js > start2) {
+                    const int32_t S2 = S1 + __builtin_amdgcn_readlane(incl8, (int)js - 1) - base2;
+                    const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
+                    s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se1 << 23) | (m2a & 0x7FFFFFu));
+                }
+                if (js >= nvalid) break;
+                const int32_t gef = __builtin_amdgcn_readlane(g.ef, (int)js);
+                if (dbg && lane == 0) {
+                    const uint32_t sb2 = __float_as_uint(s), se2 = (sb2 >> 23) & 0xFFu;  // the S the failing segment meets
+                    const int why = (se2 == 0u || se2 == 255u) ? 6 : (gef & 1) ? 3 : ((int)se2 - 127 != fs_ef_e(gef)) ? 4 : 5;
+                    atomicAdd(dbg + why, 1u);
+                }
+                readd(seg_first + js, gef, pb_g + (uint32_t)__builtin_popcount(pk_g & ((1u << js) - 1u)));
+                base2 = __builtin_amdgcn_readlane(incl8, (int)js);
+                start2 = js + 1;
+                if (start2 >= nvalid) break;
+            }
+        };
+        // two streams (an exact tie somewhere in the batch): the same with the segments' parity transducers composed over the
+        // eight lanes, the scan repeated behind every segment that does not hold (k_fs_chain's walk_lane2)
+        auto walk_lane2 = [&](uint32_t good) {
+            const uint32_t pb_g = (uint32_t)__builtin_amdgcn_readlane((int)pbefore, (int)good),
+                           pk_g = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)good);
+            const uint32_t jl = lane & 7u;
+            const uint32_t seg_first = t0 + kFsSpl * good;
+            const uint32_t nvalid = min((uint32_t)kFsSpl, nseg - seg_first);
+            FsS g = sring[ss][jl * 64u + good];
+            // the failing lane's odd streams out of its registers (lane jl takes segment jl's): no memory round trip
+            FsS g2 = g;
+#pragma unroll
+            for (int j = 0; j < kFsSpl; ++j) {
+                const int32_t od = __builtin_amdgcn_readlane(m2[j].d, (int)good), ol = __builtin_amdgcn_readlane(m2[j].lo, (int)good),
+                              oh = __builtin_amdgcn_readlane(m2[j].hi, (int)good);
+                if (jl == (uint32_t)j) g2.d = od, g2.lo = ol, g2.hi = oh;
+            }
+            if (jl >= nvalid) g.d = g.lo = g.hi = 0, g.ef = 1, g2 = g;
+            const bool usable = !(g.ef & 1);
+            const int g_e = fs_ef_e(g.ef);
+            const uint32_t beyond = ~0u << nvalid;
+            uint32_t start2 = 0;
+            for (;;) {
+                const uint32_t sb1 = __float_as_uint(s), se1 = (sb1 >> 23) & 0xFFu;
+                const int32_t mag1 = (int32_t)((sb1 & 0x7FFFFFu) | 0x800000u);
+                const int32_t S1 = (sb1 >> 31) ? -mag1 : mag1;
+                const bool in = jl >= start2;
+                FsD v;
+                v.d0 = in ? g.d : 0, v.d1 = in ? g2.d : 0;
+                fs_scan_incl8_d(v, jl);
+                const int32_t incl_d = (S1 & 1) ? v.d1 : v.d0;  // delta from segment start2 through this one, for the actual parity of S
+                int32_t before8 = __builtin_amdgcn_update_dpp(0, incl_d, 0x111, 0xF, 0xF, true);  // row_shr:1
+                if (jl == 0u) before8 = 0;
+                const int32_t Sin = S1 + before8;
+                const bool podd = (Sin & 1) != 0;
+                const bool ok = (se1 != 0u) && (se1 != 255u) && usable && ((int)se1 - 127 == g_e) &&
+                                fs_inside(Sin, podd ? g2.lo : g.lo, podd ? g2.hi : g.hi);
+                const uint32_t bad8 = (uint32_t)__ballot(!ok) & 0xFFu;
+                const uint32_t js = (uint32_t)__builtin_ctz((bad8 | beyond) & (~0u << start2));
+                if (js > start2) {
+                    const int32_t S2 = S1 + __builtin_amdgcn_readlane(incl_d, (int)js - 1);
+                    const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
+                    s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se1 << 23) | (m2a & 0x7FFFFFu));
+                }
+                if (js >= nvalid) break;
+                const int32_t gef = __builtin_amdgcn_readlane(g.ef, (int)js);
+                if (dbg && lane == 0) {
+                    const uint32_t sb2 = __float_as_uint(s), se2 = (sb2 >> 23) & 0xFFu;
+                    const int why = (se2 == 0u || se2 == 255u) ? 6 : (gef & 1) ? 3 : ((int)se2 - 127 != fs_ef_e(gef)) ? 4 : 5;
+                    atomicAdd(dbg + why, 1u);
+                }
+                readd(seg_first + js, gef, pb_g + (uint32_t)__builtin_popcount(pk_g & ((1u << js) - 1u)));
+                start2 = js + 1;
+                if (start2 >= nvalid) break;
+            }
+        };
+        const uint64_t past = nl < 64 ? (~0ull << nl) : 0ull;  // lanes behind the batch's last
+        if (!two) {
+            // one stream: the deltas simply add, ONE scan serves the whole batch
+            int32_t incl = mine.d0;
+#define VQ_FS_ADD(CTRL, COND) { const int32_t t = __builtin_amdgcn_update_dpp(0, incl, CTRL, 0xF, 0xF, true); if (COND) incl += t; }
+            VQ_FS_ADD(0x111, (lane & 15u) >= 1u)
+            VQ_FS_ADD(0x112, (lane & 15u) >= 2u)
+            VQ_FS_ADD(0x114, (lane & 15u) >= 4u)
+            VQ_FS_ADD(0x118, (lane & 15u) >= 8u)
+            VQ_FS_ADD(0x142, (lane & 16u) != 0u)
+            VQ_FS_ADD(0x143, lane >= 32u)
+#undef VQ_FS_ADD
+            const int32_t before = incl - mine.d0;
+            const bool lane_ok = (lane < nl) && !lane_bad;
+            uint32_t start = 0;   // first lane of the batch not yet applied
+            int32_t base_d = 0;   // inclusive delta of lane start - 1
+            for (;;) {
+                const uint32_t sb = __float_as_uint(s), se = (sb >> 23) & 0xFFu;
+                const bool s_normal = (se != 0u) && (se != 255u);
+                const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
+                const int32_t S = (sb >> 31) ? -mag : mag;
+                const bool ok = s_normal && lane_ok && ((int)se - 127 == lane_e) && fs_inside(S + before - base_d, mine.lo0, mine.hi0);
+                const uint64_t below = start ? ((~0ull) >> (64 - start)) : 0ull;
+                const uint64_t bad_mask = (__ballot(!ok) | past) & ~below;
+                const uint32_t good = bad_mask ? (uint32_t)__builtin_ctzll(bad_mask) : 64u;  // lanes start .. good-1 hold (uniform)
+                if (good > start) {
+                    const int32_t S2 = S + __builtin_amdgcn_readlane(incl, (int)good - 1) - base_d;
+                    const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
+                    s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2a & 0x7FFFFFu));
+                }
+                if (good >= nl) break;
+                const unsigned long long q2 = dbg ? clock64() : 0ull;
+                ++n_walks;
+                walk_lane(good);
+                if (dbg) {
+                    asm volatile("" ::"v"(s));
+                    w_walk += clock64() - q2;
+                }
+                base_d = __builtin_amdgcn_readlane(incl, (int)good);
+                start = good + 1;
+                if (start >= nl) break;
+            }
+        } else {
+            // exact ties in the batch: the scan is repeated behind every lane that did not hold
+            uint32_t start = 0;
+            for (;;) {
+                const uint32_t sb = __float_as_uint(s), se = (sb >> 23) & 0xFFu;
+                const bool s_normal = (se != 0u) && (se != 255u);
+                const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
+                const int32_t S = (sb >> 31) ? -mag : mag;
+                const bool in = lane >= start;
+                FsD v;
+                v.d0 = in ? mine.d0 : 0, v.d1 = in ? mine.d1 : 0;
+                fs_scan_incl_d(v, lane);
+                const int32_t incl_d = (S & 1) ? v.d1 : v.d0;  // delta from position `start`, for the actual parity of S
+                int32_t before = __shfl_up(incl_d, 1);
+                if (lane == 0) before = 0;
+                const int32_t Sin = S + before;
+                const bool podd = (Sin & 1) != 0;
+                bool ok = s_normal && (lane < nl) && !lane_bad && ((int)se - 127 == lane_e);
+                ok = ok && fs_inside(Sin, podd ? mine.lo1 : mine.lo0, podd ? mine.hi1 : mine.hi0);
+                const uint64_t below = start ? ((~0ull) >> (64 - start)) : 0ull;
+                const uint64_t bad_mask = (__ballot(!ok) | past) & ~below;
+                const uint32_t good = bad_mask ? (uint32_t)__builtin_ctzll(bad_mask) : 64u;
+                if (good > start) {
+                    const int32_t S2 = S + __builtin_amdgcn_readlane(incl_d, (int)good - 1);
+                    const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
+                    s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2a & 0x7FFFFFu));
+                }
+                if (good >= nl) break;
+                walk_lane2(good);
+                start = good + 1;
+                if (start >= nl) break;
+            }
+        }
+        flag_set(&sync_done, t + 1u);
+    }
+    if (lane == 0) {
+        if (MODE == 0) na.centroid[(size_t)node * d + c] = s / (float)len;  // T::from_usize(n)
+        else na.var[(size_t)node * d + c] = s;
+        if (n_fallback && fallbacks) atomicAdd(n_fallback, fallbacks);
+        if (dbg) {
+            atomicAdd(dbg + 0, 1u);
+            atomicAdd(dbg + 1, fallbacks);
+            atomicMax(dbg + 2, fallbacks);
+            atomicAdd(dbg + 8, (uint32_t)((clock64() - cyc_all) >> 6));
+            atomicMax(dbg + 13, (uint32_t)((clock64() - cyc_all) >> 6));
+            if (blockIdx.x == 0 && blockIdx.y == 0)
+                printf("[vqhip-dev] chain4(0,0) mode %d walker: %u batches, %.0f k cycles: waiting for the loader %.0f k, %u failing lanes %.0f k, %u re-added\n",
+                       MODE, nb, (double)(clock64() - cyc_all) / 1e3, (double)w_ready / 1e3, n_walks, (double)w_walk / 1e3, fallbacks);
+        }
+    }
+}
+
 // ---- round 5: re-additions looked up, not executed --------------------------------------------------------------------
 // On zero-mean columns the running sum is a random walk that keeps crossing binade edges near zero: 10-30 % of the
 // 64-row segments are parked (their guess comes close to an edge), half of those really leave the binade their summary
@@ -3067,6 +3542,11 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         const bool new_any = use_tables && mode == 0 && (policy != nullptr ? any_exact : fs_sample == 1);
         const bool old_any = !(use_tables && mode == 0) || (policy != nullptr ? any_sampled : fs_sample > 1);
         const uint32_t *only_sampled = (new_any && old_any) ? policy : nullptr;
+        // k_fs_chain4 (operands in LDS rings ahead of time) unless VQHIP_TSVQ_CHAIN4=0; its deep rings (two waves per CU)
+        // where the level has no more chains than that holds at once (VQHIP_TSVQ_CHAIN4_DEEP=0 / 1: never / always)
+        static const char *c4_env = getenv("VQHIP_TSVQ_CHAIN4"), *c4d_env = getenv("VQHIP_TSVQ_CHAIN4_DEEP");
+        const bool use_chain4 = !(c4_env && c4_env[0] == '0');
+        const bool deep4 = c4d_env ? c4d_env[0] == '1' : (uint64_t)ub_fast * d <= 2ull * (uint64_t)num_cus();
         if (mode == 0) {
             // the binade guesses: f64 sums of every 8th group of rows of each tile where k_fs_policy allows (|mean| >= sigma),
             // of every row elsewhere; prefix over the node's tiles
@@ -3080,16 +3560,33 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             }
             if (old_any) {
                 // (VQHIP_TSVQ_DEBUG counts one form per pass: the new one where both run)
-                if (dbg && !new_any) hipLaunchKernelGGL((k_fs_chain<0, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, only_sampled);
-                else hipLaunchKernelGGL((k_fs_chain<0, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, (uint32_t *)nullptr, only_sampled);
+                uint32_t *const dbg0 = (dbg && !new_any) ? dbg : nullptr;
+                if (!use_chain4) {
+                    if (dbg0) hipLaunchKernelGGL((k_fs_chain<0, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg0, only_sampled);
+                    else hipLaunchKernelGGL((k_fs_chain<0, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, (uint32_t *)nullptr, only_sampled);
+                } else if (deep4) {
+                    if (dbg0) hipLaunchKernelGGL((k_fs_chain4<0, true, 1>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg0, only_sampled);
+                    else hipLaunchKernelGGL((k_fs_chain4<0, false, 1>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, (uint32_t *)nullptr, only_sampled);
+                } else {
+                    if (dbg0) hipLaunchKernelGGL((k_fs_chain4<0, true, 0>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg0, only_sampled);
+                    else hipLaunchKernelGGL((k_fs_chain4<0, false, 0>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, (uint32_t *)nullptr, only_sampled);
+                }
             }
         } else {
             // the guess comes from the sums the mean pass of the same level left behind (same tile table: every node
             // long enough for the emulation has more than one row, so it is a split node whenever the level splits)
             hipLaunchKernelGGL(k_fs_prefix<true>, pgrid, dim3(1024), 0, stream, d, fn, fb, fc, na, ts, mom, tp, lvp, fbk + 1);
             hipLaunchKernelGGL(k_fs_fold<1>, xgrid, dim3(64), 0, stream, X, d, perm, tl, lvp, na, tp, sm, sm2, side, side_cap, fbk + 1, (double2 *)nullptr, 0.0f, (const uint32_t *)nullptr, (uint4 *)nullptr, 0u);
-            if (dbg) hipLaunchKernelGGL((k_fs_chain<1, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
-            else hipLaunchKernelGGL((k_fs_chain<1, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
+            if (!use_chain4) {
+                if (dbg) hipLaunchKernelGGL((k_fs_chain<1, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
+                else hipLaunchKernelGGL((k_fs_chain<1, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
+            } else if (deep4) {
+                if (dbg) hipLaunchKernelGGL((k_fs_chain4<1, true, 1>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
+                else hipLaunchKernelGGL((k_fs_chain4<1, false, 1>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
+            } else {
+                if (dbg) hipLaunchKernelGGL((k_fs_chain4<1, true, 0>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
+                else hipLaunchKernelGGL((k_fs_chain4<1, false, 0>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
+            }
         }
         VQ_LAUNCH_CHECK("k_fs_*");
         if (getenv("VQHIP_TSVQ_CHECK")) {
