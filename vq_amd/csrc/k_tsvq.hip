@@ -1212,18 +1212,23 @@ __global__ __launch_bounds__(64, 2) void k_fs_fold(const float *__restrict__ X, 
             // q - rne(q) = +-1/2); a run that does hold a tie is folded again by the two-stream code.
 #pragma unroll
             for (int jp = 0; jp < 4; jp += 2) {  // two columns at a time, their chains interleaved; results to LDS at once
+                // rne(q) through the adder: t = fl(q + 1.5 * 2^23) in ONE rounding (fma; q = x * scale is exact) is 1.5 * 2^23 +
+                // rne(q) for |q| < 2^22 (ties to even: the constant is even), so rne(q) as an integer is bits(t) - bits(1.5 * 2^23),
+                // as a float t - 1.5 * 2^23 (exact), and q - rne(q) one more fma (exact): six instructions per element
+                // where v_mul / v_rndne / v_cvt / the range test on bits(q) took eight.  |rne(q)| >= 2^22 (an addend a
+                // quarter of the sum: only at a chain's start) and inf end in `rmax`, a NaN in the plain sum ps.
+                constexpr float kRnd = 12582912.0f;
                 int32_t d1[2] = {0, 0}, lo1[2] = {0, 0}, hi1[2] = {0, 0};
-                float tmax[2] = {0.f, 0.f};
-                uint32_t imax[2] = {0u, 0u};
+                float tmax[2] = {0.f, 0.f}, rmax[2] = {0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
-                        const float qq = w[i][jp + jj] * scale[jp + jj];  // exact (power of two) unless it overflows: caught by imax
-                        const float r = __builtin_rintf(qq);              // v_rndne_f32
-                        tmax[jj] = fmaxf(tmax[jj], fabsf(qq - r));        // qq - r is exact; a NaN is caught by imax
-                        imax[jj] = max(imax[jj], __float_as_uint(qq) & 0x7FFFFFFFu);
-                        d1[jj] += (int32_t)r;
+                        const float t = __builtin_fmaf(w[i][jp + jj], scale[jp + jj], kRnd);
+                        const float r = t - kRnd;
+                        tmax[jj] = fmaxf(tmax[jj], fabsf(__builtin_fmaf(w[i][jp + jj], scale[jp + jj], -r)));  // |q - rne(q)|
+                        rmax[jj] = fmaxf(rmax[jj], fabsf(r));
+                        d1[jj] += (int32_t)(__float_as_uint(t) - 0x4B400000u);
                         lo1[jj] = min(lo1[jj], d1[jj]);
                         hi1[jj] = max(hi1[jj], d1[jj]);
                     }
@@ -1232,7 +1237,7 @@ __global__ __launch_bounds__(64, 2) void k_fs_fold(const float *__restrict__ X, 
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const int j = jp + jj;
-                    obad[jj] = gbad[j] | (imax[jj] >= 0x4B800000u ? 1 : 0);  // |q| >= 2^24, inf or NaN: cannot stay in the binade
+                    obad[jj] = gbad[j] | ((rmax[jj] >= 4194304.0f || ps[j] != ps[j]) ? 1 : 0);  // |q| >= 2^22, inf, NaN: re-added
                     od0[jj] = od1[jj] = d1[jj], olo0[jj] = olo1[jj] = lo1[jj], ohi0[jj] = ohi1[jj] = hi1[jj];
                     if (!obad[jj] && tmax[jj] == 0.5f) {
                         // two streams (even / odd incoming S), exact tie handling.  q = a + f, a = floor(q), 0 <= f < 1,
