@@ -114,6 +114,30 @@ def test_build_mixed_columns_both_chain_forms_and_the_policy_cache(oracle, shape
     borrowed.close()
 
 
+def test_build_uneven_split_repeats_with_both_paths(oracle, capfd, monkeypatch):
+    """The build launches, per level, only the column-sum path that evenly split nodes would take, and checks the level
+    table afterwards.  70 % of the rows tie on the widest column: the root splits 140k / 60k, two levels on long and
+    short nodes share a level -- the build must notice, repeat itself with both paths (VQHIP_TSVQ_VERBOSE says so), give
+    the oracle's tree, and a second build on the same data set must go straight to the conservative form."""
+    n, d, depth = 200_000, 16, 5
+    rng = np.random.default_rng(77)
+    X = rng.random((n, d), dtype=F)
+    X[:, 3] = np.where(rng.random(n) < 0.7, F(0.0), F(40.0))
+    want = oracle.tsvq_build(X, depth)
+    sizes = []
+    monkeypatch.setenv("VQHIP_TSVQ_VERBOSE", "1")
+    ds = _lib.Dataset.from_host(X)
+    got = build_tree(ds, depth)
+    first = capfd.readouterr().err
+    again = build_tree(ds, depth)
+    second = capfd.readouterr().err
+    ds.close()
+    _assert_same_tree(got, want)
+    _assert_same_tree(again, want)
+    assert "repeated with both column-sum paths" in first
+    assert "repeated" not in second
+
+
 def test_build_partial_nan_and_identical_rows(oracle):
     X = _data(22, 500, 8, "normal")
     X[17, 3] = np.nan

@@ -3298,6 +3298,7 @@ struct TsvqBuildWs {
     ~TsvqBuildWs() { release(); }
 };
 
+static thread_local bool tl_tsvq_conservative = false;  // the repeat of a build whose speculation failed
 int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_depth, uint32_t cap,
                       float *centroids_out, int32_t *left_out, int32_t *right_out, int32_t *n_nodes_out,
                       hipStream_t stream, TsvqPolicyCache *policy_cache) {
@@ -3510,7 +3511,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     // sequential-order column sums of the level's nodes: long nodes through the tile-parallel exact emulation (k_fs_*),
     // the rest through the plain chain kernel.  Grids are upper bounds; the kernels read the level's counts.
     static const bool fs_debug = getenv("VQHIP_TSVQ_DEBUG") != nullptr;
-    auto colsum = [&](int mode, const LevelInfo *lvp, uint32_t ub_nodes, const uint32_t *perm, bool with_fast) -> int {
+    auto colsum = [&](int mode, const LevelInfo *lvp, uint32_t ub_nodes, const uint32_t *perm, bool with_fast, bool with_slow) -> int {
         const uint32_t lvl_idx = (uint32_t)(lvp - lv);
         uint32_t *dbg = (fs_debug && lvl_idx < 64) ? fbk + 2 + (lvl_idx * 2 + (uint32_t)mode) * 16 : nullptr;
         const uint32_t ub_fast = (have_fast && with_fast) ? std::min(ub_nodes, fast_max) : 0u;
@@ -3519,7 +3520,9 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         static const char *narrow_env = getenv("VQHIP_TSVQ_NARROW_WGS");
         const uint64_t narrow_max = narrow_env ? (uint64_t)atoi(narrow_env) : (uint64_t)num_cus();  // measured: 16-column workgroups pay only while they leave CUs idle otherwise
         const bool narrow = (uint64_t)ub_nodes * g16 <= narrow_max;
-        if (narrow) {
+        if (!with_slow) {
+            // (speculation, below: no node of this level is expected on the plain chain)
+        } else if (narrow) {
             if (mode == 0) hipLaunchKernelGGL((k_seg_colsum<0, 16>), dim3(ub_nodes, g16), dim3(1024), 0, stream, X, d, perm, slow_nodes, lvp, na);
             else hipLaunchKernelGGL((k_seg_colsum<1, 16>), dim3(ub_nodes, g16), dim3(1024), 0, stream, X, d, perm, slow_nodes, lvp, na);
         } else {
@@ -3611,13 +3614,27 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     uint32_t ask_from = 0;
     while (ask_from < 31 && (uint64_t)(n >> ask_from) >= fs_min_rows) ++ask_from;
     static const char *noask_env = getenv("VQHIP_TSVQ_NO_LEVEL_ASK");  // =1: always launch both halves (A/B)
+    // Speculation: a median split halves a node (up to ties on the split dimension), so above level `ask_from` every node is
+    // long and from it on none is -- the build launches ONLY the kernels of the path each level is expected to take (an empty
+    // launch costs ~5 us: ten k_seg_colsum launches over no nodes at C4) and does not ask.  The level table read back at the
+    // end says whether a level held a node of the other kind (heavy ties: uneven children); then the build is repeated
+    // with both paths launched everywhere, and a data set remembers that (policy cache).
+    static const char *spec_env = getenv("VQHIP_TSVQ_SPECULATE");  // =0: never
+    bool cache_says_no = false;
+    if (policy_cache) {
+        std::lock_guard<std::mutex> lk(policy_cache->mu);
+        cache_says_no = policy_cache->no_speculation;
+    }
+    const bool speculate = have_fast && !tl_tsvq_conservative && !cache_says_no && !(spec_env && spec_env[0] == '0') &&
+                           !(noask_env && noask_env[0] == '1') && !getenv("VQHIP_TSVQ_DEBUG");
     hipLaunchKernelGGL(k_plan_level, dim3(1), dim3(1024), 0, stream, &lv[0], max_depth > 0 ? 1 : 0, can_fast ? 1 : 0, fs_min_rows, na, lvl_split_buf[0],
                        remap_buf[0], ws.b_fs_nodes.as<uint32_t>(), slow_nodes, ws.b_fs_base.as<uint32_t>(), ws.b_fs_nt.as<uint32_t>(),
                        ws.b_fs_tiles.as<FsTile>(), bbase, btab);
     VQ_LAUNCH_CHECK("k_plan_level");
     for (uint32_t L = 0; L < n_levels; ++L) {
         uint32_t ub_nodes = level_width(L);
-        const bool ask = fast_possible && L >= ask_from && !(noask_env && noask_env[0] == '1');
+        const bool ask = !speculate && fast_possible && L >= ask_from && !(noask_env && noask_env[0] == '1');
+        const bool lvl_fast = speculate ? L < ask_from : fast_possible, lvl_slow = speculate ? L >= ask_from : true;
         if (ub_nodes > 1024 || ask) {
             // wide levels: read the level's node count (one small copy + synchronisation) instead of launching the
             // per-node grids over 2^L mostly absent nodes; also ends the loop when the tree has stopped growing
@@ -3635,10 +3652,10 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         uint32_t *lvl_split = lvl_split_buf[L & 1], *remap = remap_buf[L & 1];
         uint32_t *perm = ws.b_perm[cur].as<uint32_t>(), *node_of = ws.b_nodeof[cur].as<uint32_t>();
         // means of every node of the level (tsvq.rs:36)
-        VQ_TRY(colsum(0, lvp, ub_nodes, perm, fast_possible));
+        VQ_TRY(colsum(0, lvp, ub_nodes, perm, lvl_fast, lvl_slow));
         if (!splits) break;
         // variances + split dimension (tsvq.rs:46-66)
-        VQ_TRY(colsum(1, lvp, ub_nodes, perm, fast_possible));
+        VQ_TRY(colsum(1, lvp, ub_nodes, perm, lvl_fast, lvl_slow));
         hipLaunchKernelGGL(k_pick_split, dim3((ub_nodes + 3) / 4), dim3(256), 0, stream, lvl_split, lvp, d, na);
         VQ_LAUNCH_CHECK("k_pick_split");
         // median (tsvq.rs:68-81): radix select (three rounds of 11 / 11 / 10 bits) of the two middle order statistics; the first round gathers the
@@ -3691,6 +3708,21 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     VQ_HIP(hipMemcpyAsync(hlv.data(), lv, (size_t)(n_levels + 1) * sizeof(LevelInfo), hipMemcpyDeviceToHost, stream));
     VQ_HIP(hipStreamSynchronize(stream));
     marks.mark("kernels-done");
+    if (speculate) {
+        bool wrong = false;
+        for (uint32_t L = 0; L < n_levels && hlv[L].count; ++L) wrong = wrong || (L < ask_from ? hlv[L].n_slow != 0 : hlv[L].n_fast != 0);
+        if (wrong) {  // a level held nodes of the kind that was not launched: their sums are missing -- once more, both paths
+            if (policy_cache) {
+                std::lock_guard<std::mutex> lk(policy_cache->mu);
+                policy_cache->no_speculation = true;
+            }
+            if (getenv("VQHIP_TSVQ_VERBOSE")) fprintf(stderr, "[vqhip] tsvq build: a level mixed long and short nodes; repeated with both column-sum paths\n");
+            tl_tsvq_conservative = true;
+            const int rc = tsvq_build_device(X, n64, d, max_depth, cap, centroids_out, left_out, right_out, n_nodes_out, stream, policy_cache);
+            tl_tsvq_conservative = false;
+            return rc;
+        }
+    }
     uint32_t total = 0;
     for (uint32_t L = 0; L < n_levels; ++L) {
         if (hlv[L].error == 1)

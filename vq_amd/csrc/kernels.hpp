@@ -203,6 +203,7 @@ int comm_kind(const Comm *c);                                // 0 identity, 1 RC
 struct TsvqPolicyCache {
     std::mutex mu;
     bool valid = false;
+    bool no_speculation = false;  // a build found levels mixing long and short nodes: launch both column-sum paths at once
     uint32_t n_cblk = 0;
     DevBuf dev;
     std::vector<uint32_t> host;
