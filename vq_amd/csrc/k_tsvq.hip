@@ -75,6 +75,7 @@ struct NodeArrays {
     float *centroid;                  // [cap][d]
     float *var;                       // [cap][d]
     uint32_t fs_seg_stride;           // k_fs_*: segment summaries are [column][segment slot], this many slots per column
+    float2 *sel_bin;                  // [cap] {lo, scale}: the linear bins of the median selection's first round (k_pick_split)
 };
 
 // order-preserving map f32 -> u32 (total order: -NaN < -inf < ... < -0 < +0 < ... < +inf < +NaN)
@@ -269,7 +270,21 @@ __global__ __launch_bounds__(256) void k_pick_split(const uint32_t *__restrict__
         na.split_dim[node] = have ? best_t : 0u;
         na.nv[node] = na.seg_len[node];  // non-NaN count: k_gather_vals subtracts the NaNs
         na.sel_prefix[2 * node] = na.sel_prefix[2 * node + 1] = 0;
+        // The median lies within one standard deviation of the mean (|mean - median| <= sigma, whatever the distribution):
+        // the selection's first round cuts [mean - 1.01 sigma, mean + 1.01 sigma] into 2046 equal bins (+ one on either
+        // side).  Any monotone map of the values is a valid first digit; this one leaves ~n / 1000 candidates where the top
+        // eleven bits of a float -- sign, exponent, two mantissa bits -- leave an eighth of the rows.
+        const float mean = na.centroid[(size_t)node * d + (have ? best_t : 0u)];
+        const float sigma = sqrtf(best / (float)na.seg_len[node]);
+        const bool ok = have && sigma > 0.0f && sigma < 3.0e38f && mean == mean && fabsf(mean) < 3.0e38f;
+        na.sel_bin[node] = ok ? make_float2(mean - 1.01f * sigma, 2046.0f / (2.02f * sigma)) : make_float2(0.0f, 0.0f);
     }
+}
+// first digit of the median selection: 0 below the window, 1 .. 2046 inside, 2047 above (monotone in x; scale 0: one bin)
+__device__ __forceinline__ uint32_t sel_bin_of(float x, float2 par) {
+    if (!(par.y > 0.0f)) return 1u;
+    const float t = (x - par.x) * par.y;
+    return t < 0.0f ? 0u : (t >= 2046.0f ? 2047u : 1u + (uint32_t)t);
 }
 
 // one radix-select round: histogram of the byte at `shift` among keys matching the prefix.
@@ -283,7 +298,7 @@ constexpr uint32_t kHistSlots11 = 2;  // 11-bit rounds (three: 11 + 11 + 10 bits
 // here (and written for the later rounds, the median test and the partition), NaNs are taken off nv[node] (k_pick_split
 // set it to the segment length); no prefix has been chosen yet, so every key counts for both ranks.
 // BITS: 8 (rounds at shift 24 / 16 / 8 / 0) or 11 (shift 21 / 10 / 0, the last one 10 bits wide: its top bins stay empty)
-template <bool GATHER, int BITS>
+template <bool GATHER, int BITS, bool LIN = false>
 __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ X, uint32_t d, const uint32_t *__restrict__ perm,
                                                      float *__restrict__ vals, uint32_t n, uint32_t chunk,
                                                      const uint32_t *__restrict__ node_of,
@@ -324,7 +339,7 @@ __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ X
 #pragma unroll
         for (uint32_t sel = 0; sel < 2u; ++sel)
             if (GATHER || (key & hi_mask) == na.sel_prefix[2 * node + sel]) {
-                const uint32_t bin = (key >> shift) & bin_mask;
+                const uint32_t bin = LIN ? sel_bin_of(x, na.sel_bin[node]) : (key >> shift) & bin_mask;  // LIN: k_pick_split's linear bins
                 if (owner == li) atomicAdd(&lh[slot][sel][bin], 1u);
                 else atomicAdd(&hist[((size_t)li * 2 + sel) * kBins + bin], 1u);
             }
@@ -403,6 +418,139 @@ __global__ __launch_bounds__(64) void k_select_pick(const uint32_t *__restrict__
         na.sel_rank[2 * node + sel] = new_rank;
         if (FIRST) na.sel_prefix[2 * node + sel] = b << shift;
         else na.sel_prefix[2 * node + sel] |= b << shift;
+    }
+}
+
+// Behind the first round (k_pick_split's 2048 linear bins around the mean) the keys that can still be the node's two
+// middle order statistics are the few in the chosen bin: instead of two more histogram rounds over all rows (hist +
+// pick twice: four launches per level) they are COLLECTED, per (node, rank), into the node's own stretch of a scratch
+// array (k_select_collect: positions from LDS counters per workgroup, one global atomic per workgroup and list to reserve
+// a range) and k_select_final picks the rank among them with four 8-bit rounds inside one workgroup (the candidates staged
+// in LDS when they fit).  Same two keys as the radix rounds give -- the k-th smallest is the k-th smallest; values that
+// pile up in one bin (a constant column, a lattice, half the rows at zero) only make the lists long: every row of the
+// node at worst, which is what they are sized for (one workgroup then streams the node's keys four times).
+__global__ __launch_bounds__(256) void k_select_collect(const float *__restrict__ vals, uint32_t n, uint32_t chunk,
+                                                        const uint32_t *__restrict__ node_of, const uint32_t *__restrict__ remap,
+                                                        const uint32_t *__restrict__ lvl_node, NodeArrays na,
+                                                        uint32_t *__restrict__ cand0, uint32_t *__restrict__ cand1,
+                                                        uint32_t *__restrict__ cnt) {
+    constexpr uint32_t kSlots = 2, kPer = 8;  // privatised counters: two nodes per workgroup (a third: straight to the global counter)
+    __shared__ uint32_t tags[kSlots], lcount[kSlots][2], lbase[kSlots][2];
+    if (threadIdx.x < kSlots) tags[threadIdx.x] = kInactive, lcount[threadIdx.x][0] = lcount[threadIdx.x][1] = 0u;
+    __syncthreads();
+    const uint32_t i0 = blockIdx.x * chunk, i1 = min(n, i0 + chunk);
+    for (uint32_t r0 = i0; r0 < i1; r0 += 256 * kPer) {  // (one trip: the chunks are ~2000 rows)
+        uint32_t key[kPer], slot_of[kPer], lpos[kPer][2], a_of[kPer], mt[kPer];  // mt: bit sel = in rank sel's bin; bit 2 = privatised
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t i = r0 + threadIdx.x + 256 * u;
+            mt[u] = 0u, key[u] = 0u, slot_of[u] = 0u, a_of[u] = 0u, lpos[u][0] = lpos[u][1] = 0u;
+            if (i >= i1) continue;
+            uint32_t li = node_of[i];
+            if (li != kInactive) li = remap[li];
+            if (li == kInactive) continue;
+            const uint32_t node = lvl_node[li];
+            const float x = vals[i];
+            if (x != x) continue;
+            const uint32_t bin = sel_bin_of(x, na.sel_bin[node]) << 21;  // (k_select_pick<true, 11> left the chosen bins at bit 21)
+            const uint32_t m = ((bin == na.sel_prefix[2 * node]) ? 1u : 0u) | ((bin == na.sel_prefix[2 * node + 1]) ? 2u : 0u);
+            if (!m) continue;
+            const uint32_t k = order_key(x), slot = li & (kSlots - 1);
+            uint32_t owner = tags[slot];
+            if (owner == kInactive) {
+                const uint32_t old = atomicCAS(&tags[slot], kInactive, li);
+                owner = (old == kInactive) ? li : old;
+            }
+            key[u] = k, a_of[u] = na.seg_start[node];
+            if (owner == li) {
+                mt[u] = m | 4u;
+                slot_of[u] = slot;
+                if (m & 1u) lpos[u][0] = atomicAdd(&lcount[slot][0], 1u);
+                if (m & 2u) lpos[u][1] = atomicAdd(&lcount[slot][1], 1u);
+            } else {  // a third node in this workgroup's chunk: its own global atomics
+                if (m & 1u) cand0[a_of[u] + atomicAdd(&cnt[2 * li], 1u)] = k;
+                if (m & 2u) cand1[a_of[u] + atomicAdd(&cnt[2 * li + 1], 1u)] = k;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kSlots * 2) {
+            const uint32_t slot = threadIdx.x >> 1, sel = threadIdx.x & 1u, c = lcount[slot][sel];
+            lbase[slot][sel] = c ? atomicAdd(&cnt[2 * tags[slot] + sel], c) : 0u;
+            lcount[slot][sel] = 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u)
+            if (mt[u] & 4u) {
+                if (mt[u] & 1u) cand0[a_of[u] + lbase[slot_of[u]][0] + lpos[u][0]] = key[u];
+                if (mt[u] & 2u) cand1[a_of[u] + lbase[slot_of[u]][1] + lpos[u][1]] = key[u];
+            }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_select_final(const uint32_t *__restrict__ lvl_node, const LevelInfo *__restrict__ lv, NodeArrays na,
+                                                       const uint32_t *__restrict__ cand0, const uint32_t *__restrict__ cand1,
+                                                       uint32_t *__restrict__ cnt) {
+    constexpr uint32_t kStage = 8192;
+    __shared__ uint32_t keys[kStage], h[256], pick_bin, pick_rank;
+    const uint32_t idx = blockIdx.x;
+    if (idx >= lv->n_split * 2) return;
+    const uint32_t li = idx >> 1, sel = idx & 1, node = lvl_node[li];
+    const uint32_t c = cnt[2 * li + sel];
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[2 * li + sel] = 0u;  // ready for the next level
+    if (na.nv[node] == 0) {  // (every value NaN: the keys stay 0, as the radix rounds leave them)
+        if (threadIdx.x == 0) na.sel_prefix[2 * node + sel] = 0u;
+        return;
+    }
+    const uint32_t *src = (sel ? cand1 : cand0) + na.seg_start[node];
+    const bool staged = c <= kStage;
+    if (staged)
+        for (uint32_t e = threadIdx.x; e < c; e += 1024) keys[e] = src[e];
+    uint32_t prefix = 0, rank = na.sel_rank[2 * node + sel];  // key bits chosen so far; rank among the candidates that carry them
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (threadIdx.x < 256) h[threadIdx.x] = 0u;
+        __syncthreads();
+        const uint32_t above = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (uint32_t e = threadIdx.x; e < c; e += 1024) {
+            const uint32_t k = staged ? keys[e] : src[e];
+            if ((k & above) == prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {  // one wave, four bins per lane; the serial rule: first bin whose cumulative count passes the rank, else the last
+            const uint32_t l = threadIdx.x;
+            const uint32_t cb[4] = {h[4 * l], h[4 * l + 1], h[4 * l + 2], h[4 * l + 3]};
+            const uint32_t mine = cb[0] + cb[1] + cb[2] + cb[3];
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+                if ((int)l >= off) incl += up;
+            }
+            const uint32_t excl = incl - mine;
+            const bool here = rank >= excl && rank < incl;
+            const uint64_t m = __ballot(here);
+            if (m) {
+                if (here) {
+                    uint32_t r = rank - excl, q = 0;
+                    while (q < 3u && r >= cb[q]) r -= cb[q], ++q;
+                    pick_bin = 4 * l + q;
+                    pick_rank = r;
+                }
+            } else if (l == 63) {
+                pick_bin = 255u;
+                pick_rank = rank - (incl - cb[3]);
+            }
+        }
+        __syncthreads();
+        prefix |= pick_bin << shift;
+        rank = pick_rank;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        na.sel_rank[2 * node + sel] = rank;
+        na.sel_prefix[2 * node + sel] = prefix;
     }
 }
 
@@ -3265,7 +3413,8 @@ struct TsvqBuildWs {
     DevBuf b_fs_tiles, b_fs_nodes, b_fs_base, b_fs_nt, b_fs_sum, b_fs_pref, b_fs_summ2, b_fs_summ, b_lvl_slow, b_fs_fb, b_fs_side, b_fs_mom, b_lv;
     DevBuf b_fs_smeta, b_fs_tab, b_fs_tmeta;  // k_fs_prep: guess + pass tag per parked slot, the tables, their validity
     DevBuf b_fs_bbase, b_fs_btab, b_fs_items, b_fs_ihdr;  // batches per fast node, batch table, the items per (batch, column)
-    DevBuf *all[46] = {&b_fs_bbase, &b_fs_btab, &b_fs_items, &b_fs_ihdr, &b_fs_smeta, &b_fs_tab, &b_fs_tmeta, &b_lvl2, &b_remap2, &b_perm[0], &b_perm[1], &b_nodeof[0], &b_nodeof[1], &b_vals, &b_flags, &b_scan, &b_bsums, &b_hist,
+    DevBuf b_selbin;                                      // the median selection's linear bins per node
+    DevBuf *all[47] = {&b_selbin, &b_fs_bbase, &b_fs_btab, &b_fs_items, &b_fs_ihdr, &b_fs_smeta, &b_fs_tab, &b_fs_tmeta, &b_lvl2, &b_remap2, &b_perm[0], &b_perm[1], &b_nodeof[0], &b_nodeof[1], &b_vals, &b_flags, &b_scan, &b_bsums, &b_hist,
                        &b_lvl, &b_remap, &b_seg_start, &b_seg_len, &b_split, &b_nv, &b_nleft, &b_median, &b_selp, &b_selr,
                        &b_child, &b_cent, &b_var, &b_left, &b_right, &b_fs_tiles, &b_fs_nodes, &b_fs_base, &b_fs_nt, &b_fs_sum, &b_fs_pref, &b_fs_summ2,
                        &b_fs_summ, &b_lvl_slow, &b_fs_fb, &b_fs_side, &b_fs_mom, &b_lv};
@@ -3370,13 +3519,14 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     static const char *radix_env = getenv("VQHIP_TSVQ_RADIX8");  // =1: four 8-bit rounds (A/B)
     const bool radix11 = wmax <= 4096 && !(radix_env && radix_env[0] == '1');
     const uint32_t hist_bins = radix11 ? 2048u : 256u;
-    VQ_TRY(ws.b_hist.ensure((size_t)wmax * 2 * hist_bins * 4));
+    VQ_TRY(ws.b_hist.ensure(((size_t)wmax * 2 * hist_bins + 2 * (size_t)wmax) * 4));  // + the candidate counters (k_select_collect)
     VQ_TRY(ws.b_seg_start.ensure((size_t)dcap * 4));
     VQ_TRY(ws.b_seg_len.ensure((size_t)dcap * 4));
     VQ_TRY(ws.b_split.ensure((size_t)dcap * 4));
     VQ_TRY(ws.b_nv.ensure((size_t)dcap * 4));
     VQ_TRY(ws.b_nleft.ensure((size_t)dcap * 4));
     VQ_TRY(ws.b_median.ensure((size_t)dcap * 4));
+    VQ_TRY(ws.b_selbin.ensure((size_t)dcap * sizeof(float2)));
     VQ_TRY(ws.b_selp.ensure((size_t)dcap * 8));
     VQ_TRY(ws.b_selr.ensure((size_t)dcap * 8));
     VQ_TRY(ws.b_child.ensure((size_t)dcap * 8));
@@ -3393,6 +3543,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     na.nv = ws.b_nv.as<uint32_t>();
     na.nleft = ws.b_nleft.as<uint32_t>();
     na.median = ws.b_median.as<float>();
+    na.sel_bin = ws.b_selbin.as<float2>();
     na.sel_prefix = ws.b_selp.as<uint32_t>();
     na.sel_rank = ws.b_selr.as<uint32_t>();
     na.child_local = ws.b_child.as<uint32_t>();
@@ -3458,7 +3609,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     hipLaunchKernelGGL(k_build_init, dim3(std::min<uint32_t>((n + 255) / 256, (uint32_t)num_cus() * 16)), dim3(256), 0, stream,
                        ws.b_perm[0].as<uint32_t>(), ws.b_nodeof[0].as<uint32_t>(), n, ws.b_left.as<int32_t>(), ws.b_right.as<int32_t>(), dcap,
                        ws.b_lv.as<uint32_t>(), (uint32_t)((n_levels + 1) * sizeof(LevelInfo) / 4), na.seg_start, na.seg_len,
-                       ws.b_fs_fb.as<uint32_t>(), (uint32_t)((8 + 64 * 2 * 64) / 4), ws.b_hist.as<uint32_t>(), wmax * 2 * hist_bins);
+                       ws.b_fs_fb.as<uint32_t>(), (uint32_t)((8 + 64 * 2 * 64) / 4), ws.b_hist.as<uint32_t>(), wmax * 2 * hist_bins + 2 * wmax);
     VQ_LAUNCH_CHECK("k_build_init");
     // the sampling policy: from the data set's cache if an earlier build left it there, else the kernel (into the cache's
     // buffer when there is one)
@@ -3674,9 +3825,23 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             using T = std::true_type;
             using F = std::false_type;
             if (radix11) {
-                round(T{}, std::integral_constant<int, 11>{}, 21u, 11u);
-                round(F{}, std::integral_constant<int, 11>{}, 10u, 11u);
-                round(F{}, std::integral_constant<int, 11>{}, 0u, 10u);  // (the low 10 bits: bins 1024.. stay empty)
+                static const char *rounds_env = getenv("VQHIP_TSVQ_RADIX_ROUNDS");  // =1: three histogram rounds on the keys' bits instead of linear bins + candidate lists (A/B)
+                if (rounds_env && rounds_env[0] == '1') {
+                    round(T{}, std::integral_constant<int, 11>{}, 21u, 11u);
+                    round(F{}, std::integral_constant<int, 11>{}, 10u, 11u);
+                    round(F{}, std::integral_constant<int, 11>{}, 0u, 10u);  // (the low 10 bits: bins 1024.. stay empty)
+                } else {
+                    // one round over k_pick_split's linear bins, then the chosen bin's keys collected per (node, rank) -- b_scan /
+                    // b_flags are free until k_flags_scan -- and the rank picked among them
+                    hipLaunchKernelGGL((k_select_hist<true, 11, true>), dim3(hblocks), dim3(256), 0, stream, X, d, perm, ws.b_vals.as<float>(), n, hchunk,
+                                       node_of, remap, lvl_split, na, 21u, ws.b_hist.as<uint32_t>(), 11u);
+                    hipLaunchKernelGGL((k_select_pick<true, 11>), dim3(ub_nodes * 2), dim3(64), 0, stream, lvl_split, lvp, na, 21u, ws.b_hist.as<uint32_t>());
+                    uint32_t *cnt = ws.b_hist.as<uint32_t>() + (size_t)wmax * 2 * hist_bins;
+                    hipLaunchKernelGGL(k_select_collect, dim3(hblocks), dim3(256), 0, stream, ws.b_vals.as<float>(), n, hchunk, node_of, remap, lvl_split, na,
+                                       ws.b_scan.as<uint32_t>(), ws.b_flags.as<uint32_t>(), cnt);
+                    hipLaunchKernelGGL(k_select_final, dim3(ub_nodes * 2), dim3(1024), 0, stream, lvl_split, lvp, na, ws.b_scan.as<uint32_t>(),
+                                       ws.b_flags.as<uint32_t>(), cnt);
+                }
             } else {
                 round(T{}, std::integral_constant<int, 8>{}, 24u, 8u);
                 round(F{}, std::integral_constant<int, 8>{}, 16u, 8u);
