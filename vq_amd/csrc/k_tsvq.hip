@@ -2417,9 +2417,48 @@ __global__ __launch_bounds__(128) void k_fs_chain4(const float *__restrict__ X, 
             }
         };
         const uint64_t past = nl < 64 ? (~0ull << nl) : 0ull;  // lanes behind the batch's last
-        if (!two) {
-            // one stream: the deltas simply add, ONE scan serves the whole batch
-            int32_t incl = mine.d0;
+        // Lanes whose run holds an exact tie (an odd stream that differs): at a chain's start -- small sums cut few bits of an
+        // addend -- and hardly anywhere else.  While such a lane lies ahead, the parity of S decides which stream a run
+        // takes and the wave-wide scan is repeated behind every lane that did not hold; behind the last of them the deltas
+        // simply add and ONE scan serves the rest of the batch.
+        const uint64_t two_mask = two ? __ballot((ef_or & 2u) != 0u) : 0ull;
+        uint32_t start = 0;  // first lane of the batch not yet applied
+        while (start < nl && (two_mask >> start) != 0ull) {
+            const uint32_t sb = __float_as_uint(s), se = (sb >> 23) & 0xFFu;
+            const bool s_normal = (se != 0u) && (se != 255u);
+            const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
+            const int32_t S = (sb >> 31) ? -mag : mag;
+            const bool in = lane >= start;
+            FsD v;
+            v.d0 = in ? mine.d0 : 0, v.d1 = in ? mine.d1 : 0;
+            fs_scan_incl_d(v, lane);
+            const int32_t incl_d = (S & 1) ? v.d1 : v.d0;  // delta from position `start`, for the actual parity of S
+            int32_t before = __shfl_up(incl_d, 1);
+            if (lane == 0) before = 0;
+            const int32_t Sin = S + before;
+            const bool podd = (Sin & 1) != 0;
+            bool ok = s_normal && (lane < nl) && !lane_bad && ((int)se - 127 == lane_e);
+            ok = ok && fs_inside(Sin, podd ? mine.lo1 : mine.lo0, podd ? mine.hi1 : mine.hi0);
+            const uint64_t below = start ? ((~0ull) >> (64 - start)) : 0ull;
+            const uint64_t bad_mask = (__ballot(!ok) | past) & ~below;
+            const uint32_t good = bad_mask ? (uint32_t)__builtin_ctzll(bad_mask) : 64u;
+            if (good > start) {
+                const int32_t S2 = S + __builtin_amdgcn_readlane(incl_d, (int)good - 1);
+                const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
+                s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2a & 0x7FFFFFu));
+            }
+            if (good >= nl) {
+                start = nl;
+                break;
+            }
+            if ((two_mask >> good) & 1ull) walk_lane2(good);
+            else walk_lane(good);
+            start = good + 1;
+        }
+        if (start < nl) {
+            // one stream from `start` on
+            int32_t incl = lane >= start ? mine.d0 : 0;
+            const int32_t own = incl;
 #define VQ_FS_ADD(CTRL, COND) { const int32_t t = __builtin_amdgcn_update_dpp(0, incl, CTRL, 0xF, 0xF, true); if (COND) incl += t; }
             VQ_FS_ADD(0x111, (lane & 15u) >= 1u)
             VQ_FS_ADD(0x112, (lane & 15u) >= 2u)
@@ -2428,10 +2467,9 @@ __global__ __launch_bounds__(128) void k_fs_chain4(const float *__restrict__ X, 
             VQ_FS_ADD(0x142, (lane & 16u) != 0u)
             VQ_FS_ADD(0x143, lane >= 32u)
 #undef VQ_FS_ADD
-            const int32_t before = incl - mine.d0;
+            const int32_t before = incl - own;
             const bool lane_ok = (lane < nl) && !lane_bad;
-            uint32_t start = 0;   // first lane of the batch not yet applied
-            int32_t base_d = 0;   // inclusive delta of lane start - 1
+            int32_t base_d = 0;  // inclusive delta of lane start - 1
             for (;;) {
                 const uint32_t sb = __float_as_uint(s), se = (sb >> 23) & 0xFFu;
                 const bool s_normal = (se != 0u) && (se != 255u);
@@ -2455,38 +2493,6 @@ __global__ __launch_bounds__(128) void k_fs_chain4(const float *__restrict__ X, 
                     w_walk += clock64() - q2;
                 }
                 base_d = __builtin_amdgcn_readlane(incl, (int)good);
-                start = good + 1;
-                if (start >= nl) break;
-            }
-        } else {
-            // exact ties in the batch: the scan is repeated behind every lane that did not hold
-            uint32_t start = 0;
-            for (;;) {
-                const uint32_t sb = __float_as_uint(s), se = (sb >> 23) & 0xFFu;
-                const bool s_normal = (se != 0u) && (se != 255u);
-                const int32_t mag = (int32_t)((sb & 0x7FFFFFu) | 0x800000u);
-                const int32_t S = (sb >> 31) ? -mag : mag;
-                const bool in = lane >= start;
-                FsD v;
-                v.d0 = in ? mine.d0 : 0, v.d1 = in ? mine.d1 : 0;
-                fs_scan_incl_d(v, lane);
-                const int32_t incl_d = (S & 1) ? v.d1 : v.d0;  // delta from position `start`, for the actual parity of S
-                int32_t before = __shfl_up(incl_d, 1);
-                if (lane == 0) before = 0;
-                const int32_t Sin = S + before;
-                const bool podd = (Sin & 1) != 0;
-                bool ok = s_normal && (lane < nl) && !lane_bad && ((int)se - 127 == lane_e);
-                ok = ok && fs_inside(Sin, podd ? mine.lo1 : mine.lo0, podd ? mine.hi1 : mine.hi0);
-                const uint64_t below = start ? ((~0ull) >> (64 - start)) : 0ull;
-                const uint64_t bad_mask = (__ballot(!ok) | past) & ~below;
-                const uint32_t good = bad_mask ? (uint32_t)__builtin_ctzll(bad_mask) : 64u;
-                if (good > start) {
-                    const int32_t S2 = S + __builtin_amdgcn_readlane(incl_d, (int)good - 1);
-                    const uint32_t m2a = (uint32_t)(S2 < 0 ? -S2 : S2);
-                    s = __uint_as_float((S2 < 0 ? 0x80000000u : 0u) | (se << 23) | (m2a & 0x7FFFFFu));
-                }
-                if (good >= nl) break;
-                walk_lane2(good);
                 start = good + 1;
                 if (start >= nl) break;
             }
