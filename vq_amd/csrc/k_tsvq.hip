@@ -2091,29 +2091,25 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
 // ---- the chain with its operands in LDS ahead of time (round 5) -------------------------------------------------------
 // k_fs_chain above keeps the next batches of summaries in registers and fetches parked addends eight segments at a time
 // on demand.  Measured (VQHIP_TSVQ_DEBUG, C4): a batch of 512 summaries that holds costs ~6000 cycles where its
-// instructions are ~2000 -- the register sets are rotated by moves, a move waits for the newest load, so the look-ahead
-// is one batch deep and every batch pays what is left of a memory round trip; and the first re-addition of a batch waits
-// 600 .. 25000 cycles for its addends (the groups of eight are requested one after the other).  Here nothing the walk
-// reads comes from memory: summaries and parked addends are written into LDS rings by LDS-DMA loads
-// (global_load_lds_dwordx4: no destination registers, so the look-ahead is as deep as the ring) issued a fixed number of
-// iterations ahead, and the only waits are s_waitcnt vmcnt(N) with N = the number of DMA instructions issued SINCE the
-// ones needed -- exact, because every iteration issues the same count (8 for a batch of summaries + P4 for its parked
-// segments, padded with loads of a dummy line).  The loads are written in inline assembly: the compiler neither knows
-// nor tracks them (its own waits for ordinary loads can only become more conservative, never wrong: loads return in
-// order) -- profiles/ubench/lds_dma.hip checks placement and the counting rule on the device.
-//   DEEP = 0: parked addends one batch ahead, summaries two (three + two ring slots, 33 KB: four waves per CU);
-//   DEEP = 1: two / four batches ahead (five + three slots, 60 KB: two waves per CU -- levels with few, long chains).
+// instructions are ~2000, and the first re-addition of a batch waits 600 .. 25000 cycles for its addends (the groups of
+// eight are requested one after the other).  Here a workgroup is two waves.  The LOADER keeps a queue of LDS-DMA loads
+// (global_load_lds_dwordx4: no destination registers) filled -- the summaries of the batch after next, the parked addends
+// of the next batch's first PCAP parked segments, listed from the summaries that have just landed -- and hands batches to
+// the WALKER through two LDS words; the walker reads nothing from memory on its way: summaries, parked addends and the
+// per-lane parking counts are in LDS rings when a batch is handed over.  The loads are written in inline assembly: the
+// compiler neither knows nor tracks them, the loader waits with s_waitcnt vmcnt(0) once per batch (the compiler's own
+// waits for ordinary loads can only become more conservative, never wrong: loads return in order) --
+// profiles/ubench/lds_dma.hip checks where the data lands and the ordering on the device.  A ring three batches deep
+// with exact wait counts (every iteration padded to the same number of DMA instructions) was built too and measured no
+// faster: one batch of look-ahead covers the round trip once the loader runs beside the walker.
 // Everything else -- lane runs of eight segments, wave scan, the eight-lane scan of a failing lane, 64 dependent
 // additions per re-added segment -- is k_fs_chain's; every sum is still the reference's bit pattern.
 __device__ __forceinline__ void fs_dma16(const void *gp, uint32_t lds_byte_addr) {  // lane l: 16 bytes from gp to lds_byte_addr + 16 l
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lds_byte_addr) : "memory");
 }
-template <int N>
-__device__ __forceinline__ void fs_wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
+__device__ __forceinline__ void fs_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int MODE, bool DBG, int DEEP>
+template <int MODE, bool DBG>
 __global__ __launch_bounds__(128) void k_fs_chain4(const float *__restrict__ X, uint32_t d, const uint32_t *__restrict__ perm,
                                                    const uint32_t *__restrict__ fast_nodes, const uint32_t *__restrict__ tile_base,
                                                    NodeArrays na, const FsS *__restrict__ summ, const FsS *__restrict__ summ_odd,
@@ -2123,9 +2119,9 @@ __global__ __launch_bounds__(128) void k_fs_chain4(const float *__restrict__ X, 
     uint32_t *const dbg = DBG ? dbg_arg : nullptr;
     if (only_sampled && only_sampled[blockIdx.y / kFsCols] == 0u) return;
     constexpr uint32_t kBatch = 64 * kFsSpl;
-    constexpr int A = DEEP ? 2 : 1, B = DEEP ? 4 : 2;  // batches ahead: parked addends, summaries
+    constexpr int A = 1, B = 2;                        // batches ahead: parked addends, summaries
     constexpr int NS = B + 1, NP = A + 1;              // ring slots
-    constexpr int P4 = DEEP ? 6 : 4;                   // parked DMA instructions per batch, four segments each
+    constexpr int P4 = 4;                              // parked DMA instructions per batch at most, four segments each
     constexpr uint32_t PCAP = 4 * P4;                  // parked segments of a batch fetched ahead (the rest: on demand)
     __shared__ __attribute__((aligned(16))) FsS sring[NS][kBatch];       // [slot][j * 64 + lane]: segment 8 lane + j of the batch
     __shared__ __attribute__((aligned(16))) float pring[NP][PCAP * 64];  // [slot][rank among the batch's parked][row]
@@ -2171,7 +2167,7 @@ __global__ __launch_bounds__(128) void k_fs_chain4(const float *__restrict__ X, 
             }
         };
         // batch b's summaries are in their slot: its parked segments listed in order, the addends of the first PCAP requested
-        // with EXACTLY P4 DMA instructions (sixteen lanes per segment; ranks past the batch's count read a line of summaries)
+        // (sixteen lanes per segment, four segments per DMA instruction; ranks past the batch's count repeat its last)
         auto issue_parked = [&](uint32_t b) {
             const uint32_t ss = b % (uint32_t)NS, ps = b % (uint32_t)NP;
             uint32_t efv[kFsSpl];
@@ -2194,12 +2190,7 @@ __global__ __launch_bounds__(128) void k_fs_chain4(const float *__restrict__ X, 
             const uint32_t pbefore = pincl - pc, ptotal = (uint32_t)__builtin_amdgcn_readlane((int)pincl, 63);
             pinfo[ps][lane] = make_uint2(pbefore, pk);
             const uint32_t pdst = pring_addr + ps * (PCAP * 256u);
-            const char *const dummy = reinterpret_cast<const char *>(sp) + 16u * (lane & 15u);
-            if (ptotal == 0u) {  // uniform: most batches -- the count of DMA instructions stays what the waits assume
-#pragma unroll
-                for (int i = 0; i < P4; ++i) fs_dma16(dummy, pdst + (uint32_t)i * 1024u);
-                return;
-            }
+            if (ptotal == 0u) return;  // uniform: most batches
             uint32_t r = pbefore;
 #pragma unroll
             for (int j = 0; j < kFsSpl; ++j)
@@ -2208,43 +2199,34 @@ __global__ __launch_bounds__(128) void k_fs_chain4(const float *__restrict__ X, 
             const uint32_t have = min(ptotal, PCAP);
             uint32_t slot[P4];
 #pragma unroll
-            for (int i = 0; i < P4; ++i) slot[i] = fs_vgpr((uint32_t)plist[ps][min(4u * (uint32_t)i + (lane >> 4), PCAP - 1u)]);
+            for (int i = 0; i < P4; ++i) slot[i] = fs_vgpr((uint32_t)plist[ps][min(4u * (uint32_t)i + (lane >> 4), have - 1u)]);
 #pragma unroll
-            for (int i = 0; i < P4; ++i) {
-                const uint32_t rank = 4u * (uint32_t)i + (lane >> 4);
-                const char *src = reinterpret_cast<const char *>(side + (size_t)slot[i] * kFsSeg) + 16u * (lane & 15u);
-                fs_dma16((rank < have) ? src : dummy, pdst + (uint32_t)i * 1024u);
-            }
+            for (int i = 0; i < P4; ++i)
+                if (4u * (uint32_t)i < have)  // uniform
+                    fs_dma16(reinterpret_cast<const char *>(side + (size_t)slot[i] * kFsSeg) + 16u * (lane & 15u), pdst + (uint32_t)i * 1024u);
         };
 #pragma unroll
         for (int b = 0; b < B; ++b) issue_summ((uint32_t)b);
-        fs_wait_vm<0>();
+        fs_wait_vm0();
         fs_wave_lds_sync();
 #pragma unroll
         for (int b = 0; b < A; ++b) issue_parked((uint32_t)b);
-        bool prev_issued = false;  // the queue starts empty for the counted wait (DEEP: drained here)
-        if (DEEP) fs_wait_vm<0>();
         unsigned long long l_all = dbg ? clock64() : 0ull, l_vm = 0ull, l_done = 0ull;  // VQHIP_TSVQ_DEBUG
         for (uint32_t t = 0; t < nb; ++t) {
             const unsigned long long q0 = dbg ? clock64() : 0ull;
             // batch t is complete once its parked addends and (for the list built next) the summaries of batch t + A have
-            // landed: everything issued before the previous iteration (DEEP) / before this one
-            if (DEEP && prev_issued) fs_wait_vm<P4 + 8>();
-            else fs_wait_vm<0>();
+            // landed: everything issued so far
+            fs_wait_vm0();
             if (dbg) l_vm += clock64() - q0;
             flag_set(&sync_ready, t + 1u);
-            if (t + (uint32_t)A >= nb) {  // nothing left to request (what is in flight is waited for above, batch by batch)
-                prev_issued = false;
-                continue;
-            }
+            if (t + (uint32_t)A >= nb) continue;  // nothing left to request
             const unsigned long long q1 = dbg ? clock64() : 0ull;
             if (t > 0u) flag_wait(&sync_done, t);  // the slots written next are batch t - 1's
             if (dbg) l_done += clock64() - q1;
             issue_parked(t + (uint32_t)A);
             issue_summ(t + (uint32_t)B);
-            prev_issued = true;
         }
-        fs_wait_vm<0>();  // (nothing may land in LDS after the wave has gone)
+        fs_wait_vm0();  // (nothing may land in LDS after the wave has gone)
         if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
             printf("[vqhip-dev] chain4(0,0) mode %d loader: %u batches, %.0f k cycles: waiting for DMA %.0f k, for the walker %.0f k\n", MODE, nb,
                    (double)(clock64() - l_all) / 1e3, (double)l_vm / 1e3, (double)l_done / 1e3);
@@ -2348,7 +2330,7 @@ __global__ __launch_bounds__(128) void k_fs_chain4(const float *__restrict__ X, 
                         fs_dma16(reinterpret_cast<const char *>(side + (size_t)sl * kFsSeg) + 16u * (lane & 15u),
                                  pring_addr + ps * (PCAP * 256u) + (uint32_t)i * 1024u);
                     }
-                    fs_wait_vm<0>();
+                    fs_wait_vm0();
                     fs_wave_lds_sync();
                     pr_base = rank;
                     if (dbg && lane == 0) atomicAdd(dbg + 7, 1u);
@@ -3760,11 +3742,9 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         const bool new_any = use_tables && mode == 0 && (policy != nullptr ? any_exact : fs_sample == 1);
         const bool old_any = !(use_tables && mode == 0) || (policy != nullptr ? any_sampled : fs_sample > 1);
         const uint32_t *only_sampled = (new_any && old_any) ? policy : nullptr;
-        // k_fs_chain4 (operands in LDS rings ahead of time) unless VQHIP_TSVQ_CHAIN4=0; its deep rings (two waves per CU)
-        // where the level has no more chains than that holds at once (VQHIP_TSVQ_CHAIN4_DEEP=0 / 1: never / always)
-        static const char *c4_env = getenv("VQHIP_TSVQ_CHAIN4"), *c4d_env = getenv("VQHIP_TSVQ_CHAIN4_DEEP");
+        // k_fs_chain4 (loader + walker, operands in LDS ahead of time) unless VQHIP_TSVQ_CHAIN4=0 (A/B: k_fs_chain)
+        static const char *c4_env = getenv("VQHIP_TSVQ_CHAIN4");
         const bool use_chain4 = !(c4_env && c4_env[0] == '0');
-        const bool deep4 = c4d_env ? c4d_env[0] == '1' : (uint64_t)ub_fast * d <= 2ull * (uint64_t)num_cus();
         if (mode == 0) {
             // the binade guesses: f64 sums of every 8th group of rows of each tile where k_fs_policy allows (|mean| >= sigma),
             // of every row elsewhere; prefix over the node's tiles
@@ -3782,12 +3762,9 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
                 if (!use_chain4) {
                     if (dbg0) hipLaunchKernelGGL((k_fs_chain<0, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg0, only_sampled);
                     else hipLaunchKernelGGL((k_fs_chain<0, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, (uint32_t *)nullptr, only_sampled);
-                } else if (deep4) {
-                    if (dbg0) hipLaunchKernelGGL((k_fs_chain4<0, true, 1>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg0, only_sampled);
-                    else hipLaunchKernelGGL((k_fs_chain4<0, false, 1>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, (uint32_t *)nullptr, only_sampled);
                 } else {
-                    if (dbg0) hipLaunchKernelGGL((k_fs_chain4<0, true, 0>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg0, only_sampled);
-                    else hipLaunchKernelGGL((k_fs_chain4<0, false, 0>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, (uint32_t *)nullptr, only_sampled);
+                    if (dbg0) hipLaunchKernelGGL((k_fs_chain4<0, true>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg0, only_sampled);
+                    else hipLaunchKernelGGL((k_fs_chain4<0, false>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, (uint32_t *)nullptr, only_sampled);
                 }
             }
         } else {
@@ -3798,12 +3775,9 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             if (!use_chain4) {
                 if (dbg) hipLaunchKernelGGL((k_fs_chain<1, true>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
                 else hipLaunchKernelGGL((k_fs_chain<1, false>), cgrid, dim3(64), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
-            } else if (deep4) {
-                if (dbg) hipLaunchKernelGGL((k_fs_chain4<1, true, 1>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
-                else hipLaunchKernelGGL((k_fs_chain4<1, false, 1>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
             } else {
-                if (dbg) hipLaunchKernelGGL((k_fs_chain4<1, true, 0>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
-                else hipLaunchKernelGGL((k_fs_chain4<1, false, 0>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
+                if (dbg) hipLaunchKernelGGL((k_fs_chain4<1, true>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
+                else hipLaunchKernelGGL((k_fs_chain4<1, false>), cgrid, dim3(128), 0, stream, X, d, perm, fn, fb, na, sm, sm2, side, fbk, lvp, dbg, (const uint32_t *)nullptr);
             }
         }
         VQ_LAUNCH_CHECK("k_fs_*");
