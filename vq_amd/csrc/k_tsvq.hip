@@ -3597,8 +3597,8 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
     static const char *nopark = getenv("VQHIP_TSVQ_NOPARK");
     static const char *seq_env = getenv("VQHIP_TSVQ_SEQSUM");  // =1: plain chain everywhere (A/B)
     const bool can_fast = (d % 4 == 0) && !(seq_env && seq_env[0] == '1');  // 16-byte row parts
-    static const char *samp_env = getenv("VQHIP_TSVQ_SAMPLE");  // rows read for the mean pass's binade guess: 1/N (default 1/8)
-    const uint32_t fs_sample = samp_env ? (uint32_t)std::max(1, std::min(16, atoi(samp_env))) : 8u;
+    static const char *samp_env = getenv("VQHIP_TSVQ_SAMPLE");  // rows read for the mean pass's binade guess: 1/N (default 1/4)
+    const uint32_t fs_sample = samp_env ? (uint32_t)std::max(1, std::min(16, atoi(samp_env))) : 4u;  // (1/8 until k_fs_chain4: 17 us a level against 30, but twice the segments folded under the wrong binade -- C4 3.90 against 3.84 ms)
     // sampling policy per block of 32 columns (k_fs_policy), behind the diagnostics in b_fs_fb; a forced VQHIP_TSVQ_SAMPLE
     // applies to every column
     const uint32_t n_cblk = (d + kFsCols - 1) / kFsCols;
@@ -3746,7 +3746,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
         static const char *c4_env = getenv("VQHIP_TSVQ_CHAIN4");
         const bool use_chain4 = !(c4_env && c4_env[0] == '0');
         if (mode == 0) {
-            // the binade guesses: f64 sums of every 8th group of rows of each tile where k_fs_policy allows (|mean| >= sigma),
+            // the binade guesses: f64 sums of every 4th group of rows of each tile where k_fs_policy allows (|mean| >= sigma),
             // of every row elsewhere; prefix over the node's tiles
             hipLaunchKernelGGL(k_fs_tile_sums<0>, tgrid, dim3(256), 0, stream, X, d, perm, tl, na, ts, fs_sample, policy, lvp);
             hipLaunchKernelGGL(k_fs_prefix<false>, pgrid, dim3(1024), 0, stream, d, fn, fb, fc, na, ts, mom, tp, lvp, fbk + 1);
