@@ -1113,15 +1113,25 @@ __global__ __launch_bounds__(256) void k_fs_tile_sums(const float *__restrict__ 
         for (int i = 0; i < 4; ++i) mu[i] = na.centroid[(size_t)tl.node * d + c0 + 4 * q + i];
     }
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (uint32_t i = 0; i < kFsTile / 32; i += samp) {
-        const uint32_t r = rr + 32 * i;
-        if (r < tl.rows && col_ok) {
-            const float4 v = *reinterpret_cast<const float4 *>(X + (size_t)perm[tl.start + r] * d + c0 + 4 * q);
-            acc[0] += (double)fs_value<MODE>(v.x, mu[0]);
-            acc[1] += (double)fs_value<MODE>(v.y, mu[1]);
-            acc[2] += (double)fs_value<MODE>(v.z, mu[2]);
-            acc[3] += (double)fs_value<MODE>(v.w, mu[3]);
+    // (row ids, then rows, as batches of eight independent loads -- clamped, nothing under an `if`: with the loads inside
+    // the test every row was two dependent round trips waited for in turn)
+    const uint32_t cq = col_ok ? c0 + 4 * q : c0, last = tl.rows - 1u;
+    for (uint32_t i0 = 0; i0 < kFsTile / 32; i0 += 8 * samp) {
+        uint32_t pr[8];
+        float4 v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) pr[u] = perm[tl.start + min(rr + 32 * (i0 + u * samp), last)];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(X + (size_t)pr[u] * d + cq);
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + u * samp;
+            if (i < kFsTile / 32 && rr + 32 * i < tl.rows && col_ok) {
+                acc[0] += (double)fs_value<MODE>(v[u].x, mu[0]);
+                acc[1] += (double)fs_value<MODE>(v[u].y, mu[1]);
+                acc[2] += (double)fs_value<MODE>(v[u].z, mu[2]);
+                acc[3] += (double)fs_value<MODE>(v[u].w, mu[3]);
+            }
         }
     }
 #pragma unroll
