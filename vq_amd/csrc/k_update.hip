@@ -450,10 +450,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials_pos(
                 for (uint32_t c0 = grp; c0 < n_chunks; c0 += 6 * kRedGroups) {
                     float v[6];
 #pragma unroll
-                    for (uint32_t u = 0; u < 6; ++u) {
-                        const uint32_t c = c0 + u * kRedGroups;
-                        v[u] = (c < n_chunks) ? p[c * stride] : 0.0f;
-                    }
+                    for (uint32_t u = 0; u < 6; ++u) v[u] = p[min(c0 + u * kRedGroups, n_chunks - 1u) * stride];  // (clamped: nothing under a test)
 #pragma unroll
                     for (uint32_t u = 0; u < 6; ++u)
                         if (c0 + u * kRedGroups < n_chunks) acc += (double)v[u];
@@ -465,12 +462,10 @@ __global__ __launch_bounds__(256) void k_reduce_partials_pos(
                 for (uint32_t c0 = grp; c0 < n_chunks; c0 += 6 * kRedGroups) {
                     uint32_t v[6];
 #pragma unroll
-                    for (uint32_t u = 0; u < 6; ++u) {
-                        const uint32_t c = c0 + u * kRedGroups;
-                        v[u] = (c < n_chunks) ? p[c * stride] : 0u;
-                    }
+                    for (uint32_t u = 0; u < 6; ++u) v[u] = p[min(c0 + u * kRedGroups, n_chunks - 1u) * stride];
 #pragma unroll
-                    for (uint32_t u = 0; u < 6; ++u) cnt += v[u];
+                    for (uint32_t u = 0; u < 6; ++u)
+                        if (c0 + u * kRedGroups < n_chunks) cnt += v[u];
                 }
                 acc = (double)cnt;
             }
