@@ -695,7 +695,16 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *sh, uint32_t *t
     return base + incl - v;
 }
 
-__device__ inline void scan_sums_body(uint32_t *__restrict__ block_sums, uint32_t nb, uint32_t *sh) {
+// What one phase of the single-workgroup planning hands the next stays in LDS when it fits (k_plan_fused): a value read
+// back from memory costs a fence (an L2 write-back on this chip) and a round trip per phase.
+constexpr uint32_t kPlanSb = 4096, kPlanNext = 2048, kPlanFast = 1024;
+struct PlanLds {
+    uint32_t *sb;              // [kPlanSb] scanned block totals (nb <= kPlanSb)
+    uint32_t *nstart, *nlen;   // [kPlanNext] the next level's segments by level-local index (count <= kPlanNext)
+    uint32_t *fnode, *fstart, *flen, *ftile, *fbat;  // [kPlanFast] the level's long nodes by fast index: id, segment, first tile, first batch
+};
+__device__ __forceinline__ uint32_t *sh_tb(const PlanLds *pl) { return pl->ftile; }
+__device__ inline void scan_sums_body(uint32_t *__restrict__ block_sums, uint32_t nb, uint32_t *sh, uint32_t *sb = nullptr) {
     // single workgroup; nb <= a few thousand: serial chunks of 1024
     uint32_t carry = 0;
     for (uint32_t c0 = 0; c0 < nb; c0 += 1024) {
@@ -703,7 +712,10 @@ __device__ inline void scan_sums_body(uint32_t *__restrict__ block_sums, uint32_
         const uint32_t v = (i < nb) ? block_sums[i] : 0u;
         uint32_t tot;
         const uint32_t ex = block_excl_scan(v, sh, &tot);
-        if (i < nb) block_sums[i] = carry + ex;
+        if (i < nb) {
+            block_sums[i] = carry + ex;
+            if (sb && i < kPlanSb) sb[i] = carry + ex;
+        }
         carry += tot;
     }
 }
@@ -3284,14 +3296,16 @@ __device__ inline void plan_level_body(LevelInfo *__restrict__ lv, int can_split
                                        uint32_t *__restrict__ fast_nodes, uint32_t *__restrict__ slow_nodes,
                                        uint32_t *__restrict__ tile_base, uint32_t *__restrict__ n_tiles_of,
                                        FsTile *__restrict__ tiles, uint32_t *__restrict__ batch_base, uint2 *__restrict__ batch_tab,
-                                       uint32_t *sh) {
-    const uint32_t first = lv->first, count = lv->count;
+                                       uint32_t *sh, const PlanLds *pl = nullptr, uint32_t first_arg = 0, uint32_t count_arg = 0) {
+    // (pl: the level's segments are in LDS -- plan_children_body has just made them; first / count come with them)
+    const bool staged = pl != nullptr && count_arg <= kPlanNext;
+    const uint32_t first = pl ? first_arg : lv->first, count = pl ? count_arg : lv->count;
     uint32_t n_split = 0, n_fast = 0, n_tiles = 0, n_bat = 0;
     for (uint32_t b = 0; b < count; b += 1024) {
         const uint32_t li = b + threadIdx.x;
         const bool in = li < count;
         const uint32_t node = first + li;
-        const uint32_t len = in ? na.seg_len[node] : 0u;
+        const uint32_t len = in ? (staged ? pl->nlen[li] : na.seg_len[node]) : 0u;
         const uint32_t is_split = (in && can_split && len > 1) ? 1u : 0u;            // src/tsvq.rs:38-44
         const uint32_t is_fast = (in && can_fast && len >= fs_min_rows) ? 1u : 0u;
         const uint32_t nt = is_fast ? (len + kFsTile - 1) / kFsTile : 0u;
@@ -3302,7 +3316,10 @@ __device__ inline void plan_level_body(LevelInfo *__restrict__ lv, int can_split
         // batches of 64 tiles (k_fs_prep / k_fs_chain3: the items of a column are kept per batch)
         uint32_t tot_b;
         const uint32_t pbt = block_excl_scan((nt + 63u) / 64u, sh, &tot_b);
-        if (in && is_fast && batch_base) batch_base[n_fast + pf] = n_bat + pbt;
+        if (in && is_fast && batch_base) {
+            batch_base[n_fast + pf] = n_bat + pbt;
+            if (staged && n_fast + pf < kPlanFast) pl->fbat[n_fast + pf] = n_bat + pbt;
+        }
         if (in) {
             remap[li] = is_split ? n_split + ps : kInactive;
             if (is_split) lvl_split[n_split + ps] = node;
@@ -3310,6 +3327,8 @@ __device__ inline void plan_level_body(LevelInfo *__restrict__ lv, int can_split
                 fast_nodes[n_fast + pf] = node;
                 tile_base[n_fast + pf] = n_tiles + pt;
                 n_tiles_of[n_fast + pf] = nt;
+                if (staged && n_fast + pf < kPlanFast)
+                    pl->fnode[n_fast + pf] = node, pl->flen[n_fast + pf] = len, pl->fstart[n_fast + pf] = pl->nstart[li], sh_tb(pl)[n_fast + pf] = n_tiles + pt;
             } else {
                 slow_nodes[(li - (n_fast + pf))] = node;  // nodes before li that are not fast: li - (fast before li)
             }
@@ -3319,45 +3338,52 @@ __device__ inline void plan_level_body(LevelInfo *__restrict__ lv, int can_split
         n_tiles += tot_t;
         n_bat += tot_b;
     }
-    __threadfence();
-    __syncthreads();
     // tile table: tile T belongs to the fast node f with tile_base[f] <= T < tile_base[f] + nt[f].  The search runs on a
     // copy of tile_base in LDS when it fits (the usual case: a handful of long nodes): five dependent global loads per tile
-    // were half of this kernel's 20 us
+    // were half of this kernel's 20 us; with the level's segments staged (k_plan_fused) nothing here is read from memory
+    const bool all_lds = staged && n_fast <= kPlanFast;
     const bool in_lds = n_fast <= 1024u;
-    if (in_lds) {
-        if (threadIdx.x < n_fast) sh[threadIdx.x] = tile_base[threadIdx.x];
+    if (all_lds) {
         __syncthreads();
+    } else {
+        __threadfence();
+        __syncthreads();
+        if (in_lds) {
+            if (threadIdx.x < n_fast) sh[threadIdx.x] = tile_base[threadIdx.x];
+            __syncthreads();
+        }
     }
+    const uint32_t *tb = all_lds ? sh_tb(pl) : sh;
     for (uint32_t T = threadIdx.x; T < n_tiles; T += 1024) {
         uint32_t lo = 0, hi = n_fast;  // last f with tile_base[f] <= T
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if ((in_lds ? sh[mid] : tile_base[mid]) <= T) lo = mid; else hi = mid;
+            if ((in_lds ? tb[mid] : tile_base[mid]) <= T) lo = mid; else hi = mid;
         }
-        const uint32_t node = fast_nodes[lo], t = T - (in_lds ? sh[lo] : tile_base[lo]);
-        const uint32_t len = na.seg_len[node];
+        const uint32_t node = all_lds ? pl->fnode[lo] : fast_nodes[lo], t = T - (in_lds ? tb[lo] : tile_base[lo]);
+        const uint32_t len = all_lds ? pl->flen[lo] : na.seg_len[node];
         FsTile tl;
         tl.node = node;
         tl.t = t;
-        tl.start = na.seg_start[node] + t * kFsTile;
+        tl.start = (all_lds ? pl->fstart[lo] : na.seg_start[node]) + t * kFsTile;
         tl.rows = min(kFsTile, len - t * kFsTile);
         tiles[T] = tl;
     }
     if (batch_tab) {  // batch B = batch B - batch_base[f] of the fast node f with batch_base[f] <= B (same search)
         const bool b_lds = n_fast <= 1024u;
         __syncthreads();
-        if (b_lds) {
+        if (b_lds && !all_lds) {
             if (threadIdx.x < n_fast) sh[threadIdx.x] = batch_base[threadIdx.x];
             __syncthreads();
         }
+        const uint32_t *bb = all_lds ? pl->fbat : sh;
         for (uint32_t B = threadIdx.x; B < n_bat; B += 1024) {
             uint32_t lo = 0, hi = n_fast;
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if ((b_lds ? sh[mid] : batch_base[mid]) <= B) lo = mid; else hi = mid;
+                if ((b_lds ? bb[mid] : batch_base[mid]) <= B) lo = mid; else hi = mid;
             }
-            batch_tab[B] = make_uint2(lo, B - (b_lds ? sh[lo] : batch_base[lo]));
+            batch_tab[B] = make_uint2(lo, B - (b_lds ? bb[lo] : batch_base[lo]));
         }
     }
     if (threadIdx.x == 0) {
@@ -3382,7 +3408,10 @@ __device__ inline void plan_children_body(LevelInfo *__restrict__ lv, LevelInfo 
                                           const uint32_t *__restrict__ lvl_split, NodeArrays na,
                                           int32_t *__restrict__ node_left, int32_t *__restrict__ node_right,
                                           uint32_t dcap, const uint32_t *__restrict__ Pb,
-                                          const uint32_t *__restrict__ bsums, const uint32_t *__restrict__ flags, uint32_t *sh) {
+                                          const uint32_t *__restrict__ bsums, const uint32_t *__restrict__ flags, uint32_t *sh,
+                                          const PlanLds *pl = nullptr, uint32_t nb = 0, uint32_t *next_first_out = nullptr,
+                                          uint32_t *made_out = nullptr) {
+    const bool sb_lds = pl != nullptr && nb <= kPlanSb;  // the scanned block totals are in LDS (scan_sums_body)
     const uint32_t n_split = lv->n_split, next_first = lv->first + lv->count;
     uint32_t made = 0, err = 0;
     for (uint32_t b = 0; b < n_split; b += 1024) {
@@ -3395,7 +3424,7 @@ __device__ inline void plan_children_body(LevelInfo *__restrict__ lv, LevelInfo 
             len = na.seg_len[node];
             // lefts of the node = scan(end) - scan(start), the exclusive scan completed with the block totals on the fly
             const uint32_t e = start + len - 1;
-            nl = (Pb[e] + bsums[e >> 10] + flags[e]) - (Pb[start] + bsums[start >> 10]);
+            nl = (Pb[e] + (sb_lds ? pl->sb[e >> 10] : bsums[e >> 10]) + flags[e]) - (Pb[start] + (sb_lds ? pl->sb[start >> 10] : bsums[start >> 10]));
             na.nleft[node] = nl;
             if (na.nv[node] == 0) err = 1;
         }
@@ -3411,11 +3440,13 @@ __device__ inline void plan_children_body(LevelInfo *__restrict__ lv, LevelInfo 
                 node_left[node] = (int32_t)(next_first + il);
                 na.seg_start[next_first + il] = start;
                 na.seg_len[next_first + il] = nl;
+                if (pl && il < kPlanNext) pl->nstart[il] = start, pl->nlen[il] = nl;
             }
             if (has_r && next_first + ir < dcap) {
                 node_right[node] = (int32_t)(next_first + ir);
                 na.seg_start[next_first + ir] = start + nl;
                 na.seg_len[next_first + ir] = nr;
+                if (pl && ir < kPlanNext) pl->nstart[ir] = start + nl, pl->nlen[ir] = nr;
             }
         }
         made += tot;
@@ -3427,6 +3458,8 @@ __device__ inline void plan_children_body(LevelInfo *__restrict__ lv, LevelInfo 
         lv_next->count = (next_first + made <= dcap) ? made : 0u;  // cannot happen (dcap bounds the tree); no overrun if it did
         if (next_first + made > dcap) lv->error = 2;
     }
+    if (next_first_out) *next_first_out = next_first;
+    if (made_out) *made_out = (next_first + made <= dcap) ? made : 0u;
 }
 // The three single-workgroup steps between two levels in ONE launch (each kernel boundary of the build costs ~5 us, and a
 // level had 24 of them): the scan of the partition's block totals and the children of level L's split nodes
@@ -3443,14 +3476,19 @@ __global__ __launch_bounds__(1024) void k_plan_fused(LevelInfo *__restrict__ lv,
                                                      uint32_t *__restrict__ n_tiles_of, FsTile *__restrict__ tiles,
                                                      uint32_t *__restrict__ batch_base, uint2 *__restrict__ batch_tab) {
     __shared__ uint32_t sh[1024];
-    scan_sums_body(bsums, nb, sh);
-    __threadfence();
+    __shared__ uint32_t l_sb[kPlanSb], l_nstart[kPlanNext], l_nlen[kPlanNext], l_fnode[kPlanFast], l_fstart[kPlanFast], l_flen[kPlanFast],
+        l_ftile[kPlanFast], l_fbat[kPlanFast];
+    PlanLds pl;
+    pl.sb = l_sb, pl.nstart = l_nstart, pl.nlen = l_nlen, pl.fnode = l_fnode, pl.fstart = l_fstart, pl.flen = l_flen, pl.ftile = l_ftile, pl.fbat = l_fbat;
+    scan_sums_body(bsums, nb, sh, l_sb);
+    if (nb > kPlanSb) __threadfence();  // (else the next phase reads the totals from LDS; k_scatter reads them behind this kernel)
     __syncthreads();
-    plan_children_body(lv, lv_next, lvl_split, na, node_left, node_right, dcap, Pb, bsums, flags, sh);
-    __threadfence();
+    uint32_t next_first = 0, made = 0;
+    plan_children_body(lv, lv_next, lvl_split, na, node_left, node_right, dcap, Pb, bsums, flags, sh, &pl, nb, &next_first, &made);
+    if (made > kPlanNext) __threadfence();  // (uniform; else the next level's segments are in LDS)
     __syncthreads();
     plan_level_body(lv_next, next_can_split, can_fast, fs_min_rows, na, lvl_split_next, remap_next, fast_nodes, slow_nodes, tile_base,
-                    n_tiles_of, tiles, batch_base, batch_tab, sh);
+                    n_tiles_of, tiles, batch_base, batch_tab, sh, &pl, next_first, made);
 }
 
 // ---- host driver of the build ------------------------------------------------------------
