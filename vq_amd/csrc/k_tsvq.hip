@@ -1557,8 +1557,12 @@ __global__ __launch_bounds__(64, 2) void k_fs_fold(const float *__restrict__ X, 
                     const size_t at = (size_t)c * na.fs_seg_stride + (size_t)cur.tile_id * kFsSegsPerTile + 2 * cur.b + sg;
                     // for k_fs_prep's tables: the guess the segment was folded under, this pass's tag (tells its slots from what
                     // an earlier pass left in the unused rest of a chunk), where its summary is, and whether the guess is a sampled one
-                    if (slot >= 0 && side_meta)
-                        side_meta[slot] = make_uint4(gb, pass_tag, (uint32_t)at, (policy && policy[cur.c0 / kFsCols] && park_rel_arg > 0.0f) ? 1u : 0u);
+                    // (second record: what the tables' test wants of the summary -- its prefix range over both streams, unusable or
+                    // not -- so that k_fs_prep does not chase the summary behind `at`: one dependent round trip per table less)
+                    if (slot >= 0 && side_meta) {
+                        side_meta[2 * slot] = make_uint4(gb, pass_tag, (uint32_t)at, (policy && policy[cur.c0 / kFsCols] && park_rel_arg > 0.0f) ? 1u : 0u);
+                        side_meta[2 * slot + 1] = make_uint4((uint32_t)min(f.lo0, f.lo1), (uint32_t)max(f.hi0, f.hi1), anybad ? 1u : 0u, 0u);
+                    }
                     FsS o;
                     o.d = f.d0, o.lo = f.lo0, o.hi = f.hi0;
                     o.ef = fs_ef(anybad, two, (int)((gb >> 23) & 0xFFu) - 127, slot) | (int32_t)(gb & 0x80000000u);
@@ -2610,30 +2614,46 @@ constexpr uint32_t kFsTabN = 32;          // candidates per table: two tables pe
 __device__ __forceinline__ void fs_tables_wave(uint32_t lane, uint32_t wave, uint32_t n_waves, const float *__restrict__ side,
                                                const uint4 *__restrict__ side_meta, uint32_t pass_tag,
                                                const uint32_t *__restrict__ side_count, uint32_t side_cap,
-                                               const FsS *__restrict__ summ, const FsS *__restrict__ summ_odd,
-                                               float *__restrict__ tab, int4 *__restrict__ tmeta) {
+                                               float *__restrict__ tab, int4 *__restrict__ tmeta, float *lad /* LDS: [2][128] of this wave */) {
     const uint32_t n_slots = min(*side_count, side_cap), half = lane >> 5, hl = lane & 31u;
-    for (uint32_t pair = wave; 2u * pair < n_slots; pair += n_waves) {
-        const uint32_t slot = min(2u * pair + half, n_slots - 1u);  // (an odd count: the last pair's second half repeats the first's slot)
+    if (2u * wave >= n_slots) return;
+    // A pair's operands a pair AHEAD of its additions, none of them in the way: the two segments' 64 addends each by ONE
+    // LDS-DMA load into this wave's double buffer (lanes 0..15 / 16..31 fetch the 16-byte pieces of the first / second
+    // segment; no destination registers, no copies), the two slot records by ordinary loads that are consumed a trip later.
+    // Fetched when needed, a pair was three dependent round trips (slot record -> summary -> addends) in front of ~700
+    // instructions, on four waves per SIMD (`SQ_WAIT_ANY` 67 % of the wave cycles).
+    const uint32_t lad_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lad);  // (wave-uniform: M0 takes a scalar)
+    auto slot_of = [&](uint32_t pair, uint32_t h) { return min(2u * pair + h, n_slots - 1u); };
+    auto fetch = [&](uint32_t pair, uint32_t buf) {
+        const uint32_t sl = slot_of(pair, (lane >> 4) & 1u);
+        fs_dma16(reinterpret_cast<const char *>(side + (size_t)sl * kFsSeg) + 16u * (lane & 15u),
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(lad_addr + buf * 1024u)));  // (lanes 32..63: the same again behind it)
+    };
+    uint32_t pair = wave, buf = 0;
+    fetch(pair, 0);
+    uint4 sm = side_meta[2 * slot_of(pair, half)], sm2 = side_meta[2 * slot_of(pair, half) + 1];
+    for (; 2u * pair < n_slots; pair += n_waves, buf ^= 1u) {
+        fs_wait_vm0();  // this pair's addends are in LDS (and its records in their registers)
+        fs_wave_lds_sync();
+        const uint32_t nxt = (2u * (pair + n_waves) < n_slots) ? pair + n_waves : pair;
+        fetch(nxt, buf ^ 1u);
+        const uint4 sm_n = side_meta[2 * slot_of(nxt, half)], sm2_n = side_meta[2 * slot_of(nxt, half) + 1];
+        const uint32_t slot = slot_of(pair, half);  // (an odd count: the last pair's second half repeats the first's slot)
         const bool dup = 2u * pair + half >= n_slots;
-        const uint4 sm = side_meta[slot];
         const uint32_t gb = sm.x, ex = (gb >> 23) & 0xFFu;
         // tmeta = {c0, mlo, mhi, bits of +-2^(e-18)}; mlo > mhi: no table.  None for: the unused rest of a wave's chunk of
         // slots (another pass's tag), a sampled guess, no normal guess (a node's first segment: the sum starts at 0) or
         // 2^(e-18) not normal, a summary that holds well around the guess
         bool none = sm.y != pass_tag || sm.w != 0u || ex < 24u || ex > 240u;
-        if (!none) {
-            const FsS g = summ[sm.z];
-            if (!(g.ef & 1)) {
-                FsS g2 = g;
-                if ((g.ef & 3) == 2) g2 = summ_odd[sm.z];
-                const int32_t lo = min(g.lo, g2.lo), hi = max(g.hi, g2.hi), mo = (int32_t)(gb & 0x7FFFFFu);
-                none = (gb >> 31) ? (mo - hi - kFsTabSlack > 0 && mo - lo + kFsTabSlack <= 0x7FFFFF)
-                                  : (mo + lo - kFsTabSlack > 0 && mo + hi + kFsTabSlack <= 0x7FFFFF);
-            }
+        if (!none && sm2.z == 0u) {
+            const int32_t lo = (int32_t)sm2.x, hi = (int32_t)sm2.y, mo = (int32_t)(gb & 0x7FFFFFu);
+            none = (gb >> 31) ? (mo - hi - kFsTabSlack > 0 && mo - lo + kFsTabSlack <= 0x7FFFFF)
+                              : (mo + lo - kFsTabSlack > 0 && mo + hi + kFsTabSlack <= 0x7FFFFF);
         }
+        const uint32_t tag_here = sm.y;
+        sm = sm_n, sm2 = sm2_n;
         if (__ballot(!none) == 0ull) {  // uniform: neither half has a table to build
-            if (hl == 0 && !dup && sm.y == pass_tag) tmeta[slot] = make_int4(0, 1, 0, 0);
+            if (hl == 0 && !dup && tag_here == pass_tag) tmeta[slot] = make_int4(0, 1, 0, 0);
             continue;
         }
         // Lane roles inside the half: both rows of sixteen lanes are complete tests of their own -- lanes 0..7 of a row run the
@@ -2646,14 +2666,10 @@ __device__ __forceinline__ void fs_tables_wave(uint32_t lane, uint32_t wave, uin
         const uint32_t rB = (pos < 8u) ? c0 - kFsTabN * (uint32_t)M : c0 + kFsTabN * (uint32_t)M + (kFsTabN - 1u);
         const bool inB = ((rB ^ c0) >> 23) == 0u;  // the end point has the guess's sign and exponent
         float sA = __uint_as_float(c0 + hl), sB = __uint_as_float(inB ? rB : c0);
-#ifdef VQ_FS_TAB_NODPP
-        float sR = __uint_as_float(c0 + 16u * row);
-#endif
         uint32_t mism = 0u;
         float amax = 0.0f;
-        // (the two halves add different segments: the addends are vector loads -- sixteen 16-byte loads, all in flight
-        // before the first addition; the other waves of the SIMD cover the one round trip)
-        const f32x4_t *ad = reinterpret_cast<const f32x4_t *>(side + (size_t)slot * kFsSeg);
+        // (the two halves add different segments: sixteen broadcast reads of the half's 256 bytes)
+        const f32x4_t *ad = reinterpret_cast<const f32x4_t *>(lad + buf * 256u + half * kFsSeg);
         f32x4_t av[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) av[u] = ad[u];
@@ -2663,12 +2679,7 @@ __device__ __forceinline__ void fs_tables_wave(uint32_t lane, uint32_t wave, uin
             for (int w = 0; w < 4; ++w) {
                 sA = sA + av[u][w];
                 sB = sB + av[u][w];
-#ifdef VQ_FS_TAB_NODPP
-                sR = sR + av[u][w];
-                const uint32_t bR = __float_as_uint(sR);
-#else
                 const uint32_t bR = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(sA), 0x150, 0xF, 0xF, true);  // row_newbcast:0
-#endif
                 mism |= __float_as_uint(sB) ^ bR;
                 amax = fmaxf(amax, fabsf(__uint_as_float(bR)));  // (an inf stays an inf; a NaN can only follow one)
             }
@@ -2685,11 +2696,12 @@ __device__ __forceinline__ void fs_tables_wave(uint32_t lane, uint32_t wave, uin
         const bool high = (int)((__float_as_uint(amax) >> 23) & 0xFFu) - (int)ex > 4;
         if ((uint32_t)(__ballot(high) >> (32u * half)) != 0u) mlo = mhi = 0;
         if (none) mlo = 1, mhi = 0;
-        if (!dup && sm.y == pass_tag) {
+        if (!dup && tag_here == pass_tag) {
             if (!none) tab[(size_t)slot * kFsTabN + hl] = sA;
             if (hl == 0) tmeta[slot] = make_int4((int32_t)c0, mlo, mhi, (int32_t)((gb & 0x80000000u) | ((ex - 18u) << 23)));
         }
     }
+    fs_wait_vm0();  // (the last trip's prefetch: nothing may land in LDS after the wave has gone)
 }
 
 // A run of consecutive segments as ONE parity transducer, with the (sign, binade) key its summaries were folded under
@@ -2873,7 +2885,8 @@ __global__ __launch_bounds__(256) void k_fs_prep(const float *__restrict__ side,
                                                  const LevelInfo *__restrict__ lv, const uint32_t *__restrict__ policy, int seg_first_default) {
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     if (blockIdx.x < n_tab_blocks) {
-        fs_tables_wave(lane, blockIdx.x * 4u + w, n_tab_blocks * 4u, side, side_meta, pass_tag, side_count, side_cap, summ, summ_odd, tab, tmeta);
+        __shared__ __attribute__((aligned(16))) float lad[4][512];  // per wave: two 1 KB landing buffers of a pair's addends
+        fs_tables_wave(lane, blockIdx.x * 4u + w, n_tab_blocks * 4u, side, side_meta, pass_tag, side_count, side_cap, tab, tmeta, &lad[w][0]);
         return;
     }
     // ---- items: one batch x four adjacent columns per workgroup, a wave per column.  The summaries are [column][segment]:
@@ -3676,7 +3689,7 @@ int tsvq_build_device(const float *X, uint64_t n64, uint32_t d, uint32_t max_dep
             VQ_TRY(ws.b_fs_side.ensure(std::max<size_t>((size_t)side_cap * kFsSeg * 4, 16)));
             if (use_tables) {
                 VQ_TRY(ws.b_fs_tab.ensure(std::max<size_t>((size_t)side_cap * kFsTabN * 4, 16)));
-                VQ_TRY(ws.b_fs_smeta.ensure(std::max<size_t>((size_t)side_cap * sizeof(uint4), 16)));
+                VQ_TRY(ws.b_fs_smeta.ensure(std::max<size_t>((size_t)side_cap * 2 * sizeof(uint4), 16)));  // two records per slot
                 VQ_TRY(ws.b_fs_tmeta.ensure(std::max<size_t>((size_t)side_cap * sizeof(int4), 16)));
                 VQ_TRY(ws.b_fs_bbase.ensure((size_t)fast_max * 4));
                 VQ_TRY(ws.b_fs_btab.ensure((size_t)batches_max * sizeof(uint2)));
