@@ -335,13 +335,21 @@ __global__ __launch_bounds__(256) void k_select_hist(const float *__restrict__ X
             li[u] = (li[u] == kInactive) ? kInactive : r;
             live[u] = live[u] && li[u] != kInactive;
         }
+        // (a row outside every split node reads entry 0 of the tables -- words nobody may have written -- and then stands at
+        // node 0, dimension 0: valid addresses for the loads behind; its value is dropped)
 #pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) node[u] = lvl_node[live[u] ? li[u] : 0u];
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t nd = lvl_node[live[u] ? li[u] : 0u];
+            node[u] = live[u] ? nd : 0u;
+        }
         float x[kPer];
         if (GATHER) {
             uint32_t dim[kPer], pr[kPer];
 #pragma unroll
-            for (uint32_t u = 0; u < kPer; ++u) dim[u] = na.split_dim[node[u]], pr[u] = perm[ic[u]];
+            for (uint32_t u = 0; u < kPer; ++u) {
+                const uint32_t dm = na.split_dim[node[u]];
+                dim[u] = live[u] ? dm : 0u, pr[u] = perm[ic[u]];
+            }
 #pragma unroll
             for (uint32_t u = 0; u < kPer; ++u) x[u] = X[(size_t)pr[u] * d + dim[u]];
         } else {
@@ -495,7 +503,10 @@ __global__ __launch_bounds__(256) void k_select_collect(const float *__restrict_
             x[u] = vals[ic[u]];
         }
 #pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) node[u] = lvl_node[live[u] ? li[u] : 0u];
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t nd = lvl_node[live[u] ? li[u] : 0u];
+            node[u] = live[u] ? nd : 0u;  // (k_select_hist: node 0 for a row outside every split node)
+        }
         float2 par[kPer];
         uint32_t pf0[kPer], pf1[kPer];
 #pragma unroll

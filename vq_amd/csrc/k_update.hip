@@ -337,13 +337,23 @@ __global__ __launch_bounds__(64) void k_accumulate_listed(
                         found = true;
                     }
                 }
-                row[u] = valid[u] ? wl_rows[(size_t)s * wl_stride + e + sh] : 0u;
+                // (clamped, never under a test: `valid ? load : 0` comes out of the compiler as a branch around the load with
+                // s_waitcnt vmcnt(0) behind it -- the eight entries of a level were eight memory round trips in a row)
+                row[u] = wl_rows[(size_t)s * wl_stride + (valid[u] ? e + sh : 0u)];
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) asm volatile("" : "+v"(row[u]));  // all eight row numbers requested before the first is used
+#pragma unroll
+            for (int u = 0; u < NB; ++u) row[u] = valid[u] ? row[u] : 0u;  // (a lane without an entry read a word nobody wrote: row 0 is a valid address)
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                code[u] = (uint32_t)codes[(size_t)row[u] * m + s];
+                x[u] = *reinterpret_cast<const float4 *>(X + (size_t)row[u] * d + (size_t)s * SD + 4 * g);
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                code[u] = valid[u] ? (uint32_t)codes[(size_t)row[u] * m + s] : 0xFFFFFFFFu;
-                x[u] = valid[u] ? *reinterpret_cast<const float4 *>(X + (size_t)row[u] * d + (size_t)s * SD + 4 * g)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                asm volatile("" : "+v"(code[u]), "+v"(x[u].x), "+v"(x[u].y), "+v"(x[u].z), "+v"(x[u].w));
+                if (!valid[u]) code[u] = 0xFFFFFFFFu, x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
