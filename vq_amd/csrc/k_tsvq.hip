@@ -630,6 +630,14 @@ __device__ __forceinline__ float median_of(const NodeArrays &na, uint32_t node) 
     return hi;
 }
 
+__device__ inline uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)v, off);
+        if ((int)lane >= off) v += u;
+    }
+    return v;
+}
 // partition flags (left = value <= the node's median, NaN -> right; tsvq.rs:84-85) and their exclusive scan inside
 // blocks of 1024 positions; block totals for k_scan_sums.  (The median of a node is formed here, by every thread that
 // needs it, from the two selected keys: one launch instead of k_median + k_flags + k_scan_blocks.)
@@ -639,55 +647,81 @@ __global__ __launch_bounds__(256) void k_flags_scan(const float *__restrict__ va
                                                     const uint32_t *__restrict__ lvl_node, NodeArrays na,
                                                     uint32_t *__restrict__ flags, uint32_t *__restrict__ out,
                                                     uint32_t *__restrict__ block_sums) {
-    __shared__ uint32_t sh[256];
+    __shared__ uint32_t sh[8];
     const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
     uint32_t v[4], s = 0;
+    // the chain position -> node -> (count, the two selected keys, segment start) as stages of four independent loads,
+    // clamped and never under a test (k_select_hist); a position outside every split node stands at node 0 and gets flag 0
+    uint32_t ic[4], li[4], node[4];
+    bool in[4], live[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint32_t i = base + q;
+        in[q] = base + q < n;
+        ic[q] = min(base + (uint32_t)q, n - 1u);
+        li[q] = node_of[ic[q]];
+    }
+    float x[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t r = remap[li[q] == kInactive ? 0u : li[q]];
+        li[q] = (li[q] == kInactive) ? kInactive : r;
+        live[q] = in[q] && li[q] != kInactive;
+        x[q] = vals[ic[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t nd = lvl_node[live[q] ? li[q] : 0u];
+        node[q] = live[q] ? nd : 0u;
+    }
+    uint32_t nvv[4], k0[4], k1[4], st[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        nvv[q] = na.nv[node[q]], k0[q] = na.sel_prefix[2 * node[q]], k1[q] = na.sel_prefix[2 * node[q] + 1], st[q] = na.seg_start[node[q]];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
         uint32_t f = 0;
-        if (i < n) {
-            uint32_t li = node_of[i];
-            if (li != kInactive) li = remap[li];
-            if (li != kInactive) {
-                const uint32_t node = lvl_node[li];
-                const float med = median_of(na, node);
-                f = (vals[i] <= med) ? 1u : 0u;  // NaN -> right
-                if (i == na.seg_start[node]) na.median[node] = med;
+        if (live[q]) {
+            float med = 0.0f;  // tsvq.rs:77-81 from the two selected keys (median_of)
+            if (nvv[q] != 0u) {
+                const float lo = key_to_float(k0[q]), hi = key_to_float(k1[q]);
+                if (nvv[q] % 2 == 0) {
+                    const float s2 = lo + hi;
+                    med = s2 / 2.0f;
+                } else {
+                    med = hi;
+                }
             }
-            flags[i] = f;
+            f = (x[q] <= med) ? 1u : 0u;  // NaN -> right
+            if (base + (uint32_t)q == st[q]) na.median[node[q]] = med;
         }
+        if (in[q]) flags[base + q] = f;
         v[q] = f;
         s += f;
     }
-    sh[threadIdx.x] = s;
+    // exclusive scan of the thread totals over the workgroup's four waves
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_u32(s, lane);
+    if (lane == 63u) sh[wave] = incl;
     __syncthreads();
-    for (uint32_t off = 1; off < 256; off <<= 1) {
-        uint32_t t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0u;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
+    uint32_t wbase = 0, wtot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+        const uint32_t t = sh[w];
+        wbase += (w < wave) ? t : 0u;
+        wtot += t;
     }
-    uint32_t excl = sh[threadIdx.x] - s;
+    uint32_t excl = wbase + incl - s;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (base + q < n) out[base + q] = excl;
         excl += v[q];
     }
-    if (threadIdx.x == 255) block_sums[blockIdx.x] = sh[255];
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = wtot;
 }
 // (body shared with the fused per-level planner k_plan_fused: one workgroup of 1024 threads, `sh` its 4 KB of LDS)
 // exclusive scan of one value per thread over the workgroup (1024 threads); returns the total.  Wave scans through
 // ds_bpermute plus one scan of the 16 wave totals: three barriers (the 10-step LDS scan it replaces had thirty, and the
 // planner runs five such scans per level: 23 us per level for what is a few hundred additions)
-__device__ inline uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)v, off);
-        if ((int)lane >= off) v += u;
-    }
-    return v;
-}
 __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *sh, uint32_t *total) {
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t incl = wave_incl_scan_u32(v, lane);
