@@ -490,10 +490,8 @@ __global__ __launch_bounds__(256) void k_reduce_partials_pos(
     }
 }
 
-// one lane per centroid component.  RUN (device-driven run, vqhip_kmeans_run): the workgroup that finishes last also ends
-// the iteration (src/core/vector.rs:440-457 without the host; it used to be a kernel of its own, k_run_update): an active
-// subspace with an empty cluster pauses the run (the caller reseeds: the draw is the host's); otherwise subspaces
-// whose centroids did not move retire, the others count one more iteration.
+// one lane per centroid component.  RUN (device-driven run, vqhip_kmeans_run): a paused run is left alone, an active
+// subspace with an empty cluster is flagged for k_run_decide, which ends the iteration behind this kernel.
 template <bool RUN>
 __global__ __launch_bounds__(256) void k_finalize(uint32_t m, uint32_t k, uint32_t sd,
                                                   const double *__restrict__ slab,
@@ -526,33 +524,30 @@ __global__ __launch_bounds__(256) void k_finalize(uint32_t m, uint32_t k, uint32
             centroids[e] = nv;
         }
     }
-    if (!RUN) return;
-    __shared__ int is_last, any_empty;
-    // every wave drains ITS OWN stores (changed[s], done_blocks[1], counts, centroids) to agent scope before the barrier:
-    // a fence by thread 0 alone waits for thread 0's wave only, and s_barrier does not wait for the other waves'
-    // outstanding stores -- the last workgroup could have read a stale flag
-    __threadfence();
-    __syncthreads();
+}
+
+// The end of one iteration of a device-driven run (src/core/vector.rs:440-457 without the host), behind k_finalize<true>: an
+// active subspace with an empty cluster pauses the run (the caller reseeds: the draw is the host's); otherwise subspaces
+// whose centroids did not move retire, the others count one more iteration.  A launch of its own: as the tail of the
+// workgroup of k_finalize that finishes last it needed every wave's stores at agent scope first -- `__threadfence()` is
+// `buffer_wbl2` + `buffer_inv` on this chip, an L2 write-back per wave -- plus a ticket on one word and the tail's cold
+// loads: 20 us for the kernel where its arithmetic is one round trip; a kernel boundary orders the same stores for ~5.
+__global__ __launch_bounds__(256) void k_run_decide(uint32_t m, uint8_t *__restrict__ active, const uint32_t *__restrict__ changed,
+                                                    uint32_t *__restrict__ gate_halt, uint32_t *__restrict__ iters,
+                                                    uint32_t *__restrict__ done_blocks) {
+    __shared__ int any_empty, halted;
     if (threadIdx.x == 0) {
-        is_last = atomicAdd(done_blocks, 1u) == gridDim.x - 1 ? 1 : 0;
-        any_empty = 0;
+        halted = *gate_halt != 0u;
+        any_empty = done_blocks[1] != 0u;
+        done_blocks[1] = 0u;  // ready for the next iteration
     }
     __syncthreads();
-    if (!is_last) return;
-    __threadfence();  // the other workgroups' writes
-    if (threadIdx.x == 0) {
-        any_empty = __builtin_nontemporal_load(&done_blocks[1]) != 0u;
-        done_blocks[0] = 0u;  // counter and flag ready for the next launch
-        done_blocks[1] = 0u;
-    }
-    __syncthreads();
-    if (halted) return;
+    if (halted) return;  // paused earlier: everything keeps the pausing iteration's values
     for (uint32_t s = threadIdx.x; s < m; s += 256) {
         if (!active[s]) continue;
         iters[s] += 1u;
-        if (!any_empty && !__builtin_nontemporal_load(&changed[s])) active[s] = 0;  // converged (vector.rs:455-457); on a pause the host decides
+        if (!any_empty && !changed[s]) active[s] = 0;  // converged (vector.rs:455-457); on a pause the host decides
     }
-    __syncthreads();
     if (threadIdx.x == 0 && any_empty) *gate_halt = 1u;
 }
 
@@ -789,6 +784,7 @@ int launch_finalize_run(uint32_t m, uint32_t k, uint32_t sd, const double *slab,
                         hipStream_t stream) {
     hipLaunchKernelGGL(k_finalize<true>, dim3((m * k * sd + 255) / 256), dim3(256), 0, stream, m, k, sd, slab, active, centroids,
                        counts, changed, 0, halt, iters, done_blocks);
+    hipLaunchKernelGGL(k_run_decide, dim3(1), dim3(256), 0, stream, m, active, changed, halt, iters, done_blocks);
     VQ_LAUNCH_CHECK("k_finalize<run>");
     return VQHIP_OK;
 }
