@@ -1426,7 +1426,7 @@ static int kmeans_small_enqueue(vqhip_kmeans *km, hipStream_t s, bool run, uint3
 
 // queue assign + update of one Lloyd iteration on `s` (no host synchronisation: capturable); gated: inside a
 // device-driven run (vqhip_kmeans_run) every kernel that changes state checks the run's device flags
-static int kmeans_accumulate_enqueue(vqhip_kmeans *km, hipStream_t s, bool gated = false) {
+static int kmeans_accumulate_enqueue(vqhip_kmeans *km, hipStream_t s, bool gated = false, bool fuse_finalize = false) {
     std::vector<uint32_t> subs;
     for (uint32_t i = 0; i < km->cs.m; ++i)
         if (km->active[i]) subs.push_back(i);
@@ -1457,7 +1457,15 @@ static int kmeans_accumulate_enqueue(vqhip_kmeans *km, hipStream_t s, bool gated
                       km->codes.as<uint8_t>(), km->engine, s, &fused));
     if (gated && !fused.used) return fail(VQHIP_ERR_FAILURE, "device-driven run without the fused update");
     const uint8_t *act = km->all_active ? nullptr : km->active_dev.as<uint8_t>();
-    if (fused.used) {
+    if (fused.used && gated && fuse_finalize) {
+        // one rank, device-driven: sums and means in one launch, the iteration's decisions behind it (k_reduce_finalize_run)
+        uint32_t *rs = km->run_state.as<uint32_t>();  // [0] halt, [1..m] iterations, [m+1] unused, [m+2] empty-cluster flag, [m+3..] `changed` scratch [m]
+        const uint32_t m = km->cs.m;
+        VQ_TRY(launch_reduce_finalize_run(m, km->cs.k, km->cs.sd, km->partial_sums.as<float>(), km->partial_counts.as<uint32_t>(),
+                                          fused.chunks, (uint32_t)subs.size(), km->ws.sub_pos.as<int32_t>(), km->slab.as<double>(),
+                                          km->active_dev.as<uint8_t>(), km->cs.cb.as<float>(), km->counts.as<uint32_t>(),
+                                          km->changed.as<uint32_t>(), rs, rs + 1, rs + 1 + m, rs + 3 + m, s));
+    } else if (fused.used) {
         VQ_TRY(launch_reduce_partials_pos(km->cs.m, km->cs.k, km->cs.sd, km->partial_sums.as<float>(),
                                           km->partial_counts.as<uint32_t>(), fused.chunks, (uint32_t)subs.size(),
                                           km->ws.sub_pos.as<int32_t>(), km->slab.as<double>(), s, fused.gate_active,
@@ -1498,9 +1506,11 @@ int vqhip_kmeans_partials(vqhip_kmeans *km, void **dev_slab, uint64_t *n_doubles
 
 // queue mean / convergence test + the read-back of counts and flags (capturable); gated (device-driven run): the same
 // kernel also ends the iteration (retire converged subspaces, count it, halt on an empty cluster)
-static int kmeans_finalize_enqueue(vqhip_kmeans *km, hipStream_t s, bool gated = false, bool read_back = true) {
+static int kmeans_finalize_enqueue(vqhip_kmeans *km, hipStream_t s, bool gated = false, bool read_back = true, bool done_already = false) {
     const uint32_t m = km->cs.m, k = km->cs.k;
-    if (gated) {
+    if (done_already) {
+        // (k_reduce_finalize_run has formed the means behind the sums)
+    } else if (gated) {
         uint32_t *rs = km->run_state.as<uint32_t>();  // [0] halt, [1..m] iterations, [m+1] finished-workgroup counter, [m+2] empty-cluster flag of the iteration
         VQ_TRY(launch_finalize_run(m, k, km->cs.sd, km->slab.as<double>(), km->active_dev.as<uint8_t>(), km->cs.cb.as<float>(),
                                    km->counts.as<uint32_t>(), km->changed.as<uint32_t>(), rs, rs + 1, rs + 1 + m, s));
@@ -1731,8 +1741,11 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
         in.synced();  // every step ended in a wait
         return VQHIP_OK;
     }
-    VQ_TRY(km->run_state.ensure((size_t)(m + 3) * 4));
-    VQ_HIP(hipMemsetAsync(km->run_state.p, 0, (size_t)(m + 3) * 4, s));
+    VQ_TRY(km->run_state.ensure((size_t)(2 * m + 3) * 4));
+    VQ_HIP(hipMemsetAsync(km->run_state.p, 0, (size_t)(2 * m + 3) * 4, s));
+    // one rank: nothing is exchanged between the sums and the means, so both are one launch (VQHIP_FUSED_FINALIZE=0: two, for A/B)
+    static const char *ff_env = getenv("VQHIP_FUSED_FINALIZE");
+    const bool fuse_finalize = world == 1 && !small_loop && !(ff_env && ff_env[0] == '0');
     if (small_loop) {  // the small form keeps the loop's decisions in two flag sets (k_lloyd_small.hip)
         VQ_TRY(kmeans_small_workspace(km, s));
         VQ_HIP(hipMemsetAsync(km->sm_tick.p, 0, (size_t)6 * m * 4, s));
@@ -1742,10 +1755,10 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
             VQ_TRY(kmeans_small_enqueue(km, s, true, it));
             continue;
         }
-        VQ_TRY(kmeans_accumulate_enqueue(km, s, true));
+        VQ_TRY(kmeans_accumulate_enqueue(km, s, true, fuse_finalize));
         // row-sharded: the one exchange of the iteration (a paused run re-sums a slab nobody reads: all ranks pause alike)
-        VQ_TRY(comm_allreduce_f64(comm, km->slab.as<double>(), (size_t)m * k * (km->cs.sd + 1), s));
-        VQ_TRY(kmeans_finalize_enqueue(km, s, true, false));  // + the iteration's decisions (k_finalize<true>)
+        if (!fuse_finalize) VQ_TRY(comm_allreduce_f64(comm, km->slab.as<double>(), (size_t)m * k * (km->cs.sd + 1), s));
+        VQ_TRY(kmeans_finalize_enqueue(km, s, true, false, fuse_finalize));  // + the iteration's decisions (k_finalize<true> + k_run_decide)
     }
     // everything the host reads goes to pinned memory, queued back to back, ONE wait
     uint32_t *const st = km->run_host, *const sm_flags = st + (m + 1);

@@ -526,15 +526,91 @@ __global__ __launch_bounds__(256) void k_finalize(uint32_t m, uint32_t k, uint32
     }
 }
 
+// Device-driven run on ONE rank (nothing is exchanged between the sums and the means): k_reduce_partials_pos and the
+// arithmetic of k_finalize<true> in one launch.  A workgroup sums 32 centroid components over the row chunks exactly as
+// k_reduce_partials_pos does (chunk groups strided, then groups ascending) -- and their clusters' counts beside them (every
+// component's lanes re-add its cluster's count: a few hundred KB of L2 reads for not having to find it in another
+// workgroup) -- and goes straight on to the mean, the |new - old| < 1e-6 test and the stores; the f64 slab is still
+// written (vqhip_kmeans_partials).  `changed` of the iteration is gathered in a scratch word per subspace that k_run_decide
+// copies out and clears: k_reduce_partials_pos cleared the flags in front of k_finalize, which in one launch would race
+// with their setting.  No fence, no counter: the decisions wait behind the kernel boundary.
+__global__ __launch_bounds__(256) void k_reduce_finalize_run(
+    const float *__restrict__ partial_sums, const uint32_t *__restrict__ partial_counts, uint32_t n_chunks, uint32_t n_sub,
+    const int32_t *__restrict__ sub_pos, uint32_t m, uint32_t k, uint32_t sd, double *__restrict__ slab, const uint8_t *__restrict__ active,
+    float *__restrict__ centroids, uint32_t *__restrict__ counts, const uint32_t *__restrict__ gate_halt,
+    uint32_t *__restrict__ done_blocks, uint32_t *__restrict__ chg_scratch) {
+    __shared__ double part[kRedGroups][32];
+    __shared__ unsigned long long partc[kRedGroups][32];
+    if (*gate_halt) return;  // paused run: slab, centroids, counts and flags keep the pausing iteration's values
+    const uint32_t total = m * k * sd;
+    const uint32_t el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const uint32_t e = blockIdx.x * 32 + el;
+    const bool in = e < total;
+    double acc = 0.0;
+    unsigned long long cnt = 0;
+    uint32_t sj = 0, t = 0, s = 0;
+    bool act = false;
+    if (in) {
+        sj = e / sd, t = e - sj * sd, s = sj / k;
+        const uint32_t j = sj - s * k;
+        const int32_t pos = sub_pos[s];
+        act = active[s] != 0;  // a subspace that converged inside this run: slab, centroids stay as they are, counts read 0
+        if (pos >= 0 && act) {
+            const size_t stride = (size_t)n_sub * k * sd, cstride = (size_t)n_sub * k;
+            const float *p = partial_sums + ((size_t)pos * k + j) * sd + t;
+            const uint32_t *pc = partial_counts + (size_t)pos * k + j;
+            for (uint32_t c0 = grp; c0 < n_chunks; c0 += 6 * kRedGroups) {  // six partials at a time, added in order (k_reduce_partials_pos)
+                float v[6];
+                uint32_t w[6];
+#pragma unroll
+                for (uint32_t u = 0; u < 6; ++u) {
+                    const uint32_t c = min(c0 + u * kRedGroups, n_chunks - 1u);  // (clamped: nothing under a test)
+                    v[u] = p[c * stride];
+                    w[u] = pc[c * cstride];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 6; ++u)
+                    if (c0 + u * kRedGroups < n_chunks) acc += (double)v[u], cnt += w[u];
+            }
+        }
+    }
+    part[grp][el] = acc;
+    partc[grp][el] = cnt;
+    __syncthreads();
+    if (grp != 0 || !in) return;
+    if (!act) {
+        if (t == 0) counts[sj] = 0u;
+        return;
+    }
+    double r = part[0][el];
+    unsigned long long c = partc[0][el];
+    for (uint32_t g = 1; g < kRedGroups; ++g) r += part[g][el], c += partc[g][el];
+    const double cd = (double)c;
+    slab[(size_t)sj * (sd + 1) + t] = r;
+    if (t == 0) {
+        slab[(size_t)sj * (sd + 1) + sd] = cd;
+        counts[sj] = (uint32_t)cd;
+        if (!(cd > 0.0)) done_blocks[1] = 1u;  // an active subspace with an empty cluster: k_run_decide pauses the run
+    }
+    if (cd > 0.0) {
+        const float EPSILON = 1e-6f;  // vector.rs:439
+        const float nv = (float)(r / cd);
+        const float diff = nv - centroids[e];
+        if (!(fabsf(diff) < EPSILON)) chg_scratch[s] = 1u;  // vector.rs:232-240, 444-446 (every writer stores the same value)
+        centroids[e] = nv;
+    }
+}
+
 // The end of one iteration of a device-driven run (src/core/vector.rs:440-457 without the host), behind k_finalize<true>: an
 // active subspace with an empty cluster pauses the run (the caller reseeds: the draw is the host's); otherwise subspaces
 // whose centroids did not move retire, the others count one more iteration.  A launch of its own: as the tail of the
 // workgroup of k_finalize that finishes last it needed every wave's stores at agent scope first -- `__threadfence()` is
 // `buffer_wbl2` + `buffer_inv` on this chip, an L2 write-back per wave -- plus a ticket on one word and the tail's cold
 // loads: 20 us for the kernel where its arithmetic is one round trip; a kernel boundary orders the same stores for ~5.
-__global__ __launch_bounds__(256) void k_run_decide(uint32_t m, uint8_t *__restrict__ active, const uint32_t *__restrict__ changed,
+__global__ __launch_bounds__(256) void k_run_decide(uint32_t m, uint8_t *__restrict__ active, uint32_t *__restrict__ changed,
                                                     uint32_t *__restrict__ gate_halt, uint32_t *__restrict__ iters,
-                                                    uint32_t *__restrict__ done_blocks) {
+                                                    uint32_t *__restrict__ done_blocks, uint32_t *__restrict__ chg_scratch) {
+    // chg_scratch (behind k_reduce_finalize_run): the iteration's flags are there; they become `changed` here
     __shared__ int any_empty, halted;
     if (threadIdx.x == 0) {
         halted = *gate_halt != 0u;
@@ -544,9 +620,15 @@ __global__ __launch_bounds__(256) void k_run_decide(uint32_t m, uint8_t *__restr
     __syncthreads();
     if (halted) return;  // paused earlier: everything keeps the pausing iteration's values
     for (uint32_t s = threadIdx.x; s < m; s += 256) {
+        uint32_t chg = changed[s];
+        if (chg_scratch) {
+            chg = chg_scratch[s];
+            chg_scratch[s] = 0u;
+            changed[s] = chg;
+        }
         if (!active[s]) continue;
         iters[s] += 1u;
-        if (!any_empty && !changed[s]) active[s] = 0;  // converged (vector.rs:455-457); on a pause the host decides
+        if (!any_empty && !chg) active[s] = 0;  // converged (vector.rs:455-457); on a pause the host decides
     }
     if (threadIdx.x == 0 && any_empty) *gate_halt = 1u;
 }
@@ -784,8 +866,22 @@ int launch_finalize_run(uint32_t m, uint32_t k, uint32_t sd, const double *slab,
                         hipStream_t stream) {
     hipLaunchKernelGGL(k_finalize<true>, dim3((m * k * sd + 255) / 256), dim3(256), 0, stream, m, k, sd, slab, active, centroids,
                        counts, changed, 0, halt, iters, done_blocks);
-    hipLaunchKernelGGL(k_run_decide, dim3(1), dim3(256), 0, stream, m, active, changed, halt, iters, done_blocks);
+    hipLaunchKernelGGL(k_run_decide, dim3(1), dim3(256), 0, stream, m, active, changed, halt, iters, done_blocks, (uint32_t *)nullptr);
     VQ_LAUNCH_CHECK("k_finalize<run>");
+    return VQHIP_OK;
+}
+
+// k_reduce_partials_pos + k_finalize<true> + k_run_decide of a one-rank device-driven run in two launches; chg_scratch: m zeroed
+// words the decision kernel leaves zeroed
+int launch_reduce_finalize_run(uint32_t m, uint32_t k, uint32_t sd, const float *partial_sums, const uint32_t *partial_counts,
+                               uint32_t n_chunks, uint32_t n_sub, const int32_t *sub_pos, double *slab, uint8_t *active, float *centroids,
+                               uint32_t *counts, uint32_t *changed, uint32_t *halt, uint32_t *iters, uint32_t *done_blocks,
+                               uint32_t *chg_scratch, hipStream_t stream) {
+    const uint32_t total = m * k * sd;
+    hipLaunchKernelGGL(k_reduce_finalize_run, dim3((total + 31) / 32), dim3(256), 0, stream, partial_sums, partial_counts, n_chunks, n_sub,
+                       sub_pos, m, k, sd, slab, active, centroids, counts, halt, done_blocks, chg_scratch);
+    hipLaunchKernelGGL(k_run_decide, dim3(1), dim3(256), 0, stream, m, active, changed, halt, iters, done_blocks, chg_scratch);
+    VQ_LAUNCH_CHECK("k_reduce_finalize_run");
     return VQHIP_OK;
 }
 

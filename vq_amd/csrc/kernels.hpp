@@ -171,6 +171,10 @@ int launch_finalize(uint32_t m, uint32_t k, uint32_t sd, const double *slab, con
 int launch_finalize_run(uint32_t m, uint32_t k, uint32_t sd, const double *slab, uint8_t *active, float *centroids,
                         uint32_t *counts, uint32_t *changed, uint32_t *halt, uint32_t *iters, uint32_t *done_blocks,
                         hipStream_t stream);
+int launch_reduce_finalize_run(uint32_t m, uint32_t k, uint32_t sd, const float *partial_sums, const uint32_t *partial_counts,
+                               uint32_t n_chunks, uint32_t n_sub, const int32_t *sub_pos, double *slab, uint8_t *active, float *centroids,
+                               uint32_t *counts, uint32_t *changed, uint32_t *halt, uint32_t *iters, uint32_t *done_blocks,
+                               uint32_t *chg_scratch, hipStream_t stream);
 // centroids[s][j] = X[rows[s*k+j]][s*sd ..]
 int launch_gather_rows(const float *X, uint32_t d, uint32_t m, uint32_t k, uint32_t sd,
                        const uint64_t *rows, float *centroids, hipStream_t stream);
