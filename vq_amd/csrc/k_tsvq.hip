@@ -2175,6 +2175,9 @@ __global__ __launch_bounds__(64) void k_fs_chain(const float *__restrict__ X, ui
 // faster: one batch of look-ahead covers the round trip once the loader runs beside the walker.
 // Everything else -- lane runs of eight segments, wave scan, the eight-lane scan of a failing lane, 64 dependent
 // additions per re-added segment -- is k_fs_chain's; every sum is still the reference's bit pattern.
+// (M0 = the LDS address; gfx9 and later need M0 for nothing else a compute kernel of this file does -- no LDS bounds, no
+// v_movrel, no ds_gws; the compiler's only own use, checked in the ISA, is the s_sendmsg of a printf in the DEBUG
+// instantiations, set right in front of it -- so no value lives in M0 across the statement)
 __device__ __forceinline__ void fs_dma16(const void *gp, uint32_t lds_byte_addr) {  // lane l: 16 bytes from gp to lds_byte_addr + 16 l
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lds_byte_addr) : "memory");
 }
