@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from vq_amd import _lib
 _lib.load(); _lib.set_device(0)
-n, d, m, k = 1_000_000, 128, 8, 256
+n, d, m, k = (int(x) for x in os.environ.get("VQ_KM_SHAPE", "1000000,128,8,256").split(","))  # C3: 1000000,768,96,256
 ds = _lib.Dataset.synthetic(n, d, 66, 0)
 km = _lib.KMeans(ds, m, k)
 km.init_from_rows(np.array([[(j * (n // k) + s) % n for j in range(k)] for s in range(m)], np.uint64))
