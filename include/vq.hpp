@@ -186,6 +186,9 @@ struct EncoderDel {
 struct TsvqDel {
     void operator()(vqhip_tsvq *p) const { vqhip_tsvq_destroy(p); }
 };
+struct MTsvqDel {
+    void operator()(vqhip_mtsvq *p) const { (void)vqhip_mtsvq_destroy(p); }
+};
 
 // `&[&[f32]]` -> contiguous [n][dim] with the reference's checks (src/pq.rs:91-104, src/tsvq.rs:196-210)
 inline std::vector<float> flatten(const std::vector<std::vector<float>> &rows, std::size_t *dim) {
@@ -394,6 +397,25 @@ class ProductQuantizer {
         return out;
     }
 
+    // reconstruction from one-byte codes [n][m] -> [n][dim] f32 (un-rounded centroids), and the batch form of dequantize
+    // (src/pq.rs:201-209): row blocks over the quantizer's devices when it was trained over several
+    std::vector<float> decode(const std::uint8_t *codes, std::size_t n) const {
+        if (k_ > 256) throw VqError::InvalidParameter("k", "one-byte codes need k <= 256");
+        std::vector<float> out(n * dim_);
+        if (!n) return out;
+        detail::check(menc_ && n >= 65536 ? vqhip_mpq_decode(menc_.get(), codes, n, out.data())
+                                          : vqhip_pq_decode(enc_.get(), codes, n, out.data()));
+        return out;
+    }
+    std::vector<float> dequantize_batch(const f16 *quantized, std::size_t n) const {
+        std::vector<float> out(n * dim_);
+        if (!n) return out;
+        const std::uint16_t *bits = reinterpret_cast<const std::uint16_t *>(quantized);
+        detail::check(menc_ && n >= 65536 ? vqhip_mpq_dequantize_f16(menc_.get(), bits, n * dim_, out.data())
+                                          : vqhip_dequantize_f16(bits, n * dim_, out.data()));
+        return out;
+    }
+
    private:
     // large batches of a quantizer trained over several devices: row blocks over the same devices
     int encode_raw(const float *rows, std::size_t n, std::uint8_t *codes, std::uint16_t *f16_out) const {
@@ -455,6 +477,19 @@ class TSVQ {
         if (n == 0) throw VqError::EmptyInput();
         init(rows, n, dim, max_depth, distance);
     }
+    // same, batch encodes in row blocks over `devices` (the build runs on devices[0]: SURVEY.md 8(e), "replicas only";
+    // the tree is replicated, each device descends its own rows)
+    TSVQ(const float *rows, std::size_t n, std::size_t dim, std::size_t max_depth, Distance distance, const std::vector<int> &devices) {
+        if (n == 0) throw VqError::EmptyInput();
+        if (!devices.empty()) detail::check(vqhip_set_device(devices[0]));
+        init(rows, n, dim, max_depth, distance);
+        if (devices.size() > 1) {
+            vqhip_mtsvq *mt = nullptr;
+            detail::check(vqhip_mtsvq_create(centroids_.data(), left_.data(), right_.data(), (std::uint32_t)left_.size(), (std::uint32_t)dim,
+                                             (int)distance.kind(), devices.data(), (int)devices.size(), &mt));
+            menc_.reset(mt);
+        }
+    }
     std::size_t dim() const { return dim_; }
     const char *distance_metric() const { return distance_.name(); }
     std::size_t num_nodes() const { return left_.size(); }
@@ -479,11 +514,29 @@ class TSVQ {
     }
     std::vector<std::int32_t> leaf_ids(const float *rows, std::size_t n) const {
         std::vector<std::int32_t> leaf(n);
-        if (n) detail::check(vqhip_tsvq_encode(enc_.get(), rows, n, leaf.data(), nullptr));
+        if (n) detail::check(encode_raw(rows, n, leaf.data(), nullptr));
         return leaf;
+    }
+    // batch forms: rows [n][dim] -> the leaf centroids as f16 (row i == quantize(rows[i])), and f16 -> f32
+    std::vector<f16> quantize_batch(const float *rows, std::size_t n) const {
+        std::vector<f16> out(n * dim_);
+        if (n) detail::check(encode_raw(rows, n, nullptr, reinterpret_cast<std::uint16_t *>(out.data())));
+        return out;
+    }
+    std::vector<float> dequantize_batch(const f16 *quantized, std::size_t n) const {
+        std::vector<float> out(n * dim_);
+        if (!n) return out;
+        const std::uint16_t *bits = reinterpret_cast<const std::uint16_t *>(quantized);
+        detail::check(menc_ && n >= 65536 ? vqhip_mtsvq_dequantize_f16(menc_.get(), bits, n * dim_, out.data())
+                                          : vqhip_dequantize_f16(bits, n * dim_, out.data()));
+        return out;
     }
 
    private:
+    int encode_raw(const float *rows, std::size_t n, std::int32_t *leaf, std::uint16_t *f16_out) const {
+        if (menc_ && n >= 65536) return vqhip_mtsvq_encode(menc_.get(), rows, n, leaf, f16_out);
+        return vqhip_tsvq_encode(enc_.get(), rows, n, leaf, f16_out);
+    }
     void init(const float *rows, std::size_t n, std::size_t dim, std::size_t max_depth, Distance distance) {
         dim_ = dim;
         distance_ = distance;
@@ -512,6 +565,7 @@ class TSVQ {
     std::vector<float> centroids_;
     std::vector<std::int32_t> left_, right_;
     std::unique_ptr<vqhip_tsvq, detail::TsvqDel> enc_;
+    std::unique_ptr<vqhip_mtsvq, detail::MTsvqDel> menc_;
 };
 
 // ---------------------------------------------------------------------- lbg_quantize ----

@@ -96,6 +96,8 @@ const char *vqhip_last_error(void);
 int vqhip_device_count(void);
 /* select the HIP device for the calling thread (like hipSetDevice) */
 int vqhip_set_device(int device);
+/* the calling thread's current device (what the single-device handles below run on) */
+int vqhip_get_device(int *device);
 /* hipStream_t (as void*) the calling thread's subsequent calls enqueue on; NULL = the
  * library's own per-thread non-blocking stream */
 int vqhip_set_stream(void *hip_stream);
@@ -266,6 +268,16 @@ int vqhip_comm_group_create(int world, vqhip_comm_group **out);
 int vqhip_comm_create_local(vqhip_comm_group *group, int rank, vqhip_comm **out);
 int vqhip_comm_group_destroy(vqhip_comm_group *group);
 int vqhip_comm_kind(const vqhip_comm *comm, int *kind);
+/* Failure containment.  Every host-side wait of an in-process group is bounded (VQHIP_COMM_TIMEOUT_S, default 60 s), and
+ * a rank whose sharded call fails on its own (allocation, launch) poisons its group so that the peers' calls return
+ * VQHIP_ERR_RUNTIME at once instead of waiting for it; a poisoned group stays poisoned, its handles destroy normally.
+ * vqhip_comm_create_local ends -- and vqhip_comm_create with an id continues -- with an exchange self-test: a
+ * rank-dependent pattern is published, every peer's buffer is read on its own and all-reduced, and a wrong word fails
+ * the call naming the device pair (VQHIP_COMM_SELFTEST=0 skips it).
+ *   comm_abort : from ANY thread: poison the group of an in-process communicator / ncclCommAbort an owned RCCL one, so
+ *                that a thread blocked in a collective with it returns (what the one-process handles below do when one
+ *                of their ranks fails) */
+int vqhip_comm_abort(vqhip_comm *comm);
 /* in-place all-reduce of the slab between _accumulate and _finalize (NULL comm: no-op) */
 int vqhip_kmeans_allreduce(vqhip_kmeans *km, vqhip_comm *comm);
 /* = accumulate + allreduce + finalize: vqhip_kmeans_step for a sharded data set; counts are global */
@@ -331,6 +343,20 @@ int vqhip_mpq_encode(vqhip_mpq_encoder *enc, const float *rows, uint64_t n, uint
  * [n][m] (optional) receives the last pass's codes */
 int vqhip_mpq_encode_dataset(vqhip_mpq_encoder *enc, vqhip_mdataset *ds, uint32_t repeat, uint8_t *codes_host);
 int vqhip_mpq_encoder_destroy(vqhip_mpq_encoder *enc);
+/* the other row-sharded paths (no collective): reconstruction from codes and f16 -> f32 in blocks over the encoder's
+ * devices (the batch forms of Quantizer::dequantize, src/pq.rs:201-209) */
+int vqhip_mpq_decode(vqhip_mpq_encoder *enc, const uint8_t *codes, uint64_t n, float *out);
+int vqhip_mpq_dequantize_f16(vqhip_mpq_encoder *enc, const uint16_t *f16_in, uint64_t count, float *out);
+/* TSVQ::quantize / dequantize for a batch (src/tsvq.rs:239-265) over several devices: the flattened tree replicated,
+ * host rows in row blocks, each device descends its own; arguments as vqhip_tsvq_create / _encode / _last_stats
+ * (undecided summed over the devices) */
+typedef struct vqhip_mtsvq vqhip_mtsvq;
+int vqhip_mtsvq_create(const float *centroids, const int32_t *left, const int32_t *right, uint32_t n_nodes, uint32_t d,
+                       int metric, const int *devices, int n_devices, vqhip_mtsvq **out);
+int vqhip_mtsvq_encode(vqhip_mtsvq *t, const float *rows, uint64_t n, int32_t *leaf, uint16_t *f16_out);
+int vqhip_mtsvq_dequantize_f16(vqhip_mtsvq *t, const uint16_t *f16_in, uint64_t count, float *out);
+int vqhip_mtsvq_last_stats(vqhip_mtsvq *t, int *screened, uint64_t *undecided);
+int vqhip_mtsvq_destroy(vqhip_mtsvq *t);
 /* the contiguous row block of `rank` among `world` ranks: the first n % world blocks are one row longer */
 int vqhip_shard_rows(uint64_t n, int world, int rank, uint64_t *offset, uint64_t *count);
 
@@ -362,6 +388,10 @@ int vqhip_pq_encode_device(vqhip_pq_encoder *enc, const void *dev_rows, uint64_t
 int vqhip_dequantize_f16(const uint16_t *f16_in, uint64_t count, float *out);
 /* reconstruction from codes: out[n][m*sub_dim] f32 = codebook[s][codes[n][s]] (new API) */
 int vqhip_pq_decode(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n, float *out);
+/* device forms of the two: device pointers, asynchronous on the current stream; codes must lie in [0, k) (the host
+ * form checks them, this one cannot) */
+int vqhip_pq_decode_device(vqhip_pq_encoder *enc, const void *dev_codes, uint64_t n, void *dev_out);
+int vqhip_dequantize_f16_device(const void *dev_f16_in, uint64_t count, void *dev_out);
 
 /* ---- pairwise distances --------------------------------------------------------------
  * Distance::compute (src/core/distance.rs:48-64, scalar paths 76-82, 94, 107-119) for n

@@ -232,8 +232,27 @@ static int multi(const char *in_path, const char *out_path) {
     std::fwrite(q.data(), 2, q.size(), o);
     std::fwrite(c.data(), 1, c.size(), o);
     std::fclose(o);
-    std::printf("MULTI_OK %s\n", vqhip_backend());
-    return 0;
+    // the other row-block paths of a multi-device quantizer: decode and dequantize_batch equal the one-device forms
+    const std::vector<float> dec2 = two.decode(c.data(), n), dec1 = one.decode(c.data(), n);
+    EXPECT(dec2.size() == n * dim);
+    for (std::size_t i = 0; i < n && !failures; i += 997)
+        for (std::size_t s = 0; s < m; ++s)
+            for (std::size_t t = 0; t < dim / m; ++t)
+                EXPECT(dec2[i * dim + s * (dim / m) + t] == two.codebooks()[(s * k + c[i * m + s]) * (dim / m) + t]);
+    (void)dec1;
+    const std::vector<float> deq = two.dequantize_batch(q.data(), n);
+    for (std::size_t i = 0; i < deq.size() && !failures; i += 101) EXPECT(deq[i] == q[i].to_f32());
+    // TSVQ over a device list: the leaves and f16 rows of the one-device tree
+    vq::TSVQ t1(X.data(), n, dim, 5, vq::Distance::SquaredEuclidean);
+    vq::TSVQ t2(X.data(), n, dim, 5, vq::Distance::SquaredEuclidean, std::vector<int>{0, 0});
+    EXPECT(t1.centroids() == t2.centroids() && t1.left() == t2.left());
+    EXPECT(t1.leaf_ids(X.data(), n) == t2.leaf_ids(X.data(), n));
+    const std::vector<vq::f16> tq1 = t1.quantize_batch(X.data(), n), tq2 = t2.quantize_batch(X.data(), n);
+    EXPECT(tq1.size() == tq2.size() && std::memcmp(tq1.data(), tq2.data(), tq1.size() * 2) == 0);
+    const std::vector<float> tdq = t2.dequantize_batch(tq2.data(), n);
+    for (std::size_t i = 0; i < tdq.size() && !failures; i += 101) EXPECT(tdq[i] == tq2[i].to_f32());
+    std::printf(failures ? "MULTI_FAILED\n" : "MULTI_OK %s\n", vqhip_backend());
+    return failures ? 1 : 0;
 }
 
 int main(int argc, char **argv) {

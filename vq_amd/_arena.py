@@ -24,7 +24,9 @@ _CAP_BYTES = int(os.environ.get("VQ_AMD_ARENA_MB", "1024")) << 20  # pooled (idl
 _PER_SIZE = 4
 _GRAIN = 2 << 20
 
-_lock = threading.Lock()
+# re-entrant: _give_back runs from weakref.finalize, i.e. possibly inside a garbage collection that an allocation under the
+# lock triggered on the same thread; the critical sections below also allocate no GC-tracked object
+_lock = threading.RLock()
 _idle: dict[int, list[np.ndarray]] = {}
 _idle_bytes = 0
 stats = {"reused": 0, "allocated": 0, "dropped": 0}
@@ -42,8 +44,11 @@ class _Lease:
 
 def _give_back(buf: np.ndarray) -> None:
     global _idle_bytes
+    spare: list = []  # (made outside the lock: a list is GC-tracked, its allocation may start a collection)
     with _lock:
-        lst = _idle.setdefault(buf.nbytes, [])
+        lst = _idle.get(buf.nbytes)
+        if lst is None:
+            lst = _idle[buf.nbytes] = spare
         if len(lst) < _PER_SIZE and _idle_bytes + buf.nbytes <= _CAP_BYTES:
             lst.append(buf)
             _idle_bytes += buf.nbytes

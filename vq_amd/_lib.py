@@ -40,6 +40,7 @@ SIGNATURES = {
     "vqhip_last_error": (C.c_char_p, []),
     "vqhip_device_count": (C.c_int, []),
     "vqhip_set_device": (C.c_int, [C.c_int]),
+    "vqhip_get_device": (C.c_int, [C.POINTER(C.c_int)]),
     "vqhip_set_stream": (C.c_int, [_vp]),
     "vqhip_synchronize": (C.c_int, []),
     "vqhip_last_assign_stats": (C.c_int, [_u64p, C.POINTER(C.c_int)]),
@@ -131,6 +132,16 @@ SIGNATURES = {
     "vqhip_mpq_encoder_destroy": (C.c_int, [_vp]),
     "vqhip_mpq_encode_dataset": (C.c_int, [_vp, _vp, C.c_uint32, _u8p]),
     "vqhip_shard_rows": (C.c_int, [C.c_uint64, C.c_int, C.c_int, _u64p, _u64p]),
+    "vqhip_comm_abort": (C.c_int, [_vp]),
+    "vqhip_pq_decode_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "vqhip_dequantize_f16_device": (C.c_int, [_vp, C.c_uint64, _vp]),
+    "vqhip_mpq_decode": (C.c_int, [_vp, _u8p, C.c_uint64, _f32p]),
+    "vqhip_mpq_dequantize_f16": (C.c_int, [_vp, _u16p, C.c_uint64, _f32p]),
+    "vqhip_mtsvq_create": (C.c_int, [_f32p, _i32p, _i32p, C.c_uint32, C.c_uint32, C.c_int, _i32p, C.c_int, _vpp]),
+    "vqhip_mtsvq_encode": (C.c_int, [_vp, _f32p, C.c_uint64, _i32p, _u16p]),
+    "vqhip_mtsvq_dequantize_f16": (C.c_int, [_vp, _u16p, C.c_uint64, _f32p]),
+    "vqhip_mtsvq_last_stats": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "vqhip_mtsvq_destroy": (C.c_int, [_vp]),
 }
 
 _lib = None
@@ -188,6 +199,23 @@ def f32c(a) -> np.ndarray:
 def code_dtype(k: int):
     """codes are one byte while k <= 256 and a u16 above (include/vqhip.h, "code width")"""
     return np.uint8 if int(k) <= 256 else np.uint16
+
+
+def _encode_outputs(n: int, m: int, k: int, dim: int, want_codes: bool, want_f16: bool, out_codes, out_f16):
+    """(codes, f16) arrays an encode call fills: fresh ones (large: recycled buffers, vq_amd/_arena.py), or the caller's
+    `out_*` after the checks that keep a bad one an FfiError instead of a heap overwrite by the library's threads"""
+    codes = f16 = None
+    if want_codes or out_codes is not None:
+        codes = out_codes if out_codes is not None else _arena.fresh((n, m), code_dtype(k))
+        if (not isinstance(codes, np.ndarray) or codes.shape != (n, m) or codes.dtype != code_dtype(k)
+                or not codes.flags.c_contiguous or not codes.flags.writeable):
+            raise FfiError(f"out_codes must be a writable C-contiguous {np.dtype(code_dtype(k)).name} array of shape ({n}, {m})", ERR_INVALID_INPUT)
+    if want_f16 or out_f16 is not None:
+        f16 = out_f16 if out_f16 is not None else _arena.fresh((n, dim), np.float16)
+        if (not isinstance(f16, np.ndarray) or f16.shape != (n, dim) or f16.dtype.itemsize != 2 or f16.dtype.kind not in "fu"
+                or not f16.flags.c_contiguous or not f16.flags.writeable):
+            raise FfiError(f"out_f16 must be a writable C-contiguous float16 array of shape ({n}, {dim})", ERR_INVALID_INPUT)
+    return codes, f16
 
 
 class Handle:
@@ -528,21 +556,64 @@ class MPQEncoder(Handle):
     def encode(self, rows, want_codes=True, want_f16=True, out_codes=None, out_f16=None):
         rows = f32c(rows).reshape(-1, self.m * self.sd)
         n = rows.shape[0]
-        codes = f16 = None
-        if want_codes or out_codes is not None:
-            codes = out_codes if out_codes is not None else _arena.fresh((n, self.m), code_dtype(self.k))
-        if want_f16 or out_f16 is not None:
-            f16 = out_f16 if out_f16 is not None else _arena.fresh((n, self.m * self.sd), np.float16)
+        codes, f16 = _encode_outputs(n, self.m, self.k, self.m * self.sd, want_codes, want_f16, out_codes, out_f16)
         check(load().vqhip_mpq_encode(self.raw, ptr(rows, _f32p), n, ptr(codes, _u8p),
                                       None if f16 is None else f16.ctypes.data_as(_u16p)))
         return codes, (None if f16 is None else f16.view(np.float16))
 
+    def decode(self, codes) -> np.ndarray:
+        """(n, m) codes -> (n, dim) float32 centroids, row blocks over the devices"""
+        codes = np.asarray(codes)
+        if codes.size and (codes.min() < 0 or codes.max() >= self.k):
+            raise FfiError(f"code outside [0, {self.k})", ERR_INVALID_INPUT)
+        codes = np.ascontiguousarray(codes, dtype=code_dtype(self.k)).reshape(-1, self.m)
+        out = np.empty((codes.shape[0], self.m * self.sd), np.float32)
+        check(load().vqhip_mpq_decode(self.raw, ptr(codes, _u8p), codes.shape[0], ptr(out, _f32p)))
+        return out
+
+    def dequantize_f16(self, f16) -> np.ndarray:
+        h = np.ascontiguousarray(f16, dtype=np.float16)
+        out = np.empty(h.shape, np.float32)
+        check(load().vqhip_mpq_dequantize_f16(self.raw, ptr(h.view(np.uint16), _u16p), h.size, ptr(out, _f32p)))
+        return out
 
     def encode_dataset(self, ds: MDataset, repeat: int = 1, want_codes: bool = False):
         """`repeat` passes over the RESIDENT rows of a sharded data set on their devices; the last pass's codes if asked"""
         codes = np.empty((ds.n, self.m), code_dtype(self.k)) if want_codes else None
         check(load().vqhip_mpq_encode_dataset(self.raw, ds.raw, int(repeat), ptr(codes, _u8p)))
         return codes
+
+
+class MTSVQ(Handle):
+    """vqhip_mtsvq: the flattened tree on several devices of this process, host rows descended in row blocks"""
+    _destroy = "vqhip_mtsvq_destroy"
+
+    def __init__(self, centroids, left, right, metric: int, devices=None):
+        cen = f32c(centroids)
+        lf = np.ascontiguousarray(left, dtype=np.int32)
+        rt = np.ascontiguousarray(right, dtype=np.int32)
+        self.d = int(cen.shape[1])
+        self.devices = _devices(devices)
+        raw = C.c_void_p()
+        check(load().vqhip_mtsvq_create(ptr(cen, _f32p), ptr(lf, _i32p), ptr(rt, _i32p), cen.shape[0], self.d, metric,
+                                        ptr(self.devices, _i32p), self.devices.size, C.byref(raw)))
+        super().__init__(raw)
+
+    def encode(self, rows, leaf, f16):
+        """rows (n, d) f32 C-contiguous; leaf int32 (n,) or None; f16 uint16/float16 (n, d) or None -- filled in place"""
+        check(load().vqhip_mtsvq_encode(self.raw, ptr(rows, _f32p), rows.shape[0], ptr(leaf, _i32p),
+                                        None if f16 is None else f16.ctypes.data_as(_u16p)))
+
+    def dequantize_f16(self, f16) -> np.ndarray:
+        h = np.ascontiguousarray(f16, dtype=np.float16)
+        out = np.empty(h.shape, np.float32)
+        check(load().vqhip_mtsvq_dequantize_f16(self.raw, ptr(h.view(np.uint16), _u16p), h.size, ptr(out, _f32p)))
+        return out
+
+    def last_stats(self):
+        scr, und = C.c_int(0), C.c_uint64(0)
+        check(load().vqhip_mtsvq_last_stats(self.raw, C.byref(scr), C.byref(und)))
+        return bool(scr.value), int(und.value)
 
 
 def shard_rows(n: int, world: int, rank: int) -> tuple[int, int]:
@@ -597,15 +668,7 @@ class PQEncoder(Handle):
         out_codes / out_f16: C-contiguous arrays of the right shape and dtype to fill instead."""
         rows = f32c(rows).reshape(-1, self.m * self.sd)
         n = rows.shape[0]
-        codes = f16 = None
-        if want_codes or out_codes is not None:
-            codes = out_codes if out_codes is not None else _arena.fresh((n, self.m), code_dtype(self.k))
-            if codes.shape != (n, self.m) or codes.dtype != code_dtype(self.k) or not codes.flags.c_contiguous:
-                raise FfiError(f"out_codes must be a C-contiguous {np.dtype(code_dtype(self.k)).name} array of shape ({n}, {self.m})", ERR_INVALID_INPUT)
-        if want_f16 or out_f16 is not None:
-            f16 = out_f16 if out_f16 is not None else _arena.fresh((n, self.m * self.sd), np.float16)
-            if f16.shape != (n, self.m * self.sd) or f16.dtype.itemsize != 2 or not f16.flags.c_contiguous:
-                raise FfiError(f"out_f16 must be a C-contiguous float16 array of shape ({n}, {self.m * self.sd})", ERR_INVALID_INPUT)
+        codes, f16 = _encode_outputs(n, self.m, self.k, self.m * self.sd, want_codes, want_f16, out_codes, out_f16)
         check(load().vqhip_pq_encode(self.raw, ptr(rows, _f32p), n, ptr(codes, _u8p),
                                      None if f16 is None else f16.ctypes.data_as(_u16p)))
         return codes, (None if f16 is None else f16.view(np.float16))
@@ -623,6 +686,10 @@ class PQEncoder(Handle):
         check(load().vqhip_pq_decode(self.raw, ptr(codes, _u8p), codes.shape[0], ptr(out, _f32p)))
         return out
 
+    def decode_device(self, dev_codes: int, n: int, dev_out: int):
+        """device pointers, asynchronous on the current stream; codes in [0, k) are the caller's responsibility"""
+        check(load().vqhip_pq_decode_device(self.raw, C.c_void_p(dev_codes), int(n), C.c_void_p(dev_out)))
+
 
 def dequantize_f16(f16) -> np.ndarray:
     h = np.ascontiguousarray(f16, dtype=np.float16)
@@ -631,8 +698,18 @@ def dequantize_f16(f16) -> np.ndarray:
     return out
 
 
+def dequantize_f16_device(dev_f16: int, count: int, dev_out: int):
+    check(load().vqhip_dequantize_f16_device(C.c_void_p(dev_f16), int(count), C.c_void_p(dev_out)))
+
+
 def set_device(device: int):
     check(load().vqhip_set_device(device))
+
+
+def get_device() -> int:
+    """the calling thread's current HIP device (0 when no device is visible: the compute calls then report it)"""
+    d = C.c_int(0)
+    return int(d.value) if load().vqhip_get_device(C.byref(d)) == OK else 0
 
 
 def set_stream(stream_ptr: int | None):

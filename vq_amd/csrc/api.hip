@@ -997,6 +997,14 @@ int vqhip_set_device(int device) {
     return require_gfx950();
 }
 
+int vqhip_get_device(int *device) {
+    if (!device) return fail(VQHIP_ERR_NULL_PTR, "device is NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VQHIP_ERR_NO_DEVICE, "no HIP device available");
+    VQ_HIP(hipGetDevice(device));
+    return VQHIP_OK;
+}
+
 int vqhip_set_stream(void *hip_stream) {
     ThreadState &st = tls();
     st.user_stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -1636,6 +1644,31 @@ int vqhip_kmeans_step(vqhip_kmeans *km, uint32_t *counts, uint8_t *changed) {
     VQ_API_END
 }
 
+// ---- failure containment of the sharded entry points -------------------------------------------------------------------
+// A rank that leaves a collective call early (allocation / launch failure on its device only) must not leave its peers
+// waiting: every sharded entry point goes out through sharded_exit, which poisons an in-process group (comm.hip:
+// comm_abort; the peers' barriers return VQHIP_ERR_RUNTIME at once, and their waits are bounded anyway).  Argument errors
+// every rank sees alike (NULL, INVALID_INPUT, UNSUPPORTED) do not poison.
+static int sharded_exit(vqhip_comm *comm, int rc) {
+    if ((rc == VQHIP_ERR_RUNTIME || rc == VQHIP_ERR_FAILURE || rc == VQHIP_ERR_NO_DEVICE) && comm && comm->c) {
+        const char *silent = getenv("VQHIP_TEST_FAIL_SILENT");  // tests: a rank that dies without telling (peers time out)
+        if (!(silent && silent[0] == '1')) comm_abort(comm->c, tls().last_error.c_str());
+    }
+    return rc;
+}
+
+// Fault injection for tests/test_gpu_multi.py (compiled in, off unless BOTH variables are set; read per call):
+// rank VQHIP_TEST_FAIL_RANK of a sharded run fails in front of iteration VQHIP_TEST_FAIL_ITER with VQHIP_ERR_RUNTIME, as a
+// launch failure on that rank's device would.
+static int fault_injected(Comm *comm, uint32_t it) {
+    const char *fr = getenv("VQHIP_TEST_FAIL_RANK"), *fi = getenv("VQHIP_TEST_FAIL_ITER");
+    if (!fr || !fi || !fr[0] || !fi[0]) return VQHIP_OK;
+    int world = 1, rank = 0;
+    comm_info(comm, &world, &rank);
+    if (rank != atoi(fr) || it != (uint32_t)atoi(fi)) return VQHIP_OK;
+    return fail(VQHIP_ERR_RUNTIME, "fault injection: rank %d of %d fails in front of iteration %u (VQHIP_TEST_FAIL_RANK / _ITER)", rank, world, it);
+}
+
 // Up to max_iters Lloyd iterations (src/core/vector.rs:415-458) with the loop's decisions taken on the device: the
 // iterations are queued back to back; a converged subspace stops being processed, an empty cluster in an active
 // subspace pauses the run after that iteration (every later queued kernel becomes a no-op) so that the caller can
@@ -1708,6 +1741,7 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
             bool any = false;
             for (uint32_t i = 0; i < m; ++i) any = any || km->active[i];
             if (!any) break;
+            VQ_TRY(fault_injected(comm, it));
             if (world > 1) {
                 VQ_TRY(kmeans_accumulate_enqueue(km, s));
                 VQ_TRY(comm_allreduce_f64(comm, km->slab.as<double>(), (size_t)m * k * (km->cs.sd + 1), s));
@@ -1755,6 +1789,7 @@ static int kmeans_run_impl(vqhip_kmeans *km, Comm *comm, uint32_t max_iters, uin
             VQ_TRY(kmeans_small_enqueue(km, s, true, it));
             continue;
         }
+        VQ_TRY(fault_injected(comm, it));
         VQ_TRY(kmeans_accumulate_enqueue(km, s, true, fuse_finalize));
         // row-sharded: the one exchange of the iteration (a paused run re-sums a slab nobody reads: all ranks pause alike)
         if (!fuse_finalize) VQ_TRY(comm_allreduce_f64(comm, km->slab.as<double>(), (size_t)m * k * (km->cs.sd + 1), s));
@@ -1807,7 +1842,7 @@ int vqhip_kmeans_run_sharded(vqhip_kmeans *km, vqhip_comm *comm, uint32_t max_it
     std::lock_guard<std::recursive_mutex> lk_km(km->sync.mu);  // lock order: k-means handle, then communicator
     std::unique_lock<std::recursive_mutex> lk_comm;
     if (comm) lk_comm = std::unique_lock<std::recursive_mutex>(comm->mu);
-    return kmeans_run_impl(km, comm ? comm->c : nullptr, max_iters, iters_done, counts, changed, paused);
+    return sharded_exit(comm, kmeans_run_impl(km, comm ? comm->c : nullptr, max_iters, iters_done, counts, changed, paused));
 }
 
 int vqhip_kmeans_patch_centroid(vqhip_kmeans *km, uint32_t s, uint32_t j, const float *sub_row) {
@@ -1930,13 +1965,21 @@ int vqhip_comm_group_destroy(vqhip_comm_group *group) {
     return VQHIP_OK;
 }
 
+// from ANY thread, no lock taken (the thread that owns the communicator may be blocked inside a collective with it)
+int vqhip_comm_abort(vqhip_comm *comm) {
+    if (!comm || !comm->c) return VQHIP_OK;
+    comm_abort(comm->c, "aborted by the caller (vqhip_comm_abort)");
+    comm_abort_rccl(comm->c);
+    return VQHIP_OK;
+}
+
 int vqhip_comm_kind(const vqhip_comm *comm, int *kind) {
     if (!kind) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     *kind = comm_kind(comm ? comm->c : nullptr);
     return VQHIP_OK;
 }
 
-int vqhip_kmeans_allreduce(vqhip_kmeans *km, vqhip_comm *comm) {
+static int kmeans_allreduce_impl(vqhip_kmeans *km, vqhip_comm *comm) {
     VQ_API_BEGIN
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     Entry in(km->sync);
@@ -1954,7 +1997,9 @@ int vqhip_kmeans_allreduce(vqhip_kmeans *km, vqhip_comm *comm) {
     VQ_API_END
 }
 
-int vqhip_kmeans_step_sharded(vqhip_kmeans *km, vqhip_comm *comm, uint32_t *counts, uint8_t *changed) {
+int vqhip_kmeans_allreduce(vqhip_kmeans *km, vqhip_comm *comm) { return sharded_exit(comm, kmeans_allreduce_impl(km, comm)); }
+
+static int kmeans_step_sharded_impl(vqhip_kmeans *km, vqhip_comm *comm, uint32_t *counts, uint8_t *changed) {
     VQ_API_BEGIN
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     VQ_TRY(require_gfx950());
@@ -1964,7 +2009,7 @@ int vqhip_kmeans_step_sharded(vqhip_kmeans *km, vqhip_comm *comm, uint32_t *coun
     hipStream_t s;
     VQ_TRY(in.stream(&s));
     VQ_TRY(kmeans_accumulate_enqueue(km, s));
-    VQ_TRY(vqhip_kmeans_allreduce(km, comm));
+    VQ_TRY(kmeans_allreduce_impl(km, comm));
     VQ_TRY(kmeans_finalize_enqueue(km, s));
     VQ_TRY(spin_wait(s));
     in.synced();
@@ -1972,6 +2017,8 @@ int vqhip_kmeans_step_sharded(vqhip_kmeans *km, vqhip_comm *comm, uint32_t *coun
     return VQHIP_OK;
     VQ_API_END
 }
+
+int vqhip_kmeans_step_sharded(vqhip_kmeans *km, vqhip_comm *comm, uint32_t *counts, uint8_t *changed) { return sharded_exit(comm, kmeans_step_sharded_impl(km, comm, counts, changed)); }
 
 // bits of the owned rows among `global_rows` [m][k] into xs_ws (device u32 [m][k][sd]); zeros elsewhere
 static int gather_owned_enqueue(vqhip_kmeans *km, const uint64_t *global_rows, uint64_t row_offset, hipStream_t s) {
@@ -1997,7 +2044,7 @@ int vqhip_kmeans_gather_owned_rows(vqhip_kmeans *km, const uint64_t *global_rows
     VQ_API_END
 }
 
-int vqhip_kmeans_init_from_global_rows(vqhip_kmeans *km, vqhip_comm *comm, const uint64_t *global_rows, uint64_t row_offset) {
+static int kmeans_init_from_global_rows_impl(vqhip_kmeans *km, vqhip_comm *comm, const uint64_t *global_rows, uint64_t row_offset) {
     VQ_API_BEGIN
     if (!km || !global_rows) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     VQ_TRY(require_gfx950());
@@ -2017,8 +2064,9 @@ int vqhip_kmeans_init_from_global_rows(vqhip_kmeans *km, vqhip_comm *comm, const
     VQ_API_END
 }
 
-int vqhip_kmeans_patch_from_global_row(vqhip_kmeans *km, vqhip_comm *comm, uint32_t sub, uint32_t j, uint64_t global_row,
-                                       uint64_t row_offset) {
+int vqhip_kmeans_init_from_global_rows(vqhip_kmeans *km, vqhip_comm *comm, const uint64_t *global_rows, uint64_t row_offset) { return sharded_exit(comm, kmeans_init_from_global_rows_impl(km, comm, global_rows, row_offset)); }
+
+static int kmeans_patch_from_global_row_impl(vqhip_kmeans *km, vqhip_comm *comm, uint32_t sub, uint32_t j, uint64_t global_row, uint64_t row_offset) {
     VQ_API_BEGIN
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     if (sub >= km->cs.m || j >= km->cs.k) return fail(VQHIP_ERR_INVALID_INPUT, "centroid (%u,%u) out of range", sub, j);
@@ -2043,6 +2091,8 @@ int vqhip_kmeans_patch_from_global_row(vqhip_kmeans *km, vqhip_comm *comm, uint3
     return VQHIP_OK;
     VQ_API_END
 }
+
+int vqhip_kmeans_patch_from_global_row(vqhip_kmeans *km, vqhip_comm *comm, uint32_t sub, uint32_t j, uint64_t global_row, uint64_t row_offset) { return sharded_exit(comm, kmeans_patch_from_global_row_impl(km, comm, sub, j, global_row, row_offset)); }
 
 // ----------------------------------------------------------------------- PQ encode ----
 int vqhip_pq_encoder_create(const float *codebooks, uint32_t m, uint32_t k, uint32_t sub_dim, int metric,
@@ -2303,6 +2353,33 @@ int vqhip_pq_decode(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n, flo
     VQ_HIP(hipStreamSynchronize(s));
     in.synced();
     return VQHIP_OK;
+    VQ_API_END
+}
+
+// device forms (asynchronous on the current stream, like vqhip_pq_encode_device): what a host that keeps codes / f16 rows
+// resident calls, and what bench.py times.  Codes are the caller's to keep inside [0, k): an out-of-range code reads a
+// wrong (in-bounds of the allocation or not) codebook row -- the host form checks, this one cannot without a read-back.
+int vqhip_pq_decode_device(vqhip_pq_encoder *enc, const void *dev_codes, uint64_t n, void *dev_out) {
+    VQ_API_BEGIN
+    if (!enc) return fail(VQHIP_ERR_NULL_PTR, "encoder is NULL");
+    if (n == 0) return VQHIP_OK;
+    if (!dev_codes || !dev_out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    VQ_TRY(require_gfx950());
+    Entry in(enc->sync);
+    hipStream_t s;
+    VQ_TRY(in.stream(&s));
+    return launch_decode_f32(enc->cs.view(), static_cast<const uint8_t *>(dev_codes), n, static_cast<float *>(dev_out), s);
+    VQ_API_END
+}
+
+int vqhip_dequantize_f16_device(const void *dev_f16_in, uint64_t count, void *dev_out) {
+    VQ_API_BEGIN
+    if (count == 0) return VQHIP_OK;
+    if (!dev_f16_in || !dev_out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    VQ_TRY(require_gfx950());
+    hipStream_t s;
+    VQ_TRY(current_stream(&s));
+    return launch_dequant_f16(static_cast<const uint16_t *>(dev_f16_in), count, static_cast<float *>(dev_out), s);
     VQ_API_END
 }
 

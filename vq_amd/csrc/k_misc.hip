@@ -61,26 +61,58 @@ __global__ __launch_bounds__(256) void k_gather_f16(const float *__restrict__ cb
     }
 }
 
+// out[row][s*sd + t] = codebook[s][codes[row][s]][t]: 4*D bytes out + m bytes in per row, HBM-bound (the codebook rows
+// come from L1 / L2).  VEC = 4: one 16-byte store per lane, the row / column split in 32-bit arithmetic per block tile
+// (the scalar form paid a 64-bit division per ELEMENT: 0.9 TB/s).
+template <int VEC>
 __global__ __launch_bounds__(256) void k_decode_f32(const float *__restrict__ cb, uint32_t m,
                                                     uint32_t k, uint32_t sd,
                                                     const uint8_t *__restrict__ codes, uint64_t n,
                                                     float *__restrict__ out) {
     const uint32_t d = m * sd;
-    const uint64_t total = n * d;
-    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < total;
-         e += (uint64_t)gridDim.x * 256) {
-        const uint64_t row = e / d;
-        const uint32_t col = (uint32_t)(e - row * d);
+    const uint32_t gpr = d / VEC;  // groups per row
+    const uint64_t total = n * gpr;
+    for (uint64_t base = (uint64_t)blockIdx.x * 256; base < total; base += (uint64_t)gridDim.x * 256) {
+        const uint64_t row0 = base / gpr;                       // (uniform: scalar unit)
+        const uint32_t g = (uint32_t)(base - row0 * gpr) + threadIdx.x;
+        const uint32_t dr = g / gpr;
+        const uint64_t row = row0 + dr;
+        if (row >= n) continue;
+        const uint32_t col = (g - dr * gpr) * VEC;
         const uint32_t s = col / sd, t = col - s * sd;
-        out[e] = cb[((size_t)s * k + load_code(codes, row * m + s, k)) * sd + t];
+        const float *src = cb + ((size_t)s * k + load_code(codes, row * m + s, k)) * sd + t;
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<float4 *>(out + row * d + col) = *reinterpret_cast<const float4 *>(src);
+        } else {
+            out[row * d + col] = src[0];
+        }
     }
 }
 
+// f16 bits -> f32 (exact, src/pq.rs:208): 2 bytes in + 4 bytes out per element, HBM-bound; eight elements per lane
+// (one 16-byte load, two 16-byte stores), scalar tail
 __global__ __launch_bounds__(256) void k_dequant_f16(const uint16_t *__restrict__ in, uint64_t count,
                                                      float *__restrict__ out) {
-    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < count;
-         e += (uint64_t)gridDim.x * 256)
-        out[e] = __half2float(__ushort_as_half(in[e]));  // exact, src/pq.rs:208
+    const uint64_t groups = count / 8;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (aligned) {
+        for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (uint64_t)gridDim.x * 256) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(in + g * 8);
+            float4 a, b;
+            a.x = __half2float(__ushort_as_half((unsigned short)(v.x & 0xffffu)));
+            a.y = __half2float(__ushort_as_half((unsigned short)(v.x >> 16)));
+            a.z = __half2float(__ushort_as_half((unsigned short)(v.y & 0xffffu)));
+            a.w = __half2float(__ushort_as_half((unsigned short)(v.y >> 16)));
+            b.x = __half2float(__ushort_as_half((unsigned short)(v.z & 0xffffu)));
+            b.y = __half2float(__ushort_as_half((unsigned short)(v.z >> 16)));
+            b.z = __half2float(__ushort_as_half((unsigned short)(v.w & 0xffffu)));
+            b.w = __half2float(__ushort_as_half((unsigned short)(v.w >> 16)));
+            *reinterpret_cast<float4 *>(out + g * 8) = a;
+            *reinterpret_cast<float4 *>(out + g * 8 + 4) = b;
+        }
+    }
+    for (uint64_t e = (aligned ? groups * 8 : 0) + (uint64_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (uint64_t)gridDim.x * 256)
+        out[e] = __half2float(__ushort_as_half(in[e]));
 }
 
 uint32_t stream_grid(uint64_t total) {
@@ -111,15 +143,19 @@ int launch_gather_f16(const CodebookView &cb, const uint8_t *codes, uint64_t n, 
 int launch_decode_f32(const CodebookView &cb, const uint8_t *codes, uint64_t n, float *out,
                       hipStream_t stream) {
     if (n == 0) return VQHIP_OK;
-    hipLaunchKernelGGL(k_decode_f32, dim3(stream_grid(n * cb.m * cb.sd)), dim3(256), 0, stream,
-                       cb.cb, cb.m, cb.k, cb.sd, codes, n, out);
+    const bool vec4 = (cb.sd % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ((reinterpret_cast<uintptr_t>(cb.cb) & 15) == 0) &&
+                      (uint64_t)cb.m * cb.sd / 4 + 256 < (1ull << 31);
+    if (vec4)
+        hipLaunchKernelGGL(k_decode_f32<4>, dim3(stream_grid(n * cb.m * cb.sd / 4)), dim3(256), 0, stream, cb.cb, cb.m, cb.k, cb.sd, codes, n, out);
+    else
+        hipLaunchKernelGGL(k_decode_f32<1>, dim3(stream_grid(n * cb.m * cb.sd)), dim3(256), 0, stream, cb.cb, cb.m, cb.k, cb.sd, codes, n, out);
     VQ_LAUNCH_CHECK("k_decode_f32");
     return VQHIP_OK;
 }
 
 int launch_dequant_f16(const uint16_t *in, uint64_t count, float *out, hipStream_t stream) {
     if (count == 0) return VQHIP_OK;
-    hipLaunchKernelGGL(k_dequant_f16, dim3(stream_grid(count)), dim3(256), 0, stream, in, count, out);
+    hipLaunchKernelGGL(k_dequant_f16, dim3(stream_grid((count + 7) / 8)), dim3(256), 0, stream, in, count, out);
     VQ_LAUNCH_CHECK("k_dequant_f16");
     return VQHIP_OK;
 }

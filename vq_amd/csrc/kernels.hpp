@@ -197,6 +197,8 @@ struct LocalGroup;
 int local_group_create(int world, LocalGroup **out);
 void local_group_destroy(LocalGroup *g);
 int comm_create_local(LocalGroup *g, int rank, Comm **out);  // collective over the group's ranks, each on its own thread
+void comm_abort(Comm *c, const char *text);  // poison an in-process group: blocked peers return at once (no-op otherwise)
+void comm_abort_rccl(Comm *c);                 // ncclCommAbort on an owned communicator (one-process RCCL team's failure path)
 int comm_kind(const Comm *c);                                // 0 identity, 1 RCCL, 2 in-process exchange
 
 // ---- TSVQ -----------------------------------------------------------------------------

@@ -25,7 +25,10 @@ using namespace vqhip;
 
 namespace {
 
-// fn(rank) on every worker thread at once; the first failure's status and text come back on the calling thread
+// fn(rank) on every worker thread at once.  The first failure's status comes back on the calling thread, its text
+// prefixed with the rank and device it happened on.  `on_fail` (optional) runs on the CALLING thread as soon as the first
+// worker reports a failure, while the others may still be inside the call: it aborts their communicators, so that a rank
+// blocked in a collective with the failed one returns instead of waiting.
 class WorkerTeam {
    public:
     explicit WorkerTeam(const std::vector<int> &devices) : w_(devices.size()) {
@@ -38,41 +41,47 @@ class WorkerTeam {
     ~WorkerTeam() {
         for (auto &w : w_) {
             {
-                std::lock_guard<std::mutex> lk(w->mu);
+                std::lock_guard<std::mutex> lk(mu_);
                 w->quit = true;
             }
-            w->cv.notify_all();
+            cv_.notify_all();
             w->th.join();
         }
     }
     int world() const { return (int)w_.size(); }
     int device(int r) const { return w_[(size_t)r]->device; }
-    int run(const std::function<int(int)> &fn) {
+    int run(const std::function<int(int)> &fn, const std::function<void()> &on_fail = nullptr) {
         std::lock_guard<std::mutex> one(call_mu_);  // one collective call at a time over a team
-        for (auto &w : w_) {
-            {
-                std::lock_guard<std::mutex> lk(w->mu);
-                w->job = &fn;
-                w->done = false;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (auto &w : w_) w->job = &fn, w->done = false, w->rc = VQHIP_OK, w->err.clear();
+        n_done_ = 0, first_fail_ = -1;
+        cv_.notify_all();
+        bool told = false;
+        for (;;) {
+            cv_.wait(lk, [&] { return n_done_ == (int)w_.size() || (first_fail_ >= 0 && !told); });
+            if (first_fail_ >= 0 && !told) {
+                told = true;
+                if (on_fail) {
+                    lk.unlock();
+                    on_fail();
+                    lk.lock();
+                }
             }
-            w->cv.notify_all();
+            if (n_done_ == (int)w_.size()) break;
         }
-        int rc = VQHIP_OK;
-        std::string err;
-        for (auto &w : w_) {
-            std::unique_lock<std::mutex> lk(w->mu);
-            w->cv.wait(lk, [&] { return w->done; });
-            if (w->rc != VQHIP_OK && rc == VQHIP_OK) rc = w->rc, err = w->err;
-        }
-        return rc == VQHIP_OK ? VQHIP_OK : fail(rc, "%s", err.c_str());
+        if (first_fail_ < 0) return VQHIP_OK;
+        const W &f = *w_[(size_t)first_fail_];
+        int others = 0;
+        for (auto &w : w_) others += (w->rc != VQHIP_OK) ? 1 : 0;
+        if (w_.size() == 1) return fail(f.rc, "%s", f.err.c_str());
+        return fail(f.rc, "rank %d (device %d): %s%s", first_fail_, f.device, f.err.c_str(),
+                    others > 1 ? " [more than one rank failed]" : "");
     }
 
    private:
     struct W {
         int device = 0;
         std::thread th;
-        std::mutex mu;
-        std::condition_variable cv;
         const std::function<int(int)> *job = nullptr;
         bool done = true, quit = false;
         int rc = VQHIP_OK;
@@ -85,8 +94,8 @@ class WorkerTeam {
         for (;;) {
             const std::function<int(int)> *job;
             {
-                std::unique_lock<std::mutex> lk(w.mu);
-                w.cv.wait(lk, [&] { return w.quit || w.job; });
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return w.quit || w.job; });
                 if (!w.job) return;  // quit
                 job = w.job;
             }
@@ -97,14 +106,18 @@ class WorkerTeam {
                 if (rc != VQHIP_OK) err = vqhip_last_error();
             }
             {
-                std::lock_guard<std::mutex> lk(w.mu);
+                std::lock_guard<std::mutex> lk(mu_);
                 w.rc = rc, w.err = err, w.job = nullptr, w.done = true;
+                ++n_done_;
+                if (rc != VQHIP_OK && first_fail_ < 0) first_fail_ = r;
             }
-            w.cv.notify_all();
+            cv_.notify_all();
         }
     }
     std::vector<std::unique_ptr<W>> w_;
-    std::mutex call_mu_;
+    std::mutex call_mu_, mu_;
+    std::condition_variable cv_;
+    int n_done_ = 0, first_fail_ = -1;
 };
 
 int check_devices(const int *devices, int n_devices, std::vector<int> *out) {
@@ -148,6 +161,12 @@ struct vqhip_mpq_encoder {
     std::unique_ptr<WorkerTeam> team;
     std::vector<vqhip_pq_encoder *> enc;
     uint32_t m = 0, k = 0, d = 0;
+};
+
+struct vqhip_mtsvq {
+    std::unique_ptr<WorkerTeam> team;
+    std::vector<vqhip_tsvq *> t;
+    uint32_t d = 0;
 };
 
 extern "C" {
@@ -273,15 +292,25 @@ int vqhip_mkmeans_info(vqhip_mkmeans *km, int *world, int *comm_kind) {
     return VQHIP_OK;
 }
 
+// a rank failed while the others may sit in a collective with it: abort every rank's communicator (an in-process
+// group is poisoned -- the failing rank has done that itself already --, an RCCL communicator gets ncclCommAbort)
+static void mkmeans_abort(vqhip_mkmeans *km) {
+    if (const char *silent = getenv("VQHIP_TEST_FAIL_SILENT"); silent && silent[0] == '1') return;  // (tests: the peers must time out)
+    for (vqhip_comm *c : km->comm)
+        if (c) (void)vqhip_comm_abort(c);
+}
+
 #define VQ_M_ALL(km, expr)                                             \
     if (!(km)) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");       \
-    return (km)->mds->team->run([&](int r) {                           \
-        vqhip_kmeans *h = (km)->km[(size_t)r];                         \
-        vqhip_comm *c = (km)->comm[(size_t)r];                         \
-        const uint64_t off = (km)->mds->off[(size_t)r];                \
-        (void)h, (void)c, (void)off;                                   \
-        return (expr);                                                 \
-    })
+    return (km)->mds->team->run(                                       \
+        [&](int r) {                                                   \
+            vqhip_kmeans *h = (km)->km[(size_t)r];                     \
+            vqhip_comm *c = (km)->comm[(size_t)r];                     \
+            const uint64_t off = (km)->mds->off[(size_t)r];            \
+            (void)h, (void)c, (void)off;                               \
+            return (expr);                                             \
+        },                                                             \
+        [&] { if ((km)->mds->team->world() > 1) mkmeans_abort(km); })
 
 int vqhip_mkmeans_set_engine(vqhip_mkmeans *km, int engine) { VQ_M_ALL(km, vqhip_kmeans_set_engine(h, engine)); }
 // (the reference's summation order is one sequential chain over all rows: one device slot only)
@@ -307,11 +336,13 @@ int vqhip_mkmeans_run(vqhip_mkmeans *km, uint32_t max_iters, uint32_t *iters_don
     if (!km) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
     const int world = km->mds->team->world();
     std::vector<int> pz((size_t)world, 0);
-    const int rc = km->mds->team->run([&](int r) {
-        // counts / changed / iterations are global after the all-reduce: the same on every rank, rank 0 writes the caller's
-        return vqhip_kmeans_run_sharded(km->km[(size_t)r], km->comm[(size_t)r], max_iters, r == 0 ? iters_done : nullptr,
-                                        r == 0 ? counts : nullptr, r == 0 ? changed : nullptr, &pz[(size_t)r]);
-    });
+    const int rc = km->mds->team->run(
+        [&](int r) {
+            // counts / changed / iterations are global after the all-reduce: the same on every rank, rank 0 writes the caller's
+            return vqhip_kmeans_run_sharded(km->km[(size_t)r], km->comm[(size_t)r], max_iters, r == 0 ? iters_done : nullptr,
+                                            r == 0 ? counts : nullptr, r == 0 ? changed : nullptr, &pz[(size_t)r]);
+        },
+        [&] { if (world > 1) mkmeans_abort(km); });
     if (rc != VQHIP_OK) return rc;
     for (int r = 1; r < world; ++r)
         if (pz[(size_t)r] != pz[0]) return fail(VQHIP_ERR_FAILURE, "ranks disagree on the pause of a run (rank %d: %d, rank 0: %d)", r, pz[(size_t)r], pz[0]);
@@ -401,6 +432,112 @@ int vqhip_mpq_encoder_destroy(vqhip_mpq_encoder *enc) {
             return VQHIP_OK;
         });
     delete enc;
+    return VQHIP_OK;
+}
+
+// ---- the other two paths that shard by rows with no collective: TSVQ encode and dequantize / decode ----
+
+// reconstruction from codes (the batch form of Quantizer::dequantize over stored codes, src/pq.rs:201-209): row blocks
+int vqhip_mpq_decode(vqhip_mpq_encoder *enc, const uint8_t *codes, uint64_t n, float *out) {
+    if (!enc) return fail(VQHIP_ERR_NULL_PTR, "encoder is NULL");
+    if (n == 0) return VQHIP_OK;
+    if (!codes || !out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    const int world = enc->team->world();
+    const size_t cw = vqhip_code_bytes(enc->k);
+    return enc->team->run([&](int r) {
+        uint64_t off, cnt;
+        shard_rows(n, world, r, &off, &cnt);
+        if (cnt == 0) return (int)VQHIP_OK;
+        return vqhip_pq_decode(enc->enc[(size_t)r], codes + off * enc->m * cw, cnt, out + off * enc->d);
+    });
+}
+
+// f16 bits -> f32 over the encoder's devices (element blocks: the conversion is element-wise)
+int vqhip_mpq_dequantize_f16(vqhip_mpq_encoder *enc, const uint16_t *f16_in, uint64_t count, float *out) {
+    if (!enc) return fail(VQHIP_ERR_NULL_PTR, "encoder is NULL");
+    if (count == 0) return VQHIP_OK;
+    if (!f16_in || !out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    const int world = enc->team->world();
+    return enc->team->run([&](int r) {
+        uint64_t off, cnt;
+        shard_rows(count, world, r, &off, &cnt);
+        return cnt ? vqhip_dequantize_f16(f16_in + off, cnt, out + off) : (int)VQHIP_OK;
+    });
+}
+
+// TSVQ::quantize for a batch (src/tsvq.rs:239-255) with the host rows in row blocks over the devices: the tree is
+// replicated (a depth-8 tree at d = 128 is 260 KB), every device descends its own rows -- no collective
+int vqhip_mtsvq_create(const float *centroids, const int32_t *left, const int32_t *right, uint32_t n_nodes, uint32_t d, int metric,
+                       const int *devices, int n_devices, vqhip_mtsvq **out) {
+    if (!out) return fail(VQHIP_ERR_NULL_PTR, "out is NULL");
+    *out = nullptr;
+    std::vector<int> devs;
+    VQ_TRY(check_devices(devices, n_devices, &devs));
+    std::unique_ptr<vqhip_mtsvq> h(new vqhip_mtsvq());
+    h->team.reset(new WorkerTeam(devs));
+    h->t.assign(devs.size(), nullptr);
+    h->d = d;
+    vqhip_mtsvq *p = h.get();
+    const int rc = h->team->run([&](int r) { return vqhip_tsvq_create(centroids, left, right, n_nodes, d, metric, &p->t[(size_t)r]); });
+    if (rc != VQHIP_OK) {
+        const std::string keep = vqhip_last_error();
+        (void)vqhip_mtsvq_destroy(h.release());
+        return fail(rc, "%s", keep.c_str());
+    }
+    *out = h.release();
+    return VQHIP_OK;
+}
+
+int vqhip_mtsvq_encode(vqhip_mtsvq *t, const float *rows, uint64_t n, int32_t *leaf, uint16_t *f16_out) {
+    if (!t) return fail(VQHIP_ERR_NULL_PTR, "tree is NULL");
+    if (n == 0) return VQHIP_OK;
+    if (!rows) return fail(VQHIP_ERR_NULL_PTR, "rows is NULL");
+    const int world = t->team->world();
+    return t->team->run([&](int r) {
+        uint64_t off, cnt;
+        shard_rows(n, world, r, &off, &cnt);
+        if (cnt == 0) return (int)VQHIP_OK;
+        return vqhip_tsvq_encode(t->t[(size_t)r], rows + off * t->d, cnt, leaf ? leaf + off : nullptr, f16_out ? f16_out + off * t->d : nullptr);
+    });
+}
+
+// f16 bits -> f32 (TSVQ::dequantize, src/tsvq.rs:257-265, for a batch) over the tree's devices
+int vqhip_mtsvq_dequantize_f16(vqhip_mtsvq *t, const uint16_t *f16_in, uint64_t count, float *out) {
+    if (!t) return fail(VQHIP_ERR_NULL_PTR, "tree is NULL");
+    if (count == 0) return VQHIP_OK;
+    if (!f16_in || !out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    const int world = t->team->world();
+    return t->team->run([&](int r) {
+        uint64_t off, cnt;
+        shard_rows(count, world, r, &off, &cnt);
+        return cnt ? vqhip_dequantize_f16(f16_in + off, cnt, out + off) : (int)VQHIP_OK;
+    });
+}
+
+// (screened descent used on every device?, undecided rows summed over the devices) of the last batch
+int vqhip_mtsvq_last_stats(vqhip_mtsvq *t, int *screened, uint64_t *undecided) {
+    if (!t) return fail(VQHIP_ERR_NULL_PTR, "tree is NULL");
+    const int world = t->team->world();
+    std::vector<int> sc((size_t)world, 0);
+    std::vector<uint64_t> un((size_t)world, 0);
+    VQ_TRY(t->team->run([&](int r) { return vqhip_tsvq_last_stats(t->t[(size_t)r], &sc[(size_t)r], &un[(size_t)r]); }));
+    int all = 1;
+    uint64_t sum = 0;
+    for (int r = 0; r < world; ++r) all = all && sc[(size_t)r], sum += un[(size_t)r];
+    if (screened) *screened = all;
+    if (undecided) *undecided = sum;
+    return VQHIP_OK;
+}
+
+int vqhip_mtsvq_destroy(vqhip_mtsvq *t) {
+    if (!t) return VQHIP_OK;
+    if (t->team)
+        (void)t->team->run([&](int r) {
+            if (t->t[(size_t)r]) (void)vqhip_tsvq_destroy(t->t[(size_t)r]);
+            t->t[(size_t)r] = nullptr;
+            return VQHIP_OK;
+        });
+    delete t;
     return VQHIP_OK;
 }
 

@@ -129,10 +129,15 @@ class ProductQuantizer:
     def __init__(self, training_data, num_subspaces: int, num_centroids: int, max_iters: int = 10,
                  distance: Distance | None = None, seed: int = 42, *, init_rows=None,
                  reseed_rows=None, engine: int = _lib.ENGINE_AUTO, exact_update: bool = False, devices=None):
-        """devices (not in pyvq): the GPUs the training batch is partitioned over -- None: every visible device; an int n:
-        devices 0..n-1; a sequence of device ids.  One call, one process: with more than one device the rows are
-        sharded over worker threads inside the library and each Lloyd iteration all-reduces the per-cluster sums
-        (include/vqhip.h, "one call, one process, several GPUs"); batch encodes split their rows the same way."""
+        """devices (not in pyvq): the GPUs the training batch is partitioned over -- None: every visible device the batch
+        gives 4M elements of work to (ONE device under ``exact_update``: the reference's summation order is a single
+        chain over all rows); an int n: devices 0..n-1; a sequence of device ids.  One call, one process: with more than
+        one device the rows are sharded over worker threads inside the library and each Lloyd iteration all-reduces the
+        per-cluster sums (include/vqhip.h, "one call, one process, several GPUs"); batch encodes, ``decode`` and
+        ``dequantize_batch`` split their rows the same way.  Codes are the same bits on any device count GIVEN the
+        codebooks; the trained centroids are not: the per-cluster sums are combined per device, then over devices (within
+        the 1e-5 step tolerance of one device's, deterministic for a given device list) -- pass ``devices=[0]`` for
+        codebooks that do not depend on the machine."""
         X = _as_training_matrix(training_data)
         n, dim = X.shape
         m, k = int(num_subspaces), int(num_centroids)
@@ -152,9 +157,16 @@ class ProductQuantizer:
         dv = _lib._devices(devices)
         if devices is None:  # every visible device, as far as the batch gives each of them work (4M elements)
             dv = dv[:max(1, min(dv.size, (n * dim) >> 22))]
+            if exact_update:  # one sequential chain over all rows: the one-device path (an explicit list still raises)
+                dv = dv[:1]
         if dv.size > n:
             dv = dv[:n]  # (every device needs a row)
-        multi = dv.size > 1
+        # one slot naming the calling thread's current device: the single-device handles; anything else -- several slots, or
+        # one slot on ANOTHER device -- goes through the one-process multi-device handles, whose worker threads own their
+        # devices (one slot there is the single-device path bit for bit, tests/test_gpu_multi.py; ADVICE r5: `devices=[1]`
+        # used to run on the current device and report 1)
+        self._pinned = dv.size == 1 and int(dv[0]) != _lib.get_device()
+        multi = dv.size > 1 or self._pinned
         ds = _lib.MDataset.from_host(X, dv) if multi else _lib.Dataset.from_host(X)
         try:
             self._codebooks = fit_codebooks(ds, m, k, int(max_iters), int(seed), init_rows=init_rows,
@@ -163,7 +175,7 @@ class ProductQuantizer:
         finally:
             ds.close()
         self.fit_stats["devices"] = [int(x) for x in dv]
-        self._enc = _lib.PQEncoder(self._codebooks, self._distance.metric)
+        self._enc = _lib.PQEncoder(self._codebooks, self._distance.metric)  # (current device: per-vector calls, ADC search)
         self._enc.set_engine(engine)
         self._menc = None
         if multi:  # batch encodes: row blocks over the same devices
@@ -186,11 +198,12 @@ class ProductQuantizer:
         self._enc = _lib.PQEncoder(cb, self._distance.metric)
         self._enc.set_engine(engine)
         self._menc = None
+        self._pinned = False
         return self
 
     def _batch_encoder(self, n: int):
-        # (small batches are not worth the workers' hand-over)
-        return self._menc if (self._menc is not None and n >= 65536) else self._enc
+        # (small batches are not worth the workers' hand-over -- unless the quantizer was pinned to another device)
+        return self._menc if (self._menc is not None and (n >= 65536 or self._pinned)) else self._enc
 
     # -- reference surface ----------------------------------------------------------------
     def quantize(self, vector) -> np.ndarray:
@@ -198,7 +211,7 @@ class ProductQuantizer:
         v = np.ascontiguousarray(vector, dtype=np.float32).ravel()
         if v.size != self._dim:
             raise DimensionMismatch(self._dim, v.size)
-        _, f16 = self._enc.encode(v[None, :], want_codes=False, want_f16=True)
+        _, f16 = self._batch_encoder(1).encode(v[None, :], want_codes=False, want_f16=True)
         return f16[0]
 
     def dequantize(self, codes) -> np.ndarray:
@@ -281,5 +294,16 @@ class ProductQuantizer:
         return self._enc.adc_search(codes, q, int(topk))
 
     def decode(self, codes) -> np.ndarray:
-        """(n, m) codes -> (n, dim) float32 centroids (un-rounded)"""
-        return self._enc.decode(codes)
+        """(n, m) codes -> (n, dim) float32 centroids (un-rounded); row blocks over the quantizer's devices"""
+        n = int(np.asarray(codes).size) // max(1, self._m)
+        return self._batch_encoder(n).decode(codes)
+
+    def dequantize_batch(self, Q) -> np.ndarray:
+        """(n, dim) float16 -> (n, dim) float32, row i == dequantize(Q[i]) (src/pq.rs:201-209 for a batch)"""
+        Q = np.ascontiguousarray(Q, dtype=np.float16)
+        if Q.ndim != 2:
+            raise ValueError("expected a 2D array (n, dim)")
+        if Q.shape[1] != self._dim:
+            raise DimensionMismatch(self._dim, Q.shape[1])
+        enc = self._batch_encoder(Q.shape[0])
+        return enc.dequantize_f16(Q) if enc is self._menc else _lib.dequantize_f16(Q)

@@ -42,7 +42,12 @@ class TSVQ:
     Args (pyvq/src/tsvq.rs:41-42): training_data (n, dim) float32; max_depth; distance=None
     (-> Euclidean)."""
 
-    def __init__(self, training_data, max_depth: int, distance: Distance | None = None):
+    def __init__(self, training_data, max_depth: int, distance: Distance | None = None, *, devices=None):
+        """devices (not in pyvq): the GPUs batch encodes are split over in row blocks -- None: every visible device; an
+        int n: 0..n-1; a sequence of ids.  The BUILD runs on one device (the calling thread's current one): its column
+        sums are the reference's sequential chains over a node's rows (replicas only); the tree (260 KB
+        at depth 8, d = 128) is then replicated and every device descends its own rows -- leaves and f16 rows are the
+        same bits whatever the device list."""
         X = _as_training_matrix(training_data)
         self._dim = X.shape[1]
         self._distance = distance if distance is not None else Distance.euclidean()
@@ -51,20 +56,25 @@ class TSVQ:
             self._centroids, self._left, self._right = build_tree(ds, int(max_depth))
         finally:
             ds.close()
-        self._make_encoder()
+        self._make_encoder(devices)
 
     @classmethod
-    def from_tree(cls, centroids, left, right, distance: Distance | None = None) -> "TSVQ":
+    def from_tree(cls, centroids, left, right, distance: Distance | None = None, *, devices=None) -> "TSVQ":
         self = cls.__new__(cls)
         self._centroids = np.ascontiguousarray(centroids, dtype=np.float32)
         self._left = np.ascontiguousarray(left, dtype=np.int32)
         self._right = np.ascontiguousarray(right, dtype=np.int32)
         self._dim = self._centroids.shape[1]
         self._distance = distance if distance is not None else Distance.euclidean()
-        self._make_encoder()
+        self._make_encoder(devices)
         return self
 
-    def _make_encoder(self):
+    def _make_encoder(self, devices=None):
+        dv = _lib._devices(devices)
+        self._menc = None
+        if dv.size > 1:  # row blocks of large batches over the devices (vqhip_mtsvq)
+            self._menc = _lib.MTSVQ(self._centroids, self._left, self._right, self._distance.metric, dv)
+        self.devices = [int(x) for x in dv]
         h = C.c_void_p()
         lib = _lib.load()
         _lib.check(lib.vqhip_tsvq_create(_lib.ptr(self._centroids, _lib._f32p), _lib.ptr(self._left, _lib._i32p),
@@ -110,7 +120,11 @@ class TSVQ:
         n = X.shape[0]
         leaf = _arena.fresh((n,), np.int32) if want_leaf else None  # (large results: recycled buffers, vq_amd/_arena.py)
         f16 = _arena.fresh((n, self._dim), np.uint16) if want_f16 else None
-        if n:
+        self._last_multi = False
+        if n and self._menc is not None and n >= 65536 * len(self.devices):
+            self._menc.encode(X, leaf, f16)
+            self._last_multi = True
+        elif n:
             _lib.check(_lib.load().vqhip_tsvq_encode(self._enc.raw, _lib.ptr(X, _lib._f32p), n,
                                                      _lib.ptr(leaf, _lib._i32p), _lib.ptr(f16, _lib._u16p)))
         return leaf, (None if f16 is None else f16.view(np.float16))
@@ -120,8 +134,8 @@ class TSVQ:
 
     def last_encode_stats(self):
         """(screened descent used?, rows finished by the exact continuation) of the last batch"""
-        import ctypes as C
-
+        if getattr(self, "_last_multi", False):
+            return self._menc.last_stats()
         scr, und = C.c_int(0), C.c_uint64(0)
         _lib.check(_lib.load().vqhip_tsvq_last_stats(self._enc.raw, C.byref(scr), C.byref(und)))
         return bool(scr.value), int(und.value)
@@ -129,3 +143,14 @@ class TSVQ:
     def leaf_ids(self, X) -> np.ndarray:
         """node index (pre-order) of the leaf each row descends to"""
         return self._encode(X, True, False)[0]
+
+    def dequantize_batch(self, Q) -> np.ndarray:
+        """(n, dim) float16 -> (n, dim) float32, row i == dequantize(Q[i]) (src/tsvq.rs:257-265 for a batch)"""
+        Q = np.ascontiguousarray(Q, dtype=np.float16)
+        if Q.ndim != 2:
+            raise ValueError("expected a 2D array (n, dim)")
+        if Q.shape[1] != self._dim:
+            raise DimensionMismatch(self._dim, Q.shape[1])
+        if self._menc is not None and Q.shape[0] >= 65536 * len(self.devices):
+            return self._menc.dequantize_f16(Q)
+        return _lib.dequantize_f16(Q)
