@@ -290,6 +290,132 @@ def eval_shape(_lib, engine):
     }
 
 
+def exact_update_case(_lib, engine):
+    """C2 k-means with `exact_update`: the only mode whose CENTROIDS are the reference's bits (sums in the reference's row
+    order, src/core/vector.rs:368-384; single GPU) -- assignment on the screen as everywhere, update by bucket + sequential
+    chains instead of the fused accumulators."""
+    import numpy as np
+
+    n, d, m, k = 1_000_000, 128, 8, 256
+    ds = _lib.Dataset.synthetic(n, d, DATA_SEED, 0)
+    km = _lib.KMeans(ds, m, k)
+    km.set_engine(engine)
+    km.set_exact_update(True)
+    init = strided_init(n, m, k).astype(np.uint64)
+    iters = 5
+
+    def restart():
+        km.init_from_rows(init)
+        km.set_active(np.ones(m, np.uint8))
+
+    restart()
+    km.run(2)
+    restart()
+    _lib.synchronize()
+    t0 = time.perf_counter()
+    it, _, _, paused = km.run(iters)
+    _lib.synchronize()
+    dt = time.perf_counter() - t0
+    it = np.asarray(it, np.int64)
+    done = max(1, int(it.max()))
+    ms = dt * 1e3 / done
+    km.close()
+    ds.close()
+    flop = 2.0 * k * d * n
+    return {"workload": "C2's shape, vqhip_kmeans_set_exact_update(1): centroids bit-identical to the reference's sequential sums",
+            "rows": n, "dim": d, "m": m, "k": k, "kmeans_ms_per_iter": ms, "kmeans_iter_per_s": 1e3 / ms,
+            "kmeans_iters_timed": [int(it.min()), int(it.max())], "kmeans_paused": bool(paused),
+            "kmeans_roofline": mfma_roofline(flop * float(it.sum()) / done / m, ms, engine=3, extra={
+                "note": "whole iteration, host-driven loop (one synchronisation per iteration); against the screen's pipe -- the "
+                        "update's sequential f32 chains (n/k = 3900 dependent adds per cluster and column) are what it adds"}),
+            "update_hbm_roofline": hbm_roofline(4.0 * n * d * 2, ms, {"note": "rows read once by the screen and once by the ordered sums"})}
+
+
+def decode_case(_lib, torch):
+    """Quantizer::dequantize for a batch, device-resident (src/pq.rs:201-209): codes -> f32 centroids (vqhip_pq_decode_device:
+    4*D + m bytes per vector) and f16 -> f32 (vqhip_dequantize_f16_device: 6*D bytes per vector); HBM-bound."""
+    import numpy as np
+
+    n, d, m, k = 1_000_000, 128, 8, 256
+    rng = np.random.default_rng(DATA_SEED)
+    cb = rng.standard_normal((m, k, d // m)).astype(np.float32)
+    enc = _lib.PQEncoder(cb, _lib.SQUARED_EUCLIDEAN)
+    g = torch.Generator(device="cuda").manual_seed(DATA_SEED)
+    codes = torch.randint(0, k, (n, m), device="cuda", generator=g, dtype=torch.uint8)
+    f16 = torch.randn((n, d), device="cuda", generator=g).to(torch.float16).contiguous()
+    out = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+
+    def timed(fn, reps=20):
+        for _ in range(10):
+            fn()
+        _lib.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        _lib.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / reps
+
+    dec_ms = timed(lambda: enc.decode_device(codes.data_ptr(), n, out.data_ptr()))
+    ok_dec = bool(torch.equal(out[:4096], torch.from_numpy(np.concatenate(
+        [cb[s][codes[:4096, s].cpu().numpy()] for s in range(m)], axis=1)).cuda()))
+    deq_ms = timed(lambda: _lib.dequantize_f16_device(f16.data_ptr(), n * d, out.data_ptr()))
+    ok_deq = bool(torch.equal(out, f16.to(torch.float32)))
+    enc.close()
+    return {"workload": "1M x 128, m=8 k=256, device-resident: codes -> f32 rows, f16 rows -> f32 rows", "rows": n, "dim": d, "m": m,
+            "decode_ms": dec_ms, "decode_vectors_per_s": n / (dec_ms * 1e-3), "decode_checked": ok_dec,
+            "decode_roofline": hbm_roofline((4.0 * d + m) * n, dec_ms, {"kernel": "k_decode_f32<4>", "note": "4*D bytes out + m code bytes in per vector (codebook rows from L2)"}),
+            "dequantize_ms": deq_ms, "dequantize_vectors_per_s": n / (deq_ms * 1e-3), "dequantize_checked": ok_deq,
+            "dequantize_roofline": hbm_roofline(6.0 * d * n, deq_ms, {"kernel": "k_dequant_f16", "note": "2*D bytes in + 4*D bytes out per vector"})}
+
+
+def adc_case(_lib, torch, engine):
+    """Asymmetric-distance search over stored codes: 64 queries against 1M x 8 device-resident codes, top 10.
+    Per call: the tables (k_adc_lut), one scan of the codes per batch of 8 queries (HBM-bound: n*m bytes per batch), the
+    exact top-k, results to the host."""
+    import numpy as np
+
+    n, d, m, k, nq, topk = 1_000_000, 128, 8, 256, 64, 10
+    ds = _lib.Dataset.synthetic(n, d, DATA_SEED, 0)
+    km = _lib.KMeans(ds, m, k)
+    km.set_engine(engine)
+    km.init_from_rows(strided_init(n, m, k).astype(np.uint64))
+    km.run(TRAIN_ITERS)
+    cb = km.get_centroids()
+    km.close()
+    enc = _lib.PQEncoder(cb, _lib.SQUARED_EUCLIDEAN)
+    enc.set_engine(engine)
+    codes = torch.empty((n, m), dtype=torch.uint8, device="cuda")
+    enc.encode_device(ds.device_ptr, n, codes.data_ptr(), None)
+    _lib.synchronize()
+    Q = _lib.synth_uniform_host(nq, d, DATA_SEED + 1, 0)
+    res = {}
+    for q in (nq, 8):
+        for _ in range(3):
+            enc.adc_search((codes.data_ptr(), n), Q[:q], topk)
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            idx, dist = enc.adc_search((codes.data_ptr(), n), Q[:q], topk)
+        res[q] = (time.perf_counter() - t0) * 1e3 / reps
+    passes = (nq + 7) // 8
+    scan_bytes = float(n) * m * passes + 4.0 * nq * m * k
+    # self-check: a query that IS the reconstruction of a stored row has ADC distance 0 to that row (ties by row index may
+    # name an earlier row with the same codes); recall against exact search is the eval CLI's job (vq_amd/evalcli.py)
+    c8 = codes[:8].cpu().numpy()
+    recon = np.concatenate([cb[s_][c8[:, s_]] for s_ in range(m)], axis=1)
+    i2, d2 = enc.adc_search((codes.data_ptr(), n), recon, 1)
+    top1_is_own_code = bool((d2[:, 0] == 0.0).all() and (i2[:, 0] <= np.arange(8)).all())
+    enc.close()
+    ds.close()
+    return {"workload": f"ADC top-{topk} of {nq} queries over {n} x {m} one-byte codes (device-resident), squared L2", "rows": n, "m": m, "k": k,
+            "queries": nq, "topk": topk, "ms_per_call": res[nq], "queries_per_s": nq / (res[nq] * 1e-3),
+            "ms_per_call_8_queries": res[8], "code_scans_per_call": passes,
+            "roofline": hbm_roofline(scan_bytes, res[nq], {"kernel": "k_adc_scan", "note": "whole call, wall clock (tables + "
+                                     f"{passes} scans of the n*m code bytes + top-k + read-back): algorithmic bytes = n*m per batch of 8 queries + the tables"}),
+            "self_check": top1_is_own_code}
+
+
 def other_configs(_lib, torch, engine):
     """BASELINE configs C1, C3, C4 on one GPU (rank 0, N=1): device-resident synthetic rows, codebooks from a few
     untimed Lloyd iterations, every entry with the roofline SURVEY.md 8(d) assigns it (HIP-event time of the
@@ -432,6 +558,13 @@ def other_configs(_lib, torch, engine):
     encode_case("C2_euclidean", 1_000_000, 128, 8, 256, _lib.EUCLIDEAN, "C2's shape under Distance::Euclidean (the pyvq default; sqrt collapses near-ties onto the earlier index)")
     encode_case("C2_manhattan", 1_000_000, 128, 8, 256, _lib.MANHATTAN, "C2's shape under Distance::Manhattan (no contraction form: exact VALU engine)")
     pq_case("C3", 1_000_000, 768, 96, 256, _lib.COSINE, "BASELINE.json configs[2]: PQ m=96 k=256 cosine, 1M x 768 (training is squared L2, src/core/vector.rs:352-363)")
+    # one GPU's share of BASELINE configs[4] (100M x 128, m = 16 over 8 GPUs): the per-rank work of every point of the 8-GPU
+    # curve; the exchange it adds per iteration is one 295 KB slab (python bench.py --gpus N reports `weak_C5` with it)
+    pq_case("C5_shard", 12_500_000, 128, 16, 256, _lib.SQUARED_EUCLIDEAN,
+            "BASELINE.json configs[4], ONE GPU's shard: PQ m=16 k=256 L2 on 12.5M x 128 (sub_dim 8), no collective in this block")
+    out["C2_exact_update"] = exact_update_case(_lib, engine)
+    out["decode"] = decode_case(_lib, torch)
+    out["adc"] = adc_case(_lib, torch, engine)
 
     out["eval_shape"] = eval_shape(_lib, engine)
 
