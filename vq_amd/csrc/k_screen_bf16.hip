@@ -698,6 +698,30 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     }
 }
 
+// ---- fused update of the pipelined screen, round 6: LDS f64 atomics ---------------------------------------------------
+// profiles/ubench/valu_waves.hip (P10-P16): on gfx950 `ds_add_f64` / `ds_add_u32` WITHOUT return cost ~18 / ~11 ns per wave
+// instruction beside the screen's own instruction mix at two waves per SIMD -- `ds_add_f32` 250 ns (!), a returning add
+// plus its wait 25 ns.  So the wave's per-cluster sums live in LDS as DOUBLES, dimension-major, and a proven row is added
+// by one fire-and-forget atomic per dimension: no ticket (count before + returning add), no rank, no second copy of the
+// sums, no read-modify-write round trips and no turns for three rows of one cluster -- ~25 of the 48 instructions the
+// update added to a sub_dim-8 step, and every wait it had.  Rows of one instruction that share a cluster are
+// serialised by the LDS in a fixed lane order and a wave's LDS operations execute in program order: the same bits run to
+// run.  The partial slab a wave leaves is still [k][SD] f32 (the f64 sum rounded once: closer to the exact sum than the
+// sequential f32 chain it replaces), so k_accumulate_listed / k_reduce_* see the format they always did.
+//   plane t (one dimension of all NT32*32 clusters) = NT32*32 doubles; planes of the upper lane half start 64 bytes
+//   (16 banks) later, so the two halves of an instruction use different banks; counts: u32 [NT32*32] + 64 dummies (the
+//   upper half's lanes add there: one address form, no exec masking)
+#ifndef VQ_ACC_F64
+#define VQ_ACC_F64 1
+#endif
+#ifndef VQ_ACC_RELOAD_PAR
+#define VQ_ACC_RELOAD_PAR 0  // the trip's step that re-reads the pair's rows: 0 = a whole step ahead of the tail that uses them
+#endif
+__host__ __device__ constexpr uint32_t x32p_acc_plane_bytes(int nt32) { return (uint32_t)nt32 * 32u * 8u; }
+__host__ __device__ constexpr uint32_t x32p_acc_bytes_per_wave(int sd, int nt32) {
+    return (uint32_t)sd * x32p_acc_plane_bytes(nt32) + 64u + ((uint32_t)nt32 * 32u + 64u) * 4u;
+}
+
 // ---- variant X32P: the X32 kernel software-pipelined across steps -------------------------------------------
 // A lone wave pays an issue slot of ~5 cycles for EVERY instruction, VALU or not (profiles/ubench/valu_issue.hip), so
 // this kernel's time is its instruction count -- and in the X32 kernel the 12 MFMAs of a step's first two tiles issue
@@ -750,12 +774,34 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
         if (lane == 0) seg_hdr[0] = 0u, seg_hdr[1] = 0u;
         return;
     }
-    // fused update (ACC, see the X32 kernel): this wave's [NT32*32][SD] sums (R copies) + counts in LDS, one partial slab
+    // fused update (ACC): this wave's sums + counts in LDS, one partial slab per (row chunk, subspace)
     extern __shared__ __attribute__((aligned(16))) float acc_lds[];
     constexpr uint32_t R = x32_acc_copies(SD, NT32);
     constexpr uint32_t kCopy = NT32 * 32 * SD;
     float *sums = nullptr;
     uint32_t *cnts = nullptr;
+#if VQ_ACC_F64
+    // (layout: x32p_acc_bytes_per_wave) sums64: plane t at byte t * kPlane (+ 64 for t >= DPH); counts behind them
+    constexpr uint32_t kPlane = x32p_acc_plane_bytes(NT32);
+    char *acc_wave = nullptr;
+    if constexpr (ACC) {
+        acc_wave = reinterpret_cast<char *>(acc_lds) + (size_t)wave * x32p_acc_bytes_per_wave(SD, NT32);
+        cnts = reinterpret_cast<uint32_t *>(acc_wave + SD * kPlane + 64);
+        for (uint32_t e = lane; e < (SD * kPlane + 64) / 16; e += 64) reinterpret_cast<float4 *>(acc_wave)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t e = lane; e < NT32 * 32 + 64; e += 64) cnts[e] = 0u;
+    }
+    auto write_partial = [&]() {
+        if constexpr (ACC) {
+            float *ps = acc_sums + ((size_t)chunk * n_sub + vv) * k_real * SD;
+            for (uint32_t e = lane; e < k_real * SD; e += 64) {  // slab element (cluster j, dimension t): the f64 sum rounded once
+                const uint32_t j = e / SD, t = e % SD;
+                ps[e] = (float)*reinterpret_cast<const double *>(acc_wave + t * kPlane + (t >= DPH ? 64u : 0u) + j * 8u);
+            }
+            uint32_t *pc = acc_counts + ((size_t)chunk * n_sub + vv) * k_real;
+            for (uint32_t e = lane; e < k_real; e += 64) pc[e] = cnts[e];
+        }
+    };
+#else
     if constexpr (ACC) {
         constexpr uint32_t kPerWave = NT32 * 32 * (R * SD + 1);
         sums = acc_lds + (size_t)wave * kPerWave;
@@ -781,6 +827,7 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
             for (uint32_t e = lane; e < k_real; e += 64) pc[e] = cnts[e];
         }
     };
+#endif
     if (st0 >= st1) {
         write_partial();  // an empty chunk still owns a (zero) slab
         if (lane == 0) seg_hdr[0] = 0u, seg_hdr[1] = 0u;
@@ -903,7 +950,7 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
         if (k == 0) {
 #pragma unroll
             for (int q = 0; q < DPH / 4; ++q) {
-                if constexpr (x32_two_waves(SD, NT32) && !ACC) {
+                if constexpr (x32_two_waves(SD, NT32) && (!ACC || VQ_ACC_F64)) {
                     f32x4 dv = xn_[nb % kDeep][q] - mu4[q];
                     asm volatile("" : "+v"(dv));  // consumed HERE (see reduce_hg), the registers are free for the next load
                     xc[4 * q + 0] = dv[0], xc[4 * q + 1] = dv[1], xc[4 * q + 2] = dv[2], xc[4 * q + 3] = dv[3];
@@ -1008,16 +1055,33 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     };
     auto acc_ticket = [&](bool mine) {
         if constexpr (ACC) {
+#if VQ_ACC_F64
+            // the whole update: one atomic per dimension of this lane half + the cluster's count (lower half; the upper half
+            // adds to a dummy word of its own), all without return -- nothing to wait for, nothing left for later gaps
+            if (mine) {
+                const uint32_t a0 = (uint32_t)(uintptr_t)(acc_wave) + (DPH * kPlane + 64u) * h + t_j * 8u;
+                const uint32_t ac = (uint32_t)(uintptr_t)(cnts) + (h ? (NT32 * 32u + p) * 4u : t_j * 4u);
+                const uint32_t one = 1u;
+#pragma unroll
+                for (int q = 0; q < DPH; ++q) {
+                    const double v = (double)pend_x[q];
+                    asm volatile("ds_add_f64 %0, %1 offset:%2" ::"v"(a0), "v"(v), "n"(q * (int)kPlane) : "memory");
+                }
+                asm volatile("ds_add_u32 %0, %1" ::"v"(ac), "v"(one) : "memory");
+            }
+            (void)pend_mine, (void)pend_j, (void)pend_before, (void)pend_seq;
+#else
             pend_mine = mine;  // both lane halves of the row agree
             pend_j = t_j;
             if (pend_mine && h == 0) {
                 pend_before = cnts[pend_j];              // every lane reads before any lane adds (one wave, in order)
                 pend_seq = atomicAdd(&cnts[pend_j], 1u);  // ds_add_rtn_u32: the rows of one cluster get before, before + 1, ...
             }
+#endif
         }
     };
     auto acc_issue = [&]() {
-        if constexpr (ACC) {
+        if constexpr (ACC && !VQ_ACC_F64) {
             uint32_t rank = (pend_mine && h == 0) ? pend_seq - pend_before : 0xFFFFFFFFu;
             rank = __builtin_amdgcn_permlane32_swap(rank, rank, false, false)[0];  // the row's other half takes the same turn
             pend_rank = rank;
@@ -1031,7 +1095,7 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
         }
     };
     auto acc_commit = [&]() {
-        if constexpr (ACC) {
+        if constexpr (ACC && !VQ_ACC_F64) {
             if (pend_rank < R) {
 #pragma unroll
                 for (int q = 0; q < DPH / 4; ++q) {
@@ -1061,6 +1125,63 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
             pend_mine = false;
             pend_rank = 0xFFFFFFFFu;
         }
+    };
+    // ACC, f64 form, in the loop: the update rides on the PAIRED tail (one tail for two steps, as in the encode form) -- there a
+    // lane owns a whole ROW's verdict (lanes 0..31 row p of step S - 1, lanes 32..63 row p of step S), so it re-reads the
+    // row's SD values (gap 0 of the trip's second step; an L2 hit) and adds all of them: SD atomics + the count per lane and
+    // two steps, the same number per step as the half-row form, and no second tail.  (The tail behind the loop is the one-step
+    // form above.)
+    constexpr bool kAccPair = ACC && VQ_ACC_F64;
+    float pend_xr[kAccPair ? SD : 1];
+    // The upper lane half walks the dimensions rotated by DPH (its registers hold x[DPH..SD), x[0..DPH)): in every atomic
+    // instruction the two halves then address different planes, 16 banks apart -- 32 rows per 16 bank pairs instead of 64.
+    auto acc_reload_pair = [&](uint32_t S) {  // rows of steps S - 1 (lower lanes) and S (upper lanes), as loaded
+        if constexpr (kAccPair) {
+            uint32_t row = (S - 1 + h) * 32 + p;
+            row = row < n32 ? row : n32 - 1;
+            const float *ptr = reinterpret_cast<const float *>(reinterpret_cast<const char *>(X + (size_t)s * SD) + (uint64_t)row * x_pitch);
+            const float *pa = ptr + DPH * h, *pb = ptr - DPH * h;
+#pragma unroll
+            for (int q = 0; q < SD; q += 4) {
+                const float4 t = *reinterpret_cast<const float4 *>((q < DPH ? pa : pb) + q);
+                pend_xr[q + 0] = t.x;
+                pend_xr[q + 1] = t.y;
+                pend_xr[q + 2] = t.z;
+                pend_xr[q + 3] = t.w;
+            }
+        }
+    };
+    // the update in kAccPieces pieces (spread over the step's free gaps: nine atomics in one gap hold the LDS pipe for
+    // ~250 ns, in front of the other waves' |c|^2 reads); piece kAccPieces is the count
+    constexpr int kAccPieces = SD / 4;
+    bool upd_mine = false;
+    uint32_t upd_j = 0;
+    auto acc_update_begin = [&](bool mine) {
+        if constexpr (kAccPair) upd_mine = mine, upd_j = t_j;
+    };
+    auto acc_update_piece = [&](int k) {
+#if VQ_ACC_F64
+        if constexpr (kAccPair) {
+#ifdef VQ_ACC_ABL
+            if (VQ_ACC_ABL == 1) return;  // (ablation builds only: timing without the atomics)
+#endif
+            if (upd_mine) {
+                const uint32_t base = (uint32_t)(uintptr_t)(acc_wave) + upd_j * 8u;
+                if (k < kAccPieces) {
+                    const uint32_t a0 = base + ((4 * k < DPH) ? (DPH * kPlane + 64u) * h : (DPH * kPlane + 64u) * (1u - h));
+#pragma unroll
+                    for (int q = 4 * k; q < 4 * k + 4; ++q) {
+                        const double v = (double)pend_xr[q];
+                        asm volatile("ds_add_f64 %0, %1 offset:%2" ::"v"(a0), "v"(v), "n"((q < DPH ? q : q - DPH) * (int)kPlane) : "memory");
+                    }
+                } else {
+                    const uint32_t ac = (uint32_t)(uintptr_t)(cnts) + upd_j * 4u;
+                    const uint32_t one = 1u;
+                    asm volatile("ds_add_u32 %0, %1" ::"v"(ac), "v"(one) : "memory");
+                }
+            }
+        }
+#endif
     };
     // tail of a finished step in 4 pieces (the X32 kernel's tail, same order of operations)
     auto tail_piece = [&](int k, int tp, uint32_t tst, bool in_loop, bool no_step = false) {
@@ -1170,6 +1291,7 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
                 }
                 seg_count += (uint32_t)__popcll(mask);
             }
+            acc_update_begin(valid && (row < n32) && t_proven);
         }
     };
 
@@ -1225,9 +1347,12 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
                         if (f == 4) reduce_hg(acc[i & 3], i, 3, par);
                         if (f == 2 || f == 5) {
                             const int slot = 2 * i + (f == 5);  // 0..15
-                            if (slot == 0) acc_reload(st - 1), split_piece(0, par ^ 1, st + 1 + kDeep, first);
-                            else if (slot <= 4) {
-                                if constexpr (ACC) {
+                            if (slot == 0) {
+                                if constexpr (kAccPair) { if (par == VQ_ACC_RELOAD_PAR) acc_reload_pair(st - VQ_ACC_RELOAD_PAR); }
+                                else acc_reload(st - 1);
+                                split_piece(0, par ^ 1, st + 1 + kDeep, first);
+                            } else if (slot <= 4) {
+                                if constexpr (ACC && !kAccPair) {
                                     tail_piece(slot - 1, par ^ 1, st - 1, true, first && par == 0);
                                 } else if (par == 0) {  // step st - 1: the lane's own merge, parked for the partner step
                                     if (slot == 1) tail_piece(0, 1, st - 1, true), tail_hold();
@@ -1239,30 +1364,39 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
                             }
                             else if (slot <= 10) split_piece(slot - 4, par ^ 1, st + 1 + kDeep);      // 2 splits, packs 0..3
                             else if (slot == 11) split_piece(7, par ^ 1, st + 1 + kDeep), split_piece(8, par ^ 1, st + 1 + kDeep);
-                            else if (slot == 12) acc_issue();
-                            else if (slot == 14) acc_commit();
+                            else if (slot == 12) { if constexpr (!kAccPair) acc_issue(); }
+                            else if (slot == 14) { if constexpr (!kAccPair) acc_commit(); }
+                            if constexpr (kAccPair) {  // the pair's update: four dimensions per gap behind the tail, the count last
+                                if (par == 1 && slot >= 5 && slot < 5 + kAccPieces) acc_update_piece(slot - 5);
+                                if (par == 1 && slot == 5 + kAccPieces) acc_update_piece(kAccPieces);
+                            }
                         }
                     } else {  // NMF == 3: one filler gap per phase
                         if (f == 0) reduce_hg(acc[i & 3], i, 0, par), reduce_hg(acc[i & 3], i, 1, par);
                         if (f == 1) reduce_hg(acc[i & 3], i, 2, par), reduce_hg(acc[i & 3], i, 3, par);
                         if (f == 2) {
                             if (i == 0) {
-                                acc_reload(st - 1);
+                                if constexpr (kAccPair) { if (par == VQ_ACC_RELOAD_PAR) acc_reload_pair(st - VQ_ACC_RELOAD_PAR); }
+                                else acc_reload(st - 1);
                                 split_piece(0, par ^ 1, st + 1 + kDeep, first);
                                 tail_piece(0, par ^ 1, st - 1, true);
-                                if constexpr (ACC) tail_piece(1, par ^ 1, st - 1, true, first && par == 0);
+                                if constexpr (ACC && !kAccPair) tail_piece(1, par ^ 1, st - 1, true, first && par == 0);
                                 else if (par == 0) tail_hold();
                                 else tail_pair_piece(1, st - 1, first);
                             } else if (i == 1) {
-                                if constexpr (ACC) tail_piece(2, par ^ 1, st - 1, true), tail_piece(3, par ^ 1, st - 1, true, first && par == 0);
+                                if constexpr (ACC && !kAccPair) tail_piece(2, par ^ 1, st - 1, true), tail_piece(3, par ^ 1, st - 1, true, first && par == 0);
                                 else if (par == 1) tail_piece(2, 0, st - 1, true), tail_pair_piece(3, st - 1, first);
                                 split_piece(1, par ^ 1, st + 1 + kDeep);
                             } else if (i < kSplitPieces) {
                                 split_piece(i, par ^ 1, st + 1 + kDeep);
                             } else if (i == 6) {
-                                acc_issue();
+                                if constexpr (!kAccPair) acc_issue();
                             } else if (i == 7) {
-                                acc_commit();
+                                if constexpr (!kAccPair) acc_commit();
+                            }
+                            if constexpr (kAccPair) {  // the pair's update: four dimensions per gap behind the tail, the count last
+                                if (par == 1 && i >= 5 && i < 5 + kAccPieces) acc_update_piece(i - 5);
+                                if (par == 1 && i == 5 + kAccPieces) acc_update_piece(kAccPieces);
                             }
                         }
                     }
@@ -1597,7 +1731,8 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
                     attr_set_p.done();
                 }
             }
-            hipLaunchKernelGGL((k_assign_screen_bf16_x32p<SD, NT32, ACC>), dim3(blocks), dim3(kBlock), dyn_lds, stream, a.X, a.n, a.d,
+            const size_t dyn_lds_p = (ACC && VQ_ACC_F64) ? (size_t)kWavesPerBlock * x32p_acc_bytes_per_wave(SD, NT32) : dyn_lds;
+            hipLaunchKernelGGL((k_assign_screen_bf16_x32p<SD, NT32, ACC>), dim3(blocks), dim3(kBlock), dyn_lds_p, stream, a.X, a.n, a.d,
                                cb.m, cb.prepA32, cb.cn32, NT32 * 32, cb.meta, a.sub_list, a.n_sub, a.codes, a.wl_rows, a.wl_seg,
                                n_chunks, a.wl_stride, a.metric == VQHIP_COSINE ? 1 : 0, cb.k, cb.cen, a.gate_active,
                                a.gate_halt, a.codes_t, a.codes_t_pitch, ACC ? a.acc_sums : nullptr, ACC ? a.acc_counts : nullptr);
