@@ -98,8 +98,8 @@
         "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v88", "v89", "v90", "v91", "v92",      \
         "v93", "v94", "v95"
 
-template <int P>
-__global__ __launch_bounds__(1024) void k(float* sink, int iters) {
+template <int P, int LB = 1024>
+__global__ __launch_bounds__(LB) void k(float* sink, int iters) {
     __shared__ float lds[8192];
     lds[threadIdx.x] = (float)threadIdx.x;
     lds[threadIdx.x + 1024] = 1.0f;
@@ -155,6 +155,8 @@ __global__ __launch_bounds__(1024) void k(float* sink, int iters) {
             if constexpr (P == 14) { unsigned r0, r1; asm volatile("ds_add_rtn_u32 %0, %2, %3 offset:0\n ds_add_rtn_u32 %1, %2, %3 offset:1088\n s_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(ad), "v"(one) : "memory"); }
             if constexpr (P == 15) asm volatile("ds_add_f64 %0, %1 offset:0\n ds_add_f64 %0, %1 offset:2176\n" ::"v"(ad), "v"(oned) : "memory");
             if constexpr (P == 16) asm volatile("ds_max_u32 %0, %1 offset:0\n ds_max_u32 %0, %1 offset:1088\n" ::"v"(ad), "v"(one) : "memory");
+        } else if constexpr (P == 8) {
+            asm volatile(BODY(MF_AG, DS_OFF)::[m] "s"(mask), [la] "v"(la) : CLOB, "a0", "a1", "a2", "a3");
         } else if constexpr (P == 9) {
             asm volatile(BODY(MF_16, DS_OFF)::[m] "s"(mask), [la] "v"(la) : CLOB);
         }
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(1024) void k(float* sink, int iters) {
     if (s == 1234.5f) sink[0] = s;
 }
 
-template <int P>
+template <int P, int LB = 1024>
 void run(const char* name, int valu_per_iter, int waves_per_simd) {
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
@@ -175,11 +177,11 @@ void run(const char* name, int valu_per_iter, int waves_per_simd) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int threads = 256 * waves_per_simd;
-    for (int w = 0; w < 3; ++w) k<P><<<grid, threads>>>(sink, iters);  // clocks up
+    for (int w = 0; w < 3; ++w) k<P, LB><<<grid, threads>>>(sink, iters);  // clocks up
     float best = 1e30f;
     for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(e0);
-        k<P><<<grid, threads>>>(sink, iters);
+        k<P, LB><<<grid, threads>>>(sink, iters);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms;
@@ -209,6 +211,8 @@ int main() {
     for (int w = 2; w <= 2; ++w) run<14>("P14 P3 + 2 ds_add_rtn_u32 + wait", 144, w);
     for (int w = 2; w <= 2; ++w) run<15>("P15 P3 + 2 ds_add_f64", 144, w);
     for (int w = 2; w <= 2; ++w) run<16>("P16 P3 + 2 ds_max_u32", 144, w);
+    for (int w = 1; w <= 2; ++w) run<2, 512>("P2 again, launch bounds 512", 144, w);
+    for (int w = 1; w <= 2; ++w) run<8, 512>("P8 P2 with A in AGPRs", 144, w);
     for (int w = 1; w <= 4; ++w) run<9>("P9 P2 with 2 x 16x16x32 per mfma", 144, w);
     return 0;
 }

@@ -25,6 +25,7 @@ namespace {
 
 constexpr int kWaves = 16;        // waves per workgroup (one workgroup per CU: the LDS holds the tree)
 constexpr int kWlBuf = 64;        // work-list entries buffered per wave between flushes
+constexpr int kScrL2 = 0, kScrCos = 1, kScrMan = 2;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -47,238 +48,6 @@ __device__ __forceinline__ float dpp_add(float v) {
 // different nodes.
 constexpr int32_t kFlagBase = INT32_MIN;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// WAVES per workgroup: 16 while a row's registers (3 x D/8 floats) fit 128 VGPRs, 8 or 4 for the long rows
-//
-// COS (Distance::CosineDistance, src/core/distance.rs:95-118): a slot holds the two UNIT vectors c_l/|c_l|, c_r/|c_r|
-// (c over the reference's own f32 norm of c; f64 on the host, rounded once) instead of w; per level P_l = x.c^_l and
-// P_r = x.c^_r, and with T = M(slot) |x|^
-//     left   iff  P_l - P_r > T  or  P_r < -T      (q_l >= q_r: 1-q and the clamp are monotone;  q_r < 0: d_r = 1 >= d_l)
-//     right  iff  P_r - P_l > T and  P_r >  T and P_l < 0.999 |x|^
-//                                                  (q_r - q_l > 2^-24 survives the rounding of 1-q; q_r > 0: d_r < 1; q_l < 1)
-// anything else is undecided (DESIGN.md 4.4 "cosine descent").  Rows whose norm is outside [1e-9, 1e18] (the
-// reference's EPSILON rule, overflow of the squared norm) or not finite make T NaN; slots with such a child carry a
-// NaN margin in info.z.
-//
-// MAN (Distance::Manhattan, src/core/distance.rs:84-93): a slot holds the two children's centroids; both L1 distances
-// are summed per level by the row's 8 lanes (the terms fl(|x - c|) are the reference's own, only the order of the
-// additions differs).  All terms are non-negative, so both sums are within a RELATIVE gamma of the same exact sum:
-//     left   iff  S_l (1 + m) <= S_r,      right  iff  S_r (1 + m) < S_l,      m = 2.01 (d + D/32 + 6) u
-// and anything else -- or a sum that is not finite and below 1e37 -- is undecided.
-constexpr int kScrL2 = 0, kScrCos = 1, kScrMan = 2;
-// DEEP: the tree has more two-child nodes than LDS holds and the deeper ones are read from L2.  Its own instantiation:
-// a global load anywhere in the descent loop makes the loop wait on vmcnt(0) at every level -- the counter the NEXT
-// tile's rows (requested before the descent, to travel during it) are counted on, so every tile waited out a full HBM
-// round trip before its first level.  Without the path (the usual case: depth <= 8 at d = 128) the rows travel while the
-// descent runs.
-template <int D, int LPR, int WAVES, int MODE, bool DEEP>
-__global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
-    const float *__restrict__ X, uint64_t n, uint32_t d_real, const float *__restrict__ w_g,
-    const int4 *__restrict__ info_g, const float *__restrict__ mu_g, uint32_t n_int, int32_t start_slot, float R,
-    float coef_a, float coef_b, int32_t *__restrict__ leaf_out, uint2 *__restrict__ wl,
-    uint32_t *__restrict__ wl_count, const uint4 *__restrict__ table16, uint4 *__restrict__ f16_out) {
-    // table16 / f16_out (optional, d_real % 8 == 0): the f16 node table [n_nodes][d_real] and the reconstruction
-    // [n][d_real]; a row that reaches its leaf here is written here (its 8 lanes copy consecutive 16-byte pieces), so
-    // the leaf ids do not travel through HBM to a gather kernel and back
-    // d_real <= D (a multiple of 4): rows are d_real floats apart; w, mu are D wide with zeros behind d_real, and the
-    // 16-byte parts of a row behind d_real are read as zeros (from a valid address), so any such d rides on the
-    // next instantiated width
-    // n_int: slots resident in LDS (the levels nearest the root, breadth-first); w_g / info_g hold EVERY slot of the
-    // tree: a row standing at a deeper slot takes the same verdict from L2 instead (one more round trip per level)
-    constexpr int CH = LPR * 4;       // floats per chunk (LPR lanes x float4)
-    constexpr int NCH = D / CH;       // chunks per row = float4 values per lane
-    constexpr int RPW = 64 / LPR;     // rows per wave step
-    constexpr bool COS = MODE == kScrCos, MAN = MODE == kScrMan;
-    constexpr int NV = (COS || MAN) ? 2 : 1;   // vectors per slot
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *lds_w = lds;                                                       // [n_int][NV][D]
-    int4 *lds_info = reinterpret_cast<int4 *>(lds + (size_t)n_int * NV * D);   // [n_int]
-    uint2 *lds_wl = reinterpret_cast<uint2 *>(lds_info + n_int);               // [kWaves][kWlBuf]
-    {
-        constexpr uint32_t T = WAVES * 64;
-        const uint32_t total = n_int * NV * (D / 4);
-        for (uint32_t e0 = 0; e0 < total; e0 += 4 * T) {  // 4 loads in flight per thread
-            float4 v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t e = e0 + i * T + threadIdx.x;
-                v[i] = reinterpret_cast<const float4 *>(w_g)[e < total ? e : 0];
-            }
-            // (pinned: left alone, the compiler sinks each load into the conditional LDS store below and waits for it there:
-            // one memory round trip per 16 KB of the 130 KB image, ~16 us in front of every workgroup's first row)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t e = e0 + i * T + threadIdx.x;
-                if (e < total) reinterpret_cast<float4 *>(lds_w)[e] = v[i];
-            }
-        }
-        for (uint32_t e = threadIdx.x; e < n_int; e += T) lds_info[e] = info_g[e];
-    }
-    __syncthreads();
-
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t j = lane % LPR, g = lane / LPR;
-    const uint32_t rot = (LPR == 4) ? ((lane >> 3) & 3u) : ((lane >> 4) & 1u);
-    uint32_t off[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) off[c] = (((uint32_t)c + rot) % NCH) * CH + 4 * j;
-    float4 mu[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) mu[c] = *reinterpret_cast<const float4 *>(mu_g + off[c]);
-    uint2 *my_wl = lds_wl + (size_t)wave * kWlBuf;
-    uint32_t wl_n = 0;  // wave-uniform
-
-    auto flush = [&]() {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(wl_count, wl_n);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (lane < wl_n) wl[base + lane] = my_wl[lane];
-        wl_n = 0;
-    };
-    auto allreduce = [&](float v) {
-        v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
-        v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
-        if (LPR == 8) v = dpp_add<0x141>(v);  // row_half_mirror
-        return v;
-    };
-
-    const uint64_t n_tiles = (n + RPW - 1) / RPW;
-    const uint64_t tile_stride = (uint64_t)gridDim.x * WAVES;
-    auto load_tile = [&](uint64_t tile, float4 (&xv)[NCH]) {
-        const uint64_t r = tile * RPW + g;
-        const float *px = X + ((r < n) ? r : (n - 1)) * d_real;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const bool live = off[c] < d_real;
-            const float4 v = *reinterpret_cast<const float4 *>(px + (live ? off[c] : 0u));
-            xv[c] = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    uint64_t tile = (uint64_t)blockIdx.x * WAVES + wave;
-    float4 xn[NCH];
-    if (tile < n_tiles) load_tile(tile, xn);
-    for (; tile < n_tiles; tile += tile_stride) {
-        const uint64_t row = tile * RPW + g;
-        float4 y[NCH];
-        float ysq0 = 0.0f, ysq1 = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            y[c] = make_float4(xn[c].x - mu[c].x, xn[c].y - mu[c].y, xn[c].z - mu[c].z, xn[c].w - mu[c].w);
-            ysq0 = fmaf(y[c].x, y[c].x, ysq0);
-            ysq1 = fmaf(y[c].y, y[c].y, ysq1);
-            ysq0 = fmaf(y[c].z, y[c].z, ysq0);
-            ysq1 = fmaf(y[c].w, y[c].w, ysq1);
-        }
-        const float ynorm = __builtin_sqrtf(allreduce(ysq0 + ysq1));
-        const float base = (ynorm + R) * 1.0001f;
-        // L2: T = u * base * (coef_a * base + coef_b * |w|) + 1e-36;   cosine: T = u * coef_a * |x|^ (+ the slot's NaN flag)
-        float t_a = fmaf(5.9604644775390625e-08f * coef_a * base, base, 1e-36f);
-        float t_b = 5.9604644775390625e-08f * coef_b * base;
-        if (COS) {  // t_a = |x|^ (>= the row's norm and the reference's f32 norm), NaN outside the screen's range
-            t_a = (ynorm >= 1e-9f && ynorm <= 1e18f) ? base : __builtin_nanf("");
-            t_b = 0.999f * t_a;
-        }
-        int32_t cur = (row < n) ? start_slot : -1;
-        if (tile + tile_stride < n_tiles) load_tile(tile + tile_stride, xn);  // in flight during the descent
-        for (;;) {
-            const int32_t a = cur > 0 ? cur : 0;
-            const bool deep = DEEP && a >= (int32_t)n_int;
-            int4 inf;
-            float P[NV];
-            const bool any_deep = DEEP && __any(deep);
-            if (!any_deep || !deep) inf = lds_info[a];
-            else inf = info_g[a];
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                float4 wv[NCH];
-                if (!any_deep || !deep) {  // the usual case: whole wave inside the LDS-resident levels
-                    const float *wp = lds_w + ((size_t)a * NV + v) * D;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
-                } else {
-                    const float *wp = w_g + ((size_t)a * NV + v) * D;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
-                }
-                if (MAN) {
-                    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;  // four chains per lane: depth NCH + 5 with the reductions
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        // the differences two at a time (v_pk_add_f32), |.| as a source modifier of the additions
-                        const f32x2 d01 = f32x2{y[c].x, y[c].y} - f32x2{wv[c].x, wv[c].y};
-                        const f32x2 d23 = f32x2{y[c].z, y[c].w} - f32x2{wv[c].z, wv[c].w};
-                        a0 = a0 + fabsf(d01.x);
-                        a1 = a1 + fabsf(d01.y);
-                        a2 = a2 + fabsf(d23.x);
-                        a3 = a3 + fabsf(d23.y);
-                    }
-                    P[v] = allreduce((a0 + a1) + (a2 + a3));
-                    continue;
-                }
-                // register-adjacent pairs -> v_pk_fma_f32 without operand shuffles
-                f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    acc01 = __builtin_elementwise_fma(f32x2{y[c].x, y[c].y}, f32x2{wv[c].x, wv[c].y}, acc01);
-                    acc23 = __builtin_elementwise_fma(f32x2{y[c].z, y[c].w}, f32x2{wv[c].z, wv[c].w}, acc23);
-                }
-                acc01 = acc01 + acc23;
-                P[v] = allreduce(acc01.x + acc01.y);
-            }
-            // NaN / inf thresholds never pass
-            const float T = COS ? t_a * __int_as_float(inf.z) : fmaf(t_b, __int_as_float(inf.w), t_a);
-            int32_t next;
-            if (MAN) {
-                const float sl = P[0], sr = P[NV - 1], mrg = __int_as_float(inf.z);  // NaN margin: exact-only slot
-                const bool fin = (sl < 1e37f) && (sr < 1e37f);
-                const bool go_l = fin && (fmaf(sl, mrg, sl) <= sr * 0.99999988f);   // one rounding each, absorbed by the 1 % on m
-                const bool go_r = fin && (fmaf(sr, mrg, sr) < sl * 0.99999988f);
-                next = go_l ? inf.x : (go_r ? inf.y : (kFlagBase + a));
-            } else if (COS) {
-                const float dlt = P[0] - P[NV - 1];
-                const bool go_l = (dlt > T) || (P[NV - 1] < -T);
-                const bool go_r = (-dlt > T) && (P[NV - 1] > T) && (P[0] < t_b);  // q_l < 1: 1 - q_l stays positive
-                next = go_l ? inf.x : (go_r ? inf.y : (kFlagBase + a));
-            } else {
-                const float delta = fmaf(-2.0f, P[0], __int_as_float(inf.z));
-                const int32_t code = (delta < 0.0f) ? inf.x : inf.y;
-                next = (fabsf(delta) > T) ? code : (kFlagBase + a);
-            }
-            cur = (cur >= 0) ? next : cur;
-            if (!__any(cur >= 0)) break;
-        }
-        if (j == 0 && cur < 0 && cur > kFlagBase / 2 && row < n) leaf_out[row] = -1 - cur;
-        if (f16_out && cur < 0 && cur > kFlagBase / 2 && row < n) {
-            // the leaf's f16 row: this lane's pieces j, j + LPR, ... all requested before the first is stored (a load next to
-            // its store waits for the table AND for the store in front of it: both sit on vmcnt)
-            const uint32_t pieces = d_real / 8;
-            const uint4 *src = table16 + (size_t)(-1 - cur) * pieces;
-            uint4 *dst = f16_out + row * pieces;
-            constexpr int NP = (D / 8 + LPR - 1) / LPR;
-            uint4 tmp[NP];
-#pragma unroll
-            for (int i = 0; i < NP; ++i) tmp[i] = src[min(j + (uint32_t)i * LPR, pieces - 1u)];
-#pragma unroll
-            for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(tmp[i].x), "+v"(tmp[i].y), "+v"(tmp[i].z), "+v"(tmp[i].w));
-#pragma unroll
-            for (int i = 0; i < NP; ++i)
-                if (j + (uint32_t)i * LPR < pieces) dst[j + (uint32_t)i * LPR] = tmp[i];
-        }
-        const bool push = (j == 0) && (cur <= kFlagBase / 2);
-        const uint64_t mask = __ballot(push);
-        if (mask) {
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (push) my_wl[wl_n + before] = make_uint2((uint32_t)row, (uint32_t)(cur - kFlagBase));
-            wl_n += (uint32_t)__popcll(mask);
-        }
-        if (wl_n > kWlBuf - RPW) flush();
-    }
-    if (wl_n) flush();
-}
 
 // Finishes the undecided rows in the reference's arithmetic: entry = (row, node to resume from).
 // 16 lanes per entry: lane j keeps the V-float pieces [q*16V + jV, +V) of the row, computes its
@@ -312,21 +81,27 @@ __device__ __forceinline__ float cosine_from_sums(float dot, float na, float nb)
 
 // COS: the two running sums are the dot products x.c_l, x.c_r (same order), the row's own squared norm is summed
 // once before the walk through the same lane chain
+// what the continuation reads besides the screen's own arguments (round 6: the descent kernel finishes its own undecided
+// rows, see k_tsvq_screen_descend's FOLD)
+struct TsvqCont {
+    const float *centroids, *cnorm;
+    const int32_t *left, *right, *slot_node, *node_slot;
+    int euclid;
+    uint32_t *clear_next;
+};
+
+// entries wl[slot], wl[slot + n_slots], ... (< count), one per 16 lanes: `wl` may point into LDS (the descent kernel's own
+// list) or to the global list; every lane of the wave calls it with the same count
 template <int D, int MODE>
-__global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__ X,
-                                                       const float *__restrict__ centroids,
-                                                       const float *__restrict__ cnorm,
-                                                       const int32_t *__restrict__ left,
-                                                       const int32_t *__restrict__ right, int euclid,
-                                                       const int32_t *__restrict__ slot_node,
-                                                       const uint2 *__restrict__ wl,
-                                                       const uint32_t *__restrict__ wl_count, uint32_t d_real,
-                                                       int32_t *__restrict__ leaf_out, const uint4 *__restrict__ table16,
-                                                       uint4 *__restrict__ f16_out, const float *__restrict__ w_g,
-                                                       const int4 *__restrict__ info_g, const int32_t *__restrict__ node_slot,
-                                                       const float *__restrict__ mu_g, float R, float coef_a, float coef_b,
-                                                       uint32_t *__restrict__ clear_next) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *clear_next = 0u;  // the next call's counter (nobody reads or appends to it in this call)
+__device__ __forceinline__ void tsvq_continue_entries(const uint2 *wl, const uint32_t count, const uint32_t slot, const uint32_t n_slots,
+                                                      const uint32_t lane, const float *__restrict__ X,
+                                                      const float *__restrict__ centroids, const float *__restrict__ cnorm,
+                                                      const int32_t *__restrict__ left, const int32_t *__restrict__ right, int euclid,
+                                                      const int32_t *__restrict__ slot_node, uint32_t d_real,
+                                                      int32_t *__restrict__ leaf_out, const uint4 *__restrict__ table16,
+                                                      uint4 *__restrict__ f16_out, const float *__restrict__ w_g,
+                                                      const int4 *__restrict__ info_g, const int32_t *__restrict__ node_slot,
+                                                      const float *__restrict__ mu_g, float R, float coef_a, float coef_b) {
     // d_real <= D: rows and centroids are d_real floats long; the pieces behind it count as zeros (a zero term
     // leaves a running sum that already holds a real term unchanged, so the reference's bits are kept)
     // w_g / info_g / node_slot: below the
@@ -336,10 +111,7 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
     constexpr int NQ = (D >= 64) ? D / 64 : 1;  // chunks of 16 lanes x V floats
     constexpr int V = D / NQ / 16;              // 2 (D = 32) or 4
     constexpr bool COS = MODE == kScrCos, MAN = MODE == kScrMan;
-    const uint32_t count = *wl_count;
-    const uint32_t lane = threadIdx.x & 63, j = lane & 15;
-    const uint32_t slot = (blockIdx.x * 256 + threadIdx.x) >> 4;
-    const uint32_t n_slots = (gridDim.x * 256) >> 4;
+    const uint32_t j = lane & 15;
     for (uint32_t e0 = 0; e0 < count; e0 += n_slots) {  // wave-uniform trip count
         const uint32_t e = e0 + slot;
         const bool valid = e < count;
@@ -582,6 +354,286 @@ __global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__
     }
 }
 
+// COS: the two running sums are the dot products x.c_l, x.c_r (same order), the row's own squared norm is summed
+// once before the walk through the same lane chain
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void k_tsvq_continue(const float *__restrict__ X,
+                                                       const float *__restrict__ centroids,
+                                                       const float *__restrict__ cnorm,
+                                                       const int32_t *__restrict__ left,
+                                                       const int32_t *__restrict__ right, int euclid,
+                                                       const int32_t *__restrict__ slot_node,
+                                                       const uint2 *__restrict__ wl,
+                                                       const uint32_t *__restrict__ wl_count, uint32_t d_real,
+                                                       int32_t *__restrict__ leaf_out, const uint4 *__restrict__ table16,
+                                                       uint4 *__restrict__ f16_out, const float *__restrict__ w_g,
+                                                       const int4 *__restrict__ info_g, const int32_t *__restrict__ node_slot,
+                                                       const float *__restrict__ mu_g, float R, float coef_a, float coef_b,
+                                                       uint32_t *__restrict__ clear_next) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *clear_next = 0u;  // the next call's counter (nobody reads or appends to it in this call)
+    tsvq_continue_entries<D, MODE>(wl, *wl_count, (blockIdx.x * 256 + threadIdx.x) >> 4, (gridDim.x * 256) >> 4, threadIdx.x & 63, X,
+                                   centroids, cnorm, left, right, euclid, slot_node, d_real, leaf_out, table16, f16_out, w_g, info_g,
+                                   node_slot, mu_g, R, coef_a, coef_b);
+}
+
+// WAVES per workgroup: 16 while a row's registers (3 x D/8 floats) fit 128 VGPRs, 8 or 4 for the long rows
+//
+// COS (Distance::CosineDistance, src/core/distance.rs:95-118): a slot holds the two UNIT vectors c_l/|c_l|, c_r/|c_r|
+// (c over the reference's own f32 norm of c; f64 on the host, rounded once) instead of w; per level P_l = x.c^_l and
+// P_r = x.c^_r, and with T = M(slot) |x|^
+//     left   iff  P_l - P_r > T  or  P_r < -T      (q_l >= q_r: 1-q and the clamp are monotone;  q_r < 0: d_r = 1 >= d_l)
+//     right  iff  P_r - P_l > T and  P_r >  T and P_l < 0.999 |x|^
+//                                                  (q_r - q_l > 2^-24 survives the rounding of 1-q; q_r > 0: d_r < 1; q_l < 1)
+// anything else is undecided (DESIGN.md 4.4 "cosine descent").  Rows whose norm is outside [1e-9, 1e18] (the
+// reference's EPSILON rule, overflow of the squared norm) or not finite make T NaN; slots with such a child carry a
+// NaN margin in info.z.
+//
+// MAN (Distance::Manhattan, src/core/distance.rs:84-93): a slot holds the two children's centroids; both L1 distances
+// are summed per level by the row's 8 lanes (the terms fl(|x - c|) are the reference's own, only the order of the
+// additions differs).  All terms are non-negative, so both sums are within a RELATIVE gamma of the same exact sum:
+//     left   iff  S_l (1 + m) <= S_r,      right  iff  S_r (1 + m) < S_l,      m = 2.01 (d + D/32 + 6) u
+// and anything else -- or a sum that is not finite and below 1e37 -- is undecided.
+// DEEP: the tree has more two-child nodes than LDS holds and the deeper ones are read from L2.  Its own instantiation:
+// a global load anywhere in the descent loop makes the loop wait on vmcnt(0) at every level -- the counter the NEXT
+// tile's rows (requested before the descent, to travel during it) are counted on, so every tile waited out a full HBM
+// round trip before its first level.  Without the path (the usual case: depth <= 8 at d = 128) the rows travel while the
+// descent runs.
+// FOLD (round 6): a wave finishes its OWN undecided rows -- tsvq_continue_entries over its list in LDS, four entries at a
+// time -- when its tiles are done (or the list is full), instead of flushing them to a global list for k_tsvq_continue: the
+// pass is one kernel (the continuation's launch, its ramp over 3000 entries and the gap in front of it were 18 of
+// 181 us at C4).  A wave holds ~0.7 entries on uniform rows; the loads of the continuation sit behind the tile loop
+// (a break out of it when the list is full), so the descent's own waits are the ones it always had.
+template <int D, int LPR, int WAVES, int MODE, bool DEEP, bool FOLD = false>
+__global__ __launch_bounds__(WAVES * 64) void k_tsvq_screen_descend(
+    const float *__restrict__ X, uint64_t n, uint32_t d_real, const float *__restrict__ w_g,
+    const int4 *__restrict__ info_g, const float *__restrict__ mu_g, uint32_t n_int, int32_t start_slot, float R,
+    float coef_a, float coef_b, int32_t *__restrict__ leaf_out, uint2 *__restrict__ wl,
+    uint32_t *__restrict__ wl_count, const uint4 *__restrict__ table16, uint4 *__restrict__ f16_out, TsvqCont ct) {
+    if (FOLD && blockIdx.x == 0 && threadIdx.x == 0) *ct.clear_next = 0u;  // the next call's counter (this call only adds to its own)
+    // table16 / f16_out (optional, d_real % 8 == 0): the f16 node table [n_nodes][d_real] and the reconstruction
+    // [n][d_real]; a row that reaches its leaf here is written here (its 8 lanes copy consecutive 16-byte pieces), so
+    // the leaf ids do not travel through HBM to a gather kernel and back
+    // d_real <= D (a multiple of 4): rows are d_real floats apart; w, mu are D wide with zeros behind d_real, and the
+    // 16-byte parts of a row behind d_real are read as zeros (from a valid address), so any such d rides on the
+    // next instantiated width
+    // n_int: slots resident in LDS (the levels nearest the root, breadth-first); w_g / info_g hold EVERY slot of the
+    // tree: a row standing at a deeper slot takes the same verdict from L2 instead (one more round trip per level)
+    constexpr int CH = LPR * 4;       // floats per chunk (LPR lanes x float4)
+    constexpr int NCH = D / CH;       // chunks per row = float4 values per lane
+    constexpr int RPW = 64 / LPR;     // rows per wave step
+    constexpr bool COS = MODE == kScrCos, MAN = MODE == kScrMan;
+    constexpr int NV = (COS || MAN) ? 2 : 1;   // vectors per slot
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *lds_w = lds;                                                       // [n_int][NV][D]
+    int4 *lds_info = reinterpret_cast<int4 *>(lds + (size_t)n_int * NV * D);   // [n_int]
+    uint2 *lds_wl = reinterpret_cast<uint2 *>(lds_info + n_int);               // [kWaves][kWlBuf]
+    {
+        constexpr uint32_t T = WAVES * 64;
+        const uint32_t total = n_int * NV * (D / 4);
+        for (uint32_t e0 = 0; e0 < total; e0 += 4 * T) {  // 4 loads in flight per thread
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t e = e0 + i * T + threadIdx.x;
+                v[i] = reinterpret_cast<const float4 *>(w_g)[e < total ? e : 0];
+            }
+            // (pinned: left alone, the compiler sinks each load into the conditional LDS store below and waits for it there:
+            // one memory round trip per 16 KB of the 130 KB image, ~16 us in front of every workgroup's first row)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t e = e0 + i * T + threadIdx.x;
+                if (e < total) reinterpret_cast<float4 *>(lds_w)[e] = v[i];
+            }
+        }
+        for (uint32_t e = threadIdx.x; e < n_int; e += T) lds_info[e] = info_g[e];
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t j = lane % LPR, g = lane / LPR;
+    const uint32_t rot = (LPR == 4) ? ((lane >> 3) & 3u) : ((lane >> 4) & 1u);
+    uint32_t off[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) off[c] = (((uint32_t)c + rot) % NCH) * CH + 4 * j;
+    float4 mu[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) mu[c] = *reinterpret_cast<const float4 *>(mu_g + off[c]);
+    uint2 *my_wl = lds_wl + (size_t)wave * kWlBuf;
+    uint32_t wl_n = 0;  // wave-uniform
+
+    auto flush = [&]() {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(wl_count, wl_n);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < wl_n) wl[base + lane] = my_wl[lane];
+        wl_n = 0;
+    };
+    auto allreduce = [&](float v) {
+        v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+        v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+        if (LPR == 8) v = dpp_add<0x141>(v);  // row_half_mirror
+        return v;
+    };
+
+    const uint64_t n_tiles = (n + RPW - 1) / RPW;
+    const uint64_t tile_stride = (uint64_t)gridDim.x * WAVES;
+    auto load_tile = [&](uint64_t tile, float4 (&xv)[NCH]) {
+        const uint64_t r = tile * RPW + g;
+        const float *px = X + ((r < n) ? r : (n - 1)) * d_real;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const bool live = off[c] < d_real;
+            const float4 v = *reinterpret_cast<const float4 *>(px + (live ? off[c] : 0u));
+            xv[c] = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    uint64_t tile = (uint64_t)blockIdx.x * WAVES + wave;
+    float4 xn[NCH];
+    if (tile < n_tiles) load_tile(tile, xn);
+    for (;;) {  // (FOLD: one more trip per full list; otherwise a single trip)
+    for (; tile < n_tiles; tile += tile_stride) {
+        const uint64_t row = tile * RPW + g;
+        float4 y[NCH];
+        float ysq0 = 0.0f, ysq1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            y[c] = make_float4(xn[c].x - mu[c].x, xn[c].y - mu[c].y, xn[c].z - mu[c].z, xn[c].w - mu[c].w);
+            ysq0 = fmaf(y[c].x, y[c].x, ysq0);
+            ysq1 = fmaf(y[c].y, y[c].y, ysq1);
+            ysq0 = fmaf(y[c].z, y[c].z, ysq0);
+            ysq1 = fmaf(y[c].w, y[c].w, ysq1);
+        }
+        const float ynorm = __builtin_sqrtf(allreduce(ysq0 + ysq1));
+        const float base = (ynorm + R) * 1.0001f;
+        // L2: T = u * base * (coef_a * base + coef_b * |w|) + 1e-36;   cosine: T = u * coef_a * |x|^ (+ the slot's NaN flag)
+        float t_a = fmaf(5.9604644775390625e-08f * coef_a * base, base, 1e-36f);
+        float t_b = 5.9604644775390625e-08f * coef_b * base;
+        if (COS) {  // t_a = |x|^ (>= the row's norm and the reference's f32 norm), NaN outside the screen's range
+            t_a = (ynorm >= 1e-9f && ynorm <= 1e18f) ? base : __builtin_nanf("");
+            t_b = 0.999f * t_a;
+        }
+        int32_t cur = (row < n) ? start_slot : -1;
+        if (tile + tile_stride < n_tiles) load_tile(tile + tile_stride, xn);  // in flight during the descent
+        for (;;) {
+            const int32_t a = cur > 0 ? cur : 0;
+            const bool deep = DEEP && a >= (int32_t)n_int;
+            int4 inf;
+            float P[NV];
+            const bool any_deep = DEEP && __any(deep);
+            if (!any_deep || !deep) inf = lds_info[a];
+            else inf = info_g[a];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float4 wv[NCH];
+                if (!any_deep || !deep) {  // the usual case: whole wave inside the LDS-resident levels
+                    const float *wp = lds_w + ((size_t)a * NV + v) * D;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
+                } else {
+                    const float *wp = w_g + ((size_t)a * NV + v) * D;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) wv[c] = *reinterpret_cast<const float4 *>(wp + off[c]);
+                }
+                if (MAN) {
+                    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;  // four chains per lane: depth NCH + 5 with the reductions
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        // the differences two at a time (v_pk_add_f32), |.| as a source modifier of the additions
+                        const f32x2 d01 = f32x2{y[c].x, y[c].y} - f32x2{wv[c].x, wv[c].y};
+                        const f32x2 d23 = f32x2{y[c].z, y[c].w} - f32x2{wv[c].z, wv[c].w};
+                        a0 = a0 + fabsf(d01.x);
+                        a1 = a1 + fabsf(d01.y);
+                        a2 = a2 + fabsf(d23.x);
+                        a3 = a3 + fabsf(d23.y);
+                    }
+                    P[v] = allreduce((a0 + a1) + (a2 + a3));
+                    continue;
+                }
+                // register-adjacent pairs -> v_pk_fma_f32 without operand shuffles
+                f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    acc01 = __builtin_elementwise_fma(f32x2{y[c].x, y[c].y}, f32x2{wv[c].x, wv[c].y}, acc01);
+                    acc23 = __builtin_elementwise_fma(f32x2{y[c].z, y[c].w}, f32x2{wv[c].z, wv[c].w}, acc23);
+                }
+                acc01 = acc01 + acc23;
+                P[v] = allreduce(acc01.x + acc01.y);
+            }
+            // NaN / inf thresholds never pass
+            const float T = COS ? t_a * __int_as_float(inf.z) : fmaf(t_b, __int_as_float(inf.w), t_a);
+            int32_t next;
+            if (MAN) {
+                const float sl = P[0], sr = P[NV - 1], mrg = __int_as_float(inf.z);  // NaN margin: exact-only slot
+                const bool fin = (sl < 1e37f) && (sr < 1e37f);
+                const bool go_l = fin && (fmaf(sl, mrg, sl) <= sr * 0.99999988f);   // one rounding each, absorbed by the 1 % on m
+                const bool go_r = fin && (fmaf(sr, mrg, sr) < sl * 0.99999988f);
+                next = go_l ? inf.x : (go_r ? inf.y : (kFlagBase + a));
+            } else if (COS) {
+                const float dlt = P[0] - P[NV - 1];
+                const bool go_l = (dlt > T) || (P[NV - 1] < -T);
+                const bool go_r = (-dlt > T) && (P[NV - 1] > T) && (P[0] < t_b);  // q_l < 1: 1 - q_l stays positive
+                next = go_l ? inf.x : (go_r ? inf.y : (kFlagBase + a));
+            } else {
+                const float delta = fmaf(-2.0f, P[0], __int_as_float(inf.z));
+                const int32_t code = (delta < 0.0f) ? inf.x : inf.y;
+                next = (fabsf(delta) > T) ? code : (kFlagBase + a);
+            }
+            cur = (cur >= 0) ? next : cur;
+            if (!__any(cur >= 0)) break;
+        }
+        if (j == 0 && cur < 0 && cur > kFlagBase / 2 && row < n) leaf_out[row] = -1 - cur;
+        if (f16_out && cur < 0 && cur > kFlagBase / 2 && row < n) {
+            // the leaf's f16 row: this lane's pieces j, j + LPR, ... all requested before the first is stored (a load next to
+            // its store waits for the table AND for the store in front of it: both sit on vmcnt)
+            const uint32_t pieces = d_real / 8;
+            const uint4 *src = table16 + (size_t)(-1 - cur) * pieces;
+            uint4 *dst = f16_out + row * pieces;
+            constexpr int NP = (D / 8 + LPR - 1) / LPR;
+            uint4 tmp[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) tmp[i] = src[min(j + (uint32_t)i * LPR, pieces - 1u)];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) asm volatile("" : "+v"(tmp[i].x), "+v"(tmp[i].y), "+v"(tmp[i].z), "+v"(tmp[i].w));
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                if (j + (uint32_t)i * LPR < pieces) dst[j + (uint32_t)i * LPR] = tmp[i];
+        }
+        const bool push = (j == 0) && (cur <= kFlagBase / 2);
+        const uint64_t mask = __ballot(push);
+        if (mask) {
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (push) my_wl[wl_n + before] = make_uint2((uint32_t)row, (uint32_t)(cur - kFlagBase));
+            wl_n += (uint32_t)__popcll(mask);
+        }
+        if (wl_n > kWlBuf - RPW) {
+            if constexpr (FOLD) {
+                tile += tile_stride;
+                break;  // finish the list below, then come back for the remaining tiles
+            } else {
+                flush();
+            }
+        }
+    }
+    if constexpr (FOLD) {
+        if (wl_n) {
+            if (lane == 0) atomicAdd(wl_count, wl_n);  // statistics only (vqhip_tsvq_last_stats)
+            tsvq_continue_entries<D, MODE>(my_wl, wl_n, lane >> 4, 4u, lane, X, ct.centroids, ct.cnorm, ct.left, ct.right, ct.euclid,
+                                           ct.slot_node, d_real, leaf_out, table16, f16_out, ct.node_slot ? w_g : nullptr,
+                                           ct.node_slot ? info_g : nullptr, ct.node_slot, mu_g, R, coef_a, coef_b);
+            wl_n = 0;
+        }
+        if (tile >= n_tiles) break;
+    } else {
+        if (wl_n) flush();
+        break;
+    }
+    }
+}
+
 // the same continuation for a dimension without a k_tsvq_continue instantiation (padded screen widths): one lane per
 // entry, run-time-length loops in the reference's order; the entries are few
 __global__ __launch_bounds__(256) void k_tsvq_continue_any(const float *__restrict__ X, uint32_t d,
@@ -663,17 +715,17 @@ static int launch_continue(const float *X, const float *centroids, const float *
     return VQHIP_OK;
 }
 
-template <int D, int LPR, int MODE>
+template <int D, int LPR, int MODE, bool FOLD>
 int launch_screen(const float *X, uint64_t n, uint32_t d_real, const TsvqScreen &s, hipStream_t stream, int32_t *leaf,
-                  const uint4 *table16, uint4 *f16_out, uint32_t *count) {
+                  const uint4 *table16, uint4 *f16_out, uint32_t *count, const TsvqCont &ct) {
     constexpr int RPW = 64 / LPR;
     constexpr int WAVES = (D >= 512) ? 4 : (D >= 256) ? 8 : kWaves;  // 512 / 256 / 128 VGPRs per lane
     const size_t lds_bytes = tsvq_screen_lds_bytes(s.n_int, MODE == kScrL2 ? 1 : 2, D);
     static PerDeviceOnce attr_set;
     if (attr_set.needed()) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR, WAVES, MODE, false>),
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR, WAVES, MODE, false, FOLD>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR, WAVES, MODE, true>),
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tsvq_screen_descend<D, LPR, WAVES, MODE, true, FOLD>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set.done();
     }
@@ -681,11 +733,11 @@ int launch_screen(const float *X, uint64_t n, uint32_t d_real, const TsvqScreen 
     uint64_t grid = (n_tiles + WAVES - 1) / WAVES;
     if (grid > (uint64_t)num_cus()) grid = (uint64_t)num_cus();
     if (s.n_slots > s.n_int)
-        hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES, MODE, true>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X, n,
-                           d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, count, table16, f16_out);
+        hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES, MODE, true, FOLD>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X, n,
+                           d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, count, table16, f16_out, ct);
     else
-        hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES, MODE, false>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X, n,
-                           d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, count, table16, f16_out);
+        hipLaunchKernelGGL((k_tsvq_screen_descend<D, LPR, WAVES, MODE, false, FOLD>), dim3((uint32_t)grid), dim3(WAVES * 64), lds_bytes, stream, X, n,
+                           d_real, s.w, s.info, s.mu, s.n_int, s.start_slot, s.R, s.coef_a, s.coef_b, leaf, s.wl, count, table16, f16_out, ct);
     VQ_LAUNCH_CHECK("k_tsvq_screen_descend");
     return VQHIP_OK;
 }
@@ -733,10 +785,19 @@ int launch_tsvq_screen_encode(const float *X, uint64_t n, uint32_t d, const floa
     const int euclid = metric == VQHIP_EUCLIDEAN ? 1 : 0;
     const int mode = metric == VQHIP_COSINE ? kScrCos : metric == VQHIP_MANHATTAN ? kScrMan : kScrL2;
     const uint32_t dp = tsvq_screen_width(d);  // instantiated width serving d (d itself, or the next one up: zero padding)
+    // one kernel: the descent finishes its own undecided rows (FOLD) wherever k_tsvq_continue has an instantiation for the
+    // width (VQHIP_TSVQ_FOLD=0: the two-kernel form, for A/B)
+    static const char *fold_env = getenv("VQHIP_TSVQ_FOLD");
+    const bool fold_on = !(fold_env && fold_env[0] == '0');
+    const TsvqCont ct{centroids, cnorm, left, right, s.slot_node, s.node_slot, euclid, clear_next};
 #define VQ_TSVQ_DM(DV, MV)                                                                         \
-    VQ_TRY((launch_screen<DV, 8, MV>(X, n, d, s, stream, leaf, table16, f16_out, count)));         \
-    if (DV >= 64 || d == DV)                                                                       \
-        VQ_TRY((launch_continue<DV, MV>(X, centroids, cnorm, left, right, euclid, s, leaf, stream, d, table16, f16_out, count, clear_next)));
+    if ((DV >= 64 || d == DV) && fold_on) {                                                        \
+        VQ_TRY((launch_screen<DV, 8, MV, true>(X, n, d, s, stream, leaf, table16, f16_out, count, ct)));   \
+    } else {                                                                                       \
+        VQ_TRY((launch_screen<DV, 8, MV, false>(X, n, d, s, stream, leaf, table16, f16_out, count, ct)));  \
+        if (DV >= 64 || d == DV)                                                                   \
+            VQ_TRY((launch_continue<DV, MV>(X, centroids, cnorm, left, right, euclid, s, leaf, stream, d, table16, f16_out, count, clear_next))); \
+    }
 #define VQ_TSVQ_D(DV)                                                                              \
     case DV:                                                                                       \
         if (mode == kScrCos) {                                                                     \
