@@ -101,11 +101,27 @@ __global__ __launch_bounds__(256) void k_adc_scan(const uint8_t *__restrict__ co
         float acc[kAdcQB];
 #pragma unroll
         for (uint32_t qq = 0; qq < kAdcQB; ++qq) acc[qq] = 0.0f;
-        for (uint32_t s = 0; s < m; ++s) {
-            const uint32_t off = s * k + load_code(codes, i * m + s, k);  // one byte per code, two above 256 centroids
+        if (k <= 256 && (m & 7u) == 0 && (reinterpret_cast<uintptr_t>(codes) & 7u) == 0) {
+            // one-byte codes, rows of whole 8-byte words: a row's codes in m / 8 loads instead of m byte loads (same order of
+            // the additions: subspace 0 first)
+            for (uint32_t s8 = 0; s8 < m; s8 += 8) {
+                const uint2 w = *reinterpret_cast<const uint2 *>(codes + i * m + s8);
 #pragma unroll
-            for (uint32_t qq = 0; qq < kAdcQB; ++qq)
-                if (qq < nqb) acc[qq] = (s == 0) ? lds_lut[qq * tab + off] : acc[qq] + lds_lut[qq * tab + off];
+                for (uint32_t b = 0; b < 8; ++b) {
+                    const uint32_t s = s8 + b;
+                    const uint32_t off = s * k + (((b < 4 ? w.x : w.y) >> (8 * (b & 3))) & 255u);
+#pragma unroll
+                    for (uint32_t qq = 0; qq < kAdcQB; ++qq)
+                        if (qq < nqb) acc[qq] = (s == 0) ? lds_lut[qq * tab + off] : acc[qq] + lds_lut[qq * tab + off];
+                }
+            }
+        } else {
+            for (uint32_t s = 0; s < m; ++s) {
+                const uint32_t off = s * k + load_code(codes, i * m + s, k);  // one byte per code, two above 256 centroids
+#pragma unroll
+                for (uint32_t qq = 0; qq < kAdcQB; ++qq)
+                    if (qq < nqb) acc[qq] = (s == 0) ? lds_lut[qq * tab + off] : acc[qq] + lds_lut[qq * tab + off];
+            }
         }
 #pragma unroll
         for (uint32_t qq = 0; qq < kAdcQB; ++qq)
@@ -326,8 +342,13 @@ int launch_adc_search(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int 
     }
     const int l1 = metric == VQHIP_MANHATTAN ? 1 : 0;
     const int take_sqrt = metric == VQHIP_EUCLIDEAN ? 1 : 0;
+    // the scan: every workgroup first copies the batch's tables (64 KB at m = 8, k = 256, 8 queries) into LDS -- two
+    // workgroups per CU is what that LDS allows, and 2048 of them spent the pass re-reading tables (128 MB of L2 traffic for
+    // 8 MB of codes: 70 us per pass at 1M rows)
+    const size_t scan_lds = (size_t)qb * ((size_t)m * k + kAdcBins) * 4;
+    const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(8, (150 * 1024) / std::max<size_t>(scan_lds, 1)));
     uint64_t blocks = (n + 255) / 256;
-    if (blocks > (uint64_t)num_cus() * 8) blocks = (uint64_t)num_cus() * 8;
+    if (blocks > (uint64_t)num_cus() * per_cu) blocks = (uint64_t)num_cus() * per_cu;
     // small state: bounds [QB][2] f32 | hist [QB][bins] u32 | sel [QB][2] u32 | cand_n [QB] u32
     float *bounds = reinterpret_cast<float *>(state_ws);
     uint32_t *hist = reinterpret_cast<uint32_t *>(bounds + 2 * kAdcQB);
