@@ -124,6 +124,34 @@ def pmc_traffic(kernel_name):
     return None, None
 
 
+def tsvq_build_traffic(rows):
+    """HBM bytes per TSVQ build at C4's shape from the newest committed PMC pass over the build's kernels
+    (tools/evidence_r6.sh: separate FETCH_SIZE / WRITE_SIZE runs of tools/tsvq_time.py, FETCH doubled as the guide prescribes
+    for gfx950); rows = "c4" (Uniform[0,1)) or "normal" (N(0,1)).  Returns (bytes or None, source)."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "tsvq_build_pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(path)).get(rows)
+            if d and d.get("hbm_bytes_per_build"):
+                return float(d["hbm_bytes_per_build"]), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+def screen_kernel_name(sd, k, training):
+    """the pipelined screen's instantiation for a shape (8 tiles, sub_dim 8 or 16), as profiles/summarize.py names it; None elsewhere"""
+    if sd in (8, 16) and 225 <= k <= 256:
+        return f"k_assign_screen_bf16_x32p<{sd},8,{'true' if training else 'false'}>"
+    return None
+
+
+def tsvq_traffic_fields(rows, algorithmic_bytes):
+    t, src = tsvq_build_traffic(rows)
+    return {"traffic": t, "traffic_source": src, "traffic_over_algorithmic": (t / algorithmic_bytes if t else None)}
+
+
 def strided_init(n_global, m, k):
     import numpy as np
 
@@ -167,6 +195,14 @@ def mfma_roofline(flop, ms, kernel=None, extra=None, engine=3):
         im = pmc_issue_model(kernel)
         if im:  # the binding resource of the screen: instruction issue of one wave per SIMD
             im["issue_bound_ms"] = im["frac_of_kernel"] * ms
+            if "<8,8," in kernel and im.get("mfma_per_launch"):
+                # two waves per SIMD (sub_dim 8): the VALU port model of profiles/ubench/valu_waves.hip -- an MFMA costs the
+                # port 2.85 issue slots of 4 cycles, two waves lose 10 % to arbitration against four (P1, P2 at W = 2 / W = 4)
+                valu = im["instructions_per_launch"] - im["mfma_per_launch"]
+                slots = valu + 2.85 * im["mfma_per_launch"]
+                im["valu_port_model"] = {"slots_per_launch": slots, "mfma_issue_slots": 2.85, "two_wave_arbitration": 1.10,
+                                         "frac_of_kernel": slots / 1024.0 * 4.0 * 1.10 / im["kernel_cycles"],
+                                         "source": "profiles/r6/ubench_valu_waves.txt (P1-P3)"}
             r["issue_bound"] = im
     if extra:
         r.update(extra)
@@ -485,13 +521,13 @@ def other_configs(_lib, torch, engine):
             "encode_vectors_per_s": n / (step_ms * 1e-3), "encode_ms_per_step": step_ms,
             "encode_engine": {1: "exact", 2: "fp32_mfma_screen", 3: "bf16x3_mfma_screen"}.get(used, str(used)),
             "recheck_fraction": rechecked / float(n * m),
-            "encode_roofline": mfma_roofline(flop, primary_ms / max(calls, 1), engine=used, extra={
+            "encode_roofline": mfma_roofline(flop, primary_ms / max(calls, 1), kernel=screen_kernel_name(d // m, k, False), engine=used, extra={
                 "step_frac": flop / (step_ms * 1e-3) / 1e12 / (PEAK_BF16X3_EQUIV_TFLOPS if used == 3 else PEAK_F32_MFMA_TFLOPS),
                 "recheck_avg_launch_ms": recheck_ms / max(calls, 1), "flop_per_launch": flop}),
             "kmeans_ms_per_iter": km_ms, "kmeans_iter_per_s": 1e3 / km_ms,
             "kmeans_iters_timed": [int(it.min()), int(it.max())], "kmeans_active_subspaces": km_active,
             "kmeans_paused": bool(paused), "kmeans_valid": km_valid,
-            "kmeans_roofline": mfma_roofline(flop * km_active / m, km_ms, engine=km_engine, extra={
+            "kmeans_roofline": mfma_roofline(flop * km_active / m, km_ms, kernel=screen_kernel_name(d // m, k, True), engine=km_engine, extra={
                 "flop_per_iter": flop * km_active / m,
                 "note": "whole Lloyd iteration (assign + fused update + reduce + finalize), decisions on the device; flop scaled by "
                         "the subspaces that executed"}),
@@ -621,9 +657,11 @@ def other_configs(_lib, torch, engine):
         "workload": "BASELINE.json configs[3]: TSVQ depth 8 on 1M x 128, tree bit-identical to the reference's recursion",
         "rows": n, "dim": d, "depth": depth, "nodes": int(len(left)),
         "build_ms": build_ms, "build_ms_all": ts,
-        "build_roofline": hbm_roofline(build_bytes, build_ms, {"note": "4*N*D bytes x (2 passes x 8 split levels + 1 leaf-mean pass)"}),
+        "build_roofline": hbm_roofline(build_bytes, build_ms, dict(
+            {"note": "4*N*D bytes x (2 passes x 8 split levels + 1 leaf-mean pass)"}, **tsvq_traffic_fields("c4", build_bytes))),
         "build_ms_zero_mean": build_ms_zero_mean, "build_ms_zero_mean_all": tz,
-        "build_roofline_zero_mean": hbm_roofline(build_bytes, build_ms_zero_mean, {"note": "same shape on N(0,1) rows"}),
+        "build_roofline_zero_mean": hbm_roofline(build_bytes, build_ms_zero_mean, dict(
+            {"note": "same shape on N(0,1) rows"}, **tsvq_traffic_fields("normal", build_bytes))),
         "encode_vectors_per_s": n / (enc_ms * 1e-3), "encode_ms_per_step": enc_ms,
         "encode_roofline": hbm_roofline((4.0 * d + 2.0 * d) * n, enc_ms, {"note": "4*D bytes in + 2*D bytes (f16 reconstruction) out per vector"}),
     }
