@@ -59,7 +59,8 @@ def test_oracle_adc_rejects_cosine(oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("metric", [O.SQUARED_EUCLIDEAN, O.EUCLIDEAN, O.MANHATTAN])
 @pytest.mark.parametrize("shape", [(5000, 8, 16, 256, 10, 9), (70_001, 16, 8, 200, 100, 3), (300, 4, 4, 7, 300, 1),
-                                   (20_000, 2, 24, 256, 1024, 17), (1, 3, 5, 2, 1, 2)])
+                                   (20_000, 2, 24, 256, 1024, 17), (1, 3, 5, 2, 1, 2),
+                                   (30_000, 8, 8, 64, 20, 70)])  # 70 queries: a full group of 64 (eight scan batches in one set of launches) + 6
 def test_gpu_adc_search_bit_exact(oracle, metric, shape):
     from vq_amd import _lib
 

@@ -2273,18 +2273,19 @@ int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uin
     hipStream_t s;
     VQ_TRY(in.stream(&s));
     const uint32_t m = enc->cs.m, k = enc->cs.k, sd = enc->cs.sd, dim = m * sd;
+    const uint32_t qg = adc_query_group(n, nq);
     VQ_TRY(enc->adc_q.ensure((size_t)nq * dim * 4));
-    VQ_TRY(enc->adc_lut.ensure((size_t)adc_query_batch() * m * k * 4));
-    VQ_TRY(enc->adc_dist.ensure((size_t)adc_query_batch() * n * 4));
+    VQ_TRY(enc->adc_lut.ensure((size_t)qg * m * k * 4));
+    VQ_TRY(enc->adc_dist.ensure((size_t)qg * n * 4));
     VQ_TRY(enc->adc_idx.ensure((size_t)nq * topk * 4));
     VQ_TRY(enc->adc_out.ensure((size_t)nq * topk * 4));
-    VQ_TRY(enc->adc_state.ensure(adc_state_bytes()));
-    VQ_TRY(enc->adc_cand.ensure(adc_cand_bytes()));
+    VQ_TRY(enc->adc_state.ensure(adc_state_bytes(qg)));
+    VQ_TRY(enc->adc_cand.ensure(adc_cand_bytes(qg)));
     VQ_HIP(hipMemcpyAsync(enc->adc_q.p, queries, (size_t)nq * dim * 4, hipMemcpyHostToDevice, s));
     VQ_TRY(launch_adc_search(enc->cs.cb.as<float>(), m, k, sd, enc->metric, reinterpret_cast<const uint8_t *>(dev_codes), n,
                              enc->adc_q.as<float>(), nq, topk, enc->adc_lut.as<float>(), enc->adc_dist.as<float>(),
                              enc->adc_state.p, enc->adc_cand.as<unsigned long long>(), enc->adc_idx.as<uint32_t>(),
-                             enc->adc_out.as<float>(), s));
+                             enc->adc_out.as<float>(), s, qg));
     VQ_HIP(hipMemcpyAsync(idx_out, enc->adc_idx.p, (size_t)nq * topk * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipMemcpyAsync(dist_out, enc->adc_out.p, (size_t)nq * topk * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipStreamSynchronize(s));

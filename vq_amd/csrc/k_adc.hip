@@ -80,12 +80,20 @@ __device__ __forceinline__ uint32_t adc_bin(float dval, float lo, float scale) {
 }
 
 // dist[qq][i] for the queries q0 .. q0+nqb-1
+// blockIdx.y = batch of kAdcQB queries inside a group (round 6: the batches of a group run in ONE set of launches; the
+// per-query arrays -- lut, bounds, dist, hist -- are laid out over the group's queries, batch b owns queries 8b .. 8b+7)
 __global__ __launch_bounds__(256) void k_adc_scan(const uint8_t *__restrict__ codes, uint64_t n, uint32_t m,
-                                                  uint32_t k, const float *__restrict__ lut, uint32_t nqb,
+                                                  uint32_t k, const float *__restrict__ lut, uint32_t nq_group, uint32_t qb,
                                                   const float *__restrict__ bounds, float *__restrict__ dist,
                                                   uint32_t *__restrict__ hist) {
     extern __shared__ float lds_lut[];  // [nqb][m][k], then the block's histograms [nqb][kAdcBins]
     const uint32_t tab = m * k;
+    const uint32_t q_first = blockIdx.y * qb;
+    const uint32_t nqb = min(qb, nq_group - q_first);
+    lut += (size_t)q_first * tab;
+    bounds += 2 * q_first;
+    dist += (size_t)q_first * n;
+    hist += (size_t)q_first * kAdcBins;
     uint32_t *lds_hist = reinterpret_cast<uint32_t *>(lds_lut + (size_t)nqb * tab);
     for (uint32_t e = threadIdx.x; e < nqb * tab; e += 256) lds_lut[e] = lut[e];
     for (uint32_t e = threadIdx.x; e < nqb * kAdcBins; e += 256) lds_hist[e] = 0u;
@@ -320,11 +328,12 @@ __global__ __launch_bounds__(1024) void k_adc_topk(const float *__restrict__ dis
 
 }  // namespace
 
-// queries_dev [nq][m*sd]; lut_ws >= kAdcQB*m*k floats; dist_ws >= kAdcQB*n floats; outputs on the device
+// queries_dev [nq][m*sd]; workspaces sized for a group of `qgroup` queries (adc_query_group): lut_ws >= qgroup*m*k floats,
+// dist_ws >= qgroup*n floats, state_ws >= adc_state_bytes(qgroup), cand_ws >= adc_cand_bytes(qgroup); outputs on the device
 int launch_adc_search(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int metric, const uint8_t *codes, uint64_t n,
                       const float *queries_dev, uint32_t nq, uint32_t topk, float *lut_ws, float *dist_ws,
                       void *state_ws, unsigned long long *cand_ws, uint32_t *idx_out_dev, float *dist_out_dev,
-                      hipStream_t stream) {
+                      hipStream_t stream, uint32_t qgroup) {
     if (vq_is_cos(metric))
         return fail(VQHIP_ERR_UNSUPPORTED, "cosine distance is not a sum over subspaces: no ADC form");
     if (topk == 0 || topk > 1024 || topk > n) return fail(VQHIP_ERR_INVALID_INPUT, "topk must be in [1, min(n, 1024)]");
@@ -347,37 +356,49 @@ int launch_adc_search(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int 
     // 8 MB of codes: 70 us per pass at 1M rows)
     const size_t scan_lds = (size_t)qb * ((size_t)m * k + kAdcBins) * 4;
     const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(8, (150 * 1024) / std::max<size_t>(scan_lds, 1)));
-    uint64_t blocks = (n + 255) / 256;
-    if (blocks > (uint64_t)num_cus() * per_cu) blocks = (uint64_t)num_cus() * per_cu;
-    // small state: bounds [QB][2] f32 | hist [QB][bins] u32 | sel [QB][2] u32 | cand_n [QB] u32
+    // A GROUP of up to `qgroup` queries (the caller's workspaces: adc_query_group(n)) goes through one set of launches: the
+    // six kernels of a pass are dependent and tiny (5-25 us each, 110 us per pass whatever the work), so eight passes one
+    // after the other cost eight times that for 64 queries
+    const uint32_t qg = std::max(qb, qgroup / qb * qb);
+    // small state per query of the group: bounds [2] f32 | hist [bins] u32 | sel [2] u32 | cand_n u32
     float *bounds = reinterpret_cast<float *>(state_ws);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(bounds + 2 * kAdcQB);
-    uint32_t *sel = hist + kAdcQB * kAdcBins;
-    uint32_t *cand_n = sel + 2 * kAdcQB;
-    const size_t state_bytes = (size_t)(2 * kAdcQB + kAdcQB * kAdcBins + 2 * kAdcQB + kAdcQB) * 4;
-    for (uint32_t q0 = 0; q0 < nq; q0 += qb) {
-        const uint32_t nqb = (nq - q0 < qb) ? nq - q0 : qb;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(bounds + 2 * (size_t)qg);
+    uint32_t *sel = hist + (size_t)qg * kAdcBins;
+    uint32_t *cand_n = sel + 2 * (size_t)qg;
+    const size_t state_bytes = adc_state_bytes(qg);
+    for (uint32_t q0 = 0; q0 < nq; q0 += qg) {
+        const uint32_t nqg = (nq - q0 < qg) ? nq - q0 : qg;
+        const uint32_t batches = (nqg + qb - 1) / qb;
+        uint64_t blocks = (n + 255) / 256;
+        const uint64_t cap = std::max<uint64_t>(1, (uint64_t)num_cus() * per_cu / batches);
+        if (blocks > cap) blocks = cap;
         VQ_HIP(hipMemsetAsync(state_ws, 0, state_bytes, stream));
-        hipLaunchKernelGGL(k_adc_lut, dim3(nqb, m), dim3(256), 0, stream, queries_dev + (size_t)q0 * m * sd, nqb, m, k, sd,
+        hipLaunchKernelGGL(k_adc_lut, dim3(nqg, m), dim3(256), 0, stream, queries_dev + (size_t)q0 * m * sd, nqg, m, k, sd,
                            cb, l1, lut_ws, bounds);
         VQ_LAUNCH_CHECK("k_adc_lut");
-        hipLaunchKernelGGL(k_adc_scan, dim3((uint32_t)blocks), dim3(256), (size_t)nqb * (m * k + kAdcBins) * 4, stream,
-                           codes, n, m, k, lut_ws, nqb, bounds, dist_ws, hist);
+        hipLaunchKernelGGL(k_adc_scan, dim3((uint32_t)blocks, batches), dim3(256), (size_t)qb * (m * k + kAdcBins) * 4, stream,
+                           codes, n, m, k, lut_ws, nqg, qb, bounds, dist_ws, hist);
         VQ_LAUNCH_CHECK("k_adc_scan");
         // top-k: candidates below a histogram cut, sorted in LDS; dense cuts fall back to the radix select
-        hipLaunchKernelGGL(k_adc_pick_bin, dim3(nqb), dim3(64), 0, stream, hist, topk, sel);
-        hipLaunchKernelGGL(k_adc_collect, dim3(64, nqb), dim3(256), 0, stream, dist_ws, n, bounds, sel, cand_ws, cand_n);
-        hipLaunchKernelGGL(k_adc_sort_out, dim3(nqb), dim3(1024), (size_t)kAdcCand * 8, stream, cand_ws, sel, topk, take_sqrt,
+        hipLaunchKernelGGL(k_adc_pick_bin, dim3(nqg), dim3(64), 0, stream, hist, topk, sel);
+        hipLaunchKernelGGL(k_adc_collect, dim3(64, nqg), dim3(256), 0, stream, dist_ws, n, bounds, sel, cand_ws, cand_n);
+        hipLaunchKernelGGL(k_adc_sort_out, dim3(nqg), dim3(1024), (size_t)kAdcCand * 8, stream, cand_ws, sel, topk, take_sqrt,
                            idx_out_dev + (size_t)q0 * topk, dist_out_dev + (size_t)q0 * topk);
-        hipLaunchKernelGGL(k_adc_topk, dim3(nqb), dim3(1024), 0, stream, dist_ws, n, topk, take_sqrt, sel,
+        hipLaunchKernelGGL(k_adc_topk, dim3(nqg), dim3(1024), 0, stream, dist_ws, n, topk, take_sqrt, sel,
                            idx_out_dev + (size_t)q0 * topk, dist_out_dev + (size_t)q0 * topk);
         VQ_LAUNCH_CHECK("k_adc_topk");
     }
     return VQHIP_OK;
 }
 
-size_t adc_state_bytes() { return (size_t)(2 * kAdcQB + kAdcQB * kAdcBins + 2 * kAdcQB + kAdcQB) * 4; }
-size_t adc_cand_bytes() { return (size_t)kAdcQB * kAdcCand * 8; }
+size_t adc_state_bytes(uint32_t qgroup) { return (size_t)qgroup * (2 + kAdcBins + 2 + 1) * 4; }
+size_t adc_cand_bytes(uint32_t qgroup) { return (size_t)qgroup * kAdcCand * 8; }
 uint32_t adc_query_batch() { return kAdcQB; }
+// queries that share one set of launches: up to 64, as long as their distance rows (4 n bytes each) stay under 1 GB
+uint32_t adc_query_group(uint64_t n, uint32_t nq) {
+    uint64_t g = (1ull << 30) / std::max<uint64_t>(4 * n, 1);
+    g = std::min<uint64_t>(std::max<uint64_t>(g / kAdcQB * kAdcQB, kAdcQB), 64);
+    return (uint32_t)std::min<uint64_t>(g, ((uint64_t)nq + kAdcQB - 1) / kAdcQB * kAdcQB);
+}
 
 }  // namespace vqhip

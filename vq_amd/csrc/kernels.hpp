@@ -241,10 +241,11 @@ int launch_tsvq_encode_small(const float *rows_dev, uint32_t n, uint32_t d, int 
 int launch_adc_search(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int metric, const uint8_t *codes, uint64_t n,
                       const float *queries_dev, uint32_t nq, uint32_t topk, float *lut_ws, float *dist_ws,
                       void *state_ws, unsigned long long *cand_ws, uint32_t *idx_out_dev, float *dist_out_dev,
-                      hipStream_t stream);
+                      hipStream_t stream, uint32_t qgroup);
 uint32_t adc_query_batch();
-size_t adc_state_bytes();
-size_t adc_cand_bytes();
+uint32_t adc_query_group(uint64_t n, uint32_t nq);  // queries that go through one set of launches (a multiple of the batch)
+size_t adc_state_bytes(uint32_t qgroup);
+size_t adc_cand_bytes(uint32_t qgroup);
 
 // prepared per-node data of the screened squared-L2 / Euclidean descent (k_tsvq_screen.hip)
 struct TsvqScreen {
