@@ -8,6 +8,7 @@ MI355X through libvqhip; the tree is kept as flat pre-order arrays.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -71,9 +72,11 @@ class TSVQ:
 
     def _make_encoder(self, devices=None):
         dv = _lib._devices(devices)
+        # the multi-device encoder (a worker thread and a replica of the tree per device slot) is made by the first batch
+        # large enough to use it: a TSVQ that only ever quantizes single vectors starts no threads
         self._menc = None
-        if dv.size > 1:  # row blocks of large batches over the devices (vqhip_mtsvq)
-            self._menc = _lib.MTSVQ(self._centroids, self._left, self._right, self._distance.metric, dv)
+        self._menc_lock = threading.Lock()
+        self._dv = dv
         self.devices = [int(x) for x in dv]
         h = C.c_void_p()
         lib = _lib.load()
@@ -121,13 +124,23 @@ class TSVQ:
         leaf = _arena.fresh((n,), np.int32) if want_leaf else None  # (large results: recycled buffers, vq_amd/_arena.py)
         f16 = _arena.fresh((n, self._dim), np.uint16) if want_f16 else None
         self._last_multi = False
-        if n and self._menc is not None and n >= 65536 * len(self.devices):
+        if n and self._multi(n) is not None:
             self._menc.encode(X, leaf, f16)
             self._last_multi = True
         elif n:
             _lib.check(_lib.load().vqhip_tsvq_encode(self._enc.raw, _lib.ptr(X, _lib._f32p), n,
                                                      _lib.ptr(leaf, _lib._i32p), _lib.ptr(f16, _lib._u16p)))
         return leaf, (None if f16 is None else f16.view(np.float16))
+
+    def _multi(self, n: int):
+        """the row-block encoder over the device list for a batch of n rows, None for batches (or device lists) too small"""
+        if self._dv.size < 2 or n < 65536 * self._dv.size:
+            return None
+        if self._menc is None:
+            with self._menc_lock:
+                if self._menc is None:
+                    self._menc = _lib.MTSVQ(self._centroids, self._left, self._right, self._distance.metric, self._dv)
+        return self._menc
 
     def quantize_batch(self, X) -> np.ndarray:
         return self._encode(X, False, True)[1]
@@ -151,6 +164,5 @@ class TSVQ:
             raise ValueError("expected a 2D array (n, dim)")
         if Q.shape[1] != self._dim:
             raise DimensionMismatch(self._dim, Q.shape[1])
-        if self._menc is not None and Q.shape[0] >= 65536 * len(self.devices):
-            return self._menc.dequantize_f16(Q)
-        return _lib.dequantize_f16(Q)
+        menc = self._multi(Q.shape[0])
+        return menc.dequantize_f16(Q) if menc is not None else _lib.dequantize_f16(Q)
