@@ -21,6 +21,7 @@ bash tools/tsvq_prof.sh tsvq_time.py c4 --sum > $O/tsvq_kernels_c4_sum.txt 2>&1
 timeout 200 python tools/host_xfer.py > $O/host_xfer.txt 2>&1; tail -4 $O/host_xfer.txt
 timeout 200 python tools/tsvq_enc_f16.py > $O/tsvq_encode_metrics.txt 2>&1; tail -2 $O/tsvq_encode_metrics.txt
 timeout 200 python tools/adc_time.py 2>&1 | grep adc > $O/adc_times.txt
+timeout 300 python tools/launch_floor.py 2>&1 | grep -v amdgpu.ids > $O/launch_floor.txt
 timeout 200 profiles/ubench/bin/valu_waves > $O/ubench_valu_waves.txt 2>&1
 # TSVQ build traffic: FETCH_SIZE / WRITE_SIZE per kernel over one script run (3 builds each), uniform and N(0,1) rows
 ( cd /tmp && export TMPDIR=/tmp
