@@ -42,10 +42,12 @@ def test_decode_device_form_and_unaligned_output():
     want = np.concatenate([cb[s][codes[:, s]] for s in range(m)], axis=1)
     enc = _lib.PQEncoder(cb, _lib.SQUARED_EUCLIDEAN)
     dc = torch.from_numpy(codes).cuda()
+    torch.cuda.synchronize()
     buf = torch.zeros(n * m * sd + 1, dtype=torch.float32, device="cuda")
     for off in (0, 1):  # 16-byte aligned: one float4 per lane; 4 bytes off: the scalar form
         out = buf[off:off + n * m * sd]
         out.zero_()
+        torch.cuda.synchronize()  # (the library launches on its own stream: torch's fill must have landed)
         enc.decode_device(dc.data_ptr(), n, out.data_ptr())
         _lib.synchronize()
         np.testing.assert_array_equal(out.cpu().numpy().reshape(n, m * sd).view(np.uint32), want.view(np.uint32))
@@ -69,10 +71,12 @@ def test_dequantize_f16_device_form_unaligned():
     h = np.random.default_rng(9).standard_normal(count + 8).astype(np.float16)
     dh = torch.from_numpy(h.view(np.int16)).cuda()
     out = torch.empty(count + 8, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
     for src_off, dst_off in ((0, 0), (1, 0), (0, 1), (3, 2)):  # element offsets: 2-byte / 4-byte misalignment of the 16-byte form
         src = dh[src_off:src_off + count]
         dst = out[dst_off:dst_off + count]
         dst.zero_()
+        torch.cuda.synchronize()  # (the library launches on its own stream: torch's fill must have landed)
         _lib.dequantize_f16_device(src.data_ptr(), count, dst.data_ptr())
         _lib.synchronize()
         np.testing.assert_array_equal(dst.cpu().numpy().view(np.uint32), h[src_off:src_off + count].astype(F).view(np.uint32))
