@@ -962,47 +962,72 @@ __global__ __launch_bounds__(256) void k_chunk_counts(const uint8_t *__restrict_
 
 // chunk_counts [chunks][m][k] -> in place: write offset of (chunk, s, j) inside members[s][..];
 // start [m][k+1]: first member of cluster j (start[s][k] = rows of the subspace)
+// Round 6: two kernels over (subspace, 32 clusters) workgroups instead of one workgroup per subspace whose threads each
+// walked all n_chunks entries of their cluster twice, one after the other (8 workgroups on the chip at C2: 263 us of a
+// 1.33 ms exact_update iteration).  A thread owns (cluster, one of 8 blocks of chunks): the walks are an eighth as long,
+// 64 workgroups run them, and a wave's 32 + 32 lanes read two contiguous 128-byte runs per chunk.
+constexpr uint32_t kBoClusters = 32, kBoBlocks = 8;  // 256 threads
+
+// totals[s][j] = rows of cluster j; block sums [s][j][cb] for the second kernel
+__global__ __launch_bounds__(256) void k_bucket_totals(const uint32_t *__restrict__ chunk_counts, uint32_t n_chunks, uint32_t m, uint32_t k,
+                                                       uint32_t *__restrict__ totals, uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t part[kBoBlocks][kBoClusters];
+    const uint32_t s = blockIdx.x, jl = threadIdx.x % kBoClusters, cb = threadIdx.x / kBoClusters;
+    const uint32_t j = blockIdx.y * kBoClusters + jl;
+    const uint32_t per = (n_chunks + kBoBlocks - 1) / kBoBlocks, c0 = cb * per, c1 = min(n_chunks, c0 + per);
+    uint32_t sum = 0;
+    if (j < k)
+        for (uint32_t c = c0; c < c1; ++c) sum += chunk_counts[((size_t)c * m + s) * k + j];
+    part[cb][jl] = sum;
+    __syncthreads();
+    if (j < k) block_sums[((size_t)s * k + j) * kBoBlocks + cb] = sum;
+    if (cb == 0 && j < k) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < kBoBlocks; ++q) tot += part[q][jl];
+        totals[(size_t)s * k + j] = tot;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_bucket_offsets(uint32_t *__restrict__ chunk_counts, uint32_t n_chunks,
-                                                        uint32_t m, uint32_t k, uint32_t *__restrict__ start) {
-    extern __shared__ uint32_t tot[];  // [k] cluster totals, then their exclusive scan
+                                                        uint32_t m, uint32_t k, uint32_t *__restrict__ start,
+                                                        const uint32_t *__restrict__ totals, const uint32_t *__restrict__ block_sums) {
     __shared__ uint32_t seg[256];
+    __shared__ uint32_t first_of[kBoClusters];
     const uint32_t s = blockIdx.x, tid = threadIdx.x;
-    for (uint32_t j = tid; j < k; j += 256) {
-        uint32_t total = 0;
-        for (uint32_t c = 0; c < n_chunks; ++c) total += chunk_counts[((size_t)c * m + s) * k + j];
-        tot[j] = total;
-    }
-    __syncthreads();
-    // exclusive scan over clusters: thread `tid` owns the contiguous run [tid*per, tid*per + per)
-    const uint32_t per = (k + 255) / 256;
-    const uint32_t j0 = tid * per, j1 = (j0 + per < k) ? (j0 + per) : k;
-    uint32_t run_sum = 0;
-    for (uint32_t j = j0; j < j1; ++j) run_sum += tot[j];
-    seg[tid] = run_sum;
-    __syncthreads();
-    for (uint32_t off = 1; off < 256; off <<= 1) {
-        const uint32_t t = (tid >= off) ? seg[tid - off] : 0u;
+    // first member of this workgroup's clusters: the clusters in front of them (every thread adds a strided share), then the
+    // 32 of its own in order
+    {
+        const uint32_t jb = blockIdx.y * kBoClusters;
+        uint32_t acc = 0;
+        for (uint32_t j = tid; j < jb; j += 256) acc += totals[(size_t)s * k + j];
+        seg[tid] = acc;
         __syncthreads();
-        seg[tid] += t;
-        __syncthreads();
-    }
-    uint32_t first = seg[tid] - run_sum;
-    for (uint32_t j = j0; j < j1; ++j) {
-        const uint32_t total = tot[j];
-        tot[j] = first;
-        first += total;
-    }
-    if (tid == 255) start[s * (k + 1) + k] = seg[255];
-    __syncthreads();
-    for (uint32_t j = tid; j < k; j += 256) {
-        uint32_t run = tot[j];
-        start[s * (k + 1) + j] = run;
-        for (uint32_t c = 0; c < n_chunks; ++c) {
-            uint32_t *p = &chunk_counts[((size_t)c * m + s) * k + j];
-            const uint32_t cnt = *p;
-            *p = run;
-            run += cnt;
+        for (uint32_t off = 128; off > 0; off >>= 1) {
+            if (tid < off) seg[tid] += seg[tid + off];
+            __syncthreads();
         }
+        if (tid == 0) {
+            uint32_t run = seg[0];
+            for (uint32_t q = 0; q < kBoClusters; ++q) {
+                first_of[q] = run;
+                if (jb + q < k) run += totals[(size_t)s * k + jb + q];
+            }
+            if (jb + kBoClusters >= k) start[s * (k + 1) + k] = run;  // (the last workgroup of the subspace: all rows)
+        }
+        __syncthreads();
+    }
+    const uint32_t jl = tid % kBoClusters, cb = tid / kBoClusters, j = blockIdx.y * kBoClusters + jl;
+    if (j >= k) return;
+    uint32_t run = first_of[jl];
+    if (cb == 0) start[s * (k + 1) + j] = run;
+    for (uint32_t q = 0; q < cb; ++q) run += block_sums[((size_t)s * k + j) * kBoBlocks + q];
+    const uint32_t per = (n_chunks + kBoBlocks - 1) / kBoBlocks, c0 = cb * per, c1 = min(n_chunks, c0 + per);
+    for (uint32_t c = c0; c < c1; ++c) {
+        uint32_t *p = &chunk_counts[((size_t)c * m + s) * k + j];
+        const uint32_t cnt = *p;
+        *p = run;
+        run += cnt;
     }
 }
 
@@ -1040,13 +1065,18 @@ __global__ __launch_bounds__(64) void k_bucket_scatter(const uint8_t *__restrict
     }
 }
 
-// one lane per (s, j, t): sequential f32 sum of the members in ascending row order
-__global__ __launch_bounds__(256) void k_chain_sums(const float *__restrict__ X, uint32_t d, uint32_t m, uint32_t k,
-                                                    uint32_t sd, const uint8_t *__restrict__ active,
-                                                    const uint32_t *__restrict__ start,
-                                                    const uint32_t *__restrict__ members, uint64_t members_stride,
-                                                    double *__restrict__ slab) {
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+// one lane per (s, j, t): sequential f32 sum of the members in ascending row order.  The chain itself is ~20 K cycles per
+// cluster (3900 dependent adds at C2); the kernel's time is the gathers' latency over what is in flight (512 waves on the
+// whole chip).  Round 6: batches of 32 members, the row ids two batches ahead and the gathers one batch ahead of the
+// additions, every load unconditional with clamped indices (a load under a per-lane test is followed by vmcnt(0)):
+// 563 -> ~200 us at C2.
+// (workgroups of ONE wave: 512 of them at C2 reach every CU's load path; 128 workgroups of four left half the chip idle)
+__global__ __launch_bounds__(64) void k_chain_sums(const float *__restrict__ X, uint32_t d, uint32_t m, uint32_t k,
+                                                   uint32_t sd, const uint8_t *__restrict__ active,
+                                                   const uint32_t *__restrict__ start,
+                                                   const uint32_t *__restrict__ members, uint64_t members_stride,
+                                                   double *__restrict__ slab) {
+    const uint32_t e = blockIdx.x * 64 + threadIdx.x;
     if (e >= m * k * sd) return;
     const uint32_t sj = e / sd, t = e - sj * sd, s = sj / k, j = sj - s * k;
     double *row = slab + (size_t)sj * (sd + 1);
@@ -1059,16 +1089,34 @@ __global__ __launch_bounds__(256) void k_chain_sums(const float *__restrict__ X,
     const uint32_t *mem = members + (size_t)s * members_stride;
     const float *px = X + (size_t)s * sd + t;
     float acc = 0.0f;  // vector.rs:374
-    uint32_t i = a;
-    constexpr int U = 16;
-    for (; i + U <= b; i += U) {
-        float v[U];
+    constexpr int U = 32;
+    const uint32_t last = (b > a) ? b - 1 : a;  // (clamp target: a valid member slot whenever the cluster has one)
+    if (b > a) {
+        uint32_t ids[2][U];
+        float v[2][U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = px[(size_t)mem[i + u] * d];
+        for (int u = 0; u < U; ++u) ids[0][u] = mem[min(a + (uint32_t)u, last)];
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc = acc + v[u];
+        for (int u = 0; u < U; ++u) ids[1][u] = mem[min(a + (uint32_t)(U + u), last)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[0][u] = px[(size_t)ids[0][u] * d];
+        for (uint32_t i = a; i < b; i += 2 * U) {
+            // batch [i, i + U): its values are in flight in v[0]; request batch i + U (ids in ids[1]), the ids of i + 2U, add v[0]
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[1][u] = px[(size_t)ids[1][u] * d];
+#pragma unroll
+            for (int u = 0; u < U; ++u) ids[0][u] = mem[min(i + (uint32_t)(2 * U + u), last)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = (i + (uint32_t)u < b) ? acc + v[0][u] : acc;
+            // batch [i + U, i + 2U): in v[1]; request batch i + 2U (ids[0]), the ids of i + 3U, add v[1]
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[0][u] = px[(size_t)ids[0][u] * d];
+#pragma unroll
+            for (int u = 0; u < U; ++u) ids[1][u] = mem[min(i + (uint32_t)(3 * U + u), last)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = (i + (uint32_t)(U + u) < b) ? acc + v[1][u] : acc;
+        }
     }
-    for (; i < b; ++i) acc = acc + px[(size_t)mem[i] * d];
     row[t] = (double)acc;
     if (t == 0) row[sd] = (double)(b - a);
 }
@@ -1076,7 +1124,8 @@ __global__ __launch_bounds__(256) void k_chain_sums(const float *__restrict__ X,
 }  // namespace
 
 size_t exact_sums_workspace_bytes(uint32_t m, uint32_t k, uint64_t n) {
-    return ((size_t)m * n + (size_t)xs_chunk_cap(m, k) * m * k + (size_t)m * (k + 1)) * 4 + 256;
+    // members [m][n] | chunk offsets [chunks][m][k] | start [m][k + 1] | totals [m][k] | block sums [m][k][8]
+    return ((size_t)m * n + (size_t)xs_chunk_cap(m, k) * m * k + (size_t)m * (k + 1) + (size_t)m * k * (1 + kBoBlocks)) * 4 + 256;
 }
 
 int launch_exact_sums(uint32_t m, uint32_t k, uint32_t sd, const float *X, uint64_t n, uint32_t d,
@@ -1093,13 +1142,16 @@ int launch_exact_sums(uint32_t m, uint32_t k, uint32_t sd, const float *X, uint6
     hipLaunchKernelGGL(k_chunk_counts, dim3(n_chunks, m), dim3(256), (size_t)k * 4, stream, codes, n, m, k, rows_per_chunk, active,
                        chunk_counts);
     VQ_LAUNCH_CHECK("k_chunk_counts");
-    hipLaunchKernelGGL(k_bucket_offsets, dim3(m), dim3(256), (size_t)k * 4, stream, chunk_counts, n_chunks, m, k, start);
+    uint32_t *totals = start + (size_t)m * (k + 1), *block_sums = totals + (size_t)m * k;
+    const dim3 bo_grid(m, (k + kBoClusters - 1) / kBoClusters);
+    hipLaunchKernelGGL(k_bucket_totals, bo_grid, dim3(256), 0, stream, chunk_counts, n_chunks, m, k, totals, block_sums);
+    hipLaunchKernelGGL(k_bucket_offsets, bo_grid, dim3(256), 0, stream, chunk_counts, n_chunks, m, k, start, totals, block_sums);
     VQ_LAUNCH_CHECK("k_bucket_offsets");
     hipLaunchKernelGGL(k_bucket_scatter, dim3(n_chunks, m), dim3(64), (size_t)k * 4, stream, codes, n, m, k, rows_per_chunk, active,
                        chunk_counts, members, n);
     VQ_LAUNCH_CHECK("k_bucket_scatter");
     const uint32_t total = m * k * sd;
-    hipLaunchKernelGGL(k_chain_sums, dim3((total + 255) / 256), dim3(256), 0, stream, X, d, m, k, sd, active, start,
+    hipLaunchKernelGGL(k_chain_sums, dim3((total + 63) / 64), dim3(64), 0, stream, X, d, m, k, sd, active, start,
                        members, n, slab);
     VQ_LAUNCH_CHECK("k_chain_sums");
     return VQHIP_OK;
