@@ -163,6 +163,27 @@ def test_comm_abort_wakes_a_blocked_rank():
     lib.vqhip_comm_group_destroy(grp)
 
 
+def test_a_rank_that_never_joins_times_the_constructor_out():
+    """vqhip_comm_create_local with one of two ranks missing: the bounded wait ends the call, the group is poisoned, its
+    slot is released by vqhip_comm_group_destroy"""
+    import ctypes as C
+
+    lib = _lib.load()
+    with _env(VQHIP_COMM_TIMEOUT_S=1):
+        grp = C.c_void_p()
+        _lib.check(lib.vqhip_comm_group_create(2, C.byref(grp)))
+    comm = C.c_void_p()
+    _lib.set_device(0)
+    t0 = time.time()
+    rc = lib.vqhip_comm_create_local(grp, 0, C.byref(comm))
+    took = time.time() - t0
+    assert rc == _lib.ERR_RUNTIME and not comm.value and 0.8 <= took < 10, (rc, took)
+    assert "waited 1 s" in _lib.last_error() and "1 of 2 ranks" in _lib.last_error(), _lib.last_error()
+    rc2 = lib.vqhip_comm_create_local(grp, 1, C.byref(comm))  # the late rank finds the group poisoned: no wait
+    assert rc2 == _lib.ERR_RUNTIME and "poisoned" in _lib.last_error()
+    lib.vqhip_comm_group_destroy(grp)
+
+
 def test_constructor_device_defaults(monkeypatch):
     """devices=None: every visible device the batch gives work to -- but ONE under exact_update (it raised)"""
     import vq_amd as pyvq
