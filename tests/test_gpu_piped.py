@@ -85,6 +85,38 @@ def test_piped_lloyd_step_ragged_rows(oracle, shape):
     ds.close()
 
 
+@pytest.mark.parametrize("sd,m", [(16, 4), (8, 8)])
+def test_piped_update_every_row_in_one_cluster(oracle, sd, m):
+    """The fused update adds a proven row by LDS f64 atomics (round 6).  Worst case for them: EVERY row of a step goes to
+    the same cluster -- 64 lanes of one atomic instruction on one address, serialised by the LDS.  Centroids far apart, all
+    rows in a small ball around centroid 7 (every row proven by a wide margin): counts exact, the one populated cluster's
+    mean within 2e-6 of the f64 mean of its rows (the reference's own sequential f32 sum of 120k terms is looser than that),
+    twice the same bits."""
+    n, k = 120_000, 256
+    rng = np.random.default_rng(sd)
+    cen = (rng.standard_normal((m, k, sd)) * 50.0).astype(F)
+    X = np.concatenate([cen[s, 7][None, :] + 0.01 * rng.standard_normal((n, sd)).astype(F) for s in range(m)], axis=1).astype(F)
+    ds = _lib.Dataset.from_host(X)
+    km = _lib.KMeans(ds, m, k)
+    outs = []
+    for _ in range(2):
+        km.set_centroids(cen)
+        km.set_active(np.ones(m, np.uint8))
+        counts, changed = km.step()
+        assert _lib.last_assign_stats() == (0, _lib.ENGINE_MFMA_BF16)  # nothing re-checked: every row went through the atomics
+        outs.append(km.get_centroids())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    for s in range(m):
+        assert counts[s, 7] == n and int(counts[s].sum()) == n
+        want = X[:, s * sd:(s + 1) * sd].astype(np.float64).mean(axis=0)
+        err = np.max(np.abs(outs[0][s, 7] - want) / np.maximum(1.0, np.abs(want)))
+        assert err <= 2e-6, (s, err)
+        others = np.delete(np.arange(k), 7)
+        np.testing.assert_array_equal(outs[0][s, others], cen[s, others])  # empty clusters keep their centroids
+    km.close()
+    ds.close()
+
+
 @pytest.mark.parametrize("tail_steps", [1, 2, 3, 4, 9])
 @pytest.mark.parametrize("sd,m", [(16, 8), (8, 16)])
 def test_piped_last_chunk_lengths(oracle, sd, m, tail_steps):
