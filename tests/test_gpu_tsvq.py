@@ -248,6 +248,33 @@ def test_screened_descent_adversarial(oracle):
     np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)
 
 
+@pytest.mark.parametrize("metric", [0, 3])
+def test_folded_continuation_with_full_lists(oracle, metric):
+    """Round 6: a wave finishes its own undecided rows.  Here most rows are undecided -- on or within an ulp of the root's
+    bisecting plane -- so every wave's list (64 entries in LDS) fills up several times and the tile loop is left and
+    re-entered; leaves and f16 rows equal the oracle's, and the two-kernel form's (VQHIP_TSVQ_FOLD is read once per
+    process: compared through the oracle)."""
+    rng = np.random.default_rng(31)
+    n0, d, depth = 6000, 128, 8
+    X = rng.standard_normal((n0, d)).astype(F)
+    tree = oracle.tsvq_build(X, depth)
+    cent, left, right = tree["centroids"], tree["left"], tree["right"]
+    cl, cr = cent[left[0]].astype(np.float64), cent[right[0]].astype(np.float64)
+    # squared L2: the midpoint of the root's children; cosine: the bisector of their directions (equal angles to both)
+    mid = ((cl + cr) / 2).astype(F) if metric == 0 else (cl / np.linalg.norm(cl) + cr / np.linalg.norm(cr)).astype(F)
+    n = 600_000  # 4096 waves x 146 rows: lists of 64 overflow in every wave
+    Q = np.repeat(mid[None, :], n, axis=0)
+    Q[::3] += (rng.standard_normal((len(Q[::3]), d)) * 1e-7).astype(F)   # a third a hair off the plane
+    Q[1::50] = rng.standard_normal((len(Q[1::50]), d)).astype(F)          # and some ordinary rows in between
+    name = {0: "squared_euclidean", 3: "cosine"}[metric]
+    t = TSVQ.from_tree(cent, left, right, Distance(name))
+    want_leaf, want_f16 = oracle.tsvq_encode(metric, Q, tree, threads=0)
+    np.testing.assert_array_equal(t.leaf_ids(Q), want_leaf)
+    screened, undecided = t.last_encode_stats()
+    assert screened and undecided > 0.5 * n  # the lists really were full
+    np.testing.assert_array_equal(t.quantize_batch(Q).view(np.uint16), want_f16)
+
+
 @pytest.mark.parametrize("kind", ["uniform", "normal", "lattice", "structured"])
 @pytest.mark.parametrize("shape", [(6000, 32, 9), (6000, 128, 8), (3000, 384, 5), (2500, 192, 6), (2000, 768, 5),
                                    (5000, 100, 7), (3000, 20, 6), (2000, 4, 5), (1500, 1024, 4), (30000, 128, 11)])
