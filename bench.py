@@ -449,6 +449,10 @@ def adc_case(_lib, torch, engine):
             "ms_per_call_8_queries": res[8], "code_scans_per_call": passes,
             "roofline": hbm_roofline(scan_bytes, res[nq], {"kernel": "k_adc_scan", "note": "whole call, wall clock (tables + "
                                      f"{passes} scans of the n*m code bytes + top-k + read-back): algorithmic bytes = n*m per batch of 8 queries + the tables"}),
+            # what actually bounds the scan: one 4-byte LDS table read per (row, query, subspace) -- 128 B per clock and CU
+            "lds_roofline": {"bound": "lds", "achieved": float(n) * nq * m / (res[nq] * 1e-3) / 1e12, "peak": 256 * 32 * 2.1e9 / 1e12,
+                             "unit": "T table reads/s", "frac": float(n) * nq * m / (res[nq] * 1e-3) / (256 * 32 * 2.1e9),
+                             "note": "whole call; peak = 256 CUs x 32 conflict-free 4-byte LDS reads per clock at 2.1 GHz (random codes conflict ~4-way)"},
             "self_check": top1_is_own_code}
 
 
