@@ -405,12 +405,18 @@ int vqhip_distance_batch(int metric, const float *a, const float *b, uint64_t n,
  * per-subspace distance (squared L2 or L1) between the query's sub-vector and centroid
  * codes[i][s]; the topk rows by (D, row index) ascending; Euclidean reports sqrt(D); cosine is
  * not separable (VQHIP_ERR_UNSUPPORTED).  codes [n][m] u8, queries [nq][dim] host f32,
- * idx_out / dist_out [nq][topk] host; 1 <= topk <= min(n, 1024). */
+ * idx_out / dist_out [nq][topk] host; 1 <= topk <= min(n, 1024).
+ * Two schedules, one result: n >= 32768 and topk <= 256 take ONE scan of the codes per batch of
+ * queries against a threshold from a sample of the rows and keep only the rows at or below it; a
+ * query whose threshold let fewer than topk (or more than 8192) rows pass -- and every other shape
+ * -- goes through the full pass (all distances, histogram cut).  vqhip_pq_adc_last_redone: how many
+ * queries of the encoder's last call took the full pass (diagnostics; VQHIP_ADC_FAST=0 sends all). */
 int vqhip_pq_adc_search(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n, const float *queries,
                         uint32_t nq, uint32_t topk, uint32_t *idx_out, float *dist_out);
 int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uint64_t n,
                                const float *queries, uint32_t nq, uint32_t topk, uint32_t *idx_out,
                                float *dist_out);
+int vqhip_pq_adc_last_redone(vqhip_pq_encoder *enc, uint32_t *queries_out);
 
 /* ---- TSVQ ----------------------------------------------------------------------------
  * build replaces TSVQNode::build (src/tsvq.rs:31-115); the tree comes back flattened in

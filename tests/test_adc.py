@@ -129,3 +129,83 @@ def test_gpu_adc_dense_ties_take_the_radix_select_path(oracle):
     np.testing.assert_array_equal(idx, want_i)
     np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
     enc.close()
+
+
+# ---- the one-scan schedule (n >= 32768, topk <= 256): a sampled threshold, candidates only ----------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", [O.SQUARED_EUCLIDEAN, O.EUCLIDEAN, O.MANHATTAN])
+@pytest.mark.parametrize("shape", [(200_000, 8, 16, 256, 10, 64),      # the bench's shape at a fifth of its rows: 8 batches of 8 queries
+                                   (1_000_000, 8, 16, 256, 10, 9),     # full size; the last batch holds one query
+                                   (50_000, 16, 8, 200, 256, 5),       # the largest topk the schedule takes
+                                   (40_000, 96, 8, 256, 20, 3),        # C3's tables: 98 KB each, one query per batch
+                                   (33_000, 3, 5, 7, 40, 11),          # m not a multiple of 8: the byte-load path; heavy ties (7^3 distinct rows)
+                                   (100_000, 4, 4, 300, 7, 6)])        # two-byte codes
+def test_gpu_adc_one_scan_bit_exact(oracle, metric, shape):
+    from vq_amd import _lib
+
+    n, m, sd, k, topk, nq = shape
+    rng = np.random.default_rng(n + m + 1)
+    cb = rng.standard_normal((m, k, sd)).astype(F)
+    codes = rng.integers(0, k, (n, m)).astype(np.uint8 if k <= 256 else np.uint16)
+    codes[n // 2: n // 2 + 20] = codes[3]
+    Q = rng.standard_normal((nq, m * sd)).astype(F)
+    Q[0] = cb[np.arange(m), codes[12345].astype(np.int64)].reshape(-1)  # a query that IS a stored row: D = 0 at the top
+    enc = _lib.PQEncoder(cb, metric)
+    idx, dist = enc.adc_search(codes, Q, topk)
+    redone = enc.adc_last_redone()
+    want_i, want_d = oracle.adc_search(metric, cb, codes, Q, topk)
+    np.testing.assert_array_equal(idx, want_i)
+    np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
+    # the threshold is placed for ~1024-4096 candidates: on random codes no query should need the full pass, except where
+    # ties pile more than 8192 rows onto one value (the 7^3-row shape)
+    if k ** m > 10 * n:
+        assert redone == 0, redone
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_adc_flagged_queries_take_the_full_pass(oracle):
+    """every query flagged by the test hook: the caller's repeat path must give the same bits"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys
+        sys.path[:0] = [".", "oracle"]
+        import numpy as np, oracle as O
+        from vq_amd import _lib
+        F = np.float32
+        rng = np.random.default_rng(3)
+        n, m, sd, k, topk, nq = 60_000, 8, 4, 64, 15, 10
+        cb = rng.standard_normal((m, k, sd)).astype(F)
+        codes = rng.integers(0, k, (n, m)).astype(np.uint8)
+        Q = rng.standard_normal((nq, m * sd)).astype(F)
+        enc = _lib.PQEncoder(cb, O.SQUARED_EUCLIDEAN)
+        idx, dist = enc.adc_search(codes, Q, topk)
+        assert enc.adc_last_redone() == nq, enc.adc_last_redone()
+        orc = O.get()
+        wi, wd = orc.adc_search(O.SQUARED_EUCLIDEAN, cb, codes, Q, topk)
+        assert (idx == wi).all() and (dist.view(np.uint32) == wd.view(np.uint32)).all()
+        print("ok")
+    """)
+    import os
+    env = dict(os.environ, VQHIP_TEST_ADC_REDO="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_gpu_adc_constant_distances_fall_back(oracle):
+    """all rows equal: every D(q, .) ties, the threshold passes n > 8192 rows, the full pass answers (lowest rows first)"""
+    from vq_amd import _lib
+
+    n, m, sd, k, topk, nq = 40_000, 8, 2, 16, 12, 3
+    rng = np.random.default_rng(9)
+    cb = rng.standard_normal((m, k, sd)).astype(F)
+    codes = np.tile(rng.integers(0, k, (1, m)).astype(np.uint8), (n, 1))
+    Q = rng.standard_normal((nq, m * sd)).astype(F)
+    enc = _lib.PQEncoder(cb, O.SQUARED_EUCLIDEAN)
+    idx, dist = enc.adc_search(codes, Q, topk)
+    assert enc.adc_last_redone() == nq
+    np.testing.assert_array_equal(idx, np.tile(np.arange(topk, dtype=np.uint32), (nq, 1)))
+    want_i, want_d = oracle.adc_search(O.SQUARED_EUCLIDEAN, cb, codes, Q, topk)
+    np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
+    enc.close()

@@ -15,7 +15,7 @@ codes = torch.empty((n, m), dtype=torch.uint8, device="cuda")
 enc.encode_device(ds.device_ptr, n, codes.data_ptr(), None)
 _lib.synchronize()
 Q = _lib.synth_uniform_host(64, d, 67, 0)
-for nq in (64, 8, 1):
+for nq in ([int(x) for x in sys.argv[1:]] or (64, 8, 1)):
     for _ in range(3):
         enc.adc_search((codes.data_ptr(), n), Q[:nq], topk)
     t0 = time.perf_counter()

@@ -99,6 +99,7 @@ SIGNATURES = {
     "vqhip_tsvq_encode_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "vqhip_pq_adc_search": (C.c_int, [_vp, _u8p, C.c_uint64, _f32p, C.c_uint32, C.c_uint32, _u32p, _f32p]),
     "vqhip_pq_adc_search_device": (C.c_int, [_vp, _vp, C.c_uint64, _f32p, C.c_uint32, C.c_uint32, _u32p, _f32p]),
+    "vqhip_pq_adc_last_redone": (C.c_int, [_vp, _u32p]),
     "vqhip_selftest": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "vqhip_mfma_bf16_probe": (C.c_int, [_u16p, _u16p, _f32p, C.c_uint64, _f32p]),
     "vqhip_mfma_bf16_model": (C.c_int, [_u16p, _u16p, _f32p, C.c_uint64, _f32p]),
@@ -660,6 +661,13 @@ class PQEncoder(Handle):
             check(lib.vqhip_pq_adc_search(self.raw, ptr(c, _u8p), c.shape[0], ptr(q, _f32p), nq, int(topk),
                                           ptr(idx, _u32p), ptr(dist, _f32p)))
         return idx, dist
+
+    def adc_last_redone(self) -> int:
+        """queries of the last adc_search that went through the full pass (all of them where the one-scan schedule does
+        not apply)"""
+        v = C.c_uint32(0)
+        check(load().vqhip_pq_adc_last_redone(self.raw, C.byref(v)))
+        return int(v.value)
 
     def encode(self, rows, want_codes=True, want_f16=True, out_codes=None, out_f16=None):
         """codes (n, m) and / or the f16 reconstruction (n, dim): fresh arrays per call, like the reference's binding

@@ -777,7 +777,8 @@ struct vqhip_pq_encoder {
     AssignWorkspace ws;
     int metric = VQHIP_EUCLIDEAN;
     int engine = VQHIP_ENGINE_AUTO;
-    DevBuf xbuf, codes, f16buf, f32buf, adc_q, adc_lut, adc_dist, adc_idx, adc_out, adc_codes, adc_state, adc_cand;
+    DevBuf xbuf, codes, f16buf, f32buf, adc_q, adc_lut, adc_dist, adc_idx, adc_out, adc_codes, adc_state, adc_cand, adc_redo;
+    uint32_t adc_last_redone = 0;  // queries of the last ADC call that went through the full pass
     std::vector<uint32_t> all_subs;
     // the per-vector path's images (codebooks, cosine norms) are complete on the DEVICE -- set only after a host wait behind
     // their prepare kernels; `cs.prepared` alone says they were ENQUEUED, possibly on another thread's stream
@@ -2273,23 +2274,97 @@ int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uin
     hipStream_t s;
     VQ_TRY(in.stream(&s));
     const uint32_t m = enc->cs.m, k = enc->cs.k, sd = enc->cs.sd, dim = m * sd;
-    const uint32_t qg = adc_query_group(n, nq);
     VQ_TRY(enc->adc_q.ensure((size_t)nq * dim * 4));
-    VQ_TRY(enc->adc_lut.ensure((size_t)qg * m * k * 4));
-    VQ_TRY(enc->adc_dist.ensure((size_t)qg * n * 4));
     VQ_TRY(enc->adc_idx.ensure((size_t)nq * topk * 4));
     VQ_TRY(enc->adc_out.ensure((size_t)nq * topk * 4));
-    VQ_TRY(enc->adc_state.ensure(adc_state_bytes(qg)));
-    VQ_TRY(enc->adc_cand.ensure(adc_cand_bytes(qg)));
-    VQ_HIP(hipMemcpyAsync(enc->adc_q.p, queries, (size_t)nq * dim * 4, hipMemcpyHostToDevice, s));
-    VQ_TRY(launch_adc_search(enc->cs.cb.as<float>(), m, k, sd, enc->metric, reinterpret_cast<const uint8_t *>(dev_codes), n,
-                             enc->adc_q.as<float>(), nq, topk, enc->adc_lut.as<float>(), enc->adc_dist.as<float>(),
-                             enc->adc_state.p, enc->adc_cand.as<unsigned long long>(), enc->adc_idx.as<uint32_t>(),
-                             enc->adc_out.as<float>(), s, qg));
+    // Small calls stage through pinned, device-mapped memory: the queries leave as one asynchronous DMA and the results
+    // are WRITTEN into host memory by the last kernel -- a copy from or into pageable memory is a staged transfer inside
+    // the runtime that holds the calling thread (~12 us each; an 8-query call spent more time in its four copies than in
+    // its kernels)
+    const size_t q_b = (size_t)nq * dim * 4, nres = (size_t)nq * topk, pack_b = (2 * nres + 2 * (size_t)nq) * 4;
+    const bool fast = adc_fast_eligible(m, k, n, topk), staged = fast && q_b + pack_b <= (1u << 20);
+    StageLease stage;
+    if (staged) {
+        VQ_TRY(stage.acquire(q_b + pack_b));
+        memcpy(stage.host(), queries, q_b);
+        VQ_HIP(hipMemcpyAsync(enc->adc_q.p, stage.host(), q_b, hipMemcpyHostToDevice, s));
+    } else {
+        VQ_HIP(hipMemcpyAsync(enc->adc_q.p, queries, q_b, hipMemcpyHostToDevice, s));
+    }
+    // the full pass (every distance written, histogram cut, candidates collected) for the queries [q0, q0 + cnt)
+    auto full_pass = [&](uint32_t q0, uint32_t cnt) -> int {
+        const uint32_t qg = adc_query_group(n, cnt);
+        VQ_TRY(enc->adc_lut.ensure((size_t)qg * m * k * 4));
+        VQ_TRY(enc->adc_dist.ensure((size_t)qg * n * 4));
+        VQ_TRY(enc->adc_state.ensure(adc_state_bytes(qg)));
+        VQ_TRY(enc->adc_cand.ensure(adc_cand_bytes(qg)));
+        return launch_adc_search(enc->cs.cb.as<float>(), m, k, sd, enc->metric, reinterpret_cast<const uint8_t *>(dev_codes), n,
+                                 enc->adc_q.as<float>() + (size_t)q0 * dim, cnt, topk, enc->adc_lut.as<float>(), enc->adc_dist.as<float>(),
+                                 enc->adc_state.p, enc->adc_cand.as<unsigned long long>(), enc->adc_idx.as<uint32_t>() + (size_t)q0 * topk,
+                                 enc->adc_out.as<float>() + (size_t)q0 * topk, s, qg);
+    };
+    if (fast) {
+        // one scan of the codes per batch of queries against a sampled threshold, only candidates written (k_adc.hip);
+        // a query whose threshold let too few or too many rows pass is repeated through the full pass
+        VQ_TRY(enc->adc_lut.ensure(adc_fast_lut_bytes(m, k, nq)));
+        VQ_TRY(enc->adc_state.ensure(adc_fast_state_bytes(m, k, nq)));
+        VQ_TRY(enc->adc_cand.ensure(adc_fast_cand_bytes(m, k, nq)));
+        // results, flags and candidate counts in ONE buffer: [nq][topk] idx | [nq][topk] dist | [nq] redo | [nq] count -- one
+        // copy back instead of three (each a staged transfer of its own into pageable memory, ~12 us)
+        if (!staged) VQ_TRY(enc->adc_redo.ensure(pack_b));
+        uint32_t *pack_dev = staged ? reinterpret_cast<uint32_t *>(stage.dev() + q_b) : enc->adc_redo.as<uint32_t>();
+        VQ_TRY(launch_adc_search_fast(enc->cs.cb.as<float>(), m, k, sd, enc->metric, reinterpret_cast<const uint8_t *>(dev_codes), n,
+                                      enc->adc_q.as<float>(), nq, topk, enc->adc_lut.as<float>(), enc->adc_state.p,
+                                      enc->adc_cand.as<unsigned long long>(), pack_dev, reinterpret_cast<float *>(pack_dev + nres),
+                                      pack_dev + 2 * nres, s));
+        std::vector<uint32_t> pack_copy;
+        const uint32_t *pack = nullptr;
+        if (staged) {
+            VQ_TRY(spin_wait(s));
+            pack = reinterpret_cast<const uint32_t *>(stage.host() + q_b);
+        } else {
+            pack_copy.resize(2 * nres + 2 * (size_t)nq);
+            VQ_HIP(hipMemcpyAsync(pack_copy.data(), pack_dev, pack_b, hipMemcpyDeviceToHost, s));
+            VQ_HIP(hipStreamSynchronize(s));
+            pack = pack_copy.data();
+        }
+        memcpy(idx_out, pack, nres * 4);
+        memcpy(dist_out, pack + nres, nres * 4);
+        const uint32_t *redo = pack + 2 * nres;
+        uint32_t redone = 0;
+        for (uint32_t q0 = 0; q0 < nq;) {
+            if (!redo[q0]) {
+                ++q0;
+                continue;
+            }
+            uint32_t q1 = q0;
+            while (q1 < nq && redo[q1]) ++q1;  // a run of flagged queries goes through together
+            VQ_TRY(full_pass(q0, q1 - q0));
+            VQ_HIP(hipMemcpyAsync(idx_out + (size_t)q0 * topk, enc->adc_idx.as<uint32_t>() + (size_t)q0 * topk, (size_t)(q1 - q0) * topk * 4, hipMemcpyDeviceToHost, s));
+            VQ_HIP(hipMemcpyAsync(dist_out + (size_t)q0 * topk, enc->adc_out.as<float>() + (size_t)q0 * topk, (size_t)(q1 - q0) * topk * 4, hipMemcpyDeviceToHost, s));
+            VQ_HIP(hipStreamSynchronize(s));
+            redone += q1 - q0;
+            q0 = q1;
+        }
+        enc->adc_last_redone = redone;
+        in.synced();
+        return VQHIP_OK;
+    }
+    VQ_TRY(full_pass(0, nq));
+    enc->adc_last_redone = nq;
     VQ_HIP(hipMemcpyAsync(idx_out, enc->adc_idx.p, (size_t)nq * topk * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipMemcpyAsync(dist_out, enc->adc_out.p, (size_t)nq * topk * 4, hipMemcpyDeviceToHost, s));
     VQ_HIP(hipStreamSynchronize(s));
     in.synced();
+    return VQHIP_OK;
+    VQ_API_END
+}
+
+int vqhip_pq_adc_last_redone(vqhip_pq_encoder *enc, uint32_t *queries_out) {
+    VQ_API_BEGIN
+    if (!enc || !queries_out) return fail(VQHIP_ERR_NULL_PTR, "NULL argument");
+    Entry in(enc->sync);
+    *queries_out = enc->adc_last_redone;
     return VQHIP_OK;
     VQ_API_END
 }

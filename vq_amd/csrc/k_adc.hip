@@ -326,6 +326,332 @@ __global__ __launch_bounds__(1024) void k_adc_topk(const float *__restrict__ dis
     }
 }
 
+
+// ---- round 6: one pass over the codes, nothing but candidates written ------------------------------------------------
+// The pass above writes every D(q, i) (4 n bytes per query) and reads it again to collect the candidates: 512 MB of
+// traffic for 64 queries over 1M rows whose codes are 8 MB, plus eight LDS atomics per row and batch for the histograms.
+// Here a THRESHOLD per query comes first, from a sample of the rows (k_adc_thresh), and the scan keeps only the rows at or
+// below it: (key, row) pairs appended to the query's candidate list.  Any threshold gives the exact answer as long as at
+// least `topk` and at most kAdcCand rows pass (every row below the topk-th smallest D, and every tie with it, is <= T);
+// k_adc_sort_thr flags the queries where that fails and the caller sends those through the pass above.
+// Tables are interleaved over the batch's queries, [s][j][QB]: one LDS address per (row, subspace) yields all QB terms
+// (QB / 4 ds_read_b128 instead of QB ds_read_b32 and their offsets).
+__host__ __device__ __forceinline__ uint32_t adc_tabp(uint32_t m, uint32_t k, uint32_t qb) { return (m * k * qb + 3u) & ~3u; }  // floats per batch of tables (16-byte units)
+template <uint32_t QB>
+__global__ __launch_bounds__(256) void k_adc_lut_i(const float *__restrict__ queries, uint32_t nq, uint32_t m, uint32_t k,
+                                                   uint32_t sd, const float *__restrict__ cb, int l1, float *__restrict__ lut) {
+    const uint32_t q = blockIdx.x, s = blockIdx.y, batch = q / QB, qq = q % QB;
+    const bool real = q < nq;  // the last batch is padded with zero tables
+    const float *x = queries + ((size_t)(real ? q : 0) * m + s) * sd;
+    for (uint32_t j = threadIdx.x; j < k; j += 256) {
+        const float *c = cb + ((size_t)s * k + j) * sd;
+        float acc = l1 ? 0.0f : -0.0f;
+        for (uint32_t t = 0; t < sd; ++t) {
+            const float diff = x[t] - c[t];
+            if (l1) {
+                acc = acc + fabsf(diff);
+            } else {
+                const float sq = diff * diff;
+                acc = acc + sq;
+            }
+        }
+        lut[(size_t)batch * adc_tabp(m, k, QB) + ((size_t)s * k + j) * QB + qq] = real ? acc : 0.0f;
+    }
+}
+
+template <uint32_t QB>
+__device__ __forceinline__ void adc_terms(const float *__restrict__ lds, uint32_t off, float (&v)[QB]) {
+    if constexpr (QB == 1) {
+        v[0] = lds[off];
+    } else if constexpr (QB == 2) {
+        const float2 a = *reinterpret_cast<const float2 *>(lds + (size_t)off * 2);
+        v[0] = a.x, v[1] = a.y;
+    } else {
+#pragma unroll
+        for (uint32_t h = 0; h < QB / 4; ++h) {
+            const float4 a = *reinterpret_cast<const float4 *>(lds + (size_t)off * QB + 4 * h);
+            v[4 * h] = a.x, v[4 * h + 1] = a.y, v[4 * h + 2] = a.z, v[4 * h + 3] = a.w;
+        }
+    }
+}
+
+// D(q, i) of the batch's QB queries for row i, subspace 0 first (the order of k_adc_scan and of the oracle)
+template <uint32_t QB>
+__device__ __forceinline__ void adc_row(const uint8_t *__restrict__ codes, uint64_t i, uint32_t m, uint32_t k, bool words,
+                                        const float *__restrict__ lds, float (&acc)[QB]) {
+    float v[QB];
+    if (words) {  // one-byte codes, rows of whole 8-byte words
+        for (uint32_t s8 = 0; s8 < m; s8 += 8) {
+            const uint2 w = *reinterpret_cast<const uint2 *>(codes + i * m + s8);
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b) {
+                const uint32_t s = s8 + b;
+                adc_terms<QB>(lds, s * k + (((b < 4 ? w.x : w.y) >> (8 * (b & 3))) & 255u), v);
+#pragma unroll
+                for (uint32_t qq = 0; qq < QB; ++qq) acc[qq] = (s == 0) ? v[qq] : acc[qq] + v[qq];
+            }
+        }
+    } else {
+        for (uint32_t s = 0; s < m; ++s) {
+            adc_terms<QB>(lds, s * k + load_code(codes, i * m + s, k), v);
+#pragma unroll
+            for (uint32_t qq = 0; qq < QB; ++qq) acc[qq] = (s == 0) ? v[qq] : acc[qq] + v[qq];
+        }
+    }
+}
+
+__device__ __forceinline__ void adc_tables_to_lds(float *__restrict__ lds, const float *__restrict__ src, uint32_t floats, uint32_t nt) {
+    for (uint32_t e = 4 * threadIdx.x; e < floats; e += 4 * nt)  // (adc_tabp floats: whole 16-byte units)
+        *reinterpret_cast<float4 *>(lds + e) = *reinterpret_cast<const float4 *>(src + e);
+}
+
+// The sample behind the thresholds: G workgroups per batch of queries, every thread `rpt` of 1024 G rpt evenly spaced rows;
+// wmins[q][16 g + wave] = the wave's minimum of D(q, .).  The scan takes the j-th smallest of a query's 16 G minima as
+// its threshold: for j well below 16 G that is close to the j-th smallest of all S = 1024 G rpt sampled distances, the
+// j / S quantile -- about n j / S rows at or below it (the host picks G, rpt, j for 1024-4096 of them).  One workgroup
+// per batch (round 6's first form) spent 40 us reading its own CU's LDS; the tables' 64 KB per workgroup are the cost now.
+constexpr uint32_t kAdcStage = 128;    // candidates a workgroup stages per query before it appends them to the query's list
+constexpr uint32_t kAdcCntStride = 64;  // the queries' list counters sit 256 bytes apart: 64 of them in two cache lines took
+                                        // every append of every workgroup through one L2 channel (~10 ns each: 320 us of a 64-query scan)
+constexpr uint32_t kAdcMaxG = 64;  // sampler workgroups per batch (16 kAdcMaxG minima per query at most)
+template <uint32_t QB>
+__global__ __launch_bounds__(1024) void k_adc_thresh(const uint8_t *__restrict__ codes, uint64_t n, uint32_t m, uint32_t k,
+                                                     const float *__restrict__ lut, uint32_t rpt, float *__restrict__ wmins,
+                                                     uint32_t *__restrict__ cand_n) {
+    extern __shared__ float lds_lut[];  // [m][k][QB]
+    const uint32_t tab = adc_tabp(m, k, QB), batch = blockIdx.y, G = gridDim.x;
+    adc_tables_to_lds(lds_lut, lut + (size_t)batch * tab, tab, 1024);
+    // (the candidate lists' counters start at zero: one launch less than a memset in front)
+    if (blockIdx.x == 0 && threadIdx.x < QB) cand_n[(size_t)(batch * QB + threadIdx.x) * kAdcCntStride] = 0u;
+    __syncthreads();
+    const bool words = k <= 256 && (m & 7u) == 0 && (reinterpret_cast<uintptr_t>(codes) & 7u) == 0;
+    float mn[QB];
+#pragma unroll
+    for (uint32_t qq = 0; qq < QB; ++qq) mn[qq] = __builtin_inff();
+    const uint64_t total = 1024ull * G * rpt;
+    for (uint32_t u = 0; u < rpt; ++u) {
+        const uint64_t i = (((uint64_t)u * G + blockIdx.x) * 1024 + threadIdx.x) * n / total;
+        float acc[QB];
+        adc_row<QB>(codes, i, m, k, words, lds_lut, acc);
+#pragma unroll
+        for (uint32_t qq = 0; qq < QB; ++qq) mn[qq] = fminf(mn[qq], acc[qq]);  // (NaN never wins)
+    }
+#pragma unroll
+    for (uint32_t qq = 0; qq < QB; ++qq) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mn[qq] = fminf(mn[qq], __shfl_xor(mn[qq], off));
+        if ((threadIdx.x & 63u) == 0) wmins[(size_t)(batch * QB + qq) * (16 * kAdcMaxG) + 16 * blockIdx.x + (threadIdx.x >> 6)] = mn[qq];
+    }
+}
+
+// the j-th smallest (j >= 1) of `count` <= 16 kAdcMaxG values, by one wave: every lane holds up to 16, j rounds of "wave
+// minimum, its first holder drops one copy"
+__device__ __forceinline__ float adc_jth_smallest(const float *__restrict__ vals, uint32_t count, uint32_t j, uint32_t lane) {
+    float v[16];
+#pragma unroll
+    for (uint32_t u = 0; u < 16; ++u) v[u] = (64 * u + lane < count) ? vals[64 * u + lane] : __builtin_inff();
+    float t = __builtin_inff();
+    for (uint32_t r = 0; r < j; ++r) {
+        float mine = v[0];
+#pragma unroll
+        for (uint32_t u = 1; u < 16; ++u) mine = fminf(mine, v[u]);
+        t = mine;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t = fminf(t, __shfl_xor(t, off));
+        const uint64_t holders = __ballot(mine == t);
+        if (holders && lane == (uint32_t)__builtin_ctzll(holders)) {
+            bool dropped = false;
+#pragma unroll
+            for (uint32_t u = 0; u < 16; ++u)
+                if (!dropped && v[u] == t) v[u] = __builtin_inff(), dropped = true;
+        }
+    }
+    return t;  // (+inf when fewer than j finite values exist: every row passes, the list overflows, the query is repeated)
+}
+
+template <uint32_t QB, uint32_t NT>
+__global__ __launch_bounds__(NT) void k_adc_scan_thr(const uint8_t *__restrict__ codes, uint64_t n, uint32_t m, uint32_t k,
+                                                     const float *__restrict__ lut, uint32_t nq, const float *__restrict__ wmins,
+                                                     uint32_t n_wmins, uint32_t order,
+                                                     unsigned long long *__restrict__ cand, uint32_t *__restrict__ cand_n) {
+    static_assert(NT >= 64 * QB, "one wave per query places its threshold");
+    extern __shared__ float lds_lut[];  // [m][k][QB], then the staged candidates [QB][kAdcStage] (8 bytes each) and their counts [QB]
+    const uint32_t tab = adc_tabp(m, k, QB), batch = blockIdx.y, q_first = batch * QB;
+    unsigned long long *stage = reinterpret_cast<unsigned long long *>(lds_lut + tab);
+    uint32_t *stage_n = reinterpret_cast<uint32_t *>(stage + QB * kAdcStage);
+    __shared__ uint32_t s_base[QB];
+    __shared__ float s_T[QB];
+    adc_tables_to_lds(lds_lut, lut + (size_t)batch * tab, tab, NT);
+    if (threadIdx.x < QB) stage_n[threadIdx.x] = 0u;
+    if (threadIdx.x < 64 * QB) {  // wave qq: the threshold of the batch's query qq (padding queries: nothing passes)
+        const uint32_t qq = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        const float t = (q_first + qq < nq) ? adc_jth_smallest(wmins + (size_t)(q_first + qq) * (16 * kAdcMaxG), n_wmins, order, lane) : -__builtin_inff();
+        if (lane == 0) s_T[qq] = t;
+    }
+    __syncthreads();
+    float T[QB];
+#pragma unroll
+    for (uint32_t qq = 0; qq < QB; ++qq) T[qq] = s_T[qq];
+    const bool words = k <= 256 && (m & 7u) == 0 && (reinterpret_cast<uintptr_t>(codes) & 7u) == 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * NT) {
+        float acc[QB];
+        adc_row<QB>(codes, i, m, k, words, lds_lut, acc);
+        bool any = false;
+#pragma unroll
+        for (uint32_t qq = 0; qq < QB; ++qq) any |= acc[qq] <= T[qq];
+        if (any) {  // ~1e-3 of the rows per query
+#pragma unroll
+            for (uint32_t qq = 0; qq < QB; ++qq)
+                if (acc[qq] <= T[qq]) {
+                    const unsigned long long e = ((unsigned long long)adc_key(acc[qq]) << 32) | (uint32_t)i;
+                    const uint32_t sp = atomicAdd(&stage_n[qq], 1u);
+                    if (sp < kAdcStage) {
+                        stage[qq * kAdcStage + sp] = e;
+                    } else {  // stage full (ties piled on one value): straight to the list
+                        const uint32_t pos = atomicAdd(&cand_n[(size_t)(q_first + qq) * kAdcCntStride], 1u);
+                        if (pos < kAdcCand) cand[(size_t)(q_first + qq) * kAdcCand + pos] = e;
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    // one append per (workgroup, query)
+    if (threadIdx.x < QB) {
+        const uint32_t c = min(stage_n[threadIdx.x], kAdcStage);
+        s_base[threadIdx.x] = c ? atomicAdd(&cand_n[(size_t)(q_first + threadIdx.x) * kAdcCntStride], c) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < QB * kAdcStage; e += NT) {
+        const uint32_t qq = e / kAdcStage, j = e % kAdcStage;
+        if (j < min(stage_n[qq], kAdcStage)) {
+            const uint32_t pos = s_base[qq] + j;
+            if (pos < kAdcCand) cand[(size_t)(q_first + qq) * kAdcCand + pos] = stage[qq * kAdcStage + j];
+        }
+    }
+}
+
+// the candidates of a query sorted by (key, row) in LDS, the first topk out; redo[q] = 1 where the threshold let fewer
+// than topk or more than kAdcCand rows pass (the caller repeats those queries with the full pass)
+__global__ __launch_bounds__(1024) void k_adc_sort_thr(const unsigned long long *__restrict__ cand,
+                                                       const uint32_t *__restrict__ cand_n, uint32_t topk, int take_sqrt,
+                                                       uint32_t *__restrict__ idx_out, float *__restrict__ dist_out,
+                                                       uint32_t *__restrict__ redo, int force_redo) {
+    extern __shared__ unsigned long long sort_buf[];  // [kAdcCand]
+    const uint32_t q = blockIdx.x, cnt = cand_n[(size_t)q * kAdcCntStride];
+    if (threadIdx.x == 0) redo[gridDim.x + q] = cnt;  // (diagnostics: candidates the threshold let pass)
+    if (cnt > kAdcCand || cnt < topk || force_redo) {
+        if (threadIdx.x == 0) redo[q] = 1u;
+        return;
+    }
+    if (threadIdx.x == 0) redo[q] = 0u;
+    const unsigned long long *cq = cand + (size_t)q * kAdcCand;
+    if (topk <= 64) {
+        // No block-wide sort (a bitonic network over >= 1024 slots is 55-66 barriers: 30 us for ~1000 candidates).  Every
+        // wave keeps the 64 smallest of its share: a chunk of 64 sorted by a shuffle network, min'ed against the reversed
+        // running best (the 64 smallest of the 128, as a bitonic sequence), six merge steps; wave 0 then folds the sixteen
+        // sorted runs the same way.  One barrier.
+        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        auto sort64 = [&](unsigned long long x) {
+#pragma unroll
+            for (uint32_t kk = 2; kk <= 64; kk <<= 1)
+#pragma unroll
+                for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                    const unsigned long long p = __shfl_xor(x, (int)j);
+                    const bool keep_min = ((lane & j) == 0) == ((lane & kk) == 0);
+                    x = keep_min ? (x < p ? x : p) : (x < p ? p : x);
+                }
+            return x;
+        };
+        auto fold = [&](unsigned long long best, unsigned long long sorted_run) {  // both ascending -> the 64 smallest, ascending
+            const unsigned long long r = __shfl(sorted_run, (int)(63u - lane));
+            unsigned long long x = best < r ? best : r;
+#pragma unroll
+            for (uint32_t j = 32; j > 0; j >>= 1) {
+                const unsigned long long p = __shfl_xor(x, (int)j);
+                x = ((lane & j) == 0) ? (x < p ? x : p) : (x < p ? p : x);
+            }
+            return x;
+        };
+        unsigned long long best = ~0ull;
+        for (uint32_t c = wv * 64; c < cnt; c += 1024) best = fold(best, sort64((c + lane < cnt) ? cq[c + lane] : ~0ull));
+        sort_buf[wv * 64 + lane] = best;
+        __syncthreads();
+        if (wv == 0) {
+            unsigned long long top = sort_buf[lane];
+            for (uint32_t r = 1; r < 16; ++r) top = fold(top, sort_buf[r * 64 + lane]);
+            if (lane < topk) {
+                float dv = adc_unkey((uint32_t)(top >> 32));
+                if (take_sqrt) dv = sqrtf(dv);
+                idx_out[(size_t)q * topk + lane] = (uint32_t)top;
+                dist_out[(size_t)q * topk + lane] = dv;
+            }
+        }
+        return;
+    }
+    uint32_t len = 1024;
+    while (len < cnt) len <<= 1;
+    for (uint32_t e = threadIdx.x; e < len; e += 1024) sort_buf[e] = (e < cnt) ? cq[e] : ~0ull;
+    __syncthreads();
+    for (uint32_t size = 2; size <= len; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = threadIdx.x; t < len; t += 1024) {
+                const uint32_t partner = t ^ stride;
+                if (partner > t) {
+                    const bool up = (t & size) == 0;
+                    const unsigned long long a = sort_buf[t], b = sort_buf[partner];
+                    if ((a > b) == up) {
+                        sort_buf[t] = b;
+                        sort_buf[partner] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x < topk) {
+        const unsigned long long w = sort_buf[threadIdx.x];
+        float dv = adc_unkey((uint32_t)(w >> 32));
+        if (take_sqrt) dv = sqrtf(dv);
+        idx_out[(size_t)q * topk + threadIdx.x] = (uint32_t)w;
+        dist_out[(size_t)q * topk + threadIdx.x] = dv;
+    }
+}
+
+template <uint32_t QB>
+int adc_fast_launch(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int l1, int take_sqrt, const uint8_t *codes, uint64_t n,
+                    const float *queries_dev, uint32_t nq, uint32_t topk, float *lut_ws, void *state_ws,
+                    unsigned long long *cand_ws, uint32_t *idx_out_dev, float *dist_out_dev, uint32_t *redo_dev,
+                    hipStream_t stream, uint32_t G, uint32_t rpt, uint32_t order, int force_redo) {
+    constexpr uint32_t NT = 512;
+    const size_t tab_b = (size_t)adc_tabp(m, k, QB) * 4;
+    static PerDeviceOnce attr;
+    if (attr.needed()) {
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_adc_scan_thr<QB, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_adc_thresh<QB>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_adc_sort_thr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kAdcCand * 8)));
+        attr.done();
+    }
+    const uint32_t batches = (nq + QB - 1) / QB;
+    // state: the sampler's wave minima [batches QB][16 kAdcMaxG] f32 | the list counters, 256 bytes apart
+    float *wmins = reinterpret_cast<float *>(state_ws);
+    uint32_t *cand_n = reinterpret_cast<uint32_t *>(wmins + (size_t)batches * QB * 16 * kAdcMaxG);
+    hipLaunchKernelGGL(k_adc_lut_i<QB>, dim3(batches * QB, m), dim3(256), 0, stream, queries_dev, nq, m, k, sd, cb, l1, lut_ws);
+    VQ_LAUNCH_CHECK("k_adc_lut_i");
+    hipLaunchKernelGGL(k_adc_thresh<QB>, dim3(G, batches), dim3(1024), tab_b, stream, codes, n, m, k, lut_ws, rpt, wmins, cand_n);
+    VQ_LAUNCH_CHECK("k_adc_thresh");
+    const size_t scan_lds = tab_b + QB * kAdcStage * 8 + QB * 4;
+    const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(4, (158 * 1024) / scan_lds));
+    uint64_t blocks = (n + NT - 1) / NT;
+    const uint64_t cap = std::max<uint64_t>(1, ((uint64_t)num_cus() * per_cu + batches - 1) / batches);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((k_adc_scan_thr<QB, NT>), dim3((uint32_t)blocks, batches), dim3(NT), scan_lds, stream, codes, n, m, k, lut_ws, nq,
+                       wmins, 16 * G, order, cand_ws, cand_n);
+    VQ_LAUNCH_CHECK("k_adc_scan_thr");
+    hipLaunchKernelGGL(k_adc_sort_thr, dim3(nq), dim3(1024), (size_t)kAdcCand * 8, stream, cand_ws, cand_n, topk, take_sqrt, idx_out_dev, dist_out_dev, redo_dev, force_redo);
+    VQ_LAUNCH_CHECK("k_adc_sort_thr");
+    return VQHIP_OK;
+}
+
 }  // namespace
 
 // queries_dev [nq][m*sd]; workspaces sized for a group of `qgroup` queries (adc_query_group): lut_ws >= qgroup*m*k floats,
@@ -399,6 +725,67 @@ uint32_t adc_query_group(uint64_t n, uint32_t nq) {
     uint64_t g = (1ull << 30) / std::max<uint64_t>(4 * n, 1);
     g = std::min<uint64_t>(std::max<uint64_t>(g / kAdcQB * kAdcQB, kAdcQB), 64);
     return (uint32_t)std::min<uint64_t>(g, ((uint64_t)nq + kAdcQB - 1) / kAdcQB * kAdcQB);
+}
+
+// ---- the threshold pass (round 6) ----
+// eligible: enough rows for a sample to place a threshold, few enough results for the candidate lists
+bool adc_fast_eligible(uint32_t m, uint32_t k, uint64_t n, uint32_t topk) {
+    static const char *env = getenv("VQHIP_ADC_FAST");
+    if (env && env[0] == '0') return false;
+    return n >= 32768 && topk <= 256 && (size_t)m * k * 4 <= 150 * 1024;
+}
+// queries per scan batch: the largest power of two whose interleaved tables fit the LDS (at most 8)
+uint32_t adc_fast_batch(uint32_t m, uint32_t k) {
+    uint32_t qb = 8;
+    while (qb > 1 && (size_t)m * k * qb * 4 > 150 * 1024) qb >>= 1;
+    return qb;
+}
+size_t adc_fast_lut_bytes(uint32_t m, uint32_t k, uint32_t nq) {
+    const uint32_t qb = adc_fast_batch(m, k);
+    return (size_t)((nq + qb - 1) / qb) * (((size_t)m * k * qb + 3) & ~(size_t)3) * 4;
+}
+size_t adc_fast_state_bytes(uint32_t m, uint32_t k, uint32_t nq) {
+    const uint32_t qb = adc_fast_batch(m, k);
+    return (size_t)((nq + qb - 1) / qb) * qb * (4 * 16 * 64 + 4 * 64);  // the sampler's wave minima (16 kAdcMaxG per query) + the list counters 256 bytes apart (kAdcCntStride)
+}
+size_t adc_fast_cand_bytes(uint32_t m, uint32_t k, uint32_t nq) {
+    const uint32_t qb = adc_fast_batch(m, k);
+    return (size_t)((nq + qb - 1) / qb) * qb * kAdcCand * 8;
+}
+// all nq queries in one set of five launches; redo_dev[q] = 1 where the caller must repeat query q with launch_adc_search
+int launch_adc_search_fast(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int metric, const uint8_t *codes, uint64_t n,
+                           const float *queries_dev, uint32_t nq, uint32_t topk, float *lut_ws, void *state_ws,
+                           unsigned long long *cand_ws, uint32_t *idx_out_dev, float *dist_out_dev, uint32_t *redo_dev,
+                           hipStream_t stream) {
+    if (vq_is_cos(metric))
+        return fail(VQHIP_ERR_UNSUPPORTED, "cosine distance is not a sum over subspaces: no ADC form");
+    if (topk == 0 || topk > 1024 || topk > n) return fail(VQHIP_ERR_INVALID_INPUT, "topk must be in [1, min(n, 1024)]");
+    const int l1 = metric == VQHIP_MANHATTAN ? 1 : 0, take_sqrt = metric == VQHIP_EUCLIDEAN ? 1 : 0;
+    // candidates wanted: 16 topk, at least 1024 (kAdcCand = 8192 is the list's size): the j-th smallest of S sampled
+    // distances sits near the j / S quantile, n j / S rows.  j = 8 (its rank among all rows scatters by 1 / sqrt(j))
+    // and S = 8 n / want rows, 1024 per sampler workgroup; past 64 workgroups x 16 rows per thread j comes down instead
+    const double want = std::min<double>(std::max<double>(16.0 * topk, 1024.0), 4096.0);
+    uint32_t order = 8;
+    const double S = std::min<double>((double)order * (double)n / want, (double)n);
+    uint32_t G = (uint32_t)std::min<double>(std::max<double>(std::ceil(S / 1024.0), 1.0), (double)kAdcMaxG);
+    uint32_t rpt = (uint32_t)std::min<double>(std::max<double>(std::ceil(S / (1024.0 * G)), 1.0), 16.0);
+    while ((uint64_t)1024 * G * rpt > n && rpt > 1) --rpt;
+    while ((uint64_t)1024 * G * rpt > n && G > 1) --G;
+    order = (uint32_t)std::min<double>(std::max<double>(std::floor(want * (1024.0 * G * rpt) / (double)n + 0.5), 1.0), 8.0);
+    static const char *force_env = getenv("VQHIP_TEST_ADC_REDO");  // tests: every query flagged, the caller's repeat path runs
+    const int force_redo = (force_env && force_env[0] == '1') ? 1 : 0;
+    switch (adc_fast_batch(m, k)) {
+#define VQ_ADC_FAST(QB)                                                                                                          \
+    case QB:                                                                                                                     \
+        return adc_fast_launch<QB>(cb, m, k, sd, l1, take_sqrt, codes, n, queries_dev, nq, topk, lut_ws, state_ws, cand_ws,      \
+                                   idx_out_dev, dist_out_dev, redo_dev, stream, G, rpt, order, force_redo);
+        VQ_ADC_FAST(8)
+        VQ_ADC_FAST(4)
+        VQ_ADC_FAST(2)
+        VQ_ADC_FAST(1)
+#undef VQ_ADC_FAST
+    }
+    return fail(VQHIP_ERR_RUNTIME, "adc_fast_batch");
 }
 
 }  // namespace vqhip

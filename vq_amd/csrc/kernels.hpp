@@ -246,6 +246,16 @@ uint32_t adc_query_batch();
 uint32_t adc_query_group(uint64_t n, uint32_t nq);  // queries that go through one set of launches (a multiple of the batch)
 size_t adc_state_bytes(uint32_t qgroup);
 size_t adc_cand_bytes(uint32_t qgroup);
+// the threshold pass (one scan of the codes, candidates only): all queries in one set of launches; redo_dev[q] = 1 where
+// query q has to be repeated through launch_adc_search
+bool adc_fast_eligible(uint32_t m, uint32_t k, uint64_t n, uint32_t topk);
+size_t adc_fast_lut_bytes(uint32_t m, uint32_t k, uint32_t nq);
+size_t adc_fast_state_bytes(uint32_t m, uint32_t k, uint32_t nq);
+size_t adc_fast_cand_bytes(uint32_t m, uint32_t k, uint32_t nq);
+int launch_adc_search_fast(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int metric, const uint8_t *codes, uint64_t n,
+                           const float *queries_dev, uint32_t nq, uint32_t topk, float *lut_ws, void *state_ws,
+                           unsigned long long *cand_ws, uint32_t *idx_out_dev, float *dist_out_dev, uint32_t *redo_dev,
+                           hipStream_t stream);
 
 // prepared per-node data of the screened squared-L2 / Euclidean descent (k_tsvq_screen.hip)
 struct TsvqScreen {
