@@ -1,9 +1,11 @@
 #!/bin/bash
-# ADC A/B on one box: the full pass (VQHIP_ADC_FAST=0) against the one-scan schedule, then per-kernel times of the latter
+# ADC A/B on one box: the full pass (VQHIP_ADC_FAST=0) against the one-scan schedule (a row per lane: VQHIP_ADC_LQ1=1; default: two
+# lanes per row), then per-kernel times of the default
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 echo "== full pass"; VQHIP_ADC_FAST=0 python3 $REPO/tools/adc_time.py 2>&1 | tail -3
-echo "== one scan"; python3 $REPO/tools/adc_time.py 2>&1 | tail -3
+echo "== one scan, 8 queries per batch, a row per lane"; VQHIP_ADC_LQ1=1 python3 $REPO/tools/adc_time.py 2>&1 | tail -3
+echo "== one scan (default)"; python3 $REPO/tools/adc_time.py 2>&1 | tail -3
 for NQ in 64 8 1; do
 rm -rf /tmp/adc_t
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/adc_t -o t -- python3 $REPO/tools/adc_time.py $NQ > /tmp/adc.log 2>&1

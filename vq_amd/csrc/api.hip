@@ -2286,8 +2286,7 @@ int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uin
     StageLease stage;
     if (staged) {
         VQ_TRY(stage.acquire(q_b + pack_b));
-        memcpy(stage.host(), queries, q_b);
-        VQ_HIP(hipMemcpyAsync(enc->adc_q.p, stage.host(), q_b, hipMemcpyHostToDevice, s));
+        memcpy(stage.host(), queries, q_b);  // (the table kernel reads them from there: no copy engine in front of the kernels)
     } else {
         VQ_HIP(hipMemcpyAsync(enc->adc_q.p, queries, q_b, hipMemcpyHostToDevice, s));
     }
@@ -2314,7 +2313,7 @@ int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uin
         if (!staged) VQ_TRY(enc->adc_redo.ensure(pack_b));
         uint32_t *pack_dev = staged ? reinterpret_cast<uint32_t *>(stage.dev() + q_b) : enc->adc_redo.as<uint32_t>();
         VQ_TRY(launch_adc_search_fast(enc->cs.cb.as<float>(), m, k, sd, enc->metric, reinterpret_cast<const uint8_t *>(dev_codes), n,
-                                      enc->adc_q.as<float>(), nq, topk, enc->adc_lut.as<float>(), enc->adc_state.p,
+                                      staged ? reinterpret_cast<const float *>(stage.dev()) : enc->adc_q.as<float>(), nq, topk, enc->adc_lut.as<float>(), enc->adc_state.p,
                                       enc->adc_cand.as<unsigned long long>(), pack_dev, reinterpret_cast<float *>(pack_dev + nres),
                                       pack_dev + 2 * nres, s));
         std::vector<uint32_t> pack_copy;
@@ -2339,6 +2338,7 @@ int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uin
             }
             uint32_t q1 = q0;
             while (q1 < nq && redo[q1]) ++q1;  // a run of flagged queries goes through together
+            if (staged && !redone) VQ_HIP(hipMemcpyAsync(enc->adc_q.p, queries, q_b, hipMemcpyHostToDevice, s));  // (the full pass reads them from device memory)
             VQ_TRY(full_pass(q0, q1 - q0));
             VQ_HIP(hipMemcpyAsync(idx_out + (size_t)q0 * topk, enc->adc_idx.as<uint32_t>() + (size_t)q0 * topk, (size_t)(q1 - q0) * topk * 4, hipMemcpyDeviceToHost, s));
             VQ_HIP(hipMemcpyAsync(dist_out + (size_t)q0 * topk, enc->adc_out.as<float>() + (size_t)q0 * topk, (size_t)(q1 - q0) * topk * 4, hipMemcpyDeviceToHost, s));

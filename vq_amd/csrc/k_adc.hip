@@ -342,12 +342,16 @@ __global__ __launch_bounds__(256) void k_adc_lut_i(const float *__restrict__ que
                                                    uint32_t sd, const float *__restrict__ cb, int l1, float *__restrict__ lut) {
     const uint32_t q = blockIdx.x, s = blockIdx.y, batch = q / QB, qq = q % QB;
     const bool real = q < nq;  // the last batch is padded with zero tables
-    const float *x = queries + ((size_t)(real ? q : 0) * m + s) * sd;
+    // (the query's sub-vector through LDS: `queries` may be pinned host memory, read once per workgroup then)
+    __shared__ float xs[256];
+    const float *xg = queries + ((size_t)(real ? q : 0) * m + s) * sd;
+    for (uint32_t t = threadIdx.x; t < min(sd, 256u); t += 256) xs[t] = xg[t];
+    __syncthreads();
     for (uint32_t j = threadIdx.x; j < k; j += 256) {
         const float *c = cb + ((size_t)s * k + j) * sd;
         float acc = l1 ? 0.0f : -0.0f;
         for (uint32_t t = 0; t < sd; ++t) {
-            const float diff = x[t] - c[t];
+            const float diff = (t < 256u ? xs[t] : xg[t]) - c[t];
             if (l1) {
                 acc = acc + fabsf(diff);
             } else {
@@ -359,43 +363,45 @@ __global__ __launch_bounds__(256) void k_adc_lut_i(const float *__restrict__ que
     }
 }
 
-template <uint32_t QB>
-__device__ __forceinline__ void adc_terms(const float *__restrict__ lds, uint32_t off, float (&v)[QB]) {
-    if constexpr (QB == 1) {
-        v[0] = lds[off];
-    } else if constexpr (QB == 2) {
-        const float2 a = *reinterpret_cast<const float2 *>(lds + (size_t)off * 2);
+// QL consecutive table entries (QL queries' terms of one (subspace, code)) from float offset `at`
+template <uint32_t QL>
+__device__ __forceinline__ void adc_terms(const float *__restrict__ lds, uint32_t at, float (&v)[QL]) {
+    if constexpr (QL == 1) {
+        v[0] = lds[at];
+    } else if constexpr (QL == 2) {
+        const float2 a = *reinterpret_cast<const float2 *>(lds + at);
         v[0] = a.x, v[1] = a.y;
     } else {
 #pragma unroll
-        for (uint32_t h = 0; h < QB / 4; ++h) {
-            const float4 a = *reinterpret_cast<const float4 *>(lds + (size_t)off * QB + 4 * h);
+        for (uint32_t h = 0; h < QL / 4; ++h) {
+            const float4 a = *reinterpret_cast<const float4 *>(lds + at + 4 * h);
             v[4 * h] = a.x, v[4 * h + 1] = a.y, v[4 * h + 2] = a.z, v[4 * h + 3] = a.w;
         }
     }
 }
 
-// D(q, i) of the batch's QB queries for row i, subspace 0 first (the order of k_adc_scan and of the oracle)
-template <uint32_t QB>
+// D(q, i) of QL of the batch's qb queries (those from `first` on) for row i, subspace 0 first (the order of k_adc_scan and
+// of the oracle)
+template <uint32_t QL>
 __device__ __forceinline__ void adc_row(const uint8_t *__restrict__ codes, uint64_t i, uint32_t m, uint32_t k, bool words,
-                                        const float *__restrict__ lds, float (&acc)[QB]) {
-    float v[QB];
+                                        const float *__restrict__ lds, uint32_t qb, uint32_t first, float (&acc)[QL]) {
+    float v[QL];
     if (words) {  // one-byte codes, rows of whole 8-byte words
         for (uint32_t s8 = 0; s8 < m; s8 += 8) {
             const uint2 w = *reinterpret_cast<const uint2 *>(codes + i * m + s8);
 #pragma unroll
             for (uint32_t b = 0; b < 8; ++b) {
                 const uint32_t s = s8 + b;
-                adc_terms<QB>(lds, s * k + (((b < 4 ? w.x : w.y) >> (8 * (b & 3))) & 255u), v);
+                adc_terms<QL>(lds, (s * k + (((b < 4 ? w.x : w.y) >> (8 * (b & 3))) & 255u)) * qb + first, v);
 #pragma unroll
-                for (uint32_t qq = 0; qq < QB; ++qq) acc[qq] = (s == 0) ? v[qq] : acc[qq] + v[qq];
+                for (uint32_t qq = 0; qq < QL; ++qq) acc[qq] = (s == 0) ? v[qq] : acc[qq] + v[qq];
             }
         }
     } else {
         for (uint32_t s = 0; s < m; ++s) {
-            adc_terms<QB>(lds, s * k + load_code(codes, i * m + s, k), v);
+            adc_terms<QL>(lds, (s * k + load_code(codes, i * m + s, k)) * qb + first, v);
 #pragma unroll
-            for (uint32_t qq = 0; qq < QB; ++qq) acc[qq] = (s == 0) ? v[qq] : acc[qq] + v[qq];
+            for (uint32_t qq = 0; qq < QL; ++qq) acc[qq] = (s == 0) ? v[qq] : acc[qq] + v[qq];
         }
     }
 }
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(1024) void k_adc_thresh(const uint8_t *__restrict__
     for (uint32_t u = 0; u < rpt; ++u) {
         const uint64_t i = (((uint64_t)u * G + blockIdx.x) * 1024 + threadIdx.x) * n / total;
         float acc[QB];
-        adc_row<QB>(codes, i, m, k, words, lds_lut, acc);
+        adc_row<QB>(codes, i, m, k, words, lds_lut, QB, 0u, acc);
 #pragma unroll
         for (uint32_t qq = 0; qq < QB; ++qq) mn[qq] = fminf(mn[qq], acc[qq]);  // (NaN never wins)
     }
@@ -469,12 +475,19 @@ __device__ __forceinline__ float adc_jth_smallest(const float *__restrict__ vals
     return t;  // (+inf when fewer than j finite values exist: every row passes, the list overflows, the query is repeated)
 }
 
-template <uint32_t QB, uint32_t NT>
+// LQ lanes per row: lane (row, part) holds QL = QB / LQ of the batch's queries, ONE 16-byte read per subspace when LQ > 1.
+// A row per lane (LQ = 1) reads QB floats at a random 4 QB-byte slot per lane and subspace: the LDS serves eight lanes'
+// 16 bytes per clock only when they fall on eight different 16-byte bank groups, and eight random ones pile ~2.7 deep
+// (measured: 35 % of the LDS rate).  With the LQ lanes of a row on consecutive 16-byte pieces of one entry a pass of eight
+// lanes touches 8 / LQ random entries instead of eight.
+template <uint32_t QB, uint32_t LQ, uint32_t NT>
 __global__ __launch_bounds__(NT) void k_adc_scan_thr(const uint8_t *__restrict__ codes, uint64_t n, uint32_t m, uint32_t k,
                                                      const float *__restrict__ lut, uint32_t nq, const float *__restrict__ wmins,
                                                      uint32_t n_wmins, uint32_t order,
                                                      unsigned long long *__restrict__ cand, uint32_t *__restrict__ cand_n) {
     static_assert(NT >= 64 * QB, "one wave per query places its threshold");
+    static_assert(QB % LQ == 0 && (LQ == 1 || QB / LQ == 4), "a lane holds all of the batch's queries or four of them");
+    constexpr uint32_t QL = QB / LQ, RPB = NT / LQ;  // queries per lane, rows per pass of the workgroup
     extern __shared__ float lds_lut[];  // [m][k][QB], then the staged candidates [QB][kAdcStage] (8 bytes each) and their counts [QB]
     const uint32_t tab = adc_tabp(m, k, QB), batch = blockIdx.y, q_first = batch * QB;
     unsigned long long *stage = reinterpret_cast<unsigned long long *>(lds_lut + tab);
@@ -489,27 +502,29 @@ __global__ __launch_bounds__(NT) void k_adc_scan_thr(const uint8_t *__restrict__
         if (lane == 0) s_T[qq] = t;
     }
     __syncthreads();
-    float T[QB];
+    const uint32_t part = threadIdx.x % LQ, first = part * QL;
+    float T[QL];
 #pragma unroll
-    for (uint32_t qq = 0; qq < QB; ++qq) T[qq] = s_T[qq];
+    for (uint32_t qq = 0; qq < QL; ++qq) T[qq] = s_T[first + qq];
     const bool words = k <= 256 && (m & 7u) == 0 && (reinterpret_cast<uintptr_t>(codes) & 7u) == 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * NT) {
-        float acc[QB];
-        adc_row<QB>(codes, i, m, k, words, lds_lut, acc);
+    for (uint64_t i = (uint64_t)blockIdx.x * RPB + threadIdx.x / LQ; i < n; i += (uint64_t)gridDim.x * RPB) {
+        float acc[QL];
+        adc_row<QL>(codes, i, m, k, words, lds_lut, QB, first, acc);
         bool any = false;
 #pragma unroll
-        for (uint32_t qq = 0; qq < QB; ++qq) any |= acc[qq] <= T[qq];
+        for (uint32_t qq = 0; qq < QL; ++qq) any |= acc[qq] <= T[qq];
         if (any) {  // ~1e-3 of the rows per query
 #pragma unroll
-            for (uint32_t qq = 0; qq < QB; ++qq)
+            for (uint32_t qq = 0; qq < QL; ++qq)
                 if (acc[qq] <= T[qq]) {
+                    const uint32_t bq = first + qq;
                     const unsigned long long e = ((unsigned long long)adc_key(acc[qq]) << 32) | (uint32_t)i;
-                    const uint32_t sp = atomicAdd(&stage_n[qq], 1u);
+                    const uint32_t sp = atomicAdd(&stage_n[bq], 1u);
                     if (sp < kAdcStage) {
-                        stage[qq * kAdcStage + sp] = e;
+                        stage[bq * kAdcStage + sp] = e;
                     } else {  // stage full (ties piled on one value): straight to the list
-                        const uint32_t pos = atomicAdd(&cand_n[(size_t)(q_first + qq) * kAdcCntStride], 1u);
-                        if (pos < kAdcCand) cand[(size_t)(q_first + qq) * kAdcCand + pos] = e;
+                        const uint32_t pos = atomicAdd(&cand_n[(size_t)(q_first + bq) * kAdcCntStride], 1u);
+                        if (pos < kAdcCand) cand[(size_t)(q_first + bq) * kAdcCand + pos] = e;
                     }
                 }
         }
@@ -574,17 +589,17 @@ __global__ __launch_bounds__(1024) void k_adc_sort_thr(const unsigned long long 
         };
         unsigned long long best = ~0ull;
         for (uint32_t c = wv * 64; c < cnt; c += 1024) best = fold(best, sort64((c + lane < cnt) ? cq[c + lane] : ~0ull));
-        sort_buf[wv * 64 + lane] = best;
-        __syncthreads();
-        if (wv == 0) {
-            unsigned long long top = sort_buf[lane];
-            for (uint32_t r = 1; r < 16; ++r) top = fold(top, sort_buf[r * 64 + lane]);
-            if (lane < topk) {
-                float dv = adc_unkey((uint32_t)(top >> 32));
-                if (take_sqrt) dv = sqrtf(dv);
-                idx_out[(size_t)q * topk + lane] = (uint32_t)top;
-                dist_out[(size_t)q * topk + lane] = dv;
-            }
+        // the sixteen runs folded pairwise (four rounds; one wave folding fifteen runs in turn was 6 of the kernel's 13 us)
+        for (uint32_t stride = 1; stride < 16; stride <<= 1) {
+            if ((wv & (2 * stride - 1)) == stride) sort_buf[wv * 64 + lane] = best;
+            __syncthreads();
+            if ((wv & (2 * stride - 1)) == 0) best = fold(best, sort_buf[(wv + stride) * 64 + lane]);
+        }
+        if (wv == 0 && lane < topk) {
+            float dv = adc_unkey((uint32_t)(best >> 32));
+            if (take_sqrt) dv = sqrtf(dv);
+            idx_out[(size_t)q * topk + lane] = (uint32_t)best;
+            dist_out[(size_t)q * topk + lane] = dv;
         }
         return;
     }
@@ -617,16 +632,15 @@ __global__ __launch_bounds__(1024) void k_adc_sort_thr(const unsigned long long 
     }
 }
 
-template <uint32_t QB>
+template <uint32_t QB, uint32_t LQ, uint32_t NT>
 int adc_fast_launch(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int l1, int take_sqrt, const uint8_t *codes, uint64_t n,
                     const float *queries_dev, uint32_t nq, uint32_t topk, float *lut_ws, void *state_ws,
                     unsigned long long *cand_ws, uint32_t *idx_out_dev, float *dist_out_dev, uint32_t *redo_dev,
                     hipStream_t stream, uint32_t G, uint32_t rpt, uint32_t order, int force_redo) {
-    constexpr uint32_t NT = 512;
     const size_t tab_b = (size_t)adc_tabp(m, k, QB) * 4;
     static PerDeviceOnce attr;
     if (attr.needed()) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_adc_scan_thr<QB, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_adc_scan_thr<QB, LQ, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_adc_thresh<QB>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_adc_sort_thr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kAdcCand * 8)));
         attr.done();
@@ -640,11 +654,11 @@ int adc_fast_launch(const float *cb, uint32_t m, uint32_t k, uint32_t sd, int l1
     hipLaunchKernelGGL(k_adc_thresh<QB>, dim3(G, batches), dim3(1024), tab_b, stream, codes, n, m, k, lut_ws, rpt, wmins, cand_n);
     VQ_LAUNCH_CHECK("k_adc_thresh");
     const size_t scan_lds = tab_b + QB * kAdcStage * 8 + QB * 4;
-    const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(4, (158 * 1024) / scan_lds));
-    uint64_t blocks = (n + NT - 1) / NT;
+    const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(2048 / NT, (158 * 1024) / scan_lds));
+    uint64_t blocks = (n + NT / LQ - 1) / (NT / LQ);
     const uint64_t cap = std::max<uint64_t>(1, ((uint64_t)num_cus() * per_cu + batches - 1) / batches);
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((k_adc_scan_thr<QB, NT>), dim3((uint32_t)blocks, batches), dim3(NT), scan_lds, stream, codes, n, m, k, lut_ws, nq,
+    hipLaunchKernelGGL((k_adc_scan_thr<QB, LQ, NT>), dim3((uint32_t)blocks, batches), dim3(NT), scan_lds, stream, codes, n, m, k, lut_ws, nq,
                        wmins, 16 * G, order, cand_ws, cand_n);
     VQ_LAUNCH_CHECK("k_adc_scan_thr");
     hipLaunchKernelGGL(k_adc_sort_thr, dim3(nq), dim3(1024), (size_t)kAdcCand * 8, stream, cand_ws, cand_n, topk, take_sqrt, idx_out_dev, dist_out_dev, redo_dev, force_redo);
@@ -734,22 +748,25 @@ bool adc_fast_eligible(uint32_t m, uint32_t k, uint64_t n, uint32_t topk) {
     if (env && env[0] == '0') return false;
     return n >= 32768 && topk <= 256 && (size_t)m * k * 4 <= 150 * 1024;
 }
-// queries per scan batch: the largest power of two whose interleaved tables fit the LDS (at most 8)
-uint32_t adc_fast_batch(uint32_t m, uint32_t k) {
+// queries per scan batch: the largest power of two up to eight whose interleaved tables fit the LDS.  (Sixteen per batch,
+// four lanes per row, one workgroup of 1024 per CU: scan 59.8 us against ~57 for 64 queries over 1M rows, and the
+// sampler's workgroups load 128 KB of tables each -- 14.6 us against 7.9: not kept.)
+uint32_t adc_fast_batch(uint32_t m, uint32_t k, uint32_t nq) {
+    (void)nq;
     uint32_t qb = 8;
     while (qb > 1 && (size_t)m * k * qb * 4 > 150 * 1024) qb >>= 1;
     return qb;
 }
 size_t adc_fast_lut_bytes(uint32_t m, uint32_t k, uint32_t nq) {
-    const uint32_t qb = adc_fast_batch(m, k);
+    const uint32_t qb = adc_fast_batch(m, k, nq);
     return (size_t)((nq + qb - 1) / qb) * (((size_t)m * k * qb + 3) & ~(size_t)3) * 4;
 }
 size_t adc_fast_state_bytes(uint32_t m, uint32_t k, uint32_t nq) {
-    const uint32_t qb = adc_fast_batch(m, k);
+    const uint32_t qb = adc_fast_batch(m, k, nq);
     return (size_t)((nq + qb - 1) / qb) * qb * (4 * 16 * 64 + 4 * 64);  // the sampler's wave minima (16 kAdcMaxG per query) + the list counters 256 bytes apart (kAdcCntStride)
 }
 size_t adc_fast_cand_bytes(uint32_t m, uint32_t k, uint32_t nq) {
-    const uint32_t qb = adc_fast_batch(m, k);
+    const uint32_t qb = adc_fast_batch(m, k, nq);
     return (size_t)((nq + qb - 1) / qb) * qb * kAdcCand * 8;
 }
 // all nq queries in one set of five launches; redo_dev[q] = 1 where the caller must repeat query q with launch_adc_search
@@ -774,17 +791,21 @@ int launch_adc_search_fast(const float *cb, uint32_t m, uint32_t k, uint32_t sd,
     order = (uint32_t)std::min<double>(std::max<double>(std::floor(want * (1024.0 * G * rpt) / (double)n + 0.5), 1.0), 8.0);
     static const char *force_env = getenv("VQHIP_TEST_ADC_REDO");  // tests: every query flagged, the caller's repeat path runs
     const int force_redo = (force_env && force_env[0] == '1') ? 1 : 0;
-    switch (adc_fast_batch(m, k)) {
-#define VQ_ADC_FAST(QB)                                                                                                          \
-    case QB:                                                                                                                     \
-        return adc_fast_launch<QB>(cb, m, k, sd, l1, take_sqrt, codes, n, queries_dev, nq, topk, lut_ws, state_ws, cand_ws,      \
-                                   idx_out_dev, dist_out_dev, redo_dev, stream, G, rpt, order, force_redo);
-        VQ_ADC_FAST(8)
-        VQ_ADC_FAST(4)
-        VQ_ADC_FAST(2)
-        VQ_ADC_FAST(1)
-#undef VQ_ADC_FAST
+    static const char *lq_env = getenv("VQHIP_ADC_LQ1");  // =1: a row per lane at eight queries per batch (A/B)
+    const bool lq1 = lq_env && lq_env[0] == '1';
+    // (workgroups of 1024, one per CU, half the table loads: 113 us against 105 per 64-query call -- not kept)
+#define VQ_ADC_FAST(QB, LQ, NT)                                                                                                     \
+    return adc_fast_launch<QB, LQ, NT>(cb, m, k, sd, l1, take_sqrt, codes, n, queries_dev, nq, topk, lut_ws, state_ws, cand_ws,     \
+                                       idx_out_dev, dist_out_dev, redo_dev, stream, G, rpt, order, force_redo);
+    switch (adc_fast_batch(m, k, nq)) {
+        case 8:
+            if (lq1) VQ_ADC_FAST(8, 1, 512)
+            VQ_ADC_FAST(8, 2, 512)
+        case 4: VQ_ADC_FAST(4, 1, 512)
+        case 2: VQ_ADC_FAST(2, 1, 512)
+        case 1: VQ_ADC_FAST(1, 1, 512)
     }
+#undef VQ_ADC_FAST
     return fail(VQHIP_ERR_RUNTIME, "adc_fast_batch");
 }
 
