@@ -209,3 +209,22 @@ def test_gpu_adc_constant_distances_fall_back(oracle):
     want_i, want_d = oracle.adc_search(O.SQUARED_EUCLIDEAN, cb, codes, Q, topk)
     np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
     enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(40_000, 4, 4, 16, 5, 5000),     # more queries than one set of launches takes (4096)
+                                   (40_000, 8, 64, 32, 9, 600)])    # 1.2 MB of queries: the copies instead of the pinned stage
+def test_gpu_adc_one_scan_many_queries(oracle, shape):
+    from vq_amd import _lib
+
+    n, m, sd, k, topk, nq = shape
+    rng = np.random.default_rng(nq)
+    cb = rng.standard_normal((m, k, sd)).astype(F)
+    codes = rng.integers(0, k, (n, m)).astype(np.uint8)
+    Q = rng.standard_normal((nq, m * sd)).astype(F)
+    enc = _lib.PQEncoder(cb, O.SQUARED_EUCLIDEAN)
+    idx, dist = enc.adc_search(codes, Q, topk)
+    want_i, want_d = oracle.adc_search(O.SQUARED_EUCLIDEAN, cb, codes, Q, topk)
+    np.testing.assert_array_equal(idx, want_i)
+    np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
+    enc.close()

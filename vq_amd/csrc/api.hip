@@ -2274,6 +2274,18 @@ int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uin
     hipStream_t s;
     VQ_TRY(in.stream(&s));
     const uint32_t m = enc->cs.m, k = enc->cs.k, sd = enc->cs.sd, dim = m * sd;
+    constexpr uint32_t kAdcCallQueries = 4096;  // per set of launches: the candidate lists are 64 KB per query
+    if (nq > kAdcCallQueries) {
+        uint32_t redone = 0;
+        for (uint32_t q0 = 0; q0 < nq; q0 += kAdcCallQueries) {
+            const uint32_t cn = std::min(kAdcCallQueries, nq - q0);
+            VQ_TRY(vqhip_pq_adc_search_device(enc, dev_codes, n, queries + (size_t)q0 * dim, cn, topk, idx_out + (size_t)q0 * topk,
+                                              dist_out + (size_t)q0 * topk));
+            redone += enc->adc_last_redone;
+        }
+        enc->adc_last_redone = redone;
+        return VQHIP_OK;
+    }
     VQ_TRY(enc->adc_q.ensure((size_t)nq * dim * 4));
     VQ_TRY(enc->adc_idx.ensure((size_t)nq * topk * 4));
     VQ_TRY(enc->adc_out.ensure((size_t)nq * topk * 4));
