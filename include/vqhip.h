@@ -416,6 +416,11 @@ int vqhip_pq_adc_search(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n,
 int vqhip_pq_adc_search_device(vqhip_pq_encoder *enc, const void *dev_codes, uint64_t n,
                                const float *queries, uint32_t nq, uint32_t topk, uint32_t *idx_out,
                                float *dist_out);
+/* a code store searched repeatedly: set_codes checks the codes against k and uploads them once into the encoder
+ * (replacing an earlier set; n = 0 drops them); search_resident = search_device over that copy */
+int vqhip_pq_adc_set_codes(vqhip_pq_encoder *enc, const uint8_t *codes, uint64_t n);
+int vqhip_pq_adc_search_resident(vqhip_pq_encoder *enc, const float *queries, uint32_t nq,
+                                 uint32_t topk, uint32_t *idx_out, float *dist_out);
 int vqhip_pq_adc_last_redone(vqhip_pq_encoder *enc, uint32_t *queries_out);
 
 /* ---- TSVQ ----------------------------------------------------------------------------

@@ -228,3 +228,92 @@ def test_gpu_adc_one_scan_many_queries(oracle, shape):
     np.testing.assert_array_equal(idx, want_i)
     np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
     enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_gpu_adc_one_scan_random_shapes(oracle, seed):
+    """random shapes above the one-scan schedule's row floor: table widths that are not powers of two, topk on both sides of
+    the wave-level top-k's limit (64), few distinct rows (long tie runs across the k-th place), duplicated blocks"""
+    from vq_amd import _lib
+
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(32_768, 120_000))
+    m = int(rng.integers(1, 13))
+    k = int(rng.choice([2, 3, 16, 37, 255, 256, 257, 300]))
+    sd = int(rng.integers(1, 9))
+    topk = int(rng.choice([1, 2, 10, 63, 64, 65, 200, 256]))
+    nq = int(rng.integers(1, 21))
+    metric = [O.SQUARED_EUCLIDEAN, O.EUCLIDEAN, O.MANHATTAN][seed % 3]
+    cb = rng.standard_normal((m, k, sd)).astype(F)
+    codes = rng.integers(0, k, (n, m)).astype(np.uint8 if k <= 256 else np.uint16)
+    if seed % 4 == 0:
+        codes[n // 3: n // 3 + 300] = codes[7]          # 300 exact ties
+    if seed % 5 == 0:
+        codes[:, : max(1, m // 2)] = codes[0, : max(1, m // 2)]  # half the subspaces constant: fewer distinct distances
+    Q = rng.standard_normal((nq, m * sd)).astype(F)
+    enc = _lib.PQEncoder(cb, metric)
+    idx, dist = enc.adc_search(codes, Q, topk)
+    want_i, want_d = oracle.adc_search(metric, cb, codes, Q, topk)
+    np.testing.assert_array_equal(idx, want_i)
+    np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_adc_one_scan_nan_and_inf_queries(oracle):
+    """a NaN query component makes every distance NaN (no row is <= any threshold: the full pass answers, rows in index
+    order); a huge component overflows every distance to +inf (all rows tie at +inf)"""
+    from vq_amd import _lib
+
+    n, m, sd, k, topk = 50_000, 8, 4, 64, 6
+    rng = np.random.default_rng(77)
+    cb = rng.standard_normal((m, k, sd)).astype(F)
+    codes = rng.integers(0, k, (n, m)).astype(np.uint8)
+    Q = rng.standard_normal((4, m * sd)).astype(F)
+    Q[1, 5] = np.nan
+    Q[2, 9] = F(3e38)
+    enc = _lib.PQEncoder(cb, O.SQUARED_EUCLIDEAN)
+    idx, dist = enc.adc_search(codes, Q, topk)
+    want_i, want_d = oracle.adc_search(O.SQUARED_EUCLIDEAN, cb, codes, Q, topk)
+    np.testing.assert_array_equal(idx, want_i)
+    assert np.isnan(dist[1]).all() and np.isnan(want_d[1]).all()
+    keep = [0, 2, 3]
+    np.testing.assert_array_equal(dist[keep].view(np.uint32), want_d[keep].view(np.uint32))
+    assert enc.adc_last_redone() == 2
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_adc_resident_code_store(oracle, tmp_path):
+    """PQIndex keeps its codes on the device after the first search; an out-of-range code is refused at upload"""
+    from vq_amd import _lib
+    from vq_amd.store import PQIndex
+    import vq_amd as pyvq
+
+    rng = np.random.default_rng(31)
+    n, m, sd, k = 45_000, 8, 4, 64
+    cb = rng.standard_normal((m, k, sd)).astype(F)
+    codes = rng.integers(0, k, (n, m)).astype(np.uint8)
+    index = PQIndex(cb, codes, pyvq.Distance.squared_euclidean())
+    for rep in range(3):
+        Q = rng.standard_normal((5 + rep, m * sd)).astype(F)
+        idx, dist = index.search(Q, 12)
+        want_i, want_d = oracle.adc_search(O.SQUARED_EUCLIDEAN, cb, codes, Q, 12)
+        np.testing.assert_array_equal(idx, want_i)
+        np.testing.assert_array_equal(dist.view(np.uint32), want_d.view(np.uint32))
+    with pytest.raises(pyvq.DimensionMismatch):
+        index.search(np.zeros((1, 3), F), 3)
+    enc = _lib.PQEncoder(cb, O.SQUARED_EUCLIDEAN)
+    with pytest.raises(_lib.FfiError, match="no codes loaded"):
+        enc.adc_search(None, Q, 3)
+    bad = codes.copy()
+    bad[17, 3] = k
+    with pytest.raises(_lib.FfiError, match="outside"):
+        enc.adc_set_codes(bad)
+    enc.adc_set_codes(codes[:40_000])
+    i2, d2 = enc.adc_search(None, Q, 4)
+    w2, wd2 = oracle.adc_search(O.SQUARED_EUCLIDEAN, cb, codes[:40_000], Q, 4)
+    np.testing.assert_array_equal(i2, w2)
+    np.testing.assert_array_equal(d2.view(np.uint32), wd2.view(np.uint32))
+    enc.close()

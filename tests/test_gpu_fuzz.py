@@ -202,9 +202,10 @@ def test_fuzz_device_driven_run_equals_step_loop(seed):
     """vqhip_kmeans_run (fused update, decisions on the device, pauses for reseeds) against the host-driven step loop
     on random shapes -- fused and non-fused sub_dims, k from 2 to 256 --, data kinds, duplicate initial rows (empty
     clusters -> pauses) and iteration budgets: identical iteration counts and pause counts, each path reproducible run
-    to run, codebooks equal within the update's summation tolerance (bit-equal while no subspace has retired: after
-    that the step loop re-packs the active subspaces over the waves while the run keeps its launch geometry and gates,
-    so the rows are grouped into other partial sums)."""
+    to run, codebooks BIT-EQUAL (round 6: the fused update's row chunks come from all m subspaces whether retired ones are
+    gated -- the run -- or dropped from the list -- the step loop --, so both group the same rows into the same partial
+    sums; before, the step loop re-packed the survivors over the waves and the two fits could part by an iteration where
+    the convergence test hangs on the last bit: seed 117 at VQ_FUZZ_SCALE=40)."""
     rng = np.random.default_rng(9000 + seed)
     sd = int(rng.choice([4, 8, 12, 16, 24, 32, 10, 7]))
     m = int(rng.integers(1, 9))
@@ -258,8 +259,7 @@ def test_fuzz_device_driven_run_equals_step_loop(seed):
     msg = f"seed={seed} n={n} m={m} k={k} sd={sd} {kind} max_iters={max_iters}"
     assert it_run.tolist() == it_step.tolist() and p_run == p_step, msg
     assert cb_run.tobytes() == cb_run2.tobytes() and it_run.tolist() == it_run2.tolist(), "run is not reproducible: " + msg
-    scale = np.abs(cb_step).max() + 1e-30
-    assert np.abs(cb_run.astype(np.float64) - cb_step).max() <= 2e-5 * scale, msg
+    assert cb_run.tobytes() == cb_step.tobytes(), "run and step loop differ: " + msg
 
 
 @pytest.mark.parametrize("seed", range(32 * SCALE))

@@ -100,6 +100,8 @@ SIGNATURES = {
     "vqhip_pq_adc_search": (C.c_int, [_vp, _u8p, C.c_uint64, _f32p, C.c_uint32, C.c_uint32, _u32p, _f32p]),
     "vqhip_pq_adc_search_device": (C.c_int, [_vp, _vp, C.c_uint64, _f32p, C.c_uint32, C.c_uint32, _u32p, _f32p]),
     "vqhip_pq_adc_last_redone": (C.c_int, [_vp, _u32p]),
+    "vqhip_pq_adc_set_codes": (C.c_int, [_vp, _u8p, C.c_uint64]),
+    "vqhip_pq_adc_search_resident": (C.c_int, [_vp, _f32p, C.c_uint32, C.c_uint32, _u32p, _f32p]),
     "vqhip_selftest": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "vqhip_mfma_bf16_probe": (C.c_int, [_u16p, _u16p, _f32p, C.c_uint64, _f32p]),
     "vqhip_mfma_bf16_model": (C.c_int, [_u16p, _u16p, _f32p, C.c_uint64, _f32p]),
@@ -641,7 +643,7 @@ class PQEncoder(Handle):
         check(load().vqhip_pq_encoder_set_engine(self.raw, engine))
 
     def adc_search(self, codes, queries, topk: int):
-        """top-k rows of `codes` [n][m] (u8, u16 above 256 centroids; numpy array, or (device_ptr, n)) per query by asymmetric
+        """top-k rows of `codes` [n][m] (u8, u16 above 256 centroids; numpy array, (device_ptr, n), or None = the store adc_set_codes uploaded) per query by asymmetric
         distance; returns (idx uint32 [nq][topk], dist float32 [nq][topk])"""
         q = np.ascontiguousarray(queries, dtype=np.float32)
         if q.ndim == 1:
@@ -652,7 +654,9 @@ class PQEncoder(Handle):
         if nq == 0:
             return idx, dist
         lib = load()
-        if isinstance(codes, tuple):
+        if codes is None:  # the codes adc_set_codes left on the device
+            check(lib.vqhip_pq_adc_search_resident(self.raw, ptr(q, _f32p), nq, int(topk), ptr(idx, _u32p), ptr(dist, _f32p)))
+        elif isinstance(codes, tuple):
             dev_ptr, n = codes
             check(lib.vqhip_pq_adc_search_device(self.raw, C.c_void_p(dev_ptr), int(n), ptr(q, _f32p), nq, int(topk),
                                                  ptr(idx, _u32p), ptr(dist, _f32p)))
@@ -661,6 +665,11 @@ class PQEncoder(Handle):
             check(lib.vqhip_pq_adc_search(self.raw, ptr(c, _u8p), c.shape[0], ptr(q, _f32p), nq, int(topk),
                                           ptr(idx, _u32p), ptr(dist, _f32p)))
         return idx, dist
+
+    def adc_set_codes(self, codes) -> None:
+        """upload a code store once; adc_search(None, queries, topk) then searches it (codes are checked against k here)"""
+        c = np.ascontiguousarray(codes, dtype=code_dtype(self.k))
+        check(load().vqhip_pq_adc_set_codes(self.raw, ptr(c, _u8p), c.shape[0]))
 
     def adc_last_redone(self) -> int:
         """queries of the last adc_search that went through the full pass (all of them where the one-scan schedule does

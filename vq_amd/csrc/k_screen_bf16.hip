@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;
     const uint32_t total_waves = gridDim.x * kWavesPerBlock;
     const uint32_t n_virt = n_sub * groups;  // (subspace, centroid group) pairs
-    const uint32_t n_chunks = total_waves / n_virt;
+    const uint32_t n_chunks = (G == 1) ? n_seg : total_waves / n_virt;  // (G == 1: the launcher's count, see the pipelined kernel)
     if (gw >= n_chunks * n_virt) return;
     const uint32_t vv = gw % n_virt;
     const uint32_t s = sub_list[vv / groups];
@@ -756,8 +756,9 @@ __global__ __launch_bounds__(kBlock, x32_two_waves(SD, NT32) ? 2 : 1) void k_ass
     const uint32_t h = lane >> 5, p = lane & 31;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t gw = blockIdx.x * kWavesPerBlock + wave;
-    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
-    const uint32_t n_chunks = total_waves / n_sub;
+    // the row chunks are the LAUNCHER's (n_seg of them: launch_one_x32 derives the count from ALL m subspaces in training,
+    // so a fit's partial sums group the same rows whether retired subspaces are gated or dropped from the list)
+    const uint32_t n_chunks = n_seg;
     if (gw >= n_chunks * n_sub) return;
     const uint32_t vv = gw % n_sub;
     const uint32_t s = sub_list[vv];
@@ -1679,15 +1680,22 @@ int launch_one_x32(const CodebookView &cb, const AssignArgs &a, hipStream_t stre
     const uint64_t n_steps = (a.n + 31) / 32;
     const uint32_t waves_per_simd = x32_two_waves(SD, NT32) ? 2 : 1;  // small A images leave room for two
     const uint32_t n_virt = a.n_sub * groups;
+    // Training: the chunk count comes from ALL m subspaces, listed or not.  A host-driven fit drops retired subspaces
+    // from the list where the device-driven run gates them; with the geometry of the list the survivors' rows were
+    // regrouped into other partial sums (each rounded to f32 once), and the two fits could part by an iteration on data
+    // whose convergence test hangs on the last bit (tests/test_gpu_fuzz.py seed 117 at VQ_FUZZ_SCALE=40).  The waves
+    // a dropped subspace would have had stay unused, as they do behind a gate.
+    const uint32_t n_virt_geom = (ACC && G == 1) ? cb.m * groups : n_virt;
     uint64_t want_waves = (uint64_t)num_cus() * kWavesPerBlock * waves_per_simd;
     // training (fused update): every row chunk costs a partial slab that k_reduce_partials_pos reads back, so a chunk
     // gets at least 8 steps (10k rows: 39 chunks instead of 313; the reduction 18 -> 5 us of a 60 us iteration)
-    const uint64_t max_useful = (ACC ? std::max<uint64_t>(1, n_steps / 8) : n_steps) * n_virt;
+    const uint64_t max_useful = (ACC ? std::max<uint64_t>(1, n_steps / 8) : n_steps) * n_virt_geom;
     if (want_waves > max_useful) want_waves = max_useful;
-    if (want_waves < n_virt) want_waves = n_virt;
+    if (want_waves < n_virt_geom) want_waves = n_virt_geom;
     uint32_t blocks = (uint32_t)((want_waves + kWavesPerBlock - 1) / kWavesPerBlock);
-    while ((uint64_t)blocks * kWavesPerBlock < n_virt) ++blocks;
-    const uint32_t n_chunks = (blocks * kWavesPerBlock) / n_virt;
+    while ((uint64_t)blocks * kWavesPerBlock < n_virt_geom) ++blocks;
+    const uint32_t n_chunks = (blocks * kWavesPerBlock) / n_virt_geom;
+    if (n_virt_geom != n_virt) blocks = (uint32_t)(((uint64_t)n_chunks * n_virt + kWavesPerBlock - 1) / kWavesPerBlock);
     if (G == 1) {
         if (!a.wl_seg || n_chunks > a.wl_seg_cap)
             return fail(VQHIP_ERR_FAILURE, "segmented work list missing or too small (%u > %u)", n_chunks, a.wl_seg_cap);

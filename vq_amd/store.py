@@ -93,10 +93,25 @@ class PQIndex:
 
     def search(self, queries, topk: int = 10):
         """top-k stored rows per query by asymmetric distance (device path; see ProductQuantizer.search)"""
-        from .pq import ProductQuantizer
+        from . import _lib
+        from .errors import DimensionMismatch, InvalidParameter
 
-        pq = ProductQuantizer.from_codebooks(self.codebooks, self.distance)
-        return pq.search(np.asarray(self.codes), queries, topk)
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.dim:
+            raise DimensionMismatch(self.dim, q.shape[1])
+        if not 1 <= topk <= min(len(self), 1024):
+            raise InvalidParameter("topk", f"must be between 1 and min(n, 1024), got {topk}")
+        if self.distance.metric in (_lib.COSINE, _lib.COSINE_UNCLAMPED):
+            raise InvalidParameter("distance", "cosine distance is not a sum over subspaces: no ADC form")
+        # the codes go to the device ONCE (checked against k there); later searches only send the queries
+        enc = getattr(self, "_enc", None)
+        if enc is None:
+            enc = _lib.PQEncoder(self.codebooks, self.distance.metric)
+            enc.adc_set_codes(np.asarray(self.codes))
+            self._enc = enc
+        return enc.adc_search(None, q, int(topk))
 
     # -- file -------------------------------------------------------------------------------
     def save(self, path) -> None:
