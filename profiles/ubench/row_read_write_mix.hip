@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     const int grid = p.multiProcessorCount * wpc;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int work : {4, 16}) {
+    for (int work : {4, 16, 24, 32, 40}) {
         for (int wm = 0; wm < 4; ++wm) {
             float best = 1e9;
             for (int rep = 0; rep < 6; ++rep) {
