@@ -5,9 +5,14 @@
 //                (squared L2: Vector::distance2, src/core/vector.rs:135-143; L1: distance.rs:85-95),
 //   D(q, i)    = t_0(q, code[i][0]) + t_1(...) + ... in subspace order, f32,
 //   result     = the topk rows by (D, row index) ascending; Euclidean reports sqrt(D).
-// Kernels: the table t (k_adc_lut), a byte-gather scan of the codes with the tables of 8 queries in
-// LDS (k_adc_scan: HBM-bound on the codes, m bytes per row), and an exact per-query radix select +
-// in-LDS sort (k_adc_topk).
+// Two schedules, one result (launch_adc_search_fast / launch_adc_search; the caller picks, vqhip_pq_adc_search_device):
+//   * one scan (round 6; n >= 32768, topk <= 256): tables interleaved over a batch of 8 queries (k_adc_lut_i), a threshold
+//     per query from a sample of the rows (k_adc_thresh), ONE pass over the codes that keeps the rows at or below it
+//     (k_adc_scan_thr: LDS-bound on the table reads), the exact top-k of those (k_adc_sort_thr); a query whose
+//     threshold let fewer than topk or more than 8192 rows pass is flagged and repeated by
+//   * the full pass: the table t (k_adc_lut), a byte-gather scan of the codes with the tables of 8 queries in LDS that
+//     writes every D(q, i) (k_adc_scan), a histogram cut + candidate sort (k_adc_pick_bin / _collect / _sort_out) and an
+//     exact per-query radix select where the cut is too dense (k_adc_topk).
 #include "common.hpp"
 #include "kernels.hpp"
 
