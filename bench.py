@@ -1079,11 +1079,13 @@ def measure(args, ranks, wl_name, scaling, *, torch, _lib, engine, ncomm, collec
     })
     if want_f16:  # same pass with the reference-shaped f16 reconstruction written too
         f16 = torch.empty((n, dim), dtype=torch.float16, device="cuda")
-        for _ in range(2):
+        # (the host work in front of this -- checksum, k-means bookkeeping -- lets the clocks fall: two warm-up calls and five
+        # timed ones read 0.52 ms for a pass that is 0.44 at steady clocks, tools/decode_time.py; same prewarm as the headline)
+        for _ in range(max(2, min(100, PREWARM_STEPS // 2))):
             enc.encode_device(xptr, n, codes.data_ptr(), f16.data_ptr())
         sync()
         t0 = time.perf_counter()
-        reps = max(3, steps // 4)
+        reps = max(10, steps)
         for _ in range(reps):
             enc.encode_device(xptr, n, codes.data_ptr(), f16.data_ptr())
         sync()

@@ -23,3 +23,16 @@ print(f"encode codes only : {timeit(lambda: enc.encode_device(ds.device_ptr, n, 
 print(f"encode codes + f16: {timeit(lambda: enc.encode_device(ds.device_ptr, n, codes.data_ptr(), f16.data_ptr())):.4f} ms")
 print(f"decode            : {timeit(lambda: enc.decode_device(codes.data_ptr(), n, out.data_ptr())):.4f} ms  ({520e6 / 1e9:.3f} GB)")
 print(f"dequantize f16    : {timeit(lambda: _lib.dequantize_f16_device(f16.data_ptr(), n * d, out.data_ptr())):.4f} ms  ({768e6 / 1e9:.3f} GB)")
+# (bench.py's f16-out figure takes 2 warm-up calls and max(3, steps // 4) timed ones: does the short loop read differently?)
+for reps in (5, 5, 20, 50):
+    for _ in range(2): enc.encode_device(ds.device_ptr, n, codes.data_ptr(), f16.data_ptr())
+    _lib.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): enc.encode_device(ds.device_ptr, n, codes.data_ptr(), f16.data_ptr())
+    _lib.synchronize(); print(f"encode codes + f16, {reps:2d} timed calls: {(time.perf_counter() - t0) / reps * 1e3:.4f} ms")
+import torch as _t
+_t.cuda.synchronize(); time.sleep(0.5)
+for reps in (5, 20):
+    for _ in range(2): enc.encode_device(ds.device_ptr, n, codes.data_ptr(), f16.data_ptr())
+    _lib.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): enc.encode_device(ds.device_ptr, n, codes.data_ptr(), f16.data_ptr())
+    _lib.synchronize(); print(f"after a 0.5 s pause, {reps:2d} timed calls: {(time.perf_counter() - t0) / reps * 1e3:.4f} ms")
