@@ -383,7 +383,7 @@ def decode_case(_lib, torch):
     torch.cuda.synchronize()
 
     def timed(fn, reps=20):
-        for _ in range(10):
+        for _ in range(60):  # (clocks up: the first ~10 ms after host work run slow)
             fn()
         _lib.synchronize()
         t0 = time.perf_counter()
@@ -427,9 +427,9 @@ def adc_case(_lib, torch, engine):
     Q = _lib.synth_uniform_host(nq, d, DATA_SEED + 1, 0)
     res = {}
     for q in (nq, 8):
-        for _ in range(3):
+        for _ in range(30):
             enc.adc_search((codes.data_ptr(), n), Q[:q], topk)
-        reps = 10
+        reps = 20
         t0 = time.perf_counter()
         for _ in range(reps):
             idx, dist = enc.adc_search((codes.data_ptr(), n), Q[:q], topk)
