@@ -618,18 +618,6 @@ __global__ __launch_bounds__(1024) void k_select_final(const uint32_t *__restric
     }
 }
 
-__device__ __forceinline__ float median_of(const NodeArrays &na, uint32_t node) {  // tsvq.rs:77-81 from the two selected keys
-    const uint32_t nv = na.nv[node];
-    if (nv == 0) return 0.0f;
-    const float lo = key_to_float(na.sel_prefix[2 * node + 0]);
-    const float hi = key_to_float(na.sel_prefix[2 * node + 1]);
-    if (nv % 2 == 0) {
-        const float s2 = lo + hi;
-        return s2 / 2.0f;
-    }
-    return hi;
-}
-
 __device__ inline uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -681,7 +669,7 @@ __global__ __launch_bounds__(256) void k_flags_scan(const float *__restrict__ va
     for (int q = 0; q < 4; ++q) {
         uint32_t f = 0;
         if (live[q]) {
-            float med = 0.0f;  // tsvq.rs:77-81 from the two selected keys (median_of)
+            float med = 0.0f;  // tsvq.rs:77-81 from the two selected keys
             if (nvv[q] != 0u) {
                 const float lo = key_to_float(k0[q]), hi = key_to_float(k1[q]);
                 if (nvv[q] % 2 == 0) {
