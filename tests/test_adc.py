@@ -231,7 +231,7 @@ def test_gpu_adc_one_scan_many_queries(oracle, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * int(__import__("os").environ.get("VQ_FUZZ_SCALE", "1"))))
 def test_gpu_adc_one_scan_random_shapes(oracle, seed):
     """random shapes above the one-scan schedule's row floor: table widths that are not powers of two, topk on both sides of
     the wave-level top-k's limit (64), few distinct rows (long tie runs across the k-th place), duplicated blocks"""
