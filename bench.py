@@ -400,7 +400,7 @@ def decode_case(_lib, torch):
     enc.close()
     return {"workload": "1M x 128, m=8 k=256, device-resident: codes -> f32 rows, f16 rows -> f32 rows", "rows": n, "dim": d, "m": m,
             "decode_ms": dec_ms, "decode_vectors_per_s": n / (dec_ms * 1e-3), "decode_checked": ok_dec,
-            "decode_roofline": hbm_roofline((4.0 * d + m) * n, dec_ms, {"kernel": "k_decode_f32<4>", "note": "4*D bytes out + m code bytes in per vector (codebook rows from L2)"}),
+            "decode_roofline": hbm_roofline((4.0 * d + m) * n, dec_ms, {"kernel": "k_decode_f32_lds<8>", "note": "4*D bytes out + m code bytes in per vector (the codebooks, 128 KB, in LDS)"}),
             "dequantize_ms": deq_ms, "dequantize_vectors_per_s": n / (deq_ms * 1e-3), "dequantize_checked": ok_deq,
             "dequantize_roofline": hbm_roofline(6.0 * d * n, deq_ms, {"kernel": "k_dequant_f16", "note": "2*D bytes in + 4*D bytes out per vector"})}
 

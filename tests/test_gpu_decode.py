@@ -32,6 +32,21 @@ def test_decode_equals_the_gather(m, k, sd, n):
     enc.close()
 
 
+@pytest.mark.parametrize("m,k,sd,n", [(4, 300, 4, 300_001), (2, 5, 12, 200_003), (8, 256, 16, 100_003), (16, 64, 8, 40_961), (9, 100, 16, 33_000)])
+def test_decode_with_the_codebooks_in_lds(m, k, sd, n):
+    """the form with the codebooks in LDS (at least 2^20 16-byte groups, codebooks up to 144 KB): two-byte codes, a last trip
+    that ends inside a row, m not a power of two"""
+    rng = np.random.default_rng(n)
+    cb = rng.standard_normal((m, k, sd)).astype(F)
+    codes = rng.integers(0, k, (n, m)).astype(_lib.code_dtype(k))
+    codes[-1, :] = k - 1
+    enc = _lib.PQEncoder(cb, _lib.SQUARED_EUCLIDEAN)
+    got = enc.decode(codes)
+    want = np.concatenate([cb[s][codes[:, s]] for s in range(m)], axis=1)
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+    enc.close()
+
+
 def test_decode_device_form_and_unaligned_output():
     import torch
 

@@ -135,6 +135,45 @@ uint32_t persistent_grid(uint64_t total) {
 
 }  // namespace
 
+// The same with the codebooks in LDS (m k sd floats <= 36864: C2's 128 KB): the gather leaves the memory pipe, which then
+// carries the code bytes in and one 16-byte store per lane out.  One workgroup of 1024 per CU, U items per lane and trip:
+// their code bytes requested together, then their table reads, then their stores -- the stores of a trip sit in front of
+// the next trip's loads on the in-order counter, U of them per wait instead of one.
+template <int U>
+__global__ __launch_bounds__(1024) void k_decode_f32_lds(const float *__restrict__ cb, uint32_t m, uint32_t k, uint32_t sd,
+                                                         const uint8_t *__restrict__ codes, uint64_t n, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds_cb[];
+    const uint32_t cb_floats = m * k * sd;  // (a multiple of 4: sd is)
+    for (uint32_t e = 4 * threadIdx.x; e < cb_floats; e += 4096) *reinterpret_cast<float4 *>(lds_cb + e) = *reinterpret_cast<const float4 *>(cb + e);
+    __syncthreads();
+    const uint32_t d = m * sd, gpr = d / 4;
+    const uint64_t total = n * gpr;
+    for (uint64_t base = (uint64_t)blockIdx.x * (1024 * U); base < total; base += (uint64_t)gridDim.x * (1024 * U)) {
+        const uint64_t row0 = base / gpr;  // (uniform: scalar unit)
+        const uint32_t g0 = (uint32_t)(base - row0 * gpr) + threadIdx.x;
+        uint32_t code[U], col[U];
+        uint64_t row[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t g = g0 + (uint32_t)u * 1024u, dr = g / gpr;
+            row[u] = min(row0 + dr, n - 1);  // (clamped: loads never under a test; the store is)
+            col[u] = (g - dr * gpr) * 4;
+            code[u] = load_code(codes, row[u] * m + col[u] / sd, k);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(code[u]));  // all U code loads requested before the first is used
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t s = col[u] / sd, t = col[u] - s * sd;
+            v[u] = *reinterpret_cast<const float4 *>(lds_cb + ((size_t)s * k + code[u]) * sd + t);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (base + (uint64_t)u * 1024u + threadIdx.x < total) *reinterpret_cast<float4 *>(out + row[u] * d + col[u]) = v[u];
+    }
+}
+
 int launch_gather_f16(const CodebookView &cb, const uint8_t *codes, uint64_t n, uint16_t *f16_out,
                       hipStream_t stream) {
     if (n == 0) return VQHIP_OK;
@@ -155,7 +194,19 @@ int launch_decode_f32(const CodebookView &cb, const uint8_t *codes, uint64_t n, 
     if (n == 0) return VQHIP_OK;
     const bool vec4 = (cb.sd % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && ((reinterpret_cast<uintptr_t>(cb.cb) & 15) == 0) &&
                       (uint64_t)cb.m * cb.sd / 4 + 256 < (1ull << 31);
-    if (vec4)
+    const size_t cb_bytes = (size_t)cb.m * cb.k * cb.sd * 4;
+    static const char *lds_env = getenv("VQHIP_DECODE_LDS");  // =0: the gather from L2 (A/B)
+    if (vec4 && cb_bytes <= 144 * 1024 && n * (uint64_t)(cb.m * cb.sd / 4) >= (1u << 20) && !(lds_env && lds_env[0] == '0')) {
+        constexpr int U = 8;
+        static PerDeviceOnce attr;
+        if (attr.needed()) {
+            VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode_f32_lds<U>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            attr.done();
+        }
+        const uint64_t trips = (n * (uint64_t)(cb.m * cb.sd / 4) + 1024 * U - 1) / (1024 * U);
+        hipLaunchKernelGGL(k_decode_f32_lds<U>, dim3((uint32_t)std::min<uint64_t>(trips, (uint64_t)num_cus())), dim3(1024), cb_bytes, stream, cb.cb, cb.m,
+                           cb.k, cb.sd, codes, n, out);
+    } else if (vec4)
         hipLaunchKernelGGL(k_decode_f32<4>, dim3(persistent_grid(n * cb.m * cb.sd / 4)), dim3(256), 0, stream, cb.cb, cb.m, cb.k, cb.sd, codes, n, out);
     else
         hipLaunchKernelGGL(k_decode_f32<1>, dim3(persistent_grid(n * cb.m * cb.sd)), dim3(256), 0, stream, cb.cb, cb.m, cb.k, cb.sd, codes, n, out);
