@@ -174,11 +174,68 @@ __global__ __launch_bounds__(1024) void k_decode_f32_lds(const float *__restrict
     }
 }
 
+// k_gather_f16 with the codebooks in LDS (as k_decode_f32_lds): eight f16 per lane and item, U items per lane and trip
+template <int U>
+__global__ __launch_bounds__(1024) void k_gather_f16_lds(const float *__restrict__ cb, uint32_t m, uint32_t k, uint32_t sd,
+                                                         const uint8_t *__restrict__ codes, uint64_t n, uint16_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds_cb[];
+    const uint32_t cb_floats = m * k * sd;
+    for (uint32_t e = 4 * threadIdx.x; e < cb_floats; e += 4096) *reinterpret_cast<float4 *>(lds_cb + e) = *reinterpret_cast<const float4 *>(cb + e);
+    __syncthreads();
+    const uint32_t d = m * sd, gpr = d / 8;
+    const uint64_t total = n * gpr;
+    for (uint64_t base = (uint64_t)blockIdx.x * (1024 * U); base < total; base += (uint64_t)gridDim.x * (1024 * U)) {
+        const uint64_t row0 = base / gpr;  // (uniform: scalar unit)
+        const uint32_t g0 = (uint32_t)(base - row0 * gpr) + threadIdx.x;
+        uint32_t code[U], col[U];
+        uint64_t row[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t g = g0 + (uint32_t)u * 1024u, dr = g / gpr;
+            row[u] = min(row0 + dr, n - 1);
+            col[u] = (g - dr * gpr) * 8;
+            code[u] = load_code(codes, row[u] * m + col[u] / sd, k);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(code[u]));
+        uint4 o[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t s = col[u] / sd, t = col[u] - s * sd;
+            const float *src = lds_cb + ((size_t)s * k + code[u]) * sd + t;
+            const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+            o[u].x = (uint32_t)__half_as_ushort(__float2half_rn(a.x)) | ((uint32_t)__half_as_ushort(__float2half_rn(a.y)) << 16);
+            o[u].y = (uint32_t)__half_as_ushort(__float2half_rn(a.z)) | ((uint32_t)__half_as_ushort(__float2half_rn(a.w)) << 16);
+            o[u].z = (uint32_t)__half_as_ushort(__float2half_rn(b.x)) | ((uint32_t)__half_as_ushort(__float2half_rn(b.y)) << 16);
+            o[u].w = (uint32_t)__half_as_ushort(__float2half_rn(b.z)) | ((uint32_t)__half_as_ushort(__float2half_rn(b.w)) << 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (base + (uint64_t)u * 1024u + threadIdx.x < total) *reinterpret_cast<uint4 *>(out + row[u] * d + col[u]) = o[u];
+    }
+}
+
 int launch_gather_f16(const CodebookView &cb, const uint8_t *codes, uint64_t n, uint16_t *f16_out,
                       hipStream_t stream) {
     if (n == 0) return VQHIP_OK;
     const bool vec8 = (cb.sd % 8 == 0) && ((reinterpret_cast<uintptr_t>(f16_out) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(cb.cb) & 15) == 0);
+    const size_t cb_bytes = (size_t)cb.m * cb.k * cb.sd * 4;
+    static const char *lds_env = getenv("VQHIP_DECODE_LDS");  // =0: the gather from L2 (A/B)
+    if (vec8 && cb_bytes <= 144 * 1024 && n * (uint64_t)(cb.m * cb.sd / 8) >= (1u << 19) && (uint64_t)cb.m * cb.sd / 8 + 8192 < (1ull << 31) &&
+        !(lds_env && lds_env[0] == '0')) {
+        constexpr int U = 8;
+        static PerDeviceOnce attr;
+        if (attr.needed()) {
+            VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gather_f16_lds<U>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            attr.done();
+        }
+        const uint64_t trips = (n * (uint64_t)(cb.m * cb.sd / 8) + 1024 * U - 1) / (1024 * U);
+        hipLaunchKernelGGL(k_gather_f16_lds<U>, dim3((uint32_t)std::min<uint64_t>(trips, (uint64_t)num_cus())), dim3(1024), cb_bytes, stream, cb.cb, cb.m,
+                           cb.k, cb.sd, codes, n, f16_out);
+        VQ_LAUNCH_CHECK("k_gather_f16_lds");
+        return VQHIP_OK;
+    }
     if (vec8)
         hipLaunchKernelGGL(k_gather_f16<8>, dim3(stream_grid(n * cb.m * cb.sd / 8)), dim3(256), 0,
                            stream, cb.cb, cb.m, cb.k, cb.sd, codes, n, f16_out);
