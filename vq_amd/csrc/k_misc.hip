@@ -175,6 +175,7 @@ __global__ __launch_bounds__(1024) void k_decode_f32_lds(const float *__restrict
 }
 
 // k_gather_f16 with the codebooks in LDS (as k_decode_f32_lds): eight f16 per lane and item, U items per lane and trip
+// (U = 2: 62 us per 1M x 128; 1: 74, 4: 66, 8: 68.5, 16: 170; the decode: U = 4: 101.6 us; 2: 110, 8: 108, 16: 112)
 template <int U>
 __global__ __launch_bounds__(1024) void k_gather_f16_lds(const float *__restrict__ cb, uint32_t m, uint32_t k, uint32_t sd,
                                                          const uint8_t *__restrict__ codes, uint64_t n, uint16_t *__restrict__ out) {
@@ -224,7 +225,7 @@ int launch_gather_f16(const CodebookView &cb, const uint8_t *codes, uint64_t n, 
     static const char *lds_env = getenv("VQHIP_DECODE_LDS");  // =0: the gather from L2 (A/B)
     if (vec8 && cb_bytes <= 144 * 1024 && n * (uint64_t)(cb.m * cb.sd / 8) >= (1u << 19) && (uint64_t)cb.m * cb.sd / 8 + 8192 < (1ull << 31) &&
         !(lds_env && lds_env[0] == '0')) {
-        constexpr int U = 8;
+        constexpr int U = 2;
         static PerDeviceOnce attr;
         if (attr.needed()) {
             VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gather_f16_lds<U>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
@@ -254,7 +255,7 @@ int launch_decode_f32(const CodebookView &cb, const uint8_t *codes, uint64_t n, 
     const size_t cb_bytes = (size_t)cb.m * cb.k * cb.sd * 4;
     static const char *lds_env = getenv("VQHIP_DECODE_LDS");  // =0: the gather from L2 (A/B)
     if (vec4 && cb_bytes <= 144 * 1024 && n * (uint64_t)(cb.m * cb.sd / 4) >= (1u << 20) && !(lds_env && lds_env[0] == '0')) {
-        constexpr int U = 8;
+        constexpr int U = 4;
         static PerDeviceOnce attr;
         if (attr.needed()) {
             VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode_f32_lds<U>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
