@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(64) void k_bucket_scatter(const uint8_t *__restrict
 
 // one lane per (s, j, t): sequential f32 sum of the members in ascending row order.  The chain itself is ~20 K cycles per
 // cluster (3900 dependent adds at C2); the kernel's time is the gathers' latency over what is in flight (512 waves on the
-// whole chip).  Round 6: batches of 32 members, the row ids two batches ahead and the gathers one batch ahead of the
+// whole chip).  Round 6: batches of 64 members (32: 2 % slower), the row ids two batches ahead and the gathers one batch ahead of the
 // additions, every load unconditional with clamped indices (a load under a per-lane test is followed by vmcnt(0)):
 // 563 -> ~200 us at C2.
 // (workgroups of ONE wave: 512 of them at C2 reach every CU's load path; 128 workgroups of four left half the chip idle)
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(64) void k_chain_sums(const float *__restrict__ X, 
     const uint32_t *mem = members + (size_t)s * members_stride;
     const float *px = X + (size_t)s * sd + t;
     float acc = 0.0f;  // vector.rs:374
-    constexpr int U = 32;
+    constexpr int U = 64;
     const uint32_t last = (b > a) ? b - 1 : a;  // (clamp target: a valid member slot whenever the cluster has one)
     if (b > a) {
         uint32_t ids[2][U];
