@@ -326,17 +326,20 @@ __global__ __launch_bounds__(64) void k_accumulate_listed(
             for (int u = 0; u < NB; ++u) {
                 const uint32_t e = b0 + (uint32_t)u * RPS + p;
                 valid[u] = lane_on && e < total;
-                // segment of entry e: the first q with incl_q > e; its `shift` turns e into a slot of the list
-                uint32_t sh = 0;
-                bool found = false;
-                for (uint32_t q = 0; q < nq; ++q) {
-                    const uint32_t iq = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)q);
-                    const uint32_t sq = (uint32_t)__builtin_amdgcn_readlane((int)shift, (int)q);
-                    if (!found && e < iq) {
-                        sh = sq;
-                        found = true;
-                    }
+                // segment of entry e: the first q with incl_q > e (a binary search over the lanes' prefix sums: six shuffles; walking
+                // the 64 headers by v_readlane was ~320 instructions per entry, most of the kernel's 10 us at C2); its
+                // `shift` turns e into a slot of the list
+                uint32_t lo = 0, hi = nq - 1u;
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint32_t im = (uint32_t)__shfl((int)incl, (int)mid);
+                    const bool right = !(e < im) && lo < hi;  // (converged lanes stay where they are)
+                    const bool left = (e < im) && lo < hi;
+                    lo = right ? mid + 1u : lo;
+                    hi = left ? mid : hi;
                 }
+                const uint32_t sh = (uint32_t)__shfl((int)shift, (int)lo);
                 // (clamped, never under a test: `valid ? load : 0` comes out of the compiler as a branch around the load with
                 // s_waitcnt vmcnt(0) behind it -- the eight entries of a level were eight memory round trips in a row)
                 row[u] = wl_rows[(size_t)s * wl_stride + (valid[u] ? e + sh : 0u)];
